@@ -1,0 +1,286 @@
+/*
+ * mesm_gfx950.h — C-ABI of libmesm_gfx950.so, the MI355X (gfx950 / CDNA4) kernel
+ * library behind the MESM training hot path (MESM.forward -> Criterion.forward ->
+ * backward).
+ *
+ * The reference (lntzm/MESM) has no FFI boundary: its hot path is PyTorch ATen ops
+ * called from model/model.py, model/transformer.py, model/attention.py,
+ * model/position_encoding.py, model/criterion.py and model/matcher.py.  Each entry
+ * point below replaces one ATen op *site class* of that path; the reference
+ * file:line it stands in for is cited on the declaration.
+ *
+ * Conventions (all entries):
+ *   - plain pointers + sizes; every pointer is a DEVICE pointer unless marked host;
+ *   - stream-ordered: work is enqueued on `stream` (a hipStream_t passed as void*),
+ *     nothing synchronises, nothing allocates; workspaces are passed in;
+ *   - return 0 on success, a negative MESM_E* code on a rejected argument, and
+ *     MESM_ELAUNCH - hipError on a failed launch; never throws;
+ *   - fp32 everywhere ("f32" arithmetic; integer indices are int32/int64 as stated);
+ *   - row-major tensors with explicit strides in ELEMENTS.
+ */
+#ifndef MESM_GFX950_H
+#define MESM_GFX950_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MESM_OK 0
+#define MESM_EINVAL (-1)   /* bad shape / null pointer / unsupported size */
+#define MESM_EALIGN (-2)   /* pointer or stride alignment not supported   */
+#define MESM_ELAUNCH (-1000) /* launch failed: code = MESM_ELAUNCH - hipError_t */
+
+/* ABI version; bumped whenever a signature changes. */
+int mesm_abi_version(void);
+/* Name of the compiled offload arch ("gfx950"). Host pointer, static storage. */
+const char* mesm_arch(void);
+
+/* ------------------------------------------------------------------------- */
+/* Activation / transform selectors shared by the GEMM prologue and epilogue */
+#define MESM_ACT_NONE 0
+#define MESM_ACT_RELU 1
+#define MESM_ACT_PRELU 2 /* single learnable slope, read from a device scalar */
+
+/* Operand layout selectors: which index of the operand is contiguous. */
+#define MESM_LAYOUT_REDUCE_CONTIG 0 /* element (i, r) at base + i*ld + r */
+#define MESM_LAYOUT_OUTER_CONTIG 1  /* element (i, r) at base + r*ld + i */
+
+/*
+ * C[M,N] (+)= epilogue( opA(A)[M,K] @ opB(B)[K,N] ), exact-f32 MFMA
+ * (v_mfma_f32_32x32x2_f32), LDS-tiled.
+ *
+ * Replaces: every nn.Linear / F.linear site on the path and their autograd
+ * backward GEMMs — nn.MultiheadAttention in/out projections
+ * (transformer.py:490,532,597,620,643), decoder sa_ / ca_ projections
+ * (transformer.py:737-741,759-766,771,779), FFN linear1/linear2
+ * (transformer.py:537,603,608,647,794), LinearLayer.net (model.py:421-431),
+ * MLP heads (model.py:397-409, transformer.py:21-33), saliency projections
+ * (model.py:301-302), MLM head (model.py:85-88).
+ *
+ * Operand indexing:  A is (i=m, r=k), B is (j=n, r=k); `*_layout` says which of the
+ * two indices is contiguous, `ld*` is the stride of the other one.
+ *
+ * Prologue on A (and on B), applied while the operand is staged into LDS:
+ *   x = A[m,k] (+ A2[m,k] if a2 != NULL, same strides)           [with_pos_embed]
+ *   x = act(x)              a_act  in {NONE, RELU, PRELU(*slope)} [FFN activation]
+ *   x = dropout(x)          a_drop_p > 0: keep iff hash(seed, m*K + k) >= p; /(1-p)
+ * B: same, logical index k*N + n.
+ *
+ * Epilogue, in this order (each step optional):
+ *   t = acc * out_scale
+ *   t += bias[n]
+ *   t = act(t)                       e_act in {NONE, RELU, PRELU(*slope)}
+ *   t = dropout(t)                   e_drop_p > 0, index m*N + n
+ *   t *= act'(aux[m,n])              e_actgrad in {NONE, RELU, PRELU}; for PRELU also
+ *                                    *dslope += sum(t_before * min(aux,0)) (atomic)
+ *   t += residual[m,n]
+ *   C[m,n] = t | C[m,n] += t | atomicAdd(C[m,n], t)      (accumulate = 0|1|2)
+ * split_k > 1 forces atomic accumulation (C must be initialised by the caller);
+ * bias / residual are then added by the first split only, and act/dropout/actgrad
+ * are rejected (MESM_EINVAL).
+ *
+ * colsum (optional): colsum[m] += sum_k opA(A)[m,k]  (atomic; used for bias grads,
+ * where A = dY^T).
+ */
+typedef struct MesmGemmArgs {
+  const float* A;
+  const float* A2;
+  const float* B;
+  float* C;
+  int32_t M, N, K;
+  int32_t a_layout, b_layout;
+  int64_t lda, ldb, ldc;
+  const float* bias;
+  const float* residual;
+  int64_t ldr;
+  const float* aux;
+  int64_t ldaux;
+  const float* slope;  /* device scalar for PRELU (prologue, epilogue, actgrad) */
+  float* dslope;       /* device scalar accumulator (actgrad PRELU), may be NULL */
+  float* colsum;       /* [M] accumulator, may be NULL */
+  int32_t a_act, b_act;
+  float a_drop_p, b_drop_p;
+  uint32_t a_drop_seed, b_drop_seed;
+  int32_t e_act, e_actgrad;
+  float e_drop_p;
+  uint32_t e_drop_seed;
+  float out_scale;
+  int32_t accumulate;
+  int32_t split_k;
+} MesmGemmArgs;
+
+int mesm_gemm_f32(const MesmGemmArgs* args, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/*
+ * LayerNorm over the last dim, rows x D, eps inside the sqrt (torch semantics).
+ * Replaces nn.LayerNorm sites: transformer.py:536,539,646,649,754,793,796,400,403;
+ * model.py:430 (LinearLayer.LayerNorm, D = 2818/4098/512/300/256).
+ * fwd writes y, and mean/rstd (rows) for the backward.
+ * bwd writes dx (or dx += if accumulate) and atomically accumulates dgamma/dbeta.
+ */
+int mesm_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                       float* mean, float* rstd, int64_t rows, int32_t D, float eps,
+                       void* stream);
+int mesm_layernorm_bwd(const float* dy, const float* x, const float* gamma,
+                       const float* mean, const float* rstd, float* dx, float* dgamma,
+                       float* dbeta, int64_t rows, int32_t D, int32_t accumulate_dx,
+                       void* stream);
+
+/* ------------------------------------------------------------------------- */
+/*
+ * Multi-head attention core: scores = scale * Q K^T -> mask(-inf) -> softmax ->
+ * dropout -> P V, one (batch, head) per workgroup column, K/V tiles staged in LDS,
+ * wavefront-shuffle row max / row sum, online softmax over key tiles.
+ *
+ * Replaces the attention core inside nn.MultiheadAttention at transformer.py:532,
+ * 597,643 (torch/nn/functional.py multi_head_attention_forward) and the custom
+ * multi_head_attention_forward core attention.py:329-386 (dk != dv allowed).
+ *
+ * Tensors: q (B, Lq, H*dk), k (B, Lk, H*dk), v (B, Lk, H*dv), o (B, Lq, H*dv) with
+ * batch stride *_bs and row stride *_ls (elements); head h occupies columns
+ * [h*dk, (h+1)*dk) of a row.  lse (B, H, Lq) = log-sum-exp of the masked scaled
+ * scores (saved for the backward).
+ *
+ * Masks (uint8, nonzero = masked):
+ *   kpad (B, Lk)   key_padding_mask;
+ *   qpad (B, Lq)   only for mask_mode = MESM_MASK_T2V_QUIRK: reproduces
+ *                  transformer.py:528-530 / :593-595, where the (B*H, Lq, Lk)
+ *                  attn_mask built with .repeat(nhead,1,1) is indexed by
+ *                  nn.MultiheadAttention as b*H+h:  key j of query i in (b,h) is
+ *                  masked iff kpad[b,j] or (qpad[b2,i] and kpad[b2,j]),
+ *                  b2 = (b*H + h) mod B.
+ * A row whose keys are all masked yields NaN, like the reference.
+ * Dropout on the probabilities: keep iff hash(seed, ((b*H+h)*Lq+i)*Lk+j) >= p.
+ */
+#define MESM_MASK_KPAD 0
+#define MESM_MASK_T2V_QUIRK 1
+
+typedef struct MesmAttnArgs {
+  const float* q;
+  const float* k;
+  const float* v;
+  float* o;
+  float* lse;
+  int32_t B, H, Lq, Lk, dk, dv;
+  int64_t q_bs, q_ls, k_bs, k_ls, v_bs, v_ls, o_bs, o_ls;
+  const uint8_t* kpad;
+  const uint8_t* qpad;
+  int32_t mask_mode;
+  float scale;
+  float drop_p;
+  uint32_t drop_seed;
+  /* backward only */
+  const float* d_o; /* (B, Lq, H*dv), strides o_bs/o_ls */
+  float* dq;        /* strides q_bs/q_ls; MUST be zero-initialised when Lk > 64 */
+  float* dk_;       /* strides k_bs/k_ls */
+  float* dv_;       /* strides v_bs/v_ls */
+} MesmAttnArgs;
+
+int mesm_attn_fwd(const MesmAttnArgs* args, void* stream);
+/* Needs q,k,v,o,lse from the forward plus d_o; writes dq,dk_,dv_. */
+int mesm_attn_bwd(const MesmAttnArgs* args, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/*
+ * Sine position encoding of a validity mask.  Replaces
+ * PositionEmbeddingSine.forward, position_encoding.py:51-72 (normalize=True,
+ * scale=2*pi, temperature 10000): x = cumsum(mask); x = x/(x[-1]+1e-6)*2pi;
+ * out[b,l,2i] = sin(x/T^(2i/D)), out[b,l,2i+1] = cos(x/T^(2i/D)).
+ * mask (B, L) uint8 (nonzero = valid) -> out (B, L, D).
+ */
+int mesm_sine_pos_fwd(const uint8_t* mask, float* out, int32_t B, int32_t L, int32_t D,
+                      void* stream);
+
+/*
+ * Query sine embedding of (center, width) reference points.  Replaces
+ * gen_sineembed_for_position, transformer.py:43-59: ref (R, 2) -> out (R, D),
+ * D/2 features for the centre then D/2 for the width, each interleaved sin/cos of
+ * ref*2pi / 10000^(2*floor(i/2)/(D/2)).
+ * bwd: dref (R, 2) (+)= sum_i dout * d(out)/d(ref).
+ */
+int mesm_query_sine_fwd(const float* ref, float* out, int64_t R, int32_t D, void* stream);
+int mesm_query_sine_bwd(const float* ref, const float* dout, float* dref, int64_t R,
+                        int32_t D, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/*
+ * Elementwise dropout with the library's counter hash (same stream of bits the GEMM
+ * prologue/epilogue and the attention core use): y = x * keep/(1-p), keep iff
+ * hash(seed, flat_index) >= p.  Replaces nn.Dropout sites not fused elsewhere and
+ * lets tests materialise the exact mask.  In-place allowed (y == x).
+ */
+int mesm_dropout(const float* x, float* y, int64_t n, float p, uint32_t seed,
+                 void* stream);
+
+/*
+ * Activation backward + bias gradient: dz = dy * act'(ref), dbias[c] += sum_rows dz,
+ * for RELU ref is the activation OUTPUT (y > 0), for PRELU ref is the
+ * pre-activation (z) and *dslope += sum(dy * min(z,0)).  In-place allowed (dz == dy).
+ * Replaces autograd of F.relu / nn.PReLU + bias at model.py:408,432-433 and
+ * transformer.py:32,537,603,608,647,794.  act = NONE gives the plain bias gradient.
+ */
+int mesm_act_bias_bwd(const float* dy, const float* ref, float* dz, float* dbias,
+                      const float* slope, float* dslope, int64_t rows, int32_t cols,
+                      int32_t act, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/*
+ * Label-smoothed masked-LM NLL over the vocabulary (C classes) with row masks.
+ * Replaces Criterion.cal_nll_loss, criterion.py:291-306 (eps = 0.1):
+ *   logp = log_softmax(logit[r,:]);  nll_r = (1-eps)*(-logp[label_r]) + eps/C*(-sum logp)
+ *   row_loss (R) = nll_r (0 where mask_r == 0);   correct (R) = argmax == label.
+ * bwd: dlogit[r,c] = g_r * ( softmax - (1-eps)*onehot - eps/C ), g_r = per-row upstream
+ * weight (already includes 1/mask.sum and 1/N from the reduction), 0 for masked rows.
+ */
+int mesm_nll_smooth_fwd(const float* logit, const int64_t* label, const uint8_t* mask,
+                        float* row_loss, float* row_lse, uint8_t* correct, int64_t R,
+                        int32_t C, float eps, void* stream);
+int mesm_nll_smooth_bwd(const float* logit, const int64_t* label, const float* row_lse,
+                        const float* row_grad, float* dlogit, int64_t R, int32_t C,
+                        float eps, void* stream);
+
+/*
+ * Saliency losses of Criterion.loss_saliency, criterion.py:139-221, fused:
+ * neg-pair BCE, the 11-stage rank-contrastive log-softmax over [pos || neg] scores
+ * (tau 0.5, +1e-6 inside the log, -1e3 fill for padded clips), optional triplet hinge.
+ * s_pos, s_neg (N, L) scores; label (N, L) float64; vmask (N, L) uint8 valid clips;
+ * pos_idx / neg_idx (N, P) int64 (may be NULL -> no triplet term).
+ * out_loss: device scalar (written).  bwd recomputes the row statistics and writes
+ * ds_pos, ds_neg (N, L) = (*gscale) * dloss/ds  (gscale: device scalar, the upstream
+ * gradient times the loss weight, so no host sync is needed).
+ */
+int mesm_saliency_loss_fwd(const float* s_pos, const float* s_neg, const double* label,
+                           const uint8_t* vmask, const int64_t* pos_idx,
+                           const int64_t* neg_idx, int32_t N, int32_t L, int32_t P,
+                           float rank_coef, float margin, float* out_loss, void* stream);
+int mesm_saliency_loss_bwd(const float* s_pos, const float* s_neg, const double* label,
+                           const uint8_t* vmask, const int64_t* pos_idx,
+                           const int64_t* neg_idx, int32_t N, int32_t L, int32_t P,
+                           float rank_coef, float margin, const float* gscale,
+                           float* ds_pos, float* ds_neg, void* stream);
+
+/*
+ * Hungarian matching cost + assignment on the device.  Replaces
+ * HungarianMatcher.forward, matcher.py:39-117:
+ *   C[b,q,t] = w_span * L1(span_cxw[b,q], tgt_cxw[t]) - w_giou * gIoU(xx(span), tgt_xx[t])
+ *              - w_class * softmax(logits[b,q])[0]
+ * and the optimal assignment of the T_b <= 16 targets of pair b to the Q <= 32 queries
+ * (shortest-augmenting-path Hungarian in fp64 on the fp32 costs, the algorithm behind
+ * scipy.optimize.linear_sum_assignment 1.9.1 pinned by the reference; identical result
+ * whenever the optimum is unique).  tgt_off (N+1) int32 prefix offsets into
+ * tgt_cxw / tgt_xx (sum T, 2).
+ * cost (N, Q, Tmax) optional output; match_q (sum T) int32: query matched to each
+ * target, in target order.
+ */
+int mesm_match(const float* logits, const float* spans, const float* tgt_cxw,
+               const float* tgt_xx, const int32_t* tgt_off, int32_t N, int32_t Q,
+               int32_t Tmax, float w_span, float w_giou, float w_class, float* cost,
+               int32_t* match_q, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MESM_GFX950_H */

@@ -1,0 +1,123 @@
+"""ctypes binding of libmesm_gfx950.so (the C-ABI declared in include/mesm_gfx950.h).
+
+There is no CPU fallback: if the shared object is missing or a call returns a non-zero
+status the caller gets an exception.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmesm_gfx950.so")
+
+ACT_NONE, ACT_RELU, ACT_PRELU = 0, 1, 2
+LAYOUT_REDUCE_CONTIG, LAYOUT_OUTER_CONTIG = 0, 1
+MASK_KPAD, MASK_T2V_QUIRK = 0, 1
+
+c_f32p = ctypes.c_void_p  # device pointers travel as opaque addresses
+c_ptr = ctypes.c_void_p
+
+
+class MesmError(RuntimeError):
+    pass
+
+
+class GemmArgs(ctypes.Structure):
+    _fields_ = [
+        ("A", c_ptr), ("A2", c_ptr), ("B", c_ptr), ("C", c_ptr),
+        ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32),
+        ("a_layout", ctypes.c_int32), ("b_layout", ctypes.c_int32),
+        ("lda", ctypes.c_int64), ("ldb", ctypes.c_int64), ("ldc", ctypes.c_int64),
+        ("bias", c_ptr), ("residual", c_ptr), ("ldr", ctypes.c_int64),
+        ("aux", c_ptr), ("ldaux", ctypes.c_int64),
+        ("slope", c_ptr), ("dslope", c_ptr), ("colsum", c_ptr),
+        ("a_act", ctypes.c_int32), ("b_act", ctypes.c_int32),
+        ("a_drop_p", ctypes.c_float), ("b_drop_p", ctypes.c_float),
+        ("a_drop_seed", ctypes.c_uint32), ("b_drop_seed", ctypes.c_uint32),
+        ("e_act", ctypes.c_int32), ("e_actgrad", ctypes.c_int32),
+        ("e_drop_p", ctypes.c_float), ("e_drop_seed", ctypes.c_uint32),
+        ("out_scale", ctypes.c_float),
+        ("accumulate", ctypes.c_int32), ("split_k", ctypes.c_int32),
+    ]
+
+
+class AttnArgs(ctypes.Structure):
+    _fields_ = [
+        ("q", c_ptr), ("k", c_ptr), ("v", c_ptr), ("o", c_ptr), ("lse", c_ptr),
+        ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("Lq", ctypes.c_int32),
+        ("Lk", ctypes.c_int32), ("dk", ctypes.c_int32), ("dv", ctypes.c_int32),
+        ("q_bs", ctypes.c_int64), ("q_ls", ctypes.c_int64),
+        ("k_bs", ctypes.c_int64), ("k_ls", ctypes.c_int64),
+        ("v_bs", ctypes.c_int64), ("v_ls", ctypes.c_int64),
+        ("o_bs", ctypes.c_int64), ("o_ls", ctypes.c_int64),
+        ("kpad", c_ptr), ("qpad", c_ptr), ("mask_mode", ctypes.c_int32),
+        ("scale", ctypes.c_float), ("drop_p", ctypes.c_float),
+        ("drop_seed", ctypes.c_uint32),
+        ("d_o", c_ptr), ("dq", c_ptr), ("dk_", c_ptr), ("dv_", c_ptr),
+    ]
+
+
+# name -> (restype, argtypes); mirrors include/mesm_gfx950.h one to one.
+_i32, _i64, _f32, _u32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_uint32
+PROTOTYPES = {
+    "mesm_abi_version": (ctypes.c_int, []),
+    "mesm_arch": (ctypes.c_char_p, []),
+    "mesm_gemm_f32": (ctypes.c_int, [ctypes.POINTER(GemmArgs), c_ptr]),
+    "mesm_layernorm_fwd": (ctypes.c_int, [c_ptr] * 6 + [_i64, _i32, _f32, c_ptr]),
+    "mesm_layernorm_bwd": (ctypes.c_int, [c_ptr] * 8 + [_i64, _i32, _i32, c_ptr]),
+    "mesm_attn_fwd": (ctypes.c_int, [ctypes.POINTER(AttnArgs), c_ptr]),
+    "mesm_attn_bwd": (ctypes.c_int, [ctypes.POINTER(AttnArgs), c_ptr]),
+    "mesm_sine_pos_fwd": (ctypes.c_int, [c_ptr, c_ptr, _i32, _i32, _i32, c_ptr]),
+    "mesm_query_sine_fwd": (ctypes.c_int, [c_ptr, c_ptr, _i64, _i32, c_ptr]),
+    "mesm_query_sine_bwd": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, _i64, _i32, c_ptr]),
+    "mesm_dropout": (ctypes.c_int, [c_ptr, c_ptr, _i64, _f32, _u32, c_ptr]),
+    "mesm_act_bias_bwd": (ctypes.c_int, [c_ptr] * 6 + [_i64, _i32, _i32, c_ptr]),
+    "mesm_nll_smooth_fwd": (ctypes.c_int, [c_ptr] * 6 + [_i64, _i32, _f32, c_ptr]),
+    "mesm_nll_smooth_bwd": (ctypes.c_int, [c_ptr] * 5 + [_i64, _i32, _f32, c_ptr]),
+    "mesm_saliency_loss_fwd": (ctypes.c_int, [c_ptr] * 6 + [_i32, _i32, _i32, _f32, _f32, c_ptr, c_ptr]),
+    "mesm_saliency_loss_bwd": (ctypes.c_int, [c_ptr] * 6 + [_i32, _i32, _i32, _f32, _f32, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "mesm_match": (ctypes.c_int, [c_ptr] * 5 + [_i32, _i32, _i32, _f32, _f32, _f32, c_ptr, c_ptr, c_ptr]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MesmError(
+                "libmesm_gfx950.so is missing (%s): run `python -m mesm_amd.build` — "
+                "there is no fallback path" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise MesmError("%s failed with status %d" % (what, rc))
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device address of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise MesmError("mesm_amd kernels need tensors on an MI355X device; got a %s tensor "
+                            "(the CPU oracle lives in oracle/, it is not a fallback)" % t.device)

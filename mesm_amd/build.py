@@ -1,0 +1,74 @@
+"""Build libmesm_gfx950.so in-tree with hipcc (cross-compiles for gfx950 without a GPU).
+
+Usage: ``python -m mesm_amd.build [--force]``.  The shared object lands next to this
+file so it travels with the repository snapshot to the GPU box.
+"""
+import concurrent.futures
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(ROOT, "include")
+LIB = os.path.join(HERE, "libmesm_gfx950.so")
+OBJ_DIR = os.path.join(CSRC, "build")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-munsafe-fp-atomics",
+    "-fno-gpu-rdc", "-I", INCLUDE, "-I", CSRC,
+    "-Wno-unused-value",
+]
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _deps():
+    deps = [os.path.join(INCLUDE, "mesm_gfx950.h")]
+    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    return deps
+
+
+def _stale(target, srcs):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in srcs)
+
+
+def _compile(src):
+    obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+    if _stale(obj, [src] + _deps()):
+        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
+    return obj
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    srcs = sources()
+    if force:
+        for f in os.listdir(OBJ_DIR):
+            os.remove(os.path.join(OBJ_DIR, f))
+        if os.path.exists(LIB):
+            os.remove(LIB)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
+        objs = list(ex.map(_compile, srcs))
+    if _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
+    if verbose:
+        print("built", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

@@ -1,0 +1,385 @@
+// Multi-head attention core for the MESM shapes (B*H ~ 256 heads, Lq,Lk <= ~700,
+// head dims 8..64), fp32 VALU math (the north star reserves MFMA for the dense
+// projections).  One workgroup (4 waves) per (batch, head[, query chunk / key tile]).
+//
+// Forward: keys are processed in tiles of 64 (one key per lane).  K/V tiles are staged
+// coalesced into LDS; each wave walks its query rows: lane j computes the score of key
+// j against the row (q broadcast from LDS), row max / row sum by wave shuffles, online
+// softmax across key tiles with the running (m, l, o) row state kept in LDS, P V with
+// lanes re-mapped to (feature d, key phase g) and the probabilities exchanged through a
+// per-wave LDS row.
+//
+// Backward: one workgroup per (batch, head, 64-key tile); lane j owns key j: K_j, V_j
+// and the dK_j, dV_j accumulators live in registers while the workgroup sweeps all
+// query rows (P is recomputed from the saved log-sum-exp).  dQ rows are reduced over
+// lanes through LDS and written (single key tile) or added atomically (several tiles).
+#include "common.hpp"
+
+namespace {
+
+constexpr int AT_THREADS = 256;
+constexpr int AT_WAVES = 4;
+constexpr int KT = 64;   // keys per tile (one per lane)
+constexpr int QCH = 64;  // query rows per forward workgroup
+constexpr int QCB = 32;  // query rows staged per backward chunk
+
+struct MaskCtx {
+  bool kp;   // kpad[b, j]
+  bool kp2;  // kpad[b2, j] (quirk mode)
+};
+
+template <int DK, int DV>
+__global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const MesmAttnArgs p) {
+  constexpr int SK = DK + 4;  // padded K row (conflict-free ds_read_b128 per lane)
+  constexpr int G = 64 / DV;  // key phases in the P V step
+  __shared__ __attribute__((aligned(16))) float Ks[KT * SK];
+  __shared__ __attribute__((aligned(16))) float Vs[KT * DV];
+  __shared__ __attribute__((aligned(16))) float Qs[QCH * DK];
+  __shared__ __attribute__((aligned(16))) float Os[QCH * DV];
+  __shared__ float Ms[QCH], Ls[QCH];
+  __shared__ float Ps[AT_WAVES * KT];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.x;
+  const int b = bh / p.H, h = bh % p.H;
+  const int q0 = blockIdx.y * QCH;
+  const int nq = (p.Lq - q0) < QCH ? (p.Lq - q0) : QCH;
+  const int b2 = (b * p.H + h) % p.B;
+  const bool quirk = (p.mask_mode == MESM_MASK_T2V_QUIRK) && p.qpad && p.kpad;
+
+  const float* qb = p.q + (int64_t)b * p.q_bs + (int64_t)h * DK;
+  const float* kb = p.k + (int64_t)b * p.k_bs + (int64_t)h * DK;
+  const float* vb = p.v + (int64_t)b * p.v_bs + (int64_t)h * DV;
+
+  // stage the query chunk and reset the row state
+  for (int idx = tid; idx < QCH * (DK / 4); idx += AT_THREADS) {
+    int r = idx / (DK / 4), c = (idx % (DK / 4)) * 4;
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < nq) t = *reinterpret_cast<const float4*>(qb + (int64_t)(q0 + r) * p.q_ls + c);
+    *reinterpret_cast<float4*>(Qs + r * DK + c) = t;
+  }
+  for (int idx = tid; idx < QCH * DV; idx += AT_THREADS) Os[idx] = 0.0f;
+  if (tid < QCH) { Ms[tid] = -INFINITY; Ls[tid] = 0.0f; }
+
+  const uint32_t thresh = p.drop_p > 0.f ? mesm_drop_threshold(p.drop_p) : 0u;
+  const float inv_keep = 1.0f / (1.0f - p.drop_p);
+
+  const int ntiles = (p.Lk + KT - 1) / KT;
+  for (int t = 0; t < ntiles; ++t) {
+    const int k0 = t * KT;
+    __syncthreads();  // previous tile fully consumed (and Qs/Os initialised)
+    for (int idx = tid; idx < KT * (DK / 4); idx += AT_THREADS) {
+      int r = idx / (DK / 4), c = (idx % (DK / 4)) * 4;
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k0 + r < p.Lk) x = *reinterpret_cast<const float4*>(kb + (int64_t)(k0 + r) * p.k_ls + c);
+      *reinterpret_cast<float4*>(Ks + r * SK + c) = x;
+    }
+    for (int idx = tid; idx < KT * (DV / 4); idx += AT_THREADS) {
+      int r = idx / (DV / 4), c = (idx % (DV / 4)) * 4;
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k0 + r < p.Lk) x = *reinterpret_cast<const float4*>(vb + (int64_t)(k0 + r) * p.v_ls + c);
+      *reinterpret_cast<float4*>(Vs + r * DV + c) = x;
+    }
+    const int j = k0 + lane;
+    const bool jvalid = j < p.Lk;
+    bool kp = !jvalid, kp2 = false;
+    if (jvalid && p.kpad) kp = p.kpad[(int64_t)b * p.Lk + j] != 0;
+    if (jvalid && quirk) kp2 = p.kpad[(int64_t)b2 * p.Lk + j] != 0;
+    __syncthreads();
+
+    float kreg[DK];
+#pragma unroll
+    for (int c = 0; c < DK; c += 4) {
+      float4 x = *reinterpret_cast<const float4*>(Ks + lane * SK + c);
+      kreg[c] = x.x; kreg[c + 1] = x.y; kreg[c + 2] = x.z; kreg[c + 3] = x.w;
+    }
+
+    for (int r = wave; r < nq; r += AT_WAVES) {
+      const int i = q0 + r;
+      float s = 0.0f;
+#pragma unroll
+      for (int c = 0; c < DK; c += 4) {
+        float4 qv = *reinterpret_cast<const float4*>(Qs + r * DK + c);
+        s += qv.x * kreg[c] + qv.y * kreg[c + 1] + qv.z * kreg[c + 2] + qv.w * kreg[c + 3];
+      }
+      s *= p.scale;
+      bool masked = kp;
+      if (quirk) {
+        bool qp = p.qpad[(int64_t)b2 * p.Lq + i] != 0;
+        masked = masked || (qp && kp2);
+      }
+      if (masked) s = -INFINITY;
+      const float m_old = Ms[r];
+      const float m_new = fmaxf(m_old, wave_max(s));
+      const float pj = (m_new == -INFINITY) ? 0.0f : __expf(s - m_new);
+      const float alpha = (m_old == -INFINITY) ? 0.0f : __expf(m_old - m_new);
+      const float l_new = Ls[r] * alpha + wave_sum(pj);
+      float pd = pj;
+      if (thresh) {
+        uint32_t idx = (uint32_t)(((int64_t)bh * p.Lq + i) * p.Lk + j);
+        pd = mesm_dropout_apply(pj, idx, p.drop_seed, thresh, inv_keep);
+      }
+      Ps[wave * KT + lane] = pd;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int d = lane % DV, g = lane / DV;
+      float acc = 0.0f;
+#pragma unroll 8
+      for (int jj = g; jj < KT; jj += G) acc += Ps[wave * KT + jj] * Vs[jj * DV + d];
+#pragma unroll
+      for (int o = DV; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
+      if (g == 0) Os[r * DV + d] = Os[r * DV + d] * alpha + acc;
+      if (lane == 0) { Ms[r] = m_new; Ls[r] = l_new; }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+
+  // finalise this wave's rows
+  float* ob = p.o + (int64_t)b * p.o_bs + (int64_t)h * DV;
+  for (int r = wave; r < nq; r += AT_WAVES) {
+    const int i = q0 + r;
+    const float l = Ls[r];
+    if (lane < DV) ob[(int64_t)i * p.o_ls + lane] = Os[r * DV + lane] / l;
+    if (lane == 0 && p.lse) p.lse[(int64_t)bh * p.Lq + i] = Ms[r] + __logf(l);
+  }
+}
+
+template <int DK, int DV>
+__global__ __launch_bounds__(AT_THREADS) void attn_bwd_kernel(const MesmAttnArgs p) {
+  constexpr int SK = DK + 4;
+  constexpr int SV = DV + 4;
+  constexpr int GQ = 64 / DK >= 1 ? 64 / DK : 1;  // key phases in the dQ step (DK <= 64)
+  constexpr int DR = (DK > DV ? DK : DV) + 1;  // +1: lane-per-row accesses stay conflict-free
+  __shared__ __attribute__((aligned(16))) float Ks[KT * SK];
+  __shared__ __attribute__((aligned(16))) float Vs[KT * SV];
+  __shared__ __attribute__((aligned(16))) float Qs[QCB * DK];
+  __shared__ __attribute__((aligned(16))) float dOs[QCB * DV];
+  __shared__ float Dl[QCB], Lse[QCB];
+  __shared__ float Ps[AT_WAVES * KT];
+  __shared__ __attribute__((aligned(16))) float Red[KT * DR];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.x;
+  const int b = bh / p.H, h = bh % p.H;
+  const int k0 = blockIdx.y * KT;
+  const int b2 = (b * p.H + h) % p.B;
+  const bool quirk = (p.mask_mode == MESM_MASK_T2V_QUIRK) && p.qpad && p.kpad;
+  const bool dq_atomic = gridDim.y > 1;
+
+  const float* qb = p.q + (int64_t)b * p.q_bs + (int64_t)h * DK;
+  const float* kb = p.k + (int64_t)b * p.k_bs + (int64_t)h * DK;
+  const float* vb = p.v + (int64_t)b * p.v_bs + (int64_t)h * DV;
+  const float* ob = p.o + (int64_t)b * p.o_bs + (int64_t)h * DV;
+  const float* dob = p.d_o + (int64_t)b * p.o_bs + (int64_t)h * DV;
+  float* dqb = p.dq + (int64_t)b * p.q_bs + (int64_t)h * DK;
+  float* dkb = p.dk_ + (int64_t)b * p.k_bs + (int64_t)h * DK;
+  float* dvb = p.dv_ + (int64_t)b * p.v_bs + (int64_t)h * DV;
+
+  for (int idx = tid; idx < KT * (DK / 4); idx += AT_THREADS) {
+    int r = idx / (DK / 4), c = (idx % (DK / 4)) * 4;
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k0 + r < p.Lk) x = *reinterpret_cast<const float4*>(kb + (int64_t)(k0 + r) * p.k_ls + c);
+    *reinterpret_cast<float4*>(Ks + r * SK + c) = x;
+  }
+  for (int idx = tid; idx < KT * (DV / 4); idx += AT_THREADS) {
+    int r = idx / (DV / 4), c = (idx % (DV / 4)) * 4;
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k0 + r < p.Lk) x = *reinterpret_cast<const float4*>(vb + (int64_t)(k0 + r) * p.v_ls + c);
+    *reinterpret_cast<float4*>(Vs + r * SV + c) = x;
+  }
+  const int j = k0 + lane;
+  const bool jvalid = j < p.Lk;
+  bool kp = !jvalid, kp2 = false;
+  if (jvalid && p.kpad) kp = p.kpad[(int64_t)b * p.Lk + j] != 0;
+  if (jvalid && quirk) kp2 = p.kpad[(int64_t)b2 * p.Lk + j] != 0;
+  __syncthreads();
+
+  float kreg[DK], vreg[DV], dkacc[DK], dvacc[DV];
+#pragma unroll
+  for (int c = 0; c < DK; c += 4) {
+    float4 x = *reinterpret_cast<const float4*>(Ks + lane * SK + c);
+    kreg[c] = x.x; kreg[c + 1] = x.y; kreg[c + 2] = x.z; kreg[c + 3] = x.w;
+    dkacc[c] = dkacc[c + 1] = dkacc[c + 2] = dkacc[c + 3] = 0.0f;
+  }
+#pragma unroll
+  for (int c = 0; c < DV; c += 4) {
+    float4 x = *reinterpret_cast<const float4*>(Vs + lane * SV + c);
+    vreg[c] = x.x; vreg[c + 1] = x.y; vreg[c + 2] = x.z; vreg[c + 3] = x.w;
+    dvacc[c] = dvacc[c + 1] = dvacc[c + 2] = dvacc[c + 3] = 0.0f;
+  }
+
+  const uint32_t thresh = p.drop_p > 0.f ? mesm_drop_threshold(p.drop_p) : 0u;
+  const float inv_keep = 1.0f / (1.0f - p.drop_p);
+
+  for (int qc = 0; qc < p.Lq; qc += QCB) {
+    const int nq = (p.Lq - qc) < QCB ? (p.Lq - qc) : QCB;
+    __syncthreads();  // previous chunk consumed
+    for (int idx = tid; idx < QCB * (DK / 4); idx += AT_THREADS) {
+      int r = idx / (DK / 4), c = (idx % (DK / 4)) * 4;
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < nq) x = *reinterpret_cast<const float4*>(qb + (int64_t)(qc + r) * p.q_ls + c);
+      *reinterpret_cast<float4*>(Qs + r * DK + c) = x;
+    }
+    // dO chunk + delta_i = sum_d dO[i,d] * O[i,d]; DV/4 consecutive threads share a row
+    for (int idx = tid; idx < QCB * (DV / 4); idx += AT_THREADS) {
+      int r = idx / (DV / 4), c = (idx % (DV / 4)) * 4;
+      float4 g = make_float4(0.f, 0.f, 0.f, 0.f), o = g;
+      if (r < nq) {
+        g = *reinterpret_cast<const float4*>(dob + (int64_t)(qc + r) * p.o_ls + c);
+        o = *reinterpret_cast<const float4*>(ob + (int64_t)(qc + r) * p.o_ls + c);
+      }
+      *reinterpret_cast<float4*>(dOs + r * DV + c) = g;
+      float part = g.x * o.x + g.y * o.y + g.z * o.z + g.w * o.w;
+#pragma unroll
+      for (int off = 1; off < DV / 4; off <<= 1) part += __shfl_xor(part, off, 64);
+      if ((idx % (DV / 4)) == 0) Dl[r] = part;
+    }
+    if (tid < QCB) Lse[tid] = (tid < nq) ? p.lse[(int64_t)bh * p.Lq + qc + tid] : 0.0f;
+    __syncthreads();
+
+    for (int r = wave; r < nq; r += AT_WAVES) {
+      const int i = qc + r;
+      float s = 0.0f;
+#pragma unroll
+      for (int c = 0; c < DK; c += 4) {
+        float4 qv = *reinterpret_cast<const float4*>(Qs + r * DK + c);
+        s += qv.x * kreg[c] + qv.y * kreg[c + 1] + qv.z * kreg[c + 2] + qv.w * kreg[c + 3];
+      }
+      s *= p.scale;
+      bool masked = kp;
+      if (quirk) {
+        bool qp = p.qpad[(int64_t)b2 * p.Lq + i] != 0;
+        masked = masked || (qp && kp2);
+      }
+      float pj = masked ? 0.0f : __expf(s - Lse[r]);
+      float km = 1.0f;
+      if (thresh) {
+        uint32_t idx = (uint32_t)(((int64_t)bh * p.Lq + i) * p.Lk + j);
+        km = mesm_hash32(idx, p.drop_seed) >= thresh ? inv_keep : 0.0f;
+      }
+      const float pd = pj * km;
+      float dp = 0.0f;
+#pragma unroll
+      for (int c = 0; c < DV; c += 4) {
+        float4 g = *reinterpret_cast<const float4*>(dOs + r * DV + c);
+        dp += g.x * vreg[c] + g.y * vreg[c + 1] + g.z * vreg[c + 2] + g.w * vreg[c + 3];
+        dvacc[c] += pd * g.x; dvacc[c + 1] += pd * g.y;
+        dvacc[c + 2] += pd * g.z; dvacc[c + 3] += pd * g.w;
+      }
+      const float ds = pj * (dp * km - Dl[r]) * p.scale;
+#pragma unroll
+      for (int c = 0; c < DK; c += 4) {
+        float4 qv = *reinterpret_cast<const float4*>(Qs + r * DK + c);
+        dkacc[c] += ds * qv.x; dkacc[c + 1] += ds * qv.y;
+        dkacc[c + 2] += ds * qv.z; dkacc[c + 3] += ds * qv.w;
+      }
+      Ps[wave * KT + lane] = ds;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int d = lane % DK, g = lane / DK;
+      float acc = 0.0f;
+#pragma unroll 8
+      for (int jj = g; jj < KT; jj += GQ) acc += Ps[wave * KT + jj] * Ks[jj * SK + d];
+#pragma unroll
+      for (int o = DK; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
+      if (g == 0) {
+        float* dst = dqb + (int64_t)i * p.q_ls + d;
+        if (dq_atomic) atomicAdd(dst, acc);
+        else *dst = acc;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+
+  // deterministic cross-wave reduction of dK then dV through LDS, wave by wave
+  for (int w = 0; w < AT_WAVES; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int c = 0; c < DK; ++c) {
+        float t = dkacc[c];
+        if (w > 0) t += Red[lane * DR + c];
+        Red[lane * DR + c] = t;
+      }
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < KT * DK; idx += AT_THREADS) {
+    int r = idx / DK, c = idx % DK;
+    if (k0 + r < p.Lk) dkb[(int64_t)(k0 + r) * p.k_ls + c] = Red[r * DR + c];
+  }
+  for (int w = 0; w < AT_WAVES; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int c = 0; c < DV; ++c) {
+        float t = dvacc[c];
+        if (w > 0) t += Red[lane * DR + c];
+        Red[lane * DR + c] = t;
+      }
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < KT * DV; idx += AT_THREADS) {
+    int r = idx / DV, c = idx % DV;
+    if (k0 + r < p.Lk) dvb[(int64_t)(k0 + r) * p.v_ls + c] = Red[r * DR + c];
+  }
+}
+
+int check_common(const MesmAttnArgs& a) {
+  if (!a.q || !a.k || !a.v || !a.o) return MESM_EINVAL;
+  if (a.B <= 0 || a.H <= 0 || a.Lq <= 0 || a.Lk <= 0) return MESM_EINVAL;
+  if (a.drop_p < 0.f || a.drop_p >= 1.f) return MESM_EINVAL;
+  if (a.mask_mode == MESM_MASK_T2V_QUIRK && (!a.qpad || !a.kpad)) return MESM_EINVAL;
+  // float4 staging: every row start must be 16-byte aligned
+  const int64_t strides[8] = {a.q_bs, a.q_ls, a.k_bs, a.k_ls, a.v_bs, a.v_ls, a.o_bs, a.o_ls};
+  for (int64_t s : strides)
+    if (s % 4 != 0) return MESM_EALIGN;
+  const void* ptrs[4] = {a.q, a.k, a.v, a.o};
+  for (const void* ptr : ptrs)
+    if (((uintptr_t)ptr % 16) != 0) return MESM_EALIGN;
+  if (a.dk % 4 != 0 || a.dv % 4 != 0) return MESM_EINVAL;
+  return MESM_OK;
+}
+
+#define ATTN_DISPATCH(KERNEL, GRID)                                                        \
+  do {                                                                                     \
+    if (a.dk == 32 && a.dv == 32) hipLaunchKernelGGL((KERNEL<32, 32>), GRID, dim3(AT_THREADS), 0, s, a); \
+    else if (a.dk == 64 && a.dv == 32) hipLaunchKernelGGL((KERNEL<64, 32>), GRID, dim3(AT_THREADS), 0, s, a); \
+    else if (a.dk == 8 && a.dv == 8) hipLaunchKernelGGL((KERNEL<8, 8>), GRID, dim3(AT_THREADS), 0, s, a); \
+    else if (a.dk == 16 && a.dv == 8) hipLaunchKernelGGL((KERNEL<16, 8>), GRID, dim3(AT_THREADS), 0, s, a); \
+    else if (a.dk == 16 && a.dv == 16) hipLaunchKernelGGL((KERNEL<16, 16>), GRID, dim3(AT_THREADS), 0, s, a); \
+    else if (a.dk == 32 && a.dv == 16) hipLaunchKernelGGL((KERNEL<32, 16>), GRID, dim3(AT_THREADS), 0, s, a); \
+    else if (a.dk == 64 && a.dv == 64) hipLaunchKernelGGL((KERNEL<64, 64>), GRID, dim3(AT_THREADS), 0, s, a); \
+    else return MESM_EINVAL;                                                               \
+  } while (0)
+
+}  // namespace
+
+extern "C" int mesm_attn_fwd(const MesmAttnArgs* args, void* stream) {
+  if (!args) return MESM_EINVAL;
+  MesmAttnArgs a = *args;
+  int rc = check_common(a);
+  if (rc != MESM_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(a.B * a.H, (a.Lq + QCH - 1) / QCH);
+  ATTN_DISPATCH(attn_fwd_kernel, grid);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_attn_bwd(const MesmAttnArgs* args, void* stream) {
+  if (!args) return MESM_EINVAL;
+  MesmAttnArgs a = *args;
+  int rc = check_common(a);
+  if (rc != MESM_OK) return rc;
+  if (!a.lse || !a.d_o || !a.dq || !a.dk_ || !a.dv_) return MESM_EINVAL;
+  const void* ptrs[4] = {a.d_o, a.dq, a.dk_, a.dv_};
+  for (const void* ptr : ptrs)
+    if (((uintptr_t)ptr % 16) != 0) return MESM_EALIGN;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid(a.B * a.H, (a.Lk + KT - 1) / KT);
+  ATTN_DISPATCH(attn_bwd_kernel, grid);
+  return mesm_launch_status();
+}

@@ -1,0 +1,181 @@
+// Small HBM-bound kernels: sine position encodings, dropout, activation/bias backward.
+#include "common.hpp"
+
+namespace {
+
+constexpr float TWO_PI_F = 6.283185307179586f;  // float32(2*math.pi), as torch casts the scalar
+
+// ---- PositionEmbeddingSine (position_encoding.py:51-72) ----
+__global__ __launch_bounds__(256) void sine_pos_kernel(const uint8_t* __restrict__ mask,
+                                                      float* __restrict__ out, int L, int D) {
+  extern __shared__ float xs[];  // L normalised positions
+  const int b = blockIdx.x;
+  const uint8_t* m = mask + (int64_t)b * L;
+  // inclusive prefix count of valid clips (exact in fp32, like cumsum(dtype=float32))
+  for (int l = threadIdx.x; l < L; l += blockDim.x) {
+    int c = 0;
+    for (int t = 0; t <= l; ++t) c += m[t] != 0;
+    xs[l] = (float)c;
+  }
+  __syncthreads();
+  const float last = xs[L - 1];
+  __syncthreads();
+  for (int l = threadIdx.x; l < L; l += blockDim.x) xs[l] = xs[l] / (last + 1e-6f) * TWO_PI_F;
+  __syncthreads();
+  float* ob = out + (int64_t)b * L * D;
+  for (int idx = threadIdx.x; idx < L * D; idx += blockDim.x) {
+    int l = idx / D, i = idx % D;
+    float e = (float)(2 * (i / 2)) / (float)D;
+    float dim_t = powf(10000.0f, e);
+    float v = xs[l] / dim_t;
+    ob[idx] = (i & 1) ? cosf(v) : sinf(v);
+  }
+}
+
+// ---- gen_sineembed_for_position (transformer.py:43-59) ----
+__global__ __launch_bounds__(256) void query_sine_fwd_kernel(const float* __restrict__ ref,
+                                                            float* __restrict__ out, int64_t R,
+                                                            int D) {
+  const int half = D / 2;
+  const int64_t total = R * D;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = idx / D;
+    int i = (int)(idx % D);
+    int which = i >= half;
+    int ii = which ? i - half : i;
+    float e = (float)(2 * (ii / 2)) / (float)half;
+    float dim_t = powf(10000.0f, e);
+    float v = ref[r * 2 + which] * TWO_PI_F / dim_t;
+    out[idx] = (ii & 1) ? cosf(v) : sinf(v);
+  }
+}
+
+// one wave per reference point
+__global__ __launch_bounds__(256) void query_sine_bwd_kernel(const float* __restrict__ ref,
+                                                            const float* __restrict__ dout,
+                                                            float* __restrict__ dref, int64_t R,
+                                                            int D) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const int half = D / 2;
+  float g0 = 0.0f, g1 = 0.0f;
+  for (int i = lane; i < D; i += 64) {
+    int which = i >= half;
+    int ii = which ? i - half : i;
+    float e = (float)(2 * (ii / 2)) / (float)half;
+    float dim_t = powf(10000.0f, e);
+    float x = ref[r * 2 + which] * TWO_PI_F;
+    float v = x / dim_t;
+    float dvdr = TWO_PI_F / dim_t;
+    float d = (ii & 1) ? -sinf(v) : cosf(v);
+    float g = dout[r * D + i] * d * dvdr;
+    if (which) g1 += g; else g0 += g;
+  }
+  g0 = wave_sum(g0);
+  g1 = wave_sum(g1);
+  if (lane == 0) {
+    dref[r * 2] += g0;
+    dref[r * 2 + 1] += g1;
+  }
+}
+
+__global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x,
+                                                     float* __restrict__ y, int64_t n,
+                                                     uint32_t thresh, float inv_keep,
+                                                     uint32_t seed) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = mesm_dropout_apply(x[i], (uint32_t)i, seed, thresh, inv_keep);
+}
+
+constexpr int AB_ROWS = 32;  // rows per workgroup
+
+__global__ __launch_bounds__(256) void act_bias_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ ref, float* __restrict__ dz,
+    float* __restrict__ dbias, const float* __restrict__ slope_p, float* __restrict__ dslope,
+    int64_t rows, int cols, int act) {
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.x * AB_ROWS;
+  const int64_t r1 = (r0 + AB_ROWS) < rows ? (r0 + AB_ROWS) : rows;
+  const float slope = slope_p ? *slope_p : 0.0f;
+  float colsum = 0.0f, ds = 0.0f;
+  if (c < cols) {
+    for (int64_t r = r0; r < r1; ++r) {
+      float g = dy[r * cols + c];
+      if (act == MESM_ACT_RELU) {
+        g = ref[r * cols + c] > 0.0f ? g : 0.0f;
+      } else if (act == MESM_ACT_PRELU) {
+        float z = ref[r * cols + c];
+        if (z <= 0.0f) {
+          ds += g * z;
+          g *= slope;
+        }
+      }
+      if (dz) dz[r * cols + c] = g;
+      colsum += g;
+    }
+    if (dbias) atomicAdd(dbias + c, colsum);
+  }
+  if (act == MESM_ACT_PRELU && dslope) {
+    ds = wave_sum(ds);
+    if ((threadIdx.x & 63) == 0 && ds != 0.0f) atomicAdd(dslope, ds);
+  }
+}
+
+}  // namespace
+
+extern "C" int mesm_sine_pos_fwd(const uint8_t* mask, float* out, int32_t B, int32_t L,
+                                 int32_t D, void* stream) {
+  if (!mask || !out || B <= 0 || L <= 0 || D <= 0 || (D & 1)) return MESM_EINVAL;
+  if (L > 8192) return MESM_EINVAL;
+  hipLaunchKernelGGL(sine_pos_kernel, dim3(B), dim3(256), (size_t)L * sizeof(float),
+                     (hipStream_t)stream, mask, out, L, D);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_query_sine_fwd(const float* ref, float* out, int64_t R, int32_t D,
+                                   void* stream) {
+  if (!ref || !out || R <= 0 || D <= 0 || (D % 4)) return MESM_EINVAL;
+  int64_t total = R * D;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(query_sine_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0,
+                     (hipStream_t)stream, ref, out, R, D);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_query_sine_bwd(const float* ref, const float* dout, float* dref, int64_t R,
+                                   int32_t D, void* stream) {
+  if (!ref || !dout || !dref || R <= 0 || D <= 0 || (D % 4)) return MESM_EINVAL;
+  hipLaunchKernelGGL(query_sine_bwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, ref, dout, dref, R, D);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_dropout(const float* x, float* y, int64_t n, float p, uint32_t seed,
+                            void* stream) {
+  if (!x || !y || n < 0 || p < 0.f || p >= 1.f) return MESM_EINVAL;
+  if (n == 0) return MESM_OK;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x,
+                     y, n, mesm_drop_threshold(p), 1.0f / (1.0f - p), seed);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_act_bias_bwd(const float* dy, const float* ref, float* dz, float* dbias,
+                                 const float* slope, float* dslope, int64_t rows, int32_t cols,
+                                 int32_t act, void* stream) {
+  if (!dy || rows <= 0 || cols <= 0) return MESM_EINVAL;
+  if (act != MESM_ACT_NONE && !ref) return MESM_EINVAL;
+  if (act == MESM_ACT_PRELU && !slope) return MESM_EINVAL;
+  dim3 grid((unsigned)((rows + AB_ROWS - 1) / AB_ROWS), (cols + 255) / 256);
+  hipLaunchKernelGGL(act_bias_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, ref, dz,
+                     dbias, slope, dslope, rows, cols, act);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_abi_version(void) { return 1; }
+extern "C" const char* mesm_arch(void) { return "gfx950"; }

@@ -1,0 +1,387 @@
+// Exact-f32 MFMA GEMM for gfx950 (v_mfma_f32_32x32x2_f32), LDS-tiled, with the
+// prologue / epilogue fusions the MESM hot path needs (see include/mesm_gfx950.h).
+//
+// Tiling: 256 threads = 4 waves in a 2x2 grid; block tile BM x BN in {128x128, 64x64},
+// K step 16.  Each wave owns a (BM/2)x(BN/2) sub-tile = TM x TN MFMA tiles of 32x32.
+// LDS image of both operands is [k][outer] so that lane l of the 32x32x2 MFMA reads
+// A[i = l&31][k = l>>5] / B[k = l>>5][j = l&31] with a conflict-free ds_read_b32
+// (the two 32-lane halves read different k rows).  Operands are staged
+// global -> registers -> LDS (a transpose is needed when the reduce index is the
+// contiguous one, which LDS-DMA cannot do) and double-buffered: the global loads of
+// tile t+1 are in flight while tile t is multiplied.
+#include "common.hpp"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BK = 16;
+constexpr int NTHREADS = 256;
+
+struct XForm {
+  int act;
+  float slope;
+  uint32_t thresh;  // 0 => no dropout
+  uint32_t seed;
+  float inv_keep;
+  int64_t lld;  // logical row length for the dropout index
+};
+
+// One operand tile: ROWS (outer index) x BK (reduce index).
+template <int ROWS, int LAYOUT, int VEC>
+struct Tile {
+  static constexpr int NVEC = ROWS * BK / (VEC * NTHREADS);
+  static_assert(NVEC >= 1, "tile too small for the block");
+  float r[NVEC][VEC];
+
+  // outer index (relative to tile) and reduce index (relative to tile) of vector v.
+  __device__ __forceinline__ static void coords(int tid, int v, int& o, int& k) {
+    int vid = tid + v * NTHREADS;
+    if (LAYOUT == MESM_LAYOUT_REDUCE_CONTIG) {
+      constexpr int VPR = BK / VEC;
+      o = vid / VPR;
+      k = (vid % VPR) * VEC;
+    } else {
+      constexpr int VPR = ROWS / VEC;
+      k = vid / VPR;
+      o = (vid % VPR) * VEC;
+    }
+  }
+
+  __device__ __forceinline__ void load(const float* __restrict__ base,
+                                       const float* __restrict__ add, int64_t ld, int o0,
+                                       int extent, int k0, int kend, int tid) {
+#pragma unroll
+    for (int v = 0; v < NVEC; ++v) {
+      int o, k;
+      coords(tid, v, o, k);
+      if (LAYOUT == MESM_LAYOUT_REDUCE_CONTIG) {
+        int go = o0 + o;
+        go = go < extent ? go : extent - 1;
+        int gk = k0 + k;
+        int64_t off = (int64_t)go * ld + gk;
+        if (gk + VEC <= kend) {
+          load_vec(base + off, r[v]);
+          if (add) {
+            float t[VEC];
+            load_vec(add + off, t);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) r[v][e] += t[e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            float x = 0.0f;
+            if (gk + e < kend) {
+              x = base[off + e];
+              if (add) x += add[off + e];
+            }
+            r[v][e] = x;
+          }
+        }
+      } else {
+        int gk = k0 + k;
+        int go = o0 + o;
+        if (gk < kend) {
+          int64_t rowoff = (int64_t)gk * ld;
+          if (go + VEC <= extent) {
+            load_vec(base + rowoff + go, r[v]);
+            if (add) {
+              float t[VEC];
+              load_vec(add + rowoff + go, t);
+#pragma unroll
+              for (int e = 0; e < VEC; ++e) r[v][e] += t[e];
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+              int g = go + e;
+              g = g < extent ? g : extent - 1;
+              float x = base[rowoff + g];
+              if (add) x += add[rowoff + g];
+              r[v][e] = x;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) r[v][e] = 0.0f;
+        }
+      }
+    }
+  }
+
+  __device__ __forceinline__ static void load_vec(const float* __restrict__ p, float* dst) {
+    if (VEC == 4) {
+      float4 t = *reinterpret_cast<const float4*>(p);
+      dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
+    } else if (VEC == 2) {
+      float2 t = *reinterpret_cast<const float2*>(p);
+      dst[0] = t.x; dst[1] = t.y;
+    } else {
+      dst[0] = *p;
+    }
+  }
+
+  // Activation / dropout on the staged registers.  OUTER_IS_ROW: logical index is
+  // outer*lld + reduce (operand A), otherwise reduce*lld + outer (operand B).
+  template <bool OUTER_IS_ROW>
+  __device__ __forceinline__ void xform(const XForm& xf, int o0, int k0, int tid) {
+    if (xf.act == MESM_ACT_NONE && xf.thresh == 0) return;
+#pragma unroll
+    for (int v = 0; v < NVEC; ++v) {
+      int o, k;
+      coords(tid, v, o, k);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        int go = o0 + o + (LAYOUT == MESM_LAYOUT_REDUCE_CONTIG ? 0 : e);
+        int gk = k0 + k + (LAYOUT == MESM_LAYOUT_REDUCE_CONTIG ? e : 0);
+        float x = mesm_act(r[v][e], xf.act, xf.slope);
+        if (xf.thresh) {
+          int64_t idx = OUTER_IS_ROW ? (int64_t)go * xf.lld + gk : (int64_t)gk * xf.lld + go;
+          x = mesm_dropout_apply(x, (uint32_t)idx, xf.seed, xf.thresh, xf.inv_keep);
+        }
+        r[v][e] = x;
+      }
+    }
+  }
+
+  // LDS image: S[k][outer], row stride `stride` floats.
+  __device__ __forceinline__ void store(float* __restrict__ S, int stride, int tid) const {
+#pragma unroll
+    for (int v = 0; v < NVEC; ++v) {
+      int o, k;
+      coords(tid, v, o, k);
+      if (LAYOUT == MESM_LAYOUT_REDUCE_CONTIG) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) S[(k + e) * stride + o] = r[v][e];
+      } else {
+        float* d = S + k * stride + o;
+        if (VEC == 4) {
+          *reinterpret_cast<float4*>(d) = make_float4(r[v][0], r[v][1], r[v][2], r[v][3]);
+        } else if (VEC == 2) {
+          *reinterpret_cast<float2*>(d) = make_float2(r[v][0], r[v][1]);
+        } else {
+          d[0] = r[v][0];
+        }
+      }
+    }
+  }
+};
+
+template <int BM, int BN, int LA, int LB, int VEC>
+__global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const MesmGemmArgs p) {
+  constexpr int PA = (LA == MESM_LAYOUT_REDUCE_CONTIG) ? 2 : 0;
+  constexpr int PB = (LB == MESM_LAYOUT_REDUCE_CONTIG) ? 2 : 0;
+  constexpr int SA = BM + PA;
+  constexpr int SB = BN + PB;
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int TM = WM / 32, TN = WN / 32;
+
+  __shared__ __attribute__((aligned(16))) float As[2][BK * SA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * SB];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+
+  int kbeg = 0, kend = p.K;
+  if (p.split_k > 1) {
+    int chunk = (p.K + p.split_k - 1) / p.split_k;
+    chunk = ((chunk + BK - 1) / BK) * BK;
+    kbeg = blockIdx.z * chunk;
+    kend = kbeg + chunk < p.K ? kbeg + chunk : p.K;
+    if (kbeg >= p.K) return;
+  }
+
+  const float slope = p.slope ? *p.slope : 0.0f;
+  XForm xa, xb;
+  xa.act = p.a_act; xa.slope = slope; xa.thresh = p.a_drop_p > 0.f ? mesm_drop_threshold(p.a_drop_p) : 0u;
+  xa.seed = p.a_drop_seed; xa.inv_keep = 1.0f / (1.0f - p.a_drop_p); xa.lld = p.K;
+  xb.act = p.b_act; xb.slope = slope; xb.thresh = p.b_drop_p > 0.f ? mesm_drop_threshold(p.b_drop_p) : 0u;
+  xb.seed = p.b_drop_seed; xb.inv_keep = 1.0f / (1.0f - p.b_drop_p); xb.lld = p.N;
+
+  Tile<BM, LA, VEC> ta;
+  Tile<BN, LB, VEC> tb;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  // bias-gradient side product: column sums of the A tile over the reduce index.
+  const bool do_colsum = (p.colsum != nullptr) && (blockIdx.y == 0);
+  float csum = 0.0f;
+  constexpr int CS_KSTEP = NTHREADS / BM;  // threads per A column
+  const int cs_i = tid % BM;
+  const int cs_k = tid / BM;
+
+  const int nkt = (kend - kbeg + BK - 1) / BK;
+  ta.load(p.A, p.A2, p.lda, m0, p.M, kbeg, kend, tid);
+  tb.load(p.B, nullptr, p.ldb, n0, p.N, kbeg, kend, tid);
+  ta.template xform<true>(xa, m0, kbeg, tid);
+  tb.template xform<false>(xb, n0, kbeg, tid);
+  ta.store(As[0], SA, tid);
+  tb.store(Bs[0], SB, tid);
+  __syncthreads();
+
+  int buf = 0;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int knext = kbeg + (kt + 1) * BK;
+    const bool has_next = (kt + 1 < nkt);
+    if (has_next) {
+      ta.load(p.A, p.A2, p.lda, m0, p.M, knext, kend, tid);
+      tb.load(p.B, nullptr, p.ldb, n0, p.N, knext, kend, tid);
+    }
+    const float* __restrict__ a_s = As[buf];
+    const float* __restrict__ b_s = Bs[buf];
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const int krow = 2 * kk + (lane >> 5);
+      float a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = a_s[krow * SA + wm * WM + i * 32 + (lane & 31)];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = b_s[krow * SB + wn * WN + j * 32 + (lane & 31)];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (do_colsum) {
+#pragma unroll
+      for (int k = 0; k < BK; k += CS_KSTEP) csum += a_s[(k + cs_k) * SA + cs_i];
+    }
+    if (has_next) {
+      ta.template xform<true>(xa, m0, knext, tid);
+      tb.template xform<false>(xb, n0, knext, tid);
+      ta.store(As[buf ^ 1], SA, tid);
+      tb.store(Bs[buf ^ 1], SB, tid);
+    }
+    __syncthreads();
+    buf ^= 1;
+  }
+
+  if (do_colsum) {
+    int gi = m0 + cs_i;
+    if (gi < p.M) atomicAdd(p.colsum + gi, csum);
+  }
+
+  // ---- epilogue ----
+  const bool first_split = (p.split_k <= 1) || (blockIdx.z == 0);
+  const uint32_t e_thresh = p.e_drop_p > 0.f ? mesm_drop_threshold(p.e_drop_p) : 0u;
+  const float e_inv_keep = 1.0f / (1.0f - p.e_drop_p);
+  float dslope_part = 0.0f;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * WN + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < p.M && col < p.N) {
+          float t = acc[i][j][r] * p.out_scale;
+          if (p.bias && first_split) t += p.bias[col];
+          t = mesm_act(t, p.e_act, slope);
+          if (e_thresh)
+            t = mesm_dropout_apply(t, (uint32_t)((int64_t)row * p.N + col), p.e_drop_seed,
+                                   e_thresh, e_inv_keep);
+          if (p.e_actgrad != MESM_ACT_NONE) {
+            float z = p.aux[(int64_t)row * p.ldaux + col];
+            if (p.e_actgrad == MESM_ACT_RELU) {
+              t = z > 0.0f ? t : 0.0f;
+            } else {
+              if (z <= 0.0f) {
+                dslope_part += t * z;
+                t *= slope;
+              }
+            }
+          }
+          if (p.residual && first_split) t += p.residual[(int64_t)row * p.ldr + col];
+          float* c = p.C + (int64_t)row * p.ldc + col;
+          if (p.accumulate == 0) *c = t;
+          else if (p.accumulate == 1) *c += t;
+          else atomicAdd(c, t);
+        }
+      }
+    }
+  }
+  if (p.e_actgrad == MESM_ACT_PRELU && p.dslope) {
+    dslope_part = wave_sum(dslope_part);
+    if (lane == 0 && dslope_part != 0.0f) atomicAdd(p.dslope, dslope_part);
+  }
+}
+
+template <int BM, int BN, int LA, int LB, int VEC>
+int launch(const MesmGemmArgs& a, hipStream_t s) {
+  dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.split_k > 1 ? a.split_k : 1);
+  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, LA, LB, VEC>), grid, dim3(NTHREADS), 0, s, a);
+  return mesm_launch_status();
+}
+
+template <int BM, int BN, int VEC>
+int launch_layout(const MesmGemmArgs& a, hipStream_t s) {
+  constexpr int R = MESM_LAYOUT_REDUCE_CONTIG, O = MESM_LAYOUT_OUTER_CONTIG;
+  if (a.a_layout == R && a.b_layout == R) return launch<BM, BN, R, R, VEC>(a, s);
+  if (a.a_layout == R && a.b_layout == O) return launch<BM, BN, R, O, VEC>(a, s);
+  if (a.a_layout == O && a.b_layout == O) return launch<BM, BN, O, O, VEC>(a, s);
+  if (a.a_layout == O && a.b_layout == R) return launch<BM, BN, O, R, VEC>(a, s);
+  return MESM_EINVAL;
+}
+
+template <int VEC>
+int launch_tile(const MesmGemmArgs& a, hipStream_t s) {
+  // 128x128 tiles only when they still give every CU a workgroup.
+  long blocks128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * (a.split_k > 1 ? a.split_k : 1);
+  if (blocks128 >= 256) return launch_layout<128, 128, VEC>(a, s);
+  return launch_layout<64, 64, VEC>(a, s);
+}
+
+inline bool aligned_to(const void* p, size_t b) { return p == nullptr || ((uintptr_t)p % b) == 0; }
+
+}  // namespace
+
+extern "C" int mesm_gemm_f32(const MesmGemmArgs* args, void* stream) {
+  if (!args) return MESM_EINVAL;
+  MesmGemmArgs a = *args;
+  if (!a.A || !a.B || !a.C) return MESM_EINVAL;
+  if (a.M <= 0 || a.N <= 0 || a.K <= 0) return MESM_EINVAL;
+  if (a.a_layout < 0 || a.a_layout > 1 || a.b_layout < 0 || a.b_layout > 1) return MESM_EINVAL;
+  if (a.e_actgrad != MESM_ACT_NONE && !a.aux) return MESM_EINVAL;
+  if ((a.a_act == MESM_ACT_PRELU || a.b_act == MESM_ACT_PRELU || a.e_act == MESM_ACT_PRELU ||
+       a.e_actgrad == MESM_ACT_PRELU) && !a.slope)
+    return MESM_EINVAL;
+  if (a.a_drop_p < 0.f || a.a_drop_p >= 1.f || a.b_drop_p < 0.f || a.b_drop_p >= 1.f ||
+      a.e_drop_p < 0.f || a.e_drop_p >= 1.f)
+    return MESM_EINVAL;
+  if (a.split_k < 1) a.split_k = 1;
+  if (a.split_k > 1) {
+    if (a.e_act != MESM_ACT_NONE || a.e_actgrad != MESM_ACT_NONE || a.e_drop_p > 0.f)
+      return MESM_EINVAL;
+    a.accumulate = 2;
+    int max_split = (a.K + BK - 1) / BK;
+    if (a.split_k > max_split) a.split_k = max_split;
+  }
+  if (a.accumulate < 0 || a.accumulate > 2) return MESM_EINVAL;
+  if (a.out_scale == 0.0f) a.out_scale = 1.0f;
+  hipStream_t s = (hipStream_t)stream;
+  // widest vector width every operand supports
+  int vec = 4;
+  while (vec > 1) {
+    bool ok = (a.lda % vec == 0) && (a.ldb % vec == 0) && aligned_to(a.A, 4 * vec) &&
+              aligned_to(a.A2, 4 * vec) && aligned_to(a.B, 4 * vec);
+    if (ok) break;
+    vec >>= 1;
+  }
+  if (!aligned_to(a.A, 4) || !aligned_to(a.B, 4) || !aligned_to(a.C, 4)) return MESM_EALIGN;
+  if (vec == 4) return launch_tile<4>(a, s);
+  if (vec == 2) return launch_tile<2>(a, s);
+  return launch_tile<1>(a, s);
+}

@@ -1,0 +1,281 @@
+// LayerNorm forward / backward, one wave64 per row, the row cached in registers
+// (NCH chunks of 64*VEC floats per lane), wave-shuffle reductions.
+// HBM-bound: fwd reads x once and writes y once (+2 floats/row); bwd reads dy, x once,
+// writes dx once; dgamma/dbeta are reduced per workgroup through LDS and added
+// atomically (few adders per address: the grid is capped).
+#include "common.hpp"
+
+namespace {
+
+constexpr int LN_THREADS = 256;
+constexpr int LN_WAVES = LN_THREADS / 64;
+
+template <int VEC>
+__device__ __forceinline__ void ld_vec(const float* __restrict__ p, float* d) {
+  if (VEC == 4) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+  } else if (VEC == 2) {
+    float2 t = *reinterpret_cast<const float2*>(p);
+    d[0] = t.x; d[1] = t.y;
+  } else {
+    d[0] = *p;
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void st_vec(float* __restrict__ p, const float* s) {
+  if (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(s[0], s[1], s[2], s[3]);
+  else if (VEC == 2) *reinterpret_cast<float2*>(p) = make_float2(s[0], s[1]);
+  else *p = s[0];
+}
+
+template <int VEC, int NCH>
+__global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ y, float* __restrict__ mean,
+    float* __restrict__ rstd, int64_t rows, int D, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_global = (int64_t)blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)gridDim.x * LN_WAVES;
+  const float invD = 1.0f / (float)D;
+  for (int64_t row = wave_global; row < rows; row += nwaves) {
+    const float* xr = x + row * D;
+    float v[NCH][VEC];
+    float s = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      int col = (c * 64 + lane) * VEC;
+      if (col < D) {  // D % VEC == 0 guaranteed by the host
+        ld_vec<VEC>(xr + col, v[c]);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s += v[c][e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[c][e] = 0.0f;
+      }
+    }
+    const float mu = wave_sum(s) * invD;
+    float q = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      int col = (c * 64 + lane) * VEC;
+      if (col < D) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float d = v[c][e] - mu;
+          q += d * d;
+        }
+      }
+    }
+    const float var = wave_sum(q) * invD;
+    const float rs = rsqrtf(var + eps);
+    float* yr = y + row * D;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      int col = (c * 64 + lane) * VEC;
+      if (col < D) {
+        float g[VEC], b[VEC], o[VEC];
+        ld_vec<VEC>(gamma + col, g);
+        ld_vec<VEC>(beta + col, b);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] = (v[c][e] - mu) * rs * g[e] + b[e];
+        st_vec<VEC>(yr + col, o);
+      }
+    }
+    if (lane == 0) {
+      mean[row] = mu;
+      rstd[row] = rs;
+    }
+  }
+}
+
+template <int VEC, int NCH, bool LDS_REDUCE>
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x,
+    const float* __restrict__ gamma, const float* __restrict__ mean,
+    const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ dgamma,
+    float* __restrict__ dbeta, int64_t rows, int D, int accumulate_dx) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // LN_WAVES * D when LDS_REDUCE
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t wave_global = (int64_t)blockIdx.x * LN_WAVES + wave;
+  const int64_t nwaves = (int64_t)gridDim.x * LN_WAVES;
+  const float invD = 1.0f / (float)D;
+
+  float g[NCH][VEC];
+  float dg[NCH][VEC], db[NCH][VEC];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    int col = (c * 64 + lane) * VEC;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { dg[c][e] = 0.0f; db[c][e] = 0.0f; g[c][e] = 0.0f; }
+    if (col < D) ld_vec<VEC>(gamma + col, g[c]);
+  }
+
+  for (int64_t row = wave_global; row < rows; row += nwaves) {
+    const float mu = mean[row];
+    const float rs = rstd[row];
+    const float* xr = x + row * D;
+    const float* dyr = dy + row * D;
+    float xh[NCH][VEC], dv[NCH][VEC];
+    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      int col = (c * 64 + lane) * VEC;
+      if (col < D) {
+        float xv[VEC];
+        ld_vec<VEC>(xr + col, xv);
+        ld_vec<VEC>(dyr + col, dv[c]);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          xh[c][e] = (xv[e] - mu) * rs;
+          float dyg = dv[c][e] * g[c][e];
+          s1 += dyg * xh[c][e];
+          s2 += dyg;
+          dg[c][e] += dv[c][e] * xh[c][e];
+          db[c][e] += dv[c][e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { xh[c][e] = 0.0f; dv[c][e] = 0.0f; }
+      }
+    }
+    const float c1 = wave_sum(s1) * invD;
+    const float c2 = wave_sum(s2) * invD;
+    float* dxr = dx + row * D;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      int col = (c * 64 + lane) * VEC;
+      if (col < D) {
+        float o[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] = rs * (dv[c][e] * g[c][e] - c2 - xh[c][e] * c1);
+        if (accumulate_dx) {
+          float old[VEC];
+          ld_vec<VEC>(dxr + col, old);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) o[e] += old[e];
+        }
+        st_vec<VEC>(dxr + col, o);
+      }
+    }
+  }
+
+  if (LDS_REDUCE) {
+    // two rounds (dgamma, dbeta) through one LN_WAVES x D buffer
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        int col = (c * 64 + lane) * VEC;
+        if (col < D) st_vec<VEC>(red + wave * D + col, round == 0 ? dg[c] : db[c]);
+      }
+      __syncthreads();
+      float* dst = round == 0 ? dgamma : dbeta;
+      for (int col = threadIdx.x; col < D; col += LN_THREADS) {
+        float t = 0.0f;
+#pragma unroll
+        for (int w = 0; w < LN_WAVES; ++w) t += red[w * D + col];
+        atomicAdd(dst + col, t);
+      }
+      __syncthreads();
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      int col = (c * 64 + lane) * VEC;
+      if (col < D) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          atomicAdd(dgamma + col + e, dg[c][e]);
+          atomicAdd(dbeta + col + e, db[c][e]);
+        }
+      }
+    }
+  }
+}
+
+inline int pick_vec(int D, const void* a, const void* b, const void* c, const void* d) {
+  int vec = 4;
+  while (vec > 1) {
+    bool ok = (D % vec == 0);
+    const void* ps[4] = {a, b, c, d};
+    for (const void* p : ps) ok = ok && (p == nullptr || ((uintptr_t)p % (4 * vec)) == 0);
+    if (ok) break;
+    vec >>= 1;
+  }
+  return vec;
+}
+
+template <int VEC, int NCH>
+int fwd_launch(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+               float* rstd, int64_t rows, int D, float eps, hipStream_t s) {
+  int64_t blocks = (rows + LN_WAVES - 1) / LN_WAVES;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL((ln_fwd_kernel<VEC, NCH>), dim3((unsigned)blocks), dim3(LN_THREADS), 0, s, x,
+                     gamma, beta, y, mean, rstd, rows, D, eps);
+  return mesm_launch_status();
+}
+
+template <int VEC, int NCH>
+int bwd_launch(const float* dy, const float* x, const float* gamma, const float* mean,
+               const float* rstd, float* dx, float* dgamma, float* dbeta, int64_t rows, int D,
+               int acc, hipStream_t s) {
+  int64_t blocks = (rows + LN_WAVES - 1) / LN_WAVES;
+  if (D <= 1024) {
+    if (blocks > 128) blocks = 128;
+    size_t lds = (size_t)LN_WAVES * D * sizeof(float);
+    hipLaunchKernelGGL((ln_bwd_kernel<VEC, NCH, true>), dim3((unsigned)blocks), dim3(LN_THREADS),
+                       lds, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, acc);
+  } else {
+    if (blocks > 64) blocks = 64;
+    hipLaunchKernelGGL((ln_bwd_kernel<VEC, NCH, false>), dim3((unsigned)blocks),
+                       dim3(LN_THREADS), 0, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows,
+                       D, acc);
+  }
+  return mesm_launch_status();
+}
+
+#define LN_DISPATCH(FN, VEC, ...)                                  \
+  do {                                                             \
+    int need = (D + 64 * VEC - 1) / (64 * VEC);                    \
+    if (need <= 1) return FN<VEC, 1>(__VA_ARGS__);                 \
+    if (need <= 2) return FN<VEC, 2>(__VA_ARGS__);                 \
+    if (need <= 4) return FN<VEC, 4>(__VA_ARGS__);                 \
+    if (need <= 8) return FN<VEC, 8>(__VA_ARGS__);                 \
+    if (need <= 16) return FN<VEC, 16>(__VA_ARGS__);               \
+    if (need <= 24) return FN<VEC, 24>(__VA_ARGS__);               \
+    if (need <= 36) return FN<VEC, 36>(__VA_ARGS__);               \
+    return MESM_EINVAL;                                            \
+  } while (0)
+
+}  // namespace
+
+extern "C" int mesm_layernorm_fwd(const float* x, const float* gamma, const float* beta,
+                                  float* y, float* mean, float* rstd, int64_t rows, int32_t D,
+                                  float eps, void* stream) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd || rows < 0 || D <= 0) return MESM_EINVAL;
+  if (rows == 0) return MESM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  int vec = pick_vec(D, x, y, gamma, beta);
+  if (vec == 4) LN_DISPATCH(fwd_launch, 4, x, gamma, beta, y, mean, rstd, rows, D, eps, s);
+  if (vec == 2) LN_DISPATCH(fwd_launch, 2, x, gamma, beta, y, mean, rstd, rows, D, eps, s);
+  LN_DISPATCH(fwd_launch, 1, x, gamma, beta, y, mean, rstd, rows, D, eps, s);
+}
+
+extern "C" int mesm_layernorm_bwd(const float* dy, const float* x, const float* gamma,
+                                  const float* mean, const float* rstd, float* dx,
+                                  float* dgamma, float* dbeta, int64_t rows, int32_t D,
+                                  int32_t accumulate_dx, void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows < 0 || D <= 0)
+    return MESM_EINVAL;
+  if (rows == 0) return MESM_OK;
+  hipStream_t s = (hipStream_t)stream;
+  int vec = pick_vec(D, x, dy, dx, gamma);
+  if (vec == 4)
+    LN_DISPATCH(bwd_launch, 4, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, accumulate_dx, s);
+  if (vec == 2)
+    LN_DISPATCH(bwd_launch, 2, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, accumulate_dx, s);
+  LN_DISPATCH(bwd_launch, 1, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, accumulate_dx, s);
+}

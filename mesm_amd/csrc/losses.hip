@@ -1,0 +1,402 @@
+// Per-pair loss reductions of model/criterion.py and the matching cost + assignment of
+// model/matcher.py as gfx950 kernels.  All are HBM/latency-bound and tiny except the
+// masked-LM NLL over the vocabulary (N*Lw rows x C ~ 5k classes).
+#include "common.hpp"
+
+namespace {
+
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  float t = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  return t;
+}
+
+// ---------------------------------------------------------------- label-smoothed NLL
+// one workgroup per row (criterion.py:291-306)
+__global__ __launch_bounds__(256) void nll_fwd_kernel(
+    const float* __restrict__ logit, const int64_t* __restrict__ label,
+    const uint8_t* __restrict__ mask, float* __restrict__ row_loss,
+    float* __restrict__ row_lse, uint8_t* __restrict__ correct, int C, float eps) {
+  __shared__ float sh[8];
+  __shared__ float shm[4];
+  __shared__ int shi[4];
+  const int64_t r = blockIdx.x;
+  const float* x = logit + r * C;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // pass 1: max + first argmax + plain sum
+  float m = -INFINITY, s = 0.0f;
+  int am = 0x7fffffff;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float v = x[c];
+    s += v;
+    if (v > m) { m = v; am = c; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float m2 = __shfl_xor(m, o, 64);
+    int a2 = __shfl_xor(am, o, 64);
+    if (m2 > m || (m2 == m && a2 < am)) { m = m2; am = a2; }
+  }
+  if (lane == 0) { shm[wave] = m; shi[wave] = am; }
+  __syncthreads();
+  float M = shm[0];
+  int AM = shi[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w)
+    if (shm[w] > M || (shm[w] == M && shi[w] < AM)) { M = shm[w]; AM = shi[w]; }
+  __syncthreads();
+  const float total = block_sum_256(s, sh);
+  // pass 2: sum exp (row is L2-resident)
+  float e = 0.0f;
+  for (int c = threadIdx.x; c < C; c += 256) e += __expf(x[c] - M);
+  const float E = block_sum_256(e, sh);
+  if (threadIdx.x == 0) {
+    const float lse = M + __logf(E);
+    const int64_t lab = label[r];
+    const float nll = -(x[lab] - lse);
+    const float smooth = -(total - (float)C * lse);
+    float loss = (1.0f - eps) * nll + eps / (float)C * smooth;
+    if (mask && mask[r] == 0) loss = 0.0f;
+    row_loss[r] = loss;
+    row_lse[r] = lse;
+    if (correct) correct[r] = (AM == (int)lab) ? 1 : 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void nll_bwd_kernel(
+    const float* __restrict__ logit, const int64_t* __restrict__ label,
+    const float* __restrict__ row_lse, const float* __restrict__ row_grad,
+    float* __restrict__ dlogit, int C, float eps) {
+  const int64_t r = blockIdx.x;
+  const float g = row_grad[r];
+  const float lse = row_lse[r];
+  const int lab = (int)label[r];
+  const float* x = logit + r * C;
+  float* d = dlogit + r * C;
+  const float u = eps / (float)C;
+  for (int c = blockIdx.y * 256 + threadIdx.x; c < C; c += gridDim.y * 256) {
+    float v = 0.0f;
+    if (g != 0.0f) {
+      float p = __expf(x[c] - lse);
+      v = g * (p - (c == lab ? (1.0f - eps) : 0.0f) - u);
+    }
+    d[c] = v;
+  }
+}
+
+// ---------------------------------------------------------------- saliency losses
+// criterion.py:139-221.  One workgroup, one wave per pair (rows strided over 4 waves).
+constexpr int SAL_STAGES = 11;   // rand_idx in range(1, 12)
+constexpr int SAL_MAXE = 20;     // elements of [pos || neg] per lane: 2L <= 1280
+
+struct SalRow {
+  float x[SAL_MAXE];    // scores / tau after the -1e3 padding fill
+  float w[SAL_MAXE];    // sum_r [label >= r] * vmask / (cnt_r + 1e-6)
+  float mx, T;          // row max, sum exp + 1e-6
+  int amax;
+  float rank;           // sum_r -(S_r / (cnt_r + 1e-6)) over stages with positives
+  float wsum;
+};
+
+__device__ __forceinline__ void sal_row_stats(const float* sp, const float* sn, const double* lab,
+                                              const uint8_t* vm, int L, int lane, SalRow& R) {
+  const int n2 = 2 * L;
+  float cnt[SAL_STAGES];
+#pragma unroll
+  for (int r = 0; r < SAL_STAGES; ++r) cnt[r] = 0.0f;
+  float mx = -INFINITY;
+  int amax = 0x7fffffff;
+  int stage_of[SAL_MAXE];  // number of stages r (1..11) with label >= r, for this element
+#pragma unroll
+  for (int e = 0; e < SAL_MAXE; ++e) {
+    const int j = e * 64 + lane;
+    float x = -INFINITY;
+    int st = 0;
+    if (j < n2) {
+      const int l = j < L ? j : j - L;
+      const float v = vm[l] ? 1.0f : 0.0f;
+      const float s = j < L ? sp[l] : sn[l];
+      x = (v * s + (1.0f - v) * -1e3f) / 0.5f;
+      const double lb = j < L ? lab[l] : 0.0;
+#pragma unroll
+      for (int r = 0; r < SAL_STAGES; ++r)
+        if (lb >= (double)(r + 1)) { cnt[r] += 1.0f; st = r + 1; }
+      if (x > mx) { mx = x; amax = j; }
+    }
+    R.x[e] = x;
+    stage_of[e] = st;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float m2 = __shfl_xor(mx, o, 64);
+    int a2 = __shfl_xor(amax, o, 64);
+    if (m2 > mx || (m2 == mx && a2 < amax)) { mx = m2; amax = a2; }
+  }
+  float inv[SAL_STAGES];
+#pragma unroll
+  for (int r = 0; r < SAL_STAGES; ++r) {
+    cnt[r] = wave_sum(cnt[r]);
+    inv[r] = cnt[r] > 0.0f ? 1.0f / (cnt[r] + 1e-6f) : 0.0f;
+  }
+  float se = 0.0f;
+#pragma unroll
+  for (int e = 0; e < SAL_MAXE; ++e) {
+    const int j = e * 64 + lane;
+    if (j < n2) se += __expf(R.x[e] - mx);
+  }
+  const float T = wave_sum(se) + 1e-6f;
+  const float logT = __logf(T);
+  float rank = 0.0f, wsum = 0.0f;
+#pragma unroll
+  for (int e = 0; e < SAL_MAXE; ++e) {
+    const int j = e * 64 + lane;
+    float w = 0.0f;
+    if (j < n2) {
+      const int l = j < L ? j : j - L;
+      const float v = vm[l] ? 1.0f : 0.0f;
+      // labels are monotone in r: element is positive for stages 1..stage_of
+#pragma unroll
+      for (int r = 0; r < SAL_STAGES; ++r)
+        if (r < stage_of[e]) w += inv[r];
+      w *= v;
+      const float lp = (R.x[e] - mx) - logT;
+      rank -= w * lp;
+      wsum += w;
+    }
+    R.w[e] = w;
+  }
+  R.mx = mx; R.T = T; R.amax = amax;
+  R.rank = wave_sum(rank);
+  R.wsum = wave_sum(wsum);
+}
+
+__global__ __launch_bounds__(256) void saliency_fwd_kernel(
+    const float* __restrict__ s_pos, const float* __restrict__ s_neg,
+    const double* __restrict__ label, const uint8_t* __restrict__ vmask,
+    const int64_t* __restrict__ pos_idx, const int64_t* __restrict__ neg_idx, int N, int L, int P,
+    float rank_coef, float margin, float* __restrict__ out_loss) {
+  __shared__ float part[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc = 0.0f;  // lane 0 of each wave accumulates its rows
+  for (int n = wave; n < N; n += 4) {
+    const float* sp = s_pos + (int64_t)n * L;
+    const float* sn = s_neg + (int64_t)n * L;
+    const uint8_t* vm = vmask + (int64_t)n * L;
+    SalRow R;
+    sal_row_stats(sp, sn, label + (int64_t)n * L, vm, L, lane, R);
+    // neg-pair term: sum_l -log(1 - sigmoid(s_neg)) * vmask
+    float np = 0.0f;
+    for (int l = lane; l < L; l += 64) {
+      float sg = 1.0f / (1.0f + __expf(-sn[l]));
+      np += -__logf(1.0f - sg) * (vm[l] ? 1.0f : 0.0f);
+    }
+    np = wave_sum(np);
+    float trip = 0.0f;
+    if (pos_idx && lane < P) {
+      float ps = sp[pos_idx[(int64_t)n * P + lane]];
+      float ns = sp[neg_idx[(int64_t)n * P + lane]];
+      float t = margin + ns - ps;
+      trip = t > 0.0f ? t : 0.0f;
+    }
+    trip = wave_sum(trip);
+    acc += R.rank / ((float)N * rank_coef) + np / (float)N;
+    if (pos_idx) acc += trip / (float)(N * P) * 2.0f;
+  }
+  if (lane == 0) part[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) *out_loss = part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ __launch_bounds__(256) void saliency_bwd_kernel(
+    const float* __restrict__ s_pos, const float* __restrict__ s_neg,
+    const double* __restrict__ label, const uint8_t* __restrict__ vmask,
+    const int64_t* __restrict__ pos_idx, const int64_t* __restrict__ neg_idx, int N, int L, int P,
+    float rank_coef, float margin, const float* __restrict__ gscale, float* __restrict__ ds_pos,
+    float* __restrict__ ds_neg) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const float gs = *gscale;
+  const float* sp = s_pos + (int64_t)n * L;
+  const float* sn = s_neg + (int64_t)n * L;
+  const uint8_t* vm = vmask + (int64_t)n * L;
+  SalRow R;
+  sal_row_stats(sp, sn, label + (int64_t)n * L, vm, L, lane, R);
+  const float k_rank = 1.0f / ((float)N * rank_coef);
+  const float eps_over_T = 1e-6f / R.T;
+#pragma unroll
+  for (int e = 0; e < SAL_MAXE; ++e) {
+    const int j = e * 64 + lane;
+    if (j < 2 * L) {
+      const int l = j < L ? j : j - L;
+      const float v = vm[l] ? 1.0f : 0.0f;
+      const float q = __expf(R.x[e] - R.mx) / R.T;
+      // d rank_row / d x_j = -(w_j - wsum * (q_j + [j == argmax] * eps/T))
+      float dx = -(R.w[e] - R.wsum * (q + (j == R.amax ? eps_over_T : 0.0f)));
+      float g = k_rank * dx * (1.0f / 0.5f) * v;  // x = (v*s + (1-v)*-1e3) / tau
+      if (j >= L) {
+        float sg = 1.0f / (1.0f + __expf(-sn[l]));
+        g += v * sg / (float)N;  // d/ds [-log(1 - sigmoid(s))] = sigmoid(s)
+        ds_neg[(int64_t)n * L + l] = gs * g;
+      } else {
+        if (pos_idx) {
+          const float kt = 2.0f / (float)(N * P);
+          for (int c = 0; c < P; ++c) {
+            const int64_t pi = pos_idx[(int64_t)n * P + c], ni = neg_idx[(int64_t)n * P + c];
+            const float t = margin + sp[ni] - sp[pi];
+            if (t >= 0.0f) {
+              if (ni == l) g += kt;
+              if (pi == l) g -= kt;
+            }
+          }
+        }
+        ds_pos[(int64_t)n * L + l] = gs * g;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- matcher
+// matcher.py:60-117.  One thread per pair: fp32 cost exactly as the reference builds it,
+// then the O(T^2 Q) shortest-augmenting-path assignment in fp64 (what scipy's
+// linear_sum_assignment computes), rows = targets, columns = queries.
+constexpr int MQ = 32;  // max queries
+constexpr int MT = 16;  // max targets per pair
+
+__global__ __launch_bounds__(64) void match_kernel(
+    const float* __restrict__ logits, const float* __restrict__ spans,
+    const float* __restrict__ tgt_cxw, const float* __restrict__ tgt_xx,
+    const int32_t* __restrict__ tgt_off, int N, int Q, int Tmax, float w_span, float w_giou,
+    float w_class, float* __restrict__ cost_out, int32_t* __restrict__ match_q) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= N) return;
+  const int t0 = tgt_off[b];
+  const int T = tgt_off[b + 1] - t0;
+  double cost[MT][MQ];
+  for (int q = 0; q < Q; ++q) {
+    const float l0 = logits[((int64_t)b * Q + q) * 2], l1 = logits[((int64_t)b * Q + q) * 2 + 1];
+    const float mx = fmaxf(l0, l1);
+    const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
+    const float prob0 = e0 / (e0 + e1);
+    const float cx = spans[((int64_t)b * Q + q) * 2], w = spans[((int64_t)b * Q + q) * 2 + 1];
+    const float x1 = cx - 0.5f * w, x2 = cx + 0.5f * w;
+    for (int t = 0; t < T; ++t) {
+      const float tc = tgt_cxw[(int64_t)(t0 + t) * 2], tw = tgt_cxw[(int64_t)(t0 + t) * 2 + 1];
+      const float g1 = tgt_xx[(int64_t)(t0 + t) * 2], g2 = tgt_xx[(int64_t)(t0 + t) * 2 + 1];
+      const float c_span = fabsf(cx - tc) + fabsf(w - tw);
+      const float a1 = x2 - x1, a2 = g2 - g1;
+      const float inter = fmaxf(fminf(x2, g2) - fmaxf(x1, g1), 0.0f);
+      const float uni = a1 + a2 - inter;
+      const float iou = inter / uni;
+      const float enc = fmaxf(fmaxf(x2, g2) - fminf(x1, g1), 0.0f);
+      const float giou = iou - (enc - uni) / enc;
+      const float c = w_span * c_span + w_giou * (-giou) + w_class * (-prob0);
+      cost[t][q] = (double)c;
+      if (cost_out) cost_out[((int64_t)b * Q + q) * Tmax + t] = c;
+    }
+  }
+  // shortest augmenting paths (rows = targets 1..T, cols = queries 1..Q), T <= Q
+  double u[MT + 1], v[MQ + 1], minv[MQ + 1];
+  int p[MQ + 1], way[MQ + 1];
+  bool used[MQ + 1];
+  for (int i = 0; i <= T; ++i) u[i] = 0.0;
+  for (int j = 0; j <= Q; ++j) { v[j] = 0.0; p[j] = 0; way[j] = 0; }
+  for (int i = 1; i <= T; ++i) {
+    p[0] = i;
+    int j0 = 0;
+    for (int j = 0; j <= Q; ++j) { minv[j] = 1e300; used[j] = false; }
+    do {
+      used[j0] = true;
+      const int i0 = p[j0];
+      double delta = 1e300;
+      int j1 = 0;
+      for (int j = 1; j <= Q; ++j) {
+        if (!used[j]) {
+          const double cur = cost[i0 - 1][j - 1] - u[i0] - v[j];
+          if (cur < minv[j]) { minv[j] = cur; way[j] = j0; }
+          if (minv[j] < delta) { delta = minv[j]; j1 = j; }
+        }
+      }
+      for (int j = 0; j <= Q; ++j) {
+        if (used[j]) { u[p[j]] += delta; v[j] -= delta; }
+        else minv[j] -= delta;
+      }
+      j0 = j1;
+    } while (p[j0] != 0);
+    do {
+      const int j1 = way[j0];
+      p[j0] = p[j1];
+      j0 = j1;
+    } while (j0);
+  }
+  for (int j = 1; j <= Q; ++j)
+    if (p[j] != 0) match_q[t0 + p[j] - 1] = j - 1;
+}
+
+}  // namespace
+
+extern "C" int mesm_nll_smooth_fwd(const float* logit, const int64_t* label, const uint8_t* mask,
+                                   float* row_loss, float* row_lse, uint8_t* correct, int64_t R,
+                                   int32_t C, float eps, void* stream) {
+  if (!logit || !label || !row_loss || !row_lse || R <= 0 || C <= 0) return MESM_EINVAL;
+  hipLaunchKernelGGL(nll_fwd_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, logit,
+                     label, mask, row_loss, row_lse, correct, C, eps);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_nll_smooth_bwd(const float* logit, const int64_t* label, const float* row_lse,
+                                   const float* row_grad, float* dlogit, int64_t R, int32_t C,
+                                   float eps, void* stream) {
+  if (!logit || !label || !row_lse || !row_grad || !dlogit || R <= 0 || C <= 0) return MESM_EINVAL;
+  int gy = (C + 1023) / 1024;
+  if (gy < 1) gy = 1;
+  hipLaunchKernelGGL(nll_bwd_kernel, dim3((unsigned)R, gy), dim3(256), 0, (hipStream_t)stream,
+                     logit, label, row_lse, row_grad, dlogit, C, eps);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_saliency_loss_fwd(const float* s_pos, const float* s_neg, const double* label,
+                                      const uint8_t* vmask, const int64_t* pos_idx,
+                                      const int64_t* neg_idx, int32_t N, int32_t L, int32_t P,
+                                      float rank_coef, float margin, float* out_loss,
+                                      void* stream) {
+  if (!s_pos || !s_neg || !label || !vmask || !out_loss || N <= 0 || L <= 0) return MESM_EINVAL;
+  if (2 * L > 64 * SAL_MAXE) return MESM_EINVAL;
+  if ((pos_idx == nullptr) != (neg_idx == nullptr)) return MESM_EINVAL;
+  if (pos_idx && (P <= 0 || P > 64)) return MESM_EINVAL;
+  hipLaunchKernelGGL(saliency_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, s_pos, s_neg,
+                     label, vmask, pos_idx, neg_idx, N, L, P, rank_coef, margin, out_loss);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_saliency_loss_bwd(const float* s_pos, const float* s_neg, const double* label,
+                                      const uint8_t* vmask, const int64_t* pos_idx,
+                                      const int64_t* neg_idx, int32_t N, int32_t L, int32_t P,
+                                      float rank_coef, float margin, const float* gscale,
+                                      float* ds_pos, float* ds_neg, void* stream) {
+  if (!s_pos || !s_neg || !label || !vmask || !gscale || !ds_pos || !ds_neg || N <= 0 || L <= 0)
+    return MESM_EINVAL;
+  if (2 * L > 64 * SAL_MAXE) return MESM_EINVAL;
+  if ((pos_idx == nullptr) != (neg_idx == nullptr)) return MESM_EINVAL;
+  if (pos_idx && (P <= 0 || P > 64)) return MESM_EINVAL;
+  hipLaunchKernelGGL(saliency_bwd_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                     s_pos, s_neg, label, vmask, pos_idx, neg_idx, N, L, P, rank_coef, margin,
+                     gscale, ds_pos, ds_neg);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_match(const float* logits, const float* spans, const float* tgt_cxw,
+                          const float* tgt_xx, const int32_t* tgt_off, int32_t N, int32_t Q,
+                          int32_t Tmax, float w_span, float w_giou, float w_class, float* cost,
+                          int32_t* match_q, void* stream) {
+  if (!logits || !spans || !tgt_cxw || !tgt_xx || !tgt_off || !match_q) return MESM_EINVAL;
+  if (N <= 0 || Q <= 0 || Q > MQ || Tmax <= 0 || Tmax > MT || Tmax > Q) return MESM_EINVAL;
+  hipLaunchKernelGGL(match_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, logits,
+                     spans, tgt_cxw, tgt_xx, tgt_off, N, Q, Tmax, w_span, w_giou, w_class, cost,
+                     match_q);
+  return mesm_launch_status();
+}

@@ -1,0 +1,307 @@
+"""Tensor-level wrappers over the C-ABI (no autograd here; see ops.py).
+
+Every function launches on torch's current HIP stream and returns immediately.
+Tensors must live on the GPU, be fp32 and (unless stated) contiguous.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_NONE, ACT_PRELU, ACT_RELU, LAYOUT_OUTER_CONTIG,
+                   LAYOUT_REDUCE_CONTIG, MASK_KPAD, MASK_T2V_QUIRK, AttnArgs, GemmArgs,
+                   check, lib, ptr, require_gpu, stream_ptr)
+
+__all__ = [
+    "gemm", "layernorm_fwd", "layernorm_bwd", "attn_fwd", "attn_bwd", "sine_pos",
+    "query_sine_fwd", "query_sine_bwd", "dropout", "act_bias_bwd",
+    "ACT_NONE", "ACT_RELU", "ACT_PRELU",
+]
+
+
+def _mat(t):
+    """(rows, cols, ld, layout_if_reduce_is_cols) view info of a 2-D tensor with one unit stride."""
+    assert t.dim() == 2
+    r, c = t.shape
+    s0, s1 = t.stride()
+    return r, c, s0, s1
+
+
+def gemm(A, B, C, *, trans_a=False, trans_b=False, A2=None, bias=None, residual=None,
+         aux=None, slope=None, dslope=None, colsum=None, a_act=ACT_NONE, b_act=ACT_NONE,
+         a_drop=(0.0, 0), b_drop=(0.0, 0), e_act=ACT_NONE, e_actgrad=ACT_NONE,
+         e_drop=(0.0, 0), out_scale=1.0, accumulate=0, split_k=1):
+    """C[M,N] (+)= epi( op(A) @ op(B) ).
+
+    A is (M,K) (or (K,M) with trans_a), B is (K,N) (or (N,K) with trans_b); both are
+    2-D views whose last stride is 1.  C is (M,N) with unit column stride.
+    """
+    require_gpu(A, B, C)
+    assert A.dtype == B.dtype == C.dtype == torch.float32
+    assert A.dim() == 2 and B.dim() == 2 and C.dim() == 2
+    assert A.stride(1) == 1 and B.stride(1) == 1 and C.stride(1) == 1
+    if trans_a:
+        K, M = A.shape
+        a_layout = LAYOUT_OUTER_CONTIG  # element (m, k) at k*ld + m
+    else:
+        M, K = A.shape
+        a_layout = LAYOUT_REDUCE_CONTIG
+    if trans_b:
+        N, Kb = B.shape
+        b_layout = LAYOUT_REDUCE_CONTIG  # element (n, k) at n*ld + k
+    else:
+        Kb, N = B.shape
+        b_layout = LAYOUT_OUTER_CONTIG
+    assert K == Kb, (A.shape, B.shape, trans_a, trans_b)
+    assert C.shape == (M, N), (C.shape, M, N)
+    g = GemmArgs()
+    g.A, g.B, g.C = A.data_ptr(), B.data_ptr(), C.data_ptr()
+    if A2 is not None:
+        assert A2.shape == A.shape and A2.stride() == A.stride()
+        g.A2 = A2.data_ptr()
+    g.M, g.N, g.K = M, N, K
+    g.a_layout, g.b_layout = a_layout, b_layout
+    g.lda, g.ldb, g.ldc = A.stride(0), B.stride(0), C.stride(0)
+    if bias is not None:
+        assert bias.numel() == N and bias.is_contiguous()
+        g.bias = bias.data_ptr()
+    if residual is not None:
+        assert residual.shape == (M, N) and residual.stride(1) == 1
+        g.residual, g.ldr = residual.data_ptr(), residual.stride(0)
+    if aux is not None:
+        assert aux.shape == (M, N) and aux.stride(1) == 1
+        g.aux, g.ldaux = aux.data_ptr(), aux.stride(0)
+    if slope is not None:
+        g.slope = slope.data_ptr()
+    if dslope is not None:
+        g.dslope = dslope.data_ptr()
+    if colsum is not None:
+        assert colsum.numel() == M
+        g.colsum = colsum.data_ptr()
+    g.a_act, g.b_act = a_act, b_act
+    g.a_drop_p, g.a_drop_seed = float(a_drop[0]), int(a_drop[1]) & 0xFFFFFFFF
+    g.b_drop_p, g.b_drop_seed = float(b_drop[0]), int(b_drop[1]) & 0xFFFFFFFF
+    g.e_act, g.e_actgrad = e_act, e_actgrad
+    g.e_drop_p, g.e_drop_seed = float(e_drop[0]), int(e_drop[1]) & 0xFFFFFFFF
+    g.out_scale = float(out_scale)
+    g.accumulate, g.split_k = int(accumulate), int(split_k)
+    check(lib().mesm_gemm_f32(ctypes.byref(g), stream_ptr()), "mesm_gemm_f32")
+    return C
+
+
+def layernorm_fwd(x, gamma, beta, eps=1e-5):
+    require_gpu(x, gamma, beta)
+    D = x.shape[-1]
+    x2 = x.reshape(-1, D)
+    assert x2.is_contiguous()
+    rows = x2.shape[0]
+    y = torch.empty_like(x2)
+    mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    check(lib().mesm_layernorm_fwd(ptr(x2), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd),
+                                   rows, D, eps, stream_ptr()), "mesm_layernorm_fwd")
+    return y.view(x.shape), mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx=None, accumulate_dx=False):
+    """dgamma/dbeta are ACCUMULATED into (flat-gradient views)."""
+    require_gpu(dy, x, gamma)
+    D = x.shape[-1]
+    x2 = x.reshape(-1, D)
+    dy2 = dy.reshape(-1, D)
+    assert x2.is_contiguous() and dy2.is_contiguous()
+    if dx is None:
+        assert not accumulate_dx
+        dx = torch.empty_like(x2)
+    dx2 = dx.view(-1, D)
+    check(lib().mesm_layernorm_bwd(ptr(dy2), ptr(x2), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx2),
+                                   ptr(dgamma), ptr(dbeta), x2.shape[0], D,
+                                   1 if accumulate_dx else 0, stream_ptr()),
+          "mesm_layernorm_bwd")
+    return dx2.view(x.shape)
+
+
+def _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop):
+    B, Lq, Eq = q.shape
+    _, Lk, Ek = k.shape
+    Ev = v.shape[2]
+    assert Eq == Ek and Eq % H == 0 and Ev % H == 0
+    for t in (q, k, v, o):
+        assert t.dtype == torch.float32 and t.stride(2) == 1
+    a = AttnArgs()
+    a.q, a.k, a.v, a.o = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr()
+    a.lse = lse.data_ptr() if lse is not None else None
+    a.B, a.H, a.Lq, a.Lk, a.dk, a.dv = B, H, Lq, Lk, Eq // H, Ev // H
+    a.q_bs, a.q_ls = q.stride(0), q.stride(1)
+    a.k_bs, a.k_ls = k.stride(0), k.stride(1)
+    a.v_bs, a.v_ls = v.stride(0), v.stride(1)
+    a.o_bs, a.o_ls = o.stride(0), o.stride(1)
+    if kpad is not None:
+        assert kpad.dtype in (torch.uint8, torch.bool) and kpad.shape == (B, Lk) and kpad.is_contiguous()
+        a.kpad = kpad.data_ptr()
+    if qpad is not None:
+        assert qpad.dtype in (torch.uint8, torch.bool) and qpad.shape == (B, Lq) and qpad.is_contiguous()
+        a.qpad = qpad.data_ptr()
+        a.mask_mode = MASK_T2V_QUIRK
+    else:
+        a.mask_mode = MASK_KPAD
+    a.scale = float(scale)
+    a.drop_p, a.drop_seed = float(drop[0]), int(drop[1]) & 0xFFFFFFFF
+    return a
+
+
+def attn_fwd(q, k, v, H, kpad=None, qpad=None, scale=None, drop=(0.0, 0)):
+    """q (B,Lq,H*dk), k (B,Lk,H*dk), v (B,Lk,H*dv) -> o (B,Lq,H*dv), lse (B,H,Lq)."""
+    require_gpu(q, k, v)
+    B, Lq, Eq = q.shape
+    if scale is None:
+        scale = (Eq // H) ** -0.5
+    o = torch.empty(B, Lq, v.shape[2], device=q.device, dtype=torch.float32)
+    lse = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32)
+    a = _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop)
+    check(lib().mesm_attn_fwd(ctypes.byref(a), stream_ptr()), "mesm_attn_fwd")
+    return o, lse
+
+
+def attn_bwd(do, q, k, v, o, lse, H, kpad=None, qpad=None, scale=None, drop=(0.0, 0)):
+    require_gpu(do, q, k, v, o, lse)
+    B, Lq, Eq = q.shape
+    if scale is None:
+        scale = (Eq // H) ** -0.5
+    do = do.contiguous() if do.stride() != o.stride() else do
+    assert do.stride() == o.stride()
+    # dq is accumulated atomically when there are several key tiles -> start from zero
+    dq = torch.zeros(q.shape, device=q.device, dtype=torch.float32)
+    dk = torch.empty(k.shape, device=q.device, dtype=torch.float32)
+    dv = torch.empty(v.shape, device=q.device, dtype=torch.float32)
+    qc, kc, vc = q, k, v
+    # gradients are written with the strides of q/k/v: require the packed layout
+    assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
+    a = _attn_args(qc, kc, vc, o, lse, H, kpad, qpad, scale, drop)
+    a.d_o, a.dq, a.dk_, a.dv_ = do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    check(lib().mesm_attn_bwd(ctypes.byref(a), stream_ptr()), "mesm_attn_bwd")
+    return dq, dk, dv
+
+
+def sine_pos(mask, D):
+    """mask (B, L) bool/uint8, True = valid -> (B, L, D) fp32."""
+    require_gpu(mask)
+    B, L = mask.shape
+    m = mask.contiguous()
+    out = torch.empty(B, L, D, device=mask.device, dtype=torch.float32)
+    check(lib().mesm_sine_pos_fwd(ptr(m), ptr(out), B, L, D, stream_ptr()), "mesm_sine_pos_fwd")
+    return out
+
+
+def query_sine_fwd(ref, D):
+    """ref (..., 2) -> (..., D)."""
+    require_gpu(ref)
+    r2 = ref.reshape(-1, 2).contiguous()
+    out = torch.empty(r2.shape[0], D, device=ref.device, dtype=torch.float32)
+    check(lib().mesm_query_sine_fwd(ptr(r2), ptr(out), r2.shape[0], D, stream_ptr()),
+          "mesm_query_sine_fwd")
+    return out.view(*ref.shape[:-1], D)
+
+
+def query_sine_bwd(ref, dout):
+    require_gpu(ref, dout)
+    D = dout.shape[-1]
+    r2 = ref.reshape(-1, 2).contiguous()
+    d2 = dout.reshape(-1, D).contiguous()
+    dref = torch.zeros_like(r2)
+    check(lib().mesm_query_sine_bwd(ptr(r2), ptr(d2), ptr(dref), r2.shape[0], D, stream_ptr()),
+          "mesm_query_sine_bwd")
+    return dref.view(ref.shape)
+
+
+def dropout(x, p, seed, out=None):
+    require_gpu(x)
+    assert x.is_contiguous()
+    y = torch.empty_like(x) if out is None else out
+    check(lib().mesm_dropout(ptr(x), ptr(y), x.numel(), float(p), int(seed) & 0xFFFFFFFF,
+                             stream_ptr()), "mesm_dropout")
+    return y
+
+
+def act_bias_bwd(dy, ref, act, dbias=None, slope=None, dslope=None, inplace=False):
+    """dz = dy * act'(ref); dbias += colsum(dz); returns dz (dy itself if inplace)."""
+    require_gpu(dy)
+    cols = dy.shape[-1]
+    dy2 = dy.reshape(-1, cols)
+    assert dy2.is_contiguous()
+    ref2 = ref.reshape(-1, cols) if ref is not None else None
+    if act == ACT_NONE:
+        dz = None
+    else:
+        dz = dy2 if inplace else torch.empty_like(dy2)
+    check(lib().mesm_act_bias_bwd(ptr(dy2), ptr(ref2), ptr(dz), ptr(dbias), ptr(slope),
+                                  ptr(dslope), dy2.shape[0], cols, act, stream_ptr()),
+          "mesm_act_bias_bwd")
+    return (dz if dz is not None else dy2).view(dy.shape)
+
+
+# ----------------------------------------------------------------------------- losses
+def nll_smooth_fwd(logit, label, mask, eps=0.1):
+    """logit (R, C), label (R,) int64, mask (R,) bool -> row_loss (R), row_lse (R), correct (R) uint8."""
+    require_gpu(logit, label, mask)
+    R, C = logit.shape
+    assert logit.is_contiguous() and label.dtype == torch.int64 and label.is_contiguous()
+    m = mask.contiguous() if mask is not None else None
+    row_loss = torch.empty(R, device=logit.device, dtype=torch.float32)
+    row_lse = torch.empty(R, device=logit.device, dtype=torch.float32)
+    correct = torch.empty(R, device=logit.device, dtype=torch.uint8)
+    check(lib().mesm_nll_smooth_fwd(ptr(logit), ptr(label), ptr(m), ptr(row_loss), ptr(row_lse),
+                                    ptr(correct), R, C, float(eps), stream_ptr()),
+          "mesm_nll_smooth_fwd")
+    return row_loss, row_lse, correct
+
+
+def nll_smooth_bwd(logit, label, row_lse, row_grad, eps=0.1):
+    require_gpu(logit, label, row_lse, row_grad)
+    R, C = logit.shape
+    dlogit = torch.empty_like(logit)
+    check(lib().mesm_nll_smooth_bwd(ptr(logit), ptr(label), ptr(row_lse), ptr(row_grad.contiguous()),
+                                    ptr(dlogit), R, C, float(eps), stream_ptr()),
+          "mesm_nll_smooth_bwd")
+    return dlogit
+
+
+def saliency_loss_fwd(s_pos, s_neg, label64, vmask, pos_idx, neg_idx, rank_coef, margin):
+    require_gpu(s_pos, s_neg, label64, vmask)
+    N, L = s_pos.shape
+    assert label64.dtype == torch.float64 and label64.is_contiguous()
+    assert s_pos.is_contiguous() and s_neg.is_contiguous() and vmask.is_contiguous()
+    P = pos_idx.shape[1] if pos_idx is not None else 0
+    out = torch.empty(1, device=s_pos.device, dtype=torch.float32)
+    check(lib().mesm_saliency_loss_fwd(ptr(s_pos), ptr(s_neg), ptr(label64), ptr(vmask),
+                                       ptr(pos_idx), ptr(neg_idx), N, L, P, float(rank_coef),
+                                       float(margin), ptr(out), stream_ptr()),
+          "mesm_saliency_loss_fwd")
+    return out
+
+
+def saliency_loss_bwd(s_pos, s_neg, label64, vmask, pos_idx, neg_idx, rank_coef, margin, gscale):
+    N, L = s_pos.shape
+    P = pos_idx.shape[1] if pos_idx is not None else 0
+    ds_pos = torch.empty_like(s_pos)
+    ds_neg = torch.empty_like(s_neg)
+    check(lib().mesm_saliency_loss_bwd(ptr(s_pos), ptr(s_neg), ptr(label64), ptr(vmask),
+                                       ptr(pos_idx), ptr(neg_idx), N, L, P, float(rank_coef),
+                                       float(margin), ptr(gscale), ptr(ds_pos), ptr(ds_neg),
+                                       stream_ptr()), "mesm_saliency_loss_bwd")
+    return ds_pos, ds_neg
+
+
+def match(logits, spans, tgt_cxw, tgt_xx, tgt_off, Tmax, w_span, w_giou, w_class, want_cost=False):
+    """logits (N,Q,2), spans (N,Q,2), targets (sumT,2) x2, tgt_off (N+1) int32 ->
+    match_q (sumT) int32 [, cost (N,Q,Tmax)]."""
+    require_gpu(logits, spans, tgt_cxw, tgt_xx, tgt_off)
+    N, Q, _ = logits.shape
+    assert tgt_off.dtype == torch.int32
+    match_q = torch.empty(tgt_cxw.shape[0], device=logits.device, dtype=torch.int32)
+    cost = torch.zeros(N, Q, Tmax, device=logits.device, dtype=torch.float32) if want_cost else None
+    check(lib().mesm_match(ptr(logits.contiguous()), ptr(spans.contiguous()), ptr(tgt_cxw.contiguous()),
+                           ptr(tgt_xx.contiguous()), ptr(tgt_off), N, Q, int(Tmax), float(w_span),
+                           float(w_giou), float(w_class), ptr(cost), ptr(match_q), stream_ptr()),
+          "mesm_match")
+    return (match_q, cost) if want_cost else match_q

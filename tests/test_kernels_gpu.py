@@ -1,0 +1,463 @@
+"""Per-kernel numerics on the MI355X: each HIP kernel against a plain PyTorch reference
+(fp64 on the same device where a floating-point reference is needed).
+
+Tolerance for fp32 kernels: 1e-4 relative to the output scale (the north-star budget).
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel_err(a, b):
+    a = a.double()
+    b = b.double()
+    scale = max(b.abs().max().item(), 1e-6)
+    return (a - b).abs().max().item() / scale
+
+
+def gen(shape, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev())
+
+
+# --------------------------------------------------------------------------- GEMM
+GEMM_SHAPES = [(2400, 256, 256), (75, 33, 17), (320, 1024, 256), (300, 256, 2818),
+               (130, 70, 50), (256, 256, 2400), (64, 64, 16), (1, 5, 3), (1024, 5003, 256)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
+def test_gemm_plain(M, N, K, ta, tb):
+    from mesm_amd import kernels as kn
+    A = gen((K, M) if ta else (M, K), 1)
+    B = gen((N, K) if tb else (K, N), 2)
+    C = torch.full((M, N), float("nan"), device=dev())
+    kn.gemm(A, B, C, trans_a=ta, trans_b=tb)
+    ref = (A.t() if ta else A).double() @ (B.t() if tb else B).double()
+    assert rel_err(C, ref) < TOL
+
+
+def test_gemm_strided_views_and_bias_residual():
+    from mesm_amd import kernels as kn
+    M, N, K = 150, 96, 256
+    Wfull = gen((3 * N, K), 3)
+    W = Wfull[N:2 * N]  # a row slice of in_proj_weight
+    X = gen((M, K), 4)
+    X2 = gen((M, K), 5)
+    bias = gen((N,), 6)
+    res = gen((M, N), 7)
+    Cbig = torch.zeros(M, 2 * N, device=dev())
+    C = Cbig[:, N:]  # strided output
+    kn.gemm(X, W, C, trans_b=True, A2=X2, bias=bias, residual=res, out_scale=0.5)
+    ref = ((X + X2).double() @ W.t().double()) * 0.5 + bias.double() + res.double()
+    assert rel_err(C, ref) < TOL
+    assert Cbig[:, :N].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("split", [2, 4, 16])
+def test_gemm_split_k_and_accumulate(split):
+    from mesm_amd import kernels as kn
+    M, N, K = 256, 300, 2400
+    A = gen((K, M), 8)
+    B = gen((K, N), 9)
+    base = gen((M, N), 10)
+    C = base.clone()
+    bias = gen((N,), 11)
+    kn.gemm(A, B, C, trans_a=True, split_k=split, bias=bias)
+    ref = A.t().double() @ B.double() + base.double() + bias.double()
+    assert rel_err(C, ref) < TOL
+    C2 = base.clone()
+    kn.gemm(A, B, C2, trans_a=True, accumulate=1)
+    assert rel_err(C2, A.t().double() @ B.double() + base.double()) < TOL
+
+
+def test_gemm_activations_and_grad_epilogue():
+    from mesm_amd import kernels as kn
+    M, N, K = 200, 160, 96
+    X = gen((M, K), 12)
+    W = gen((N, K), 13)
+    b = gen((N,), 14)
+    slope = torch.tensor([0.25], device=dev())
+    z_ref = X.double() @ W.t().double() + b.double()
+    C = torch.empty(M, N, device=dev())
+    kn.gemm(X, W, C, trans_b=True, bias=b, e_act=kn.ACT_RELU)
+    assert rel_err(C, z_ref.clamp(min=0)) < TOL
+    kn.gemm(X, W, C, trans_b=True, bias=b, e_act=kn.ACT_PRELU, slope=slope)
+    assert rel_err(C, torch.where(z_ref > 0, z_ref, 0.25 * z_ref)) < TOL
+    # prologue PReLU on A:  prelu(Z) @ W2^T
+    Z = gen((M, N), 15)
+    W2 = gen((K, N), 16)
+    C2 = torch.empty(M, K, device=dev())
+    kn.gemm(Z, W2, C2, trans_b=True, a_act=kn.ACT_PRELU, slope=slope)
+    H = torch.where(Z > 0, Z, 0.25 * Z).double()
+    assert rel_err(C2, H @ W2.t().double()) < TOL
+    # same on B (dW2 = dY^T @ prelu(Z))
+    dY = gen((M, K), 17)
+    dW = torch.empty(K, N, device=dev())
+    colsum = torch.zeros(K, device=dev())
+    kn.gemm(dY, Z, dW, trans_a=True, b_act=kn.ACT_PRELU, slope=slope, colsum=colsum)
+    assert rel_err(dW, dY.t().double() @ H) < TOL
+    assert rel_err(colsum, dY.double().sum(0)) < TOL
+    # backward epilogue: dZ = (dY @ W2) * prelu'(Z), dslope = sum(dH * min(Z,0))
+    dZ = torch.empty(M, N, device=dev())
+    dslope = torch.zeros(1, device=dev())
+    kn.gemm(dY, W2, dZ, aux=Z, e_actgrad=kn.ACT_PRELU, slope=slope, dslope=dslope)
+    dH = dY.double() @ W2.double()
+    assert rel_err(dZ, torch.where(Z > 0, dH, 0.25 * dH)) < TOL
+    ds_ref = (dH * Z.double().clamp(max=0)).sum()
+    assert abs(dslope.item() - ds_ref.item()) / max(abs(ds_ref.item()), 1.0) < TOL
+    # relu grad epilogue uses the activation output
+    Y = Z.clamp(min=0)
+    kn.gemm(dY, W2, dZ, aux=Y, e_actgrad=kn.ACT_RELU)
+    assert rel_err(dZ, torch.where(Y > 0, dH, torch.zeros_like(dH))) < TOL
+
+
+def test_gemm_dropout_matches_materialised_mask():
+    from mesm_amd import kernels as kn
+    M, N, K = 190, 130, 300
+    X = gen((M, K), 18)
+    W = gen((N, K), 19)
+    Xd = kn.dropout(X, 0.5, 77)
+    keep = (Xd != 0).float().mean().item()
+    assert 0.45 < keep < 0.55
+    assert torch.allclose(Xd[Xd != 0], (X * 2.0)[Xd != 0])
+    C = torch.empty(M, N, device=dev())
+    kn.gemm(X, W, C, trans_b=True, a_drop=(0.5, 77))
+    assert rel_err(C, Xd.double() @ W.t().double()) < TOL
+    # operand B (dW = dY^T @ dropout(X)): same mask, logical index m*K + k
+    dY = gen((M, N), 20)
+    dW = torch.empty(N, K, device=dev())
+    kn.gemm(dY, X, dW, trans_a=True, b_drop=(0.5, 77))
+    assert rel_err(dW, dY.t().double() @ Xd.double()) < TOL
+    # epilogue dropout (dX = dropout_mask * (dY @ W))
+    dX = torch.empty(M, K, device=dev())
+    kn.gemm(dY, W, dX, e_drop=(0.5, 77))
+    full = (dY.double() @ W.double())
+    mask = (Xd != 0).double() * 2.0
+    assert rel_err(dX, full * mask) < TOL
+    # prelu + dropout on A together
+    slope = torch.tensor([0.1], device=dev())
+    Z = gen((M, K), 21)
+    Hd = kn.dropout(torch.where(Z > 0, Z, 0.1 * Z).contiguous(), 0.1, 5)
+    kn.gemm(Z, W, C, trans_b=True, a_act=kn.ACT_PRELU, slope=slope, a_drop=(0.1, 5))
+    assert rel_err(C, Hd.double() @ W.t().double()) < TOL
+
+
+# --------------------------------------------------------------------------- LayerNorm
+@pytest.mark.parametrize("rows,D", [(2400, 256), (7, 32), (1056, 512), (64, 300), (300, 2818),
+                                    (33, 4098), (5, 1024)])
+def test_layernorm(rows, D):
+    from mesm_amd import kernels as kn
+    x = gen((rows, D), 30, 2.0) + 0.5
+    g = gen((D,), 31) * 0.2 + 1.0
+    b = gen((D,), 32) * 0.1
+    y, mean, rstd = kn.layernorm_fwd(x, g, b)
+    xd = x.double().requires_grad_(True)
+    gd = g.double().requires_grad_(True)
+    bd = b.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xd, (D,), gd, bd, 1e-5)
+    assert rel_err(y, ref) < TOL
+    dy = gen((rows, D), 33)
+    ref.backward(dy.double())
+    dg = torch.zeros(D, device=dev())
+    db = torch.zeros(D, device=dev())
+    dx = kn.layernorm_bwd(dy, x, g, mean, rstd, dg, db)
+    assert rel_err(dx, xd.grad) < TOL
+    assert rel_err(dg, gd.grad) < TOL
+    assert rel_err(db, bd.grad) < TOL
+    # accumulate into an existing dx
+    base = gen((rows, D), 34)
+    dx2 = base.clone()
+    kn.layernorm_bwd(dy, x, g, mean, rstd, dg, db, dx=dx2, accumulate_dx=True)
+    assert rel_err(dx2, xd.grad + base.double()) < TOL
+
+
+# --------------------------------------------------------------------------- attention
+def attn_reference(q, k, v, H, kpad, qpad, scale, quirk_B=None):
+    """fp64 restatement of nn.MultiheadAttention's core incl. the reference's
+    .repeat(nhead,1,1) attn_mask (transformer.py:528-530)."""
+    B, Lq, E = q.shape
+    Lk = k.shape[1]
+    dk = E // H
+    dv = v.shape[2] // H
+    qh = q.double().view(B, Lq, H, dk).permute(0, 2, 1, 3).reshape(B * H, Lq, dk)
+    kh = k.double().view(B, Lk, H, dk).permute(0, 2, 1, 3).reshape(B * H, Lk, dk)
+    vh = v.double().view(B, Lk, H, dv).permute(0, 2, 1, 3).reshape(B * H, Lk, dv)
+    s = torch.bmm(qh * scale, kh.transpose(1, 2))
+    if qpad is not None:
+        am = torch.matmul(qpad.float().unsqueeze(2), kpad.float().unsqueeze(1)).bool().repeat(H, 1, 1)
+        s = s.masked_fill(am, float("-inf"))
+    if kpad is not None:
+        s = s.view(B, H, Lq, Lk).masked_fill(kpad.view(B, 1, 1, Lk), float("-inf")).view(B * H, Lq, Lk)
+    p = torch.softmax(s, dim=-1)
+    o = torch.bmm(p, vh).view(B, H, Lq, dv).permute(0, 2, 1, 3).reshape(B, Lq, H * dv)
+    return o, p
+
+
+def make_pad(B, L, seed, min_valid=1):
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(min_valid, L + 1, (B,), generator=g)
+    lens[0] = L
+    return (torch.arange(L)[None, :] >= lens[:, None]).to(dev())
+
+
+ATTN_CASES = [
+    # B, H, Lq, Lk, dk, dv, kpad, quirk
+    (32, 8, 75, 32, 32, 32, True, True),
+    (32, 8, 75, 33, 32, 32, True, True),
+    (4, 8, 76, 76, 32, 32, True, False),
+    (32, 8, 10, 75, 64, 32, True, False),
+    (32, 8, 10, 10, 32, 32, False, False),
+    (6, 4, 20, 12, 8, 8, True, True),
+    (3, 4, 7, 300, 8, 8, True, True),
+    (2, 8, 130, 513, 32, 32, True, False),
+    (5, 4, 9, 20, 16, 8, True, False),
+]
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,dk,dv,use_kpad,quirk", ATTN_CASES)
+def test_attention_fwd_bwd(B, H, Lq, Lk, dk, dv, use_kpad, quirk):
+    from mesm_amd import kernels as kn
+    q = gen((B, Lq, H * dk), 40)
+    k = gen((B, Lk, H * dk), 41)
+    v = gen((B, Lk, H * dv), 42)
+    kpad = make_pad(B, Lk, 43) if use_kpad else None
+    qpad = make_pad(B, Lq, 44) if quirk else None
+    scale = dk ** -0.5
+    o, lse = kn.attn_fwd(q, k, v, H, kpad=kpad, qpad=qpad, scale=scale)
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    ref, _ = attn_reference(qd, kd, vd, H, kpad, qpad, scale)
+    assert rel_err(o, ref) < TOL
+    do = gen((B, Lq, H * dv), 45)
+    ref.backward(do.double())
+    dq, dk_, dv_ = kn.attn_bwd(do, q, k, v, o, lse, H, kpad=kpad, qpad=qpad, scale=scale)
+    assert rel_err(dq, qd.grad) < TOL
+    assert rel_err(dk_, kd.grad) < TOL
+    assert rel_err(dv_, vd.grad) < TOL
+
+
+def test_attention_dropout_is_consistent_between_fwd_and_bwd():
+    from mesm_amd import kernels as kn
+    B, H, Lq, Lk, dk = 4, 8, 30, 90, 32
+    q = gen((B, Lq, H * dk), 50)
+    k = gen((B, Lk, H * dk), 51)
+    v = gen((B, Lk, H * dk), 52)
+    p, seed = 0.1, 1234
+    o, lse = kn.attn_fwd(q, k, v, H, drop=(p, seed))
+    # materialise the mask with the same counter hash: element index ((b*H+h)*Lq+i)*Lk+j
+    ones = torch.ones(B * H * Lq * Lk, device=dev())
+    mask = kn.dropout(ones, p, seed).view(B * H, Lq, Lk).double()
+    assert 0.85 < (mask != 0).double().mean().item() < 0.95
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    _, probs = attn_reference(qd, kd, vd, H, None, None, dk ** -0.5)
+    vh = vd.view(B, Lk, H, dk).permute(0, 2, 1, 3).reshape(B * H, Lk, dk)
+    ref = torch.bmm(probs * mask, vh).view(B, H, Lq, dk).permute(0, 2, 1, 3).reshape(B, Lq, H * dk)
+    assert rel_err(o, ref) < TOL
+    do = gen((B, Lq, H * dk), 53)
+    ref.backward(do.double())
+    dq, dk_, dv_ = kn.attn_bwd(do, q, k, v, o, lse, H, drop=(p, seed))
+    assert rel_err(dq, qd.grad) < TOL
+    assert rel_err(dk_, kd.grad) < TOL
+    assert rel_err(dv_, vd.grad) < TOL
+
+
+# --------------------------------------------------------------------------- position encodings
+def sine_pos_reference(mask, D):
+    # restatement of position_encoding.py:61-70 on the CPU in fp32
+    x = mask.cpu().cumsum(1, dtype=torch.float32)
+    x = x / (x[:, -1:] + 1e-6) * (2 * math.pi)
+    dim_t = torch.arange(D, dtype=torch.float32)
+    dim_t = 10000 ** (2 * torch.div(dim_t, 2, rounding_mode="trunc") / D)
+    pos = x[:, :, None] / dim_t
+    return torch.stack((pos[:, :, 0::2].sin(), pos[:, :, 1::2].cos()), dim=3).flatten(2)
+
+
+@pytest.mark.parametrize("B,L,D", [(32, 75, 256), (3, 600, 256), (4, 13, 32)])
+def test_sine_pos(B, L, D):
+    from mesm_amd import kernels as kn
+    mask = ~make_pad(B, L, 60)
+    out = kn.sine_pos(mask, D)
+    ref = sine_pos_reference(mask, D)
+    assert (out.cpu() - ref).abs().max().item() < 2e-5
+
+
+def query_sine_reference(ref_pts, D):
+    scale = 2 * math.pi
+    half = D // 2
+    dim_t = torch.arange(half, dtype=ref_pts.dtype, device=ref_pts.device)
+    dim_t = 10000 ** (2 * torch.div(dim_t, 2, rounding_mode="trunc") / half)
+    outs = []
+    for c in range(2):
+        e = ref_pts[..., c] * scale
+        pos = e[..., None] / dim_t
+        outs.append(torch.stack((pos[..., 0::2].sin(), pos[..., 1::2].cos()), dim=-1).flatten(-2))
+    return torch.cat(outs, dim=-1)
+
+
+@pytest.mark.parametrize("R,D", [(320, 256), (20, 32)])
+def test_query_sine(R, D):
+    from mesm_amd import kernels as kn
+    ref_pts = torch.sigmoid(gen((R, 2), 61))
+    out = kn.query_sine_fwd(ref_pts, D)
+    rd = ref_pts.double().requires_grad_(True)
+    ref = query_sine_reference(rd, D)
+    assert (out.double() - ref).abs().max().item() < 2e-5
+    dout = gen((R, D), 62)
+    ref.backward(dout.double())
+    dref = kn.query_sine_bwd(ref_pts, dout)
+    assert rel_err(dref, rd.grad) < TOL
+
+
+# --------------------------------------------------------------------------- act / bias backward
+@pytest.mark.parametrize("rows,cols", [(2400, 1024), (37, 50), (320, 256)])
+def test_act_bias_bwd(rows, cols):
+    from mesm_amd import kernels as kn
+    dy = gen((rows, cols), 70)
+    z = gen((rows, cols), 71)
+    slope = torch.tensor([0.3], device=dev())
+    db = torch.zeros(cols, device=dev())
+    ds = torch.zeros(1, device=dev())
+    dz = kn.act_bias_bwd(dy, z, kn.ACT_PRELU, dbias=db, slope=slope, dslope=ds)
+    ref = torch.where(z > 0, dy, 0.3 * dy).double()
+    assert rel_err(dz, ref) < TOL
+    assert rel_err(db, ref.sum(0)) < TOL
+    ds_ref = (dy.double() * z.double().clamp(max=0)).sum().item()
+    assert abs(ds.item() - ds_ref) / max(abs(ds_ref), 1.0) < TOL
+    y = z.clamp(min=0)
+    db.zero_()
+    dz = kn.act_bias_bwd(dy, y, kn.ACT_RELU, dbias=db)
+    ref = torch.where(y > 0, dy, torch.zeros_like(dy)).double()
+    assert rel_err(dz, ref) < TOL
+    assert rel_err(db, ref.sum(0)) < TOL
+    db.zero_()
+    kn.act_bias_bwd(dy, None, kn.ACT_NONE, dbias=db)
+    assert rel_err(db, dy.double().sum(0)) < TOL
+
+
+# --------------------------------------------------------------------------- losses
+@pytest.mark.parametrize("R,C", [(1024, 5003), (64, 1112), (10, 53)])
+def test_nll_smooth(R, C):
+    from mesm_amd import kernels as kn
+    logit = gen((R, C), 80, 3.0)
+    g = torch.Generator().manual_seed(81)
+    label = torch.randint(0, C, (R,), generator=g).to(dev())
+    mask = (torch.rand(R, generator=g) > 0.3).to(dev())
+    row_loss, row_lse, correct = kn.nll_smooth_fwd(logit, label, mask)
+    ld = logit.double().requires_grad_(True)
+    lp = ld.log_softmax(-1)
+    nll = -lp.gather(-1, label[:, None]).squeeze(-1)
+    smooth = -lp.sum(-1)
+    ref = ((1 - 0.1) * nll + 0.1 / C * smooth).masked_fill(~mask, 0)
+    assert rel_err(row_loss, ref) < TOL
+    assert torch.equal(correct.bool(), logit.argmax(-1) == label)
+    w = gen((R,), 82).abs() * mask
+    (ref * w.double()).sum().backward()
+    dl = kn.nll_smooth_bwd(logit, label, row_lse, w)
+    assert rel_err(dl, ld.grad) < TOL
+
+
+def saliency_reference(s_pos, s_neg, label, vmask, pos_idx, neg_idx, rank_coef, margin):
+    """fp64 restatement of criterion.py:139-221."""
+    vm = vmask.double()
+    N = s_pos.shape[0]
+    loss_neg = (-torch.log(1.0 - torch.sigmoid(s_neg)) * vm).sum(1).mean()
+    sc = torch.cat([s_pos, s_neg], 1)
+    lab = torch.cat([label, torch.zeros_like(label)], 1)
+    vm2 = vm.repeat(1, 2)
+    sc = vm2 * sc + (1.0 - vm2) * -1e3
+    total = 0.0
+    for r in range(1, 12):
+        pos = lab >= r
+        if pos.sum() == 0:
+            continue
+        bd = pos.sum(1) > 0
+        cur = sc / 0.5
+        lg = cur - cur.max(1, keepdim=True)[0]
+        lp = lg - torch.log(torch.exp(lg).sum(1, keepdim=True) + 1e-6)
+        mlp = (pos * lp * vm2).sum(1) / (pos.sum(1) + 1e-6)
+        total = total + (-mlp * bd).mean()
+    total = total / rank_coef + loss_neg
+    if pos_idx is not None:
+        P = pos_idx.shape[1]
+        bi = torch.arange(N, device=s_pos.device)
+        ps = torch.stack([s_pos[bi, pos_idx[:, c]] for c in range(P)], 1)
+        ns = torch.stack([s_pos[bi, neg_idx[:, c]] for c in range(P)], 1)
+        total = total + torch.clamp(margin + ns - ps, min=0).sum() / (N * P) * 2
+    return total
+
+
+@pytest.mark.parametrize("N,L,qvh", [(32, 75, True), (5, 40, False), (3, 600, False)])
+def test_saliency_loss(N, L, qvh):
+    from mesm_amd import kernels as kn
+    s_pos = gen((N, L), 90)
+    s_neg = gen((N, L), 91)
+    vmask = ~make_pad(N, L, 92, min_valid=12)
+    g = torch.Generator().manual_seed(93)
+    if qvh:
+        label = torch.randint(0, 13, (N, L), generator=g).double().to(dev())
+        label = label * (torch.rand(N, L, generator=g) > 0.6).to(dev())
+    else:
+        label = (torch.rand(N, L, generator=g) > 0.7).double().to(dev())
+    label = label * vmask
+    label[0] = 0  # a row without positives
+    pos_idx = torch.randint(0, 12, (N, 2), generator=g).to(dev())
+    neg_idx = torch.randint(0, 12, (N, 2), generator=g).to(dev())
+    out = kn.saliency_loss_fwd(s_pos, s_neg, label, vmask, pos_idx, neg_idx, 12.0, 0.2)
+    sp = s_pos.double().requires_grad_(True)
+    sn = s_neg.double().requires_grad_(True)
+    ref = saliency_reference(sp, sn, label, vmask, pos_idx, neg_idx, 12.0, 0.2)
+    assert abs(out.item() - ref.item()) / max(abs(ref.item()), 1.0) < TOL
+    ref.backward()
+    gs = torch.tensor([0.7], device=dev())
+    ds_pos, ds_neg = kn.saliency_loss_bwd(s_pos, s_neg, label, vmask, pos_idx, neg_idx, 12.0, 0.2, gs)
+    assert rel_err(ds_pos, 0.7 * sp.grad) < TOL
+    assert rel_err(ds_neg, 0.7 * sn.grad) < TOL
+    # without the triplet term
+    out2 = kn.saliency_loss_fwd(s_pos, s_neg, label, vmask, None, None, 1.0, 0.2)
+    ref2 = saliency_reference(s_pos.double(), s_neg.double(), label, vmask, None, None, 1.0, 0.2)
+    assert abs(out2.item() - ref2.item()) / max(abs(ref2.item()), 1.0) < TOL
+
+
+def test_match_against_scipy():
+    from scipy.optimize import linear_sum_assignment
+    from mesm_amd import kernels as kn
+    N, Q = 32, 10
+    g = torch.Generator().manual_seed(95)
+    logits = gen((N, Q, 2), 96)
+    spans = torch.sigmoid(gen((N, Q, 2), 97))
+    sizes = [1 + (i % 5) for i in range(N)]
+    off = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32)
+    T = int(off[-1])
+    st = torch.rand(T, generator=g) * 0.6
+    ed = st + 0.05 + torch.rand(T, generator=g) * 0.3
+    xx = torch.stack([st, ed], 1).to(dev())
+    cxw = torch.stack([(st + ed) * 0.5, ed - st], 1).to(dev())
+    mq, cost = kn.match(logits, spans, cxw, xx, off.to(dev()), 5, 10.0, 1.0, 4.0, want_cost=True)
+    # cost against the reference formula (matcher.py:70-105) in fp32 torch
+    prob = logits.flatten(0, 1).softmax(-1)
+    osp = spans.flatten(0, 1)
+    c_span = torch.cdist(osp, cxw, p=1)
+    x1 = osp[:, 0] - 0.5 * osp[:, 1]
+    x2 = osp[:, 0] + 0.5 * osp[:, 1]
+    inter = (torch.min(x2[:, None], xx[:, 1]) - torch.max(x1[:, None], xx[:, 0])).clamp(min=0)
+    union = (x2 - x1)[:, None] + (xx[:, 1] - xx[:, 0]) - inter
+    enc = (torch.max(x2[:, None], xx[:, 1]) - torch.min(x1[:, None], xx[:, 0])).clamp(min=0)
+    giou = inter / union - (enc - union) / enc
+    Cref = (10.0 * c_span + 1.0 * (-giou) + 4.0 * (-prob[:, :1])).view(N, Q, T).cpu()
+    mq = mq.cpu()
+    for b in range(N):
+        cb = Cref[b, :, off[b]:off[b + 1]]
+        assert (cost[b, :, :sizes[b]].cpu() - cb).abs().max().item() < 1e-5
+        qi, ti = linear_sum_assignment(cb.numpy())
+        want = torch.empty(sizes[b], dtype=torch.int32)
+        want[torch.as_tensor(ti)] = torch.as_tensor(qi, dtype=torch.int32)
+        assert torch.equal(mq[off[b]:off[b + 1]], want), (b, mq[off[b]:off[b + 1]], want)
