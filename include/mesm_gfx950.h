@@ -63,10 +63,10 @@ const char* mesm_arch(void);
  * two indices is contiguous, `ld*` is the stride of the other one.
  *
  * Prologue on A (and on B), applied while the operand is staged into LDS:
- *   x = A[m,k] (+ A2[m,k] if a2 != NULL, same strides)           [with_pos_embed]
+ *   x = A[m,k] (+ A2[m,k] if A2 != NULL, same strides)           [with_pos_embed]
  *   x = act(x)              a_act  in {NONE, RELU, PRELU(*slope)} [FFN activation]
  *   x = dropout(x)          a_drop_p > 0: keep iff hash(seed, m*K + k) >= p; /(1-p)
- * B: same, logical index k*N + n.
+ * B: same (B2 is the optional second addend), logical index k*N + n.
  *
  * Epilogue, in this order (each step optional):
  *   t = acc * out_scale
@@ -88,6 +88,7 @@ typedef struct MesmGemmArgs {
   const float* A;
   const float* A2;
   const float* B;
+  const float* B2;
   float* C;
   int32_t M, N, K;
   int32_t a_layout, b_layout;

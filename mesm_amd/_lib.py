@@ -25,7 +25,7 @@ class MesmError(RuntimeError):
 
 class GemmArgs(ctypes.Structure):
     _fields_ = [
-        ("A", c_ptr), ("A2", c_ptr), ("B", c_ptr), ("C", c_ptr),
+        ("A", c_ptr), ("A2", c_ptr), ("B", c_ptr), ("B2", c_ptr), ("C", c_ptr),
         ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("K", ctypes.c_int32),
         ("a_layout", ctypes.c_int32), ("b_layout", ctypes.c_int32),
         ("lda", ctypes.c_int64), ("ldb", ctypes.c_int64), ("ldc", ctypes.c_int64),

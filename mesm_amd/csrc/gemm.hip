@@ -223,7 +223,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const MesmGemmArgs p
 
   const int nkt = (kend - kbeg + BK - 1) / BK;
   ta.load(p.A, p.A2, p.lda, m0, p.M, kbeg, kend, tid);
-  tb.load(p.B, nullptr, p.ldb, n0, p.N, kbeg, kend, tid);
+  tb.load(p.B, p.B2, p.ldb, n0, p.N, kbeg, kend, tid);
   ta.template xform<true>(xa, m0, kbeg, tid);
   tb.template xform<false>(xb, n0, kbeg, tid);
   ta.store(As[0], SA, tid);
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const MesmGemmArgs p
     const bool has_next = (kt + 1 < nkt);
     if (has_next) {
       ta.load(p.A, p.A2, p.lda, m0, p.M, knext, kend, tid);
-      tb.load(p.B, nullptr, p.ldb, n0, p.N, knext, kend, tid);
+      tb.load(p.B, p.B2, p.ldb, n0, p.N, knext, kend, tid);
     }
     const float* __restrict__ a_s = As[buf];
     const float* __restrict__ b_s = Bs[buf];
@@ -376,7 +376,7 @@ extern "C" int mesm_gemm_f32(const MesmGemmArgs* args, void* stream) {
   int vec = 4;
   while (vec > 1) {
     bool ok = (a.lda % vec == 0) && (a.ldb % vec == 0) && aligned_to(a.A, 4 * vec) &&
-              aligned_to(a.A2, 4 * vec) && aligned_to(a.B, 4 * vec);
+              aligned_to(a.A2, 4 * vec) && aligned_to(a.B, 4 * vec) && aligned_to(a.B2, 4 * vec);
     if (ok) break;
     vec >>= 1;
   }

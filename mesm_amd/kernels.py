@@ -27,7 +27,7 @@ def _mat(t):
     return r, c, s0, s1
 
 
-def gemm(A, B, C, *, trans_a=False, trans_b=False, A2=None, bias=None, residual=None,
+def gemm(A, B, C, *, trans_a=False, trans_b=False, A2=None, B2=None, bias=None, residual=None,
          aux=None, slope=None, dslope=None, colsum=None, a_act=ACT_NONE, b_act=ACT_NONE,
          a_drop=(0.0, 0), b_drop=(0.0, 0), e_act=ACT_NONE, e_actgrad=ACT_NONE,
          e_drop=(0.0, 0), out_scale=1.0, accumulate=0, split_k=1):
@@ -59,6 +59,9 @@ def gemm(A, B, C, *, trans_a=False, trans_b=False, A2=None, bias=None, residual=
     if A2 is not None:
         assert A2.shape == A.shape and A2.stride() == A.stride()
         g.A2 = A2.data_ptr()
+    if B2 is not None:
+        assert B2.shape == B.shape and B2.stride() == B.stride()
+        g.B2 = B2.data_ptr()
     g.M, g.N, g.K = M, N, K
     g.a_layout, g.b_layout = a_layout, b_layout
     g.lda, g.ldb, g.ldc = A.stride(0), B.stride(0), C.stride(0)
@@ -181,6 +184,21 @@ def attn_bwd(do, q, k, v, o, lse, H, kpad=None, qpad=None, scale=None, drop=(0.0
     a.d_o, a.dq, a.dk_, a.dv_ = do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
     check(lib().mesm_attn_bwd(ctypes.byref(a), stream_ptr()), "mesm_attn_bwd")
     return dq, dk, dv
+
+
+def attn_bwd_into(do, q, k, v, o, lse, H, dq, dk, dv, kpad=None, qpad=None, scale=None,
+                  drop=(0.0, 0)):
+    """attn_bwd writing into caller-provided gradient tensors whose strides equal those of
+    q / k / v (e.g. column slices of one fused [dq|dk|dv] buffer).  dq must be zero-initialised
+    when Lk > 64 (several key tiles add into it atomically)."""
+    require_gpu(do, q, k, v, o, lse, dq, dk, dv)
+    if scale is None:
+        scale = (q.shape[-1] // H) ** -0.5
+    assert do.stride() == o.stride()
+    assert dq.stride() == q.stride() and dk.stride() == k.stride() and dv.stride() == v.stride()
+    a = _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop)
+    a.d_o, a.dq, a.dk_, a.dv_ = do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    check(lib().mesm_attn_bwd(ctypes.byref(a), stream_ptr()), "mesm_attn_bwd")
 
 
 def sine_pos(mask, D):

@@ -1,0 +1,334 @@
+"""Parameter containers + fused forward blocks of the MESM transformer stacks.
+
+Module / parameter names reproduce the reference's state_dict keys
+so checkpoints interchange; the forward passes are written on mesm_amd.ops (HIP kernels),
+batch-first, and never call torch.nn.functional compute ops.
+"""
+import copy
+import math
+
+import torch
+from torch import nn
+
+from . import ops
+from .ops import drop_state
+
+
+class ParamLinear(nn.Module):
+    """weight (out, in) + bias (out) with nn.Linear's default initialisation; no forward —
+    the owning block passes the tensors to a fused op."""
+
+    def __init__(self, in_f, out_f):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(out_f, in_f))
+        self.bias = nn.Parameter(torch.empty(out_f))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1 / math.sqrt(in_f) if in_f > 0 else 0
+        nn.init.uniform_(self.bias, -bound, bound)
+
+
+class ParamLayerNorm(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(d))
+        self.bias = nn.Parameter(torch.zeros(d))
+
+    def forward(self, x):
+        return ops.layer_norm(x, self.weight, self.bias)
+
+
+class PReLUParam(nn.Module):
+    """nn.PReLU(): one learnable slope, init 0.25 (runner.py:199 'prelu', transformer.py:902-903)."""
+
+    def __init__(self):
+        super().__init__()
+        self.weight = nn.Parameter(torch.full((1,), 0.25))
+
+
+class PackedMHAParams(nn.Module):
+    """Parameters of nn.MultiheadAttention(d, h): in_proj_{weight,bias}, out_proj.{weight,bias}."""
+
+    def __init__(self, d):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d, d))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d))
+        self.out_proj = ParamLinear(d, d)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.zeros_(self.out_proj.bias)
+
+
+class OutProjOnly(nn.Module):
+    """The custom decoder MultiheadAttention (attention.py:61-182) only owns out_proj."""
+
+    def __init__(self, vdim):
+        super().__init__()
+        self.out_proj = ParamLinear(vdim, vdim)
+        nn.init.zeros_(self.out_proj.bias)
+
+
+class MLPHead(nn.Module):
+    """MLP (model.py:397-409 / transformer.py:21-33): ReLU between layers."""
+
+    def __init__(self, in_d, hid, out_d, n):
+        super().__init__()
+        dims = [in_d] + [hid] * (n - 1) + [out_d]
+        self.layers = nn.ModuleList(ParamLinear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+
+    def forward(self, x):
+        n = len(self.layers)
+        for i, l in enumerate(self.layers):
+            x = ops.linear(x, l.weight, l.bias, relu=i < n - 1)
+        return x
+
+
+class LinearLayer(nn.Module):
+    """LN -> dropout -> Linear -> [ReLU] (model.py:412-434); the dropout rides the GEMM's A load."""
+
+    def __init__(self, in_f, out_f, dropout, relu):
+        super().__init__()
+        self.LayerNorm = ParamLayerNorm(in_f)
+        self.net = nn.ModuleList([nn.Identity(), ParamLinear(in_f, out_f)])
+        self.p = dropout
+        self.relu = relu
+
+    def forward(self, x):
+        x = self.LayerNorm(x)
+        lin = self.net[1]
+        return ops.linear(x, lin.weight, lin.bias, relu=self.relu, in_drop=drop_state.next(self.p))
+
+
+class T2VLayer(nn.Module):
+    """T2V_TransformerEncoderLayer[_TwoMLP].forward_post (transformer.py:508-540, 573-612)."""
+
+    def __init__(self, d, h, ff, dropout, two_mlp=False):
+        super().__init__()
+        self.self_attn = PackedMHAParams(d)
+        self.linear1 = ParamLinear(d, ff)
+        self.linear2 = ParamLinear(ff, d)
+        self.norm1 = ParamLayerNorm(d)
+        self.norm2 = ParamLayerNorm(d)
+        self.activation = PReLUParam()
+        if two_mlp:
+            self.linear1_1 = ParamLinear(d, ff)
+            self.linear2_1 = ParamLinear(ff, d)
+            self.norm1_1 = ParamLayerNorm(d)
+            self.norm2_1 = ParamLayerNorm(d)
+        self.two_mlp = two_mlp
+        self.nhead = h
+        self.p = dropout
+
+    def forward(self, txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm=False):
+        sa = self.self_attn
+        x = ops.mha(vid, pos_vid, txt, pos_txt, vid, sa.in_proj_weight, sa.in_proj_bias,
+                    sa.out_proj.weight, sa.out_proj.bias, self.nhead, kpad=txt_pad, qpad=vid_pad,
+                    attn_drop=drop_state.next(self.p), out_drop=drop_state.next(self.p))
+        alt = self.two_mlp and is_mlm
+        n1, n2 = (self.norm1_1, self.norm2_1) if alt else (self.norm1, self.norm2)
+        l1, l2 = (self.linear1_1, self.linear2_1) if alt else (self.linear1, self.linear2)
+        y = ops.ffn(n1(x), x, l1.weight, l1.bias, self.activation.weight, l2.weight, l2.bias,
+                    mid_drop=drop_state.next(self.p), out_drop=drop_state.next(self.p))
+        return n2(y)
+
+
+def _clones(m, n):
+    return nn.ModuleList([copy.deepcopy(m) for _ in range(n)])
+
+
+class T2VStack(nn.Module):
+    """T2V_TransformerEncoder (transformer.py:208-242)."""
+
+    def __init__(self, layer, n):
+        super().__init__()
+        self.layers = _clones(layer, n)
+
+    def forward(self, txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm=False):
+        for l in self.layers:
+            vid = l(txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm)
+        return vid
+
+
+def _xavier_(module):
+    for p in module.parameters():
+        if p.dim() > 1:
+            nn.init.xavier_uniform_(p)
+
+
+class T2VEncoder(nn.Module):
+    """T2VEncoder / T2VEncoder_TwoMLP (transformer.py:62-116): xavier on every matrix."""
+
+    def __init__(self, d, h, n_layers, ff, dropout, two_mlp=False):
+        super().__init__()
+        self.t2v_encoder = T2VStack(T2VLayer(d, h, ff, dropout, two_mlp), n_layers)
+        _xavier_(self)
+        self.d_model, self.nhead = d, h
+
+    def forward(self, txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm=False):
+        return self.t2v_encoder(txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm)
+
+
+class EncoderLayer(nn.Module):
+    """TransformerEncoderLayer.forward_post (transformer.py:637-650)."""
+
+    def __init__(self, d, h, ff, dropout):
+        super().__init__()
+        self.self_attn = PackedMHAParams(d)
+        self.linear1 = ParamLinear(d, ff)
+        self.linear2 = ParamLinear(ff, d)
+        self.norm1 = ParamLayerNorm(d)
+        self.norm2 = ParamLayerNorm(d)
+        self.activation = PReLUParam()
+        self.nhead, self.p = h, dropout
+
+    def forward(self, src, pos, pad):
+        sa = self.self_attn
+        x = ops.mha(src, pos, None, None, src, sa.in_proj_weight, sa.in_proj_bias,
+                    sa.out_proj.weight, sa.out_proj.bias, self.nhead, kpad=pad,
+                    attn_drop=drop_state.next(self.p), out_drop=drop_state.next(self.p),
+                    self_attn=True)
+        x = self.norm1(x)
+        y = ops.ffn(x, x, self.linear1.weight, self.linear1.bias, self.activation.weight,
+                    self.linear2.weight, self.linear2.bias, mid_drop=drop_state.next(self.p),
+                    out_drop=drop_state.next(self.p))
+        return self.norm2(y)
+
+
+class EncoderStack(nn.Module):
+    def __init__(self, layer, n):
+        super().__init__()
+        self.layers = _clones(layer, n)
+
+    def forward(self, src, pos, pad):
+        for l in self.layers:
+            src = l(src, pos, pad)
+        return src
+
+
+class DecoderLayer(nn.Module):
+    """TransformerDecoderLayer.forward (transformer.py:723-797), conditional-DETR style cross
+    attention with per-head [content || positional] queries and keys."""
+
+    def __init__(self, d, h, ff, dropout):
+        super().__init__()
+        for name in ("sa_qcontent_proj", "sa_qpos_proj", "sa_kcontent_proj", "sa_kpos_proj",
+                     "sa_v_proj"):
+            setattr(self, name, ParamLinear(d, d))
+        self.self_attn = OutProjOnly(d)
+        self.norm1 = ParamLayerNorm(d)
+        for name in ("ca_qcontent_proj", "ca_qpos_proj", "ca_kcontent_proj", "ca_kpos_proj",
+                     "ca_v_proj", "ca_qpos_sine_proj"):
+            setattr(self, name, ParamLinear(d, d))
+        self.cross_attn = OutProjOnly(d)
+        self.linear1 = ParamLinear(d, ff)
+        self.linear2 = ParamLinear(ff, d)
+        self.norm2 = ParamLayerNorm(d)
+        self.norm3 = ParamLayerNorm(d)
+        self.activation = PReLUParam()
+        self.nhead, self.p = h, dropout
+
+    def forward(self, tgt, memory, mem_pad, pos, query_pos, qsine, is_first):
+        L = ops.linear
+        n, nq, d = tgt.shape
+        h = self.nhead
+        dh = d // h
+        q = L(tgt, self.sa_qcontent_proj.weight, self.sa_qcontent_proj.bias) + \
+            L(query_pos, self.sa_qpos_proj.weight, self.sa_qpos_proj.bias)
+        k = L(tgt, self.sa_kcontent_proj.weight, self.sa_kcontent_proj.bias) + \
+            L(query_pos, self.sa_kpos_proj.weight, self.sa_kpos_proj.bias)
+        v = L(tgt, self.sa_v_proj.weight, self.sa_v_proj.bias)
+        a = ops.attention(q, k, v, h, drop=drop_state.next(self.p))
+        so = self.self_attn.out_proj
+        tgt = self.norm1(L(a, so.weight, so.bias, residual=tgt, out_drop=drop_state.next(self.p)))
+
+        qc = L(tgt, self.ca_qcontent_proj.weight, self.ca_qcontent_proj.bias)
+        kc = L(memory, self.ca_kcontent_proj.weight, self.ca_kcontent_proj.bias)
+        v = L(memory, self.ca_v_proj.weight, self.ca_v_proj.bias)
+        kp = L(pos, self.ca_kpos_proj.weight, self.ca_kpos_proj.bias)
+        if is_first:
+            qc = qc + L(query_pos, self.ca_qpos_proj.weight, self.ca_qpos_proj.bias)
+            kc = kc + kp
+        qs = L(qsine, self.ca_qpos_sine_proj.weight, self.ca_qpos_sine_proj.bias)
+        lm = memory.shape[1]
+        q2 = torch.cat([qc.view(n, nq, h, dh), qs.view(n, nq, h, dh)], -1).view(n, nq, 2 * d)
+        k2 = torch.cat([kc.view(n, lm, h, dh), kp.view(n, lm, h, dh)], -1).view(n, lm, 2 * d)
+        a = ops.attention(q2, k2, v, h, kpad=mem_pad, drop=drop_state.next(self.p))
+        co = self.cross_attn.out_proj
+        tgt = self.norm2(L(a, co.weight, co.bias, residual=tgt, out_drop=drop_state.next(self.p)))
+        y = ops.ffn(tgt, tgt, self.linear1.weight, self.linear1.bias, self.activation.weight,
+                    self.linear2.weight, self.linear2.bias, mid_drop=drop_state.next(self.p),
+                    out_drop=drop_state.next(self.p))
+        return self.norm3(y)
+
+
+def inverse_sigmoid(x, eps=1e-3):
+    x = x.clamp(min=0, max=1)
+    return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
+
+
+class Decoder(nn.Module):
+    """TransformerDecoder (transformer.py:280-420): DAB-style iterative reference refinement."""
+
+    def __init__(self, layer, n, d):
+        super().__init__()
+        self.layers = _clones(layer, n)
+        self.num_layers = n
+        self.norm = ParamLayerNorm(d)
+        self.query_scale = MLPHead(d, d, d, 2)
+        self.ref_point_head = MLPHead(d, d, d, 2)
+        self.bbox_embed = MLPHead(d, d, 2, 3)
+        self.ref_anchor_head = MLPHead(d, d, 1, 2)
+        self.d_model = d
+        # keep_query_pos=False: ca_qpos_proj exists on layer 0 only (transformer.py:329-331)
+        for i in range(1, n):
+            self.layers[i].ca_qpos_proj = None
+
+    def forward(self, memory, mem_pad, pos, refpoints_unsigmoid):
+        n = memory.shape[0]
+        nq = refpoints_unsigmoid.shape[0]
+        d = self.d_model
+        ref = torch.sigmoid(refpoints_unsigmoid)[None].expand(n, nq, 2)
+        refs = [ref]
+        out = torch.zeros(n, nq, d, device=memory.device, dtype=torch.float32)
+        inter = []
+        for li, layer in enumerate(self.layers):
+            qsine = ops.query_sine(ref, d)
+            query_pos = self.ref_point_head(qsine)
+            if li > 0:
+                qsine = qsine * self.query_scale(out)
+            cond = torch.sigmoid(self.ref_anchor_head(out))
+            qsine = qsine * (cond[..., 0] / ref[..., 1]).unsqueeze(-1)
+            out = layer(out, memory, mem_pad, pos, query_pos, qsine, li == 0)
+            new_ref = torch.sigmoid(self.bbox_embed(out) + inverse_sigmoid(ref))
+            if li != self.num_layers - 1:
+                refs.append(new_ref)
+            ref = new_ref.detach()
+            inter.append(self.norm(out))
+        return torch.stack(inter), torch.stack(refs)
+
+
+class Transformer(nn.Module):
+    """Transformer (transformer.py:119-205): 2 self-attention encoder layers over
+    [global token || video] + the moment-query decoder."""
+
+    def __init__(self, d, h, num_queries, enc_layers, dec_layers, ff, dropout):
+        super().__init__()
+        self.encoder = EncoderStack(EncoderLayer(d, h, ff, dropout), enc_layers)
+        self.decoder = Decoder(DecoderLayer(d, h, ff, dropout), dec_layers, d)
+        _xavier_(self)
+        self.d_model, self.nhead = d, h
+        self.dim_feedforward, self.dropout = ff, dropout
+        self.num_queries = num_queries
+
+    def forward(self, src, vid_pad, query_embed, pos, g_tok, g_pos, run_decoder=True):
+        """src (N, L, d); vid_pad (N, L) True = padding.  The global token is prepended as a
+        MASKED key (transformer.py:185-186): it pools, nobody attends to it."""
+        n = src.shape[0]
+        d = self.d_model
+        x = torch.cat([g_tok.view(1, 1, d).expand(n, 1, d), src], 1)
+        p = torch.cat([g_pos.view(1, 1, d).expand(n, 1, d), pos], 1)
+        pad = torch.cat([torch.ones(n, 1, dtype=torch.bool, device=src.device), vid_pad], 1)
+        mem = self.encoder(x, p, pad.contiguous())
+        mem_g, mem_l = mem[:, 0], mem[:, 1:]
+        if not run_decoder:
+            return None, None, mem_l, mem_g
+        hs, refs = self.decoder(mem_l.contiguous(), vid_pad, pos, query_embed)
+        return hs, refs, mem_l, mem_g

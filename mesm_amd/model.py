@@ -1,0 +1,338 @@
+"""MESM (model/model.py:16-394 of the reference) on the gfx950 kernels.
+
+Same constructor semantics, call signature, returned dict and state_dict keys as the
+reference module, so `runner.build_model` / train.py / eval.py can use it unchanged
+(SURVEY.md §8b).  Differences that do not change any output or gradient:
+  * dead compute of the reference is skipped: the negative pass runs the encoder
+    only (its decoder output is discarded at model.py:295), SegSenRecon's unused position
+    embedding is not computed;
+  * all host-side decisions (group splits, negative indices, MLM word choice, gather maps) are
+    made once per call in `make_plan` from CPU copies of the masks, so the device work is a
+    fixed sequence of kernels (capturable in a HIP graph for a fixed batch shape).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import kernels as kn
+from . import ops
+from .gradbuf import GradBuffer
+from .layers import (LinearLayer, MLPHead, ParamLayerNorm, ParamLinear, T2VLayer, T2VStack,
+                     inverse_sigmoid)
+from .ops import drop_state
+
+
+class TrainablePositionalEncoding(nn.Module):
+    """position_encoding.py:10-32.  Built for state_dict compatibility; bypassed while
+    use_txt_pos=False (model.py:169-172), like in the reference."""
+
+    def __init__(self, max_pos, d, dropout):
+        super().__init__()
+        self.position_embeddings = nn.Embedding(max_pos, d)
+        self.LayerNorm = ParamLayerNorm(d)
+        self.p = dropout
+
+
+class SegSenRecon(nn.Module):
+    """SS-MESM reconstructor (model.py:437-503)."""
+
+    def __init__(self, input_dropout, d, h, n_layers, ff, dropout):
+        super().__init__()
+        self.masked_sent_token = nn.Parameter(torch.zeros(d))
+        self.recon_trans = T2VStack(T2VLayer(d, h, ff, dropout), n_layers)
+        self.output_sent_proj = nn.Sequential(LinearLayer(d, d, input_dropout, True),
+                                              LinearLayer(d, d, input_dropout, False))
+
+
+class Plan:
+    """Host-side decisions of one forward call, as device index tensors."""
+    pass
+
+
+class MESM(nn.Module):
+    def __init__(self, text_encoder, enhance_encoder, t2v_encoder, transformer,
+                 vid_position_embed, txt_position_embed, txt_dim, vid_dim, num_queries,
+                 input_dropout, aux_loss=False, max_video_l=75, max_words_l=32, normalize_txt=True,
+                 use_txt_pos=False, span_loss_type="l1", n_input_proj=2, rec_fw=False,
+                 vocab_size=1111, rec_ss=False, num_recss_layers=2, share_MLP=True):
+        super().__init__()
+        if text_encoder is not None:
+            raise NotImplementedError(
+                "text encoders are outside this build's hot path: pass pre-extracted word features "
+                "as a 3-D words_id (tokenizer_type='GloVeNLTK', load_vocab_pkl=True — model.py:160-161)")
+        if use_txt_pos:
+            raise NotImplementedError("use_txt_pos=True is not used by any shipped config")
+        if span_loss_type != "l1":
+            raise NotImplementedError("span_loss_type 'ce' raises in the reference as well")
+        self.text_encoder = None
+        self.enhance_encoder = enhance_encoder
+        self.t2v_encoder = t2v_encoder
+        self.transformer = transformer
+        self.vid_position_embed = vid_position_embed  # None: the sine kernel has no parameters
+        self.txt_position_embed = txt_position_embed
+        self.num_queries = num_queries
+        d = transformer.d_model
+        self.hidden_dim = d
+        self.span_loss_type = span_loss_type
+        self.max_video_l, self.max_words_l = max_video_l, max_words_l
+        self.normalize_txt = normalize_txt
+        self.use_txt_pos = use_txt_pos
+        self.n_input_proj = n_input_proj
+        self.aux_loss = aux_loss
+        self.share_MLP = share_MLP
+        self.span_embed = MLPHead(d, d, 2, 3)
+        self.class_embed = ParamLinear(d, 2)
+        self.query_embed = nn.Embedding(num_queries, 2)
+        relu = [True] * 3
+        relu[n_input_proj - 1] = False
+        dims_t = [txt_dim, d, d]
+        dims_v = [vid_dim, d, d]
+        self.input_txt_proj = nn.Sequential(*[LinearLayer(dims_t[i], d, input_dropout, relu[i])
+                                              for i in range(n_input_proj)])
+        self.input_vid_proj = nn.Sequential(*[LinearLayer(dims_v[i], d, input_dropout, relu[i])
+                                              for i in range(n_input_proj)])
+        self.saliency_proj1 = ParamLinear(d, d)
+        self.saliency_proj2 = ParamLinear(d, d)
+        self.global_rep_token = nn.Parameter(torch.randn(d))
+        self.global_rep_pos = nn.Parameter(torch.randn(d))
+        self.rec_fw = rec_fw
+        num_classes = vocab_size + 1  # text_encoder is None (model.py:76-77)
+        if rec_fw:
+            self.masked_token = nn.Parameter(torch.zeros(txt_dim))
+            self.unknown_token = nn.Parameter(torch.zeros(txt_dim))
+            self.output_txt_proj = nn.Sequential(LinearLayer(d, d, input_dropout, True),
+                                                 ParamLinear(d, num_classes))
+        self.rec_ss = rec_ss
+        if rec_ss:
+            self.ss_reconstructor = SegSenRecon(input_dropout, d, transformer.nhead, num_recss_layers,
+                                                transformer.dim_feedforward, transformer.dropout)
+        self._gradbuf = None
+        self._step = 0
+
+    # ------------------------------------------------------------------ infrastructure
+    def gradbuf(self):
+        if self._gradbuf is None:
+            self._gradbuf = GradBuffer([(n, p) for n, p in self.named_parameters() if p.requires_grad])
+        return self._gradbuf
+
+    def _begin(self, device, is_training):
+        if not device.type == "cuda":
+            raise kn._lib.MesmError(
+                "mesm_amd.MESM runs on an MI355X only (got %s); the CPU oracle in oracle/ is a "
+                "test checker, not a fallback" % device)
+        gb = self.gradbuf()
+        gb.ensure(device)
+        if torch.is_grad_enabled():
+            gb.begin_step()
+        self._step += 1
+        drop_state.begin(self.training, torch.initial_seed() + self._step)
+
+    def _proj(self, seq, x):
+        for m in seq:
+            x = m(x)
+        return x
+
+    # ------------------------------------------------------------------ host-side plan
+    @torch.no_grad()
+    def make_plan(self, video_mask, words_mask, num_clips, dataset_name, is_training, words_weight=None,
+                  clip_mask=None, neg_index=None, masked_words=None, device=None):
+        """All data-dependent host decisions of model.py:184-207, :260, :307-325 in one place.
+        Inputs may live on any device; one D2H copy of the (small) masks is made."""
+        device = device or video_mask.device
+        vm = video_mask.cpu()
+        wm = words_mask.cpu()
+        groups = [int(g) for g in num_clips.tolist()]
+        N, Lv = vm.shape
+        pl = Plan()
+        pl.groups = groups
+        # negative query index: uniform over the queries of other groups (data_utils.py:113-124)
+        if neg_index is None:
+            if len(groups) < 2:
+                raise IndexError("index 0 is out of bounds: negatives need >= 2 video groups in a batch")
+            neg, start = [], 0
+            for g in groups:
+                cand = torch.cat([torch.arange(0, start), torch.arange(start + g, N)])
+                for _ in range(g):
+                    neg.append(cand[torch.randperm(cand.shape[0])][0])
+                start += g
+            neg_index = torch.stack(neg)
+        pl.neg_index = neg_index.to(device)
+        if self.rec_ss:
+            slot = torch.cat([torch.arange(g) for g in groups])
+            M = max(groups)
+            pl.sent_src = torch.zeros(N, M, dtype=torch.int64)  # row of sentence_feat per slot
+            pl.sent_mask = torch.zeros(N, M, dtype=torch.bool)
+            start = 0
+            for g in groups:
+                for i in range(start, start + g):
+                    pl.sent_src[i, :g] = torch.arange(start, start + g)
+                    pl.sent_mask[i, :g] = True
+                start += g
+            pl.sent_loc = torch.zeros(N, M, dtype=torch.bool)
+            pl.sent_loc[torch.arange(N), slot] = True
+            pl.sent_slot = slot.to(device)
+            pl.rows = torch.arange(N, device=device)
+            if dataset_name == "qvhighlights":
+                flat_valid = vm.reshape(-1).nonzero().squeeze(1)  # rows of (N*Lv) that are valid
+                counts = vm.sum(1)
+                offs = torch.cat([torch.zeros(1, dtype=torch.int64), counts.cumsum(0)])
+                seg, start = [], 0
+                for g in groups:
+                    idx = flat_valid[offs[start]:offs[start + g]]
+                    seg += [idx] * g
+                    start += g
+                Lss = max(len(s) for s in seg)
+                pl.vid_src = torch.zeros(N, Lss, dtype=torch.int64)
+                pl.vid_mask = torch.zeros(N, Lss, dtype=torch.bool)
+                for i, s in enumerate(seg):
+                    pl.vid_src[i, :len(s)] = s
+                    pl.vid_mask[i, :len(s)] = True
+                pl.vid_src = pl.vid_src.to(device)
+                pl.vid_pad = (~pl.vid_mask).to(device)
+                pl.vid_mask = pl.vid_mask.to(device)
+            elif dataset_name in ("charades", "charades-cg", "charades-cd", "tacos"):
+                pl.vid_src = None
+            else:
+                raise NotImplementedError
+            pl.sent_src = pl.sent_src.to(device)
+            pl.sent_pad = (~pl.sent_mask).to(device)
+            pl.sent_mask = pl.sent_mask.to(device)
+            pl.sent_loc = pl.sent_loc.to(device)
+        if self.rec_fw and is_training:
+            cm = clip_mask.cpu()
+            lens = cm.sum(1)
+            Lc = int(lens.max())
+            flat = cm.reshape(-1).nonzero().squeeze(1)
+            offs = torch.cat([torch.zeros(1, dtype=torch.int64), lens.cumsum(0)])
+            src = torch.zeros(N, Lc, dtype=torch.int64)
+            cmask = torch.zeros(N, Lc, dtype=torch.bool)
+            for i in range(N):
+                li = int(lens[i])
+                src[i, :li] = flat[offs[i]:offs[i + 1]]
+                cmask[i, :li] = True
+            pl.clip_src = src.to(device)
+            pl.clip_mask = cmask.to(device)
+            pl.clip_pad = (~cmask).to(device)
+            if masked_words is None:
+                # _mask_words, model.py:361-384: numpy RNG on the host, p ~ words_weight
+                masked_words = torch.zeros_like(wm)
+                weight = F.normalize(words_weight.float().cpu(), dim=1, p=1) if words_weight is not None else None
+                for i, l in enumerate(wm.count_nonzero(dim=1)):
+                    l = int(l)
+                    if l <= 1:
+                        continue
+                    k = max(l // 3, 1)
+                    p = weight[i, :l].numpy() if weight is not None else None
+                    choices = np.random.choice(np.arange(0, l), k, replace=False, p=p)
+                    masked_words[i, choices] = 1
+            pl.masked_words = masked_words.bool().to(device)
+        return pl
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, video_feat, video_mask, words_id, words_mask, words_weight, num_clips, **kwargs):
+        if words_id.dim() != 3:
+            raise NotImplementedError("token ids need a text encoder; pass (N, Lw, Dt) word features")
+        dev = video_feat.device
+        is_training = kwargs["is_training"]
+        self._begin(dev, is_training)
+        d, h = self.hidden_dim, self.transformer.nhead
+        N, Lv = video_mask.shape
+
+        # post_process_text (model.py:145-152)
+        words = words_id
+        if self.normalize_txt:
+            words = F.normalize(words, dim=-1, p=2, eps=1e-5)
+        words_mask = words.sum(dim=-1) != 0
+        sent = words.sum(dim=1) / words_mask.sum(dim=1).unsqueeze(-1)
+        if self.normalize_txt:
+            sent = F.normalize(sent, dim=-1, p=2, eps=1e-5)
+
+        plan = kwargs.get("plan")
+        if plan is None:
+            plan = self.make_plan(video_mask, words_mask, num_clips, kwargs["dataset_name"], is_training,
+                                  words_weight=words_weight, clip_mask=kwargs.get("clip_mask"),
+                                  neg_index=kwargs.get("neg_index"),
+                                  masked_words=kwargs.get("masked_words"), device=dev)
+
+        vid_pad = (~video_mask).contiguous()
+        words_pad = (~words_mask).contiguous()
+        pv = self._proj(self.input_vid_proj, video_feat)
+        pw = self._proj(self.input_txt_proj, words)
+        vpos = kn.sine_pos(video_mask, d)
+
+        enc = self.enhance_encoder
+        enhanced = enc(pw, pv, None, vpos, words_pad, vid_pad) if self.rec_fw else pv
+
+        out = {}
+        if self.rec_ss:
+            if plan.vid_src is not None:
+                bvid = video_feat.reshape(N * Lv, -1)[plan.vid_src] * plan.vid_mask.unsqueeze(-1)
+                bvid_pad = plan.vid_pad
+            else:
+                bvid, bvid_pad = video_feat, vid_pad
+            bsent = sent[plan.sent_src] * plan.sent_mask.unsqueeze(-1)
+            bvid = self._proj(self.input_vid_proj, bvid)
+            bsent = self._proj(self.input_txt_proj, bsent)
+            tok = self.ss_reconstructor.masked_sent_token.view(1, 1, d)
+            q_tok = torch.where(plan.sent_loc.unsqueeze(-1), tok, bsent)
+            rec = self.ss_reconstructor.recon_trans(bvid, q_tok, None, None, bvid_pad, plan.sent_pad)
+            recon = F.normalize(rec[plan.rows, plan.sent_slot])  # the masked slot of every pair
+            # projed_recon_feat feeds no loss (criterion.py:246-255) but is part of the returned dict
+            projed_recon = self._proj(self.ss_reconstructor.output_sent_proj, recon)
+            ewords = torch.cat([recon.unsqueeze(1), pw], dim=1)
+            emask = torch.cat([torch.ones(N, 1, dtype=torch.bool, device=dev), words_mask], dim=1)
+        else:
+            ewords, emask = pw, words_mask
+        epad = (~emask).contiguous()
+
+        encoded = self.t2v_encoder(ewords, enhanced, None, vpos, epad, vid_pad)
+        hs, refs, memory, memory_g = self.transformer(encoded, vid_pad, self.query_embed.weight, vpos,
+                                                      self.global_rep_token, self.global_rep_pos)
+        logits = ops.linear(hs, self.class_embed.weight, self.class_embed.bias)
+        spans = torch.sigmoid(self.span_embed(hs) + inverse_sigmoid(refs))
+
+        # negative pass (model.py:260-299); decoder skipped: its outputs are discarded at :295
+        ni = plan.neg_index
+        n_ewords, n_emask = ewords[ni], emask[ni]
+        if self.rec_ss:
+            n_words, n_wpad = n_ewords[:, 1:], (~n_emask[:, 1:]).contiguous()
+        else:
+            n_words, n_wpad = n_ewords, (~n_emask).contiguous()
+        n_enh = enc(n_words, pv, None, vpos, n_wpad, vid_pad) if self.rec_fw else pv
+        n_enc = self.t2v_encoder(n_ewords, n_enh, None, vpos, (~n_emask).contiguous(), vid_pad)
+        _, _, n_memory, n_memory_g = self.transformer(n_enc, vid_pad, self.query_embed.weight, vpos,
+                                                      self.global_rep_token, self.global_rep_pos,
+                                                      run_decoder=False)
+
+        def saliency(mem, mem_g):
+            a = ops.linear(mem, self.saliency_proj1.weight, self.saliency_proj1.bias)
+            b = ops.linear(mem_g, self.saliency_proj2.weight, self.saliency_proj2.bias)
+            return torch.sum(a * b.unsqueeze(1), dim=-1) / np.sqrt(d)
+
+        out.update({
+            "pred_logits": logits[-1], "pred_spans": spans[-1],
+            "saliency_scores": saliency(memory, memory_g),
+            "neg_saliency_scores": saliency(n_memory, n_memory_g),
+        })
+        if self.aux_loss:
+            out["aux_outputs"] = [{"pred_logits": a, "pred_spans": b} for a, b in zip(logits[:-1], spans[:-1])]
+
+        if self.rec_fw and is_training:
+            # FW-MESM masked-language-model branch (model.py:307-332)
+            unk = self._proj(self.input_txt_proj, self.unknown_token.view(1, 1, -1))
+            msk = self._proj(self.input_txt_proj, self.masked_token.view(1, 1, -1))
+            w = torch.where(kwargs["unknown_mask"].unsqueeze(-1), unk, pw)
+            w = torch.where(plan.masked_words.unsqueeze(-1), msk, w)
+            cfeat = pv.reshape(N * Lv, d)[plan.clip_src] * plan.clip_mask.unsqueeze(-1)
+            cpos = vpos.reshape(N * Lv, d)[plan.clip_src] * plan.clip_mask.unsqueeze(-1)
+            rec_w = enc(cfeat, w, cpos, None, plan.clip_pad, words_pad, is_mlm=True)
+            hid = self.output_txt_proj[0](rec_w)
+            head = self.output_txt_proj[1]
+            out["recfw_words_logit"] = ops.linear(hid, head.weight, head.bias)
+            out["words_mask"] = words_mask
+        if self.rec_ss:
+            out.update({"projed_video_feat": pv, "recon_feat": recon, "projed_recon_feat": projed_recon,
+                        "expanded_words_feat": ewords, "expanded_words_mask": emask,
+                        "enhanced_video_feat": enhanced, "projed_words_feat": pw})
+        return out

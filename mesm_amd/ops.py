@@ -1,0 +1,442 @@
+"""autograd.Function blocks over the gfx950 kernels.
+
+Granularity is chosen for fusion, not to mirror torch.nn: a Function covers a whole
+nn.Linear(+epilogue), a whole FFN, a whole nn.MultiheadAttention, ... and its backward is
+hand-written on the same kernels.  Parameter gradients are accumulated in place into the
+model's flat gradient buffer (gradbuf.py); autograd only routes activation gradients.
+
+All activations are batch-first (N, L, d) contiguous fp32; the reference's (L, N, d)
+layout (transformer.py:93-96) is never materialised.
+"""
+import torch
+from torch.autograd import Function
+
+from . import kernels as kn
+from ._lib import ACT_NONE, ACT_PRELU, ACT_RELU
+from .gradbuf import grad_target
+
+NO_DROP = (0.0, 0)
+
+
+class DropState:
+    """Per-step dropout seeds: every dropout site of a forward draws the next seed; the
+    backward replays the (p, seed) it saved.  Off (p = 0) in eval mode."""
+
+    def __init__(self):
+        self.training = False
+        self.base = 0
+        self.counter = 0
+
+    def begin(self, training, base):
+        self.training = training
+        self.base = int(base) & 0x7FFFFFFF
+        self.counter = 0
+
+    def next(self, p):
+        if not self.training or p <= 0.0:
+            return NO_DROP
+        self.counter += 1
+        return (float(p), (self.base * 1000003 + self.counter * 104729) & 0xFFFFFFFF)
+
+
+drop_state = DropState()
+
+
+def _2d(t):
+    return t.reshape(-1, t.shape[-1])
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _dw_split(n_out, k_in, rows):
+    tiles = ((n_out + 63) // 64) * ((k_in + 63) // 64)
+    return max(1, min(256 // max(tiles, 1), rows // 128, 32))
+
+
+def _accum_dw(dz, xin, gw, gb_view, x2=None, b_act=ACT_NONE, b_drop=NO_DROP, slope=None):
+    """gw (N_out, K_in) += dz^T @ f(xin (+x2));  gb_view (N_out) += colsum(dz)."""
+    rows = dz.shape[0]
+    s = _dw_split(gw.shape[0], gw.shape[1], rows)
+    kn.gemm(dz, xin, gw, trans_a=True, B2=x2, colsum=gb_view, b_act=b_act, b_drop=b_drop,
+            slope=slope, split_k=s, accumulate=1 if s == 1 else 2)
+
+
+def _rows(t, rows):
+    return t if rows is None else t[rows[0]:rows[1]]
+
+
+# ----------------------------------------------------------------------------- Linear
+class LinearFn(Function):
+    """y = dropout_out( relu?( dropout_in(x [+ x2]) @ W[rows]^T + b[rows] ) ) [+ residual].
+
+    Covers nn.Linear sites with their neighbours fused: with_pos_embed add (x2), the input
+    dropout of LinearLayer (model.py:421-431), ReLU (model.py:408,432), and
+    `residual + dropout(linear(.))` (transformer.py:534,538,645,648,753,792,795).
+    """
+
+    @staticmethod
+    def forward(ctx, x, x2, residual, w, b, rows, relu, in_drop, out_drop):
+        wv, bv = _rows(w, rows), (_rows(b, rows) if b is not None else None)
+        x = _c(x)
+        x2c = _c(x2) if x2 is not None else None
+        K = x.shape[-1]
+        N = wv.shape[0]
+        y = torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=torch.float32)
+        res2 = _2d(_c(residual)) if residual is not None else None
+        kn.gemm(_2d(x), wv, _2d(y), trans_b=True, A2=_2d(x2c) if x2c is not None else None,
+                bias=bv, e_act=ACT_RELU if relu else ACT_NONE, a_drop=in_drop, e_drop=out_drop,
+                residual=res2)
+        ctx.save_for_backward(x, x2c, y if relu else None)
+        ctx.w, ctx.b, ctx.rows = w, b, rows
+        ctx.relu, ctx.in_drop, ctx.out_drop = relu, in_drop, out_drop
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, x2, y = ctx.saved_tensors
+        w, b, rows = ctx.w, ctx.b, ctx.rows
+        dy = _c(dy)
+        dy2 = _2d(dy)
+        if ctx.out_drop[0] > 0:
+            dz = kn.dropout(dy2, *ctx.out_drop)
+        elif ctx.relu:
+            dz = kn.act_bias_bwd(dy2, _2d(y), ACT_RELU)
+        else:
+            dz = dy2
+        gw, wdirect = grad_target(w)
+        gb, bdirect = grad_target(b) if b is not None else (None, True)
+        _accum_dw(dz, _2d(x), _rows(gw, rows), _rows(gb, rows) if gb is not None else None,
+                  x2=_2d(x2) if x2 is not None else None, b_drop=ctx.in_drop)
+        dx = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dx = torch.empty_like(x)
+            kn.gemm(dz, _rows(w, rows), _2d(dx), e_drop=ctx.in_drop)
+        return (dx if ctx.needs_input_grad[0] else None,
+                dx if (x2 is not None and ctx.needs_input_grad[1]) else None,
+                dy if ctx.has_res and ctx.needs_input_grad[2] else None,
+                None if wdirect else gw, None if (b is None or bdirect) else gb,
+                None, None, None, None)
+
+
+def linear(x, w, b, *, x2=None, residual=None, rows=None, relu=False, in_drop=NO_DROP,
+           out_drop=NO_DROP):
+    return LinearFn.apply(x, x2, residual, w, b, rows, relu, in_drop, out_drop)
+
+
+# ----------------------------------------------------------------------------- FFN
+class FFNFn(Function):
+    """y = residual + dropout_out( dropout_mid(prelu(x W1^T + b1)) W2^T + b2 ).
+
+    linear2(dropout(activation(linear1(.)))) with activation = nn.PReLU (one learnable
+    slope) and the residual add: transformer.py:537-538, 603-604, 608-609, 647-648, 794-795.
+    The pre-activation z is the only saved intermediate; PReLU and the inner dropout are
+    re-applied while z is staged into LDS by the second GEMM and by the dW2 GEMM.
+    """
+
+    @staticmethod
+    def forward(ctx, x, residual, w1, b1, slope, w2, b2, mid_drop, out_drop):
+        x = _c(x)
+        F_ = w1.shape[0]
+        z = torch.empty(x.shape[:-1] + (F_,), device=x.device, dtype=torch.float32)
+        kn.gemm(_2d(x), w1, _2d(z), trans_b=True, bias=b1)
+        y = torch.empty_like(x)
+        kn.gemm(_2d(z), w2, _2d(y), trans_b=True, bias=b2, a_act=ACT_PRELU, slope=slope,
+                a_drop=mid_drop, e_drop=out_drop,
+                residual=_2d(_c(residual)) if residual is not None else None)
+        ctx.save_for_backward(x, z)
+        ctx.params = (w1, b1, slope, w2, b2)
+        ctx.mid_drop, ctx.out_drop = mid_drop, out_drop
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, z = ctx.saved_tensors
+        w1, b1, slope, w2, b2 = ctx.params
+        dy = _c(dy)
+        dy2 = _2d(dy)
+        dz2 = kn.dropout(dy2, *ctx.out_drop) if ctx.out_drop[0] > 0 else dy2
+        gw2, d_w2 = grad_target(w2)
+        gb2, d_b2 = grad_target(b2)
+        gw1, d_w1 = grad_target(w1)
+        gb1, d_b1 = grad_target(b1)
+        gs, d_s = grad_target(slope)
+        _accum_dw(dz2, _2d(z), gw2, gb2, b_act=ACT_PRELU, b_drop=ctx.mid_drop, slope=slope)
+        dz1 = torch.empty_like(z)
+        kn.gemm(dz2, w2, _2d(dz1), e_drop=ctx.mid_drop, aux=_2d(z), e_actgrad=ACT_PRELU,
+                slope=slope, dslope=gs)
+        _accum_dw(_2d(dz1), _2d(x), gw1, gb1)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            kn.gemm(_2d(dz1), w1, _2d(dx))
+        return (dx, dy if ctx.has_res and ctx.needs_input_grad[1] else None,
+                None if d_w1 else gw1, None if d_b1 else gb1, None if d_s else gs,
+                None if d_w2 else gw2, None if d_b2 else gb2, None, None)
+
+
+def ffn(x, residual, w1, b1, slope, w2, b2, mid_drop=NO_DROP, out_drop=NO_DROP):
+    return FFNFn.apply(x, residual, w1, b1, slope, w2, b2, mid_drop, out_drop)
+
+
+# ----------------------------------------------------------------------------- LayerNorm
+class LayerNormFn(Function):
+    """nn.LayerNorm over the last dim (transformer.py:536,539,646,649,754,793,796,400;
+    model.py:430)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = _c(x)
+        y, mean, rstd = kn.layernorm_fwd(x, gamma, beta, eps)
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.gamma, ctx.beta = gamma, beta
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd = ctx.saved_tensors
+        gg, dg = grad_target(ctx.gamma)
+        gb, db = grad_target(ctx.beta)
+        dx = kn.layernorm_bwd(_c(dy), x, ctx.gamma, mean, rstd, gg, gb)
+        return (dx if ctx.needs_input_grad[0] else None, None if dg else gg, None if db else gb, None)
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    return LayerNormFn.apply(x, gamma, beta, eps)
+
+
+# ----------------------------------------------------------------------------- attention core
+class AttentionFn(Function):
+    """softmax(scale * q k^T, masks) -> dropout -> @ v for packed heads, no projections:
+    the core of attention.py:329-386 (decoder self / cross attention, dk may differ from dv)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, H, kpad, qpad, scale, drop):
+        q, k, v = _c(q), _c(k), _c(v)
+        o, lse = kn.attn_fwd(q, k, v, H, kpad=kpad, qpad=qpad, scale=scale, drop=drop)
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.cfg = (H, kpad, qpad, scale, drop)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        H, kpad, qpad, scale, drop = ctx.cfg
+        dq, dk, dv = kn.attn_bwd(_c(do), q, k, v, o, lse, H, kpad=kpad, qpad=qpad, scale=scale,
+                                 drop=drop)
+        return dq, dk, dv, None, None, None, None, None
+
+
+def attention(q, k, v, H, kpad=None, qpad=None, scale=None, drop=NO_DROP):
+    if scale is None:
+        scale = (q.shape[-1] // H) ** -0.5
+    return AttentionFn.apply(q, k, v, H, kpad, qpad, scale, drop)
+
+
+# ----------------------------------------------------------------------------- packed MHA
+class MHAFn(Function):
+    """A whole nn.MultiheadAttention call plus its residual:
+
+        out = residual + dropout_out( out_proj( attn( (xq+pq) Wq, (xk+pk) Wk, xk Wv ) ) )
+
+    (transformer.py:523-534 cross-attention of the T2V layers, :642-645 encoder self
+    attention; in_proj_weight rows are q,k,v — torch/nn/functional.py multi_head_attention_forward).
+    `self_attn=True`: xq is xk (query = key input incl. pos, value = xq without pos): Q and
+    K projections run as ONE GEMM over in_proj_weight[0:2d].  Otherwise, when the key has no
+    positional term (use_txt_pos=False in every shipped config; SegSenRecon passes None),
+    K and V run as ONE GEMM over in_proj_weight[d:3d].
+    """
+
+    @staticmethod
+    def forward(ctx, xq, pq, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad, qpad, attn_drop,
+                out_drop, self_attn):
+        xq = _c(xq)
+        pq = _c(pq) if pq is not None else None
+        d = xq.shape[-1]
+        N, Lq = xq.shape[0], xq.shape[1]
+        dev = xq.device
+        if self_attn:
+            Lk = Lq
+            qkv = torch.empty(N, Lq, 3 * d, device=dev, dtype=torch.float32)
+            q2 = _2d(qkv)
+            kn.gemm(_2d(xq), w_in[:2 * d], q2[:, :2 * d], trans_b=True,
+                    A2=_2d(pq) if pq is not None else None, bias=b_in[:2 * d])
+            kn.gemm(_2d(xq), w_in[2 * d:], q2[:, 2 * d:], trans_b=True, bias=b_in[2 * d:])
+            q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+            xk = pk = None
+        else:
+            xk = _c(xk)
+            pk = _c(pk) if pk is not None else None
+            Lk = xk.shape[1]
+            q = torch.empty(N, Lq, d, device=dev, dtype=torch.float32)
+            kn.gemm(_2d(xq), w_in[:d], _2d(q), trans_b=True, A2=_2d(pq) if pq is not None else None,
+                    bias=b_in[:d])
+            kv = torch.empty(N, Lk, 2 * d, device=dev, dtype=torch.float32)
+            kv2 = _2d(kv)
+            if pk is None:
+                kn.gemm(_2d(xk), w_in[d:], kv2, trans_b=True, bias=b_in[d:])
+            else:
+                kn.gemm(_2d(xk), w_in[d:2 * d], kv2[:, :d], trans_b=True, A2=_2d(pk), bias=b_in[d:2 * d])
+                kn.gemm(_2d(xk), w_in[2 * d:], kv2[:, d:], trans_b=True, bias=b_in[2 * d:])
+            k, v = kv[..., :d], kv[..., d:]
+        o, lse = kn.attn_fwd(q, k, v, H, kpad=kpad, qpad=qpad, drop=attn_drop)
+        out = torch.empty(N, Lq, d, device=dev, dtype=torch.float32)
+        kn.gemm(_2d(o), w_out, _2d(out), trans_b=True, bias=b_out, e_drop=out_drop,
+                residual=_2d(_c(residual)) if residual is not None else None)
+        ctx.save_for_backward(xq, pq, xk, pk, q, k, v, o, lse)
+        ctx.params = (w_in, b_in, w_out, b_out)
+        ctx.cfg = (H, kpad, qpad, attn_drop, out_drop, self_attn, residual is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        xq, pq, xk, pk, q, k, v, o, lse = ctx.saved_tensors
+        w_in, b_in, w_out, b_out = ctx.params
+        H, kpad, qpad, attn_drop, out_drop, self_attn, has_res = ctx.cfg
+        d = xq.shape[-1]
+        N, Lq = xq.shape[0], xq.shape[1]
+        dev = xq.device
+        dy = _c(dy)
+        dy2 = _2d(dy)
+        dz = kn.dropout(dy2, *out_drop) if out_drop[0] > 0 else dy2
+        gwo, d_wo = grad_target(w_out)
+        gbo, d_bo = grad_target(b_out)
+        gwi, d_wi = grad_target(w_in)
+        gbi, d_bi = grad_target(b_in)
+        _accum_dw(dz, _2d(o), gwo, gbo)
+        do = torch.empty_like(o)
+        kn.gemm(dz, w_out, _2d(do))
+        need_q, need_pq = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_k, need_pk = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        dxq = dpq = dxk = dpk = None
+        if self_attn:
+            dqkv = torch.zeros(N, Lq, 3 * d, device=dev, dtype=torch.float32)
+            kn.attn_bwd_into(do, q, k, v, o, lse, H, dqkv[..., :d], dqkv[..., d:2 * d],
+                             dqkv[..., 2 * d:], kpad=kpad, qpad=qpad, drop=attn_drop)
+            g2 = _2d(dqkv)
+            _accum_dw(g2[:, :2 * d], _2d(xq), gwi[:2 * d], gbi[:2 * d],
+                      x2=_2d(pq) if pq is not None else None)
+            _accum_dw(g2[:, 2 * d:], _2d(xq), gwi[2 * d:], gbi[2 * d:])
+            if need_q or need_pq:
+                dqk_in = torch.empty_like(xq)  # gradient of (xq + pq) through q and k
+                kn.gemm(g2[:, :2 * d], w_in[:2 * d], _2d(dqk_in))
+                if need_pq:
+                    dpq = dqk_in
+                if need_q:
+                    dxq = torch.empty_like(xq)
+                    kn.gemm(g2[:, 2 * d:], w_in[2 * d:], _2d(dxq), residual=_2d(dqk_in))
+        else:
+            Lk = xk.shape[1]
+            dq = torch.zeros(N, Lq, d, device=dev, dtype=torch.float32)
+            dkv = torch.empty(N, Lk, 2 * d, device=dev, dtype=torch.float32)
+            kn.attn_bwd_into(do, q, k, v, o, lse, H, dq, dkv[..., :d], dkv[..., d:], kpad=kpad,
+                             qpad=qpad, drop=attn_drop)
+            _accum_dw(_2d(dq), _2d(xq), gwi[:d], gbi[:d], x2=_2d(pq) if pq is not None else None)
+            g2 = _2d(dkv)
+            if pk is None:
+                _accum_dw(g2, _2d(xk), gwi[d:], gbi[d:])
+            else:
+                _accum_dw(g2[:, :d], _2d(xk), gwi[d:2 * d], gbi[d:2 * d], x2=_2d(pk))
+                _accum_dw(g2[:, d:], _2d(xk), gwi[2 * d:], gbi[2 * d:])
+            if need_q or need_pq:
+                dxq = torch.empty_like(xq)
+                kn.gemm(_2d(dq), w_in[:d], _2d(dxq))
+                dpq = dxq if need_pq else None
+                dxq = dxq if need_q else None
+            if need_k or need_pk:
+                if pk is None:
+                    dxk = torch.empty_like(xk)
+                    kn.gemm(g2, w_in[d:], _2d(dxk))
+                else:
+                    dk_in = torch.empty_like(xk)
+                    kn.gemm(g2[:, :d], w_in[d:2 * d], _2d(dk_in))
+                    dpk = dk_in if need_pk else None
+                    if need_k:
+                        dxk = torch.empty_like(xk)
+                        kn.gemm(g2[:, d:], w_in[2 * d:], _2d(dxk), residual=_2d(dk_in))
+        return (dxq, dpq, dxk, dpk, dy if has_res and ctx.needs_input_grad[4] else None,
+                None if d_wi else gwi, None if d_bi else gbi, None if d_wo else gwo,
+                None if d_bo else gbo, None, None, None, None, None, None)
+
+
+def mha(xq, pq, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad=None, qpad=None,
+        attn_drop=NO_DROP, out_drop=NO_DROP, self_attn=False):
+    return MHAFn.apply(xq, pq, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad, qpad, attn_drop,
+                       out_drop, self_attn)
+
+
+# ----------------------------------------------------------------------------- sine embeddings
+class QuerySineFn(Function):
+    """gen_sineembed_for_position, transformer.py:43-59 (gradient flows to the reference
+    points of decoder layer 0)."""
+
+    @staticmethod
+    def forward(ctx, ref, D):
+        ref = _c(ref)
+        ctx.save_for_backward(ref)
+        return kn.query_sine_fwd(ref, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (ref,) = ctx.saved_tensors
+        return kn.query_sine_bwd(ref, _c(dout)), None
+
+
+def query_sine(ref, D):
+    return QuerySineFn.apply(ref, D)
+
+
+# ----------------------------------------------------------------------------- losses
+class NLLSmoothFn(Function):
+    """Criterion.cal_nll_loss (criterion.py:291-306): per-row label-smoothed NLL, 0 on masked rows."""
+
+    @staticmethod
+    def forward(ctx, logit, label, mask, eps):
+        logit = _c(logit)
+        C = logit.shape[-1]
+        l2 = logit.view(-1, C)
+        row_loss, row_lse, correct = kn.nll_smooth_fwd(l2, _c(label).view(-1), _c(mask).view(-1), eps)
+        ctx.save_for_backward(l2, _c(label).view(-1), row_lse, _c(mask).view(-1))
+        ctx.eps = eps
+        ctx.shape = logit.shape
+        correct = correct.view(logit.shape[:-1])
+        ctx.mark_non_differentiable(correct)
+        return row_loss.view(logit.shape[:-1]), correct
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_correct):
+        l2, label, row_lse, mask = ctx.saved_tensors
+        rg = (_c(g_loss).view(-1) * mask.to(torch.float32)).contiguous()
+        dl = kn.nll_smooth_bwd(l2, label, row_lse, rg, ctx.eps)
+        return dl.view(ctx.shape), None, None, None
+
+
+def nll_smooth(logit, label, mask, eps=0.1):
+    return NLLSmoothFn.apply(logit, label, mask, eps)
+
+
+class SaliencyLossFn(Function):
+    """Criterion.loss_saliency (criterion.py:139-221) as one fused reduction."""
+
+    @staticmethod
+    def forward(ctx, s_pos, s_neg, label64, vmask, pos_idx, neg_idx, rank_coef, margin):
+        s_pos, s_neg = _c(s_pos), _c(s_neg)
+        out = kn.saliency_loss_fwd(s_pos, s_neg, label64, vmask, pos_idx, neg_idx, rank_coef, margin)
+        ctx.save_for_backward(s_pos, s_neg, label64, vmask, pos_idx, neg_idx)
+        ctx.cfg = (rank_coef, margin)
+        return out.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        s_pos, s_neg, label64, vmask, pos_idx, neg_idx = ctx.saved_tensors
+        gs = g.reshape(1).to(torch.float32).contiguous()
+        ds_pos, ds_neg = kn.saliency_loss_bwd(s_pos, s_neg, label64, vmask, pos_idx, neg_idx,
+                                              ctx.cfg[0], ctx.cfg[1], gs)
+        return ds_pos, ds_neg, None, None, None, None, None, None
+
+
+def saliency_loss(s_pos, s_neg, label64, vmask, pos_idx, neg_idx, rank_coef, margin):
+    return SaliencyLossFn.apply(s_pos, s_neg, label64, vmask, pos_idx, neg_idx, rank_coef, margin)

@@ -1,0 +1,253 @@
+"""End-to-end parity of the HIP build on the MI355X:
+
+  * against the golden vectors produced by the REAL reference (tests/golden/*.npz): outputs,
+    losses, matched indices (bit-exact), parameter gradients;
+  * against the CPU oracle on freshly seeded inputs at the reference hidden size (d = 256);
+  * train-mode (dropout on) consistency of the fused autograd blocks.
+
+Tolerance: 1e-4 relative to the tensor scale for fp32 values (north-star budget); integer
+results (matched query indices) must be identical.
+"""
+import argparse
+
+import pytest
+import torch
+
+from golden_io import CASES, Fixture
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-3)
+
+
+def build(cfg, sd):
+    from mesm_amd import build_criterion, build_model
+    args = argparse.Namespace(**cfg)
+    args.device = "cuda:0"
+    model = build_model(args)
+    model.load_state_dict(sd)
+    crit = build_criterion(args)
+    return args, model, crit
+
+
+def run_step(model, crit, batch_cpu, cfg, neg_index, masked_words, train=False):
+    from mesm_amd import synthetic
+    batch = synthetic.to_device(batch_cpu, dev())
+    model.train(train)
+    out = model(**batch, dataset_name=cfg["dataset_name"], is_training=True, neg_index=neg_index,
+                masked_words=masked_words)
+    losses, total = crit(out, batch, True)
+    model.zero_grad()
+    total.backward()
+    torch.cuda.synchronize()
+    return out, losses, total
+
+
+@pytest.fixture(scope="module", params=CASES)
+def golden_step(request):
+    fx = Fixture(request.param)
+    args, model, crit = build(fx.cfg, fx.sd)
+    out, losses, total = run_step(model, crit, fx.batch, fx.cfg, fx.neg_index, fx.masked_words)
+    return fx, model, crit, out, losses, total
+
+
+def test_outputs_match_reference_golden(golden_step):
+    fx, _, _, out, _, _ = golden_step
+    for k in ("pred_logits", "pred_spans", "saliency_scores", "neg_saliency_scores",
+              "recfw_words_logit", "recon_feat", "projed_recon_feat", "projed_video_feat",
+              "expanded_words_feat", "enhanced_video_feat", "projed_words_feat"):
+        assert rel(out[k], fx.out[k]) < TOL, k
+    assert rel(out["aux_outputs"][0]["pred_logits"], fx.out["aux0.pred_logits"]) < TOL
+    assert rel(out["aux_outputs"][0]["pred_spans"], fx.out["aux0.pred_spans"]) < TOL
+    assert torch.equal(out["expanded_words_mask"].cpu(), fx.out["expanded_words_mask"].bool())
+    assert torch.equal(out["words_mask"].cpu(), fx.out["words_mask"].bool())
+
+
+def test_losses_match_reference_golden(golden_step):
+    fx, _, _, _, losses, total = golden_step
+    for k, v in fx.losses.items():
+        got = float(total) if k == "total" else float(losses[k])
+        assert abs(got - v) < TOL * max(1.0, abs(v)), (k, got, v)
+
+
+def test_matched_indices_bit_exact(golden_step):
+    fx, _, crit, _, _, _ = golden_step
+    qvh = fx.cfg["dataset_name"] == "qvhighlights"
+    for layer, mq in zip(["main", "aux0"], crit.last_match):
+        mq = mq.cpu().tolist()
+        sizes = fx.match["%s.sizes" % layer].tolist()
+        got, k = set(), 0
+        for b, s in enumerate(sizes):
+            for t in range(s):
+                got.add((b, mq[k], t if qvh else 0))
+                k += 1
+        assert got == fx.matched_pairs(layer), layer
+
+
+def test_matcher_module_returns_reference_format(golden_step):
+    fx, _, crit, out, _, _ = golden_step
+    from mesm_amd import synthetic
+    batch = synthetic.to_device(fx.batch, dev())
+    res = crit.matcher({k: v for k, v in out.items() if k != "aux_outputs"}, batch)
+    if fx.cfg["dataset_name"] == "qvhighlights":
+        q = torch.cat([a for a, _ in res])
+        t = torch.cat([b for _, b in res])
+        assert torch.equal(q, fx.match["main.q"]) and torch.equal(t, fx.match["main.t"])
+    else:
+        assert torch.equal(res[:, 0], fx.match["main.q"]) and torch.equal(res[:, 1], fx.match["main.t"])
+
+
+def test_gradients_match_reference_golden(golden_step):
+    fx, model, _, _, _, _ = golden_step
+    grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    assert set(grads) == set(fx.grads), sorted(set(grads) ^ set(fx.grads))
+    worst = max((rel(grads[k], g), k) for k, g in fx.grads.items())
+    assert worst[0] < 5 * TOL, worst
+    gb = model.gradbuf()
+    for n, p in model.named_parameters():
+        if p.grad is not None:
+            assert p.grad.data_ptr() == p._mesm_gview.data_ptr(), n  # lives in the flat buffer
+
+
+def test_second_step_after_zero_grad_gives_same_gradients(golden_step):
+    fx, model, crit, _, _, _ = golden_step
+    g1 = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    # train.py order: forward, criterion, optimizer.zero_grad() (set_to_none), backward
+    from mesm_amd import synthetic
+    batch = synthetic.to_device(fx.batch, dev())
+    out = model(**batch, dataset_name=fx.cfg["dataset_name"], is_training=True,
+                neg_index=fx.neg_index, masked_words=fx.masked_words)
+    _, total = crit(out, batch, True)
+    model.zero_grad(set_to_none=True)
+    total.backward()
+    for n, p in model.named_parameters():
+        if n in g1:
+            assert rel(p.grad, g1[n]) < 1e-5, n
+        else:
+            assert p.grad is None, n
+    # and accumulation without zeroing doubles them
+    out = model(**batch, dataset_name=fx.cfg["dataset_name"], is_training=True,
+                neg_index=fx.neg_index, masked_words=fx.masked_words)
+    _, total = crit(out, batch, True)
+    total.backward()
+    for n, p in model.named_parameters():
+        if n in g1:
+            assert rel(p.grad, 2 * g1[n]) < 1e-5, n
+
+
+# ----------------------------------------------------------------------------- oracle at d=256
+@pytest.mark.parametrize("dataset,groups,Lv,Lw,ragged", [
+    ("qvhighlights", [2, 1, 3, 2], 75, 32, True),
+    ("charades", [2, 2, 1], 75, 16, False),
+])
+def test_against_cpu_oracle_at_reference_width(dataset, groups, Lv, Lw, ragged):
+    from mesm_amd import build_criterion, build_model, synthetic
+    from oracle import mesm_oracle as O
+    over = dict(dataset_name=dataset, v_feat_dim=130, t_feat_dim=64, vocab_size=301, share_MLP=True,
+                set_cost_class=4, loss_label_coef=4, rank_coef=12 if dataset == "qvhighlights" else 1,
+                use_triplet=dataset == "qvhighlights", loss_recfw_coef=0.5, loss_recss_coef=0.1,
+                max_video_l=Lv, max_words_l=Lw, device="cuda:0")
+    args = synthetic.make_args(None, **over)
+    torch.manual_seed(5)
+    model = build_model(args)
+    with torch.no_grad():
+        for n_, p in model.named_parameters():
+            if n_.endswith("_token") or "masked_sent_token" in n_:
+                p.normal_(0, 0.5)
+    crit = build_criterion(args)
+    batch = synthetic.make_batch(dataset, groups, Lv, Lw, 130, 64, 302, seed=3, ragged=ragged)
+    neg, masked = synthetic.host_draws(batch, seed=3)
+    out, losses, total = run_step(model, crit, batch, vars(args), neg, masked)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    cfg = dict(vars(args))
+    o_out, o_losses, o_total, o_grads, o_idx = O.train_step(sd, cfg, batch, neg, masked)
+    for k in ("pred_logits", "pred_spans", "saliency_scores", "neg_saliency_scores", "recfw_words_logit"):
+        assert rel(out[k], o_out[k]) < TOL, k
+    for k, v in o_losses.items():
+        assert abs(float(losses[k]) - float(v)) < TOL * max(1.0, abs(float(v))), k
+    assert abs(float(total) - float(o_total)) < TOL * max(1.0, abs(float(o_total)))
+    # matched indices
+    mq = crit.last_match[0].cpu().tolist()
+    want = []
+    for q, t in o_idx[0]:
+        order = torch.argsort(t)
+        want += q[order].tolist()
+    assert mq == want
+    grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    assert set(grads) == set(o_grads)
+    worst = max((rel(grads[k], g), k) for k, g in o_grads.items())
+    assert worst[0] < 5 * TOL, worst
+
+
+# ----------------------------------------------------------------------------- dropout consistency
+def test_fused_blocks_with_dropout_match_autograd_on_materialised_masks():
+    """Train mode: the in-kernel dropout of LinearFn / FFNFn must equal applying the same
+    counter-hash masks explicitly and differentiating with torch autograd."""
+    from mesm_amd import kernels as kn, ops
+    g = torch.Generator().manual_seed(9)
+    M, K, Fd = 300, 64, 128
+    x = torch.randn(M, K, generator=g).to(dev()).requires_grad_(True)
+    w1 = (torch.randn(Fd, K, generator=g) * 0.2).to(dev()).requires_grad_(True)
+    b1 = (torch.randn(Fd, generator=g) * 0.1).to(dev()).requires_grad_(True)
+    w2 = (torch.randn(K, Fd, generator=g) * 0.2).to(dev()).requires_grad_(True)
+    b2 = (torch.randn(K, generator=g) * 0.1).to(dev()).requires_grad_(True)
+    slope = torch.tensor([0.25], device=dev(), requires_grad=True)
+    mid, outd = (0.1, 11), (0.1, 22)
+    y = ops.ffn(x, x, w1, b1, slope, w2, b2, mid_drop=mid, out_drop=outd)
+    gy = torch.randn(M, K, generator=g).to(dev())
+    y.backward(gy)
+    got = [t.grad.clone() for t in (x, w1, b1, w2, b2, slope)]
+    for t in (x, w1, b1, w2, b2, slope):
+        t.grad = None
+    m_mid = kn.dropout(torch.ones(M, Fd, device=dev()), *mid)
+    m_out = kn.dropout(torch.ones(M, K, device=dev()), *outd)
+    z = x @ w1.t() + b1
+    hdn = torch.where(z > 0, z, slope * z) * m_mid
+    ref = x + (hdn @ w2.t() + b2) * m_out
+    assert rel(y, ref) < TOL
+    ref.backward(gy)
+    for a, t, name in zip(got, (x, w1, b1, w2, b2, slope), "x w1 b1 w2 b2 slope".split()):
+        assert rel(a, t.grad) < 2 * TOL, name
+    # LinearLayer-style: input dropout + relu
+    for t in (x, w1, b1):
+        t.grad = None
+    ind = (0.5, 33)
+    y = ops.linear(x, w1, b1, relu=True, in_drop=ind)
+    gy = torch.randn(M, Fd, generator=g).to(dev())
+    y.backward(gy)
+    got = [t.grad.clone() for t in (x, w1, b1)]
+    for t in (x, w1, b1):
+        t.grad = None
+    m_in = kn.dropout(torch.ones(M, K, device=dev()), *ind)
+    ref = torch.relu((x * m_in) @ w1.t() + b1)
+    assert rel(y, ref) < TOL
+    ref.backward(gy)
+    for a, t, name in zip(got, (x, w1, b1), "x w1 b1".split()):
+        assert rel(a, t.grad) < 2 * TOL, name
+
+
+def test_train_mode_step_is_finite_and_seed_dependent():
+    fx = Fixture("qvh_tiny")
+    args, model, crit = build(fx.cfg, fx.sd)
+    _, _, t1 = run_step(model, crit, fx.batch, fx.cfg, fx.neg_index, fx.masked_words, train=True)
+    _, _, t2 = run_step(model, crit, fx.batch, fx.cfg, fx.neg_index, fx.masked_words, train=True)
+    assert torch.isfinite(t1) and torch.isfinite(t2)
+    assert float(t1) != float(t2)  # a new dropout seed every step
+    for n, p in model.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all(), n
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    fx = Fixture("charades_tiny")
+    args, model, crit = build(fx.cfg, fx.sd)
+    with pytest.raises(Exception):
+        model(**fx.batch, dataset_name=fx.cfg["dataset_name"], is_training=True)
