@@ -114,6 +114,16 @@ typedef struct MesmGemmArgs {
 
 int mesm_gemm_f32(const MesmGemmArgs* args, void* stream);
 
+/*
+ * Launch-duration instrumentation of mesm_gemm_f32 (the dominant kernel of the step) for
+ * bench.py's roofline object: while enabled, every GEMM launch is bracketed by two HIP events
+ * recorded on the launch stream and its algorithmic FLOPs (2*M*N*K) are tallied.
+ * mesm_profile_read synchronises on the recorded events (host-blocking; not for use inside a
+ * timed region), returns the sums since the last read and clears them.
+ */
+int mesm_profile_enable(int32_t on);
+int mesm_profile_read(double* total_ms, int64_t* launches, double* total_flops);
+
 /* ------------------------------------------------------------------------- */
 /*
  * LayerNorm over the last dim, rows x D, eps inside the sqrt (torch semantics).

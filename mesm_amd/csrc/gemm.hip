@@ -9,6 +9,9 @@
 // global -> registers -> LDS (a transpose is needed when the reduce index is the
 // contiguous one, which LDS-DMA cannot do) and double-buffered: the global loads of
 // tile t+1 are in flight while tile t is multiplied.
+#include <utility>
+#include <vector>
+
 #include "common.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -344,6 +347,13 @@ int launch_tile(const MesmGemmArgs& a, hipStream_t s) {
   return launch_layout<64, 64, VEC>(a, s);
 }
 
+struct ProfState {
+  bool on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  double flops = 0.0;
+};
+ProfState g_prof;
+
 inline bool aligned_to(const void* p, size_t b) { return p == nullptr || ((uintptr_t)p % b) == 0; }
 
 }  // namespace
@@ -381,7 +391,44 @@ extern "C" int mesm_gemm_f32(const MesmGemmArgs* args, void* stream) {
     vec >>= 1;
   }
   if (!aligned_to(a.A, 4) || !aligned_to(a.B, 4) || !aligned_to(a.C, 4)) return MESM_EALIGN;
-  if (vec == 4) return launch_tile<4>(a, s);
-  if (vec == 2) return launch_tile<2>(a, s);
-  return launch_tile<1>(a, s);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (g_prof.on) {
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipEventRecord(e0, s);
+  }
+  int rc;
+  if (vec == 4) rc = launch_tile<4>(a, s);
+  else if (vec == 2) rc = launch_tile<2>(a, s);
+  else rc = launch_tile<1>(a, s);
+  if (g_prof.on) {
+    hipEventRecord(e1, s);
+    g_prof.events.emplace_back(e0, e1);
+    g_prof.flops += 2.0 * (double)a.M * (double)a.N * (double)a.K;
+  }
+  return rc;
+}
+
+extern "C" int mesm_profile_enable(int32_t on) {
+  g_prof.on = on != 0;
+  return MESM_OK;
+}
+
+extern "C" int mesm_profile_read(double* total_ms, int64_t* launches, double* total_flops) {
+  if (!total_ms || !launches || !total_flops) return MESM_EINVAL;
+  double ms = 0.0;
+  for (auto& pr : g_prof.events) {
+    hipEventSynchronize(pr.second);
+    float t = 0.0f;
+    hipEventElapsedTime(&t, pr.first, pr.second);
+    ms += t;
+    hipEventDestroy(pr.first);
+    hipEventDestroy(pr.second);
+  }
+  *total_ms = ms;
+  *launches = (int64_t)g_prof.events.size();
+  *total_flops = g_prof.flops;
+  g_prof.events.clear();
+  g_prof.flops = 0.0;
+  return MESM_OK;
 }

@@ -85,7 +85,7 @@ class GradBuffer:
             v.copy_(g)
             p.grad = v
         if self.on_ready is not None:
-            self.on_ready(p)
+            _touched.append(p)  # reported by flush_ready() once the writing kernels are enqueued
         return v
 
     def zero(self):
@@ -96,6 +96,19 @@ class GradBuffer:
         """Point every parameter's .grad at its view (used by graph-captured steps)."""
         for p in self.params:
             p.grad = p._mesm_gview
+
+
+_touched = []
+
+
+def flush_ready():
+    """Called at the end of every backward block: the kernels that accumulate into the views
+    handed out since the last flush are now enqueued, so a reducer may order a collective after them."""
+    while _touched:
+        p = _touched.pop()
+        gb = p._mesm_gb
+        if gb.on_ready is not None:
+            gb.on_ready(p)
 
 
 def grad_target(p):

@@ -323,3 +323,14 @@ def match(logits, spans, tgt_cxw, tgt_xx, tgt_off, Tmax, w_span, w_giou, w_class
                            float(w_giou), float(w_class), ptr(cost), ptr(match_q), stream_ptr()),
           "mesm_match")
     return (match_q, cost) if want_cost else match_q
+
+
+# ----------------------------------------------------------------------------- instrumentation
+def profile_enable(on):
+    check(lib().mesm_profile_enable(1 if on else 0), "mesm_profile_enable")
+
+
+def profile_read():
+    ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+    check(lib().mesm_profile_read(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "mesm_profile_read")
+    return {"ms": ms.value, "launches": n.value, "flops": fl.value}

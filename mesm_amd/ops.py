@@ -13,7 +13,7 @@ from torch.autograd import Function
 
 from . import kernels as kn
 from ._lib import ACT_NONE, ACT_PRELU, ACT_RELU
-from .gradbuf import grad_target
+from .gradbuf import flush_ready, grad_target
 
 NO_DROP = (0.0, 0)
 
@@ -114,6 +114,7 @@ class LinearFn(Function):
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             dx = torch.empty_like(x)
             kn.gemm(dz, _rows(w, rows), _2d(dx), e_drop=ctx.in_drop)
+        flush_ready()
         return (dx if ctx.needs_input_grad[0] else None,
                 dx if (x2 is not None and ctx.needs_input_grad[1]) else None,
                 dy if ctx.has_res and ctx.needs_input_grad[2] else None,
@@ -173,6 +174,7 @@ class FFNFn(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             kn.gemm(_2d(dz1), w1, _2d(dx))
+        flush_ready()
         return (dx, dy if ctx.has_res and ctx.needs_input_grad[1] else None,
                 None if d_w1 else gw1, None if d_b1 else gb1, None if d_s else gs,
                 None if d_w2 else gw2, None if d_b2 else gb2, None, None)
@@ -201,6 +203,7 @@ class LayerNormFn(Function):
         gg, dg = grad_target(ctx.gamma)
         gb, db = grad_target(ctx.beta)
         dx = kn.layernorm_bwd(_c(dy), x, ctx.gamma, mean, rstd, gg, gb)
+        flush_ready()
         return (dx if ctx.needs_input_grad[0] else None, None if dg else gg, None if db else gb, None)
 
 
@@ -357,6 +360,7 @@ class MHAFn(Function):
                     if need_k:
                         dxk = torch.empty_like(xk)
                         kn.gemm(g2[:, d:], w_in[2 * d:], _2d(dxk), residual=_2d(dk_in))
+        flush_ready()
         return (dxq, dpq, dxk, dpk, dy if has_res and ctx.needs_input_grad[4] else None,
                 None if d_wi else gwi, None if d_bi else gbi, None if d_wo else gwo,
                 None if d_bo else gbo, None, None, None, None, None, None)
