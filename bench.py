@@ -40,7 +40,30 @@ def parse():
     ap.add_argument("--workload", default="C3a")
     ap.add_argument("--cpu-steps", type=int, default=3, help="oracle steps for cpu_baseline (0 = skip)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="launch every kernel from Python (no HIP graph)")
     return ap.parse_args()
+
+
+def log(msg):
+    print("[bench %8.2fs] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
+
+
+T_START = time.perf_counter()
+
+
+def host_cores():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    # respect a cgroup CPU quota if there is one
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def main():
@@ -67,19 +90,35 @@ def main():
     model = build_model(args)
     crit = build_criterion(args)
     model.train()
-    reducer = GradReducer(model.gradbuf()) if world > 1 else None
+    from mesm_amd.graphed import GraphedStep
 
     batch_cpu = synthetic.workload_batch(opt.workload, seed=rank)
     batch = synthetic.to_device(batch_cpu, dev)
     n_pairs = batch_cpu["video_feat"].shape[0]
     torch.manual_seed(99 + rank)
 
-    def step():
+    def eager_step():
         out = model(**batch, dataset_name=args.dataset_name, is_training=True)
         losses, total = crit(out, batch, True)
         model.zero_grad(set_to_none=True)
         total.backward()  # the reducer's finish() runs as an engine callback for world > 1
         return total
+
+    if opt.eager:
+        reducer = GradReducer(model.gradbuf()) if world > 1 else None
+        step = eager_step
+    else:
+        # one HIP graph per step: forward + criterion + backward; fresh host draws + dropout masks
+        # every replay; for N > 1 the flat gradient buffer is all-reduced right after the replay
+        gstep = GraphedStep(model, crit, batch, args.dataset_name)
+        reducer = GradReducer(model.gradbuf(), hook=False) if world > 1 else None
+        log("step captured in a HIP graph")
+
+        def step():
+            total = gstep.run(redraw=True)
+            if reducer is not None:
+                reducer.finish()
+            return total
 
     def fence():
         torch.cuda.synchronize()
@@ -87,9 +126,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(opt.warmup):
+    log("model built (%d params), starting warm-up" % sum(p.numel() for p in model.parameters()))
+    for i in range(opt.warmup):
         step()
+        if i == 0:
+            torch.cuda.synchronize()
+            log("first step done")
     fence()
+    log("warm-up done")
     t0 = time.perf_counter()
     for _ in range(opt.steps):
         last = step()
@@ -100,15 +144,30 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert torch.isfinite(last), "non-finite loss in the timed region"
+    log("timed region: %.3f ms/step" % (dt / opt.steps * 1e3))
 
     roofline = None
     if not opt.no_roofline:
-        kn.profile_enable(True)
-        for _ in range(opt.steps):
-            step()
-        torch.cuda.synchronize()
-        prof = kn.profile_read()
-        kn.profile_enable(False)
+        if opt.eager:
+            model.gradbuf().on_ready = None
+            kn.profile_enable(True)
+            for _ in range(opt.steps):
+                eager_step()
+            torch.cuda.synchronize()
+            prof = kn.profile_read(clear=True)
+            kn.profile_enable(False)
+        else:
+            # a second capture of the same step whose GEMM launches are bracketed by external event
+            # nodes; every replay re-stamps them, so the durations are those inside the graph
+            istep = GraphedStep(model, crit, batch, args.dataset_name, warmup=1, instrument=True)
+            prof = {"ms": 0.0, "launches": 0, "flops": 0.0}
+            for _ in range(opt.steps):
+                istep.run(redraw=True)
+                torch.cuda.synchronize()
+                r = kn.profile_read(clear=False)
+                for k in prof:
+                    prof[k] += r[k]
+            kn.profile_read(clear=True)
         if prof["launches"] > 0:
             avg_ms = prof["ms"] / prof["launches"]
             flops_per_launch = prof["flops"] / prof["launches"]
@@ -126,9 +185,11 @@ def main():
         sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
         cfg = dict(vars(args))
         neg, masked = synthetic.host_draws(batch_cpu, seed=0)
-        ncores = os.cpu_count() or 1
+        ncores = min(host_cores(), 64)
         torch.set_num_threads(ncores)
+        log("cpu baseline on %d threads" % ncores)
         O.train_step(sd, cfg, batch_cpu, neg, masked)  # warm-up
+        log("cpu warm-up step done")
         c0 = time.perf_counter()
         for _ in range(opt.cpu_steps):
             O.train_step(sd, cfg, batch_cpu, neg, masked)
@@ -148,7 +209,8 @@ def main():
                                    "Dv=%d, Dt=%d, C=%d, 10 moment queries, train mode (dropout on)"
                                    % (opt.workload, n_pairs, len(wl["groups"]), wl["Lv"], wl["Lw"],
                                       wl["v_feat_dim"], wl["t_feat_dim"], wl["vocab_size"] + 1),
-                       "global_pairs": n_pairs * world, "parallelism": "dp%d" % world},
+                       "global_pairs": n_pairs * world, "parallelism": "dp%d" % world,
+                       "launch": "eager" if opt.eager else "hip-graph"},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line), flush=True)

@@ -110,6 +110,9 @@ typedef struct MesmGemmArgs {
   float out_scale;
   int32_t accumulate;
   int32_t split_k;
+  /* optional device scalar added to every dropout seed of this launch at run time, so a
+     captured HIP graph draws fresh masks on every replay (NULL = 0) */
+  const uint32_t* seed_offset;
 } MesmGemmArgs;
 
 int mesm_gemm_f32(const MesmGemmArgs* args, void* stream);
@@ -117,12 +120,15 @@ int mesm_gemm_f32(const MesmGemmArgs* args, void* stream);
 /*
  * Launch-duration instrumentation of mesm_gemm_f32 (the dominant kernel of the step) for
  * bench.py's roofline object: while enabled, every GEMM launch is bracketed by two HIP events
- * recorded on the launch stream and its algorithmic FLOPs (2*M*N*K) are tallied.
- * mesm_profile_read synchronises on the recorded events (host-blocking; not for use inside a
- * timed region), returns the sums since the last read and clears them.
+ * on the launch stream and its algorithmic FLOPs (2*M*N*K) are tallied.  When the stream is
+ * being captured into a HIP graph the events are recorded as EXTERNAL event nodes
+ * (hipEventRecordExternal), so they are re-stamped by every replay of that graph.
+ * mesm_profile_read synchronises on the recorded events (host-blocking; never inside a timed
+ * region) and returns the sum of their elapsed times, the number of bracketed launches and their
+ * FLOPs; clear != 0 destroys the events (otherwise they stay valid for the next replay).
  */
 int mesm_profile_enable(int32_t on);
-int mesm_profile_read(double* total_ms, int64_t* launches, double* total_flops);
+int mesm_profile_read(double* total_ms, int64_t* launches, double* total_flops, int32_t clear);
 
 /* ------------------------------------------------------------------------- */
 /*
@@ -188,6 +194,7 @@ typedef struct MesmAttnArgs {
   float* dq;        /* strides q_bs/q_ls; MUST be zero-initialised when Lk > 64 */
   float* dk_;       /* strides k_bs/k_ls */
   float* dv_;       /* strides v_bs/v_ls */
+  const uint32_t* seed_offset; /* see MesmGemmArgs.seed_offset */
 } MesmAttnArgs;
 
 int mesm_attn_fwd(const MesmAttnArgs* args, void* stream);
@@ -224,7 +231,7 @@ int mesm_query_sine_bwd(const float* ref, const float* dout, float* dref, int64_
  * lets tests materialise the exact mask.  In-place allowed (y == x).
  */
 int mesm_dropout(const float* x, float* y, int64_t n, float p, uint32_t seed,
-                 void* stream);
+                 const uint32_t* seed_offset, void* stream);
 
 /*
  * Activation backward + bias gradient: dz = dy * act'(ref), dbias[c] += sum_rows dz,

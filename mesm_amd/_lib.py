@@ -39,6 +39,7 @@ class GemmArgs(ctypes.Structure):
         ("e_drop_p", ctypes.c_float), ("e_drop_seed", ctypes.c_uint32),
         ("out_scale", ctypes.c_float),
         ("accumulate", ctypes.c_int32), ("split_k", ctypes.c_int32),
+        ("seed_offset", c_ptr),
     ]
 
 
@@ -55,6 +56,7 @@ class AttnArgs(ctypes.Structure):
         ("scale", ctypes.c_float), ("drop_p", ctypes.c_float),
         ("drop_seed", ctypes.c_uint32),
         ("d_o", c_ptr), ("dq", c_ptr), ("dk_", c_ptr), ("dv_", c_ptr),
+        ("seed_offset", c_ptr),
     ]
 
 
@@ -66,7 +68,7 @@ PROTOTYPES = {
     "mesm_gemm_f32": (ctypes.c_int, [ctypes.POINTER(GemmArgs), c_ptr]),
     "mesm_profile_enable": (ctypes.c_int, [_i32]),
     "mesm_profile_read": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int64),
-                                         ctypes.POINTER(ctypes.c_double)]),
+                                         ctypes.POINTER(ctypes.c_double), _i32]),
     "mesm_layernorm_fwd": (ctypes.c_int, [c_ptr] * 6 + [_i64, _i32, _f32, c_ptr]),
     "mesm_layernorm_bwd": (ctypes.c_int, [c_ptr] * 8 + [_i64, _i32, _i32, c_ptr]),
     "mesm_attn_fwd": (ctypes.c_int, [ctypes.POINTER(AttnArgs), c_ptr]),
@@ -74,7 +76,7 @@ PROTOTYPES = {
     "mesm_sine_pos_fwd": (ctypes.c_int, [c_ptr, c_ptr, _i32, _i32, _i32, c_ptr]),
     "mesm_query_sine_fwd": (ctypes.c_int, [c_ptr, c_ptr, _i64, _i32, c_ptr]),
     "mesm_query_sine_bwd": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, _i64, _i32, c_ptr]),
-    "mesm_dropout": (ctypes.c_int, [c_ptr, c_ptr, _i64, _f32, _u32, c_ptr]),
+    "mesm_dropout": (ctypes.c_int, [c_ptr, c_ptr, _i64, _f32, _u32, c_ptr, c_ptr]),
     "mesm_act_bias_bwd": (ctypes.c_int, [c_ptr] * 6 + [_i64, _i32, _i32, c_ptr]),
     "mesm_nll_smooth_fwd": (ctypes.c_int, [c_ptr] * 6 + [_i64, _i32, _f32, c_ptr]),
     "mesm_nll_smooth_bwd": (ctypes.c_int, [c_ptr] * 5 + [_i64, _i32, _f32, c_ptr]),

@@ -63,6 +63,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const MesmAttnArgs
 
   const uint32_t thresh = p.drop_p > 0.f ? mesm_drop_threshold(p.drop_p) : 0u;
   const float inv_keep = 1.0f / (1.0f - p.drop_p);
+  const uint32_t drop_seed = p.drop_seed + (p.seed_offset ? *p.seed_offset : 0u);
 
   const int ntiles = (p.Lk + KT - 1) / KT;
   for (int t = 0; t < ntiles; ++t) {
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const MesmAttnArgs
       float pd = pj;
       if (thresh) {
         uint32_t idx = (uint32_t)(((int64_t)bh * p.Lq + i) * p.Lk + j);
-        pd = mesm_dropout_apply(pj, idx, p.drop_seed, thresh, inv_keep);
+        pd = mesm_dropout_apply(pj, idx, drop_seed, thresh, inv_keep);
       }
       Ps[wave * KT + lane] = pd;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -211,6 +212,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_kernel(const MesmAttnArgs
 
   const uint32_t thresh = p.drop_p > 0.f ? mesm_drop_threshold(p.drop_p) : 0u;
   const float inv_keep = 1.0f / (1.0f - p.drop_p);
+  const uint32_t drop_seed = p.drop_seed + (p.seed_offset ? *p.seed_offset : 0u);
 
   for (int qc = 0; qc < p.Lq; qc += QCB) {
     const int nq = (p.Lq - qc) < QCB ? (p.Lq - qc) : QCB;
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_kernel(const MesmAttnArgs
       float km = 1.0f;
       if (thresh) {
         uint32_t idx = (uint32_t)(((int64_t)bh * p.Lq + i) * p.Lk + j);
-        km = mesm_hash32(idx, p.drop_seed) >= thresh ? inv_keep : 0.0f;
+        km = mesm_hash32(idx, drop_seed) >= thresh ? inv_keep : 0.0f;
       }
       const float pd = pj * km;
       float dp = 0.0f;

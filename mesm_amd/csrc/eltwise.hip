@@ -84,7 +84,9 @@ __global__ __launch_bounds__(256) void query_sine_bwd_kernel(const float* __rest
 __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ x,
                                                      float* __restrict__ y, int64_t n,
                                                      uint32_t thresh, float inv_keep,
-                                                     uint32_t seed) {
+                                                     uint32_t seed,
+                                                     const uint32_t* __restrict__ seed_offset) {
+  if (seed_offset) seed += *seed_offset;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x)
     y[i] = mesm_dropout_apply(x[i], (uint32_t)i, seed, thresh, inv_keep);
@@ -155,13 +157,13 @@ extern "C" int mesm_query_sine_bwd(const float* ref, const float* dout, float* d
 }
 
 extern "C" int mesm_dropout(const float* x, float* y, int64_t n, float p, uint32_t seed,
-                            void* stream) {
+                            const uint32_t* seed_offset, void* stream) {
   if (!x || !y || n < 0 || p < 0.f || p >= 1.f) return MESM_EINVAL;
   if (n == 0) return MESM_OK;
   int64_t blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x,
-                     y, n, mesm_drop_threshold(p), 1.0f / (1.0f - p), seed);
+                     y, n, mesm_drop_threshold(p), 1.0f / (1.0f - p), seed, seed_offset);
   return mesm_launch_status();
 }
 
@@ -177,5 +179,5 @@ extern "C" int mesm_act_bias_bwd(const float* dy, const float* ref, float* dz, f
   return mesm_launch_status();
 }
 
-extern "C" int mesm_abi_version(void) { return 1; }
+extern "C" int mesm_abi_version(void) { return 2; }
 extern "C" const char* mesm_arch(void) { return "gfx950"; }

@@ -18,7 +18,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BK = 16;
+constexpr int BK = 32;
 constexpr int NTHREADS = 256;
 
 struct XForm {
@@ -30,14 +30,17 @@ struct XForm {
   int64_t lld;  // logical row length for the dropout index
 };
 
-// One operand tile: ROWS (outer index) x BK (reduce index).
-template <int ROWS, int LAYOUT, int VEC>
+// One operand tile: ROWS (outer index) x BK (reduce index), staged through registers.
+// Loads are written branch-free so that every global load of a k-step is in flight before
+// the first wait: full tiles use unguarded vector loads (rows clamped with a select), the
+// single K-tail tile uses clamped scalar loads + selects.
+template <int ROWS, int LAYOUT, int VEC, bool ADD>
 struct Tile {
   static constexpr int NVEC = ROWS * BK / (VEC * NTHREADS);
   static_assert(NVEC >= 1, "tile too small for the block");
   float r[NVEC][VEC];
+  float t[ADD ? NVEC : 1][VEC];
 
-  // outer index (relative to tile) and reduce index (relative to tile) of vector v.
   __device__ __forceinline__ static void coords(int tid, int v, int& o, int& k) {
     int vid = tid + v * NTHREADS;
     if (LAYOUT == MESM_LAYOUT_REDUCE_CONTIG) {
@@ -51,6 +54,21 @@ struct Tile {
     }
   }
 
+  __device__ __forceinline__ static void load_vec(const float* __restrict__ p, float* dst) {
+    if (VEC == 4) {
+      float4 x = *reinterpret_cast<const float4*>(p);
+      dst[0] = x.x; dst[1] = x.y; dst[2] = x.z; dst[3] = x.w;
+    } else if (VEC == 2) {
+      float2 x = *reinterpret_cast<const float2*>(p);
+      dst[0] = x.x; dst[1] = x.y;
+    } else {
+      dst[0] = *p;
+    }
+  }
+
+  // FULLK: every reduce index of the tile is < kend.  For OUTER_CONTIG operands the host
+  // guarantees extent % VEC == 0, so a vector is either fully inside or fully outside.
+  template <bool FULLK>
   __device__ __forceinline__ void load(const float* __restrict__ base,
                                        const float* __restrict__ add, int64_t ld, int o0,
                                        int extent, int k0, int kend, int tid) {
@@ -61,74 +79,53 @@ struct Tile {
       if (LAYOUT == MESM_LAYOUT_REDUCE_CONTIG) {
         int go = o0 + o;
         go = go < extent ? go : extent - 1;
-        int gk = k0 + k;
-        int64_t off = (int64_t)go * ld + gk;
-        if (gk + VEC <= kend) {
-          load_vec(base + off, r[v]);
-          if (add) {
-            float t[VEC];
-            load_vec(add + off, t);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) r[v][e] += t[e];
-          }
+        const int gk = k0 + k;
+        const int64_t rowoff = (int64_t)go * ld;
+        if (FULLK) {
+          load_vec(base + rowoff + gk, r[v]);
+          if (ADD) load_vec(add + rowoff + gk, t[v]);
         } else {
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
-            float x = 0.0f;
-            if (gk + e < kend) {
-              x = base[off + e];
-              if (add) x += add[off + e];
+            const int kk = gk + e;
+            const int kc = kk < kend ? kk : kend - 1;
+            float x = base[rowoff + kc];
+            r[v][e] = kk < kend ? x : 0.0f;
+            if (ADD) {
+              float y = add[rowoff + kc];
+              t[v][e] = kk < kend ? y : 0.0f;
             }
-            r[v][e] = x;
           }
         }
       } else {
-        int gk = k0 + k;
+        const int gk = k0 + k;
+        const int kc = (FULLK || gk < kend) ? gk : kend - 1;
         int go = o0 + o;
-        if (gk < kend) {
-          int64_t rowoff = (int64_t)gk * ld;
-          if (go + VEC <= extent) {
-            load_vec(base + rowoff + go, r[v]);
-            if (add) {
-              float t[VEC];
-              load_vec(add + rowoff + go, t);
+        go = (go + VEC <= extent) ? go : extent - VEC;
+        const int64_t off = (int64_t)kc * ld + go;
+        load_vec(base + off, r[v]);
+        if (ADD) load_vec(add + off, t[v]);
+        if (!FULLK) {
 #pragma unroll
-              for (int e = 0; e < VEC; ++e) r[v][e] += t[e];
-            }
-          } else {
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-              int g = go + e;
-              g = g < extent ? g : extent - 1;
-              float x = base[rowoff + g];
-              if (add) x += add[rowoff + g];
-              r[v][e] = x;
-            }
+          for (int e = 0; e < VEC; ++e) {
+            r[v][e] = gk < kend ? r[v][e] : 0.0f;
+            if (ADD) t[v][e] = gk < kend ? t[v][e] : 0.0f;
           }
-        } else {
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) r[v][e] = 0.0f;
         }
       }
     }
   }
 
-  __device__ __forceinline__ static void load_vec(const float* __restrict__ p, float* dst) {
-    if (VEC == 4) {
-      float4 t = *reinterpret_cast<const float4*>(p);
-      dst[0] = t.x; dst[1] = t.y; dst[2] = t.z; dst[3] = t.w;
-    } else if (VEC == 2) {
-      float2 t = *reinterpret_cast<const float2*>(p);
-      dst[0] = t.x; dst[1] = t.y;
-    } else {
-      dst[0] = *p;
-    }
-  }
-
-  // Activation / dropout on the staged registers.  OUTER_IS_ROW: logical index is
+  // addend + activation / dropout on the staged registers.  OUTER_IS_ROW: logical index is
   // outer*lld + reduce (operand A), otherwise reduce*lld + outer (operand B).
   template <bool OUTER_IS_ROW>
-  __device__ __forceinline__ void xform(const XForm& xf, int o0, int k0, int tid) {
+  __device__ __forceinline__ void finish(const XForm& xf, int o0, int k0, int tid) {
+    if (ADD) {
+#pragma unroll
+      for (int v = 0; v < NVEC; ++v)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) r[v][e] += t[v][e];
+    }
     if (xf.act == MESM_ACT_NONE && xf.thresh == 0) return;
 #pragma unroll
     for (int v = 0; v < NVEC; ++v) {
@@ -171,7 +168,8 @@ struct Tile {
   }
 };
 
-template <int BM, int BN, int LA, int LB, int VEC>
+// ADD: 0 = no addend, 1 = A2 present, 2 = B2 present
+template <int BM, int BN, int LA, int LB, int VEC, int ADD>
 __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const MesmGemmArgs p) {
   constexpr int PA = (LA == MESM_LAYOUT_REDUCE_CONTIG) ? 2 : 0;
   constexpr int PB = (LB == MESM_LAYOUT_REDUCE_CONTIG) ? 2 : 0;
@@ -200,14 +198,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const MesmGemmArgs p
   }
 
   const float slope = p.slope ? *p.slope : 0.0f;
+  const uint32_t seed_off = p.seed_offset ? *p.seed_offset : 0u;
   XForm xa, xb;
   xa.act = p.a_act; xa.slope = slope; xa.thresh = p.a_drop_p > 0.f ? mesm_drop_threshold(p.a_drop_p) : 0u;
-  xa.seed = p.a_drop_seed; xa.inv_keep = 1.0f / (1.0f - p.a_drop_p); xa.lld = p.K;
+  xa.seed = p.a_drop_seed + seed_off; xa.inv_keep = 1.0f / (1.0f - p.a_drop_p); xa.lld = p.K;
   xb.act = p.b_act; xb.slope = slope; xb.thresh = p.b_drop_p > 0.f ? mesm_drop_threshold(p.b_drop_p) : 0u;
-  xb.seed = p.b_drop_seed; xb.inv_keep = 1.0f / (1.0f - p.b_drop_p); xb.lld = p.N;
+  xb.seed = p.b_drop_seed + seed_off; xb.inv_keep = 1.0f / (1.0f - p.b_drop_p); xb.lld = p.N;
 
-  Tile<BM, LA, VEC> ta;
-  Tile<BN, LB, VEC> tb;
+  Tile<BM, LA, VEC, ADD == 1> ta;
+  Tile<BN, LB, VEC, ADD == 2> tb;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -224,23 +223,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const MesmGemmArgs p
   const int cs_i = tid % BM;
   const int cs_k = tid / BM;
 
-  const int nkt = (kend - kbeg + BK - 1) / BK;
-  ta.load(p.A, p.A2, p.lda, m0, p.M, kbeg, kend, tid);
-  tb.load(p.B, p.B2, p.ldb, n0, p.N, kbeg, kend, tid);
-  ta.template xform<true>(xa, m0, kbeg, tid);
-  tb.template xform<false>(xb, n0, kbeg, tid);
-  ta.store(As[0], SA, tid);
-  tb.store(Bs[0], SB, tid);
-  __syncthreads();
-
-  int buf = 0;
-  for (int kt = 0; kt < nkt; ++kt) {
-    const int knext = kbeg + (kt + 1) * BK;
-    const bool has_next = (kt + 1 < nkt);
-    if (has_next) {
-      ta.load(p.A, p.A2, p.lda, m0, p.M, knext, kend, tid);
-      tb.load(p.B, p.B2, p.ldb, n0, p.N, knext, kend, tid);
-    }
+  auto compute = [&](int buf) {
     const float* __restrict__ a_s = As[buf];
     const float* __restrict__ b_s = Bs[buf];
 #pragma unroll
@@ -261,57 +244,126 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const MesmGemmArgs p
 #pragma unroll
       for (int k = 0; k < BK; k += CS_KSTEP) csum += a_s[(k + cs_k) * SA + cs_i];
     }
-    if (has_next) {
-      ta.template xform<true>(xa, m0, knext, tid);
-      tb.template xform<false>(xb, n0, knext, tid);
-      ta.store(As[buf ^ 1], SA, tid);
-      tb.store(Bs[buf ^ 1], SB, tid);
-    }
+  };
+
+  const int nfull = (kend - kbeg) / BK;
+  const bool has_tail = ((kend - kbeg) % BK) != 0;
+  const int ntiles = nfull + (has_tail ? 1 : 0);
+
+  if (nfull > 0) {
+    ta.template load<true>(p.A, p.A2, p.lda, m0, p.M, kbeg, kend, tid);
+    tb.template load<true>(p.B, p.B2, p.ldb, n0, p.N, kbeg, kend, tid);
+  } else {
+    ta.template load<false>(p.A, p.A2, p.lda, m0, p.M, kbeg, kend, tid);
+    tb.template load<false>(p.B, p.B2, p.ldb, n0, p.N, kbeg, kend, tid);
+  }
+  ta.template finish<true>(xa, m0, kbeg, tid);
+  tb.template finish<false>(xb, n0, kbeg, tid);
+  ta.store(As[0], SA, tid);
+  tb.store(Bs[0], SB, tid);
+  __syncthreads();
+
+  int buf = 0;
+  int kt = 0;
+  // steady state: the next tile is a full one, its loads fly while this tile is multiplied
+  for (; kt + 1 < nfull; ++kt) {
+    const int knext = kbeg + (kt + 1) * BK;
+    ta.template load<true>(p.A, p.A2, p.lda, m0, p.M, knext, kend, tid);
+    tb.template load<true>(p.B, p.B2, p.ldb, n0, p.N, knext, kend, tid);
+    compute(buf);
+    ta.template finish<true>(xa, m0, knext, tid);
+    tb.template finish<false>(xb, n0, knext, tid);
+    ta.store(As[buf ^ 1], SA, tid);
+    tb.store(Bs[buf ^ 1], SB, tid);
     __syncthreads();
     buf ^= 1;
   }
+  if (kt + 1 < ntiles) {  // one guarded K-tail tile follows the current one
+    const int knext = kbeg + (kt + 1) * BK;
+    ta.template load<false>(p.A, p.A2, p.lda, m0, p.M, knext, kend, tid);
+    tb.template load<false>(p.B, p.B2, p.ldb, n0, p.N, knext, kend, tid);
+    compute(buf);
+    ta.template finish<true>(xa, m0, knext, tid);
+    tb.template finish<false>(xb, n0, knext, tid);
+    ta.store(As[buf ^ 1], SA, tid);
+    tb.store(Bs[buf ^ 1], SB, tid);
+    __syncthreads();
+    buf ^= 1;
+  }
+  compute(buf);
 
   if (do_colsum) {
     int gi = m0 + cs_i;
     if (gi < p.M) atomicAdd(p.colsum + gi, csum);
   }
 
-  // ---- epilogue ----
+  // ---- epilogue: all side loads of a 32x32 tile are issued before the first use ----
   const bool first_split = (p.split_k <= 1) || (blockIdx.z == 0);
   const uint32_t e_thresh = p.e_drop_p > 0.f ? mesm_drop_threshold(p.e_drop_p) : 0u;
   const float e_inv_keep = 1.0f / (1.0f - p.e_drop_p);
+  const bool use_bias = p.bias != nullptr && first_split;
+  const bool use_res = p.residual != nullptr && first_split;
+  const bool use_aux = p.e_actgrad != MESM_ACT_NONE;
+  const bool rmw = p.accumulate == 1;
   float dslope_part = 0.0f;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + wn * WN + j * 32 + (lane & 31);
+      const bool colok = col < p.N;
+      const int colc = colok ? col : p.N - 1;
+      const int rbase = m0 + wm * WM + i * 32 + 4 * (lane >> 5);
+      float resv[16], auxv[16], oldv[16];
+      float bias_v = 0.0f;
+      if (use_bias) bias_v = p.bias[colc];
+      if (use_res) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int row = rbase + (r & 3) + 8 * (r >> 2);
+          row = row < p.M ? row : p.M - 1;
+          resv[r] = p.residual[(int64_t)row * p.ldr + colc];
+        }
+      }
+      if (use_aux) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int row = rbase + (r & 3) + 8 * (r >> 2);
+          row = row < p.M ? row : p.M - 1;
+          auxv[r] = p.aux[(int64_t)row * p.ldaux + colc];
+        }
+      }
+      if (rmw) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int row = rbase + (r & 3) + 8 * (r >> 2);
+          row = row < p.M ? row : p.M - 1;
+          oldv[r] = p.C[(int64_t)row * p.ldc + colc];
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < p.M && col < p.N) {
-          float t = acc[i][j][r] * p.out_scale;
-          if (p.bias && first_split) t += p.bias[col];
-          t = mesm_act(t, p.e_act, slope);
-          if (e_thresh)
-            t = mesm_dropout_apply(t, (uint32_t)((int64_t)row * p.N + col), p.e_drop_seed,
-                                   e_thresh, e_inv_keep);
-          if (p.e_actgrad != MESM_ACT_NONE) {
-            float z = p.aux[(int64_t)row * p.ldaux + col];
-            if (p.e_actgrad == MESM_ACT_RELU) {
-              t = z > 0.0f ? t : 0.0f;
-            } else {
-              if (z <= 0.0f) {
-                dslope_part += t * z;
-                t *= slope;
-              }
-            }
+        const int row = rbase + (r & 3) + 8 * (r >> 2);
+        float t = acc[i][j][r] * p.out_scale + bias_v;
+        t = mesm_act(t, p.e_act, slope);
+        if (e_thresh)
+          t = mesm_dropout_apply(t, (uint32_t)((int64_t)row * p.N + col), p.e_drop_seed + seed_off, e_thresh,
+                                 e_inv_keep);
+        if (use_aux) {
+          const float z = auxv[r];
+          if (p.e_actgrad == MESM_ACT_RELU) {
+            t = z > 0.0f ? t : 0.0f;
+          } else if (z <= 0.0f) {
+            if (row < p.M && colok) dslope_part += t * z;
+            t *= slope;
           }
-          if (p.residual && first_split) t += p.residual[(int64_t)row * p.ldr + col];
+        }
+        if (use_res) t += resv[r];
+        if (rmw) t += oldv[r];
+        if (row < p.M && colok) {
           float* c = p.C + (int64_t)row * p.ldc + col;
-          if (p.accumulate == 0) *c = t;
-          else if (p.accumulate == 1) *c += t;
-          else atomicAdd(c, t);
+          if (p.accumulate == 2) atomicAdd(c, t);
+          else *c = t;
         }
       }
     }
@@ -322,29 +374,33 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const MesmGemmArgs p
   }
 }
 
-template <int BM, int BN, int LA, int LB, int VEC>
+template <int BM, int BN, int LA, int LB, int VEC, int ADD>
 int launch(const MesmGemmArgs& a, hipStream_t s) {
   dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.split_k > 1 ? a.split_k : 1);
-  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, LA, LB, VEC>), grid, dim3(NTHREADS), 0, s, a);
+  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, LA, LB, VEC, ADD>), grid, dim3(NTHREADS), 0, s, a);
   return mesm_launch_status();
 }
 
-template <int BM, int BN, int VEC>
+template <int BM, int BN, int VEC, int ADD>
 int launch_layout(const MesmGemmArgs& a, hipStream_t s) {
   constexpr int R = MESM_LAYOUT_REDUCE_CONTIG, O = MESM_LAYOUT_OUTER_CONTIG;
-  if (a.a_layout == R && a.b_layout == R) return launch<BM, BN, R, R, VEC>(a, s);
-  if (a.a_layout == R && a.b_layout == O) return launch<BM, BN, R, O, VEC>(a, s);
-  if (a.a_layout == O && a.b_layout == O) return launch<BM, BN, O, O, VEC>(a, s);
-  if (a.a_layout == O && a.b_layout == R) return launch<BM, BN, O, R, VEC>(a, s);
+  if (a.a_layout == R && a.b_layout == R) return launch<BM, BN, R, R, VEC, ADD>(a, s);
+  if (a.a_layout == R && a.b_layout == O) return launch<BM, BN, R, O, VEC, ADD>(a, s);
+  if (a.a_layout == O && a.b_layout == O) return launch<BM, BN, O, O, VEC, ADD>(a, s);
+  if (a.a_layout == O && a.b_layout == R) return launch<BM, BN, O, R, VEC, ADD>(a, s);
   return MESM_EINVAL;
 }
 
 template <int VEC>
 int launch_tile(const MesmGemmArgs& a, hipStream_t s) {
-  // 128x128 tiles only when they still give every CU a workgroup.
+  const int add = a.A2 ? 1 : (a.B2 ? 2 : 0);
+  // 128x128 tiles only when they still give every CU a workgroup (and no addend: keeps the
+  // number of instantiations small).
   long blocks128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * (a.split_k > 1 ? a.split_k : 1);
-  if (blocks128 >= 256) return launch_layout<128, 128, VEC>(a, s);
-  return launch_layout<64, 64, VEC>(a, s);
+  if (blocks128 >= 256 && add == 0) return launch_layout<128, 128, VEC, 0>(a, s);
+  if (add == 0) return launch_layout<64, 64, VEC, 0>(a, s);
+  if (add == 1) return launch_layout<64, 64, VEC, 1>(a, s);
+  return launch_layout<64, 64, VEC, 2>(a, s);
 }
 
 struct ProfState {
@@ -383,26 +439,34 @@ extern "C" int mesm_gemm_f32(const MesmGemmArgs* args, void* stream) {
   if (a.out_scale == 0.0f) a.out_scale = 1.0f;
   hipStream_t s = (hipStream_t)stream;
   // widest vector width every operand supports
+  if (a.A2 && a.B2) return MESM_EINVAL;
   int vec = 4;
   while (vec > 1) {
     bool ok = (a.lda % vec == 0) && (a.ldb % vec == 0) && aligned_to(a.A, 4 * vec) &&
               aligned_to(a.A2, 4 * vec) && aligned_to(a.B, 4 * vec) && aligned_to(a.B2, 4 * vec);
+    if (a.a_layout == MESM_LAYOUT_OUTER_CONTIG) ok = ok && (a.M % vec == 0);
+    if (a.b_layout == MESM_LAYOUT_OUTER_CONTIG) ok = ok && (a.N % vec == 0);
     if (ok) break;
     vec >>= 1;
   }
   if (!aligned_to(a.A, 4) || !aligned_to(a.B, 4) || !aligned_to(a.C, 4)) return MESM_EALIGN;
   hipEvent_t e0 = nullptr, e1 = nullptr;
+  bool capturing = false;
   if (g_prof.on) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) == hipSuccess) capturing = st == hipStreamCaptureStatusActive;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    hipEventRecord(e0, s);
+    if (capturing) hipEventRecordWithFlags(e0, s, hipEventRecordExternal);
+    else hipEventRecord(e0, s);
   }
   int rc;
   if (vec == 4) rc = launch_tile<4>(a, s);
   else if (vec == 2) rc = launch_tile<2>(a, s);
   else rc = launch_tile<1>(a, s);
   if (g_prof.on) {
-    hipEventRecord(e1, s);
+    if (capturing) hipEventRecordWithFlags(e1, s, hipEventRecordExternal);
+    else hipEventRecord(e1, s);
     g_prof.events.emplace_back(e0, e1);
     g_prof.flops += 2.0 * (double)a.M * (double)a.N * (double)a.K;
   }
@@ -414,7 +478,8 @@ extern "C" int mesm_profile_enable(int32_t on) {
   return MESM_OK;
 }
 
-extern "C" int mesm_profile_read(double* total_ms, int64_t* launches, double* total_flops) {
+extern "C" int mesm_profile_read(double* total_ms, int64_t* launches, double* total_flops,
+                                 int32_t clear) {
   if (!total_ms || !launches || !total_flops) return MESM_EINVAL;
   double ms = 0.0;
   for (auto& pr : g_prof.events) {
@@ -422,13 +487,17 @@ extern "C" int mesm_profile_read(double* total_ms, int64_t* launches, double* to
     float t = 0.0f;
     hipEventElapsedTime(&t, pr.first, pr.second);
     ms += t;
-    hipEventDestroy(pr.first);
-    hipEventDestroy(pr.second);
   }
   *total_ms = ms;
   *launches = (int64_t)g_prof.events.size();
   *total_flops = g_prof.flops;
-  g_prof.events.clear();
-  g_prof.flops = 0.0;
+  if (clear) {
+    for (auto& pr : g_prof.events) {
+      hipEventDestroy(pr.first);
+      hipEventDestroy(pr.second);
+    }
+    g_prof.events.clear();
+    g_prof.flops = 0.0;
+  }
   return MESM_OK;
 }

@@ -19,7 +19,7 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, gradbuf, process_group=None, n_buckets=6):
+    def __init__(self, gradbuf, process_group=None, n_buckets=6, hook=True):
         self.gb = gradbuf
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -33,7 +33,8 @@ class GradReducer:
         self.buckets = None         # list of (lo, hi, [param ids])
         self.bucket_left = None
         self.param_bucket = {}
-        gradbuf.on_ready = self._on_ready
+        if hook:  # overlap mode: collectives are launched from inside backward
+            gradbuf.on_ready = self._on_ready
 
     # bucket = contiguous slice of the flat buffer, roughly equal sizes
     def _make_buckets(self):

@@ -19,6 +19,22 @@ __all__ = [
 ]
 
 
+# Device scalar (uint32 stored in an int32 tensor) added to every dropout seed at run time;
+# set by graphed steps so that replays draw fresh masks.  None = no offset.
+_seed_offset = None
+
+
+def set_seed_offset(t):
+    global _seed_offset
+    if t is not None:
+        assert t.is_cuda and t.dtype == torch.int32 and t.numel() == 1
+    _seed_offset = t
+
+
+def _seed_off_ptr():
+    return _seed_offset.data_ptr() if _seed_offset is not None else None
+
+
 def _mat(t):
     """(rows, cols, ld, layout_if_reduce_is_cols) view info of a 2-D tensor with one unit stride."""
     assert t.dim() == 2
@@ -88,6 +104,7 @@ def gemm(A, B, C, *, trans_a=False, trans_b=False, A2=None, B2=None, bias=None, 
     g.e_drop_p, g.e_drop_seed = float(e_drop[0]), int(e_drop[1]) & 0xFFFFFFFF
     g.out_scale = float(out_scale)
     g.accumulate, g.split_k = int(accumulate), int(split_k)
+    g.seed_offset = _seed_off_ptr()
     check(lib().mesm_gemm_f32(ctypes.byref(g), stream_ptr()), "mesm_gemm_f32")
     return C
 
@@ -150,6 +167,7 @@ def _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop):
         a.mask_mode = MASK_KPAD
     a.scale = float(scale)
     a.drop_p, a.drop_seed = float(drop[0]), int(drop[1]) & 0xFFFFFFFF
+    a.seed_offset = _seed_off_ptr()
     return a
 
 
@@ -237,7 +255,7 @@ def dropout(x, p, seed, out=None):
     assert x.is_contiguous()
     y = torch.empty_like(x) if out is None else out
     check(lib().mesm_dropout(ptr(x), ptr(y), x.numel(), float(p), int(seed) & 0xFFFFFFFF,
-                             stream_ptr()), "mesm_dropout")
+                             ptr(_seed_offset), stream_ptr()), "mesm_dropout")
     return y
 
 
@@ -330,7 +348,8 @@ def profile_enable(on):
     check(lib().mesm_profile_enable(1 if on else 0), "mesm_profile_enable")
 
 
-def profile_read():
+def profile_read(clear=True):
     ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
-    check(lib().mesm_profile_read(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "mesm_profile_read")
+    check(lib().mesm_profile_read(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), 1 if clear else 0),
+          "mesm_profile_read")
     return {"ms": ms.value, "launches": n.value, "flops": fl.value}

@@ -133,6 +133,38 @@ class MESM(nn.Module):
             x = m(x)
         return x
 
+    # ------------------------------------------------------------------ host RNG draws
+    @staticmethod
+    def draw_neg_index(groups):
+        """sample_outclass_neg (utils/data_utils.py:113-124): for every pair one query index drawn
+        uniformly from the OTHER video groups, one torch.randperm per pair (host generator)."""
+        if len(groups) < 2:
+            raise IndexError("index 0 is out of bounds: negatives need >= 2 video groups in a batch")
+        N = sum(groups)
+        neg, start = [], 0
+        for g in groups:
+            cand = torch.cat([torch.arange(0, start), torch.arange(start + g, N)])
+            for _ in range(g):
+                neg.append(cand[torch.randperm(cand.shape[0])][0])
+            start += g
+        return torch.stack(neg)
+
+    @staticmethod
+    def draw_masked_words(words_mask_cpu, words_weight):
+        """_mask_words (model.py:361-384): max(l//3, 1) positions per pair, without replacement,
+        p ~ words_weight, numpy global RNG on the host; pairs with <= 1 word are skipped."""
+        masked = torch.zeros_like(words_mask_cpu)
+        weight = F.normalize(words_weight.float().cpu(), dim=1, p=1) if words_weight is not None else None
+        for i, l in enumerate(words_mask_cpu.count_nonzero(dim=1)):
+            l = int(l)
+            if l <= 1:
+                continue
+            k = max(l // 3, 1)
+            p = weight[i, :l].numpy() if weight is not None else None
+            choices = np.random.choice(np.arange(0, l), k, replace=False, p=p)
+            masked[i, choices] = 1
+        return masked
+
     # ------------------------------------------------------------------ host-side plan
     @torch.no_grad()
     def make_plan(self, video_mask, words_mask, num_clips, dataset_name, is_training, words_weight=None,
@@ -146,17 +178,8 @@ class MESM(nn.Module):
         N, Lv = vm.shape
         pl = Plan()
         pl.groups = groups
-        # negative query index: uniform over the queries of other groups (data_utils.py:113-124)
         if neg_index is None:
-            if len(groups) < 2:
-                raise IndexError("index 0 is out of bounds: negatives need >= 2 video groups in a batch")
-            neg, start = [], 0
-            for g in groups:
-                cand = torch.cat([torch.arange(0, start), torch.arange(start + g, N)])
-                for _ in range(g):
-                    neg.append(cand[torch.randperm(cand.shape[0])][0])
-                start += g
-            neg_index = torch.stack(neg)
+            neg_index = self.draw_neg_index(groups)
         pl.neg_index = neg_index.to(device)
         if self.rec_ss:
             slot = torch.cat([torch.arange(g) for g in groups])
@@ -215,17 +238,7 @@ class MESM(nn.Module):
             pl.clip_mask = cmask.to(device)
             pl.clip_pad = (~cmask).to(device)
             if masked_words is None:
-                # _mask_words, model.py:361-384: numpy RNG on the host, p ~ words_weight
-                masked_words = torch.zeros_like(wm)
-                weight = F.normalize(words_weight.float().cpu(), dim=1, p=1) if words_weight is not None else None
-                for i, l in enumerate(wm.count_nonzero(dim=1)):
-                    l = int(l)
-                    if l <= 1:
-                        continue
-                    k = max(l // 3, 1)
-                    p = weight[i, :l].numpy() if weight is not None else None
-                    choices = np.random.choice(np.arange(0, l), k, replace=False, p=p)
-                    masked_words[i, choices] = 1
+                masked_words = self.draw_masked_words(wm, words_weight)
             pl.masked_words = masked_words.bool().to(device)
         return pl
 
