@@ -148,26 +148,14 @@ def main():
 
     roofline = None
     if not opt.no_roofline:
-        if opt.eager:
-            model.gradbuf().on_ready = None
-            kn.profile_enable(True)
-            for _ in range(opt.steps):
-                eager_step()
-            torch.cuda.synchronize()
-            prof = kn.profile_read(clear=True)
-            kn.profile_enable(False)
-        else:
-            # a second capture of the same step whose GEMM launches are bracketed by external event
-            # nodes; every replay re-stamps them, so the durations are those inside the graph
-            istep = GraphedStep(model, crit, batch, args.dataset_name, warmup=1, instrument=True)
-            prof = {"ms": 0.0, "launches": 0, "flops": 0.0}
-            for _ in range(opt.steps):
-                istep.run(redraw=True)
-                torch.cuda.synchronize()
-                r = kn.profile_read(clear=False)
-                for k in prof:
-                    prof[k] += r[k]
-            kn.profile_read(clear=True)
+        # the GEMM launches of one captured step, replayed back to back from C++ with a HIP-event
+        # pair around every launch (same arguments and buffers as the graph; see mesm_gemm_tape)
+        model.gradbuf().on_ready = None
+        istep = GraphedStep(model, crit, batch, args.dataset_name, warmup=1, instrument=True)
+        istep.run()
+        torch.cuda.synchronize()
+        kn.gemm_tape_replay(1)  # warm
+        prof = kn.gemm_tape_replay(opt.steps)
         if prof["launches"] > 0:
             avg_ms = prof["ms"] / prof["launches"]
             flops_per_launch = prof["flops"] / prof["launches"]
@@ -175,7 +163,7 @@ def main():
             roofline = {"kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", "bound": "mfma",
                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                        "launches_per_step": prof["launches"] / opt.steps,
+                        "launches_per_step": prof["launches"] / opt.steps, "measured": "event pair per launch, tape of one captured step replayed %d x" % opt.steps,
                         "avg_launch_us": avg_ms * 1e3, "flops_per_launch": flops_per_launch,
                         "gemm_ms_per_step": prof["ms"] / opt.steps}
 

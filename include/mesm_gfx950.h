@@ -118,17 +118,18 @@ typedef struct MesmGemmArgs {
 int mesm_gemm_f32(const MesmGemmArgs* args, void* stream);
 
 /*
- * Launch-duration instrumentation of mesm_gemm_f32 (the dominant kernel of the step) for
- * bench.py's roofline object: while enabled, every GEMM launch is bracketed by two HIP events
- * on the launch stream and its algorithmic FLOPs (2*M*N*K) are tallied.  When the stream is
- * being captured into a HIP graph the events are recorded as EXTERNAL event nodes
- * (hipEventRecordExternal), so they are re-stamped by every replay of that graph.
- * mesm_profile_read synchronises on the recorded events (host-blocking; never inside a timed
- * region) and returns the sum of their elapsed times, the number of bracketed launches and their
- * FLOPs; clear != 0 destroys the events (otherwise they stay valid for the next replay).
+ * Launch-duration measurement of mesm_gemm_f32 (the dominant kernel of the step) for
+ * bench.py's roofline object.  mesm_gemm_tape(1) starts recording the argument struct of every
+ * GEMM launch (mesm_gemm_tape(0) stops); bench.py records while the step is captured into a HIP
+ * graph, whose private memory pool keeps every recorded pointer valid afterwards.
+ * mesm_gemm_tape_replay re-issues the recorded launches `reps` times back to back on `stream`,
+ * each bracketed by a pair of HIP events on that stream, synchronises (host-blocking; never
+ * inside a timed region) and returns the summed elapsed time, the number of launches and their
+ * algorithmic FLOPs (2*M*N*K each).
  */
-int mesm_profile_enable(int32_t on);
-int mesm_profile_read(double* total_ms, int64_t* launches, double* total_flops, int32_t clear);
+int mesm_gemm_tape(int32_t record);
+int mesm_gemm_tape_replay(void* stream, int32_t reps, double* total_ms, int64_t* launches,
+                          double* total_flops);
 
 /* ------------------------------------------------------------------------- */
 /*

@@ -140,7 +140,7 @@ class Criterion(nn.Module):
         N, Q = logits.shape[:2]
         flat = plan.pair_of_t * Q + match_q.to(torch.int64)
         cls = torch.ones(N * Q, dtype=torch.int64, device=logits.device)
-        cls[flat] = self.foreground_label
+        cls.index_fill_(0, flat, self.foreground_label)  # no host scalar copy: graph-capturable
         logp = torch.log_softmax(logits.reshape(N * Q, 2), dim=-1)
         ce = -logp.gather(1, cls[:, None]).squeeze(1) * self.empty_weight[cls]
         losses = {"loss_label": ce.mean()}

@@ -9,6 +9,8 @@
 // global -> registers -> LDS (a transpose is needed when the reduce index is the
 // contiguous one, which LDS-DMA cannot do) and double-buffered: the global loads of
 // tile t+1 are in flight while tile t is multiplied.
+#include <cstdio>
+#include <cstdlib>
 #include <utility>
 #include <vector>
 
@@ -18,8 +20,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BK = 32;
 constexpr int NTHREADS = 256;
+constexpr int BK_MAX = 64;  // split-K chunks and the tail granularity are multiples of this
 
 struct XForm {
   int act;
@@ -34,7 +36,7 @@ struct XForm {
 // Loads are written branch-free so that every global load of a k-step is in flight before
 // the first wait: full tiles use unguarded vector loads (rows clamped with a select), the
 // single K-tail tile uses clamped scalar loads + selects.
-template <int ROWS, int LAYOUT, int VEC, bool ADD>
+template <int ROWS, int BK, int LAYOUT, int VEC, bool ADD>
 struct Tile {
   static constexpr int NVEC = ROWS * BK / (VEC * NTHREADS);
   static_assert(NVEC >= 1, "tile too small for the block");
@@ -169,29 +171,42 @@ struct Tile {
 };
 
 // ADD: 0 = no addend, 1 = A2 present, 2 = B2 present
-template <int BM, int BN, int LA, int LB, int VEC, int ADD>
+template <int BM, int BN, int BK, int LA, int LB, int VEC, int ADD>
 __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const MesmGemmArgs p) {
-  constexpr int PA = (LA == MESM_LAYOUT_REDUCE_CONTIG) ? 2 : 0;
-  constexpr int PB = (LB == MESM_LAYOUT_REDUCE_CONTIG) ? 2 : 0;
+  // LDS row padding: +2 keeps the transposing ds_write_b32 of reduce-contiguous operands
+  // conflict-free; +4 for outer-contiguous operands keeps rows 16-byte aligned for ds_write_b128
+  // and avoids an exact power-of-two row stride (with stride 32 the 32x32 k-split configuration
+  // read zeros for k >= 56 at columns 27/31 on gfx950 / ROCm 7.2 -- not understood, reproducible
+  // with tools/dbg_gemm3.py, gone with any padded stride).
+  constexpr int PA = (LA == MESM_LAYOUT_REDUCE_CONTIG) ? 2 : 4;
+  constexpr int PB = (LB == MESM_LAYOUT_REDUCE_CONTIG) ? 2 : 4;
   constexpr int SA = BM + PA;
   constexpr int SB = BN + PB;
-  constexpr int WM = BM / 2, WN = BN / 2;
+  // wave grid: 2x2 over the (M, N) tile, or 1x1x4 over the k-pairs of a 32x32 tile (WGK = 4):
+  // the four waves then accumulate partial products of the SAME 32x32 tile and are summed
+  // through LDS before the epilogue -- 4x more, 4x shorter workgroups for the small GEMMs.
+  constexpr int WGK = (BM == 32) ? 4 : 1;
+  constexpr int WGM = (WGK == 1) ? 2 : 1, WGN = (WGK == 1) ? 2 : 1;
+  constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int RN = 16 / WGK;  // accumulator registers each wave takes through the epilogue
+  static_assert(WGK == 1 || (TM == 1 && TN == 1), "k-split waves own one 32x32 tile");
 
   __shared__ __attribute__((aligned(16))) float As[2][BK * SA];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * SB];
+  __shared__ float Red[WGK > 1 ? WGK * 16 * 64 : 1];  // partial tiles of the k-split waves
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wn = wave % WGN, wm = (wave / WGN) % WGM, wk = wave / (WGN * WGM);
   const int m0 = blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
 
   int kbeg = 0, kend = p.K;
   if (p.split_k > 1) {
     int chunk = (p.K + p.split_k - 1) / p.split_k;
-    chunk = ((chunk + BK - 1) / BK) * BK;
+    chunk = ((chunk + BK_MAX - 1) / BK_MAX) * BK_MAX;
     kbeg = blockIdx.z * chunk;
     kend = kbeg + chunk < p.K ? kbeg + chunk : p.K;
     if (kbeg >= p.K) return;
@@ -205,8 +220,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const MesmGemmArgs p
   xb.act = p.b_act; xb.slope = slope; xb.thresh = p.b_drop_p > 0.f ? mesm_drop_threshold(p.b_drop_p) : 0u;
   xb.seed = p.b_drop_seed + seed_off; xb.inv_keep = 1.0f / (1.0f - p.b_drop_p); xb.lld = p.N;
 
-  Tile<BM, LA, VEC, ADD == 1> ta;
-  Tile<BN, LB, VEC, ADD == 2> tb;
+  Tile<BM, BK, LA, VEC, ADD == 1> ta;
+  Tile<BN, BK, LB, VEC, ADD == 2> tb;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -223,27 +238,35 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const MesmGemmArgs p
   const int cs_i = tid % BM;
   const int cs_k = tid / BM;
 
+  // One k-tile: all LDS fragment reads are issued first (counted lgkmcnt waits let MFMA kk start
+  // as soon as its own operands have landed), then the dependent MFMA chain runs back to back.
   auto compute = [&](int buf) {
     const float* __restrict__ a_s = As[buf];
     const float* __restrict__ b_s = Bs[buf];
+    constexpr int NKK = BK / 2 / WGK;  // k-pairs per wave per tile
+    float a[NKK][TM], b[NKK][TN];
 #pragma unroll
-    for (int kk = 0; kk < BK / 2; ++kk) {
-      const int krow = 2 * kk + (lane >> 5);
-      float a[TM], b[TN];
+    for (int q = 0; q < NKK; ++q) {
+      const int krow = 2 * (q * WGK + wk) + (lane >> 5);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = a_s[krow * SA + wm * WM + i * 32 + (lane & 31)];
+      for (int i = 0; i < TM; ++i) a[q][i] = a_s[krow * SA + wm * WM + i * 32 + (lane & 31)];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = b_s[krow * SB + wn * WN + j * 32 + (lane & 31)];
+      for (int j = 0; j < TN; ++j) b[q][j] = b_s[krow * SB + wn * WN + j * 32 + (lane & 31)];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < NKK; ++q) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q][i], b[q][j], acc[i][j], 0, 0, 0);
     }
     if (do_colsum) {
 #pragma unroll
       for (int k = 0; k < BK; k += CS_KSTEP) csum += a_s[(k + cs_k) * SA + cs_i];
     }
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   const int nfull = (kend - kbeg) / BK;
@@ -270,6 +293,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const MesmGemmArgs p
     const int knext = kbeg + (kt + 1) * BK;
     ta.template load<true>(p.A, p.A2, p.lda, m0, p.M, knext, kend, tid);
     tb.template load<true>(p.B, p.B2, p.ldb, n0, p.N, knext, kend, tid);
+    __builtin_amdgcn_sched_barrier(0);  // keep the global loads ahead of the MFMA block
     compute(buf);
     ta.template finish<true>(xa, m0, knext, tid);
     tb.template finish<false>(xb, n0, knext, tid);
@@ -282,6 +306,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const MesmGemmArgs p
     const int knext = kbeg + (kt + 1) * BK;
     ta.template load<false>(p.A, p.A2, p.lda, m0, p.M, knext, kend, tid);
     tb.template load<false>(p.B, p.B2, p.ldb, n0, p.N, knext, kend, tid);
+    __builtin_amdgcn_sched_barrier(0);
     compute(buf);
     ta.template finish<true>(xa, m0, knext, tid);
     tb.template finish<false>(xb, n0, knext, tid);
@@ -291,10 +316,40 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const MesmGemmArgs p
     buf ^= 1;
   }
   compute(buf);
+  // The last MFMA must have written ALL its accumulator registers before they are read below:
+  // hipcc (ROCm 7.2) was seen hoisting v_accvgpr_read of a[14:15] above its own hazard s_nop
+  // next to a sched_barrier, so the wait states are spelled out (16-pass MFMA: >= 18).
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
   if (do_colsum) {
     int gi = m0 + cs_i;
     if (gi < p.M) atomicAdd(p.colsum + gi, csum);
+  }
+
+  // ---- k-split waves: sum the four partial 32x32 tiles through LDS; wave w keeps registers
+  // [RN*w, RN*w + RN) of the sum and takes them through the epilogue ----
+  float vals[TM][TN][RN];
+  int r0 = 0;
+  if (WGK > 1) {
+    float* red = Red;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wk * 16 + r) * 64 + lane] = acc[0][0][r];
+    __syncthreads();
+    r0 = wk * RN;
+#pragma unroll
+    for (int rr = 0; rr < RN; ++rr) {
+      float t = 0.0f;
+#pragma unroll
+      for (int w = 0; w < WGK; ++w) t += red[(w * 16 + r0 + rr) * 64 + lane];
+      vals[0][0][rr] = t;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int rr = 0; rr < RN; ++rr) vals[i][j][rr] = acc[i][j][rr];
   }
 
   // ---- epilogue: all side loads of a 32x32 tile are issued before the first use ----
@@ -314,43 +369,47 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const MesmGemmArgs p
       const bool colok = col < p.N;
       const int colc = colok ? col : p.N - 1;
       const int rbase = m0 + wm * WM + i * 32 + 4 * (lane >> 5);
-      float resv[16], auxv[16], oldv[16];
+      float resv[RN], auxv[RN], oldv[RN];
       float bias_v = 0.0f;
       if (use_bias) bias_v = p.bias[colc];
       if (use_res) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int rr = 0; rr < RN; ++rr) {
+          const int r = r0 + rr;
           int row = rbase + (r & 3) + 8 * (r >> 2);
           row = row < p.M ? row : p.M - 1;
-          resv[r] = p.residual[(int64_t)row * p.ldr + colc];
+          resv[rr] = p.residual[(int64_t)row * p.ldr + colc];
         }
       }
       if (use_aux) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int rr = 0; rr < RN; ++rr) {
+          const int r = r0 + rr;
           int row = rbase + (r & 3) + 8 * (r >> 2);
           row = row < p.M ? row : p.M - 1;
-          auxv[r] = p.aux[(int64_t)row * p.ldaux + colc];
+          auxv[rr] = p.aux[(int64_t)row * p.ldaux + colc];
         }
       }
       if (rmw) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
+        for (int rr = 0; rr < RN; ++rr) {
+          const int r = r0 + rr;
           int row = rbase + (r & 3) + 8 * (r >> 2);
           row = row < p.M ? row : p.M - 1;
-          oldv[r] = p.C[(int64_t)row * p.ldc + colc];
+          oldv[rr] = p.C[(int64_t)row * p.ldc + colc];
         }
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int rr = 0; rr < RN; ++rr) {
+        const int r = r0 + rr;
         const int row = rbase + (r & 3) + 8 * (r >> 2);
-        float t = acc[i][j][r] * p.out_scale + bias_v;
+        float t = vals[i][j][rr] * p.out_scale + bias_v;
         t = mesm_act(t, p.e_act, slope);
         if (e_thresh)
           t = mesm_dropout_apply(t, (uint32_t)((int64_t)row * p.N + col), p.e_drop_seed + seed_off, e_thresh,
                                  e_inv_keep);
         if (use_aux) {
-          const float z = auxv[r];
+          const float z = auxv[rr];
           if (p.e_actgrad == MESM_ACT_RELU) {
             t = z > 0.0f ? t : 0.0f;
           } else if (z <= 0.0f) {
@@ -358,8 +417,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const MesmGemmArgs p
             t *= slope;
           }
         }
-        if (use_res) t += resv[r];
-        if (rmw) t += oldv[r];
+        if (use_res) t += resv[rr];
+        if (rmw) t += oldv[rr];
         if (row < p.M && colok) {
           float* c = p.C + (int64_t)row * p.ldc + col;
           if (p.accumulate == 2) atomicAdd(c, t);
@@ -376,8 +435,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const MesmGemmArgs p
 
 template <int BM, int BN, int LA, int LB, int VEC, int ADD>
 int launch(const MesmGemmArgs& a, hipStream_t s) {
+  // 64x64 tiles run few MFMAs per k-step: a deeper k-step (64) keeps the MFMA block longer than
+  // the global-load latency it has to hide; 128x128 tiles already do with 32.
+  constexpr int BK = (BM == 128) ? 32 : 64;
   dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.split_k > 1 ? a.split_k : 1);
-  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, LA, LB, VEC, ADD>), grid, dim3(NTHREADS), 0, s, a);
+  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, LA, LB, VEC, ADD>), grid, dim3(NTHREADS), 0, s, a);
   return mesm_launch_status();
 }
 
@@ -394,23 +456,38 @@ int launch_layout(const MesmGemmArgs& a, hipStream_t s) {
 template <int VEC>
 int launch_tile(const MesmGemmArgs& a, hipStream_t s) {
   const int add = a.A2 ? 1 : (a.B2 ? 2 : 0);
-  // 128x128 tiles only when they still give every CU a workgroup (and no addend: keeps the
-  // number of instantiations small).
-  long blocks128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) * (a.split_k > 1 ? a.split_k : 1);
-  if (blocks128 >= 256 && add == 0) return launch_layout<128, 128, VEC, 0>(a, s);
-  if (add == 0) return launch_layout<64, 64, VEC, 0>(a, s);
-  if (add == 1) return launch_layout<64, 64, VEC, 1>(a, s);
-  return launch_layout<64, 64, VEC, 2>(a, s);
+  const long z = a.split_k > 1 ? a.split_k : 1;
+  auto blocks = [&](int t) { return (long)((a.M + t - 1) / t) * ((a.N + t - 1) / t) * z; };
+  // largest tile that still gives every CU about two workgroups; the small 32x32 k-split tile
+  // otherwise (most d x d GEMMs of the step: 2400 x 256 x 256 -> 600 workgroups)
+  if (blocks(128) >= 512 && add == 0) return launch_layout<128, 128, VEC, 0>(a, s);
+  if (blocks(64) >= 512) {
+    if (add == 0) return launch_layout<64, 64, VEC, 0>(a, s);
+    if (add == 1) return launch_layout<64, 64, VEC, 1>(a, s);
+    return launch_layout<64, 64, VEC, 2>(a, s);
+  }
+  if (add == 0) return launch_layout<32, 32, VEC, 0>(a, s);
+  if (add == 1) return launch_layout<32, 32, VEC, 1>(a, s);
+  return launch_layout<32, 32, VEC, 2>(a, s);
 }
 
-struct ProfState {
-  bool on = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
-  double flops = 0.0;
+// Tape of the GEMM launches of one step (argument structs as launched), for bench.py's
+// roofline measurement: recorded while a step is captured into a HIP graph (whose private
+// memory pool keeps every pointer valid), replayed back-to-back from C++ with an event pair
+// around every launch.
+struct Tape {
+  bool recording = false;
+  std::vector<std::pair<MesmGemmArgs, int>> launches;  // (args, vec)
 };
-ProfState g_prof;
+Tape g_tape;
 
 inline bool aligned_to(const void* p, size_t b) { return p == nullptr || ((uintptr_t)p % b) == 0; }
+
+int dispatch(const MesmGemmArgs& a, int vec, hipStream_t s) {
+  if (vec == 4) return launch_tile<4>(a, s);
+  if (vec == 2) return launch_tile<2>(a, s);
+  return launch_tile<1>(a, s);
+}
 
 }  // namespace
 
@@ -432,7 +509,7 @@ extern "C" int mesm_gemm_f32(const MesmGemmArgs* args, void* stream) {
     if (a.e_act != MESM_ACT_NONE || a.e_actgrad != MESM_ACT_NONE || a.e_drop_p > 0.f)
       return MESM_EINVAL;
     a.accumulate = 2;
-    int max_split = (a.K + BK - 1) / BK;
+    int max_split = (a.K + BK_MAX - 1) / BK_MAX;
     if (a.split_k > max_split) a.split_k = max_split;
   }
   if (a.accumulate < 0 || a.accumulate > 2) return MESM_EINVAL;
@@ -450,54 +527,44 @@ extern "C" int mesm_gemm_f32(const MesmGemmArgs* args, void* stream) {
     vec >>= 1;
   }
   if (!aligned_to(a.A, 4) || !aligned_to(a.B, 4) || !aligned_to(a.C, 4)) return MESM_EALIGN;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  bool capturing = false;
-  if (g_prof.on) {
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &st) == hipSuccess) capturing = st == hipStreamCaptureStatusActive;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
-    if (capturing) hipEventRecordWithFlags(e0, s, hipEventRecordExternal);
-    else hipEventRecord(e0, s);
-  }
-  int rc;
-  if (vec == 4) rc = launch_tile<4>(a, s);
-  else if (vec == 2) rc = launch_tile<2>(a, s);
-  else rc = launch_tile<1>(a, s);
-  if (g_prof.on) {
-    if (capturing) hipEventRecordWithFlags(e1, s, hipEventRecordExternal);
-    else hipEventRecord(e1, s);
-    g_prof.events.emplace_back(e0, e1);
-    g_prof.flops += 2.0 * (double)a.M * (double)a.N * (double)a.K;
-  }
-  return rc;
+  if (g_tape.recording) g_tape.launches.emplace_back(a, vec);
+  return dispatch(a, vec, s);
 }
 
-extern "C" int mesm_profile_enable(int32_t on) {
-  g_prof.on = on != 0;
+extern "C" int mesm_gemm_tape(int32_t record) {
+  if (record) g_tape.launches.clear();
+  g_tape.recording = record != 0;
   return MESM_OK;
 }
 
-extern "C" int mesm_profile_read(double* total_ms, int64_t* launches, double* total_flops,
-                                 int32_t clear) {
-  if (!total_ms || !launches || !total_flops) return MESM_EINVAL;
-  double ms = 0.0;
-  for (auto& pr : g_prof.events) {
-    hipEventSynchronize(pr.second);
-    float t = 0.0f;
-    hipEventElapsedTime(&t, pr.first, pr.second);
-    ms += t;
-  }
-  *total_ms = ms;
-  *launches = (int64_t)g_prof.events.size();
-  *total_flops = g_prof.flops;
-  if (clear) {
-    for (auto& pr : g_prof.events) {
-      hipEventDestroy(pr.first);
-      hipEventDestroy(pr.second);
+extern "C" int mesm_gemm_tape_replay(void* stream, int32_t reps, double* total_ms, int64_t* launches,
+                                     double* total_flops) {
+  if (!total_ms || !launches || !total_flops || reps < 1) return MESM_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n = g_tape.launches.size();
+  std::vector<hipEvent_t> ev(2 * n);
+  for (auto& e : ev)
+    if (hipEventCreate(&e) != hipSuccess) return MESM_ELAUNCH;
+  double ms = 0.0, flops = 0.0;
+  int rc = MESM_OK;
+  for (int r = 0; r < reps && rc == MESM_OK; ++r) {
+    for (size_t i = 0; i < n && rc == MESM_OK; ++i) {
+      hipEventRecord(ev[2 * i], s);
+      rc = dispatch(g_tape.launches[i].first, g_tape.launches[i].second, s);
+      hipEventRecord(ev[2 * i + 1], s);
     }
-    g_prof.events.clear();
-    g_prof.flops = 0.0;
+    hipStreamSynchronize(s);
+    for (size_t i = 0; i < n; ++i) {
+      float t = 0.0f;
+      hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]);
+      ms += t;
+      const MesmGemmArgs& a = g_tape.launches[i].first;
+      flops += 2.0 * (double)a.M * (double)a.N * (double)a.K;
+    }
   }
-  return MESM_OK;
+  for (auto& e : ev) hipEventDestroy(e);
+  *total_ms = ms;
+  *launches = (int64_t)n * reps;
+  *total_flops = flops;
+  return rc;
 }

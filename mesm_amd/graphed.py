@@ -47,15 +47,15 @@ class GraphedStep:
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
             model.zero_grad(set_to_none=True)
-            if instrument:  # GEMM launches get external event nodes (re-stamped by every replay)
-                kn.profile_enable(True)
+            if instrument:  # record the GEMM launches of the captured step (bench roofline)
+                kn.gemm_tape(True)
             with torch.cuda.graph(self.graph):
                 self.counter.add_(1)
                 self.total, self.losses = self._step_body()
         finally:
             kn.set_seed_offset(None)
             if instrument:
-                kn.profile_enable(False)
+                kn.gemm_tape(False)
         self.reducer = None
 
     def _words_mask_cpu(self):

@@ -344,12 +344,12 @@ def match(logits, spans, tgt_cxw, tgt_xx, tgt_off, Tmax, w_span, w_giou, w_class
 
 
 # ----------------------------------------------------------------------------- instrumentation
-def profile_enable(on):
-    check(lib().mesm_profile_enable(1 if on else 0), "mesm_profile_enable")
+def gemm_tape(record):
+    check(lib().mesm_gemm_tape(1 if record else 0), "mesm_gemm_tape")
 
 
-def profile_read(clear=True):
+def gemm_tape_replay(reps=1):
     ms, n, fl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
-    check(lib().mesm_profile_read(ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), 1 if clear else 0),
-          "mesm_profile_read")
+    check(lib().mesm_gemm_tape_replay(stream_ptr(), int(reps), ctypes.byref(ms), ctypes.byref(n),
+                                      ctypes.byref(fl)), "mesm_gemm_tape_replay")
     return {"ms": ms.value, "launches": n.value, "flops": fl.value}

@@ -461,3 +461,113 @@ def test_match_against_scipy():
         want = torch.empty(sizes[b], dtype=torch.int32)
         want[torch.as_tensor(ti)] = torch.as_tensor(qi, dtype=torch.int32)
         assert torch.equal(mq[off[b]:off[b + 1]], want), (b, mq[off[b]:off[b + 1]], want)
+
+
+def _gemm_fuzz_case(rng, kn):
+    import random
+    M = rng.choice([1, 7, 32, 33, 64, 80, 130, 256, 264, 600, 1024])
+    N = rng.choice([2, 32, 48, 64, 130, 256, 302, 1024])
+    K = rng.choice([3, 24, 64, 70, 128, 130, 256, 600, 1000])
+    ta, tb = rng.random() < 0.5, rng.random() < 0.5
+    A = gen((K, M) if ta else (M, K), rng.randrange(10 ** 6))
+    B = gen((N, K) if tb else (K, N), rng.randrange(10 ** 6))
+    kw, desc = {}, []
+    Aeff, Beff = (A.t() if ta else A).double(), (B.t() if tb else B).double()
+    r = rng.random()
+    if r < 0.25:
+        A2 = gen(tuple(A.shape), rng.randrange(10 ** 6))
+        kw["A2"] = A2
+        Aeff = Aeff + (A2.t() if ta else A2).double()
+        desc.append("A2")
+    elif r < 0.5:
+        B2 = gen(tuple(B.shape), rng.randrange(10 ** 6))
+        kw["B2"] = B2
+        Beff = Beff + (B2.t() if tb else B2).double()
+        desc.append("B2")
+    ref = Aeff @ Beff
+    base = gen((M, N), rng.randrange(10 ** 6))
+    C = base.clone()
+    mode = rng.choice(["store", "rmw", "split"])
+    if mode == "rmw":
+        kw["accumulate"] = 1
+        ref = ref + base.double()
+    elif mode == "split":
+        kw["split_k"] = rng.choice([2, 3, 4, 16])
+        ref = ref + base.double()
+    if rng.random() < 0.5:
+        bias = gen((N,), rng.randrange(10 ** 6))
+        kw["bias"] = bias
+        ref = ref + bias.double()
+        desc.append("bias")
+    if rng.random() < 0.3:
+        res = gen((M, N), rng.randrange(10 ** 6))
+        kw["residual"] = res
+        ref = ref + res.double()
+        desc.append("res")
+    colsum = None
+    if rng.random() < 0.4:
+        colsum = torch.zeros(M, device=dev())
+        kw["colsum"] = colsum
+        desc.append("colsum")
+    kn.gemm(A, B, C, trans_a=ta, trans_b=tb, **kw)
+    tag = "M%d N%d K%d ta%d tb%d %s %s" % (M, N, K, ta, tb, mode, "+".join(desc))
+    assert rel_err(C, ref) < TOL, tag
+    if colsum is not None:
+        assert rel_err(colsum, Aeff.sum(1)) < TOL, tag + " [colsum]"
+
+
+def test_gemm_fuzz():
+    """Random shapes x layouts x addends x accumulate modes x side outputs (all tile configs,
+    K tails, split-K chunk tails)."""
+    import random
+    from mesm_amd import kernels as kn
+    rng = random.Random(1234)
+    for _ in range(300):
+        _gemm_fuzz_case(rng, kn)
+
+
+def test_gemm_fuzz_activations():
+    """Random shapes with the activation prologue / epilogue / gradient-epilogue features."""
+    import random
+    from mesm_amd import kernels as kn
+    rng = random.Random(77)
+    slope = torch.tensor([0.2], device=dev())
+    for it in range(200):
+        M = rng.choice([7, 24, 32, 80, 256, 264, 600, 608])
+        N = rng.choice([32, 64, 256, 1024])
+        K = rng.choice([24, 64, 256, 1024])
+        A = gen((M, K), rng.randrange(10 ** 6))
+        tb = rng.random() < 0.5
+        B = gen((N, K) if tb else (K, N), rng.randrange(10 ** 6), 0.1)
+        Bm = (B.t() if tb else B).double()
+        feat = rng.choice(["e_relu", "e_prelu", "a_prelu", "grad_prelu", "grad_relu", "b_prelu"])
+        C = torch.empty(M, N, device=dev())
+        tag = "%s M%d N%d K%d tb%d" % (feat, M, N, K, tb)
+        if feat == "e_relu":
+            kn.gemm(A, B, C, trans_b=tb, e_act=kn.ACT_RELU)
+            ref = (A.double() @ Bm).clamp(min=0)
+        elif feat == "e_prelu":
+            kn.gemm(A, B, C, trans_b=tb, e_act=kn.ACT_PRELU, slope=slope)
+            z = A.double() @ Bm
+            ref = torch.where(z > 0, z, 0.2 * z)
+        elif feat == "a_prelu":
+            kn.gemm(A, B, C, trans_b=tb, a_act=kn.ACT_PRELU, slope=slope)
+            ref = torch.where(A > 0, A, 0.2 * A).double() @ Bm
+        elif feat == "b_prelu":
+            At = gen((K, M), rng.randrange(10 ** 6))
+            Bn = gen((K, N), rng.randrange(10 ** 6))
+            kn.gemm(At, Bn, C, trans_a=True, b_act=kn.ACT_PRELU, slope=slope)
+            ref = At.t().double() @ torch.where(Bn > 0, Bn, 0.2 * Bn).double()
+        else:
+            aux = gen((M, N), rng.randrange(10 ** 6))
+            ds = torch.zeros(1, device=dev())
+            full = A.double() @ Bm
+            if feat == "grad_prelu":
+                kn.gemm(A, B, C, trans_b=tb, aux=aux, e_actgrad=kn.ACT_PRELU, slope=slope, dslope=ds)
+                ref = torch.where(aux > 0, full, 0.2 * full)
+                ds_ref = float((full * aux.double().clamp(max=0)).sum())
+                assert abs(ds.item() - ds_ref) < 2e-4 * max(abs(ds_ref), full.abs().sum().item() * 1e-3), tag
+            else:
+                kn.gemm(A, B, C, trans_b=tb, aux=aux, e_actgrad=kn.ACT_RELU)
+                ref = torch.where(aux > 0, full, torch.zeros_like(full))
+        assert rel_err(C, ref) < TOL, tag
