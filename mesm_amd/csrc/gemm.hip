@@ -458,6 +458,20 @@ int launch_tile(const MesmGemmArgs& a, hipStream_t s) {
   const int add = a.A2 ? 1 : (a.B2 ? 2 : 0);
   const long z = a.split_k > 1 ? a.split_k : 1;
   auto blocks = [&](int t) { return (long)((a.M + t - 1) / t) * ((a.N + t - 1) / t) * z; };
+  // tuning knob (tools/gemm_bench3.py): MESM_GEMM_TILE=32|64|128 pins the configuration
+  const char* force_env = getenv("MESM_GEMM_TILE");
+  const int force_tile = force_env ? atoi(force_env) : 0;
+  if (force_tile == 128 && add == 0) return launch_layout<128, 128, VEC, 0>(a, s);
+  if (force_tile == 64) {
+    if (add == 0) return launch_layout<64, 64, VEC, 0>(a, s);
+    if (add == 1) return launch_layout<64, 64, VEC, 1>(a, s);
+    return launch_layout<64, 64, VEC, 2>(a, s);
+  }
+  if (force_tile == 32) {
+    if (add == 0) return launch_layout<32, 32, VEC, 0>(a, s);
+    if (add == 1) return launch_layout<32, 32, VEC, 1>(a, s);
+    return launch_layout<32, 32, VEC, 2>(a, s);
+  }
   // largest tile that still gives every CU about two workgroups; the small 32x32 k-split tile
   // otherwise (most d x d GEMMs of the step: 2400 x 256 x 256 -> 600 workgroups)
   if (blocks(128) >= 512 && add == 0) return launch_layout<128, 128, VEC, 0>(a, s);

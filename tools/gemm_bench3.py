@@ -28,14 +28,18 @@ for name, M, N, K, ta, tb, split in SHAPES:
     B = torch.randn((N, K) if tb else (K, N), device=dev)
     C = torch.zeros(M, N, device=dev)
     keep.append((A, B, C))
-    kn.gemm_tape(True)
-    kn.gemm(A, B, C, trans_a=ta, trans_b=tb, split_k=split)
-    kn.gemm_tape(False)
-    kn.gemm_tape_replay(5)
-    r = kn.gemm_tape_replay(100)
-    us = r["ms"] / r["launches"] * 1e3
-    print("%s M=%5d N=%5d K=%5d  %8.2f us %6.1f TF (same kernel x100, event pair each)" % (
-        name, M, N, K, us, 2.0 * M * N * K / us / 1e6), flush=True)
+    res = []
+    for tile in ("0", "32", "64", "128"):
+        os.environ["MESM_GEMM_TILE"] = tile
+        kn.gemm_tape(True)
+        kn.gemm(A, B, C, trans_a=ta, trans_b=tb, split_k=split)
+        kn.gemm_tape(False)
+        kn.gemm_tape_replay(5)
+        r = kn.gemm_tape_replay(100)
+        res.append(r["ms"] / r["launches"] * 1e3)
+    os.environ["MESM_GEMM_TILE"] = "0"
+    print("%s M=%5d N=%5d K=%5d  auto %7.2f | t32 %7.2f | t64 %7.2f | t128 %7.2f us  (best %5.1f TF)" % (
+        name, M, N, K, res[0], res[1], res[2], res[3], 2.0 * M * N * K / min(res) / 1e6), flush=True)
 # all shapes interleaved (code of different instantiations alternates)
 kn.gemm_tape(True)
 for (name, M, N, K, ta, tb, split), (A, B, C) in zip(SHAPES, keep):
