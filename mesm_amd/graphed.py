@@ -76,6 +76,17 @@ class GraphedStep:
         total.backward()
         return total.detach(), {k: v.detach() for k, v in losses.items()}
 
+    def load_batch(self, batch):
+        """Copy a new batch of the SAME shapes (and the same group sizes / target counts, which
+        the captured index plans depend on) into the static input buffers."""
+        for k, v in batch.items():
+            cur = self.batch.get(k)
+            if torch.is_tensor(cur) and torch.is_tensor(v):
+                if cur.shape != v.shape:
+                    raise ValueError("GraphedStep.load_batch: %s changed shape %s -> %s"
+                                     % (k, tuple(cur.shape), tuple(v.shape)))
+                cur.copy_(v, non_blocking=True)
+
     def redraw(self):
         """New negative-query indices and MLM word choices (host RNG, like the reference does on
         every forward), copied into the static index tensors the graph reads."""

@@ -10,6 +10,9 @@ reference module, so `runner.build_model` / train.py / eval.py can use it unchan
     made once per call in `make_plan` from CPU copies of the masks, so the device work is a
     fixed sequence of kernels (capturable in a HIP graph for a fixed batch shape).
 """
+import contextlib
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -21,6 +24,14 @@ from .gradbuf import GradBuffer
 from .layers import (LinearLayer, MLPHead, ParamLayerNorm, ParamLinear, T2VLayer, T2VStack,
                      inverse_sigmoid)
 from .ops import drop_state
+
+
+_SCOPES = os.environ.get("MESM_SCOPES") == "1"
+
+
+def _scope(name):
+    """Profiler region (tools/count_kernels.py); a no-op unless MESM_SCOPES=1."""
+    return torch.profiler.record_function("R:" + name) if _SCOPES else contextlib.nullcontext()
 
 
 class TrainablePositionalEncoding(nn.Module):
@@ -252,14 +263,15 @@ class MESM(nn.Module):
         d, h = self.hidden_dim, self.transformer.nhead
         N, Lv = video_mask.shape
 
-        # post_process_text (model.py:145-152)
-        words = words_id
-        if self.normalize_txt:
-            words = F.normalize(words, dim=-1, p=2, eps=1e-5)
-        words_mask = words.sum(dim=-1) != 0
-        sent = words.sum(dim=1) / words_mask.sum(dim=1).unsqueeze(-1)
-        if self.normalize_txt:
-            sent = F.normalize(sent, dim=-1, p=2, eps=1e-5)
+        with _scope("text"):
+            # post_process_text (model.py:145-152)
+            words = words_id
+            if self.normalize_txt:
+                words = F.normalize(words, dim=-1, p=2, eps=1e-5)
+            words_mask = words.sum(dim=-1) != 0
+            sent = words.sum(dim=1) / words_mask.sum(dim=1).unsqueeze(-1)
+            if self.normalize_txt:
+                sent = F.normalize(sent, dim=-1, p=2, eps=1e-5)
 
         plan = kwargs.get("plan")
         if plan is None:
@@ -268,55 +280,62 @@ class MESM(nn.Module):
                                   neg_index=kwargs.get("neg_index"),
                                   masked_words=kwargs.get("masked_words"), device=dev)
 
-        vid_pad = (~video_mask).contiguous()
-        words_pad = (~words_mask).contiguous()
-        pv = self._proj(self.input_vid_proj, video_feat)
-        pw = self._proj(self.input_txt_proj, words)
-        vpos = kn.sine_pos(video_mask, d)
+        with _scope("inproj"):
+            vid_pad = (~video_mask).contiguous()
+            words_pad = (~words_mask).contiguous()
+            pv = self._proj(self.input_vid_proj, video_feat)
+            pw = self._proj(self.input_txt_proj, words)
+            vpos = kn.sine_pos(video_mask, d)
 
         enc = self.enhance_encoder
-        enhanced = enc(pw, pv, None, vpos, words_pad, vid_pad) if self.rec_fw else pv
+        with _scope("enhance"):
+            enhanced = enc(pw, pv, None, vpos, words_pad, vid_pad) if self.rec_fw else pv
 
         out = {}
-        if self.rec_ss:
-            if plan.vid_src is not None:
-                bvid = video_feat.reshape(N * Lv, -1)[plan.vid_src] * plan.vid_mask.unsqueeze(-1)
-                bvid_pad = plan.vid_pad
+        with _scope("ss"):
+            if self.rec_ss:
+                if plan.vid_src is not None:
+                    bvid = video_feat.reshape(N * Lv, -1)[plan.vid_src] * plan.vid_mask.unsqueeze(-1)
+                    bvid_pad = plan.vid_pad
+                else:
+                    bvid, bvid_pad = video_feat, vid_pad
+                bsent = sent[plan.sent_src] * plan.sent_mask.unsqueeze(-1)
+                bvid = self._proj(self.input_vid_proj, bvid)
+                bsent = self._proj(self.input_txt_proj, bsent)
+                tok = self.ss_reconstructor.masked_sent_token.view(1, 1, d)
+                q_tok = torch.where(plan.sent_loc.unsqueeze(-1), tok, bsent)
+                rec = self.ss_reconstructor.recon_trans(bvid, q_tok, None, None, bvid_pad, plan.sent_pad)
+                recon = F.normalize(rec[plan.rows, plan.sent_slot])  # the masked slot of every pair
+                # projed_recon_feat feeds no loss (criterion.py:246-255) but is part of the returned dict
+                projed_recon = self._proj(self.ss_reconstructor.output_sent_proj, recon)
+                ewords = torch.cat([recon.unsqueeze(1), pw], dim=1)
+                emask = torch.cat([torch.ones(N, 1, dtype=torch.bool, device=dev), words_mask], dim=1)
             else:
-                bvid, bvid_pad = video_feat, vid_pad
-            bsent = sent[plan.sent_src] * plan.sent_mask.unsqueeze(-1)
-            bvid = self._proj(self.input_vid_proj, bvid)
-            bsent = self._proj(self.input_txt_proj, bsent)
-            tok = self.ss_reconstructor.masked_sent_token.view(1, 1, d)
-            q_tok = torch.where(plan.sent_loc.unsqueeze(-1), tok, bsent)
-            rec = self.ss_reconstructor.recon_trans(bvid, q_tok, None, None, bvid_pad, plan.sent_pad)
-            recon = F.normalize(rec[plan.rows, plan.sent_slot])  # the masked slot of every pair
-            # projed_recon_feat feeds no loss (criterion.py:246-255) but is part of the returned dict
-            projed_recon = self._proj(self.ss_reconstructor.output_sent_proj, recon)
-            ewords = torch.cat([recon.unsqueeze(1), pw], dim=1)
-            emask = torch.cat([torch.ones(N, 1, dtype=torch.bool, device=dev), words_mask], dim=1)
-        else:
-            ewords, emask = pw, words_mask
+                ewords, emask = pw, words_mask
         epad = (~emask).contiguous()
 
-        encoded = self.t2v_encoder(ewords, enhanced, None, vpos, epad, vid_pad)
-        hs, refs, memory, memory_g = self.transformer(encoded, vid_pad, self.query_embed.weight, vpos,
-                                                      self.global_rep_token, self.global_rep_pos)
-        logits = ops.linear(hs, self.class_embed.weight, self.class_embed.bias)
-        spans = torch.sigmoid(self.span_embed(hs) + inverse_sigmoid(refs))
+        with _scope("t2v"):
+            encoded = self.t2v_encoder(ewords, enhanced, None, vpos, epad, vid_pad)
+        with _scope("transformer"):
+            hs, refs, memory, memory_g = self.transformer(encoded, vid_pad, self.query_embed.weight, vpos,
+                                                          self.global_rep_token, self.global_rep_pos)
+        with _scope("heads"):
+            logits = ops.linear(hs, self.class_embed.weight, self.class_embed.bias)
+            spans = torch.sigmoid(self.span_embed(hs) + inverse_sigmoid(refs))
 
         # negative pass (model.py:260-299); decoder skipped: its outputs are discarded at :295
-        ni = plan.neg_index
-        n_ewords, n_emask = ewords[ni], emask[ni]
-        if self.rec_ss:
-            n_words, n_wpad = n_ewords[:, 1:], (~n_emask[:, 1:]).contiguous()
-        else:
-            n_words, n_wpad = n_ewords, (~n_emask).contiguous()
-        n_enh = enc(n_words, pv, None, vpos, n_wpad, vid_pad) if self.rec_fw else pv
-        n_enc = self.t2v_encoder(n_ewords, n_enh, None, vpos, (~n_emask).contiguous(), vid_pad)
-        _, _, n_memory, n_memory_g = self.transformer(n_enc, vid_pad, self.query_embed.weight, vpos,
-                                                      self.global_rep_token, self.global_rep_pos,
-                                                      run_decoder=False)
+        with _scope("neg"):
+            ni = plan.neg_index
+            n_ewords, n_emask = ewords[ni], emask[ni]
+            if self.rec_ss:
+                n_words, n_wpad = n_ewords[:, 1:], (~n_emask[:, 1:]).contiguous()
+            else:
+                n_words, n_wpad = n_ewords, (~n_emask).contiguous()
+            n_enh = enc(n_words, pv, None, vpos, n_wpad, vid_pad) if self.rec_fw else pv
+            n_enc = self.t2v_encoder(n_ewords, n_enh, None, vpos, (~n_emask).contiguous(), vid_pad)
+            _, _, n_memory, n_memory_g = self.transformer(n_enc, vid_pad, self.query_embed.weight, vpos,
+                                                          self.global_rep_token, self.global_rep_pos,
+                                                          run_decoder=False)
 
         def saliency(mem, mem_g):
             a = ops.linear(mem, self.saliency_proj1.weight, self.saliency_proj1.bias)

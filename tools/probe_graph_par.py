@@ -1,0 +1,101 @@
+"""Probe: do parallel branches of a captured HIP graph run concurrently on gfx950 / ROCm 7.2, and
+what does a fork/join pair cost?  Workload: 64 launches of the 2400x256x256 forward GEMM."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mesm_amd import kernels as kn
+
+dev = torch.device("cuda:0")
+M, N, K = [int(x) for x in (sys.argv[1:4] if len(sys.argv) > 3 else (2400, 256, 256))]
+NL = 64
+A = [torch.randn(M, K, device=dev) for _ in range(NL)]
+W = [torch.randn(N, K, device=dev) for _ in range(NL)]
+C = [torch.zeros(M, N, device=dev) for _ in range(NL)]
+
+
+def g(i):
+    kn.gemm(A[i], W[i], C[i], trans_b=True)
+
+
+def capture(body):
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        body()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        body()
+    return gr
+
+
+def timeit(gr, reps=50):
+    for _ in range(5):
+        gr.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        gr.replay()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e6
+
+
+def serial():
+    for i in range(NL):
+        g(i)
+
+
+def branches(nb):
+    sides = [torch.cuda.Stream() for _ in range(nb - 1)]
+
+    def body():
+        cur = torch.cuda.current_stream()
+        for s in sides:
+            s.wait_stream(cur)
+        per = NL // nb
+        for b in range(nb):
+            st = cur if b == 0 else sides[b - 1]
+            with torch.cuda.stream(st):
+                for i in range(b * per, (b + 1) * per):
+                    g(i)
+        for s in sides:
+            cur.wait_stream(s)
+    return body
+
+
+def forkjoin_each():
+    side = torch.cuda.Stream()
+
+    def body():
+        cur = torch.cuda.current_stream()
+        for i in range(0, NL, 2):
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                g(i)
+            g(i + 1)
+            cur.wait_stream(side)
+    return body
+
+
+def fork_only():
+    """main chain of 32, each step forks one side kernel; single join at the end (dW pattern)."""
+    side = torch.cuda.Stream()
+
+    def body():
+        cur = torch.cuda.current_stream()
+        for i in range(0, NL, 2):
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                g(i)
+            g(i + 1)
+        cur.wait_stream(side)
+    return body
+
+
+print("shape", M, N, K)
+print("serial 64           : %8.1f us" % timeit(capture(serial)))
+for nb in (2, 4, 8):
+    print("%d branches          : %8.1f us" % (nb, timeit(capture(branches(nb)))))
+print("fork+join each pair : %8.1f us" % timeit(capture(forkjoin_each())))
+print("fork each, join end : %8.1f us" % timeit(capture(fork_only())))
