@@ -299,6 +299,87 @@ int mesm_match(const float* logits, const float* spans, const float* tgt_cxw,
                int32_t Tmax, float w_span, float w_giou, float w_class, float* cost,
                int32_t* match_q, void* stream);
 
+/* ------------------------------------------------------------------------- */
+/* Fused criterion blocks: one launch per loss and direction (criterion.hip).   */
+
+/*
+ * Hungarian match + span / gIoU / label losses of ONE decoder layer.  Replaces
+ * HungarianMatcher.forward (matcher.py:39-117) followed by Criterion.loss_spans
+ * (criterion.py:71-110) and Criterion.loss_labels (criterion.py:112-137):
+ *   out4[0] = mean |src - tgt| over the matched (sumT x 2) elements
+ *   out4[1] = mean (1 - gIoU(xx(src), tgt_xx)) over the matched pairs
+ *   out4[2] = mean over N*Q of -log_softmax(logits)[cls] * {1, eos_coef}[cls]
+ *             (cls = 0 on matched queries, 1 elsewhere; plain mean, quirk Q9)
+ *   out4[3] = class_error = 100 - 100 * #(matched & argmax == 0) / sumT
+ * match_q (sumT) int32 as in mesm_match.  One workgroup, deterministic sums.
+ * bwd: dlogits, dspans (N, Q, 2) fully written; g3 = device pointer to the upstream
+ * gradients of out4[0..2] (three consecutive floats).
+ */
+int mesm_set_loss_fwd(const float* logits, const float* spans, const float* tgt_cxw,
+                      const float* tgt_xx, const int32_t* tgt_off, int32_t N, int32_t Q,
+                      int32_t Tmax, float w_span, float w_giou, float w_class, float eos_coef,
+                      int32_t* match_q, float* out4, void* stream);
+int mesm_set_loss_bwd(const float* logits, const float* spans, const float* tgt_cxw,
+                      const float* tgt_xx, const int32_t* tgt_off, const int32_t* match_q,
+                      int32_t N, int32_t Q, float eos_coef, const float* g3, float* dlogits,
+                      float* dspans, void* stream);
+
+/*
+ * SS-MESM reconstruction loss, Criterion.loss_rec_ss (criterion.py:223-274, "ablation 3"):
+ * masked mean of projed_video_feat pv (N, Lv, D) over the GT clips cmask and of
+ * expanded_words_feat ew (N, Le, D) over wmask, F.normalize (eps 1e-12), sim = cn wn^T / tau,
+ * logits = sim - rowmax, log_prob = logits - log(sum exp + 1e-6),
+ * loss = mean_n -(sum_k pos[n,k] log_prob[n,k]) / (sum_k pos[n,k] + 1e-6).
+ * pos (N, N) uint8 is target-only (block-diagonal gIoU >= gamma) and built by the caller.
+ * Saved for backward: cn, wn (N, D), stats (N, 4) = {#clips, #words, |clip|, |words|},
+ * sim (N, N).  bwd writes dpv (N, Lv, D) and dew (N, Le, D) in full; g = device scalar.
+ */
+int mesm_rec_ss_fwd(const float* pv, const uint8_t* cmask, int32_t Lv, const float* ew,
+                    const uint8_t* wmask, int32_t Le, const uint8_t* pos, int32_t N, int32_t D,
+                    float tau, float* cn, float* wn, float* stats, float* sim, float* out,
+                    void* stream);
+int mesm_rec_ss_bwd(const float* cn, const float* wn, const uint8_t* pos, const float* sim,
+                    const float* stats, const uint8_t* cmask, const uint8_t* wmask, int32_t N,
+                    int32_t D, int32_t Lv, int32_t Le, float tau, const float* g, float* dpv,
+                    float* dew, void* stream);
+
+/*
+ * Reductions around mesm_nll_smooth_* for Criterion.loss_rec_fw (criterion.py:276-304):
+ * out2[0] = mean_n( sum_w row_loss[n,w] / #valid words of n ), out2[1] = masked accuracy.
+ * rowgrad: row_grad[n,w] = (*g) * mask[n,w] / (N * #valid words of n)  -> mesm_nll_smooth_bwd.
+ */
+int mesm_rec_fw_reduce(const float* row_loss, const uint8_t* correct, const uint8_t* mask,
+                       int32_t N, int32_t Lw, float* out2, void* stream);
+int mesm_rec_fw_rowgrad(const uint8_t* mask, int32_t N, int32_t Lw, const float* g,
+                        float* row_grad, void* stream);
+
+/*
+ * Saliency score (model.py:301-302): s[n,l] = <a[n,l,:], b[n,:]> * scale with
+ * a = saliency_proj1(memory) (N, L, D), b = saliency_proj2(memory_global) (N, D),
+ * scale = 1/sqrt(hidden_dim).  bwd: da = ds (x) b * scale, db = sum_l ds * a * scale.
+ */
+int mesm_rowdot_fwd(const float* a, const float* b, int32_t N, int32_t L, int32_t D, float scale,
+                    float* s, void* stream);
+int mesm_rowdot_bwd(const float* a, const float* b, const float* ds, int32_t N, int32_t L,
+                    int32_t D, float scale, float* da, float* db, void* stream);
+
+/*
+ * MESM.post_process_text (model.py:145-152): words = F.normalize(x, eps 1e-5) when
+ * `normalize`, wmask = (sum_c words != 0), sent = normalize(sum_w words / #valid).
+ * x, words (N, Lw, D); wmask (N, Lw) uint8; sent (N, D).  No gradient (inputs are features).
+ */
+int mesm_text_prep(const float* x, int32_t N, int32_t Lw, int32_t D, int32_t normalize,
+                   float* words, uint8_t* wmask, float* sent, void* stream);
+
+/*
+ * total = sum_k weights[k] * vals[k] (Criterion.forward, criterion.py:361-365; entries with
+ * weight 0 are skipped so logged-only values may be non-finite) and its backward
+ * out[k] = (*g) * weights[k].  All device pointers.
+ */
+int mesm_weighted_sum(const float* vals, const float* weights, int32_t n, float* out,
+                      void* stream);
+int mesm_scale_vec(const float* g, const float* weights, int32_t n, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

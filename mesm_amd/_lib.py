@@ -83,6 +83,17 @@ PROTOTYPES = {
     "mesm_saliency_loss_fwd": (ctypes.c_int, [c_ptr] * 6 + [_i32, _i32, _i32, _f32, _f32, c_ptr, c_ptr]),
     "mesm_saliency_loss_bwd": (ctypes.c_int, [c_ptr] * 6 + [_i32, _i32, _i32, _f32, _f32, c_ptr, c_ptr, c_ptr, c_ptr]),
     "mesm_match": (ctypes.c_int, [c_ptr] * 5 + [_i32, _i32, _i32, _f32, _f32, _f32, c_ptr, c_ptr, c_ptr]),
+    "mesm_set_loss_fwd": (ctypes.c_int, [c_ptr] * 5 + [_i32, _i32, _i32, _f32, _f32, _f32, _f32, c_ptr, c_ptr, c_ptr]),
+    "mesm_set_loss_bwd": (ctypes.c_int, [c_ptr] * 6 + [_i32, _i32, _f32, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "mesm_rec_ss_fwd": (ctypes.c_int, [c_ptr, c_ptr, _i32, c_ptr, c_ptr, _i32, c_ptr, _i32, _i32, _f32] + [c_ptr] * 6),
+    "mesm_rec_ss_bwd": (ctypes.c_int, [c_ptr] * 7 + [_i32, _i32, _i32, _i32, _f32] + [c_ptr] * 4),
+    "mesm_rec_fw_reduce": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, _i32, _i32, c_ptr, c_ptr]),
+    "mesm_rec_fw_rowgrad": (ctypes.c_int, [c_ptr, _i32, _i32, c_ptr, c_ptr, c_ptr]),
+    "mesm_rowdot_fwd": (ctypes.c_int, [c_ptr, c_ptr, _i32, _i32, _i32, _f32, c_ptr, c_ptr]),
+    "mesm_rowdot_bwd": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, _i32, _i32, _i32, _f32, c_ptr, c_ptr, c_ptr]),
+    "mesm_text_prep": (ctypes.c_int, [c_ptr, _i32, _i32, _i32, _i32, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "mesm_weighted_sum": (ctypes.c_int, [c_ptr, c_ptr, _i32, c_ptr, c_ptr]),
+    "mesm_scale_vec": (ctypes.c_int, [c_ptr, c_ptr, _i32, c_ptr, c_ptr]),
 }
 
 _lib = None

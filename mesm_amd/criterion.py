@@ -1,13 +1,13 @@
-"""Criterion + HungarianMatcher (model/criterion.py, model/matcher.py of the reference) with
-the per-pair reductions on the gfx950 kernels and no host synchronisation inside forward:
-matching cost + assignment run on the device (mesm_match), the saliency losses and the
-masked-LM NLL are fused kernels, and every index the losses need is a device tensor.
+"""Criterion + HungarianMatcher (model/criterion.py, model/matcher.py of the reference) as ONE
+autograd block on the gfx950 kernels: every loss is one forward and one backward launch
+(csrc/criterion.hip, csrc/losses.hip), the matching runs on the device inside the set-loss
+kernel, all indices the losses need are device tensors, and nothing synchronises with the host.
 """
 import torch
 from torch import nn
+from torch.autograd import Function
 
 from . import kernels as kn
-from . import ops
 
 
 def span_cxw_to_xx(s):
@@ -19,7 +19,7 @@ def span_xx_to_cxw(s):
 
 
 def generalized_temporal_iou(a, b):
-    """utils/span_utils.py:92-121 (pairwise (len(a), len(b)) matrix)."""
+    """utils/span_utils.py:92-121 (pairwise (len(a), len(b)) matrix); host-side use only."""
     a, b = a.float(), b.float()
     inter = (torch.min(a[:, None, 1], b[:, 1]) - torch.max(a[:, None, 0], b[:, 0])).clamp(min=0)
     union = (a[:, 1] - a[:, 0])[:, None] + (b[:, 1] - b[:, 0]) - inter
@@ -27,28 +27,27 @@ def generalized_temporal_iou(a, b):
     return inter / union - (enc - union) / enc
 
 
-def paired_giou(a, b):
-    """diag(generalized_temporal_iou(a, b)) without the full matrix."""
-    inter = (torch.min(a[:, 1], b[:, 1]) - torch.max(a[:, 0], b[:, 0])).clamp(min=0)
-    union = (a[:, 1] - a[:, 0]) + (b[:, 1] - b[:, 0]) - inter
-    enc = (torch.max(a[:, 1], b[:, 1]) - torch.min(a[:, 0], b[:, 0])).clamp(min=0)
-    return inter / union - (enc - union) / enc
-
-
 class TargetPlan:
     """Flattened targets + host-built index tensors (built once per batch, reused for the aux
     decoder layers): tgt_cxw / tgt_xx (sumT, 2), tgt_off (N+1) int32, pair_of_t (sumT) int64,
-    Tmax, group_mask (N, N) bool (True where two pairs share a video group)."""
+    Tmax, group_mask (N, N) bool (True where two pairs share a video group) and ss_pos (N, N)
+    uint8, the positives of loss_rec_ss (criterion.py:224-238: block-diagonal gIoU of the
+    merged moments >= gamma) — target-only, so it is evaluated on the host in fp32."""
 
-    def __init__(self, targets, multi_clip, device):
+    def __init__(self, targets, multi_clip, device, gamma=0.9):
         if multi_clip:
             sizes = [len(t["spans"]) for t in targets["norm_span"]]
-            self.tgt_cxw = torch.cat([t["spans"] for t in targets["norm_span"]]).to(device).float().contiguous()
-            self.tgt_xx = torch.cat([t["moments"] for t in targets["norm_moment"]]).to(device).float().contiguous()
+            cxw = torch.cat([t["spans"] for t in targets["norm_span"]]).float().cpu()
+            xx = torch.cat([t["moments"] for t in targets["norm_moment"]]).float().cpu()
+            mom = torch.stack([torch.stack([t["moments"].min(), t["moments"].max()])
+                               for t in targets["norm_moment"]]).float().cpu()
         else:
-            self.tgt_cxw = targets["norm_span"].to(device).float().contiguous()
-            self.tgt_xx = targets["norm_moment"].to(device).float().contiguous()
-            sizes = [1] * self.tgt_cxw.shape[0]
+            cxw = targets["norm_span"].float().cpu()
+            xx = targets["norm_moment"].float().cpu()
+            sizes = [1] * cxw.shape[0]
+            mom = xx
+        self.tgt_cxw = cxw.contiguous().to(device)
+        self.tgt_xx = xx.contiguous().to(device)
         self.sizes = sizes
         self.N = len(sizes)
         self.Tmax = max(sizes)
@@ -57,10 +56,11 @@ class TargetPlan:
             off.append(off[-1] + s)
         self.tgt_off = torch.tensor(off, dtype=torch.int32, device=device)
         self.pair_of_t = torch.repeat_interleave(torch.arange(self.N), torch.tensor(sizes)).to(device)
-        nc = targets["num_clips"]
-        groups = [int(g) for g in nc.tolist()]
+        groups = [int(g) for g in targets["num_clips"].tolist()]
         gid = torch.repeat_interleave(torch.arange(len(groups)), torch.tensor(groups))
-        self.group_mask = (gid[:, None] == gid[None, :]).to(device)
+        gmask = gid[:, None] == gid[None, :]
+        self.group_mask = gmask.to(device)
+        self.ss_pos = ((generalized_temporal_iou(mom, mom) >= gamma) & gmask).to(torch.uint8).contiguous().to(device)
 
 
 class HungarianMatcher(nn.Module):
@@ -83,12 +83,10 @@ class HungarianMatcher(nn.Module):
                         outputs["pred_spans"].detach().contiguous(), plan.tgt_cxw, plan.tgt_xx,
                         plan.tgt_off, plan.Tmax, self.cost_span, self.cost_giou, self.cost_class)
 
-    @torch.no_grad()
-    def forward(self, outputs, targets):
-        """Reference-format result (host tensors; synchronises): list of (query_idx, target_idx)
-        sorted by query for multi_clip, else an (N, 2) tensor [query, 0]."""
-        plan = TargetPlan(targets, self.multi_clip, outputs["pred_spans"].device)
-        mq = self.match_device(outputs, plan).cpu().to(torch.int64)
+    def to_reference_format(self, mq, plan):
+        """device match_q -> the reference's return value (host tensors; synchronises): list of
+        (query_idx, target_idx) sorted by query for multi_clip, else an (N, 2) tensor [query, 0]."""
+        mq = mq.cpu().to(torch.int64)
         if not self.multi_clip:
             return torch.stack([mq, torch.zeros_like(mq)], dim=1)
         res, start = [], 0
@@ -98,6 +96,94 @@ class HungarianMatcher(nn.Module):
             res.append((q[order], order.to(torch.int64)))
             start += s
         return res
+
+    @torch.no_grad()
+    def forward(self, outputs, targets):
+        plan = TargetPlan(targets, self.multi_clip, outputs["pred_spans"].device)
+        return self.to_reference_format(self.match_device(outputs, plan), plan)
+
+
+class _Spec:
+    """Static description of one criterion call: which blocks run, where their values sit in the
+    loss vector, and the non-differentiable side inputs."""
+    pass
+
+
+class CriterionFn(Function):
+    """(total, loss_vector) = criterion(model outputs).  Forward: one launch per loss block writing
+    straight into its slots of the loss vector + one weighted sum.  Backward: one launch that
+    turns d total into per-slot scales, then one launch per block."""
+
+    @staticmethod
+    def forward(ctx, spec, *t):
+        c, plan = spec.crit, spec.plan
+        m = c.matcher
+        dev = t[0].device
+        lv = torch.empty(len(spec.names), device=dev, dtype=torch.float32)
+        saved = {}
+        matches = []
+        for li, (il, isp, slot) in enumerate(spec.set_layers):
+            logits, spans = t[il].contiguous(), t[isp].contiguous()
+            mq = kn.set_loss_fwd(logits, spans, plan.tgt_cxw, plan.tgt_xx, plan.tgt_off, plan.Tmax,
+                                 m.cost_span, m.cost_giou, m.cost_class, c.eos_coef, lv[slot:slot + 4])
+            matches.append(mq)
+            saved["set%d" % li] = (logits, spans, mq)
+        if spec.sal is not None:
+            ip, ineg, slot = spec.sal
+            sp, sn = t[ip].contiguous(), t[ineg].contiguous()
+            kn.saliency_loss_fwd(sp, sn, spec.sal_label, spec.vmask, spec.pos_idx, spec.neg_idx,
+                                 float(c.rank_coef), float(c.saliency_margin), out=lv[slot:slot + 1])
+            saved["sal"] = (sp, sn)
+        if spec.recfw is not None:
+            il, slot = spec.recfw
+            logit = t[il].contiguous()
+            C = logit.shape[-1]
+            row_loss, row_lse, correct = kn.nll_smooth_fwd(logit.view(-1, C), spec.words_label,
+                                                           spec.words_mask.view(-1), 0.1)
+            kn.rec_fw_reduce(row_loss, correct, spec.words_mask, lv[slot:slot + 2])
+            saved["recfw"] = (logit, row_lse)
+        if spec.recss is not None:
+            ipv, iew, slot = spec.recss
+            pv, ew = t[ipv].contiguous(), t[iew].contiguous()
+            saved["recss"] = kn.rec_ss_fwd(pv, spec.clip_mask, ew, spec.ewords_mask, plan.ss_pos,
+                                           c.recss_tau, lv[slot:slot + 1])
+            saved["recss_shape"] = (pv.shape[1], ew.shape[1])
+        total = kn.weighted_sum(lv, spec.wv)
+        ctx.spec, ctx.saved, ctx.n_in = spec, saved, len(t)
+        spec.matches = matches
+        ctx.mark_non_differentiable(lv)
+        return total, lv
+
+    @staticmethod
+    def backward(ctx, g_total, _g_lv):
+        spec, saved = ctx.spec, ctx.saved
+        c, plan = spec.crit, spec.plan
+        grads = [None] * ctx.n_in
+        g = g_total.reshape(1).to(torch.float32).contiguous()
+        gv = kn.scale_vec(g, spec.wv)
+        for li, (il, isp, slot) in enumerate(spec.set_layers):
+            logits, spans, mq = saved["set%d" % li]
+            grads[il], grads[isp] = kn.set_loss_bwd(logits, spans, plan.tgt_cxw, plan.tgt_xx,
+                                                    plan.tgt_off, mq, c.eos_coef, gv[slot:slot + 3])
+        if spec.sal is not None:
+            ip, ineg, slot = spec.sal
+            sp, sn = saved["sal"]
+            grads[ip], grads[ineg] = kn.saliency_loss_bwd(
+                sp, sn, spec.sal_label, spec.vmask, spec.pos_idx, spec.neg_idx, float(c.rank_coef),
+                float(c.saliency_margin), gv[slot:slot + 1])
+        if spec.recfw is not None:
+            il, slot = spec.recfw
+            logit, row_lse = saved["recfw"]
+            C = logit.shape[-1]
+            rg = kn.rec_fw_rowgrad(spec.words_mask, gv[slot:slot + 1])
+            grads[il] = kn.nll_smooth_bwd(logit.view(-1, C), spec.words_label, row_lse, rg, 0.1).view(logit.shape)
+        if spec.recss is not None:
+            ipv, iew, slot = spec.recss
+            Lv, Le = saved["recss_shape"]
+            grads[ipv], grads[iew] = kn.rec_ss_bwd(saved["recss"], plan.ss_pos, spec.clip_mask,
+                                                   spec.ewords_mask, Lv, Le, c.recss_tau,
+                                                   gv[slot:slot + 1])
+        return (None,) + tuple(grads)
 
 
 class Criterion(nn.Module):
@@ -124,109 +210,83 @@ class Criterion(nn.Module):
         self.multi_clip = multi_clip
         self.gamma = gamma
         self.recss_tau = recss_tau
+        self._wv_cache = {}
+        for loss in losses:
+            if loss not in ("span", "label", "saliency", "rec_fw", "rec_ss"):
+                raise AssertionError("do you really want to compute %s loss?" % loss)
 
-    # -- span / label losses on the matched pairs (criterion.py:71-137)
-    def loss_spans(self, outputs, plan, match_q):
-        spans = outputs["pred_spans"]
-        Q = spans.shape[1]
-        flat = plan.pair_of_t * Q + match_q.to(torch.int64)
-        src = spans.reshape(-1, 2)[flat]
-        loss_span = (src - plan.tgt_cxw).abs().mean()
-        loss_giou = (1 - paired_giou(span_cxw_to_xx(src), plan.tgt_xx)).mean()
-        return {"loss_span": loss_span, "loss_giou": loss_giou}
-
-    def loss_labels(self, outputs, plan, match_q, log=True):
-        logits = outputs["pred_logits"]
-        N, Q = logits.shape[:2]
-        flat = plan.pair_of_t * Q + match_q.to(torch.int64)
-        cls = torch.ones(N * Q, dtype=torch.int64, device=logits.device)
-        cls.index_fill_(0, flat, self.foreground_label)  # no host scalar copy: graph-capturable
-        logp = torch.log_softmax(logits.reshape(N * Q, 2), dim=-1)
-        ce = -logp.gather(1, cls[:, None]).squeeze(1) * self.empty_weight[cls]
-        losses = {"loss_label": ce.mean()}
-        if log:
-            picked = logits.detach().reshape(N * Q, 2)[flat]
-            acc = (picked.argmax(-1) == self.foreground_label).float().sum() * (100.0 / picked.shape[0])
-            losses["class_error"] = 100 - acc
-        return losses
-
-    def loss_saliency(self, outputs, targets):
-        vmask = targets["video_mask"]
-        if "saliency_label" in targets:
-            label = targets["saliency_label"]
-        else:
-            label = targets["clip_mask"]
-        label = label.to(torch.float64).contiguous()
-        pos_idx = targets["pos_idx"].contiguous() if self.use_triplet else None
-        neg_idx = targets["neg_idx"].contiguous() if self.use_triplet else None
-        loss = ops.saliency_loss(outputs["saliency_scores"], outputs["neg_saliency_scores"], label,
-                                 vmask.contiguous(), pos_idx, neg_idx, float(self.rank_coef),
-                                 float(self.saliency_margin))
-        return {"loss_saliency": loss}
-
-    def loss_rec_ss(self, outputs, targets, plan):
-        """criterion.py:223-274 (ablation 3)."""
-        if self.multi_clip:
-            idx = plan.pair_of_t[:, None].expand(-1, 1)
-            lo = torch.full((plan.N, 1), float("inf"), device=idx.device).scatter_reduce(
-                0, idx, plan.tgt_xx.min(1, keepdim=True)[0], "amin")
-            hi = torch.full((plan.N, 1), float("-inf"), device=idx.device).scatter_reduce(
-                0, idx, plan.tgt_xx.max(1, keepdim=True)[0], "amax")
-            mom = torch.cat([lo, hi], dim=1)
-        else:
-            mom = plan.tgt_xx
-        pos = (generalized_temporal_iou(mom, mom) >= self.gamma) & plan.group_mask
-        cm = targets["clip_mask"].unsqueeze(-1)
-        clip = (outputs["projed_video_feat"] * cm).sum(dim=1) / cm.sum(dim=1)
-        wm = outputs["expanded_words_mask"].unsqueeze(-1)
-        wf = (outputs["expanded_words_feat"] * wm).sum(dim=1) / wm.sum(dim=1)
-        sim = torch.nn.functional.normalize(clip, dim=-1) @ torch.nn.functional.normalize(wf, dim=-1).t()
-        sim = sim / self.recss_tau
-        lg = sim - sim.max(dim=1, keepdim=True)[0]
-        logp = lg - torch.log(torch.exp(lg).sum(1, keepdim=True) + 1e-6)
-        loss = -(pos * logp).sum(1) / (pos.sum(1) + 1e-6)
-        return {"loss_rec_ss": loss.mean()}
-
-    def loss_rec_fw(self, outputs, targets):
-        """criterion.py:276-306."""
-        mask = outputs["words_mask"]
-        row_loss, correct = ops.nll_smooth(outputs["recfw_words_logit"], targets["words_label"], mask, 0.1)
-        acc = (correct.float() * mask).sum() / mask.sum()
-        nll = row_loss.sum(dim=-1) / mask.sum(dim=-1)
-        return {"loss_rec_fw": nll.mean(), "rec_fw_acc": acc}
+    def _weights(self, names, device):
+        key = (tuple(names), str(device))
+        wv = self._wv_cache.get(key)
+        if wv is None:
+            wv = torch.tensor([float(self.weight_dict.get(n, 0.0)) for n in names], dtype=torch.float32,
+                              device=device)
+            self._wv_cache[key] = wv
+        return wv
 
     def forward(self, outputs, targets, is_training=True):
         device = outputs["pred_spans"].device
         plan = targets.get("_target_plan")
         if plan is None:
-            plan = TargetPlan(targets, self.multi_clip, device)
-        losses = {}
-        mq = self.matcher.match_device(outputs, plan)
-        self.last_match = [mq]
+            plan = TargetPlan(targets, self.multi_clip, device, self.gamma)
+        spec = _Spec()
+        spec.crit, spec.plan = self, plan
+        names, tensors = [], []
+
+        def add(t):
+            tensors.append(t)
+            return len(tensors) - 1
+
+        # span + label blocks need each other's matching: they run in one kernel whenever either
+        # is requested; a loss that was not requested simply gets no entry in the returned dict.
+        want_span, want_label = "span" in self.losses, "label" in self.losses
+        spec.set_layers = []
+        layers = [(outputs["pred_logits"], outputs["pred_spans"], "")]
+        layers += [(a["pred_logits"], a["pred_spans"], "_%d" % i)
+                   for i, a in enumerate(outputs.get("aux_outputs", []))]
+        hidden = set()
+        spec.sal = spec.recfw = spec.recss = None
+
+        def set_block(logits, spans, suffix):
+            slot = len(names)
+            block = ["loss_span", "loss_giou", "loss_label", "class_error"]
+            names.extend(k + suffix for k in block)
+            if not want_span:
+                hidden.update({"loss_span" + suffix, "loss_giou" + suffix})
+            if not want_label:
+                hidden.update({"loss_label" + suffix, "class_error" + suffix})
+            spec.set_layers.append((add(logits), add(spans), slot))
+
+        if want_span or want_label:
+            set_block(*layers[0])
         for loss in self.losses:
-            if loss == "span":
-                losses.update(self.loss_spans(outputs, plan, mq))
-            elif loss == "label":
-                losses.update(self.loss_labels(outputs, plan, mq))
-            elif loss == "saliency":
-                losses.update(self.loss_saliency(outputs, targets))
-            elif loss == "rec_fw":
-                if is_training:
-                    losses.update(self.loss_rec_fw(outputs, targets))
+            if loss == "saliency":
+                vmask = targets["video_mask"]
+                label = targets["saliency_label"] if "saliency_label" in targets else targets["clip_mask"]
+                spec.sal_label = label.to(torch.float64).contiguous()
+                spec.vmask = vmask.contiguous()
+                spec.pos_idx = targets["pos_idx"].contiguous() if self.use_triplet else None
+                spec.neg_idx = targets["neg_idx"].contiguous() if self.use_triplet else None
+                spec.sal = (add(outputs["saliency_scores"]), add(outputs["neg_saliency_scores"]), len(names))
+                names.append("loss_saliency")
+            elif loss == "rec_fw" and is_training:
+                spec.words_label = targets["words_label"].contiguous().view(-1)
+                spec.words_mask = outputs["words_mask"].contiguous()
+                spec.recfw = (add(outputs["recfw_words_logit"]), len(names))
+                names.extend(["loss_rec_fw", "rec_fw_acc"])
             elif loss == "rec_ss":
-                losses.update(self.loss_rec_ss(outputs, targets, plan))
-            else:
-                raise AssertionError("do you really want to compute %s loss?" % loss)
-        for i, aux in enumerate(outputs.get("aux_outputs", [])):
-            amq = self.matcher.match_device(aux, plan)
-            self.last_match.append(amq)
-            for loss in self.losses:
-                if loss == "span":
-                    l = self.loss_spans(aux, plan, amq)
-                elif loss == "label":
-                    l = self.loss_labels(aux, plan, amq)
-                else:
-                    continue
-                losses.update({k + "_%d" % i: v for k, v in l.items()})
-        total = sum(losses[k] * self.weight_dict[k] for k in losses.keys() if k in self.weight_dict)
+                spec.clip_mask = targets["clip_mask"].contiguous()
+                spec.ewords_mask = outputs["expanded_words_mask"].contiguous()
+                spec.recss = (add(outputs["projed_video_feat"]), add(outputs["expanded_words_feat"]),
+                              len(names))
+                names.append("loss_rec_ss")
+        if want_span or want_label:
+            for lg, sp, suffix in layers[1:]:
+                set_block(lg, sp, suffix)
+        spec.names = names
+        wnames = [n if n not in hidden else "" for n in names]
+        spec.wv = self._weights(wnames, device)
+        total, lv = CriterionFn.apply(spec, *tensors)
+        self.last_match = spec.matches
+        losses = {n: lv[i] for i, n in enumerate(names) if n not in hidden}
         return losses, total

@@ -1,0 +1,676 @@
+// Fused criterion blocks (model/criterion.py of the reference): each loss is ONE forward and
+// ONE backward launch instead of a chain of ~50 element-wise ATen kernels.  A serial HIP-graph
+// chain costs ~6 us per launch on MI355X whatever the kernel does, so for these latency-bound
+// reductions the launch count is the cost.
+//
+//   set loss   : Hungarian match (matcher.py:39-117) + loss_spans (criterion.py:71-110)
+//                + loss_labels (:112-137) for one decoder layer
+//   rec_ss     : loss_rec_ss (:223-274)
+//   rec_fw     : reductions after cal_nll_loss (:276-306)
+//   sal score  : saliency dot product (model.py:301-302)
+//   text prep  : post_process_text (model.py:145-152)
+//   wsum       : total = sum_k w_k * loss_k (criterion.py:361-365)
+#include "common.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// 1-D generalized IoU of a predicted span (x1,x2) with a target (g1,g2): span_utils.py:92-121
+struct Giou {
+  float inter, uni, enc, raw_i, raw_e;
+};
+__device__ __forceinline__ float giou_1d(float x1, float x2, float g1, float g2, Giou& s) {
+  s.raw_i = fminf(x2, g2) - fmaxf(x1, g1);
+  s.inter = fmaxf(s.raw_i, 0.0f);
+  s.uni = (x2 - x1) + (g2 - g1) - s.inter;
+  s.raw_e = fmaxf(x2, g2) - fminf(x1, g1);
+  s.enc = fmaxf(s.raw_e, 0.0f);
+  return s.inter / s.uni - (s.enc - s.uni) / s.enc;
+}
+
+__device__ __forceinline__ float tie(float a, float b) {  // d max(a,b)/da with torch's tie split
+  return a > b ? 1.0f : (a == b ? 0.5f : 0.0f);
+}
+
+// ------------------------------------------------------------------------------------------
+// Shortest-augmenting-path assignment (rows = targets, cols = queries, T <= Q) in fp64 on the
+// fp32 costs -- the algorithm of scipy.optimize.linear_sum_assignment.  Work arrays live in LDS,
+// element i of thread `tid` at [i * nthr + tid] (conflict-free).
+struct Sap {
+  double *cost, *u, *v, *minv;
+  int *p, *way;
+  uint8_t* used;
+  int nthr, tid, Q;
+  __device__ __forceinline__ double& C(int t, int q) { return cost[(t * Q + q) * nthr + tid]; }
+  __device__ __forceinline__ double& U(int i) { return u[i * nthr + tid]; }
+  __device__ __forceinline__ double& V(int j) { return v[j * nthr + tid]; }
+  __device__ __forceinline__ double& MV(int j) { return minv[j * nthr + tid]; }
+  __device__ __forceinline__ int& P(int j) { return p[j * nthr + tid]; }
+  __device__ __forceinline__ int& W(int j) { return way[j * nthr + tid]; }
+  __device__ __forceinline__ uint8_t& US(int j) { return used[j * nthr + tid]; }
+};
+
+__device__ void sap_solve(Sap& s, int T, int Q) {
+  for (int i = 0; i <= T; ++i) s.U(i) = 0.0;
+  for (int j = 0; j <= Q; ++j) { s.V(j) = 0.0; s.P(j) = 0; s.W(j) = 0; }
+  for (int i = 1; i <= T; ++i) {
+    s.P(0) = i;
+    int j0 = 0;
+    for (int j = 0; j <= Q; ++j) { s.MV(j) = 1e300; s.US(j) = 0; }
+    do {
+      s.US(j0) = 1;
+      const int i0 = s.P(j0);
+      double delta = 1e300;
+      int j1 = 0;
+      const double ui0 = s.U(i0);
+      for (int j = 1; j <= Q; ++j) {
+        if (!s.US(j)) {
+          const double cur = s.C(i0 - 1, j - 1) - ui0 - s.V(j);
+          double mv = s.MV(j);
+          if (cur < mv) { mv = cur; s.MV(j) = cur; s.W(j) = j0; }
+          if (mv < delta) { delta = mv; j1 = j; }
+        }
+      }
+      for (int j = 0; j <= Q; ++j) {
+        if (s.US(j)) { s.U(s.P(j)) += delta; s.V(j) -= delta; }
+        else s.MV(j) -= delta;
+      }
+      j0 = j1;
+    } while (s.P(j0) != 0);
+    do {
+      const int j1 = s.W(j0);
+      s.P(j0) = s.P(j1);
+      j0 = j1;
+    } while (j0);
+  }
+}
+
+__host__ __device__ inline size_t sap_bytes_per_thread(int Tmax, int Q) {
+  // doubles: cost T*Q, u T+1, v Q+1, minv Q+1;  ints: p, way (Q+1 each);  bytes: used Q+1 (padded to 8)
+  size_t d = (size_t)Tmax * Q + (Tmax + 1) + 2 * (Q + 1);
+  return d * 8 + 2 * (size_t)(Q + 1) * 4 + (size_t)((Q + 1 + 7) / 8 * 8);
+}
+
+// One thread per pair (chunks of blockDim.x pairs); one workgroup, so the four loss sums are
+// reduced without atomics (deterministic).  out[0..3] = loss_span, loss_giou, loss_label,
+// class_error.
+__global__ void set_loss_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ spans,
+                                    const float* __restrict__ tgt_cxw, const float* __restrict__ tgt_xx,
+                                    const int32_t* __restrict__ tgt_off, int N, int Q, int Tmax,
+                                    float w_span, float w_giou, float w_class, float eos_coef, int P,
+                                    int32_t* __restrict__ match_q, float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int nthr = P, tid = threadIdx.x;  // P pairs per pass (LDS budget); threads >= P idle
+  Sap s;
+  s.nthr = nthr; s.tid = tid; s.Q = Q;
+  double* dp = reinterpret_cast<double*>(smem);
+  s.cost = dp; dp += (size_t)Tmax * Q * nthr;
+  s.u = dp; dp += (size_t)(Tmax + 1) * nthr;
+  s.v = dp; dp += (size_t)(Q + 1) * nthr;
+  s.minv = dp; dp += (size_t)(Q + 1) * nthr;
+  int* ip = reinterpret_cast<int*>(dp);
+  s.p = ip; ip += (size_t)(Q + 1) * nthr;
+  s.way = ip; ip += (size_t)(Q + 1) * nthr;
+  s.used = reinterpret_cast<uint8_t*>(ip);
+  __shared__ float red[4][16];
+
+  float a_l1 = 0.0f, a_giou = 0.0f, a_ce = 0.0f, a_ok = 0.0f;
+  for (int b0 = 0; b0 < N; b0 += nthr) {
+    const int b = b0 + tid;
+    if (tid < P && b < N) {
+      const int t0 = tgt_off[b];
+      const int T = tgt_off[b + 1] - t0;
+      for (int q = 0; q < Q; ++q) {
+        const float l0 = logits[((int64_t)b * Q + q) * 2], l1 = logits[((int64_t)b * Q + q) * 2 + 1];
+        const float mx = fmaxf(l0, l1);
+        const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
+        const float prob0 = e0 / (e0 + e1);
+        const float cx = spans[((int64_t)b * Q + q) * 2], w = spans[((int64_t)b * Q + q) * 2 + 1];
+        const float x1 = cx - 0.5f * w, x2 = cx + 0.5f * w;
+        for (int t = 0; t < T; ++t) {
+          const float tc = tgt_cxw[(int64_t)(t0 + t) * 2], tw = tgt_cxw[(int64_t)(t0 + t) * 2 + 1];
+          const float g1 = tgt_xx[(int64_t)(t0 + t) * 2], g2 = tgt_xx[(int64_t)(t0 + t) * 2 + 1];
+          const float c_span = fabsf(cx - tc) + fabsf(w - tw);
+          Giou gi;
+          const float giou = giou_1d(x1, x2, g1, g2, gi);
+          s.C(t, q) = (double)(w_span * c_span + w_giou * (-giou) + w_class * (-prob0));
+        }
+      }
+      sap_solve(s, T, Q);
+      uint32_t matched = 0;
+      for (int j = 1; j <= Q; ++j) {
+        const int pj = s.P(j);
+        if (pj != 0) {
+          const int q = j - 1, t = t0 + pj - 1;
+          match_q[t] = q;
+          matched |= 1u << q;
+          const float cx = spans[((int64_t)b * Q + q) * 2], w = spans[((int64_t)b * Q + q) * 2 + 1];
+          a_l1 += fabsf(cx - tgt_cxw[(int64_t)t * 2]) + fabsf(w - tgt_cxw[(int64_t)t * 2 + 1]);
+          Giou gi;
+          a_giou += 1.0f - giou_1d(cx - 0.5f * w, cx + 0.5f * w, tgt_xx[(int64_t)t * 2],
+                                   tgt_xx[(int64_t)t * 2 + 1], gi);
+          const float l0 = logits[((int64_t)b * Q + q) * 2], l1 = logits[((int64_t)b * Q + q) * 2 + 1];
+          a_ok += (l0 >= l1) ? 1.0f : 0.0f;  // argmax == foreground (first max wins)
+        }
+      }
+      for (int q = 0; q < Q; ++q) {
+        const float l0 = logits[((int64_t)b * Q + q) * 2], l1 = logits[((int64_t)b * Q + q) * 2 + 1];
+        const float mx = fmaxf(l0, l1);
+        const float lse = mx + logf(expf(l0 - mx) + expf(l1 - mx));
+        const bool fg = (matched >> q) & 1u;
+        a_ce += fg ? -(l0 - lse) : -(l1 - lse) * eos_coef;
+      }
+    }
+  }
+  float vals[4] = {a_l1, a_giou, a_ce, a_ok};
+  const int lane = tid & 63, wave = tid >> 6, nw = (int)(blockDim.x >> 6);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float v = wave_sum(vals[k]);
+    if (lane == 0) red[k][wave] = v;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float r[4] = {0, 0, 0, 0};
+    for (int k = 0; k < 4; ++k)
+      for (int w = 0; w < nw; ++w) r[k] += red[k][w];
+    const float sumT = (float)tgt_off[N];
+    out[0] = r[0] / (2.0f * sumT);
+    out[1] = r[1] / sumT;
+    out[2] = r[2] / (float)(N * Q);
+    out[3] = 100.0f - r[3] * (100.0f / sumT);
+  }
+}
+
+// one thread per (pair, query): g = upstream gradient of [loss_span, loss_giou, loss_label, *]
+__global__ __launch_bounds__(256) void set_loss_bwd_kernel(
+    const float* __restrict__ logits, const float* __restrict__ spans, const float* __restrict__ tgt_cxw,
+    const float* __restrict__ tgt_xx, const int32_t* __restrict__ tgt_off,
+    const int32_t* __restrict__ match_q, int N, int Q, float eos_coef, const float* __restrict__ g,
+    float* __restrict__ dlogits, float* __restrict__ dspans) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * Q) return;
+  const int b = i / Q, q = i % Q;
+  const int t0 = tgt_off[b], T = tgt_off[b + 1] - t0;
+  const float sumT = (float)tgt_off[N];
+  int t = -1;
+  for (int k = 0; k < T; ++k)
+    if (match_q[t0 + k] == q) t = t0 + k;
+  const float l0 = logits[(int64_t)i * 2], l1 = logits[(int64_t)i * 2 + 1];
+  const float mx = fmaxf(l0, l1);
+  const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
+  const float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
+  const float gl = g[2] / (float)(N * Q) * (t >= 0 ? 1.0f : eos_coef);
+  // d(-logp[cls])/dl_c = p_c - [c == cls]
+  dlogits[(int64_t)i * 2] = gl * (p0 - (t >= 0 ? 1.0f : 0.0f));
+  dlogits[(int64_t)i * 2 + 1] = gl * (p1 - (t >= 0 ? 0.0f : 1.0f));
+  float dcx = 0.0f, dw = 0.0f;
+  if (t >= 0) {
+    const float cx = spans[(int64_t)i * 2], w = spans[(int64_t)i * 2 + 1];
+    const float tc = tgt_cxw[(int64_t)t * 2], tw = tgt_cxw[(int64_t)t * 2 + 1];
+    const float ks = g[0] / (2.0f * sumT);
+    const float a = cx - tc, c = w - tw;
+    dcx += ks * (a > 0.0f ? 1.0f : (a < 0.0f ? -1.0f : 0.0f));
+    dw += ks * (c > 0.0f ? 1.0f : (c < 0.0f ? -1.0f : 0.0f));
+    const float x1 = cx - 0.5f * w, x2 = cx + 0.5f * w;
+    const float g1 = tgt_xx[(int64_t)t * 2], g2 = tgt_xx[(int64_t)t * 2 + 1];
+    Giou s;
+    giou_1d(x1, x2, g1, g2, s);
+    const float ci = s.raw_i >= 0.0f ? 1.0f : 0.0f, ce = s.raw_e >= 0.0f ? 1.0f : 0.0f;
+    const float dI2 = ci * tie(g2, x2);   // d min(x2,g2)/dx2 = [x2 < g2]
+    const float dI1 = -ci * tie(x1, g1);  // -d max(x1,g1)/dx1
+    const float dU2 = 1.0f - dI2, dU1 = -1.0f - dI1;
+    const float dE2 = ce * tie(x2, g2);
+    const float dE1 = -ce * tie(g1, x1);  // -d min(x1,g1)/dx1 = -[x1 < g1]
+    // L = 1 - giou = 2 - I/U - U/E
+    const float iu2 = 1.0f / (s.uni * s.uni), ie2 = 1.0f / (s.enc * s.enc);
+    const float dL2 = -(dI2 * s.uni - s.inter * dU2) * iu2 - (dU2 * s.enc - s.uni * dE2) * ie2;
+    const float dL1 = -(dI1 * s.uni - s.inter * dU1) * iu2 - (dU1 * s.enc - s.uni * dE1) * ie2;
+    const float kg = g[1] / sumT;
+    dcx += kg * (dL1 + dL2);
+    dw += kg * 0.5f * (dL2 - dL1);
+  }
+  dspans[(int64_t)i * 2] = dcx;
+  dspans[(int64_t)i * 2 + 1] = dw;
+}
+
+// ------------------------------------------------------------------------------------------
+// rec_ss (criterion.py:223-274).  Stage A, one workgroup per pair: masked means over the GT clips /
+// the valid (expanded) words, L2-normalised.
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  float t = 0.0f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
+  return t;
+}
+
+__global__ __launch_bounds__(256) void ss_mean_fwd_kernel(
+    const float* __restrict__ pv, const uint8_t* __restrict__ cmask, int Lv,
+    const float* __restrict__ ew, const uint8_t* __restrict__ wmask, int Le, int D,
+    float* __restrict__ cn, float* __restrict__ wn, float* __restrict__ stats) {
+  __shared__ float sh[8];
+  const int n = blockIdx.x;
+  float ccnt = 0.0f, wcnt = 0.0f;
+  for (int l = 0; l < Lv; ++l) ccnt += cmask[(int64_t)n * Lv + l] ? 1.0f : 0.0f;
+  for (int l = 0; l < Le; ++l) wcnt += wmask[(int64_t)n * Le + l] ? 1.0f : 0.0f;
+  // D <= 4 * 256 handled per thread in registers
+  float cs[4] = {0, 0, 0, 0}, ws[4] = {0, 0, 0, 0};
+  for (int l = 0; l < Lv; ++l) {
+    if (!cmask[(int64_t)n * Lv + l]) continue;
+    const float* r = pv + ((int64_t)n * Lv + l) * D;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = threadIdx.x + k * 256;
+      if (c < D) cs[k] += r[c];
+    }
+  }
+  for (int l = 0; l < Le; ++l) {
+    if (!wmask[(int64_t)n * Le + l]) continue;
+    const float* r = ew + ((int64_t)n * Le + l) * D;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = threadIdx.x + k * 256;
+      if (c < D) ws[k] += r[c];
+    }
+  }
+  float c2 = 0.0f, w2 = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    cs[k] /= ccnt; ws[k] /= wcnt;
+    c2 += cs[k] * cs[k]; w2 += ws[k] * ws[k];
+  }
+  const float cnorm = fmaxf(sqrtf(block_sum(c2, sh)), 1e-12f);
+  const float wnorm = fmaxf(sqrtf(block_sum(w2, sh)), 1e-12f);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = threadIdx.x + k * 256;
+    if (c < D) {
+      cn[(int64_t)n * D + c] = cs[k] / cnorm;
+      wn[(int64_t)n * D + c] = ws[k] / wnorm;
+    }
+  }
+  if (threadIdx.x == 0) {
+    stats[n * 4 + 0] = ccnt; stats[n * 4 + 1] = wcnt;
+    stats[n * 4 + 2] = cnorm; stats[n * 4 + 3] = wnorm;
+  }
+}
+
+// Stage B, one workgroup: sim = cn wn^T / tau (saved), SupCon-style loss with +1e-6 in the log.
+__global__ __launch_bounds__(256) void ss_loss_fwd_kernel(
+    const float* __restrict__ cn, const float* __restrict__ wn, const uint8_t* __restrict__ pos, int N,
+    int D, float inv_tau, float* __restrict__ sim, float* __restrict__ out) {
+  __shared__ float sh[8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int e = wave; e < N * N; e += 4) {
+    const int n = e / N, k = e % N;
+    float a = 0.0f;
+    for (int c = lane; c < D; c += 64) a += cn[(int64_t)n * D + c] * wn[(int64_t)k * D + c];
+    a = wave_sum(a);
+    if (lane == 0) sim[e] = a * inv_tau;
+  }
+  __threadfence_block();
+  __syncthreads();
+  float acc = 0.0f;
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const float* r = sim + (int64_t)n * N;
+    float m = -INFINITY;
+    for (int k = 0; k < N; ++k) m = fmaxf(m, r[k]);
+    float S = 0.0f;
+    for (int k = 0; k < N; ++k) S += expf(r[k] - m);
+    const float logS = logf(S + 1e-6f);
+    float num = 0.0f, cnt = 0.0f;
+    for (int k = 0; k < N; ++k)
+      if (pos[(int64_t)n * N + k]) { num += (r[k] - m) - logS; cnt += 1.0f; }
+    acc += -num / (cnt + 1e-6f);
+  }
+  const float tot = block_sum(acc, sh);
+  if (threadIdx.x == 0) out[0] = tot / (float)N;
+}
+
+// Backward, one workgroup per pair n: rebuild dsim (N x N) in LDS from the saved sim, then
+// d cn[n] = dsim[n,:] wn / tau, d wn[n] = dsim[:,n]^T cn / tau, through the L2 normalisation and the
+// masked means into d projed_video_feat[n] (Lv, D) and d expanded_words_feat[n] (Le, D).
+__global__ __launch_bounds__(256) void ss_bwd_kernel(
+    const float* __restrict__ cn, const float* __restrict__ wn, const uint8_t* __restrict__ pos,
+    const float* __restrict__ sim, const float* __restrict__ stats, const uint8_t* __restrict__ cmask,
+    const uint8_t* __restrict__ wmask, int N, int D, int Lv, int Le, float inv_tau,
+    const float* __restrict__ g, float* __restrict__ dpv, float* __restrict__ dew) {
+  extern __shared__ float dsim[];  // N*N
+  __shared__ float sh[8];
+  const int n = blockIdx.x;
+  const float gs = g[0] / (float)N;
+  for (int r = threadIdx.x; r < N; r += 256) {
+    const float* row = sim + (int64_t)r * N;
+    float m = -INFINITY;
+    int am = 0;
+    for (int k = 0; k < N; ++k)
+      if (row[k] > m) { m = row[k]; am = k; }
+    float S = 0.0f, cnt = 0.0f;
+    for (int k = 0; k < N; ++k) {
+      S += expf(row[k] - m);
+      cnt += pos[(int64_t)r * N + k] ? 1.0f : 0.0f;
+    }
+    const float a = gs / (cnt + 1e-6f);
+    const float iS = 1.0f / (S + 1e-6f);
+    for (int k = 0; k < N; ++k) {
+      float d = -a * (pos[(int64_t)r * N + k] ? 1.0f : 0.0f) + a * cnt * expf(row[k] - m) * iS;
+      if (k == am) d += a * cnt * 1e-6f * iS;
+      dsim[r * N + k] = d * inv_tau;
+    }
+  }
+  __syncthreads();
+  float dc[4] = {0, 0, 0, 0}, dw[4] = {0, 0, 0, 0}, yc[4], yw[4];
+  for (int k = 0; k < N; ++k) {
+    const float a = dsim[n * N + k], b = dsim[k * N + n];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = threadIdx.x + j * 256;
+      if (c < D) {
+        dc[j] += a * wn[(int64_t)k * D + c];
+        dw[j] += b * cn[(int64_t)k * D + c];
+      }
+    }
+  }
+  float pc = 0.0f, pw = 0.0f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = threadIdx.x + j * 256;
+    yc[j] = c < D ? cn[(int64_t)n * D + c] : 0.0f;
+    yw[j] = c < D ? wn[(int64_t)n * D + c] : 0.0f;
+    pc += yc[j] * dc[j];
+    pw += yw[j] * dw[j];
+  }
+  pc = block_sum(pc, sh);
+  pw = block_sum(pw, sh);
+  const float ccnt = stats[n * 4 + 0], wcnt = stats[n * 4 + 1];
+  const float cnorm = stats[n * 4 + 2], wnorm = stats[n * 4 + 3];
+  // y = x / max(|x|, eps): dx = (dy - y (y.dy)) / |x|  (|x| > eps; F.normalize's clamp branch has
+  // zero gradient through the norm, dx = dy / eps)
+  const bool cok = cnorm > 1e-12f, wok = wnorm > 1e-12f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    dc[j] = (cok ? (dc[j] - yc[j] * pc) : dc[j]) / (cnorm * ccnt);
+    dw[j] = (wok ? (dw[j] - yw[j] * pw) : dw[j]) / (wnorm * wcnt);
+  }
+  for (int l = 0; l < Lv; ++l) {
+    const float m = cmask[(int64_t)n * Lv + l] ? 1.0f : 0.0f;
+    float* r = dpv + ((int64_t)n * Lv + l) * D;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = threadIdx.x + j * 256;
+      if (c < D) r[c] = m * dc[j];
+    }
+  }
+  for (int l = 0; l < Le; ++l) {
+    const float m = wmask[(int64_t)n * Le + l] ? 1.0f : 0.0f;
+    float* r = dew + ((int64_t)n * Le + l) * D;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = threadIdx.x + j * 256;
+      if (c < D) r[c] = m * dw[j];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// rec_fw reductions (criterion.py:293-304): out[0] = mean_n( sum_w row_loss / cnt_n ),
+// out[1] = sum(correct * mask) / sum(mask).  One workgroup; one wave per pair.
+__global__ __launch_bounds__(256) void recfw_reduce_kernel(const float* __restrict__ row_loss,
+                                                           const uint8_t* __restrict__ correct,
+                                                           const uint8_t* __restrict__ mask, int N,
+                                                           int Lw, float* __restrict__ out) {
+  __shared__ float sh[3][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float loss = 0.0f, ok = 0.0f, tot = 0.0f;
+  for (int n = wave; n < N; n += 4) {
+    float s = 0.0f, c = 0.0f, k = 0.0f;
+    for (int w = lane; w < Lw; w += 64) {
+      const float m = mask[(int64_t)n * Lw + w] ? 1.0f : 0.0f;
+      s += row_loss[(int64_t)n * Lw + w];
+      c += m;
+      k += m * (correct[(int64_t)n * Lw + w] ? 1.0f : 0.0f);
+    }
+    s = wave_sum(s); c = wave_sum(c); k = wave_sum(k);
+    loss += s / c; ok += k; tot += c;
+  }
+  if (lane == 0) { sh[0][wave] = loss; sh[1][wave] = ok; sh[2][wave] = tot; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0, b = 0, c = 0;
+    for (int w = 0; w < 4; ++w) { a += sh[0][w]; b += sh[1][w]; c += sh[2][w]; }
+    out[0] = a / (float)N;
+    out[1] = b / c;
+  }
+}
+
+// row_grad[n,w] = g * mask / (N * cnt_n): the per-row weights mesm_nll_smooth_bwd consumes
+__global__ __launch_bounds__(64) void recfw_rowgrad_kernel(const uint8_t* __restrict__ mask, int N, int Lw,
+                                                          const float* __restrict__ g,
+                                                          float* __restrict__ row_grad) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  float c = 0.0f;
+  for (int w = lane; w < Lw; w += 64) c += mask[(int64_t)n * Lw + w] ? 1.0f : 0.0f;
+  c = wave_sum(c);
+  const float k = g[0] / ((float)N * c);
+  for (int w = lane; w < Lw; w += 64) row_grad[(int64_t)n * Lw + w] = mask[(int64_t)n * Lw + w] ? k : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------
+// saliency score (model.py:301-302): s[n,l] = <a[n,l,:], b[n,:]> * scale.  One wave per row.
+__global__ __launch_bounds__(256) void rowdot_fwd_kernel(const float* __restrict__ a,
+                                                         const float* __restrict__ b, int64_t rows, int L,
+                                                         int D, float scale, float* __restrict__ s) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* x = a + r * D;
+  const float* y = b + (r / L) * D;
+  float acc = 0.0f;
+  for (int c = lane * 4; c < D; c += 256) {
+    const float4 u = *reinterpret_cast<const float4*>(x + c);
+    const float4 v = *reinterpret_cast<const float4*>(y + c);
+    acc += u.x * v.x + u.y * v.y + u.z * v.z + u.w * v.w;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) s[r] = acc * scale;
+}
+
+// da[n,l,:] = ds[n,l] * b[n,:] * scale;  db[n,:] = sum_l ds[n,l] * a[n,l,:] * scale.
+// One workgroup per (pair, 256-column slab); thread = column.
+__global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict__ a,
+                                                         const float* __restrict__ b,
+                                                         const float* __restrict__ ds, int L, int D,
+                                                         float scale, float* __restrict__ da,
+                                                         float* __restrict__ db) {
+  const int n = blockIdx.x;
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= D) return;
+  const float bv = b[(int64_t)n * D + c] * scale;
+  float acc = 0.0f;
+  for (int l = 0; l < L; ++l) {
+    const float d = ds[(int64_t)n * L + l];
+    const int64_t o = ((int64_t)n * L + l) * D + c;
+    acc += d * a[o];
+    da[o] = d * bv;
+  }
+  db[(int64_t)n * D + c] = acc * scale;
+}
+
+// ------------------------------------------------------------------------------------------
+// post_process_text (model.py:145-152): per-word L2 normalisation (eps 1e-5), word mask =
+// (sum of normalised features != 0), sentence feature = normalised mean over valid words.
+// One workgroup per pair; a wave per word.
+__global__ __launch_bounds__(256) void text_prep_kernel(const float* __restrict__ x, int Lw, int D,
+                                                        int normalize, float* __restrict__ words,
+                                                        uint8_t* __restrict__ wmask,
+                                                        float* __restrict__ sent) {
+  extern __shared__ float sm[];  // D accumulators + Lw flags
+  float* accv = sm;
+  float* flags = sm + D;
+  __shared__ float sh[8];
+  const int n = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int c = threadIdx.x; c < D; c += 256) accv[c] = 0.0f;
+  __syncthreads();
+  for (int w = wave; w < Lw; w += 4) {
+    const float* r = x + ((int64_t)n * Lw + w) * D;
+    float* o = words + ((int64_t)n * Lw + w) * D;
+    float s2 = 0.0f;
+    for (int c = lane; c < D; c += 64) { const float v = r[c]; s2 += v * v; }
+    s2 = wave_sum(s2);
+    const float inv = normalize ? 1.0f / fmaxf(sqrtf(s2), 1e-5f) : 1.0f;
+    float s = 0.0f;
+    for (int c = lane; c < D; c += 64) { const float v = r[c] * inv; o[c] = v; s += v; }
+    s = wave_sum(s);
+    if (lane == 0) {
+      flags[w] = s != 0.0f ? 1.0f : 0.0f;
+      wmask[(int64_t)n * Lw + w] = s != 0.0f ? 1 : 0;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  float cnt = 0.0f;
+  for (int w = 0; w < Lw; ++w) cnt += flags[w];
+  float part = 0.0f;
+  // the reference sums ALL words (pads are zero vectors) and divides by the number of valid ones
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float a = 0.0f;
+    for (int w = 0; w < Lw; ++w) a += words[((int64_t)n * Lw + w) * D + c];
+    a /= cnt;
+    accv[c] = a;
+    part += a * a;
+  }
+  const float nrm = sqrtf(block_sum(part, sh));
+  const float inv = normalize ? 1.0f / fmaxf(nrm, 1e-5f) : 1.0f;
+  for (int c = threadIdx.x; c < D; c += 256) sent[(int64_t)n * D + c] = accv[c] * inv;
+}
+
+// ------------------------------------------------------------------------------------------
+// total = sum_k w[k] * vals[k];  and its backward gv[k] = g * w[k]  (criterion.py:361-365)
+__global__ void wsum_kernel(const float* __restrict__ vals, const float* __restrict__ w, int n,
+                            float* __restrict__ out) {
+  float t = 0.0f;
+  for (int k = 0; k < n; ++k)
+    if (w[k] != 0.0f) t += w[k] * vals[k];
+  out[0] = t;
+}
+__global__ void scale_vec_kernel(const float* __restrict__ g, const float* __restrict__ w, int n,
+                                 float* __restrict__ out) {
+  const int k = threadIdx.x;
+  if (k < n) out[k] = g[0] * w[k];
+}
+
+}  // namespace
+
+extern "C" int mesm_set_loss_fwd(const float* logits, const float* spans, const float* tgt_cxw,
+                                 const float* tgt_xx, const int32_t* tgt_off, int32_t N, int32_t Q,
+                                 int32_t Tmax, float w_span, float w_giou, float w_class,
+                                 float eos_coef, int32_t* match_q, float* out4, void* stream) {
+  if (!logits || !spans || !tgt_cxw || !tgt_xx || !tgt_off || !match_q || !out4) return MESM_EINVAL;
+  if (N <= 0 || Q <= 0 || Q > 32 || Tmax <= 0 || Tmax > 16 || Tmax > Q) return MESM_EINVAL;
+  const size_t per = sap_bytes_per_thread(Tmax, Q);
+  int P = 64;
+  while (P > 1 && per * P > 60 * 1024) P >>= 1;
+  if (per * P > 60 * 1024) return MESM_EINVAL;
+  while (P > 1 && P / 2 >= N) P >>= 1;
+  hipLaunchKernelGGL(set_loss_fwd_kernel, dim3(1), dim3(64), per * P, (hipStream_t)stream, logits, spans,
+                     tgt_cxw, tgt_xx, tgt_off, N, Q, Tmax, w_span, w_giou, w_class, eos_coef, P,
+                     match_q, out4);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_set_loss_bwd(const float* logits, const float* spans, const float* tgt_cxw,
+                                 const float* tgt_xx, const int32_t* tgt_off, const int32_t* match_q,
+                                 int32_t N, int32_t Q, float eos_coef, const float* g4, float* dlogits,
+                                 float* dspans, void* stream) {
+  if (!logits || !spans || !tgt_cxw || !tgt_xx || !tgt_off || !match_q || !g4 || !dlogits || !dspans)
+    return MESM_EINVAL;
+  if (N <= 0 || Q <= 0) return MESM_EINVAL;
+  hipLaunchKernelGGL(set_loss_bwd_kernel, dim3((N * Q + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     logits, spans, tgt_cxw, tgt_xx, tgt_off, match_q, N, Q, eos_coef, g4, dlogits,
+                     dspans);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_rec_ss_fwd(const float* pv, const uint8_t* cmask, int32_t Lv, const float* ew,
+                               const uint8_t* wmask, int32_t Le, const uint8_t* pos, int32_t N,
+                               int32_t D, float tau, float* cn, float* wn, float* stats, float* sim,
+                               float* out, void* stream) {
+  if (!pv || !cmask || !ew || !wmask || !pos || !cn || !wn || !stats || !sim || !out) return MESM_EINVAL;
+  if (N <= 0 || D <= 0 || D > 1024 || Lv <= 0 || Le <= 0 || tau <= 0.f) return MESM_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(ss_mean_fwd_kernel, dim3(N), dim3(256), 0, s, pv, cmask, Lv, ew, wmask, Le, D, cn,
+                     wn, stats);
+  hipLaunchKernelGGL(ss_loss_fwd_kernel, dim3(1), dim3(256), 0, s, cn, wn, pos, N, D, 1.0f / tau, sim,
+                     out);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_rec_ss_bwd(const float* cn, const float* wn, const uint8_t* pos, const float* sim,
+                               const float* stats, const uint8_t* cmask, const uint8_t* wmask,
+                               int32_t N, int32_t D, int32_t Lv, int32_t Le, float tau, const float* g,
+                               float* dpv, float* dew, void* stream) {
+  if (!cn || !wn || !pos || !sim || !stats || !cmask || !wmask || !g || !dpv || !dew) return MESM_EINVAL;
+  if (N <= 0 || N > 120 || D <= 0 || D > 1024 || tau <= 0.f) return MESM_EINVAL;
+  hipLaunchKernelGGL(ss_bwd_kernel, dim3(N), dim3(256), (size_t)N * N * 4, (hipStream_t)stream, cn, wn,
+                     pos, sim, stats, cmask, wmask, N, D, Lv, Le, 1.0f / tau, g, dpv, dew);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_rec_fw_reduce(const float* row_loss, const uint8_t* correct, const uint8_t* mask,
+                                  int32_t N, int32_t Lw, float* out2, void* stream) {
+  if (!row_loss || !correct || !mask || !out2 || N <= 0 || Lw <= 0) return MESM_EINVAL;
+  hipLaunchKernelGGL(recfw_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, row_loss, correct,
+                     mask, N, Lw, out2);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_rec_fw_rowgrad(const uint8_t* mask, int32_t N, int32_t Lw, const float* g,
+                                   float* row_grad, void* stream) {
+  if (!mask || !g || !row_grad || N <= 0 || Lw <= 0) return MESM_EINVAL;
+  hipLaunchKernelGGL(recfw_rowgrad_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, mask, N, Lw, g,
+                     row_grad);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_rowdot_fwd(const float* a, const float* b, int32_t N, int32_t L, int32_t D,
+                               float scale, float* s, void* stream) {
+  if (!a || !b || !s || N <= 0 || L <= 0 || D <= 0 || (D % 4) != 0) return MESM_EINVAL;
+  const int64_t rows = (int64_t)N * L;
+  hipLaunchKernelGGL(rowdot_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, a, b, rows, L, D, scale, s);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_rowdot_bwd(const float* a, const float* b, const float* ds, int32_t N, int32_t L,
+                               int32_t D, float scale, float* da, float* db, void* stream) {
+  if (!a || !b || !ds || !da || !db || N <= 0 || L <= 0 || D <= 0) return MESM_EINVAL;
+  hipLaunchKernelGGL(rowdot_bwd_kernel, dim3(N, (D + 255) / 256), dim3(256), 0, (hipStream_t)stream, a,
+                     b, ds, L, D, scale, da, db);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_text_prep(const float* x, int32_t N, int32_t Lw, int32_t D, int32_t normalize,
+                              float* words, uint8_t* wmask, float* sent, void* stream) {
+  if (!x || !words || !wmask || !sent || N <= 0 || Lw <= 0 || D <= 0) return MESM_EINVAL;
+  hipLaunchKernelGGL(text_prep_kernel, dim3(N), dim3(256), (size_t)(D + Lw) * 4, (hipStream_t)stream, x,
+                     Lw, D, normalize, words, wmask, sent);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_weighted_sum(const float* vals, const float* weights, int32_t n, float* out,
+                                 void* stream) {
+  if (!vals || !weights || !out || n <= 0) return MESM_EINVAL;
+  hipLaunchKernelGGL(wsum_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, vals, weights, n, out);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_scale_vec(const float* g, const float* weights, int32_t n, float* out, void* stream) {
+  if (!g || !weights || !out || n <= 0 || n > 256) return MESM_EINVAL;
+  hipLaunchKernelGGL(scale_vec_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, g, weights, n, out);
+  return mesm_launch_status();
+}

@@ -179,5 +179,5 @@ extern "C" int mesm_act_bias_bwd(const float* dy, const float* ref, float* dz, f
   return mesm_launch_status();
 }
 
-extern "C" int mesm_abi_version(void) { return 2; }
+extern "C" int mesm_abi_version(void) { return 3; }
 extern "C" const char* mesm_arch(void) { return "gfx950"; }

@@ -32,7 +32,7 @@ class GraphedStep:
         self._wm_cpu = self._words_mask_cpu()
         self._groups = [int(g) for g in batch["num_clips"].tolist()]
         self.plan = self._make_plan()
-        self.tplan = TargetPlan(batch, criterion.multi_clip, dev)
+        self.tplan = TargetPlan(batch, criterion.multi_clip, dev, criterion.gamma)
         self.batch["_target_plan"] = self.tplan
         gb = model.gradbuf()
         gb.ensure(dev)
@@ -60,7 +60,7 @@ class GraphedStep:
 
     def _words_mask_cpu(self):
         w = self.batch["words_id"]
-        return (torch.nn.functional.normalize(w, dim=-1, p=2, eps=1e-5).sum(-1) != 0).cpu()
+        return kn.text_prep(w, self.model.normalize_txt)[1].cpu()
 
     def _make_plan(self):
         b = self.batch

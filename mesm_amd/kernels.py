@@ -302,13 +302,14 @@ def nll_smooth_bwd(logit, label, row_lse, row_grad, eps=0.1):
     return dlogit
 
 
-def saliency_loss_fwd(s_pos, s_neg, label64, vmask, pos_idx, neg_idx, rank_coef, margin):
+def saliency_loss_fwd(s_pos, s_neg, label64, vmask, pos_idx, neg_idx, rank_coef, margin, out=None):
     require_gpu(s_pos, s_neg, label64, vmask)
     N, L = s_pos.shape
     assert label64.dtype == torch.float64 and label64.is_contiguous()
     assert s_pos.is_contiguous() and s_neg.is_contiguous() and vmask.is_contiguous()
     P = pos_idx.shape[1] if pos_idx is not None else 0
-    out = torch.empty(1, device=s_pos.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(1, device=s_pos.device, dtype=torch.float32)
     check(lib().mesm_saliency_loss_fwd(ptr(s_pos), ptr(s_neg), ptr(label64), ptr(vmask),
                                        ptr(pos_idx), ptr(neg_idx), N, L, P, float(rank_coef),
                                        float(margin), ptr(out), stream_ptr()),
@@ -341,6 +342,120 @@ def match(logits, spans, tgt_cxw, tgt_xx, tgt_off, Tmax, w_span, w_giou, w_class
                            float(w_giou), float(w_class), ptr(cost), ptr(match_q), stream_ptr()),
           "mesm_match")
     return (match_q, cost) if want_cost else match_q
+
+
+# ----------------------------------------------------------------------------- fused criterion
+def set_loss_fwd(logits, spans, tgt_cxw, tgt_xx, tgt_off, Tmax, w_span, w_giou, w_class, eos_coef, out4):
+    """Match + span/gIoU/label losses of one decoder layer; writes out4 (4 floats), returns match_q."""
+    require_gpu(logits, spans, tgt_cxw, tgt_xx, tgt_off, out4)
+    N, Q, _ = logits.shape
+    assert logits.is_contiguous() and spans.is_contiguous() and tgt_off.dtype == torch.int32
+    match_q = torch.empty(tgt_cxw.shape[0], device=logits.device, dtype=torch.int32)
+    check(lib().mesm_set_loss_fwd(ptr(logits), ptr(spans), ptr(tgt_cxw), ptr(tgt_xx), ptr(tgt_off), N, Q,
+                                  int(Tmax), float(w_span), float(w_giou), float(w_class),
+                                  float(eos_coef), ptr(match_q), ptr(out4), stream_ptr()),
+          "mesm_set_loss_fwd")
+    return match_q
+
+
+def set_loss_bwd(logits, spans, tgt_cxw, tgt_xx, tgt_off, match_q, eos_coef, g3):
+    N, Q, _ = logits.shape
+    dlogits = torch.empty_like(logits)
+    dspans = torch.empty_like(spans)
+    check(lib().mesm_set_loss_bwd(ptr(logits), ptr(spans), ptr(tgt_cxw), ptr(tgt_xx), ptr(tgt_off),
+                                  ptr(match_q), N, Q, float(eos_coef), ptr(g3), ptr(dlogits),
+                                  ptr(dspans), stream_ptr()), "mesm_set_loss_bwd")
+    return dlogits, dspans
+
+
+def rec_ss_fwd(pv, cmask, ew, wmask, pos, tau, out):
+    """-> saved (cn, wn, stats, sim); writes the loss into out (1 float)."""
+    require_gpu(pv, cmask, ew, wmask, pos, out)
+    N, Lv, D = pv.shape
+    Le = ew.shape[1]
+    assert pv.is_contiguous() and ew.is_contiguous() and cmask.is_contiguous() and wmask.is_contiguous()
+    assert pos.shape == (N, N) and pos.is_contiguous()
+    dev = pv.device
+    cn = torch.empty(N, D, device=dev, dtype=torch.float32)
+    wn = torch.empty(N, D, device=dev, dtype=torch.float32)
+    stats = torch.empty(N, 4, device=dev, dtype=torch.float32)
+    sim = torch.empty(N, N, device=dev, dtype=torch.float32)
+    check(lib().mesm_rec_ss_fwd(ptr(pv), ptr(cmask), Lv, ptr(ew), ptr(wmask), Le, ptr(pos), N, D,
+                                float(tau), ptr(cn), ptr(wn), ptr(stats), ptr(sim), ptr(out),
+                                stream_ptr()), "mesm_rec_ss_fwd")
+    return cn, wn, stats, sim
+
+
+def rec_ss_bwd(saved, pos, cmask, wmask, Lv, Le, tau, g):
+    cn, wn, stats, sim = saved
+    N, D = cn.shape
+    dpv = torch.empty(N, Lv, D, device=cn.device, dtype=torch.float32)
+    dew = torch.empty(N, Le, D, device=cn.device, dtype=torch.float32)
+    check(lib().mesm_rec_ss_bwd(ptr(cn), ptr(wn), ptr(pos), ptr(sim), ptr(stats), ptr(cmask), ptr(wmask),
+                                N, D, Lv, Le, float(tau), ptr(g), ptr(dpv), ptr(dew), stream_ptr()),
+          "mesm_rec_ss_bwd")
+    return dpv, dew
+
+
+def rec_fw_reduce(row_loss, correct, mask, out2):
+    N, Lw = mask.shape
+    check(lib().mesm_rec_fw_reduce(ptr(row_loss), ptr(correct), ptr(mask), N, Lw, ptr(out2), stream_ptr()),
+          "mesm_rec_fw_reduce")
+
+
+def rec_fw_rowgrad(mask, g):
+    N, Lw = mask.shape
+    rg = torch.empty(N * Lw, device=mask.device, dtype=torch.float32)
+    check(lib().mesm_rec_fw_rowgrad(ptr(mask), N, Lw, ptr(g), ptr(rg), stream_ptr()), "mesm_rec_fw_rowgrad")
+    return rg
+
+
+def rowdot_fwd(a, b, scale):
+    """a (N, L, D), b (N, D) -> (N, L): <a[n,l], b[n]> * scale."""
+    require_gpu(a, b)
+    N, L, D = a.shape
+    assert a.is_contiguous() and b.is_contiguous() and b.shape == (N, D)
+    s = torch.empty(N, L, device=a.device, dtype=torch.float32)
+    check(lib().mesm_rowdot_fwd(ptr(a), ptr(b), N, L, D, float(scale), ptr(s), stream_ptr()),
+          "mesm_rowdot_fwd")
+    return s
+
+
+def rowdot_bwd(a, b, ds, scale):
+    N, L, D = a.shape
+    da = torch.empty_like(a)
+    db = torch.empty_like(b)
+    check(lib().mesm_rowdot_bwd(ptr(a), ptr(b), ptr(ds), N, L, D, float(scale), ptr(da), ptr(db),
+                                stream_ptr()), "mesm_rowdot_bwd")
+    return da, db
+
+
+def text_prep(x, normalize=True):
+    """post_process_text: (N, Lw, D) word features -> words, words_mask (bool), sentence feature."""
+    require_gpu(x)
+    x = x.contiguous()
+    N, Lw, D = x.shape
+    words = torch.empty_like(x)
+    wmask = torch.empty(N, Lw, device=x.device, dtype=torch.bool)
+    sent = torch.empty(N, D, device=x.device, dtype=torch.float32)
+    check(lib().mesm_text_prep(ptr(x), N, Lw, D, 1 if normalize else 0, ptr(words), ptr(wmask), ptr(sent),
+                               stream_ptr()), "mesm_text_prep")
+    return words, wmask, sent
+
+
+def weighted_sum(vals, weights):
+    require_gpu(vals, weights)
+    out = torch.empty((), device=vals.device, dtype=torch.float32)
+    check(lib().mesm_weighted_sum(ptr(vals), ptr(weights), vals.numel(), ptr(out), stream_ptr()),
+          "mesm_weighted_sum")
+    return out
+
+
+def scale_vec(g, weights):
+    out = torch.empty_like(weights)
+    check(lib().mesm_scale_vec(ptr(g), ptr(weights), weights.numel(), ptr(out), stream_ptr()),
+          "mesm_scale_vec")
+    return out
 
 
 # ----------------------------------------------------------------------------- instrumentation

@@ -264,14 +264,8 @@ class MESM(nn.Module):
         N, Lv = video_mask.shape
 
         with _scope("text"):
-            # post_process_text (model.py:145-152)
-            words = words_id
-            if self.normalize_txt:
-                words = F.normalize(words, dim=-1, p=2, eps=1e-5)
-            words_mask = words.sum(dim=-1) != 0
-            sent = words.sum(dim=1) / words_mask.sum(dim=1).unsqueeze(-1)
-            if self.normalize_txt:
-                sent = F.normalize(sent, dim=-1, p=2, eps=1e-5)
+            # post_process_text (model.py:145-152), one kernel; word features carry no gradient
+            words, words_mask, sent = kn.text_prep(words_id, self.normalize_txt)
 
         plan = kwargs.get("plan")
         if plan is None:
@@ -340,7 +334,7 @@ class MESM(nn.Module):
         def saliency(mem, mem_g):
             a = ops.linear(mem, self.saliency_proj1.weight, self.saliency_proj1.bias)
             b = ops.linear(mem_g, self.saliency_proj2.weight, self.saliency_proj2.bias)
-            return torch.sum(a * b.unsqueeze(1), dim=-1) / np.sqrt(d)
+            return ops.rowdot(a, b, 1.0 / float(np.sqrt(d)))
 
         out.update({
             "pred_logits": logits[-1], "pred_spans": spans[-1],

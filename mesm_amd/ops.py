@@ -444,3 +444,24 @@ class SaliencyLossFn(Function):
 
 def saliency_loss(s_pos, s_neg, label64, vmask, pos_idx, neg_idx, rank_coef, margin):
     return SaliencyLossFn.apply(s_pos, s_neg, label64, vmask, pos_idx, neg_idx, rank_coef, margin)
+
+
+class RowDotFn(Function):
+    """saliency score (model.py:301-302): s[n,l] = <a[n,l,:], b[n,:]> * scale."""
+
+    @staticmethod
+    def forward(ctx, a, b, scale):
+        a, b = _c(a), _c(b)
+        ctx.save_for_backward(a, b)
+        ctx.scale = scale
+        return kn.rowdot_fwd(a, b, scale)
+
+    @staticmethod
+    def backward(ctx, ds):
+        a, b = ctx.saved_tensors
+        da, db = kn.rowdot_bwd(a, b, _c(ds), ctx.scale)
+        return da, db, None
+
+
+def rowdot(a, b, scale):
+    return RowDotFn.apply(a, b, scale)
