@@ -485,6 +485,516 @@ int launch_tile(const MesmGemmArgs& a, hipStream_t s) {
   return launch_layout<32, 32, VEC, 2>(a, s);
 }
 
+inline bool aligned_to(const void* p, size_t b) { return p == nullptr || ((uintptr_t)p % b) == 0; }
+
+// Epilogue shared by the k-split kernels: the four waves hold partial sums of the same 32x32 tile;
+// they meet in LDS (Red: 4 x 16 x 64 floats) and wave w takes accumulator registers [4w, 4w+4)
+// through bias / activation / dropout / activation-gradient / residual / accumulate.
+__device__ __forceinline__ void ksplit_epilogue(const MesmGemmArgs& p, const f32x16& acc, float* Red, int m0,
+                                                int n0, float slope, uint32_t seed_off) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  // sum the four partial tiles; wave w takes accumulator registers [4w, 4w+4) through the epilogue
+#pragma unroll
+  for (int r = 0; r < 16; ++r) Red[(wave * 16 + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  const int r0 = wave * 4;
+  float vals[4];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    float t = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) t += Red[(w * 16 + r0 + rr) * 64 + lane];
+    vals[rr] = t;
+  }
+
+  const bool first_split = (p.split_k <= 1) || (blockIdx.z == 0);
+  const uint32_t e_thresh = p.e_drop_p > 0.f ? mesm_drop_threshold(p.e_drop_p) : 0u;
+  const float e_inv_keep = 1.0f / (1.0f - p.e_drop_p);
+  const bool use_bias = p.bias != nullptr && first_split;
+  const bool use_res = p.residual != nullptr && first_split;
+  const bool use_aux = p.e_actgrad != MESM_ACT_NONE;
+  const bool rmw = p.accumulate == 1;
+  float dslope_part = 0.0f;
+  const int col = n0 + li;
+  const bool colok = col < p.N;
+  const int colc = colok ? col : p.N - 1;
+  const int rbase = m0 + 4 * h;
+  float resv[4], auxv[4], oldv[4];
+  const float bias_v = use_bias ? p.bias[colc] : 0.0f;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int r = r0 + rr;
+    int row = rbase + (r & 3) + 8 * (r >> 2);
+    row = row < p.M ? row : p.M - 1;
+    resv[rr] = use_res ? p.residual[(int64_t)row * p.ldr + colc] : 0.0f;
+    auxv[rr] = use_aux ? p.aux[(int64_t)row * p.ldaux + colc] : 0.0f;
+    oldv[rr] = rmw ? p.C[(int64_t)row * p.ldc + colc] : 0.0f;
+  }
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int r = r0 + rr;
+    const int row = rbase + (r & 3) + 8 * (r >> 2);
+    float t = vals[rr] * p.out_scale + bias_v;
+    t = mesm_act(t, p.e_act, slope);
+    if (e_thresh)
+      t = mesm_dropout_apply(t, (uint32_t)((int64_t)row * p.N + col), p.e_drop_seed + seed_off, e_thresh,
+                             e_inv_keep);
+    if (use_aux) {
+      const float z = auxv[rr];
+      if (p.e_actgrad == MESM_ACT_RELU) {
+        t = z > 0.0f ? t : 0.0f;
+      } else if (z <= 0.0f) {
+        if (row < p.M && colok) dslope_part += t * z;
+        t *= slope;
+      }
+    }
+    t += resv[rr] + oldv[rr];
+    if (row < p.M && colok) {
+      float* c = p.C + (int64_t)row * p.ldc + col;
+      if (p.accumulate == 2) atomicAdd(c, t);
+      else *c = t;
+    }
+  }
+  if (p.e_actgrad == MESM_ACT_PRELU && p.dslope) {
+    dslope_part = wave_sum(dslope_part);
+    if (lane == 0 && dslope_part != 0.0f) atomicAdd(p.dslope, dslope_part);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small-problem kernel ("frag"): one 32x32 output tile per workgroup, the reduce range split over
+// the four waves, MFMA operand fragments loaded STRAIGHT from global memory into registers -- no
+// LDS staging, no barrier in the k loop.  Most GEMMs of the step are (2400 | 1024 | 320) x 256 x 256:
+// far too small to amortise a staged pipeline (their k loop is 4 tiles), so what counts is how
+// much latency sits on the critical path of a workgroup.  Here it is ONE round trip: a wave issues
+// the loads of its whole reduce range slice up front (16 B per lane for a reduce-contiguous operand
+// = 4 MFMAs worth, one coalesced dword per MFMA for an outer-contiguous operand), then runs its
+// MFMA chain; the four partial tiles meet in LDS once, for the epilogue.
+// Lane l of a wave holds row/column (l & 31); in MFMA j of a k-step of 8 the lane half h = l >> 5
+// supplies k = kb + 4h + j (both operands use the same map, so any k permutation is harmless).
+constexpr int FRAG_STEPS = 4;  // k-steps of 8 per loop iteration (32 reduce indices)
+
+template <int LAYOUT, bool ADD>
+struct Frag {
+  float v[FRAG_STEPS][4];
+
+  // Unguarded: every k in [kb, kb + 32) is inside the wave's range.  No arithmetic touches the
+  // loaded registers here, so the loads of iteration t+1 stay in flight behind the MFMAs of t.
+  __device__ __forceinline__ void load_full(const float* __restrict__ base, const float* __restrict__ add,
+                                            int64_t ld, int row, int kb, int h) {
+#pragma unroll
+    for (int s = 0; s < FRAG_STEPS; ++s) {
+      const int k = kb + 8 * s + 4 * h;
+      if (LAYOUT == MESM_LAYOUT_REDUCE_CONTIG) {
+        const float4 x = *reinterpret_cast<const float4*>(base + (int64_t)row * ld + k);
+        v[s][0] = x.x; v[s][1] = x.y; v[s][2] = x.z; v[s][3] = x.w;
+        if (ADD) {
+          const float4 y = *reinterpret_cast<const float4*>(add + (int64_t)row * ld + k);
+          v[s][0] += y.x; v[s][1] += y.y; v[s][2] += y.z; v[s][3] += y.w;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[s][j] = base[(int64_t)(k + j) * ld + row];
+          if (ADD) v[s][j] += add[(int64_t)(k + j) * ld + row];
+        }
+      }
+    }
+  }
+
+  // Guarded tail (at most one per wave): k >= k1 contributes zeros.
+  __device__ __forceinline__ void load_tail(const float* __restrict__ base, const float* __restrict__ add,
+                                            int64_t ld, int row, int kb, int k1, int h) {
+#pragma unroll
+    for (int s = 0; s < FRAG_STEPS; ++s) {
+      const int k = kb + 8 * s + 4 * h;
+      if (LAYOUT == MESM_LAYOUT_REDUCE_CONTIG) {
+        const bool ok = k < k1;  // ranges are multiples of 4: a vector is all in or all out
+        const int kc = ok ? k : 0;
+        float4 x = *reinterpret_cast<const float4*>(base + (int64_t)row * ld + kc);
+        if (ADD) {
+          const float4 y = *reinterpret_cast<const float4*>(add + (int64_t)row * ld + kc);
+          x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+        }
+        v[s][0] = ok ? x.x : 0.0f; v[s][1] = ok ? x.y : 0.0f;
+        v[s][2] = ok ? x.z : 0.0f; v[s][3] = ok ? x.w : 0.0f;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool ok = k + j < k1;
+          const int kc = ok ? k + j : 0;
+          float x = base[(int64_t)kc * ld + row];
+          if (ADD) x += add[(int64_t)kc * ld + row];
+          v[s][j] = ok ? x : 0.0f;
+        }
+      }
+    }
+  }
+
+  // activation / dropout on the fragment; `o` = unclamped outer index of this lane
+  template <bool OUTER_IS_ROW>
+  __device__ __forceinline__ void finish(const XForm& xf, int o, int kb, int h) {
+#pragma unroll
+    for (int s = 0; s < FRAG_STEPS; ++s)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int gk = kb + 8 * s + 4 * h + j;
+        float x = mesm_act(v[s][j], xf.act, xf.slope);
+        if (xf.thresh) {
+          const int64_t idx = OUTER_IS_ROW ? (int64_t)o * xf.lld + gk : (int64_t)gk * xf.lld + o;
+          x = mesm_dropout_apply(x, (uint32_t)idx, xf.seed, xf.thresh, xf.inv_keep);
+        }
+        v[s][j] = x;
+      }
+  }
+};
+
+// XF: operand transforms (activation / dropout on A or B) compiled in; the plain instantiation
+// carries none of that code.
+template <int LA, int LB, int ADD, bool XF>
+__global__ __launch_bounds__(NTHREADS) void gemm_frag_kernel(const MesmGemmArgs p) {
+  __shared__ float Red[4 * 16 * 64];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+
+  int kbeg = 0, kend = p.K;
+  if (p.split_k > 1) {
+    int chunk = (p.K + p.split_k - 1) / p.split_k;
+    chunk = ((chunk + BK_MAX - 1) / BK_MAX) * BK_MAX;
+    kbeg = blockIdx.z * chunk;
+    kend = kbeg + chunk < p.K ? kbeg + chunk : p.K;
+    if (kbeg >= p.K) return;
+  }
+  // this wave's slice of [kbeg, kend): a multiple of 32 long except for the last wave's tail
+  const int kw = (((kend - kbeg + 3) >> 2) + 31) & ~31;
+  const int k0 = kbeg + wave * kw;
+  const int k1 = k0 + kw < kend ? k0 + kw : kend;
+  const int nfull = k1 > k0 ? (k1 - k0) >> 5 : 0;
+  const bool tail = k1 > k0 && ((k1 - k0) & 31) != 0;
+
+  const float slope = p.slope ? *p.slope : 0.0f;
+  const uint32_t seed_off = p.seed_offset ? *p.seed_offset : 0u;
+  XForm xa, xb;
+  xa.act = p.a_act; xa.slope = slope; xa.thresh = p.a_drop_p > 0.f ? mesm_drop_threshold(p.a_drop_p) : 0u;
+  xa.seed = p.a_drop_seed + seed_off; xa.inv_keep = 1.0f / (1.0f - p.a_drop_p); xa.lld = p.K;
+  xb.act = p.b_act; xb.slope = slope; xb.thresh = p.b_drop_p > 0.f ? mesm_drop_threshold(p.b_drop_p) : 0u;
+  xb.seed = p.b_drop_seed + seed_off; xb.inv_keep = 1.0f / (1.0f - p.b_drop_p); xb.lld = p.N;
+
+  const int ra = m0 + li < p.M ? m0 + li : p.M - 1;
+  const int rb = n0 + li < p.N ? n0 + li : p.N - 1;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  float csum = 0.0f;
+  const bool do_colsum = (p.colsum != nullptr) && (blockIdx.y == 0);
+
+  Frag<LA, ADD == 1> fa, na;
+  Frag<LB, ADD == 2> fb, nb;
+
+  auto mma = [&](Frag<LA, ADD == 1>& a, Frag<LB, ADD == 2>& b, int kb) {
+    if (XF) {
+      a.template finish<true>(xa, m0 + li, kb, h);
+      b.template finish<false>(xb, n0 + li, kb, h);
+    }
+#pragma unroll
+    for (int s = 0; s < FRAG_STEPS; ++s)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[s][j], b.v[s][j], acc, 0, 0, 0);
+    if (do_colsum) {
+#pragma unroll
+      for (int s = 0; s < FRAG_STEPS; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) csum += a.v[s][j];
+    }
+  };
+
+  // Register ping-pong, branch-free in the steady state (a conditional prefetch makes hipcc merge
+  // its vmcnt bookkeeping pessimistically and wait for the NEW loads before the MFMAs of the old
+  // ones): the loads of iteration t+1 are always in flight behind the MFMAs of iteration t.
+  // sched_barrier: keep every load group ahead of the MFMA block it overlaps (hipcc otherwise sinks
+  // the loads between the MFMAs to recycle fragment registers, which halves the prefetch distance)
+#define MESM_SB() __builtin_amdgcn_sched_barrier(0)
+  if (nfull > 0) {
+    fa.load_full(p.A, p.A2, p.lda, ra, k0, h);
+    fb.load_full(p.B, p.B2, p.ldb, rb, k0, h);
+  }
+  int it = 0;
+  for (; it + 2 < nfull; it += 2) {
+    const int kb = k0 + 32 * it;
+    na.load_full(p.A, p.A2, p.lda, ra, kb + 32, h);
+    nb.load_full(p.B, p.B2, p.ldb, rb, kb + 32, h);
+    MESM_SB();
+    mma(fa, fb, kb);
+    MESM_SB();
+    fa.load_full(p.A, p.A2, p.lda, ra, kb + 64, h);
+    fb.load_full(p.B, p.B2, p.ldb, rb, kb + 64, h);
+    MESM_SB();
+    mma(na, nb, kb + 32);
+    MESM_SB();
+  }
+  if (nfull - it == 2) {
+    const int kb = k0 + 32 * it;
+    na.load_full(p.A, p.A2, p.lda, ra, kb + 32, h);
+    nb.load_full(p.B, p.B2, p.ldb, rb, kb + 32, h);
+    MESM_SB();
+    mma(fa, fb, kb);
+    mma(na, nb, kb + 32);
+  } else if (nfull - it == 1) {
+    mma(fa, fb, k0 + 32 * it);
+  }
+#undef MESM_SB
+  if (tail) {
+    const int kb = k0 + 32 * nfull;
+    fa.load_tail(p.A, p.A2, p.lda, ra, kb, k1, h);
+    fb.load_tail(p.B, p.B2, p.ldb, rb, kb, k1, h);
+    mma(fa, fb, kb);
+  }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+
+  if (do_colsum) {
+    csum += __shfl_xor(csum, 32, 64);
+    if (h == 0 && m0 + li < p.M && csum != 0.0f) atomicAdd(p.colsum + m0 + li, csum);
+  }
+
+  ksplit_epilogue(p, acc, Red, m0, n0, slope, seed_off);
+}
+
+template <int LA, int LB>
+int launch_frag_add(const MesmGemmArgs& a, hipStream_t s) {
+  dim3 grid((a.M + 31) / 32, (a.N + 31) / 32, a.split_k > 1 ? a.split_k : 1);
+  const int add = a.A2 ? 1 : (a.B2 ? 2 : 0);
+  const bool xf = a.a_act != MESM_ACT_NONE || a.b_act != MESM_ACT_NONE || a.a_drop_p > 0.f || a.b_drop_p > 0.f;
+  if (xf) {
+    if (add == 0) hipLaunchKernelGGL((gemm_frag_kernel<LA, LB, 0, true>), grid, dim3(NTHREADS), 0, s, a);
+    else if (add == 1) hipLaunchKernelGGL((gemm_frag_kernel<LA, LB, 1, true>), grid, dim3(NTHREADS), 0, s, a);
+    else hipLaunchKernelGGL((gemm_frag_kernel<LA, LB, 2, true>), grid, dim3(NTHREADS), 0, s, a);
+  } else {
+    if (add == 0) hipLaunchKernelGGL((gemm_frag_kernel<LA, LB, 0, false>), grid, dim3(NTHREADS), 0, s, a);
+    else if (add == 1) hipLaunchKernelGGL((gemm_frag_kernel<LA, LB, 1, false>), grid, dim3(NTHREADS), 0, s, a);
+    else hipLaunchKernelGGL((gemm_frag_kernel<LA, LB, 2, false>), grid, dim3(NTHREADS), 0, s, a);
+  }
+  return mesm_launch_status();
+}
+
+int launch_frag(const MesmGemmArgs& a, hipStream_t s) {
+  constexpr int R = MESM_LAYOUT_REDUCE_CONTIG, O = MESM_LAYOUT_OUTER_CONTIG;
+  if (a.a_layout == R && a.b_layout == R) return launch_frag_add<R, R>(a, s);
+  if (a.a_layout == R && a.b_layout == O) return launch_frag_add<R, O>(a, s);
+  if (a.a_layout == O && a.b_layout == O) return launch_frag_add<O, O>(a, s);
+  return launch_frag_add<O, R>(a, s);
+}
+
+// the frag kernel reads reduce-contiguous operands as 16-byte vectors
+bool frag_ok(const MesmGemmArgs& a) {
+  auto vec_ok = [&](const float* p, const float* p2, int64_t ld) {
+    return (ld % 4 == 0) && aligned_to(p, 16) && aligned_to(p2, 16);
+  };
+  if (a.a_layout == MESM_LAYOUT_REDUCE_CONTIG && !(vec_ok(a.A, a.A2, a.lda) && a.K % 4 == 0)) return false;
+  if (a.b_layout == MESM_LAYOUT_REDUCE_CONTIG && !(vec_ok(a.B, a.B2, a.ldb) && a.K % 4 == 0)) return false;
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// "wstage" kernel: same decomposition as the frag kernel (32x32 tile per workgroup, reduce range
+// split over the four waves) but each wave brings ITS OWN k-slice in through LDS in full 128-byte
+// lines with LDS-DMA (global_load_lds_dwordx4: one instruction = 8 rows x 128 B, no VGPRs), then
+// reads MFMA fragments back with ds_read_b128.  tools/probe/loads.hip: the line-shaped loads move the
+// 39 MB a 2400x256x256 GEMM pulls out of L2 in 3.2-3.7 us, the fragment-shaped ones (32 B per row
+// per instruction) in 5.9 us -- and that traffic, not the MFMA work (2.0 us), bounds these GEMMs.
+// The slabs are wave-private, so there is no barrier in the k loop: a wave waits on its own vmcnt.
+//
+// Stage = 32 reduce indices; slab = 32 x 32 floats (4 KB) per operand; 2 stages per wave (64 KB per
+// workgroup, 2 workgroups per CU).  LDS-DMA writes lane-linear, so the bank-conflict-free image is made
+// by permuting the SOURCE addresses:
+//   reduce-contiguous operand: slot (row r, 16-B position p) holds chunk p ^ ((r >> 1) & 7) of row r;
+//     the reader (row i, chunk c = 2s + h) finds it at position c ^ ((i >> 1) & 7) with one ds_read_b128;
+//   outer-contiguous operand: LDS row 8q + sr holds reduce index 8q + (((sr & 1) << 2) | (sr >> 1)), so
+//     that k and k + 4 (the two lane halves) sit in opposite bank halves; read with ds_read_b32.
+constexpr int WS_SLAB = 32 * 32;  // floats
+
+template <int LAYOUT>
+__device__ __forceinline__ void ws_issue(const float* __restrict__ base, int64_t ld, int o0, int extent,
+                                         int kb, int k1, float* slab, int lane) {
+  const int sr = lane >> 3, pos = lane & 7;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float* g;
+    if (LAYOUT == MESM_LAYOUT_REDUCE_CONTIG) {
+      const int r = 8 * q + sr;
+      int row = o0 + r;
+      row = row < extent ? row : extent - 1;
+      const int c = pos ^ ((r >> 1) & 7);
+      int k = kb + 4 * c;
+      k = k < k1 ? k : k1 - 4;  // tail: clamped garbage, zeroed at fragment read
+      g = base + (int64_t)row * ld + k;
+    } else {
+      int k = kb + 8 * q + (((sr & 1) << 2) | (sr >> 1));
+      k = k < k1 ? k : k1 - 1;
+      int o = o0 + 4 * pos;
+      o = o + 4 <= extent ? o : extent - 4;  // extent % 4 == 0: a chunk is all in or all out
+      g = base + (int64_t)k * ld + o;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)(slab + q * 256), 16, 0, 0);
+  }
+}
+
+// fragment of one stage: v[s][j] = operand[outer = lane & 31][k = kb + 8s + 4h + j]
+template <int LAYOUT>
+__device__ __forceinline__ void ws_read(const float* slab, int li, int h, float (&v)[4][4]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (LAYOUT == MESM_LAYOUT_REDUCE_CONTIG) {
+      const int pos = (2 * s + h) ^ ((li >> 1) & 7);
+      const float4 x = *reinterpret_cast<const float4*>(slab + li * 32 + pos * 4);
+      v[s][0] = x.x; v[s][1] = x.y; v[s][2] = x.z; v[s][3] = x.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[s][j] = slab[(8 * s + 2 * j + h) * 32 + li];
+    }
+  }
+}
+
+template <int LA, int LB, bool XF>
+__global__ __launch_bounds__(NTHREADS) void gemm_wstage_kernel(const MesmGemmArgs p) {
+  __shared__ __attribute__((aligned(16))) float L[4 * 2 * 2 * WS_SLAB];  // [wave][stage][operand]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+
+  int kbeg = 0, kend = p.K;
+  if (p.split_k > 1) {
+    int chunk = (p.K + p.split_k - 1) / p.split_k;
+    chunk = ((chunk + BK_MAX - 1) / BK_MAX) * BK_MAX;
+    kbeg = blockIdx.z * chunk;
+    kend = kbeg + chunk < p.K ? kbeg + chunk : p.K;
+    if (kbeg >= p.K) return;
+  }
+  const int kw = (((kend - kbeg + 3) >> 2) + 31) & ~31;
+  const int k0 = kbeg + wave * kw;
+  const int k1 = k0 + kw < kend ? k0 + kw : kend;
+  const int nst = k1 > k0 ? (k1 - k0 + 31) >> 5 : 0;
+
+  const float slope = p.slope ? *p.slope : 0.0f;
+  const uint32_t seed_off = p.seed_offset ? *p.seed_offset : 0u;
+  XForm xa, xb;
+  xa.act = p.a_act; xa.slope = slope; xa.thresh = p.a_drop_p > 0.f ? mesm_drop_threshold(p.a_drop_p) : 0u;
+  xa.seed = p.a_drop_seed + seed_off; xa.inv_keep = 1.0f / (1.0f - p.a_drop_p); xa.lld = p.K;
+  xb.act = p.b_act; xb.slope = slope; xb.thresh = p.b_drop_p > 0.f ? mesm_drop_threshold(p.b_drop_p) : 0u;
+  xb.seed = p.b_drop_seed + seed_off; xb.inv_keep = 1.0f / (1.0f - p.b_drop_p); xb.lld = p.N;
+
+  float* mine = L + wave * (2 * 2 * WS_SLAB);
+  auto issue = [&](int st) {
+    float* buf = mine + (st & 1) * (2 * WS_SLAB);
+    const int kb = k0 + 32 * st;
+    ws_issue<LA>(p.A, p.lda, m0, p.M, kb, k1, buf, lane);
+    ws_issue<LB>(p.B, p.ldb, n0, p.N, kb, k1, buf + WS_SLAB, lane);
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  float csum = 0.0f;
+  const bool do_colsum = (p.colsum != nullptr) && (blockIdx.y == 0);
+
+  if (nst > 0) issue(0);
+  if (nst > 1) issue(1);
+  for (int st = 0; st < nst; ++st) {
+    // each stage is 8 LDS-DMA instructions; leave the next stage in flight
+    if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const float* buf = mine + (st & 1) * (2 * WS_SLAB);
+    float a[4][4], b[4][4];
+    ws_read<LA>(buf, li, h, a);
+    ws_read<LB>(buf + WS_SLAB, li, h, b);
+    const int kb = k0 + 32 * st;
+    if (st + 2 < nst) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments are in registers: slab is free
+      issue(st + 2);
+    }
+    if (kb + 32 > k1) {  // partial last stage: reduce indices >= k1 contribute zeros
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool ok = kb + 8 * s_ + 4 * h + j < k1;
+          a[s_][j] = ok ? a[s_][j] : 0.0f;
+          b[s_][j] = ok ? b[s_][j] : 0.0f;
+        }
+    }
+    if (XF) {
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int gk = kb + 8 * s_ + 4 * h + j;
+          float x = mesm_act(a[s_][j], xa.act, xa.slope);
+          if (xa.thresh)
+            x = mesm_dropout_apply(x, (uint32_t)((int64_t)(m0 + li) * xa.lld + gk), xa.seed, xa.thresh, xa.inv_keep);
+          a[s_][j] = x;
+          float y = mesm_act(b[s_][j], xb.act, xb.slope);
+          if (xb.thresh)
+            y = mesm_dropout_apply(y, (uint32_t)((int64_t)gk * xb.lld + n0 + li), xb.seed, xb.thresh, xb.inv_keep);
+          b[s_][j] = y;
+        }
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s_][j], b[s_][j], acc, 0, 0, 0);
+    if (do_colsum) {
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) csum += a[s_][j];
+    }
+  }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+
+  if (do_colsum) {
+    csum += __shfl_xor(csum, 32, 64);
+    if (h == 0 && m0 + li < p.M && csum != 0.0f) atomicAdd(p.colsum + m0 + li, csum);
+  }
+  __syncthreads();  // every wave is done with its slabs: the reduction buffer aliases them
+  ksplit_epilogue(p, acc, L, m0, n0, slope, seed_off);
+}
+
+template <int LA, int LB>
+int launch_wstage_l(const MesmGemmArgs& a, hipStream_t s) {
+  dim3 grid((a.M + 31) / 32, (a.N + 31) / 32, a.split_k > 1 ? a.split_k : 1);
+  const bool xf = a.a_act != MESM_ACT_NONE || a.b_act != MESM_ACT_NONE || a.a_drop_p > 0.f || a.b_drop_p > 0.f;
+  if (xf) hipLaunchKernelGGL((gemm_wstage_kernel<LA, LB, true>), grid, dim3(NTHREADS), 0, s, a);
+  else hipLaunchKernelGGL((gemm_wstage_kernel<LA, LB, false>), grid, dim3(NTHREADS), 0, s, a);
+  return mesm_launch_status();
+}
+
+int launch_wstage(const MesmGemmArgs& a, hipStream_t s) {
+  constexpr int R = MESM_LAYOUT_REDUCE_CONTIG, O = MESM_LAYOUT_OUTER_CONTIG;
+  if (a.a_layout == R && a.b_layout == R) return launch_wstage_l<R, R>(a, s);
+  if (a.a_layout == R && a.b_layout == O) return launch_wstage_l<R, O>(a, s);
+  if (a.a_layout == O && a.b_layout == O) return launch_wstage_l<O, O>(a, s);
+  return launch_wstage_l<O, R>(a, s);
+}
+
+// LDS-DMA moves 16-byte chunks: no addend operand; reduce-contiguous operands need K % 4 == 0 and
+// 16-byte aligned rows, outer-contiguous ones an outer extent that is a multiple of 4.
+bool wstage_ok(const MesmGemmArgs& a) {
+  if (a.A2 || a.B2) return false;
+  auto ok = [&](int layout, const float* p, int64_t ld, int extent) {
+    if (!aligned_to(p, 16) || ld % 4 != 0) return false;
+    if (layout == MESM_LAYOUT_REDUCE_CONTIG) return a.K % 4 == 0 && a.K >= 4;
+    return extent % 4 == 0 && extent >= 4;
+  };
+  return ok(a.a_layout, a.A, a.lda, a.M) && ok(a.b_layout, a.B, a.ldb, a.N);
+}
+
 // Tape of the GEMM launches of one step (argument structs as launched), for bench.py's
 // roofline measurement: recorded while a step is captured into a HIP graph (whose private
 // memory pool keeps every pointer valid), replayed back-to-back from C++ with an event pair
@@ -495,9 +1005,17 @@ struct Tape {
 };
 Tape g_tape;
 
-inline bool aligned_to(const void* p, size_t b) { return p == nullptr || ((uintptr_t)p % b) == 0; }
-
 int dispatch(const MesmGemmArgs& a, int vec, hipStream_t s) {
+  {
+    // small problems (fewer than ~2 workgroups of 64x64 per CU): register-fragment kernel
+    const char* env = getenv("MESM_GEMM_TILE");
+    const long z = a.split_k > 1 ? a.split_k : 1;
+    const long b64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * z;
+    const int force = env ? atoi(env) : 0;  // 1 = frag kernel, 32 | 64 | 128 = staged tile, 0 = auto
+    // 1 = frag, 2 = wstage (line-shaped LDS-DMA staging), 32 | 64 | 128 = staged tile, 0 = auto
+    if ((force == 2 || (force == 0 && b64 < 512)) && wstage_ok(a)) return launch_wstage(a, s);
+    if ((force == 1 || (force == 0 && b64 < 512)) && frag_ok(a)) return launch_frag(a, s);
+  }
   if (vec == 4) return launch_tile<4>(a, s);
   if (vec == 2) return launch_tile<2>(a, s);
   return launch_tile<1>(a, s);

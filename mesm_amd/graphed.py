@@ -14,6 +14,8 @@ replayed with a single host call.  What stays dynamic is moved to device memory:
 Gradients land in the model's flat gradient buffer (param.grad aliases it), exactly as in the
 eager path, so optimizer / clip_grad_norm_ / the DDP reducer work unchanged after `run()`.
 """
+import os
+
 import torch
 
 from . import kernels as kn
@@ -46,12 +48,17 @@ class GraphedStep:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
+            dot = os.environ.get("MESM_GRAPH_DOT")
+            if dot:
+                self.graph.enable_debug_mode()
             model.zero_grad(set_to_none=True)
             if instrument:  # record the GEMM launches of the captured step (bench roofline)
                 kn.gemm_tape(True)
             with torch.cuda.graph(self.graph):
                 self.counter.add_(1)
                 self.total, self.losses = self._step_body()
+            if dot:
+                self.graph.debug_dump(dot)
         finally:
             kn.set_seed_offset(None)
             if instrument:

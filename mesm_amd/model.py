@@ -120,12 +120,21 @@ class MESM(nn.Module):
                                                 transformer.dim_feedforward, transformer.dropout)
         self._gradbuf = None
         self._step = 0
+        # run the positive pass and the SS + negative pass on two HIP streams (see forward)
+        self.two_streams = os.environ.get("MESM_TWO_STREAMS", "1") != "0"
+        self._side = {}
 
     # ------------------------------------------------------------------ infrastructure
     def gradbuf(self):
         if self._gradbuf is None:
             self._gradbuf = GradBuffer([(n, p) for n, p in self.named_parameters() if p.requires_grad])
         return self._gradbuf
+
+    def _side_stream(self, device):
+        st = self._side.get(device)
+        if st is None:
+            st = self._side[device] = torch.cuda.Stream(device=device)
+        return st
 
     def _begin(self, device, is_training):
         if not device.type == "cuda":
@@ -281,12 +290,33 @@ class MESM(nn.Module):
             pw = self._proj(self.input_txt_proj, words)
             vpos = kn.sine_pos(video_mask, d)
 
+        # Two HIP streams from here on (kernels of this size leave most CUs idle; two independent
+        # chains overlap ~1.6x, tools/probe_graph_par.py):
+        #   main: enhance(pos) -> [SS done] -> t2v(pos) -> encoder -> decoder -> heads -> MLM branch
+        #   side: SS reconstruction -> enhance(neg) -> t2v(neg) -> encoder(neg)
+        # Autograd replays every backward block on the stream of its forward, so the backward pass
+        # overlaps the same way.  Under graph capture the fork/join become graph edges.
+        main = torch.cuda.current_stream()
+        side = self._side_stream(dev) if self.two_streams else main
+        forked = side is not main
+
+        def hand(ts, to):
+            """tensors made on one stream and read on the other: tell the caching allocator"""
+            if forked:
+                for t_ in ts:
+                    if t_ is not None:
+                        t_.record_stream(to)
+
+        if forked:
+            side.wait_stream(main)
+            hand([pv, pw, vpos, vid_pad, words_pad, words_mask, sent, words, video_feat], side)
+
         enc = self.enhance_encoder
         with _scope("enhance"):
             enhanced = enc(pw, pv, None, vpos, words_pad, vid_pad) if self.rec_fw else pv
 
         out = {}
-        with _scope("ss"):
+        with torch.cuda.stream(side), _scope("ss"):
             if self.rec_ss:
                 if plan.vid_src is not None:
                     bvid = video_feat.reshape(N * Lv, -1)[plan.vid_src] * plan.vid_mask.unsqueeze(-1)
@@ -306,19 +336,16 @@ class MESM(nn.Module):
                 emask = torch.cat([torch.ones(N, 1, dtype=torch.bool, device=dev), words_mask], dim=1)
             else:
                 ewords, emask = pw, words_mask
-        epad = (~emask).contiguous()
+            epad = (~emask).contiguous()
+        if forked:
+            ss_done = torch.cuda.Event()
+            ss_done.record(side)
+            main.wait_event(ss_done)
+            hand([ewords, emask, epad] + ([recon, projed_recon] if self.rec_ss else []), main)
 
-        with _scope("t2v"):
-            encoded = self.t2v_encoder(ewords, enhanced, None, vpos, epad, vid_pad)
-        with _scope("transformer"):
-            hs, refs, memory, memory_g = self.transformer(encoded, vid_pad, self.query_embed.weight, vpos,
-                                                          self.global_rep_token, self.global_rep_pos)
-        with _scope("heads"):
-            logits = ops.linear(hs, self.class_embed.weight, self.class_embed.bias)
-            spans = torch.sigmoid(self.span_embed(hs) + inverse_sigmoid(refs))
-
-        # negative pass (model.py:260-299); decoder skipped: its outputs are discarded at :295
-        with _scope("neg"):
+        # negative pass (model.py:260-299) on the side stream; decoder skipped: its outputs are
+        # discarded at :295
+        with torch.cuda.stream(side), _scope("neg"):
             ni = plan.neg_index
             n_ewords, n_emask = ewords[ni], emask[ni]
             if self.rec_ss:
@@ -330,33 +357,47 @@ class MESM(nn.Module):
             _, _, n_memory, n_memory_g = self.transformer(n_enc, vid_pad, self.query_embed.weight, vpos,
                                                           self.global_rep_token, self.global_rep_pos,
                                                           run_decoder=False)
+            n_memory = n_memory.contiguous()
+            n_memory_g = n_memory_g.contiguous()
+
+        with _scope("t2v"):
+            encoded = self.t2v_encoder(ewords, enhanced, None, vpos, epad, vid_pad)
+        with _scope("transformer"):
+            hs, refs, memory, memory_g = self.transformer(encoded, vid_pad, self.query_embed.weight, vpos,
+                                                          self.global_rep_token, self.global_rep_pos)
+        with _scope("heads"):
+            logits = ops.linear(hs, self.class_embed.weight, self.class_embed.bias)
+            spans = torch.sigmoid(self.span_embed(hs) + inverse_sigmoid(refs))
 
         def saliency(mem, mem_g):
             a = ops.linear(mem, self.saliency_proj1.weight, self.saliency_proj1.bias)
             b = ops.linear(mem_g, self.saliency_proj2.weight, self.saliency_proj2.bias)
             return ops.rowdot(a, b, 1.0 / float(np.sqrt(d)))
 
-        out.update({
-            "pred_logits": logits[-1], "pred_spans": spans[-1],
-            "saliency_scores": saliency(memory, memory_g),
-            "neg_saliency_scores": saliency(n_memory, n_memory_g),
-        })
+        out.update({"pred_logits": logits[-1], "pred_spans": spans[-1],
+                    "saliency_scores": saliency(memory, memory_g)})
         if self.aux_loss:
             out["aux_outputs"] = [{"pred_logits": a, "pred_spans": b} for a, b in zip(logits[:-1], spans[:-1])]
 
         if self.rec_fw and is_training:
             # FW-MESM masked-language-model branch (model.py:307-332)
-            unk = self._proj(self.input_txt_proj, self.unknown_token.view(1, 1, -1))
-            msk = self._proj(self.input_txt_proj, self.masked_token.view(1, 1, -1))
-            w = torch.where(kwargs["unknown_mask"].unsqueeze(-1), unk, pw)
-            w = torch.where(plan.masked_words.unsqueeze(-1), msk, w)
-            cfeat = pv.reshape(N * Lv, d)[plan.clip_src] * plan.clip_mask.unsqueeze(-1)
-            cpos = vpos.reshape(N * Lv, d)[plan.clip_src] * plan.clip_mask.unsqueeze(-1)
-            rec_w = enc(cfeat, w, cpos, None, plan.clip_pad, words_pad, is_mlm=True)
-            hid = self.output_txt_proj[0](rec_w)
-            head = self.output_txt_proj[1]
-            out["recfw_words_logit"] = ops.linear(hid, head.weight, head.bias)
-            out["words_mask"] = words_mask
+            with _scope("mlm"):
+                unk = self._proj(self.input_txt_proj, self.unknown_token.view(1, 1, -1))
+                msk = self._proj(self.input_txt_proj, self.masked_token.view(1, 1, -1))
+                w = torch.where(kwargs["unknown_mask"].unsqueeze(-1), unk, pw)
+                w = torch.where(plan.masked_words.unsqueeze(-1), msk, w)
+                cfeat = pv.reshape(N * Lv, d)[plan.clip_src] * plan.clip_mask.unsqueeze(-1)
+                cpos = vpos.reshape(N * Lv, d)[plan.clip_src] * plan.clip_mask.unsqueeze(-1)
+                rec_w = enc(cfeat, w, cpos, None, plan.clip_pad, words_pad, is_mlm=True)
+                hid = self.output_txt_proj[0](rec_w)
+                head = self.output_txt_proj[1]
+                out["recfw_words_logit"] = ops.linear(hid, head.weight, head.bias)
+                out["words_mask"] = words_mask
+
+        if forked:  # join: everything below reads the negative pass
+            main.wait_stream(side)
+            hand([n_memory, n_memory_g], main)
+        out["neg_saliency_scores"] = saliency(n_memory, n_memory_g)
         if self.rec_ss:
             out.update({"projed_video_feat": pv, "recon_feat": recon, "projed_recon_feat": projed_recon,
                         "expanded_words_feat": ewords, "expanded_words_mask": emask,

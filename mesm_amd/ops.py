@@ -60,7 +60,7 @@ def _accum_dw(dz, xin, gw, gb_view, x2=None, b_act=ACT_NONE, b_drop=NO_DROP, slo
     rows = dz.shape[0]
     s = _dw_split(gw.shape[0], gw.shape[1], rows)
     kn.gemm(dz, xin, gw, trans_a=True, B2=x2, colsum=gb_view, b_act=b_act, b_drop=b_drop,
-            slope=slope, split_k=s, accumulate=1 if s == 1 else 2)
+            slope=slope, split_k=s, accumulate=2)  # atomic: two streams may add into the same view
 
 
 def _rows(t, rows):
