@@ -137,7 +137,8 @@ int mesm_gemm_tape_replay(void* stream, int32_t reps, double* total_ms, int64_t*
  * Replaces nn.LayerNorm sites: transformer.py:536,539,646,649,754,793,796,400,403;
  * model.py:430 (LinearLayer.LayerNorm, D = 2818/4098/512/300/256).
  * fwd writes y, and mean/rstd (rows) for the backward.
- * bwd writes dx (or dx += if accumulate) and atomically accumulates dgamma/dbeta.
+ * bwd writes dx (or dx += if accumulate) and atomically accumulates dgamma/dbeta;
+ * dx == NULL (input needs no gradient) runs the parameter-gradient reduction only.
  */
 int mesm_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
                        float* mean, float* rstd, int64_t rows, int32_t D, float eps,
@@ -331,7 +332,8 @@ int mesm_set_loss_bwd(const float* logits, const float* spans, const float* tgt_
  * logits = sim - rowmax, log_prob = logits - log(sum exp + 1e-6),
  * loss = mean_n -(sum_k pos[n,k] log_prob[n,k]) / (sum_k pos[n,k] + 1e-6).
  * pos (N, N) uint8 is target-only (block-diagonal gIoU >= gamma) and built by the caller.
- * Saved for backward: cn, wn (N, D), stats (N, 4) = {#clips, #words, |clip|, |words|},
+ * Saved for backward: cn, wn (N, D), stats (2N, 4): rows < N = {#clips, #words, |clip|, |words|},
+ * rows >= N scratch for the per-row loss terms,
  * sim (N, N).  bwd writes dpv (N, Lv, D) and dew (N, Le, D) in full; g = device scalar.
  */
 int mesm_rec_ss_fwd(const float* pv, const uint8_t* cmask, int32_t Lv, const float* ew,

@@ -17,10 +17,16 @@
 
 namespace {
 
+// Both kernels are latency-bound per wave (every query row is a chain of LDS reads, ~17 cross-lane
+// exchanges and a P V / dQ sweep, ~1.5-2k cycles), so the lever is rows per wave: the forward
+// splits the queries into chunks of 16 (4 rows per wave; K/V tiles are L2-resident, re-staging
+// them per chunk is cheap), the backward sweeps all queries with 8 waves per workgroup.
 constexpr int AT_THREADS = 256;
 constexpr int AT_WAVES = 4;
+constexpr int BW_THREADS = 512;
+constexpr int BW_WAVES = 8;
 constexpr int KT = 64;   // keys per tile (one per lane)
-constexpr int QCH = 64;  // query rows per forward workgroup
+constexpr int QCH = 16;  // query rows per forward workgroup
 constexpr int QCB = 32;  // query rows staged per backward chunk
 
 struct MaskCtx {
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const MesmAttnArgs
 }
 
 template <int DK, int DV>
-__global__ __launch_bounds__(AT_THREADS) void attn_bwd_kernel(const MesmAttnArgs p) {
+__global__ __launch_bounds__(BW_THREADS) void attn_bwd_kernel(const MesmAttnArgs p) {
   constexpr int SK = DK + 4;
   constexpr int SV = DV + 4;
   constexpr int GQ = 64 / DK >= 1 ? 64 / DK : 1;  // key phases in the dQ step (DK <= 64)
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_kernel(const MesmAttnArgs
   __shared__ __attribute__((aligned(16))) float Qs[QCB * DK];
   __shared__ __attribute__((aligned(16))) float dOs[QCB * DV];
   __shared__ float Dl[QCB], Lse[QCB];
-  __shared__ float Ps[AT_WAVES * KT];
+  __shared__ float Ps[BW_WAVES * KT];
   __shared__ __attribute__((aligned(16))) float Red[KT * DR];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -177,13 +183,13 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_kernel(const MesmAttnArgs
   float* dkb = p.dk_ + (int64_t)b * p.k_bs + (int64_t)h * DK;
   float* dvb = p.dv_ + (int64_t)b * p.v_bs + (int64_t)h * DV;
 
-  for (int idx = tid; idx < KT * (DK / 4); idx += AT_THREADS) {
+  for (int idx = tid; idx < KT * (DK / 4); idx += BW_THREADS) {
     int r = idx / (DK / 4), c = (idx % (DK / 4)) * 4;
     float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
     if (k0 + r < p.Lk) x = *reinterpret_cast<const float4*>(kb + (int64_t)(k0 + r) * p.k_ls + c);
     *reinterpret_cast<float4*>(Ks + r * SK + c) = x;
   }
-  for (int idx = tid; idx < KT * (DV / 4); idx += AT_THREADS) {
+  for (int idx = tid; idx < KT * (DV / 4); idx += BW_THREADS) {
     int r = idx / (DV / 4), c = (idx % (DV / 4)) * 4;
     float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
     if (k0 + r < p.Lk) x = *reinterpret_cast<const float4*>(vb + (int64_t)(k0 + r) * p.v_ls + c);
@@ -217,14 +223,14 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_kernel(const MesmAttnArgs
   for (int qc = 0; qc < p.Lq; qc += QCB) {
     const int nq = (p.Lq - qc) < QCB ? (p.Lq - qc) : QCB;
     __syncthreads();  // previous chunk consumed
-    for (int idx = tid; idx < QCB * (DK / 4); idx += AT_THREADS) {
+    for (int idx = tid; idx < QCB * (DK / 4); idx += BW_THREADS) {
       int r = idx / (DK / 4), c = (idx % (DK / 4)) * 4;
       float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
       if (r < nq) x = *reinterpret_cast<const float4*>(qb + (int64_t)(qc + r) * p.q_ls + c);
       *reinterpret_cast<float4*>(Qs + r * DK + c) = x;
     }
     // dO chunk + delta_i = sum_d dO[i,d] * O[i,d]; DV/4 consecutive threads share a row
-    for (int idx = tid; idx < QCB * (DV / 4); idx += AT_THREADS) {
+    for (int idx = tid; idx < QCB * (DV / 4); idx += BW_THREADS) {
       int r = idx / (DV / 4), c = (idx % (DV / 4)) * 4;
       float4 g = make_float4(0.f, 0.f, 0.f, 0.f), o = g;
       if (r < nq) {
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_kernel(const MesmAttnArgs
     if (tid < QCB) Lse[tid] = (tid < nq) ? p.lse[(int64_t)bh * p.Lq + qc + tid] : 0.0f;
     __syncthreads();
 
-    for (int r = wave; r < nq; r += AT_WAVES) {
+    for (int r = wave; r < nq; r += BW_WAVES) {
       const int i = qc + r;
       float s = 0.0f;
 #pragma unroll
@@ -296,7 +302,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_kernel(const MesmAttnArgs
   }
 
   // deterministic cross-wave reduction of dK then dV through LDS, wave by wave
-  for (int w = 0; w < AT_WAVES; ++w) {
+  for (int w = 0; w < BW_WAVES; ++w) {
     __syncthreads();
     if (wave == w) {
 #pragma unroll
@@ -308,11 +314,11 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_kernel(const MesmAttnArgs
     }
   }
   __syncthreads();
-  for (int idx = tid; idx < KT * DK; idx += AT_THREADS) {
+  for (int idx = tid; idx < KT * DK; idx += BW_THREADS) {
     int r = idx / DK, c = idx % DK;
     if (k0 + r < p.Lk) dkb[(int64_t)(k0 + r) * p.k_ls + c] = Red[r * DR + c];
   }
-  for (int w = 0; w < AT_WAVES; ++w) {
+  for (int w = 0; w < BW_WAVES; ++w) {
     __syncthreads();
     if (wave == w) {
 #pragma unroll
@@ -324,7 +330,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd_kernel(const MesmAttnArgs
     }
   }
   __syncthreads();
-  for (int idx = tid; idx < KT * DV; idx += AT_THREADS) {
+  for (int idx = tid; idx < KT * DV; idx += BW_THREADS) {
     int r = idx / DV, c = idx % DV;
     if (k0 + r < p.Lk) dvb[(int64_t)(k0 + r) * p.v_ls + c] = Red[r * DR + c];
   }
@@ -346,7 +352,7 @@ int check_common(const MesmAttnArgs& a) {
   return MESM_OK;
 }
 
-#define ATTN_DISPATCH(KERNEL, GRID)                                                        \
+#define ATTN_DISPATCH(KERNEL, GRID, AT_THREADS)                                            \
   do {                                                                                     \
     if (a.dk == 32 && a.dv == 32) hipLaunchKernelGGL((KERNEL<32, 32>), GRID, dim3(AT_THREADS), 0, s, a); \
     else if (a.dk == 64 && a.dv == 32) hipLaunchKernelGGL((KERNEL<64, 32>), GRID, dim3(AT_THREADS), 0, s, a); \
@@ -367,7 +373,7 @@ extern "C" int mesm_attn_fwd(const MesmAttnArgs* args, void* stream) {
   if (rc != MESM_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(a.B * a.H, (a.Lq + QCH - 1) / QCH);
-  ATTN_DISPATCH(attn_fwd_kernel, grid);
+  ATTN_DISPATCH(attn_fwd_kernel, grid, AT_THREADS);
   return mesm_launch_status();
 }
 
@@ -382,6 +388,6 @@ extern "C" int mesm_attn_bwd(const MesmAttnArgs* args, void* stream) {
     if (((uintptr_t)ptr % 16) != 0) return MESM_EALIGN;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(a.B * a.H, (a.Lk + KT - 1) / KT);
-  ATTN_DISPATCH(attn_bwd_kernel, grid);
+  ATTN_DISPATCH(attn_bwd_kernel, grid, BW_THREADS);
   return mesm_launch_status();
 }

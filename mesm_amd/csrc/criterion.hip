@@ -248,49 +248,62 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
   return t;
 }
 
-__global__ __launch_bounds__(256) void ss_mean_fwd_kernel(
+constexpr int SSM_G = 4;  // row groups per workgroup (independent load chains)
+__global__ __launch_bounds__(256 * SSM_G) void ss_mean_fwd_kernel(
     const float* __restrict__ pv, const uint8_t* __restrict__ cmask, int Lv,
     const float* __restrict__ ew, const uint8_t* __restrict__ wmask, int Le, int D,
     float* __restrict__ cn, float* __restrict__ wn, float* __restrict__ stats) {
-  __shared__ float sh[8];
+  __shared__ float sh[16];
+  __shared__ float part[2][SSM_G][1024];
   const int n = blockIdx.x;
+  const int t = threadIdx.x & 255, g = threadIdx.x >> 8;
   float ccnt = 0.0f, wcnt = 0.0f;
   for (int l = 0; l < Lv; ++l) ccnt += cmask[(int64_t)n * Lv + l] ? 1.0f : 0.0f;
   for (int l = 0; l < Le; ++l) wcnt += wmask[(int64_t)n * Le + l] ? 1.0f : 0.0f;
   // D <= 4 * 256 handled per thread in registers
   float cs[4] = {0, 0, 0, 0}, ws[4] = {0, 0, 0, 0};
-  for (int l = 0; l < Lv; ++l) {
-    if (!cmask[(int64_t)n * Lv + l]) continue;
+  for (int l = g; l < Lv; l += SSM_G) {
+    const float m = cmask[(int64_t)n * Lv + l] ? 1.0f : 0.0f;
     const float* r = pv + ((int64_t)n * Lv + l) * D;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int c = threadIdx.x + k * 256;
-      if (c < D) cs[k] += r[c];
+      const int c = t + k * 256;
+      if (c < D) cs[k] += m * r[c];
     }
   }
-  for (int l = 0; l < Le; ++l) {
-    if (!wmask[(int64_t)n * Le + l]) continue;
+  for (int l = g; l < Le; l += SSM_G) {
+    const float m = wmask[(int64_t)n * Le + l] ? 1.0f : 0.0f;
     const float* r = ew + ((int64_t)n * Le + l) * D;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const int c = threadIdx.x + k * 256;
-      if (c < D) ws[k] += r[c];
+      const int c = t + k * 256;
+      if (c < D) ws[k] += m * r[c];
     }
   }
-  float c2 = 0.0f, w2 = 0.0f;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    cs[k] /= ccnt; ws[k] /= wcnt;
-    c2 += cs[k] * cs[k]; w2 += ws[k] * ws[k];
+  for (int k = 0; k < 4; ++k) { part[0][g][t + k * 256] = cs[k]; part[1][g][t + k * 256] = ws[k]; }
+  __syncthreads();
+  float c2 = 0.0f, w2 = 0.0f;
+  if (g == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float a = 0.0f, b = 0.0f;
+#pragma unroll
+      for (int gg = 0; gg < SSM_G; ++gg) { a += part[0][gg][t + k * 256]; b += part[1][gg][t + k * 256]; }
+      cs[k] = a / ccnt; ws[k] = b / wcnt;
+      c2 += cs[k] * cs[k]; w2 += ws[k] * ws[k];
+    }
   }
   const float cnorm = fmaxf(sqrtf(block_sum(c2, sh)), 1e-12f);
   const float wnorm = fmaxf(sqrtf(block_sum(w2, sh)), 1e-12f);
+  if (g == 0) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int c = threadIdx.x + k * 256;
-    if (c < D) {
-      cn[(int64_t)n * D + c] = cs[k] / cnorm;
-      wn[(int64_t)n * D + c] = ws[k] / wnorm;
+    for (int k = 0; k < 4; ++k) {
+      const int c = t + k * 256;
+      if (c < D) {
+        cn[(int64_t)n * D + c] = cs[k] / cnorm;
+        wn[(int64_t)n * D + c] = ws[k] / wnorm;
+      }
     }
   }
   if (threadIdx.x == 0) {
@@ -299,36 +312,44 @@ __global__ __launch_bounds__(256) void ss_mean_fwd_kernel(
   }
 }
 
-// Stage B, one workgroup: sim = cn wn^T / tau (saved), SupCon-style loss with +1e-6 in the log.
+// Stage B, one workgroup per row n: sim[n,:] = cn[n] wn^T / tau (saved) and the row's loss term
+// (SupCon-style, +1e-6 inside the log); stage C sums the N row terms (deterministic).
 __global__ __launch_bounds__(256) void ss_loss_fwd_kernel(
     const float* __restrict__ cn, const float* __restrict__ wn, const uint8_t* __restrict__ pos, int N,
-    int D, float inv_tau, float* __restrict__ sim, float* __restrict__ out) {
-  __shared__ float sh[8];
+    int D, float inv_tau, float* __restrict__ sim, float* __restrict__ rowloss) {
+  extern __shared__ float srow[];  // N
+  const int n = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int e = wave; e < N * N; e += 4) {
-    const int n = e / N, k = e % N;
+  float q[16];  // D <= 1024: this lane's slice of cn[n]
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { const int c = lane + 64 * i; q[i] = c < D ? cn[(int64_t)n * D + c] : 0.0f; }
+  for (int k = wave; k < N; k += 4) {
     float a = 0.0f;
-    for (int c = lane; c < D; c += 64) a += cn[(int64_t)n * D + c] * wn[(int64_t)k * D + c];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int c = lane + 64 * i; if (c < D) a += q[i] * wn[(int64_t)k * D + c]; }
     a = wave_sum(a);
-    if (lane == 0) sim[e] = a * inv_tau;
+    if (lane == 0) { srow[k] = a * inv_tau; sim[(int64_t)n * N + k] = a * inv_tau; }
   }
-  __threadfence_block();
   __syncthreads();
-  float acc = 0.0f;
-  for (int n = threadIdx.x; n < N; n += 256) {
-    const float* r = sim + (int64_t)n * N;
+  if (threadIdx.x == 0) {
     float m = -INFINITY;
-    for (int k = 0; k < N; ++k) m = fmaxf(m, r[k]);
+    for (int k = 0; k < N; ++k) m = fmaxf(m, srow[k]);
     float S = 0.0f;
-    for (int k = 0; k < N; ++k) S += expf(r[k] - m);
+    for (int k = 0; k < N; ++k) S += expf(srow[k] - m);
     const float logS = logf(S + 1e-6f);
     float num = 0.0f, cnt = 0.0f;
     for (int k = 0; k < N; ++k)
-      if (pos[(int64_t)n * N + k]) { num += (r[k] - m) - logS; cnt += 1.0f; }
-    acc += -num / (cnt + 1e-6f);
+      if (pos[(int64_t)n * N + k]) { num += (srow[k] - m) - logS; cnt += 1.0f; }
+    rowloss[n] = -num / (cnt + 1e-6f);
   }
-  const float tot = block_sum(acc, sh);
-  if (threadIdx.x == 0) out[0] = tot / (float)N;
+}
+
+__global__ __launch_bounds__(64) void ss_reduce_kernel(const float* __restrict__ rowloss, int N,
+                                                       float* __restrict__ out) {
+  float a = 0.0f;
+  for (int n = threadIdx.x; n < N; n += 64) a += rowloss[n];
+  a = wave_sum(a);
+  if (threadIdx.x == 0) out[0] = a / (float)N;
 }
 
 // Backward, one workgroup per pair n: rebuild dsim (N x N) in LDS from the saved sim, then
@@ -491,6 +512,7 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict
   if (c >= D) return;
   const float bv = b[(int64_t)n * D + c] * scale;
   float acc = 0.0f;
+#pragma unroll 5
   for (int l = 0; l < L; ++l) {
     const float d = ds[(int64_t)n * L + l];
     const int64_t o = ((int64_t)n * L + l) * D + c;
@@ -504,19 +526,20 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict
 // post_process_text (model.py:145-152): per-word L2 normalisation (eps 1e-5), word mask =
 // (sum of normalised features != 0), sentence feature = normalised mean over valid words.
 // One workgroup per pair; a wave per word.
-__global__ __launch_bounds__(256) void text_prep_kernel(const float* __restrict__ x, int Lw, int D,
+constexpr int TP_THREADS = 1024;
+__global__ __launch_bounds__(TP_THREADS) void text_prep_kernel(const float* __restrict__ x, int Lw, int D,
                                                         int normalize, float* __restrict__ words,
                                                         uint8_t* __restrict__ wmask,
                                                         float* __restrict__ sent) {
   extern __shared__ float sm[];  // D accumulators + Lw flags
   float* accv = sm;
   float* flags = sm + D;
-  __shared__ float sh[8];
+  __shared__ float sh[16];
   const int n = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int c = threadIdx.x; c < D; c += 256) accv[c] = 0.0f;
+  for (int c = threadIdx.x; c < D; c += TP_THREADS) accv[c] = 0.0f;
   __syncthreads();
-  for (int w = wave; w < Lw; w += 4) {
+  for (int w = wave; w < Lw; w += TP_THREADS / 64) {
     const float* r = x + ((int64_t)n * Lw + w) * D;
     float* o = words + ((int64_t)n * Lw + w) * D;
     float s2 = 0.0f;
@@ -537,7 +560,7 @@ __global__ __launch_bounds__(256) void text_prep_kernel(const float* __restrict_
   for (int w = 0; w < Lw; ++w) cnt += flags[w];
   float part = 0.0f;
   // the reference sums ALL words (pads are zero vectors) and divides by the number of valid ones
-  for (int c = threadIdx.x; c < D; c += 256) {
+  for (int c = threadIdx.x; c < D; c += TP_THREADS) {
     float a = 0.0f;
     for (int w = 0; w < Lw; ++w) a += words[((int64_t)n * Lw + w) * D + c];
     a /= cnt;
@@ -546,7 +569,7 @@ __global__ __launch_bounds__(256) void text_prep_kernel(const float* __restrict_
   }
   const float nrm = sqrtf(block_sum(part, sh));
   const float inv = normalize ? 1.0f / fmaxf(nrm, 1e-5f) : 1.0f;
-  for (int c = threadIdx.x; c < D; c += 256) sent[(int64_t)n * D + c] = accv[c] * inv;
+  for (int c = threadIdx.x; c < D; c += TP_THREADS) sent[(int64_t)n * D + c] = accv[c] * inv;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -603,10 +626,13 @@ extern "C" int mesm_rec_ss_fwd(const float* pv, const uint8_t* cmask, int32_t Lv
   if (!pv || !cmask || !ew || !wmask || !pos || !cn || !wn || !stats || !sim || !out) return MESM_EINVAL;
   if (N <= 0 || D <= 0 || D > 1024 || Lv <= 0 || Le <= 0 || tau <= 0.f) return MESM_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(ss_mean_fwd_kernel, dim3(N), dim3(256), 0, s, pv, cmask, Lv, ew, wmask, Le, D, cn,
-                     wn, stats);
-  hipLaunchKernelGGL(ss_loss_fwd_kernel, dim3(1), dim3(256), 0, s, cn, wn, pos, N, D, 1.0f / tau, sim,
-                     out);
+  hipLaunchKernelGGL(ss_mean_fwd_kernel, dim3(N), dim3(256 * SSM_G), 0, s, pv, cmask, Lv, ew, wmask, Le,
+                     D, cn, wn, stats);
+  // stats (N, 4) has one spare use: the row losses are staged in column 0 of a second block
+  float* rowloss = stats + (size_t)N * 4;
+  hipLaunchKernelGGL(ss_loss_fwd_kernel, dim3(N), dim3(256), (size_t)N * 4, s, cn, wn, pos, N, D,
+                     1.0f / tau, sim, rowloss);
+  hipLaunchKernelGGL(ss_reduce_kernel, dim3(1), dim3(64), 0, s, rowloss, N, out);
   return mesm_launch_status();
 }
 
@@ -657,7 +683,7 @@ extern "C" int mesm_rowdot_bwd(const float* a, const float* b, const float* ds, 
 extern "C" int mesm_text_prep(const float* x, int32_t N, int32_t Lw, int32_t D, int32_t normalize,
                               float* words, uint8_t* wmask, float* sent, void* stream) {
   if (!x || !words || !wmask || !sent || N <= 0 || Lw <= 0 || D <= 0) return MESM_EINVAL;
-  hipLaunchKernelGGL(text_prep_kernel, dim3(N), dim3(256), (size_t)(D + Lw) * 4, (hipStream_t)stream, x,
+  hipLaunchKernelGGL(text_prep_kernel, dim3(N), dim3(TP_THREADS), (size_t)(D + Lw) * 4, (hipStream_t)stream, x,
                      Lw, D, normalize, words, wmask, sent);
   return mesm_launch_status();
 }

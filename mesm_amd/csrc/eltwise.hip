@@ -6,29 +6,33 @@ namespace {
 constexpr float TWO_PI_F = 6.283185307179586f;  // float32(2*math.pi), as torch casts the scalar
 
 // ---- PositionEmbeddingSine (position_encoding.py:51-72) ----
+constexpr int SP_ROWS = 8;  // positions per workgroup
 __global__ __launch_bounds__(256) void sine_pos_kernel(const uint8_t* __restrict__ mask,
                                                       float* __restrict__ out, int L, int D) {
-  extern __shared__ float xs[];  // L normalised positions
+  __shared__ float xs[SP_ROWS + 1];  // inclusive prefix counts of this chunk's rows, then the total
   const int b = blockIdx.x;
+  const int l0 = blockIdx.y * SP_ROWS;
   const uint8_t* m = mask + (int64_t)b * L;
   // inclusive prefix count of valid clips (exact in fp32, like cumsum(dtype=float32))
-  for (int l = threadIdx.x; l < L; l += blockDim.x) {
+  if (threadIdx.x <= SP_ROWS) {
+    const int upto = threadIdx.x == SP_ROWS ? L - 1 : l0 + threadIdx.x;
     int c = 0;
-    for (int t = 0; t <= l; ++t) c += m[t] != 0;
-    xs[l] = (float)c;
+    for (int t = 0; t <= upto && t < L; ++t) c += m[t] != 0;
+    xs[threadIdx.x] = (float)c;
   }
   __syncthreads();
-  const float last = xs[L - 1];
-  __syncthreads();
-  for (int l = threadIdx.x; l < L; l += blockDim.x) xs[l] = xs[l] / (last + 1e-6f) * TWO_PI_F;
-  __syncthreads();
-  float* ob = out + (int64_t)b * L * D;
-  for (int idx = threadIdx.x; idx < L * D; idx += blockDim.x) {
-    int l = idx / D, i = idx % D;
-    float e = (float)(2 * (i / 2)) / (float)D;
-    float dim_t = powf(10000.0f, e);
-    float v = xs[l] / dim_t;
-    ob[idx] = (i & 1) ? cosf(v) : sinf(v);
+  const float last = xs[SP_ROWS];
+  for (int i = threadIdx.x; i < D; i += blockDim.x) {
+    const float e = (float)(2 * (i / 2)) / (float)D;
+    const float dim_t = powf(10000.0f, e);
+#pragma unroll
+    for (int r = 0; r < SP_ROWS; ++r) {
+      const int l = l0 + r;
+      if (l < L) {
+        const float v = xs[r] / (last + 1e-6f) * TWO_PI_F / dim_t;
+        out[((int64_t)b * L + l) * D + i] = (i & 1) ? cosf(v) : sinf(v);
+      }
+    }
   }
 }
 
@@ -132,7 +136,7 @@ extern "C" int mesm_sine_pos_fwd(const uint8_t* mask, float* out, int32_t B, int
                                  int32_t D, void* stream) {
   if (!mask || !out || B <= 0 || L <= 0 || D <= 0 || (D & 1)) return MESM_EINVAL;
   if (L > 8192) return MESM_EINVAL;
-  hipLaunchKernelGGL(sine_pos_kernel, dim3(B), dim3(256), (size_t)L * sizeof(float),
+  hipLaunchKernelGGL(sine_pos_kernel, dim3(B, (L + SP_ROWS - 1) / SP_ROWS), dim3(256), 0,
                      (hipStream_t)stream, mask, out, L, D);
   return mesm_launch_status();
 }

@@ -196,6 +196,26 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
   }
 }
 
+// Parameter gradients only (dx == NULL: the input needs no gradient, e.g. the LayerNorm over the raw
+// 2818-d video features): a column-parallel reduction, thread = column, blockIdx.y = row chunk.
+__global__ __launch_bounds__(256) void ln_bwd_params_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
+    const float* __restrict__ rstd, float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows,
+    int D, int rows_per_block) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= D) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  float dg = 0.0f, db = 0.0f;
+  for (int64_t r = r0; r < r1; ++r) {
+    const float d = dy[r * D + col];
+    dg += d * (x[r * D + col] - mean[r]) * rstd[r];
+    db += d;
+  }
+  atomicAdd(dgamma + col, dg);
+  atomicAdd(dbeta + col, db);
+}
+
 inline int pick_vec(int D, const void* a, const void* b, const void* c, const void* d) {
   int vec = 4;
   while (vec > 1) {
@@ -268,10 +288,21 @@ extern "C" int mesm_layernorm_bwd(const float* dy, const float* x, const float* 
                                   const float* mean, const float* rstd, float* dx,
                                   float* dgamma, float* dbeta, int64_t rows, int32_t D,
                                   int32_t accumulate_dx, void* stream) {
-  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows < 0 || D <= 0)
+  if (!dy || !x || !gamma || !mean || !rstd || !dgamma || !dbeta || rows < 0 || D <= 0)
     return MESM_EINVAL;
   if (rows == 0) return MESM_OK;
   hipStream_t s = (hipStream_t)stream;
+  if (!dx) {
+    if (accumulate_dx) return MESM_EINVAL;
+    const int cb = (D + 255) / 256;
+    int rb = (int)((1024 + cb - 1) / cb);  // about 1024 workgroups
+    if (rb > rows) rb = (int)rows;
+    const int rpb = (int)((rows + rb - 1) / rb);
+    rb = (int)((rows + rpb - 1) / rpb);
+    hipLaunchKernelGGL(ln_bwd_params_kernel, dim3(cb, rb), dim3(256), 0, s, dy, x, mean, rstd, dgamma,
+                       dbeta, rows, D, rpb);
+    return mesm_launch_status();
+  }
   int vec = pick_vec(D, x, dy, dx, gamma);
   if (vec == 4)
     LN_DISPATCH(bwd_launch, 4, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, accumulate_dx, s);

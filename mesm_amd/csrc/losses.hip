@@ -174,15 +174,16 @@ __device__ __forceinline__ void sal_row_stats(const float* sp, const float* sn, 
   R.wsum = wave_sum(wsum);
 }
 
-__global__ __launch_bounds__(256) void saliency_fwd_kernel(
+constexpr int SAL_FWD_WAVES = 16;  // one workgroup (deterministic sum), a wave per pair
+__global__ __launch_bounds__(64 * SAL_FWD_WAVES) void saliency_fwd_kernel(
     const float* __restrict__ s_pos, const float* __restrict__ s_neg,
     const double* __restrict__ label, const uint8_t* __restrict__ vmask,
     const int64_t* __restrict__ pos_idx, const int64_t* __restrict__ neg_idx, int N, int L, int P,
     float rank_coef, float margin, float* __restrict__ out_loss) {
-  __shared__ float part[4];
+  __shared__ float part[SAL_FWD_WAVES];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float acc = 0.0f;  // lane 0 of each wave accumulates its rows
-  for (int n = wave; n < N; n += 4) {
+  for (int n = wave; n < N; n += SAL_FWD_WAVES) {
     const float* sp = s_pos + (int64_t)n * L;
     const float* sn = s_neg + (int64_t)n * L;
     const uint8_t* vm = vmask + (int64_t)n * L;
@@ -208,7 +209,11 @@ __global__ __launch_bounds__(256) void saliency_fwd_kernel(
   }
   if (lane == 0) part[wave] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) *out_loss = part[0] + part[1] + part[2] + part[3];
+  if (threadIdx.x == 0) {
+    float t = 0.0f;
+    for (int w = 0; w < SAL_FWD_WAVES; ++w) t += part[w];
+    *out_loss = t;
+  }
 }
 
 __global__ __launch_bounds__(256) void saliency_bwd_kernel(
@@ -368,7 +373,7 @@ extern "C" int mesm_saliency_loss_fwd(const float* s_pos, const float* s_neg, co
   if (2 * L > 64 * SAL_MAXE) return MESM_EINVAL;
   if ((pos_idx == nullptr) != (neg_idx == nullptr)) return MESM_EINVAL;
   if (pos_idx && (P <= 0 || P > 64)) return MESM_EINVAL;
-  hipLaunchKernelGGL(saliency_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, s_pos, s_neg,
+  hipLaunchKernelGGL(saliency_fwd_kernel, dim3(1), dim3(64 * SAL_FWD_WAVES), 0, (hipStream_t)stream, s_pos, s_neg,
                      label, vmask, pos_idx, neg_idx, N, L, P, rank_coef, margin, out_loss);
   return mesm_launch_status();
 }

@@ -123,13 +123,19 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5):
     return y.view(x.shape), mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx=None, accumulate_dx=False):
-    """dgamma/dbeta are ACCUMULATED into (flat-gradient views)."""
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx=None, accumulate_dx=False, need_dx=True):
+    """dgamma/dbeta are ACCUMULATED into (flat-gradient views).  need_dx=False: parameter
+    gradients only (returns None)."""
     require_gpu(dy, x, gamma)
     D = x.shape[-1]
     x2 = x.reshape(-1, D)
     dy2 = dy.reshape(-1, D)
     assert x2.is_contiguous() and dy2.is_contiguous()
+    if not need_dx:
+        check(lib().mesm_layernorm_bwd(ptr(dy2), ptr(x2), ptr(gamma), ptr(mean), ptr(rstd), None,
+                                       ptr(dgamma), ptr(dbeta), x2.shape[0], D, 0, stream_ptr()),
+              "mesm_layernorm_bwd")
+        return None
     if dx is None:
         assert not accumulate_dx
         dx = torch.empty_like(x2)
@@ -378,7 +384,7 @@ def rec_ss_fwd(pv, cmask, ew, wmask, pos, tau, out):
     dev = pv.device
     cn = torch.empty(N, D, device=dev, dtype=torch.float32)
     wn = torch.empty(N, D, device=dev, dtype=torch.float32)
-    stats = torch.empty(N, 4, device=dev, dtype=torch.float32)
+    stats = torch.empty(2 * N, 4, device=dev, dtype=torch.float32)  # rows N.. : per-row loss staging
     sim = torch.empty(N, N, device=dev, dtype=torch.float32)
     check(lib().mesm_rec_ss_fwd(ptr(pv), ptr(cmask), Lv, ptr(ew), ptr(wmask), Le, ptr(pos), N, D,
                                 float(tau), ptr(cn), ptr(wn), ptr(stats), ptr(sim), ptr(out),

@@ -329,7 +329,7 @@ class MESM(nn.Module):
                 tok = self.ss_reconstructor.masked_sent_token.view(1, 1, d)
                 q_tok = torch.where(plan.sent_loc.unsqueeze(-1), tok, bsent)
                 rec = self.ss_reconstructor.recon_trans(bvid, q_tok, None, None, bvid_pad, plan.sent_pad)
-                recon = F.normalize(rec[plan.rows, plan.sent_slot])  # the masked slot of every pair
+                recon = F.normalize(ops.gather_rows(rec.reshape(-1, d), plan.rows * rec.shape[1] + plan.sent_slot))  # the masked slot of every pair
                 # projed_recon_feat feeds no loss (criterion.py:246-255) but is part of the returned dict
                 projed_recon = self._proj(self.ss_reconstructor.output_sent_proj, recon)
                 ewords = torch.cat([recon.unsqueeze(1), pw], dim=1)
@@ -347,7 +347,8 @@ class MESM(nn.Module):
         # discarded at :295
         with torch.cuda.stream(side), _scope("neg"):
             ni = plan.neg_index
-            n_ewords, n_emask = ewords[ni], emask[ni]
+            n_ewords = ops.gather_rows(ewords.reshape(N, -1), ni).view(N, ewords.shape[1], d)
+            n_emask = emask[ni]
             if self.rec_ss:
                 n_words, n_wpad = n_ewords[:, 1:], (~n_emask[:, 1:]).contiguous()
             else:
@@ -386,7 +387,7 @@ class MESM(nn.Module):
                 msk = self._proj(self.input_txt_proj, self.masked_token.view(1, 1, -1))
                 w = torch.where(kwargs["unknown_mask"].unsqueeze(-1), unk, pw)
                 w = torch.where(plan.masked_words.unsqueeze(-1), msk, w)
-                cfeat = pv.reshape(N * Lv, d)[plan.clip_src] * plan.clip_mask.unsqueeze(-1)
+                cfeat = ops.gather_rows(pv.reshape(N * Lv, d), plan.clip_src) * plan.clip_mask.unsqueeze(-1)
                 cpos = vpos.reshape(N * Lv, d)[plan.clip_src] * plan.clip_mask.unsqueeze(-1)
                 rec_w = enc(cfeat, w, cpos, None, plan.clip_pad, words_pad, is_mlm=True)
                 hid = self.output_txt_proj[0](rec_w)

@@ -179,6 +179,12 @@ def test_layernorm(rows, D):
     dx2 = base.clone()
     kn.layernorm_bwd(dy, x, g, mean, rstd, dg, db, dx=dx2, accumulate_dx=True)
     assert rel_err(dx2, xd.grad + base.double()) < TOL
+    # parameter gradients only (input without gradient)
+    dg2 = torch.zeros(D, device=dev())
+    db2 = torch.zeros(D, device=dev())
+    assert kn.layernorm_bwd(dy, x, g, mean, rstd, dg2, db2, need_dx=False) is None
+    assert rel_err(dg2, gd.grad) < TOL
+    assert rel_err(db2, bd.grad) < TOL
 
 
 # --------------------------------------------------------------------------- attention

@@ -1,0 +1,55 @@
+"""In-situ cost of a kernel family: time the captured training step with that family's launches
+turned into no-ops (results are garbage; only the step time matters).  rocprofv3 inflates short
+kernels by ~2 us each, so this is the attribution that adds up to the real step time.
+Usage: python tools/ablate.py [families...]   families: gemm attn ln loss elt  (default: each in turn)"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from mesm_amd import _lib, build_criterion, build_model, synthetic
+from mesm_amd.graphed import GraphedStep
+
+FAMILIES = {
+    "gemm": ["mesm_gemm_f32"],
+    "attn": ["mesm_attn_fwd", "mesm_attn_bwd"],
+    "ln": ["mesm_layernorm_fwd", "mesm_layernorm_bwd"],
+    "loss": ["mesm_set_loss_fwd", "mesm_set_loss_bwd", "mesm_rec_ss_fwd", "mesm_rec_ss_bwd", "mesm_rec_fw_reduce",
+             "mesm_rec_fw_rowgrad", "mesm_nll_smooth_fwd", "mesm_nll_smooth_bwd", "mesm_saliency_loss_fwd",
+             "mesm_saliency_loss_bwd", "mesm_weighted_sum", "mesm_scale_vec", "mesm_rowdot_fwd", "mesm_rowdot_bwd"],
+    "elt": ["mesm_dropout", "mesm_act_bias_bwd", "mesm_sine_pos_fwd", "mesm_query_sine_fwd", "mesm_query_sine_bwd",
+            "mesm_text_prep"],
+}
+L = _lib.lib()
+REAL = {n: getattr(L, n) for fam in FAMILIES.values() for n in fam}
+
+
+def step_ms(skip):
+    for n, f in REAL.items():
+        setattr(L, n, f)
+    for fam in skip:
+        for n in FAMILIES[fam]:
+            setattr(L, n, lambda *a, **k: 0)
+    dev = torch.device("cuda:0")
+    args = synthetic.make_args("C3a", device=str(dev))
+    torch.manual_seed(1234)
+    model = build_model(args); crit = build_criterion(args); model.train()
+    batch = synthetic.to_device(synthetic.workload_batch("C3a", seed=0), dev)
+    g = GraphedStep(model, crit, batch, args.dataset_name, warmup=1)
+    for _ in range(3):
+        g.run(redraw=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        g.run(redraw=False)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / 20 * 1e3
+
+
+base = step_ms([])
+print("full step            %.3f ms" % base)
+fams = sys.argv[1:] or list(FAMILIES)
+for f in fams:
+    t = step_ms([f])
+    print("without %-6s       %.3f ms   -> %-6s costs %.3f ms" % (f, t, f, base - t))
+t = step_ms(list(FAMILIES))
+print("without all of them  %.3f ms   (= ATen glue + launch floor)" % t)

@@ -51,11 +51,12 @@ for name, M, N, K, ta, tb, split in SHAPES:
         for _ in range(3):
             g.replay()
         torch.cuda.synchronize()
+        REPS = int(os.environ.get("REPS", "20"))
         t0 = time.perf_counter()
-        for _ in range(20):
+        for _ in range(REPS):
             g.replay()
         torch.cuda.synchronize()
-        res.append((time.perf_counter() - t0) / 20 / NL * 1e6)
+        res.append((time.perf_counter() - t0) / REPS / NL * 1e6)
     os.environ["MESM_GEMM_TILE"] = "0"
     print("%s M=%5d N=%5d K=%5d s%-2d auto %7.2f | frag %7.2f | wstage %7.2f | t32 %7.2f | t64 %7.2f us  (best %5.1f TF)" % (
         name, M, N, K, split, res[0], res[1], res[2], res[3], res[4], 2.0 * M * N * K / min(res) / 1e6), flush=True)
