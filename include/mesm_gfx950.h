@@ -65,8 +65,11 @@ const char* mesm_arch(void);
  * Prologue on A (and on B), applied while the operand is staged into LDS:
  *   x = A[m,k] (+ A2[m,k] if A2 != NULL, same strides)           [with_pos_embed]
  *   x = act(x)              a_act  in {NONE, RELU, PRELU(*slope)} [FFN activation]
- *   x = dropout(x)          a_drop_p > 0: keep iff hash(seed, m*K + k) >= p; /(1-p)
- * B: same (B2 is the optional second addend), logical index k*N + n.
+ *   x = dropout(x)          a_drop_p > 0: keep iff hash(seed, idx) >= p; /(1-p), where idx is the
+ *                           dense row-major index of the element in the operand AS STORED:
+ *                           m*K + k for a reduce-contiguous A, k*M + m for an outer-contiguous
+ *                           A (A = dY^T reads the mask that the forward epilogue wrote on Y)
+ * B: same (B2 is the optional second addend); index k*N + n (outer-contiguous) or n*K + k.
  *
  * Epilogue, in this order (each step optional):
  *   t = acc * out_scale
@@ -74,7 +77,7 @@ const char* mesm_arch(void);
  *   t = act(t)                       e_act in {NONE, RELU, PRELU(*slope)}
  *   t = dropout(t)                   e_drop_p > 0, index m*N + n
  *   t *= act'(aux[m,n])              e_actgrad in {NONE, RELU, PRELU}; for PRELU also
- *                                    *dslope += sum(t_before * min(aux,0)) (atomic)
+ *                                    *dslope += sum(t_before * min(aux,0)) (via dslope_ws)
  *   t += residual[m,n]
  *   C[m,n] = t | C[m,n] += t | atomicAdd(C[m,n], t)      (accumulate = 0|1|2)
  * split_k > 1 forces atomic accumulation (C must be initialised by the caller);
@@ -113,6 +116,10 @@ typedef struct MesmGemmArgs {
   /* optional device scalar added to every dropout seed of this launch at run time, so a
      captured HIP graph draws fresh masks on every replay (NULL = 0) */
   const uint32_t* seed_offset;
+  /* workspace for the PRELU slope gradient: >= ceil(M/32) * ceil(N/32) * max(split_k, 1) floats,
+     required when e_actgrad == PRELU and dslope != NULL (one plain store per workgroup, then a
+     1-workgroup reduction adds the sum into *dslope) */
+  float* dslope_ws;
 } MesmGemmArgs;
 
 int mesm_gemm_f32(const MesmGemmArgs* args, void* stream);
@@ -197,6 +204,10 @@ typedef struct MesmAttnArgs {
   float* dk_;       /* strides k_bs/k_ls */
   float* dv_;       /* strides v_bs/v_ls */
   const uint32_t* seed_offset; /* see MesmGemmArgs.seed_offset */
+  /* T2V_QUIRK with several independent batches stacked along B (positive and negative pass in
+     one launch): the batch index wraps inside groups of mask_group rows,
+     b2 = (b / G) * G + ((b % G) * H + h) mod G.  0 = one group of B rows. */
+  int32_t mask_group;
 } MesmAttnArgs;
 
 int mesm_attn_fwd(const MesmAttnArgs* args, void* stream);

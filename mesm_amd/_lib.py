@@ -39,7 +39,7 @@ class GemmArgs(ctypes.Structure):
         ("e_drop_p", ctypes.c_float), ("e_drop_seed", ctypes.c_uint32),
         ("out_scale", ctypes.c_float),
         ("accumulate", ctypes.c_int32), ("split_k", ctypes.c_int32),
-        ("seed_offset", c_ptr),
+        ("seed_offset", c_ptr), ("dslope_ws", c_ptr),
     ]
 
 
@@ -56,7 +56,7 @@ class AttnArgs(ctypes.Structure):
         ("scale", ctypes.c_float), ("drop_p", ctypes.c_float),
         ("drop_seed", ctypes.c_uint32),
         ("d_o", c_ptr), ("dq", c_ptr), ("dk_", c_ptr), ("dv_", c_ptr),
-        ("seed_offset", c_ptr),
+        ("seed_offset", c_ptr), ("mask_group", ctypes.c_int32),
     ]
 
 

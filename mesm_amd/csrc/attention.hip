@@ -50,7 +50,8 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const MesmAttnArgs
   const int b = bh / p.H, h = bh % p.H;
   const int q0 = blockIdx.y * QCH;
   const int nq = (p.Lq - q0) < QCH ? (p.Lq - q0) : QCH;
-  const int b2 = (b * p.H + h) % p.B;
+  const int mg = p.mask_group > 0 ? p.mask_group : p.B;
+  const int b2 = (b / mg) * mg + ((b % mg) * p.H + h) % mg;
   const bool quirk = (p.mask_mode == MESM_MASK_T2V_QUIRK) && p.qpad && p.kpad;
 
   const float* qb = p.q + (int64_t)b * p.q_bs + (int64_t)h * DK;
@@ -170,7 +171,8 @@ __global__ __launch_bounds__(BW_THREADS) void attn_bwd_kernel(const MesmAttnArgs
   const int bh = blockIdx.x;
   const int b = bh / p.H, h = bh % p.H;
   const int k0 = blockIdx.y * KT;
-  const int b2 = (b * p.H + h) % p.B;
+  const int mg = p.mask_group > 0 ? p.mask_group : p.B;
+  const int b2 = (b / mg) * mg + ((b % mg) * p.H + h) % mg;
   const bool quirk = (p.mask_mode == MESM_MASK_T2V_QUIRK) && p.qpad && p.kpad;
   const bool dq_atomic = gridDim.y > 1;
 

@@ -32,6 +32,40 @@ struct XForm {
   int64_t lld;  // logical row length for the dropout index
 };
 
+// PReLU slope gradient: every workgroup stores ONE partial sum (plain store) into the workspace
+// slot of its linear block id and a 1-workgroup kernel adds them into the parameter gradient.
+// (One float atomic per wave on the single dslope address cost +45 us per GEMM: same-address
+// atomics serialise at the memory side.)
+__device__ __forceinline__ void dslope_store(const MesmGemmArgs& p, float part, float* sh4) {
+  part = wave_sum(part);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh4[wave] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int64_t bid = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    p.dslope_ws[bid] = sh4[0] + sh4[1] + sh4[2] + sh4[3];
+  }
+}
+
+__global__ __launch_bounds__(256) void dslope_reduce_kernel(const float* __restrict__ ws, int64_t n,
+                                                            float* __restrict__ dst) {
+  __shared__ float sh[4];
+  float a = 0.0f;
+  for (int64_t i = threadIdx.x; i < n; i += 256) a += ws[i];
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) dst[0] += sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+inline int dslope_finish(const MesmGemmArgs& a, dim3 grid, hipStream_t s) {
+  if (a.e_actgrad != MESM_ACT_PRELU || !a.dslope) return MESM_OK;
+  hipLaunchKernelGGL(dslope_reduce_kernel, dim3(1), dim3(256), 0, s, a.dslope_ws,
+                     (int64_t)grid.x * grid.y * grid.z, a.dslope);
+  return mesm_launch_status();
+}
+
 // One operand tile: ROWS (outer index) x BK (reduce index), staged through registers.
 // Loads are written branch-free so that every global load of a k-step is in flight before
 // the first wait: full tiles use unguarded vector loads (rows clamped with a select), the
@@ -194,7 +228,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const MesmGemmArgs p
 
   __shared__ __attribute__((aligned(16))) float As[2][BK * SA];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK * SB];
-  __shared__ float Red[WGK > 1 ? WGK * 16 * 64 : 1];  // partial tiles of the k-split waves
+  __shared__ float Red[WGK > 1 ? WGK * 16 * 64 : 4];  // partial tiles of the k-split waves
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -216,9 +250,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const MesmGemmArgs p
   const uint32_t seed_off = p.seed_offset ? *p.seed_offset : 0u;
   XForm xa, xb;
   xa.act = p.a_act; xa.slope = slope; xa.thresh = p.a_drop_p > 0.f ? mesm_drop_threshold(p.a_drop_p) : 0u;
-  xa.seed = p.a_drop_seed + seed_off; xa.inv_keep = 1.0f / (1.0f - p.a_drop_p); xa.lld = p.K;
+  xa.seed = p.a_drop_seed + seed_off; xa.inv_keep = 1.0f / (1.0f - p.a_drop_p);
+  xa.lld = LA == MESM_LAYOUT_REDUCE_CONTIG ? p.K : p.M;  // dropout index = dense index of the operand AS STORED
   xb.act = p.b_act; xb.slope = slope; xb.thresh = p.b_drop_p > 0.f ? mesm_drop_threshold(p.b_drop_p) : 0u;
-  xb.seed = p.b_drop_seed + seed_off; xb.inv_keep = 1.0f / (1.0f - p.b_drop_p); xb.lld = p.N;
+  xb.seed = p.b_drop_seed + seed_off; xb.inv_keep = 1.0f / (1.0f - p.b_drop_p);
+  xb.lld = LB == MESM_LAYOUT_REDUCE_CONTIG ? p.K : p.N;
 
   Tile<BM, BK, LA, VEC, ADD == 1> ta;
   Tile<BN, BK, LB, VEC, ADD == 2> tb;
@@ -280,8 +316,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const MesmGemmArgs p
     ta.template load<false>(p.A, p.A2, p.lda, m0, p.M, kbeg, kend, tid);
     tb.template load<false>(p.B, p.B2, p.ldb, n0, p.N, kbeg, kend, tid);
   }
-  ta.template finish<true>(xa, m0, kbeg, tid);
-  tb.template finish<false>(xb, n0, kbeg, tid);
+  ta.template finish<LA == MESM_LAYOUT_REDUCE_CONTIG>(xa, m0, kbeg, tid);
+  tb.template finish<LB == MESM_LAYOUT_REDUCE_CONTIG>(xb, n0, kbeg, tid);
   ta.store(As[0], SA, tid);
   tb.store(Bs[0], SB, tid);
   __syncthreads();
@@ -295,8 +331,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const MesmGemmArgs p
     tb.template load<true>(p.B, p.B2, p.ldb, n0, p.N, knext, kend, tid);
     __builtin_amdgcn_sched_barrier(0);  // keep the global loads ahead of the MFMA block
     compute(buf);
-    ta.template finish<true>(xa, m0, knext, tid);
-    tb.template finish<false>(xb, n0, knext, tid);
+    ta.template finish<LA == MESM_LAYOUT_REDUCE_CONTIG>(xa, m0, knext, tid);
+    tb.template finish<LB == MESM_LAYOUT_REDUCE_CONTIG>(xb, n0, knext, tid);
     ta.store(As[buf ^ 1], SA, tid);
     tb.store(Bs[buf ^ 1], SB, tid);
     __syncthreads();
@@ -308,8 +344,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const MesmGemmArgs p
     tb.template load<false>(p.B, p.B2, p.ldb, n0, p.N, knext, kend, tid);
     __builtin_amdgcn_sched_barrier(0);
     compute(buf);
-    ta.template finish<true>(xa, m0, knext, tid);
-    tb.template finish<false>(xb, n0, knext, tid);
+    ta.template finish<LA == MESM_LAYOUT_REDUCE_CONTIG>(xa, m0, knext, tid);
+    tb.template finish<LB == MESM_LAYOUT_REDUCE_CONTIG>(xb, n0, knext, tid);
     ta.store(As[buf ^ 1], SA, tid);
     tb.store(Bs[buf ^ 1], SB, tid);
     __syncthreads();
@@ -427,10 +463,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const MesmGemmArgs p
       }
     }
   }
-  if (p.e_actgrad == MESM_ACT_PRELU && p.dslope) {
-    dslope_part = wave_sum(dslope_part);
-    if (lane == 0 && dslope_part != 0.0f) atomicAdd(p.dslope, dslope_part);
-  }
+  if (p.e_actgrad == MESM_ACT_PRELU && p.dslope) dslope_store(p, dslope_part, Red);
 }
 
 template <int BM, int BN, int LA, int LB, int VEC, int ADD>
@@ -440,7 +473,8 @@ int launch(const MesmGemmArgs& a, hipStream_t s) {
   constexpr int BK = (BM == 128) ? 32 : 64;
   dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.split_k > 1 ? a.split_k : 1);
   hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, LA, LB, VEC, ADD>), grid, dim3(NTHREADS), 0, s, a);
-  return mesm_launch_status();
+  const int rc = mesm_launch_status();
+  return rc != MESM_OK ? rc : dslope_finish(a, grid, s);
 }
 
 template <int BM, int BN, int VEC, int ADD>
@@ -556,10 +590,7 @@ __device__ __forceinline__ void ksplit_epilogue(const MesmGemmArgs& p, const f32
       else *c = t;
     }
   }
-  if (p.e_actgrad == MESM_ACT_PRELU && p.dslope) {
-    dslope_part = wave_sum(dslope_part);
-    if (lane == 0 && dslope_part != 0.0f) atomicAdd(p.dslope, dslope_part);
-  }
+  if (p.e_actgrad == MESM_ACT_PRELU && p.dslope) dslope_store(p, dslope_part, Red);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -679,9 +710,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_frag_kernel(const MesmGemmArgs 
   const uint32_t seed_off = p.seed_offset ? *p.seed_offset : 0u;
   XForm xa, xb;
   xa.act = p.a_act; xa.slope = slope; xa.thresh = p.a_drop_p > 0.f ? mesm_drop_threshold(p.a_drop_p) : 0u;
-  xa.seed = p.a_drop_seed + seed_off; xa.inv_keep = 1.0f / (1.0f - p.a_drop_p); xa.lld = p.K;
+  xa.seed = p.a_drop_seed + seed_off; xa.inv_keep = 1.0f / (1.0f - p.a_drop_p);
+  xa.lld = LA == MESM_LAYOUT_REDUCE_CONTIG ? p.K : p.M;  // dropout index = dense index of the operand AS STORED
   xb.act = p.b_act; xb.slope = slope; xb.thresh = p.b_drop_p > 0.f ? mesm_drop_threshold(p.b_drop_p) : 0u;
-  xb.seed = p.b_drop_seed + seed_off; xb.inv_keep = 1.0f / (1.0f - p.b_drop_p); xb.lld = p.N;
+  xb.seed = p.b_drop_seed + seed_off; xb.inv_keep = 1.0f / (1.0f - p.b_drop_p);
+  xb.lld = LB == MESM_LAYOUT_REDUCE_CONTIG ? p.K : p.N;
 
   const int ra = m0 + li < p.M ? m0 + li : p.M - 1;
   const int rb = n0 + li < p.N ? n0 + li : p.N - 1;
@@ -697,8 +730,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_frag_kernel(const MesmGemmArgs 
 
   auto mma = [&](Frag<LA, ADD == 1>& a, Frag<LB, ADD == 2>& b, int kb) {
     if (XF) {
-      a.template finish<true>(xa, m0 + li, kb, h);
-      b.template finish<false>(xb, n0 + li, kb, h);
+      a.template finish<LA == MESM_LAYOUT_REDUCE_CONTIG>(xa, m0 + li, kb, h);
+      b.template finish<LB == MESM_LAYOUT_REDUCE_CONTIG>(xb, n0 + li, kb, h);
     }
 #pragma unroll
     for (int s = 0; s < FRAG_STEPS; ++s)
@@ -778,7 +811,8 @@ int launch_frag_add(const MesmGemmArgs& a, hipStream_t s) {
     else if (add == 1) hipLaunchKernelGGL((gemm_frag_kernel<LA, LB, 1, false>), grid, dim3(NTHREADS), 0, s, a);
     else hipLaunchKernelGGL((gemm_frag_kernel<LA, LB, 2, false>), grid, dim3(NTHREADS), 0, s, a);
   }
-  return mesm_launch_status();
+  const int rc = mesm_launch_status();
+  return rc != MESM_OK ? rc : dslope_finish(a, grid, s);
 }
 
 int launch_frag(const MesmGemmArgs& a, hipStream_t s) {
@@ -885,9 +919,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_wstage_kernel(const MesmGemmArg
   const uint32_t seed_off = p.seed_offset ? *p.seed_offset : 0u;
   XForm xa, xb;
   xa.act = p.a_act; xa.slope = slope; xa.thresh = p.a_drop_p > 0.f ? mesm_drop_threshold(p.a_drop_p) : 0u;
-  xa.seed = p.a_drop_seed + seed_off; xa.inv_keep = 1.0f / (1.0f - p.a_drop_p); xa.lld = p.K;
+  xa.seed = p.a_drop_seed + seed_off; xa.inv_keep = 1.0f / (1.0f - p.a_drop_p);
+  xa.lld = LA == MESM_LAYOUT_REDUCE_CONTIG ? p.K : p.M;  // dropout index = dense index of the operand AS STORED
   xb.act = p.b_act; xb.slope = slope; xb.thresh = p.b_drop_p > 0.f ? mesm_drop_threshold(p.b_drop_p) : 0u;
-  xb.seed = p.b_drop_seed + seed_off; xb.inv_keep = 1.0f / (1.0f - p.b_drop_p); xb.lld = p.N;
+  xb.seed = p.b_drop_seed + seed_off; xb.inv_keep = 1.0f / (1.0f - p.b_drop_p);
+  xb.lld = LB == MESM_LAYOUT_REDUCE_CONTIG ? p.K : p.N;
 
   float* mine = L + wave * (2 * 2 * WS_SLAB);
   auto issue = [&](int st) {
@@ -936,11 +972,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_wstage_kernel(const MesmGemmArg
           const int gk = kb + 8 * s_ + 4 * h + j;
           float x = mesm_act(a[s_][j], xa.act, xa.slope);
           if (xa.thresh)
-            x = mesm_dropout_apply(x, (uint32_t)((int64_t)(m0 + li) * xa.lld + gk), xa.seed, xa.thresh, xa.inv_keep);
+            x = mesm_dropout_apply(x, (uint32_t)(LA == MESM_LAYOUT_REDUCE_CONTIG ? (int64_t)(m0 + li) * xa.lld + gk : (int64_t)gk * xa.lld + m0 + li),
+                                   xa.seed, xa.thresh, xa.inv_keep);
           a[s_][j] = x;
           float y = mesm_act(b[s_][j], xb.act, xb.slope);
           if (xb.thresh)
-            y = mesm_dropout_apply(y, (uint32_t)((int64_t)gk * xb.lld + n0 + li), xb.seed, xb.thresh, xb.inv_keep);
+            y = mesm_dropout_apply(y, (uint32_t)(LB == MESM_LAYOUT_REDUCE_CONTIG ? (int64_t)(n0 + li) * xb.lld + gk : (int64_t)gk * xb.lld + n0 + li),
+                                   xb.seed, xb.thresh, xb.inv_keep);
           b[s_][j] = y;
         }
     }
@@ -972,7 +1010,8 @@ int launch_wstage_l(const MesmGemmArgs& a, hipStream_t s) {
   const bool xf = a.a_act != MESM_ACT_NONE || a.b_act != MESM_ACT_NONE || a.a_drop_p > 0.f || a.b_drop_p > 0.f;
   if (xf) hipLaunchKernelGGL((gemm_wstage_kernel<LA, LB, true>), grid, dim3(NTHREADS), 0, s, a);
   else hipLaunchKernelGGL((gemm_wstage_kernel<LA, LB, false>), grid, dim3(NTHREADS), 0, s, a);
-  return mesm_launch_status();
+  const int rc = mesm_launch_status();
+  return rc != MESM_OK ? rc : dslope_finish(a, grid, s);
 }
 
 int launch_wstage(const MesmGemmArgs& a, hipStream_t s) {
@@ -1030,6 +1069,7 @@ extern "C" int mesm_gemm_f32(const MesmGemmArgs* args, void* stream) {
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return MESM_EINVAL;
   if (a.a_layout < 0 || a.a_layout > 1 || a.b_layout < 0 || a.b_layout > 1) return MESM_EINVAL;
   if (a.e_actgrad != MESM_ACT_NONE && !a.aux) return MESM_EINVAL;
+  if (a.e_actgrad == MESM_ACT_PRELU && a.dslope && !a.dslope_ws) return MESM_EINVAL;
   if ((a.a_act == MESM_ACT_PRELU || a.b_act == MESM_ACT_PRELU || a.e_act == MESM_ACT_PRELU ||
        a.e_actgrad == MESM_ACT_PRELU) && !a.slope)
     return MESM_EINVAL;

@@ -94,6 +94,10 @@ def gemm(A, B, C, *, trans_a=False, trans_b=False, A2=None, B2=None, bias=None, 
         g.slope = slope.data_ptr()
     if dslope is not None:
         g.dslope = dslope.data_ptr()
+        # one partial per workgroup of the finest tiling; stream-ordered scratch
+        ws = torch.empty(((M + 31) // 32) * ((N + 31) // 32) * max(int(split_k), 1), device=C.device,
+                         dtype=torch.float32)
+        g.dslope_ws = ws.data_ptr()
     if colsum is not None:
         assert colsum.numel() == M
         g.colsum = colsum.data_ptr()
@@ -147,7 +151,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx=None, accumulate_d
     return dx2.view(x.shape)
 
 
-def _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop):
+def _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop, group=0):
     B, Lq, Eq = q.shape
     _, Lk, Ek = k.shape
     Ev = v.shape[2]
@@ -174,10 +178,11 @@ def _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop):
     a.scale = float(scale)
     a.drop_p, a.drop_seed = float(drop[0]), int(drop[1]) & 0xFFFFFFFF
     a.seed_offset = _seed_off_ptr()
+    a.mask_group = int(group)
     return a
 
 
-def attn_fwd(q, k, v, H, kpad=None, qpad=None, scale=None, drop=(0.0, 0)):
+def attn_fwd(q, k, v, H, kpad=None, qpad=None, scale=None, drop=(0.0, 0), group=0):
     """q (B,Lq,H*dk), k (B,Lk,H*dk), v (B,Lk,H*dv) -> o (B,Lq,H*dv), lse (B,H,Lq)."""
     require_gpu(q, k, v)
     B, Lq, Eq = q.shape
@@ -185,12 +190,12 @@ def attn_fwd(q, k, v, H, kpad=None, qpad=None, scale=None, drop=(0.0, 0)):
         scale = (Eq // H) ** -0.5
     o = torch.empty(B, Lq, v.shape[2], device=q.device, dtype=torch.float32)
     lse = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32)
-    a = _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop)
+    a = _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop, group)
     check(lib().mesm_attn_fwd(ctypes.byref(a), stream_ptr()), "mesm_attn_fwd")
     return o, lse
 
 
-def attn_bwd(do, q, k, v, o, lse, H, kpad=None, qpad=None, scale=None, drop=(0.0, 0)):
+def attn_bwd(do, q, k, v, o, lse, H, kpad=None, qpad=None, scale=None, drop=(0.0, 0), group=0):
     require_gpu(do, q, k, v, o, lse)
     B, Lq, Eq = q.shape
     if scale is None:
@@ -204,14 +209,14 @@ def attn_bwd(do, q, k, v, o, lse, H, kpad=None, qpad=None, scale=None, drop=(0.0
     qc, kc, vc = q, k, v
     # gradients are written with the strides of q/k/v: require the packed layout
     assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
-    a = _attn_args(qc, kc, vc, o, lse, H, kpad, qpad, scale, drop)
+    a = _attn_args(qc, kc, vc, o, lse, H, kpad, qpad, scale, drop, group)
     a.d_o, a.dq, a.dk_, a.dv_ = do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
     check(lib().mesm_attn_bwd(ctypes.byref(a), stream_ptr()), "mesm_attn_bwd")
     return dq, dk, dv
 
 
 def attn_bwd_into(do, q, k, v, o, lse, H, dq, dk, dv, kpad=None, qpad=None, scale=None,
-                  drop=(0.0, 0)):
+                  drop=(0.0, 0), group=0):
     """attn_bwd writing into caller-provided gradient tensors whose strides equal those of
     q / k / v (e.g. column slices of one fused [dq|dk|dv] buffer).  dq must be zero-initialised
     when Lk > 64 (several key tiles add into it atomically)."""
@@ -220,7 +225,7 @@ def attn_bwd_into(do, q, k, v, o, lse, H, dq, dk, dv, kpad=None, qpad=None, scal
         scale = (q.shape[-1] // H) ** -0.5
     assert do.stride() == o.stride()
     assert dq.stride() == q.stride() and dk.stride() == k.stride() and dv.stride() == v.stride()
-    a = _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop)
+    a = _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop, group)
     a.d_o, a.dq, a.dk_, a.dv_ = do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
     check(lib().mesm_attn_bwd(ctypes.byref(a), stream_ptr()), "mesm_attn_bwd")
 

@@ -117,11 +117,11 @@ class T2VLayer(nn.Module):
         self.nhead = h
         self.p = dropout
 
-    def forward(self, txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm=False):
+    def forward(self, txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm=False, group=0):
         sa = self.self_attn
         x = ops.mha(vid, pos_vid, txt, pos_txt, vid, sa.in_proj_weight, sa.in_proj_bias,
                     sa.out_proj.weight, sa.out_proj.bias, self.nhead, kpad=txt_pad, qpad=vid_pad,
-                    attn_drop=drop_state.next(self.p), out_drop=drop_state.next(self.p))
+                    attn_drop=drop_state.next(self.p), out_drop=drop_state.next(self.p), group=group)
         alt = self.two_mlp and is_mlm
         n1, n2 = (self.norm1_1, self.norm2_1) if alt else (self.norm1, self.norm2)
         l1, l2 = (self.linear1_1, self.linear2_1) if alt else (self.linear1, self.linear2)
@@ -141,9 +141,9 @@ class T2VStack(nn.Module):
         super().__init__()
         self.layers = _clones(layer, n)
 
-    def forward(self, txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm=False):
+    def forward(self, txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm=False, group=0):
         for l in self.layers:
-            vid = l(txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm)
+            vid = l(txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm, group)
         return vid
 
 
@@ -162,8 +162,10 @@ class T2VEncoder(nn.Module):
         _xavier_(self)
         self.d_model, self.nhead = d, h
 
-    def forward(self, txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm=False):
-        return self.t2v_encoder(txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm)
+    def forward(self, txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm=False, group=0):
+        """group: rows per independent batch when the positive and the negative pass are stacked
+        along the batch dimension (the Q1 mask rule wraps inside a group)."""
+        return self.t2v_encoder(txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm, group)
 
 
 class EncoderLayer(nn.Module):
@@ -318,9 +320,11 @@ class Transformer(nn.Module):
         self.dim_feedforward, self.dropout = ff, dropout
         self.num_queries = num_queries
 
-    def forward(self, src, vid_pad, query_embed, pos, g_tok, g_pos, run_decoder=True):
+    def forward(self, src, vid_pad, query_embed, pos, g_tok, g_pos, run_decoder=True, n_dec=None):
         """src (N, L, d); vid_pad (N, L) True = padding.  The global token is prepended as a
-        MASKED key (transformer.py:185-186): it pools, nobody attends to it."""
+        MASKED key (transformer.py:185-186): it pools, nobody attends to it.  n_dec: only the first
+        n_dec rows of the batch go through the decoder (the negative pass stacked behind them
+        stops after the encoder: its decoder output is discarded at model.py:295)."""
         n = src.shape[0]
         d = self.d_model
         x = torch.cat([g_tok.view(1, 1, d).expand(n, 1, d), src], 1)
@@ -330,5 +334,9 @@ class Transformer(nn.Module):
         mem_g, mem_l = mem[:, 0], mem[:, 1:]
         if not run_decoder:
             return None, None, mem_l, mem_g
-        hs, refs = self.decoder(mem_l.contiguous(), vid_pad, pos, query_embed)
+        if n_dec is None or n_dec == n:
+            hs, refs = self.decoder(mem_l.contiguous(), vid_pad, pos, query_embed)
+        else:
+            hs, refs = self.decoder(mem_l[:n_dec].contiguous(), vid_pad[:n_dec].contiguous(),
+                                    pos[:n_dec].contiguous(), query_embed)
         return hs, refs, mem_l, mem_g

@@ -120,21 +120,12 @@ class MESM(nn.Module):
                                                 transformer.dim_feedforward, transformer.dropout)
         self._gradbuf = None
         self._step = 0
-        # run the positive pass and the SS + negative pass on two HIP streams (see forward)
-        self.two_streams = os.environ.get("MESM_TWO_STREAMS", "1") != "0"
-        self._side = {}
 
     # ------------------------------------------------------------------ infrastructure
     def gradbuf(self):
         if self._gradbuf is None:
             self._gradbuf = GradBuffer([(n, p) for n, p in self.named_parameters() if p.requires_grad])
         return self._gradbuf
-
-    def _side_stream(self, device):
-        st = self._side.get(device)
-        if st is None:
-            st = self._side[device] = torch.cuda.Stream(device=device)
-        return st
 
     def _begin(self, device, is_training):
         if not device.type == "cuda":
@@ -290,33 +281,30 @@ class MESM(nn.Module):
             pw = self._proj(self.input_txt_proj, words)
             vpos = kn.sine_pos(video_mask, d)
 
-        # Two HIP streams from here on (kernels of this size leave most CUs idle; two independent
-        # chains overlap ~1.6x, tools/probe_graph_par.py):
-        #   main: enhance(pos) -> [SS done] -> t2v(pos) -> encoder -> decoder -> heads -> MLM branch
-        #   side: SS reconstruction -> enhance(neg) -> t2v(neg) -> encoder(neg)
-        # Autograd replays every backward block on the stream of its forward, so the backward pass
-        # overlaps the same way.  Under graph capture the fork/join become graph edges.
-        main = torch.cuda.current_stream()
-        side = self._side_stream(dev) if self.two_streams else main
-        forked = side is not main
-
-        def hand(ts, to):
-            """tensors made on one stream and read on the other: tell the caching allocator"""
-            if forked:
-                for t_ in ts:
-                    if t_ is not None:
-                        t_.record_stream(to)
-
-        if forked:
-            side.wait_stream(main)
-            hand([pv, pw, vpos, vid_pad, words_pad, words_mask, sent, words, video_feat], side)
-
+        # The positive and the negative pass (model.py:260-299) run the SAME weights over the same
+        # video with different queries: they are stacked along the batch (rows [0, N) positive,
+        # [N, 2N) negative) so every layer is one launch over 2N rows instead of two over N --
+        # these kernels are far too small to fill 256 CUs, so rows are what buys efficiency.
+        # The Q1 mask rule wraps inside each group of N rows (group=N).  The decoder runs on the
+        # positive half only: the reference discards the negative decoder output (model.py:295).
         enc = self.enhance_encoder
+        ni = plan.neg_index
+        two = lambda t_: torch.cat([t_, t_], 0)
+        pv2, vpos2, vid_pad2 = two(pv), two(vpos), two(vid_pad)
         with _scope("enhance"):
-            enhanced = enc(pw, pv, None, vpos, words_pad, vid_pad) if self.rec_fw else pv
+            if self.rec_fw:
+                # neg_words_feat = expanded_words_feat[neg_index][:, 1:] = projected words of the
+                # negative query (the SS token is stripped again, model.py:264-266)
+                pw2 = torch.cat([pw, ops.gather_rows(pw.reshape(N, -1), ni).view(N, -1, d)], 0)
+                wpad2 = torch.cat([words_pad, words_pad[ni]], 0)
+                enhanced2 = enc(pw2, pv2, None, vpos2, wpad2, vid_pad2, group=N)
+                enhanced = enhanced2[:N]
+            else:
+                enhanced2 = pv2
+                enhanced = pv
 
         out = {}
-        with torch.cuda.stream(side), _scope("ss"):
+        with _scope("ss"):
             if self.rec_ss:
                 if plan.vid_src is not None:
                     bvid = video_feat.reshape(N * Lv, -1)[plan.vid_src] * plan.vid_mask.unsqueeze(-1)
@@ -337,46 +325,25 @@ class MESM(nn.Module):
             else:
                 ewords, emask = pw, words_mask
             epad = (~emask).contiguous()
-        if forked:
-            ss_done = torch.cuda.Event()
-            ss_done.record(side)
-            main.wait_event(ss_done)
-            hand([ewords, emask, epad] + ([recon, projed_recon] if self.rec_ss else []), main)
-
-        # negative pass (model.py:260-299) on the side stream; decoder skipped: its outputs are
-        # discarded at :295
-        with torch.cuda.stream(side), _scope("neg"):
-            ni = plan.neg_index
-            n_ewords = ops.gather_rows(ewords.reshape(N, -1), ni).view(N, ewords.shape[1], d)
-            n_emask = emask[ni]
-            if self.rec_ss:
-                n_words, n_wpad = n_ewords[:, 1:], (~n_emask[:, 1:]).contiguous()
-            else:
-                n_words, n_wpad = n_ewords, (~n_emask).contiguous()
-            n_enh = enc(n_words, pv, None, vpos, n_wpad, vid_pad) if self.rec_fw else pv
-            n_enc = self.t2v_encoder(n_ewords, n_enh, None, vpos, (~n_emask).contiguous(), vid_pad)
-            _, _, n_memory, n_memory_g = self.transformer(n_enc, vid_pad, self.query_embed.weight, vpos,
-                                                          self.global_rep_token, self.global_rep_pos,
-                                                          run_decoder=False)
-            n_memory = n_memory.contiguous()
-            n_memory_g = n_memory_g.contiguous()
 
         with _scope("t2v"):
-            encoded = self.t2v_encoder(ewords, enhanced, None, vpos, epad, vid_pad)
+            ewords2 = torch.cat([ewords, ops.gather_rows(ewords.reshape(N, -1), ni).view(N, -1, d)], 0)
+            epad2 = torch.cat([epad, epad[ni]], 0)
+            encoded2 = self.t2v_encoder(ewords2, enhanced2, None, vpos2, epad2, vid_pad2, group=N)
         with _scope("transformer"):
-            hs, refs, memory, memory_g = self.transformer(encoded, vid_pad, self.query_embed.weight, vpos,
-                                                          self.global_rep_token, self.global_rep_pos)
+            hs, refs, memory2, memory_g2 = self.transformer(
+                encoded2, vid_pad2, self.query_embed.weight, vpos2, self.global_rep_token,
+                self.global_rep_pos, n_dec=N)
         with _scope("heads"):
             logits = ops.linear(hs, self.class_embed.weight, self.class_embed.bias)
             spans = torch.sigmoid(self.span_embed(hs) + inverse_sigmoid(refs))
-
-        def saliency(mem, mem_g):
-            a = ops.linear(mem, self.saliency_proj1.weight, self.saliency_proj1.bias)
-            b = ops.linear(mem_g, self.saliency_proj2.weight, self.saliency_proj2.bias)
-            return ops.rowdot(a, b, 1.0 / float(np.sqrt(d)))
+            # saliency scores (model.py:301-302) for both passes in one go
+            sa = ops.linear(memory2, self.saliency_proj1.weight, self.saliency_proj1.bias)
+            sb = ops.linear(memory_g2, self.saliency_proj2.weight, self.saliency_proj2.bias)
+            sal2 = ops.rowdot(sa, sb, 1.0 / float(np.sqrt(d)))
 
         out.update({"pred_logits": logits[-1], "pred_spans": spans[-1],
-                    "saliency_scores": saliency(memory, memory_g)})
+                    "saliency_scores": sal2[:N], "neg_saliency_scores": sal2[N:]})
         if self.aux_loss:
             out["aux_outputs"] = [{"pred_logits": a, "pred_spans": b} for a, b in zip(logits[:-1], spans[:-1])]
 
@@ -394,11 +361,6 @@ class MESM(nn.Module):
                 head = self.output_txt_proj[1]
                 out["recfw_words_logit"] = ops.linear(hid, head.weight, head.bias)
                 out["words_mask"] = words_mask
-
-        if forked:  # join: everything below reads the negative pass
-            main.wait_stream(side)
-            hand([n_memory, n_memory_g], main)
-        out["neg_saliency_scores"] = saliency(n_memory, n_memory_g)
         if self.rec_ss:
             out.update({"projed_video_feat": pv, "recon_feat": recon, "projed_recon_feat": projed_recon,
                         "expanded_words_feat": ewords, "expanded_words_mask": emask,

@@ -255,7 +255,7 @@ class MHAFn(Function):
 
     @staticmethod
     def forward(ctx, xq, pq, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad, qpad, attn_drop,
-                out_drop, self_attn):
+                out_drop, self_attn, group=0):
         xq = _c(xq)
         pq = _c(pq) if pq is not None else None
         d = xq.shape[-1]
@@ -285,20 +285,20 @@ class MHAFn(Function):
                 kn.gemm(_2d(xk), w_in[d:2 * d], kv2[:, :d], trans_b=True, A2=_2d(pk), bias=b_in[d:2 * d])
                 kn.gemm(_2d(xk), w_in[2 * d:], kv2[:, d:], trans_b=True, bias=b_in[2 * d:])
             k, v = kv[..., :d], kv[..., d:]
-        o, lse = kn.attn_fwd(q, k, v, H, kpad=kpad, qpad=qpad, drop=attn_drop)
+        o, lse = kn.attn_fwd(q, k, v, H, kpad=kpad, qpad=qpad, drop=attn_drop, group=group)
         out = torch.empty(N, Lq, d, device=dev, dtype=torch.float32)
         kn.gemm(_2d(o), w_out, _2d(out), trans_b=True, bias=b_out, e_drop=out_drop,
                 residual=_2d(_c(residual)) if residual is not None else None)
         ctx.save_for_backward(xq, pq, xk, pk, q, k, v, o, lse)
         ctx.params = (w_in, b_in, w_out, b_out)
-        ctx.cfg = (H, kpad, qpad, attn_drop, out_drop, self_attn, residual is not None)
+        ctx.cfg = (H, kpad, qpad, attn_drop, out_drop, self_attn, residual is not None, group)
         return out
 
     @staticmethod
     def backward(ctx, dy):
         xq, pq, xk, pk, q, k, v, o, lse = ctx.saved_tensors
         w_in, b_in, w_out, b_out = ctx.params
-        H, kpad, qpad, attn_drop, out_drop, self_attn, has_res = ctx.cfg
+        H, kpad, qpad, attn_drop, out_drop, self_attn, has_res, group = ctx.cfg
         d = xq.shape[-1]
         N, Lq = xq.shape[0], xq.shape[1]
         dev = xq.device
@@ -318,7 +318,7 @@ class MHAFn(Function):
         if self_attn:
             dqkv = torch.zeros(N, Lq, 3 * d, device=dev, dtype=torch.float32)
             kn.attn_bwd_into(do, q, k, v, o, lse, H, dqkv[..., :d], dqkv[..., d:2 * d],
-                             dqkv[..., 2 * d:], kpad=kpad, qpad=qpad, drop=attn_drop)
+                             dqkv[..., 2 * d:], kpad=kpad, qpad=qpad, drop=attn_drop, group=group)
             g2 = _2d(dqkv)
             _accum_dw(g2[:, :2 * d], _2d(xq), gwi[:2 * d], gbi[:2 * d],
                       x2=_2d(pq) if pq is not None else None)
@@ -336,7 +336,7 @@ class MHAFn(Function):
             dq = torch.zeros(N, Lq, d, device=dev, dtype=torch.float32)
             dkv = torch.empty(N, Lk, 2 * d, device=dev, dtype=torch.float32)
             kn.attn_bwd_into(do, q, k, v, o, lse, H, dq, dkv[..., :d], dkv[..., d:], kpad=kpad,
-                             qpad=qpad, drop=attn_drop)
+                             qpad=qpad, drop=attn_drop, group=group)
             _accum_dw(_2d(dq), _2d(xq), gwi[:d], gbi[:d], x2=_2d(pq) if pq is not None else None)
             g2 = _2d(dkv)
             if pk is None:
@@ -363,13 +363,14 @@ class MHAFn(Function):
         flush_ready()
         return (dxq, dpq, dxk, dpk, dy if has_res and ctx.needs_input_grad[4] else None,
                 None if d_wi else gwi, None if d_bi else gbi, None if d_wo else gwo,
-                None if d_bo else gbo, None, None, None, None, None, None)
+                None if d_bo else gbo, None, None, None, None, None, None, None)
 
 
 def mha(xq, pq, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad=None, qpad=None,
-        attn_drop=NO_DROP, out_drop=NO_DROP, self_attn=False):
+        attn_drop=NO_DROP, out_drop=NO_DROP, self_attn=False, group=0):
+    """group: rows per independent batch when several batches are stacked (mask quirk Q1)."""
     return MHAFn.apply(xq, pq, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad, qpad, attn_drop,
-                       out_drop, self_attn)
+                       out_drop, self_attn, group)
 
 
 # ----------------------------------------------------------------------------- sine embeddings

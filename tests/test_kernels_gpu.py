@@ -144,6 +144,32 @@ def test_gemm_dropout_matches_materialised_mask():
     full = (dY.double() @ W.double())
     mask = (Xd != 0).double() * 2.0
     assert rel_err(dX, full * mask) < TOL
+
+
+@pytest.mark.parametrize("tile", ["0", "1", "2", "32", "64"])
+@pytest.mark.parametrize("M,N,K", [(2400, 256, 256), (190, 132, 300)])
+def test_gemm_operand_dropout_uses_the_stored_index(tile, M, N, K, monkeypatch):
+    """The mask an epilogue wrote on Y (index row*N + col) is replayed when dY is an operand:
+    as A of dX = drop(dY) @ W and as A^T of dW = drop(dY)^T @ X (+ the bias column sums)."""
+    from mesm_amd import kernels as kn
+    monkeypatch.setenv("MESM_GEMM_TILE", tile)
+    dY = gen((M, N), 40)
+    W = gen((N, K), 41)
+    X = gen((M, K), 42)
+    dYd = kn.dropout(dY, 0.1, 1234)
+    dX = torch.empty(M, K, device=dev())
+    kn.gemm(dY, W, dX, a_drop=(0.1, 1234))
+    assert rel_err(dX, dYd.double() @ W.double()) < TOL
+    dW = torch.zeros(N, K, device=dev())
+    db = torch.zeros(N, device=dev())
+    kn.gemm(dY, X, dW, trans_a=True, a_drop=(0.1, 1234), colsum=db, split_k=4, accumulate=2)
+    assert rel_err(dW, dYd.t().double() @ X.double()) < TOL
+    assert rel_err(db, dYd.double().sum(0)) < TOL
+    # and operand B stored (N, K) (trans_b): index n*K + k
+    Wd = kn.dropout(W, 0.1, 99)
+    C = torch.empty(M, N, device=dev())
+    kn.gemm(X, W, C, trans_b=True, b_drop=(0.1, 99))
+    assert rel_err(C, X.double() @ Wd.t().double()) < TOL
     # prelu + dropout on A together
     slope = torch.tensor([0.1], device=dev())
     Z = gen((M, K), 21)
