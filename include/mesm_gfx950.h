@@ -146,13 +146,18 @@ int mesm_gemm_tape_replay(void* stream, int32_t reps, double* total_ms, int64_t*
  * fwd writes y, and mean/rstd (rows) for the backward.
  * bwd writes dx (or dx += if accumulate) and atomically accumulates dgamma/dbeta;
  * dx == NULL (input needs no gradient) runs the parameter-gradient reduction only.
+ * drop_p > 0 fuses the Dropout that follows the LayerNorm in LinearLayer (model.py:421-431):
+ * fwd writes dropout(LN(x)) (keep iff hash(seed, row*D + col) >= p, scaled 1/(1-p)) and bwd
+ * applies the same mask to dy while loading it.
  */
 int mesm_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
                        float* mean, float* rstd, int64_t rows, int32_t D, float eps,
+                       float drop_p, uint32_t drop_seed, const uint32_t* seed_offset,
                        void* stream);
 int mesm_layernorm_bwd(const float* dy, const float* x, const float* gamma,
                        const float* mean, const float* rstd, float* dx, float* dgamma,
                        float* dbeta, int64_t rows, int32_t D, int32_t accumulate_dx,
+                       float drop_p, uint32_t drop_seed, const uint32_t* seed_offset,
                        void* stream);
 
 /* ------------------------------------------------------------------------- */
@@ -245,6 +250,13 @@ int mesm_query_sine_bwd(const float* ref, const float* dout, float* dref, int64_
  */
 int mesm_dropout(const float* x, float* y, int64_t n, float p, uint32_t seed,
                  const uint32_t* seed_offset, void* stream);
+
+/*
+ * y = dropout(act(x)), flat index = element index (n % 4 == 0, 16-byte aligned): the FFN hidden
+ * activation dropout(PReLU(linear1(.))) of transformer.py:537,603,608,647,794 written once.
+ */
+int mesm_act_dropout(const float* x, float* y, int64_t n, int32_t act, const float* slope, float p,
+                     uint32_t seed, const uint32_t* seed_offset, void* stream);
 
 /*
  * Activation backward + bias gradient: dz = dy * act'(ref), dbias[c] += sum_rows dz,

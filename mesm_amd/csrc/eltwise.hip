@@ -96,6 +96,26 @@ __global__ __launch_bounds__(256) void dropout_kernel(const float* __restrict__ 
     y[i] = mesm_dropout_apply(x[i], (uint32_t)i, seed, thresh, inv_keep);
 }
 
+// y = dropout(act(x)): the FFN hidden activation, materialised once (transformer.py:537: as an
+// operand transform of linear2 and of its dW GEMM it was recomputed by every output tile)
+__global__ __launch_bounds__(256) void act_dropout_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                         int64_t n4, int act, const float* __restrict__ slope_p,
+                                                         uint32_t thresh, float inv_keep, uint32_t seed,
+                                                         const uint32_t* __restrict__ seed_offset) {
+  if (seed_offset) seed += *seed_offset;
+  const float slope = slope_p ? *slope_p : 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[e] = mesm_act(o[e], act, slope);
+      if (thresh) o[e] = mesm_dropout_apply(o[e], (uint32_t)(4 * i + e), seed, thresh, inv_keep);
+    }
+    reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 constexpr int AB_ROWS = 32;  // rows per workgroup
 
 __global__ __launch_bounds__(256) void act_bias_bwd_kernel(
@@ -183,5 +203,18 @@ extern "C" int mesm_act_bias_bwd(const float* dy, const float* ref, float* dz, f
   return mesm_launch_status();
 }
 
-extern "C" int mesm_abi_version(void) { return 3; }
+extern "C" int mesm_act_dropout(const float* x, float* y, int64_t n, int32_t act, const float* slope,
+                                float p, uint32_t seed, const uint32_t* seed_offset, void* stream) {
+  if (!x || !y || n <= 0 || (n & 3) || p < 0.f || p >= 1.f) return MESM_EINVAL;
+  if (act == MESM_ACT_PRELU && !slope) return MESM_EINVAL;
+  if (((uintptr_t)x | (uintptr_t)y) & 15) return MESM_EALIGN;
+  const int64_t n4 = n / 4;
+  int64_t blocks = (n4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(act_dropout_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, n4,
+                     act, slope, p > 0.f ? mesm_drop_threshold(p) : 0u, 1.0f / (1.0f - p), seed, seed_offset);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_abi_version(void) { return 4; }
 extern "C" const char* mesm_arch(void) { return "gfx950"; }

@@ -10,6 +10,24 @@ namespace {
 constexpr int LN_THREADS = 256;
 constexpr int LN_WAVES = LN_THREADS / 64;
 
+// optional dropout fused behind the normalisation (LinearLayer: LN -> Dropout -> Linear,
+// model.py:421-431): the forward writes dropout(LN(x)), the backward masks dy while loading it.
+struct LnDrop {
+  uint32_t thresh;  // 0 = off
+  uint32_t seed;
+  float inv_keep;
+  const uint32_t* seed_offset;
+};
+
+inline LnDrop make_drop(float p, uint32_t seed, const uint32_t* seed_offset) {
+  LnDrop d;
+  d.thresh = p > 0.f ? mesm_drop_threshold(p) : 0u;
+  d.seed = seed;
+  d.inv_keep = 1.0f / (1.0f - p);
+  d.seed_offset = seed_offset;
+  return d;
+}
+
 template <int VEC>
 __device__ __forceinline__ void ld_vec(const float* __restrict__ p, float* d) {
   if (VEC == 4) {
@@ -34,11 +52,12 @@ template <int VEC, int NCH>
 __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ y, float* __restrict__ mean,
-    float* __restrict__ rstd, int64_t rows, int D, float eps) {
+    float* __restrict__ rstd, int64_t rows, int D, float eps, LnDrop dr) {
   const int lane = threadIdx.x & 63;
   const int64_t wave_global = (int64_t)blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * LN_WAVES;
   const float invD = 1.0f / (float)D;
+  const uint32_t dseed = dr.seed + (dr.seed_offset ? *dr.seed_offset : 0u);
   for (int64_t row = wave_global; row < rows; row += nwaves) {
     const float* xr = x + row * D;
     float v[NCH][VEC];
@@ -79,7 +98,10 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
         ld_vec<VEC>(gamma + col, g);
         ld_vec<VEC>(beta + col, b);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) o[e] = (v[c][e] - mu) * rs * g[e] + b[e];
+        for (int e = 0; e < VEC; ++e) {
+          o[e] = (v[c][e] - mu) * rs * g[e] + b[e];
+          if (dr.thresh) o[e] = mesm_dropout_apply(o[e], (uint32_t)(row * D + col + e), dseed, dr.thresh, dr.inv_keep);
+        }
         st_vec<VEC>(yr + col, o);
       }
     }
@@ -95,8 +117,9 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x,
     const float* __restrict__ gamma, const float* __restrict__ mean,
     const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ dgamma,
-    float* __restrict__ dbeta, int64_t rows, int D, int accumulate_dx) {
+    float* __restrict__ dbeta, int64_t rows, int D, int accumulate_dx, LnDrop dr) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // LN_WAVES * D when LDS_REDUCE
+  const uint32_t dseed = dr.seed + (dr.seed_offset ? *dr.seed_offset : 0u);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int64_t wave_global = (int64_t)blockIdx.x * LN_WAVES + wave;
@@ -129,6 +152,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
         ld_vec<VEC>(dyr + col, dv[c]);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
+          if (dr.thresh) dv[c][e] = mesm_dropout_apply(dv[c][e], (uint32_t)(row * D + col + e), dseed, dr.thresh, dr.inv_keep);
           xh[c][e] = (xv[e] - mu) * rs;
           float dyg = dv[c][e] * g[c][e];
           s1 += dyg * xh[c][e];
@@ -201,14 +225,16 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
 __global__ __launch_bounds__(256) void ln_bwd_params_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
     const float* __restrict__ rstd, float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows,
-    int D, int rows_per_block) {
+    int D, int rows_per_block, LnDrop dr) {
   const int col = blockIdx.x * 256 + threadIdx.x;
   if (col >= D) return;
+  const uint32_t dseed = dr.seed + (dr.seed_offset ? *dr.seed_offset : 0u);
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
   float dg = 0.0f, db = 0.0f;
   for (int64_t r = r0; r < r1; ++r) {
-    const float d = dy[r * D + col];
+    float d = dy[r * D + col];
+    if (dr.thresh) d = mesm_dropout_apply(d, (uint32_t)(r * D + col), dseed, dr.thresh, dr.inv_keep);
     dg += d * (x[r * D + col] - mean[r]) * rstd[r];
     db += d;
   }
@@ -230,29 +256,29 @@ inline int pick_vec(int D, const void* a, const void* b, const void* c, const vo
 
 template <int VEC, int NCH>
 int fwd_launch(const float* x, const float* gamma, const float* beta, float* y, float* mean,
-               float* rstd, int64_t rows, int D, float eps, hipStream_t s) {
+               float* rstd, int64_t rows, int D, float eps, LnDrop dr, hipStream_t s) {
   int64_t blocks = (rows + LN_WAVES - 1) / LN_WAVES;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL((ln_fwd_kernel<VEC, NCH>), dim3((unsigned)blocks), dim3(LN_THREADS), 0, s, x,
-                     gamma, beta, y, mean, rstd, rows, D, eps);
+                     gamma, beta, y, mean, rstd, rows, D, eps, dr);
   return mesm_launch_status();
 }
 
 template <int VEC, int NCH>
 int bwd_launch(const float* dy, const float* x, const float* gamma, const float* mean,
                const float* rstd, float* dx, float* dgamma, float* dbeta, int64_t rows, int D,
-               int acc, hipStream_t s) {
+               int acc, LnDrop dr, hipStream_t s) {
   int64_t blocks = (rows + LN_WAVES - 1) / LN_WAVES;
   if (D <= 1024) {
     if (blocks > 128) blocks = 128;
     size_t lds = (size_t)LN_WAVES * D * sizeof(float);
     hipLaunchKernelGGL((ln_bwd_kernel<VEC, NCH, true>), dim3((unsigned)blocks), dim3(LN_THREADS),
-                       lds, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, acc);
+                       lds, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, acc, dr);
   } else {
     if (blocks > 64) blocks = 64;
     hipLaunchKernelGGL((ln_bwd_kernel<VEC, NCH, false>), dim3((unsigned)blocks),
                        dim3(LN_THREADS), 0, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows,
-                       D, acc);
+                       D, acc, dr);
   }
   return mesm_launch_status();
 }
@@ -274,24 +300,30 @@ int bwd_launch(const float* dy, const float* x, const float* gamma, const float*
 
 extern "C" int mesm_layernorm_fwd(const float* x, const float* gamma, const float* beta,
                                   float* y, float* mean, float* rstd, int64_t rows, int32_t D,
-                                  float eps, void* stream) {
+                                  float eps, float drop_p, uint32_t drop_seed,
+                                  const uint32_t* seed_offset, void* stream) {
   if (!x || !gamma || !beta || !y || !mean || !rstd || rows < 0 || D <= 0) return MESM_EINVAL;
+  if (drop_p < 0.f || drop_p >= 1.f) return MESM_EINVAL;
   if (rows == 0) return MESM_OK;
   hipStream_t s = (hipStream_t)stream;
+  const LnDrop dr = make_drop(drop_p, drop_seed, seed_offset);
   int vec = pick_vec(D, x, y, gamma, beta);
-  if (vec == 4) LN_DISPATCH(fwd_launch, 4, x, gamma, beta, y, mean, rstd, rows, D, eps, s);
-  if (vec == 2) LN_DISPATCH(fwd_launch, 2, x, gamma, beta, y, mean, rstd, rows, D, eps, s);
-  LN_DISPATCH(fwd_launch, 1, x, gamma, beta, y, mean, rstd, rows, D, eps, s);
+  if (vec == 4) LN_DISPATCH(fwd_launch, 4, x, gamma, beta, y, mean, rstd, rows, D, eps, dr, s);
+  if (vec == 2) LN_DISPATCH(fwd_launch, 2, x, gamma, beta, y, mean, rstd, rows, D, eps, dr, s);
+  LN_DISPATCH(fwd_launch, 1, x, gamma, beta, y, mean, rstd, rows, D, eps, dr, s);
 }
 
 extern "C" int mesm_layernorm_bwd(const float* dy, const float* x, const float* gamma,
                                   const float* mean, const float* rstd, float* dx,
                                   float* dgamma, float* dbeta, int64_t rows, int32_t D,
-                                  int32_t accumulate_dx, void* stream) {
+                                  int32_t accumulate_dx, float drop_p, uint32_t drop_seed,
+                                  const uint32_t* seed_offset, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dgamma || !dbeta || rows < 0 || D <= 0)
     return MESM_EINVAL;
+  if (drop_p < 0.f || drop_p >= 1.f) return MESM_EINVAL;
   if (rows == 0) return MESM_OK;
   hipStream_t s = (hipStream_t)stream;
+  const LnDrop dr = make_drop(drop_p, drop_seed, seed_offset);
   if (!dx) {
     if (accumulate_dx) return MESM_EINVAL;
     const int cb = (D + 255) / 256;
@@ -300,13 +332,13 @@ extern "C" int mesm_layernorm_bwd(const float* dy, const float* x, const float* 
     const int rpb = (int)((rows + rb - 1) / rb);
     rb = (int)((rows + rpb - 1) / rpb);
     hipLaunchKernelGGL(ln_bwd_params_kernel, dim3(cb, rb), dim3(256), 0, s, dy, x, mean, rstd, dgamma,
-                       dbeta, rows, D, rpb);
+                       dbeta, rows, D, rpb, dr);
     return mesm_launch_status();
   }
   int vec = pick_vec(D, x, dy, dx, gamma);
   if (vec == 4)
-    LN_DISPATCH(bwd_launch, 4, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, accumulate_dx, s);
+    LN_DISPATCH(bwd_launch, 4, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, accumulate_dx, dr, s);
   if (vec == 2)
-    LN_DISPATCH(bwd_launch, 2, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, accumulate_dx, s);
-  LN_DISPATCH(bwd_launch, 1, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, accumulate_dx, s);
+    LN_DISPATCH(bwd_launch, 2, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, accumulate_dx, dr, s);
+  LN_DISPATCH(bwd_launch, 1, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, accumulate_dx, dr, s);
 }

@@ -113,7 +113,8 @@ def gemm(A, B, C, *, trans_a=False, trans_b=False, A2=None, B2=None, bias=None, 
     return C
 
 
-def layernorm_fwd(x, gamma, beta, eps=1e-5):
+def layernorm_fwd(x, gamma, beta, eps=1e-5, drop=(0.0, 0)):
+    """y = dropout(LN(x)) (drop = (p, seed); p = 0: plain LayerNorm), mean, rstd."""
     require_gpu(x, gamma, beta)
     D = x.shape[-1]
     x2 = x.reshape(-1, D)
@@ -123,13 +124,16 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5):
     mean = torch.empty(rows, device=x.device, dtype=torch.float32)
     rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
     check(lib().mesm_layernorm_fwd(ptr(x2), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd),
-                                   rows, D, eps, stream_ptr()), "mesm_layernorm_fwd")
+                                   rows, D, eps, float(drop[0]), int(drop[1]) & 0xFFFFFFFF,
+                                   ptr(_seed_offset), stream_ptr()), "mesm_layernorm_fwd")
     return y.view(x.shape), mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx=None, accumulate_dx=False, need_dx=True):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx=None, accumulate_dx=False, need_dx=True,
+                  drop=(0.0, 0)):
     """dgamma/dbeta are ACCUMULATED into (flat-gradient views).  need_dx=False: parameter
-    gradients only (returns None)."""
+    gradients only (returns None).  drop: the (p, seed) the forward fused; dy is masked on load."""
+    dp, dseed = float(drop[0]), int(drop[1]) & 0xFFFFFFFF
     require_gpu(dy, x, gamma)
     D = x.shape[-1]
     x2 = x.reshape(-1, D)
@@ -137,7 +141,8 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx=None, accumulate_d
     assert x2.is_contiguous() and dy2.is_contiguous()
     if not need_dx:
         check(lib().mesm_layernorm_bwd(ptr(dy2), ptr(x2), ptr(gamma), ptr(mean), ptr(rstd), None,
-                                       ptr(dgamma), ptr(dbeta), x2.shape[0], D, 0, stream_ptr()),
+                                       ptr(dgamma), ptr(dbeta), x2.shape[0], D, 0, dp, dseed,
+                                       ptr(_seed_offset), stream_ptr()),
               "mesm_layernorm_bwd")
         return None
     if dx is None:
@@ -146,7 +151,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx=None, accumulate_d
     dx2 = dx.view(-1, D)
     check(lib().mesm_layernorm_bwd(ptr(dy2), ptr(x2), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx2),
                                    ptr(dgamma), ptr(dbeta), x2.shape[0], D,
-                                   1 if accumulate_dx else 0, stream_ptr()),
+                                   1 if accumulate_dx else 0, dp, dseed, ptr(_seed_offset), stream_ptr()),
           "mesm_layernorm_bwd")
     return dx2.view(x.shape)
 
@@ -267,6 +272,16 @@ def dropout(x, p, seed, out=None):
     y = torch.empty_like(x) if out is None else out
     check(lib().mesm_dropout(ptr(x), ptr(y), x.numel(), float(p), int(seed) & 0xFFFFFFFF,
                              ptr(_seed_offset), stream_ptr()), "mesm_dropout")
+    return y
+
+
+def act_dropout(x, act, slope, p, seed):
+    """dropout(act(x)) with the library's counter-based mask (flat element index)."""
+    require_gpu(x)
+    assert x.is_contiguous()
+    y = torch.empty_like(x)
+    check(lib().mesm_act_dropout(ptr(x), ptr(y), x.numel(), int(act), ptr(slope), float(p),
+                                 int(seed) & 0xFFFFFFFF, ptr(_seed_offset), stream_ptr()), "mesm_act_dropout")
     return y
 
 

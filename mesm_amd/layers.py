@@ -82,7 +82,9 @@ class MLPHead(nn.Module):
 
 
 class LinearLayer(nn.Module):
-    """LN -> dropout -> Linear -> [ReLU] (model.py:412-434); the dropout rides the GEMM's A load."""
+    """LN -> dropout -> Linear -> [ReLU] (model.py:412-434); the dropout is applied by the LayerNorm
+    kernel's store (once per element; as a GEMM operand transform it was re-hashed by every
+    column tile) and replayed on dy by the LayerNorm backward."""
 
     def __init__(self, in_f, out_f, dropout, relu):
         super().__init__()
@@ -92,9 +94,10 @@ class LinearLayer(nn.Module):
         self.relu = relu
 
     def forward(self, x):
-        x = self.LayerNorm(x)
+        ln = self.LayerNorm
+        x = ops.layer_norm(x, ln.weight, ln.bias, drop=drop_state.next(self.p))
         lin = self.net[1]
-        return ops.linear(x, lin.weight, lin.bias, relu=self.relu, in_drop=drop_state.next(self.p))
+        return ops.linear(x, lin.weight, lin.bias, relu=self.relu)
 
 
 class T2VLayer(nn.Module):

@@ -48,7 +48,7 @@ def test_bad_arguments_are_rejected_without_a_gpu():
     assert L.mesm_gemm_f32(ctypes.byref(g), None) == -1  # MESM_EINVAL: null operands
     a = _lib.AttnArgs()
     assert L.mesm_attn_fwd(ctypes.byref(a), None) == -1
-    assert L.mesm_layernorm_fwd(None, None, None, None, None, None, 4, 256, 1e-5, None) == -1
+    assert L.mesm_layernorm_fwd(None, None, None, None, None, None, 4, 256, 1e-5, 0.0, 0, None, None) == -1
     assert L.mesm_match(None, None, None, None, None, 1, 1, 1, 1.0, 1.0, 1.0, None, None, None) == -1
 
 
