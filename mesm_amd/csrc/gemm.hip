@@ -1034,6 +1034,232 @@ bool wstage_ok(const MesmGemmArgs& a) {
   return ok(a.a_layout, a.A, a.lda, a.M) && ok(a.b_layout, a.B, a.ldb, a.N);
 }
 
+// ------------------------------------------------------------------------------------------------
+// "lds64" kernel for the large GEMMs of the step (FFN 4800 x 1024 x 256 and transposes, the 2818-wide
+// input projections, the vocabulary head): 64 x 64 tile, 2 x 2 waves of 32 x 32, k-tiles of 32 staged
+// by LDS-DMA in full 128-byte lines into a 3-deep ring (48 KB: three workgroups per CU), ONE raw
+// s_barrier per k-tile, fragments by ds_read_b128.  The loads are inline asm so that hipcc's vmcnt
+// bookkeeping does not drain the ring before every fragment read (it waits vmcnt(0) on any LDS access
+// that may alias an LDS-DMA it knows about): the only waits on the ring are the counted ones below.
+// Slab layouts / source-address swizzles are the wstage kernel's (ws_issue_asm mirrors ws_issue).
+constexpr int L64_STAGES = 3;
+constexpr int L64_STAGE_FLOATS = 4 * WS_SLAB;  // A rows 0-31, A rows 32-63, B rows 0-31, B rows 32-63
+
+__device__ __forceinline__ void glds16(const float* g, float* lds_dst) {
+  // LDS-DMA: 16 bytes per lane, destination = wave-uniform LDS byte address (M0) + lane * 16
+  const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_dst;
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(g), "s"(__builtin_amdgcn_readfirstlane(dst))
+               : "memory");
+}
+
+// one 32-row slab of a k-tile: 4 LDS-DMA instructions of this wave (same address rules as ws_issue)
+template <int LAYOUT>
+__device__ __forceinline__ void l64_issue(const float* __restrict__ base, int64_t ld, int o0, int extent,
+                                          int kb, int kend, float* slab, int lane) {
+  const int sr = lane >> 3, pos = lane & 7;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float* g;
+    if (LAYOUT == MESM_LAYOUT_REDUCE_CONTIG) {
+      const int r = 8 * q + sr;
+      int row = o0 + r;
+      row = row < extent ? row : extent - 1;
+      const int c = pos ^ ((r >> 1) & 7);
+      int k = kb + 4 * c;
+      k = k < kend ? k : kend - 4;
+      g = base + (int64_t)row * ld + k;
+    } else {
+      int k = kb + 8 * q + (((sr & 1) << 2) | (sr >> 1));
+      k = k < kend ? k : kend - 1;
+      int o = o0 + 4 * pos;
+      o = o + 4 <= extent ? o : extent - 4;
+      g = base + (int64_t)k * ld + o;
+    }
+    glds16(g, slab + q * 256);
+  }
+}
+
+template <int LA, int LB, bool XF>
+__global__ __launch_bounds__(NTHREADS) void gemm_lds64_kernel(const MesmGemmArgs p) {
+  __shared__ __attribute__((aligned(16))) float L[L64_STAGES * L64_STAGE_FLOATS];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+
+  int kbeg = 0, kend = p.K;
+  if (p.split_k > 1) {
+    int chunk = (p.K + p.split_k - 1) / p.split_k;
+    chunk = ((chunk + BK_MAX - 1) / BK_MAX) * BK_MAX;
+    kbeg = blockIdx.z * chunk;
+    kend = kbeg + chunk < p.K ? kbeg + chunk : p.K;
+    if (kbeg >= p.K) return;
+  }
+  const int nst = (kend - kbeg + 31) >> 5;
+
+  const float slope = p.slope ? *p.slope : 0.0f;
+  const uint32_t seed_off = p.seed_offset ? *p.seed_offset : 0u;
+  XForm xa, xb;
+  xa.act = p.a_act; xa.slope = slope; xa.thresh = p.a_drop_p > 0.f ? mesm_drop_threshold(p.a_drop_p) : 0u;
+  xa.seed = p.a_drop_seed + seed_off; xa.inv_keep = 1.0f / (1.0f - p.a_drop_p);
+  xa.lld = LA == MESM_LAYOUT_REDUCE_CONTIG ? p.K : p.M;
+  xb.act = p.b_act; xb.slope = slope; xb.thresh = p.b_drop_p > 0.f ? mesm_drop_threshold(p.b_drop_p) : 0u;
+  xb.seed = p.b_drop_seed + seed_off; xb.inv_keep = 1.0f / (1.0f - p.b_drop_p);
+  xb.lld = LB == MESM_LAYOUT_REDUCE_CONTIG ? p.K : p.N;
+
+  // wave w stages slab w of every k-tile: 0/1 = A rows [0,32) / [32,64), 2/3 = B rows [0,32) / [32,64)
+  auto issue = [&](int st) {
+    float* slab = L + (st % L64_STAGES) * L64_STAGE_FLOATS + wave * WS_SLAB;
+    const int kb = kbeg + 32 * st;
+    if (wave < 2) l64_issue<LA>(p.A, p.lda, m0 + 32 * wave, p.M, kb, kend, slab, lane);
+    else l64_issue<LB>(p.B, p.ldb, n0 + 32 * (wave - 2), p.N, kb, kend, slab, lane);
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  float csum = 0.0f;
+  const bool do_colsum = (p.colsum != nullptr) && (blockIdx.y == 0) && (wn == 0);
+
+  if (nst > 0) issue(0);
+  if (nst > 1) issue(1);
+  for (int st = 0; st < nst; ++st) {
+    // this wave's 4 LDS-DMA instructions of k-tile st have landed (k-tile st+1 may still fly) ...
+    if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ... and so have the other waves': one barrier per k-tile.  It also orders the fragment reads of
+    // k-tile st-1 (finished by every wave before it arrived here) ahead of the refill issued below.
+    __builtin_amdgcn_s_barrier();
+    if (st + 2 < nst) issue(st + 2);
+    const float* buf = L + (st % L64_STAGES) * L64_STAGE_FLOATS;
+    float a[4][4], b[4][4];
+    ws_read<LA>(buf + wm * WS_SLAB, li, h, a);
+    ws_read<LB>(buf + (2 + wn) * WS_SLAB, li, h, b);
+    const int kb = kbeg + 32 * st;
+    if (kb + 32 > kend) {
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool ok = kb + 8 * s_ + 4 * h + j < kend;
+          a[s_][j] = ok ? a[s_][j] : 0.0f;
+          b[s_][j] = ok ? b[s_][j] : 0.0f;
+        }
+    }
+    if (XF) {
+      const int gm = m0 + 32 * wm + li, gn = n0 + 32 * wn + li;
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int gk = kb + 8 * s_ + 4 * h + j;
+          float x = mesm_act(a[s_][j], xa.act, xa.slope);
+          if (xa.thresh)
+            x = mesm_dropout_apply(x, (uint32_t)(LA == MESM_LAYOUT_REDUCE_CONTIG ? (int64_t)gm * xa.lld + gk : (int64_t)gk * xa.lld + gm),
+                                   xa.seed, xa.thresh, xa.inv_keep);
+          a[s_][j] = x;
+          float y = mesm_act(b[s_][j], xb.act, xb.slope);
+          if (xb.thresh)
+            y = mesm_dropout_apply(y, (uint32_t)(LB == MESM_LAYOUT_REDUCE_CONTIG ? (int64_t)gn * xb.lld + gk : (int64_t)gk * xb.lld + gn),
+                                   xb.seed, xb.thresh, xb.inv_keep);
+          b[s_][j] = y;
+        }
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s_][j], b[s_][j], acc, 0, 0, 0);
+    if (do_colsum) {
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) csum += a[s_][j];
+    }
+  }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+
+  if (do_colsum) {
+    csum += __shfl_xor(csum, 32, 64);
+    const int gm = m0 + 32 * wm + li;
+    if (h == 0 && gm < p.M && csum != 0.0f) atomicAdd(p.colsum + gm, csum);
+  }
+
+  // ---- epilogue: this wave's 32 x 32 tile (accumulator register r <-> row 4h + (r & 3) + 8 (r >> 2)) ----
+  const bool first_split = (p.split_k <= 1) || (blockIdx.z == 0);
+  const uint32_t e_thresh = p.e_drop_p > 0.f ? mesm_drop_threshold(p.e_drop_p) : 0u;
+  const float e_inv_keep = 1.0f / (1.0f - p.e_drop_p);
+  const bool use_bias = p.bias != nullptr && first_split;
+  const bool use_res = p.residual != nullptr && first_split;
+  const bool use_aux = p.e_actgrad != MESM_ACT_NONE;
+  const bool rmw = p.accumulate == 1;
+  float dslope_part = 0.0f;
+  const int col = n0 + 32 * wn + li;
+  const bool colok = col < p.N;
+  const int colc = colok ? col : p.N - 1;
+  const int rbase = m0 + 32 * wm + 4 * h;
+  const float bias_v = use_bias ? p.bias[colc] : 0.0f;
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {  // groups of 4 rows: side loads of a group are issued together
+    float resv[4], auxv[4], oldv[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      int row = rbase + rr + 8 * g4;
+      row = row < p.M ? row : p.M - 1;
+      resv[rr] = use_res ? p.residual[(int64_t)row * p.ldr + colc] : 0.0f;
+      auxv[rr] = use_aux ? p.aux[(int64_t)row * p.ldaux + colc] : 0.0f;
+      oldv[rr] = rmw ? p.C[(int64_t)row * p.ldc + colc] : 0.0f;
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int row = rbase + rr + 8 * g4;
+      float t = acc[4 * g4 + rr] * p.out_scale + bias_v;
+      t = mesm_act(t, p.e_act, slope);
+      if (e_thresh)
+        t = mesm_dropout_apply(t, (uint32_t)((int64_t)row * p.N + col), p.e_drop_seed + seed_off, e_thresh,
+                               e_inv_keep);
+      if (use_aux) {
+        const float z = auxv[rr];
+        if (p.e_actgrad == MESM_ACT_RELU) {
+          t = z > 0.0f ? t : 0.0f;
+        } else if (z <= 0.0f) {
+          if (row < p.M && colok) dslope_part += t * z;
+          t *= slope;
+        }
+      }
+      t += resv[rr] + oldv[rr];
+      if (row < p.M && colok) {
+        float* c = p.C + (int64_t)row * p.ldc + col;
+        if (p.accumulate == 2) atomicAdd(c, t);
+        else *c = t;
+      }
+    }
+  }
+  if (p.e_actgrad == MESM_ACT_PRELU && p.dslope) dslope_store(p, dslope_part, L);
+}
+
+template <int LA, int LB>
+int launch_lds64_l(const MesmGemmArgs& a, hipStream_t s) {
+  dim3 grid((a.M + 63) / 64, (a.N + 63) / 64, a.split_k > 1 ? a.split_k : 1);
+  const bool xf = a.a_act != MESM_ACT_NONE || a.b_act != MESM_ACT_NONE || a.a_drop_p > 0.f || a.b_drop_p > 0.f;
+  if (xf) hipLaunchKernelGGL((gemm_lds64_kernel<LA, LB, true>), grid, dim3(NTHREADS), 0, s, a);
+  else hipLaunchKernelGGL((gemm_lds64_kernel<LA, LB, false>), grid, dim3(NTHREADS), 0, s, a);
+  const int rc = mesm_launch_status();
+  return rc != MESM_OK ? rc : dslope_finish(a, grid, s);
+}
+
+int launch_lds64(const MesmGemmArgs& a, hipStream_t s) {
+  constexpr int R = MESM_LAYOUT_REDUCE_CONTIG, O = MESM_LAYOUT_OUTER_CONTIG;
+  if (a.a_layout == R && a.b_layout == R) return launch_lds64_l<R, R>(a, s);
+  if (a.a_layout == R && a.b_layout == O) return launch_lds64_l<R, O>(a, s);
+  if (a.a_layout == O && a.b_layout == O) return launch_lds64_l<O, O>(a, s);
+  return launch_lds64_l<O, R>(a, s);
+}
+
 // Tape of the GEMM launches of one step (argument structs as launched), for bench.py's
 // roofline measurement: recorded while a step is captured into a HIP graph (whose private
 // memory pool keeps every pointer valid), replayed back-to-back from C++ with an event pair
@@ -1051,7 +1277,9 @@ int dispatch(const MesmGemmArgs& a, int vec, hipStream_t s) {
     const long z = a.split_k > 1 ? a.split_k : 1;
     const long b64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * z;
     const int force = env ? atoi(env) : 0;  // 1 = frag kernel, 32 | 64 | 128 = staged tile, 0 = auto
-    // 1 = frag, 2 = wstage (line-shaped LDS-DMA staging), 32 | 64 | 128 = staged tile, 0 = auto
+    // 1 = frag, 2 = wstage (k-split 32x32, wave-private LDS-DMA), 3 = lds64 (64x64, LDS-DMA ring),
+    // 32 | 64 | 128 = register-staged tile, 0 = auto
+    if ((force == 3 || (force == 0 && b64 >= 512)) && wstage_ok(a)) return launch_lds64(a, s);
     if ((force == 2 || (force == 0 && b64 < 512)) && wstage_ok(a)) return launch_wstage(a, s);
     if ((force == 1 || (force == 0 && b64 < 512)) && frag_ok(a)) return launch_frag(a, s);
   }

@@ -7,6 +7,12 @@ import torch
 from mesm_amd import kernels as kn
 dev = torch.device("cuda:0")
 SHAPES = [
+    ("FFN1 4800     ", 4800, 1024, 256, False, True, 1),
+    ("FFN2 4800     ", 4800, 256, 1024, False, True, 1),
+    ("dz1 4800      ", 4800, 1024, 256, False, False, 1),
+    ("dx 4800 F->d  ", 4800, 256, 1024, False, False, 1),
+    ("dW Fxd 4800 s4", 1024, 256, 4800, True, False, 4),
+    ("dW dxF 4800 s4", 256, 1024, 4800, True, False, 4),
     ("fwd d->d      ", 2400, 256, 256, False, True, 1),
     ("fwd 2N d->d   ", 4800, 256, 256, False, True, 1),
     ("fwd d->F      ", 2400, 1024, 256, False, True, 1),
@@ -33,7 +39,7 @@ for name, M, N, K, ta, tb, split in SHAPES:
     sets = [(torch.randn((K, M) if ta else (M, K), device=dev), torch.randn((N, K) if tb else (K, N), device=dev),
              torch.zeros(M, N, device=dev)) for _ in range(NSET)]
     res = []
-    for tile in ("0", "1", "2", "32", "64"):
+    for tile in ("0", "2", "3", "32", "64"):
         os.environ["MESM_GEMM_TILE"] = tile
         def body():
             for i in range(NL):
@@ -58,5 +64,5 @@ for name, M, N, K, ta, tb, split in SHAPES:
         torch.cuda.synchronize()
         res.append((time.perf_counter() - t0) / REPS / NL * 1e6)
     os.environ["MESM_GEMM_TILE"] = "0"
-    print("%s M=%5d N=%5d K=%5d s%-2d auto %7.2f | frag %7.2f | wstage %7.2f | t32 %7.2f | t64 %7.2f us  (best %5.1f TF)" % (
+    print("%s M=%5d N=%5d K=%5d s%-2d auto %7.2f | wstage %7.2f | lds64 %7.2f | t32 %7.2f | t64 %7.2f us  (best %5.1f TF)" % (
         name, M, N, K, split, res[0], res[1], res[2], res[3], res[4], 2.0 * M * N * K / min(res) / 1e6), flush=True)
