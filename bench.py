@@ -11,9 +11,11 @@ C=5003, fp32).  Inputs are resident in HBM before the timed region; the host-sid
 the reference (negative query index, MLM word choice) are re-drawn every step.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
-  roofline     — the dominant kernel (gemm_f32_kernel, exact-f32 MFMA): algorithmic FLOPs per
-                 launch / mean launch duration, HIP events on the launch stream, measured in an
-                 instrumented re-run of the same steps right after the timed region;
+  roofline     — the dominant kernel family (mesm_gemm_f32: exact-f32 MFMA GEMMs, 61 % of the
+                 step by in-situ ablation, tools/ablate.py): algorithmic FLOPs per launch / mean
+                 launch duration, HIP events on the launch stream around back-to-back replays of
+                 the GEMM launches of one captured step, right after the timed region; `traffic`
+                 = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/);
   cpu_baseline — the CPU oracle (a port of the reference step, oracle/mesm_oracle.py) timed on
                  this box's host cores on the same workload (rank 0, N = 1 only).
 """
@@ -160,12 +162,21 @@ def main():
             avg_ms = prof["ms"] / prof["launches"]
             flops_per_launch = prof["flops"] / prof["launches"]
             achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-            roofline = {"kernel": "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", "bound": "mfma",
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
+            if os.path.exists(tpath):  # PMC FETCH_SIZE / WRITE_SIZE passes of this same command
+                with open(tpath) as f:
+                    traffic = json.load(f).get("hbm_bytes_per_launch")
+            roofline = {"kernel": "mesm_gemm_f32 (gemm_wstage / gemm_lds64 / gemm_frag / gemm_f32 kernels, "
+                                  "v_mfma_f32_32x32x2_f32)", "bound": "mfma",
                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                        "launches_per_step": prof["launches"] / opt.steps, "measured": "event pair per launch, tape of one captured step replayed %d x" % opt.steps,
+                        "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                        "launches_per_step": prof["launches"] / opt.steps,
+                        "measured": "HIP event pair around the back-to-back GEMM launches of one captured "
+                                    "step, replayed %d x" % opt.steps,
                         "avg_launch_us": avg_ms * 1e3, "flops_per_launch": flops_per_launch,
-                        "gemm_ms_per_step": prof["ms"] / opt.steps}
+                        "gemm_ms_per_step": prof["ms"] / opt.steps,
+                        "algorithmic_bytes_per_launch": prof.get("bytes", 0) / max(prof["launches"], 1)}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and opt.cpu_steps > 0:

@@ -130,13 +130,14 @@ int mesm_gemm_f32(const MesmGemmArgs* args, void* stream);
  * GEMM launch (mesm_gemm_tape(0) stops); bench.py records while the step is captured into a HIP
  * graph, whose private memory pool keeps every recorded pointer valid afterwards.
  * mesm_gemm_tape_replay re-issues the recorded launches `reps` times back to back on `stream`,
- * each bracketed by a pair of HIP events on that stream, synchronises (host-blocking; never
- * inside a timed region) and returns the summed elapsed time, the number of launches and their
- * algorithmic FLOPs (2*M*N*K each).
+ * every repetition bracketed by ONE pair of HIP events on that stream (a pair per launch costs
+ * ~5 us of its own), synchronises (host-blocking; never inside a timed region) and returns the
+ * summed elapsed time, the number of launches and their algorithmic FLOPs (2*M*N*K each):
+ * average launch duration = total_ms / launches.
  */
 int mesm_gemm_tape(int32_t record);
 int mesm_gemm_tape_replay(void* stream, int32_t reps, double* total_ms, int64_t* launches,
-                          double* total_flops);
+                          double* total_flops, double* total_bytes);
 
 /* ------------------------------------------------------------------------- */
 /*

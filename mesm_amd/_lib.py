@@ -68,7 +68,8 @@ PROTOTYPES = {
     "mesm_gemm_f32": (ctypes.c_int, [ctypes.POINTER(GemmArgs), c_ptr]),
     "mesm_gemm_tape": (ctypes.c_int, [_i32]),
     "mesm_gemm_tape_replay": (ctypes.c_int, [c_ptr, _i32, ctypes.POINTER(ctypes.c_double),
-                                             ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double)]),
+                                             ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double),
+                                             ctypes.POINTER(ctypes.c_double)]),
     "mesm_layernorm_fwd": (ctypes.c_int, [c_ptr] * 6 + [_i64, _i32, _f32, _f32, _u32, c_ptr, c_ptr]),
     "mesm_layernorm_bwd": (ctypes.c_int, [c_ptr] * 8 + [_i64, _i32, _i32, _f32, _u32, c_ptr, c_ptr]),
     "mesm_attn_fwd": (ctypes.c_int, [ctypes.POINTER(AttnArgs), c_ptr]),

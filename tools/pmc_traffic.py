@@ -1,0 +1,29 @@
+"""HBM traffic of the GEMM kernels from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, in
+separate runs: they do not fit one pass on gfx950).  Units and corrections per
+MI355X_MICROARCH.md "HBM": both counters are in KiB; on gfx950 FETCH_SIZE reports exactly half of
+the bytes of wide coalesced reads (128-B requests tallied at 64 B), so it is doubled; WRITE_SIZE is
+exact.  Usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
+import csv, json, sys
+csv.field_size_limit(1 << 30)
+
+
+def gemm_sum(path, counter):
+    tot, n = 0.0, 0
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter and "gemm_" in r["Kernel_Name"]:
+            tot += float(r["Counter_Value"])
+            n += 1
+    return tot, n
+
+
+f, nf = gemm_sum(sys.argv[1], "FETCH_SIZE")
+w, nw = gemm_sum(sys.argv[2], "WRITE_SIZE")
+out = {
+    "kernels": "every kernel whose name contains gemm_ (gemm_wstage / gemm_lds64 / gemm_frag / gemm_f32)",
+    "launches_fetch_pass": nf, "launches_write_pass": nw,
+    "fetch_kib_raw_per_launch": f / max(nf, 1), "write_kib_per_launch": w / max(nw, 1),
+    "correction": "FETCH_SIZE x2 (gfx950: 128-B requests tallied at 64 B), WRITE_SIZE x1, KiB -> bytes",
+    "hbm_bytes_per_launch": (2.0 * f / max(nf, 1) + w / max(nw, 1)) * 1024.0,
+}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(out))
