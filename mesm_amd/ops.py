@@ -149,6 +149,7 @@ class FFNFn(Function):
         kn.gemm(_2d(h), w2, _2d(y), trans_b=True, bias=b2, e_drop=out_drop,
                 residual=_2d(_c(residual)) if residual is not None else None)
         ctx.save_for_backward(x, z, h)
+        ctx.res_is_x = residual is not None and residual.data_ptr() == x.data_ptr() and residual.shape == x.shape
         ctx.params = (w1, b1, slope, w2, b2)
         ctx.mid_drop, ctx.out_drop = mid_drop, out_drop
         ctx.has_res = residual is not None
@@ -172,11 +173,13 @@ class FFNFn(Function):
                 slope=slope, dslope=gs)
         _accum_dw(_2d(dz1), _2d(x), gw1, gb1)
         dx = None
+        fold_res = ctx.res_is_x and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            kn.gemm(_2d(dz1), w1, _2d(dx))
+            # residual input IS x: its gradient (dy) rides the epilogue of the dX GEMM
+            kn.gemm(_2d(dz1), w1, _2d(dx), residual=dy2 if fold_res else None)
         flush_ready()
-        return (dx, dy if ctx.has_res and ctx.needs_input_grad[1] else None,
+        return (dx, dy if ctx.has_res and ctx.needs_input_grad[1] and not fold_res else None,
                 None if d_w1 else gw1, None if d_b1 else gb1, None if d_s else gs,
                 None if d_w2 else gw2, None if d_b2 else gb2, None, None)
 
@@ -294,6 +297,7 @@ class MHAFn(Function):
                 residual=_2d(_c(residual)) if residual is not None else None)
         ctx.save_for_backward(xq, pq, xk, pk, q, k, v, o, lse)
         ctx.params = (w_in, b_in, w_out, b_out)
+        ctx.res_is_xq = residual is not None and residual.data_ptr() == xq.data_ptr() and residual.shape == xq.shape
         ctx.cfg = (H, kpad, qpad, attn_drop, out_drop, self_attn, residual is not None, group)
         return out
 
@@ -317,9 +321,11 @@ class MHAFn(Function):
         kn.gemm(dz, w_out, _2d(do))
         need_q, need_pq = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         need_k, need_pk = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
+        fold_res = ctx.res_is_xq and need_q and ctx.needs_input_grad[4]
         dxq = dpq = dxk = dpk = None
         if self_attn:
-            dqkv = torch.zeros(N, Lq, 3 * d, device=dev, dtype=torch.float32)
+            # dq is added atomically only when several 64-key tiles contribute
+            dqkv = (torch.zeros if Lq > 64 else torch.empty)(N, Lq, 3 * d, device=dev, dtype=torch.float32)
             kn.attn_bwd_into(do, q, k, v, o, lse, H, dqkv[..., :d], dqkv[..., d:2 * d],
                              dqkv[..., 2 * d:], kpad=kpad, qpad=qpad, drop=attn_drop, group=group)
             g2 = _2d(dqkv)
@@ -328,15 +334,18 @@ class MHAFn(Function):
             _accum_dw(g2[:, 2 * d:], _2d(xq), gwi[2 * d:], gbi[2 * d:])
             if need_q or need_pq:
                 dqk_in = torch.empty_like(xq)  # gradient of (xq + pq) through q and k
-                kn.gemm(g2[:, :2 * d], w_in[:2 * d], _2d(dqk_in))
+                early = fold_res and not need_pq  # residual input IS xq: dy rides this epilogue
+                kn.gemm(g2[:, :2 * d], w_in[:2 * d], _2d(dqk_in), residual=dy2 if early else None)
                 if need_pq:
                     dpq = dqk_in
                 if need_q:
                     dxq = torch.empty_like(xq)
                     kn.gemm(g2[:, 2 * d:], w_in[2 * d:], _2d(dxq), residual=_2d(dqk_in))
+                    if fold_res and not early:
+                        dxq.add_(dy)
         else:
             Lk = xk.shape[1]
-            dq = torch.zeros(N, Lq, d, device=dev, dtype=torch.float32)
+            dq = (torch.zeros if Lk > 64 else torch.empty)(N, Lq, d, device=dev, dtype=torch.float32)
             dkv = torch.empty(N, Lk, 2 * d, device=dev, dtype=torch.float32)
             kn.attn_bwd_into(do, q, k, v, o, lse, H, dq, dkv[..., :d], dkv[..., d:], kpad=kpad,
                              qpad=qpad, drop=attn_drop, group=group)
@@ -349,7 +358,13 @@ class MHAFn(Function):
                 _accum_dw(g2[:, d:], _2d(xk), gwi[2 * d:], gbi[2 * d:])
             if need_q or need_pq:
                 dxq = torch.empty_like(xq)
-                kn.gemm(_2d(dq), w_in[:d], _2d(dxq))
+                if fold_res and not need_pq:
+                    # the residual input IS xq: its gradient (dy) rides the epilogue of this GEMM
+                    kn.gemm(_2d(dq), w_in[:d], _2d(dxq), residual=dy2)
+                else:
+                    kn.gemm(_2d(dq), w_in[:d], _2d(dxq))
+                    if fold_res:
+                        dxq = dxq + dy
                 dpq = dxq if need_pq else None
                 dxq = dxq if need_q else None
             if need_k or need_pk:
@@ -364,7 +379,7 @@ class MHAFn(Function):
                         dxk = torch.empty_like(xk)
                         kn.gemm(g2[:, d:], w_in[2 * d:], _2d(dxk), residual=_2d(dk_in))
         flush_ready()
-        return (dxq, dpq, dxk, dpk, dy if has_res and ctx.needs_input_grad[4] else None,
+        return (dxq, dpq, dxk, dpk, dy if has_res and ctx.needs_input_grad[4] and not fold_res else None,
                 None if d_wi else gwi, None if d_bi else gbi, None if d_wo else gwo,
                 None if d_bo else gbo, None, None, None, None, None, None, None)
 
