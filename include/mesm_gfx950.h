@@ -125,6 +125,16 @@ typedef struct MesmGemmArgs {
 int mesm_gemm_f32(const MesmGemmArgs* args, void* stream);
 
 /*
+ * n <= 64 INDEPENDENT GEMMs (no problem reads what another writes, except atomic accumulation
+ * into the same gradient) issued together: the small ones (those mesm_gemm_f32 would hand to its
+ * k-split kernel) share launches of up to 8 problems, whatever their shapes, layouts and fusions;
+ * the others are launched one by one.  Replaces nothing new in the reference: it is how the
+ * backward GEMM pairs (dW, dX) of every nn.Linear and the decoder's per-layer projections
+ * (transformer.py:737-747, 759-784) are issued here -- a launch costs ~5 us whatever its size.
+ */
+int mesm_gemm_group(const MesmGemmArgs* args, int32_t n, void* stream);
+
+/*
  * Launch-duration measurement of mesm_gemm_f32 (the dominant kernel of the step) for
  * bench.py's roofline object.  mesm_gemm_tape(1) starts recording the argument struct of every
  * GEMM launch (mesm_gemm_tape(0) stops); bench.py records while the step is captured into a HIP

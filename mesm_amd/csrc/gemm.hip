@@ -36,16 +36,17 @@ struct XForm {
 // slot of its linear block id and a 1-workgroup kernel adds them into the parameter gradient.
 // (One float atomic per wave on the single dslope address cost +45 us per GEMM: same-address
 // atomics serialise at the memory side.)
-__device__ __forceinline__ void dslope_store(const MesmGemmArgs& p, float part, float* sh4) {
+__device__ __forceinline__ int64_t linear_block() {
+  return ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+}
+
+__device__ __forceinline__ void dslope_store(const MesmGemmArgs& p, float part, float* sh4, int64_t slot) {
   part = wave_sum(part);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   __syncthreads();
   if (lane == 0) sh4[wave] = part;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const int64_t bid = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    p.dslope_ws[bid] = sh4[0] + sh4[1] + sh4[2] + sh4[3];
-  }
+  if (threadIdx.x == 0) p.dslope_ws[slot] = sh4[0] + sh4[1] + sh4[2] + sh4[3];
 }
 
 __global__ __launch_bounds__(256) void dslope_reduce_kernel(const float* __restrict__ ws, int64_t n,
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const MesmGemmArgs p
       }
     }
   }
-  if (p.e_actgrad == MESM_ACT_PRELU && p.dslope) dslope_store(p, dslope_part, Red);
+  if (p.e_actgrad == MESM_ACT_PRELU && p.dslope) dslope_store(p, dslope_part, Red, linear_block());
 }
 
 template <int BM, int BN, int LA, int LB, int VEC, int ADD>
@@ -525,7 +526,7 @@ inline bool aligned_to(const void* p, size_t b) { return p == nullptr || ((uintp
 // they meet in LDS (Red: 4 x 16 x 64 floats) and wave w takes accumulator registers [4w, 4w+4)
 // through bias / activation / dropout / activation-gradient / residual / accumulate.
 __device__ __forceinline__ void ksplit_epilogue(const MesmGemmArgs& p, const f32x16& acc, float* Red, int m0,
-                                                int n0, float slope, uint32_t seed_off) {
+                                                int n0, float slope, uint32_t seed_off, int bz, int64_t slot) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 31, h = lane >> 5;
   // sum the four partial tiles; wave w takes accumulator registers [4w, 4w+4) through the epilogue
@@ -542,7 +543,7 @@ __device__ __forceinline__ void ksplit_epilogue(const MesmGemmArgs& p, const f32
     vals[rr] = t;
   }
 
-  const bool first_split = (p.split_k <= 1) || (blockIdx.z == 0);
+  const bool first_split = (p.split_k <= 1) || (bz == 0);
   const uint32_t e_thresh = p.e_drop_p > 0.f ? mesm_drop_threshold(p.e_drop_p) : 0u;
   const float e_inv_keep = 1.0f / (1.0f - p.e_drop_p);
   const bool use_bias = p.bias != nullptr && first_split;
@@ -590,7 +591,7 @@ __device__ __forceinline__ void ksplit_epilogue(const MesmGemmArgs& p, const f32
       else *c = t;
     }
   }
-  if (p.e_actgrad == MESM_ACT_PRELU && p.dslope) dslope_store(p, dslope_part, Red);
+  if (p.e_actgrad == MESM_ACT_PRELU && p.dslope) dslope_store(p, dslope_part, Red, slot);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -794,7 +795,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_frag_kernel(const MesmGemmArgs 
     if (h == 0 && m0 + li < p.M && csum != 0.0f) atomicAdd(p.colsum + m0 + li, csum);
   }
 
-  ksplit_epilogue(p, acc, Red, m0, n0, slope, seed_off);
+  ksplit_epilogue(p, acc, Red, m0, n0, slope, seed_off, blockIdx.z, linear_block());
 }
 
 template <int LA, int LB>
@@ -894,19 +895,23 @@ __device__ __forceinline__ void ws_read(const float* slab, int li, int h, float 
   }
 }
 
+struct Blk {
+  int x, y, z;    // tile coordinates of this workgroup inside ITS problem
+  int64_t slot;   // linear id inside its problem (dslope workspace slot)
+};
+
 template <int LA, int LB, bool XF>
-__global__ __launch_bounds__(NTHREADS) void gemm_wstage_kernel(const MesmGemmArgs p) {
-  __shared__ __attribute__((aligned(16))) float L[4 * 2 * 2 * WS_SLAB];  // [wave][stage][operand]
+__device__ __forceinline__ void wstage_body(const MesmGemmArgs& p, const Blk blk, float* L) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, h = lane >> 5;
-  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int m0 = blk.x * 32, n0 = blk.y * 32;
 
   int kbeg = 0, kend = p.K;
   if (p.split_k > 1) {
     int chunk = (p.K + p.split_k - 1) / p.split_k;
     chunk = ((chunk + BK_MAX - 1) / BK_MAX) * BK_MAX;
-    kbeg = blockIdx.z * chunk;
+    kbeg = blk.z * chunk;
     kend = kbeg + chunk < p.K ? kbeg + chunk : p.K;
     if (kbeg >= p.K) return;
   }
@@ -937,7 +942,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_wstage_kernel(const MesmGemmArg
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
   float csum = 0.0f;
-  const bool do_colsum = (p.colsum != nullptr) && (blockIdx.y == 0);
+  const bool do_colsum = (p.colsum != nullptr) && (blk.y == 0);
 
   if (nst > 0) issue(0);
   if (nst > 1) issue(1);
@@ -1001,7 +1006,56 @@ __global__ __launch_bounds__(NTHREADS) void gemm_wstage_kernel(const MesmGemmArg
     if (h == 0 && m0 + li < p.M && csum != 0.0f) atomicAdd(p.colsum + m0 + li, csum);
   }
   __syncthreads();  // every wave is done with its slabs: the reduction buffer aliases them
-  ksplit_epilogue(p, acc, L, m0, n0, slope, seed_off);
+  ksplit_epilogue(p, acc, L, m0, n0, slope, seed_off, blk.z, blk.slot);
+}
+
+constexpr int WS_LDS_FLOATS = 4 * 2 * 2 * WS_SLAB;  // [wave][stage][operand], 64 KB
+
+template <int LA, int LB, bool XF>
+__global__ __launch_bounds__(NTHREADS) void gemm_wstage_kernel(const MesmGemmArgs p) {
+  __shared__ __attribute__((aligned(16))) float L[WS_LDS_FLOATS];
+  Blk blk;
+  blk.x = blockIdx.x; blk.y = blockIdx.y; blk.z = blockIdx.z; blk.slot = linear_block();
+  wstage_body<LA, LB, XF>(p, blk, L);
+}
+
+// Grouped launch: up to GROUP_MAX independent small problems in ONE kernel (a launch costs 1.66 us of
+// dispatch + ~3 us of exposed latency chain whatever its size, and the backward of every block as well
+// as the decoder are made of independent 5 us GEMMs).  The workgroups of all problems are laid out
+// back to back on blockIdx.x; layouts / transforms are selected per problem at run time (wave-uniform).
+constexpr int GROUP_MAX = 8;
+struct GroupArgs {
+  MesmGemmArgs p[GROUP_MAX];
+  int start[GROUP_MAX + 1];  // first workgroup of every problem
+  int n;
+};
+
+__global__ __launch_bounds__(NTHREADS) void gemm_wstage_group_kernel(const GroupArgs g) {
+  __shared__ __attribute__((aligned(16))) float L[WS_LDS_FLOATS];
+  const int bid = blockIdx.x;
+  int gi = 0;
+#pragma unroll
+  for (int k = 1; k < GROUP_MAX; ++k)
+    if (k < g.n && bid >= g.start[k]) gi = k;
+  const MesmGemmArgs& p = g.p[gi];
+  const int local = bid - g.start[gi];
+  const int mt = (p.M + 31) / 32, nt = (p.N + 31) / 32;
+  Blk blk;
+  blk.x = local % mt; blk.y = (local / mt) % nt; blk.z = local / (mt * nt); blk.slot = local;
+  constexpr int R = MESM_LAYOUT_REDUCE_CONTIG, O = MESM_LAYOUT_OUTER_CONTIG;
+  const bool xf = p.a_act != MESM_ACT_NONE || p.b_act != MESM_ACT_NONE || p.a_drop_p > 0.f || p.b_drop_p > 0.f;
+  const int sel = (p.a_layout == O ? 2 : 0) + (p.b_layout == O ? 1 : 0);
+  if (!xf) {
+    if (sel == 0) wstage_body<R, R, false>(p, blk, L);
+    else if (sel == 1) wstage_body<R, O, false>(p, blk, L);
+    else if (sel == 2) wstage_body<O, R, false>(p, blk, L);
+    else wstage_body<O, O, false>(p, blk, L);
+  } else {
+    if (sel == 0) wstage_body<R, R, true>(p, blk, L);
+    else if (sel == 1) wstage_body<R, O, true>(p, blk, L);
+    else if (sel == 2) wstage_body<O, R, true>(p, blk, L);
+    else wstage_body<O, O, true>(p, blk, L);
+  }
 }
 
 template <int LA, int LB>
@@ -1239,7 +1293,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_lds64_kernel(const MesmGemmArgs
       }
     }
   }
-  if (p.e_actgrad == MESM_ACT_PRELU && p.dslope) dslope_store(p, dslope_part, L);
+  if (p.e_actgrad == MESM_ACT_PRELU && p.dslope) dslope_store(p, dslope_part, L, linear_block());
 }
 
 template <int LA, int LB>
@@ -1264,9 +1318,15 @@ int launch_lds64(const MesmGemmArgs& a, hipStream_t s) {
 // roofline measurement: recorded while a step is captured into a HIP graph (whose private
 // memory pool keeps every pointer valid), replayed back-to-back from C++ with an event pair
 // around every launch.
+struct TapeEntry {
+  std::vector<MesmGemmArgs> args;  // one problem (mesm_gemm_f32) or a group (mesm_gemm_group)
+  std::vector<int> vecs;
+  int n = 1;
+  int group = 0;
+};
 struct Tape {
   bool recording = false;
-  std::vector<std::pair<MesmGemmArgs, int>> launches;  // (args, vec)
+  std::vector<TapeEntry> launches;
 };
 Tape g_tape;
 
@@ -1288,11 +1348,8 @@ int dispatch(const MesmGemmArgs& a, int vec, hipStream_t s) {
   return launch_tile<1>(a, s);
 }
 
-}  // namespace
-
-extern "C" int mesm_gemm_f32(const MesmGemmArgs* args, void* stream) {
-  if (!args) return MESM_EINVAL;
-  MesmGemmArgs a = *args;
+// argument validation / normalisation shared by the single and the grouped entry
+int prepare(MesmGemmArgs& a, int& vec) {
   if (!a.A || !a.B || !a.C) return MESM_EINVAL;
   if (a.M <= 0 || a.N <= 0 || a.K <= 0) return MESM_EINVAL;
   if (a.a_layout < 0 || a.a_layout > 1 || a.b_layout < 0 || a.b_layout > 1) return MESM_EINVAL;
@@ -1314,10 +1371,9 @@ extern "C" int mesm_gemm_f32(const MesmGemmArgs* args, void* stream) {
   }
   if (a.accumulate < 0 || a.accumulate > 2) return MESM_EINVAL;
   if (a.out_scale == 0.0f) a.out_scale = 1.0f;
-  hipStream_t s = (hipStream_t)stream;
   // widest vector width every operand supports
   if (a.A2 && a.B2) return MESM_EINVAL;
-  int vec = 4;
+  vec = 4;
   while (vec > 1) {
     bool ok = (a.lda % vec == 0) && (a.ldb % vec == 0) && aligned_to(a.A, 4 * vec) &&
               aligned_to(a.A2, 4 * vec) && aligned_to(a.B, 4 * vec) && aligned_to(a.B2, 4 * vec);
@@ -1327,8 +1383,87 @@ extern "C" int mesm_gemm_f32(const MesmGemmArgs* args, void* stream) {
     vec >>= 1;
   }
   if (!aligned_to(a.A, 4) || !aligned_to(a.B, 4) || !aligned_to(a.C, 4)) return MESM_EALIGN;
-  if (g_tape.recording) g_tape.launches.emplace_back(a, vec);
-  return dispatch(a, vec, s);
+  return MESM_OK;
+}
+
+// does the auto dispatch send this problem to the wstage kernel (the one that can be grouped)?
+bool groupable(const MesmGemmArgs& a) {
+  const char* env = getenv("MESM_GEMM_TILE");
+  const int force = env ? atoi(env) : 0;
+  if (force != 0 && force != 2) return false;
+  const long z = a.split_k > 1 ? a.split_k : 1;
+  const long b64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * z;
+  return (force == 2 || b64 < 512) && wstage_ok(a);
+}
+
+}  // namespace
+
+extern "C" int mesm_gemm_f32(const MesmGemmArgs* args, void* stream) {
+  if (!args) return MESM_EINVAL;
+  MesmGemmArgs a = *args;
+  int vec = 1;
+  const int rc = prepare(a, vec);
+  if (rc != MESM_OK) return rc;
+  if (g_tape.recording) { TapeEntry e; e.args = {a}; e.vecs = {vec}; g_tape.launches.push_back(e); }
+  return dispatch(a, vec, (hipStream_t)stream);
+}
+
+namespace {
+int launch_group(const MesmGemmArgs* list, const int* vecs, int n, hipStream_t s) {
+  // problems the wstage kernel takes go into grouped launches of up to GROUP_MAX; the rest go alone
+  GroupArgs g;
+  g.n = 0;
+  g.start[0] = 0;
+  int rc = MESM_OK;
+  auto flush = [&]() {
+    if (g.n == 0) return;
+    if (g.n == 1) {
+      rc = launch_wstage(g.p[0], s);
+    } else {
+      hipLaunchKernelGGL(gemm_wstage_group_kernel, dim3(g.start[g.n]), dim3(NTHREADS), 0, s, g);
+      rc = mesm_launch_status();
+      for (int k = 0; k < g.n && rc == MESM_OK; ++k) {
+        const MesmGemmArgs& a = g.p[k];
+        dim3 grid((a.M + 31) / 32, (a.N + 31) / 32, a.split_k > 1 ? a.split_k : 1);
+        rc = dslope_finish(a, grid, s);
+      }
+    }
+    g.n = 0;
+  };
+  for (int i = 0; i < n && rc == MESM_OK; ++i) {
+    const MesmGemmArgs& a = list[i];
+    if (groupable(a)) {
+      const int wgs = ((a.M + 31) / 32) * ((a.N + 31) / 32) * (a.split_k > 1 ? a.split_k : 1);
+      g.p[g.n] = a;
+      g.start[g.n + 1] = g.start[g.n] + wgs;
+      if (++g.n == GROUP_MAX) flush();
+    } else {
+      rc = dispatch(a, vecs[i], s);
+    }
+  }
+  if (rc == MESM_OK) flush();
+  return rc;
+}
+}  // namespace
+
+extern "C" int mesm_gemm_group(const MesmGemmArgs* args, int32_t n, void* stream) {
+  if (!args || n <= 0 || n > 64) return MESM_EINVAL;
+  MesmGemmArgs list[64];
+  int vecs[64];
+  for (int i = 0; i < n; ++i) {
+    list[i] = args[i];
+    const int rc = prepare(list[i], vecs[i]);
+    if (rc != MESM_OK) return rc;
+  }
+  if (g_tape.recording) {
+    TapeEntry e;
+    e.args.assign(list, list + n);
+    e.vecs.assign(vecs, vecs + n);
+    e.group = 1;
+    e.n = n;
+    g_tape.launches.push_back(e);
+  }
+  return launch_group(list, vecs, n, (hipStream_t)stream);
 }
 
 extern "C" int mesm_gemm_tape(int32_t record) {
@@ -1350,18 +1485,20 @@ extern "C" int mesm_gemm_tape_replay(void* stream, int32_t reps, double* total_m
   int rc = MESM_OK;
   for (int r = 0; r < reps && rc == MESM_OK; ++r) {
     hipEventRecord(e0, s);
-    for (size_t i = 0; i < n && rc == MESM_OK; ++i)
-      rc = dispatch(g_tape.launches[i].first, g_tape.launches[i].second, s);
+    for (size_t i = 0; i < n && rc == MESM_OK; ++i) {
+      const TapeEntry& e = g_tape.launches[i];
+      rc = e.group ? launch_group(e.args.data(), e.vecs.data(), e.n, s) : dispatch(e.args[0], e.vecs[0], s);
+    }
     hipEventRecord(e1, s);
     hipStreamSynchronize(s);
     float t = 0.0f;
     hipEventElapsedTime(&t, e0, e1);
     ms += t;
-    for (size_t i = 0; i < n; ++i) {
-      const MesmGemmArgs& a = g_tape.launches[i].first;
-      flops += 2.0 * (double)a.M * (double)a.N * (double)a.K;
-      bytes += 4.0 * ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N);
-    }
+    for (size_t i = 0; i < n; ++i)
+      for (const MesmGemmArgs& a : g_tape.launches[i].args) {
+        flops += 2.0 * (double)a.M * (double)a.N * (double)a.K;
+        bytes += 4.0 * ((double)a.M * a.K + (double)a.K * a.N + (double)a.M * a.N);
+      }
   }
   hipEventDestroy(e0);
   hipEventDestroy(e1);

@@ -13,7 +13,7 @@ from ._lib import (ACT_NONE, ACT_PRELU, ACT_RELU, LAYOUT_OUTER_CONTIG,
                    check, lib, ptr, require_gpu, stream_ptr)
 
 __all__ = [
-    "gemm", "layernorm_fwd", "layernorm_bwd", "attn_fwd", "attn_bwd", "sine_pos",
+    "gemm", "gemm_group", "layernorm_fwd", "layernorm_bwd", "attn_fwd", "attn_bwd", "sine_pos",
     "query_sine_fwd", "query_sine_bwd", "dropout", "act_bias_bwd",
     "ACT_NONE", "ACT_RELU", "ACT_PRELU",
 ]
@@ -109,8 +109,49 @@ def gemm(A, B, C, *, trans_a=False, trans_b=False, A2=None, B2=None, bias=None, 
     g.out_scale = float(out_scale)
     g.accumulate, g.split_k = int(accumulate), int(split_k)
     g.seed_offset = _seed_off_ptr()
+    if _pending is not None:
+        # inside gemm_group(): queued; the tensors stay referenced until the group is launched
+        _pending.append((g, (A, B, C, A2, B2, bias, residual, aux, slope, dslope, colsum,
+                             ws if dslope is not None else None)))
+        return C
     check(lib().mesm_gemm_f32(ctypes.byref(g), stream_ptr()), "mesm_gemm_f32")
     return C
+
+
+_pending = None
+
+
+class gemm_group:
+    """Context manager: the gemm() calls made inside are INDEPENDENT of each other (none reads what
+    another writes; atomic accumulation into the same gradient view is fine) and are issued together
+    on exit through mesm_gemm_group: the small ones share launches of up to 8 problems.  Nothing
+    else may be enqueued inside the block that consumes their outputs."""
+
+    def __enter__(self):
+        global _pending
+        self.outer = _pending
+        if _pending is None:
+            _pending = []
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _pending
+        if self.outer is not None:  # nested: the outermost group launches
+            return False
+        items, _pending = _pending, None
+        if et is None and items:
+            flush_gemms(items)
+        return False
+
+
+def flush_gemms(items):
+    for i in range(0, len(items), 64):
+        chunk = items[i:i + 64]
+        if len(chunk) == 1:
+            check(lib().mesm_gemm_f32(ctypes.byref(chunk[0][0]), stream_ptr()), "mesm_gemm_f32")
+            continue
+        arr = (GemmArgs * len(chunk))(*[c[0] for c in chunk])
+        check(lib().mesm_gemm_group(arr, len(chunk), stream_ptr()), "mesm_gemm_group")
 
 
 def layernorm_fwd(x, gamma, beta, eps=1e-5, drop=(0.0, 0)):

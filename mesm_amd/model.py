@@ -335,11 +335,17 @@ class MESM(nn.Module):
                 encoded2, vid_pad2, self.query_embed.weight, vpos2, self.global_rep_token,
                 self.global_rep_pos, n_dec=N)
         with _scope("heads"):
-            logits = ops.linear(hs, self.class_embed.weight, self.class_embed.bias)
-            spans = torch.sigmoid(self.span_embed(hs) + inverse_sigmoid(refs))
-            # saliency scores (model.py:301-302) for both passes in one go
-            sa = ops.linear(memory2, self.saliency_proj1.weight, self.saliency_proj1.bias)
-            sb = ops.linear(memory_g2, self.saliency_proj2.weight, self.saliency_proj2.bias)
+            # independent projections share one grouped launch: class head, first span-head layer,
+            # and the two saliency projections (model.py:301-302, both passes in one go)
+            l0 = self.span_embed.layers[0]
+            with kn.gemm_group():
+                logits = ops.linear(hs, self.class_embed.weight, self.class_embed.bias)
+                sp = ops.linear(hs, l0.weight, l0.bias, relu=True)
+                sa = ops.linear(memory2, self.saliency_proj1.weight, self.saliency_proj1.bias)
+                sb = ops.linear(memory_g2, self.saliency_proj2.weight, self.saliency_proj2.bias)
+            for i_, l_ in enumerate(self.span_embed.layers[1:], 1):
+                sp = ops.linear(sp, l_.weight, l_.bias, relu=i_ < len(self.span_embed.layers) - 1)
+            spans = torch.sigmoid(sp + inverse_sigmoid(refs))
             sal2 = ops.rowdot(sa, sb, 1.0 / float(np.sqrt(d)))
 
         out.update({"pred_logits": logits[-1], "pred_spans": spans[-1],

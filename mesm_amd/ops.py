@@ -108,12 +108,13 @@ class LinearFn(Function):
             dz = dy2
         gw, wdirect = grad_target(w)
         gb, bdirect = grad_target(b) if b is not None else (None, True)
-        _accum_dw(dz, _2d(x), _rows(gw, rows), _rows(gb, rows) if gb is not None else None,
-                  x2=_2d(x2) if x2 is not None else None, b_drop=ctx.in_drop)
         dx = None
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            dx = torch.empty_like(x)
-            kn.gemm(dz, _rows(w, rows), _2d(dx), e_drop=ctx.in_drop)
+        with kn.gemm_group():  # dW and dX are independent: one launch when both are small
+            _accum_dw(dz, _2d(x), _rows(gw, rows), _rows(gb, rows) if gb is not None else None,
+                      x2=_2d(x2) if x2 is not None else None, b_drop=ctx.in_drop)
+            if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+                dx = torch.empty_like(x)
+                kn.gemm(dz, _rows(w, rows), _2d(dx), e_drop=ctx.in_drop)
         flush_ready()
         return (dx if ctx.needs_input_grad[0] else None,
                 dx if (x2 is not None and ctx.needs_input_grad[1]) else None,
@@ -167,17 +168,19 @@ class FFNFn(Function):
         gw1, d_w1 = grad_target(w1)
         gb1, d_b1 = grad_target(b1)
         gs, d_s = grad_target(slope)
-        _accum_dw(dz2, _2d(h), gw2, gb2)
         dz1 = torch.empty_like(z)
-        kn.gemm(dz2, w2, _2d(dz1), e_drop=ctx.mid_drop, aux=_2d(z), e_actgrad=ACT_PRELU,
-                slope=slope, dslope=gs)
-        _accum_dw(_2d(dz1), _2d(x), gw1, gb1)
+        with kn.gemm_group():
+            _accum_dw(dz2, _2d(h), gw2, gb2)
+            kn.gemm(dz2, w2, _2d(dz1), e_drop=ctx.mid_drop, aux=_2d(z), e_actgrad=ACT_PRELU,
+                    slope=slope, dslope=gs)
         dx = None
         fold_res = ctx.res_is_x and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            # residual input IS x: its gradient (dy) rides the epilogue of the dX GEMM
-            kn.gemm(_2d(dz1), w1, _2d(dx), residual=dy2 if fold_res else None)
+        with kn.gemm_group():
+            _accum_dw(_2d(dz1), _2d(x), gw1, gb1)
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                # residual input IS x: its gradient (dy) rides the epilogue of the dX GEMM
+                kn.gemm(_2d(dz1), w1, _2d(dx), residual=dy2 if fold_res else None)
         flush_ready()
         return (dx, dy if ctx.has_res and ctx.needs_input_grad[1] and not fold_res else None,
                 None if d_w1 else gw1, None if d_b1 else gb1, None if d_s else gs,
@@ -316,9 +319,10 @@ class MHAFn(Function):
         gbo, d_bo = grad_target(b_out)
         gwi, d_wi = grad_target(w_in)
         gbi, d_bi = grad_target(b_in)
-        _accum_dw(dz, _2d(o), gwo, gbo)
         do = torch.empty_like(o)
-        kn.gemm(dz, w_out, _2d(do))
+        with kn.gemm_group():
+            _accum_dw(dz, _2d(o), gwo, gbo)
+            kn.gemm(dz, w_out, _2d(do))
         need_q, need_pq = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         need_k, need_pk = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
         fold_res = ctx.res_is_xq and need_q and ctx.needs_input_grad[4]
@@ -329,13 +333,15 @@ class MHAFn(Function):
             kn.attn_bwd_into(do, q, k, v, o, lse, H, dqkv[..., :d], dqkv[..., d:2 * d],
                              dqkv[..., 2 * d:], kpad=kpad, qpad=qpad, drop=attn_drop, group=group)
             g2 = _2d(dqkv)
-            _accum_dw(g2[:, :2 * d], _2d(xq), gwi[:2 * d], gbi[:2 * d],
-                      x2=_2d(pq) if pq is not None else None)
-            _accum_dw(g2[:, 2 * d:], _2d(xq), gwi[2 * d:], gbi[2 * d:])
+            with kn.gemm_group():
+                _accum_dw(g2[:, :2 * d], _2d(xq), gwi[:2 * d], gbi[:2 * d],
+                          x2=_2d(pq) if pq is not None else None)
+                _accum_dw(g2[:, 2 * d:], _2d(xq), gwi[2 * d:], gbi[2 * d:])
+                if need_q or need_pq:
+                    dqk_in = torch.empty_like(xq)  # gradient of (xq + pq) through q and k
+                    early = fold_res and not need_pq  # residual input IS xq: dy rides this epilogue
+                    kn.gemm(g2[:, :2 * d], w_in[:2 * d], _2d(dqk_in), residual=dy2 if early else None)
             if need_q or need_pq:
-                dqk_in = torch.empty_like(xq)  # gradient of (xq + pq) through q and k
-                early = fold_res and not need_pq  # residual input IS xq: dy rides this epilogue
-                kn.gemm(g2[:, :2 * d], w_in[:2 * d], _2d(dqk_in), residual=dy2 if early else None)
                 if need_pq:
                     dpq = dqk_in
                 if need_q:
@@ -349,35 +355,40 @@ class MHAFn(Function):
             dkv = torch.empty(N, Lk, 2 * d, device=dev, dtype=torch.float32)
             kn.attn_bwd_into(do, q, k, v, o, lse, H, dq, dkv[..., :d], dkv[..., d:], kpad=kpad,
                              qpad=qpad, drop=attn_drop, group=group)
-            _accum_dw(_2d(dq), _2d(xq), gwi[:d], gbi[:d], x2=_2d(pq) if pq is not None else None)
             g2 = _2d(dkv)
-            if pk is None:
-                _accum_dw(g2, _2d(xk), gwi[d:], gbi[d:])
-            else:
-                _accum_dw(g2[:, :d], _2d(xk), gwi[d:2 * d], gbi[d:2 * d], x2=_2d(pk))
-                _accum_dw(g2[:, d:], _2d(xk), gwi[2 * d:], gbi[2 * d:])
-            if need_q or need_pq:
-                dxq = torch.empty_like(xq)
-                if fold_res and not need_pq:
-                    # the residual input IS xq: its gradient (dy) rides the epilogue of this GEMM
-                    kn.gemm(_2d(dq), w_in[:d], _2d(dxq), residual=dy2)
+            add_dy = False
+            with kn.gemm_group():  # dWq, dWkv, dX(query side), dX(key side): all independent
+                _accum_dw(_2d(dq), _2d(xq), gwi[:d], gbi[:d], x2=_2d(pq) if pq is not None else None)
+                if pk is None:
+                    _accum_dw(g2, _2d(xk), gwi[d:], gbi[d:])
                 else:
-                    kn.gemm(_2d(dq), w_in[:d], _2d(dxq))
-                    if fold_res:
-                        dxq = dxq + dy
+                    _accum_dw(g2[:, :d], _2d(xk), gwi[d:2 * d], gbi[d:2 * d], x2=_2d(pk))
+                    _accum_dw(g2[:, d:], _2d(xk), gwi[2 * d:], gbi[2 * d:])
+                if need_q or need_pq:
+                    dxq = torch.empty_like(xq)
+                    if fold_res and not need_pq:
+                        # the residual input IS xq: its gradient (dy) rides the epilogue of this GEMM
+                        kn.gemm(_2d(dq), w_in[:d], _2d(dxq), residual=dy2)
+                    else:
+                        kn.gemm(_2d(dq), w_in[:d], _2d(dxq))
+                        add_dy = fold_res
+                if need_k or need_pk:
+                    if pk is None:
+                        dxk = torch.empty_like(xk)
+                        kn.gemm(g2, w_in[d:], _2d(dxk))
+                    else:
+                        dk_in = torch.empty_like(xk)
+                        kn.gemm(g2[:, :d], w_in[d:2 * d], _2d(dk_in))
+            if need_q or need_pq:
+                if add_dy:
+                    dxq = dxq + dy
                 dpq = dxq if need_pq else None
                 dxq = dxq if need_q else None
-            if need_k or need_pk:
-                if pk is None:
+            if (need_k or need_pk) and pk is not None:
+                dpk = dk_in if need_pk else None
+                if need_k:
                     dxk = torch.empty_like(xk)
-                    kn.gemm(g2, w_in[d:], _2d(dxk))
-                else:
-                    dk_in = torch.empty_like(xk)
-                    kn.gemm(g2[:, :d], w_in[d:2 * d], _2d(dk_in))
-                    dpk = dk_in if need_pk else None
-                    if need_k:
-                        dxk = torch.empty_like(xk)
-                        kn.gemm(g2[:, d:], w_in[2 * d:], _2d(dxk), residual=_2d(dk_in))
+                    kn.gemm(g2[:, d:], w_in[2 * d:], _2d(dxk), residual=_2d(dk_in))
         flush_ready()
         return (dxq, dpq, dxk, dpk, dy if has_res and ctx.needs_input_grad[4] and not fold_res else None,
                 None if d_wi else gwi, None if d_bi else gbi, None if d_wo else gwo,

@@ -558,6 +558,53 @@ def test_gemm_fuzz():
         _gemm_fuzz_case(rng, kn)
 
 
+def test_gemm_group_matches_individual_launches():
+    """mesm_gemm_group: independent problems of mixed shapes, layouts and fusions (small ones share
+    launches, large / addend ones fall through) give exactly what the single launches give."""
+    import random
+    from mesm_amd import kernels as kn
+    rng = random.Random(99)
+    slope = torch.tensor([0.25], device=dev())
+    for rep in range(6):
+        calls = []
+        for k in range(rng.choice([2, 5, 11])):
+            M = rng.choice([32, 320, 1024, 2400, 4800]); N = rng.choice([4, 256, 512, 1024]); K = rng.choice([64, 256, 320, 1024])
+            ta, tb = rng.random() < 0.4, rng.random() < 0.5
+            A = gen((K, M) if ta else (M, K), rng.randrange(10 ** 6))
+            B = gen((N, K) if tb else (K, N), rng.randrange(10 ** 6), 0.1)
+            kw = dict(trans_a=ta, trans_b=tb)
+            r = rng.random()
+            if r < 0.2: kw["bias"] = gen((N,), 5)
+            elif r < 0.4: kw.update(residual=gen((M, N), 6), e_drop=(0.1, 9))
+            elif r < 0.55: kw.update(aux=gen((M, N), 7), e_actgrad=kn.ACT_PRELU, slope=slope, dslope=torch.zeros(1, device=dev()))
+            elif r < 0.7 and ta: kw.update(split_k=4, accumulate=2, colsum=torch.zeros(M, device=dev()))
+            elif r < 0.8 and not ta: kw["A2"] = gen((M, K), 8)
+            calls.append((A, B, kw))
+        outs1, outs2, side1, side2 = [], [], [], []
+        for A, B, kw in calls:
+            kw1 = {k_: (v.clone() if k_ in ("colsum", "dslope") else v) for k_, v in kw.items()}
+            M = A.shape[1] if kw["trans_a"] else A.shape[0]
+            N = B.shape[0] if kw["trans_b"] else B.shape[1]
+            C = torch.zeros(M, N, device=dev())
+            kn.gemm(A, B, C, **kw1)
+            outs1.append(C); side1.append([kw1.get("colsum"), kw1.get("dslope")])
+        with kn.gemm_group():
+            for A, B, kw in calls:
+                kw2 = {k_: (v.clone() if k_ in ("colsum", "dslope") else v) for k_, v in kw.items()}
+                M = A.shape[1] if kw["trans_a"] else A.shape[0]
+                N = B.shape[0] if kw["trans_b"] else B.shape[1]
+                C = torch.zeros(M, N, device=dev())
+                kn.gemm(A, B, C, **kw2)
+                outs2.append(C); side2.append([kw2.get("colsum"), kw2.get("dslope")])
+        torch.cuda.synchronize()
+        for a, b in zip(outs1, outs2):
+            assert rel_err(b, a) < 1e-5
+        for sa, sb in zip(side1, side2):
+            for x, y in zip(sa, sb):
+                if x is not None:
+                    assert rel_err(y, x) < 1e-4
+
+
 @pytest.mark.parametrize("tile", ["1", "2", "3"])
 def test_gemm_fuzz_forced_kernel(tile, monkeypatch):
     """The same fuzz with every launch forced onto one of the small-problem / LDS-DMA kernels
