@@ -120,12 +120,32 @@ class MESM(nn.Module):
                                                 transformer.dim_feedforward, transformer.dropout)
         self._gradbuf = None
         self._step = 0
+        # run the FW-MESM masked-word branch on a second HIP stream (mesm_amd/sidecall.py).  Off by
+        # default: correct (tests run both ways) but the captured graph executes it serially on
+        # ROCm 7.2 (tools/side_probe.py), although plain two-branch graphs do overlap
+        # (tools/probe_graph_par.py) -- kept as the place to continue from
+        self.side_streams = os.environ.get("MESM_SIDE_STREAMS", "0") == "1"
+        self._branches = {}
 
     # ------------------------------------------------------------------ infrastructure
     def gradbuf(self):
         if self._gradbuf is None:
             self._gradbuf = GradBuffer([(n, p) for n, p in self.named_parameters() if p.requires_grad])
         return self._gradbuf
+
+    def _branch(self, name, device):
+        from .sidecall import Branch
+        key = (name, device)
+        br = self._branches.get(key)
+        if br is None:
+            gb = self.gradbuf()
+
+            def on_fork():  # the flat gradient buffer must be zeroed on the MAIN stream before the fork
+                if gb.pending:
+                    gb._open()
+            br = self._branches[key] = Branch(device, on_fork)
+        br.in_grads.clear()
+        return br
 
     def _begin(self, device, is_training):
         if not device.type == "cuda":
@@ -281,6 +301,17 @@ class MESM(nn.Module):
             pw = self._proj(self.input_txt_proj, words)
             vpos = kn.sine_pos(video_mask, d)
 
+        mlm_side = self.side_streams and self.rec_fw and is_training and torch.is_grad_enabled()
+        if mlm_side:
+            # FW-MESM masked-word branch: depends on pv / pw only and feeds only the criterion, so it
+            # runs on a second stream next to the whole main path, forward and backward (sidecall.py);
+            # the JoinGrad blocks are created HERE so that their backward (the join) runs last
+            from .sidecall import JoinGrad
+            mlm_br = self._branch("mlm", dev)
+            mlm_br.mark_fork()
+            pv_mlm = JoinGrad.apply(pv, mlm_br, 0)
+            pw_mlm = JoinGrad.apply(pw, mlm_br, 1)
+
         # The positive and the negative pass (model.py:260-299) run the SAME weights over the same
         # video with different queries: they are stacked along the batch (rows [0, N) positive,
         # [N, 2N) negative) so every layer is one launch over 2N rows instead of two over N --
@@ -355,18 +386,28 @@ class MESM(nn.Module):
 
         if self.rec_fw and is_training:
             # FW-MESM masked-language-model branch (model.py:307-332)
-            with _scope("mlm"):
-                unk = self._proj(self.input_txt_proj, self.unknown_token.view(1, 1, -1))
-                msk = self._proj(self.input_txt_proj, self.masked_token.view(1, 1, -1))
-                w = torch.where(kwargs["unknown_mask"].unsqueeze(-1), unk, pw)
-                w = torch.where(plan.masked_words.unsqueeze(-1), msk, w)
-                cfeat = ops.gather_rows(pv.reshape(N * Lv, d), plan.clip_src) * plan.clip_mask.unsqueeze(-1)
-                cpos = vpos.reshape(N * Lv, d)[plan.clip_src] * plan.clip_mask.unsqueeze(-1)
-                rec_w = enc(cfeat, w, cpos, None, plan.clip_pad, words_pad, is_mlm=True)
-                hid = self.output_txt_proj[0](rec_w)
-                head = self.output_txt_proj[1]
-                out["recfw_words_logit"] = ops.linear(hid, head.weight, head.bias)
-                out["words_mask"] = words_mask
+            def mlm_branch(pv_, pw_):
+                with _scope("mlm"):
+                    unk = self._proj(self.input_txt_proj, self.unknown_token.view(1, 1, -1))
+                    msk = self._proj(self.input_txt_proj, self.masked_token.view(1, 1, -1))
+                    w = torch.where(kwargs["unknown_mask"].unsqueeze(-1), unk, pw_)
+                    w = torch.where(plan.masked_words.unsqueeze(-1), msk, w)
+                    cfeat = ops.gather_rows(pv_.reshape(N * Lv, d), plan.clip_src) * plan.clip_mask.unsqueeze(-1)
+                    cpos = vpos.reshape(N * Lv, d)[plan.clip_src] * plan.clip_mask.unsqueeze(-1)
+                    rec_w = enc(cfeat, w, cpos, None, plan.clip_pad, words_pad, is_mlm=True)
+                    hid = self.output_txt_proj[0](rec_w)
+                    head = self.output_txt_proj[1]
+                    return ops.linear(hid, head.weight, head.bias)
+
+            if mlm_side:
+                from .sidecall import side_call
+                for t_ in (vpos, words_pad, kwargs["unknown_mask"]):
+                    t_.record_stream(mlm_br.stream)
+                (out["recfw_words_logit"],) = side_call(mlm_br, mlm_branch, [(0, pv_mlm), (1, pw_mlm)])
+                torch.cuda.current_stream().wait_event(mlm_br.done_fwd)  # join: the criterion is next
+            else:
+                out["recfw_words_logit"] = mlm_branch(pv, pw)
+            out["words_mask"] = words_mask
         if self.rec_ss:
             out.update({"projed_video_feat": pv, "recon_feat": recon, "projed_recon_feat": projed_recon,
                         "expanded_words_feat": ewords, "expanded_words_mask": emask,

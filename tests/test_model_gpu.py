@@ -210,3 +210,27 @@ def test_against_cpu_oracle_at_reference_width(dataset, groups, Lv, Lw, ragged):
     assert loose[0] < 5e-2, loose
     worst2 = max((l2(grads[k], g), k) for k, g in o_grads.items())
     assert worst2[0] < 1e-2, worst2
+
+
+def test_side_stream_branch_gives_the_same_step():
+    """The explicit fork/join of the masked-word branch onto a second HIP stream (sidecall.py) changes
+    nothing: same loss, same gradients as the single-stream step."""
+    import argparse
+    from mesm_amd import synthetic
+    fx = Fixture("qvh_tiny")
+    res = []
+    for side in (False, True):
+        _, model, crit = build(fx.cfg, fx.sd)
+        model.eval()
+        model.side_streams = side
+        batch = synthetic.to_device(fx.batch, dev())
+        out = model(**batch, dataset_name=fx.cfg["dataset_name"], is_training=True,
+                    neg_index=fx.neg_index, masked_words=fx.masked_words)
+        _, total = crit(out, batch, True)
+        total.backward()
+        torch.cuda.synchronize()
+        res.append((float(total), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+    assert abs(res[0][0] - res[1][0]) < 1e-6 * max(1.0, abs(res[0][0]))
+    assert set(res[0][1]) == set(res[1][1])
+    for n, g in res[0][1].items():
+        assert rel(res[1][1][n], g) < 1e-4, n

@@ -10,7 +10,7 @@ from mesm_amd import _lib, build_criterion, build_model, synthetic
 from mesm_amd.graphed import GraphedStep
 
 FAMILIES = {
-    "gemm": ["mesm_gemm_f32"],
+    "gemm": ["mesm_gemm_f32", "mesm_gemm_group"],
     "attn": ["mesm_attn_fwd", "mesm_attn_bwd"],
     "ln": ["mesm_layernorm_fwd", "mesm_layernorm_bwd"],
     "loss": ["mesm_set_loss_fwd", "mesm_set_loss_bwd", "mesm_rec_ss_fwd", "mesm_rec_ss_bwd", "mesm_rec_fw_reduce",

@@ -93,9 +93,78 @@ def fork_only():
     return body
 
 
+def early_event_late_enqueue():
+    """main: g0, record ev, g1..g31; THEN side (waits ev): g32..g63; join.  Same dependencies as two
+    branches forked after g0, but the side work is enqueued after the main work in host order."""
+    side = torch.cuda.Stream()
+
+    def body():
+        cur = torch.cuda.current_stream()
+        g(0)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        for i in range(1, NL // 2):
+            g(i)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            for i in range(NL // 2, NL):
+                g(i)
+        cur.wait_stream(side)
+    return body
+
+
+def interleaved_enqueue():
+    """same graph, but host enqueue alternates between the two streams"""
+    side = torch.cuda.Stream()
+
+    def body():
+        cur = torch.cuda.current_stream()
+        g(0)
+        side.wait_stream(cur)
+        for i in range(1, NL // 2):
+            g(i)
+            with torch.cuda.stream(side):
+                g(NL // 2 + i)
+        cur.wait_stream(side)
+    return body
+
+
+def branches_with(kind):
+    """2 branches whose every step also enqueues an ATen op of a given kind"""
+    side = torch.cuda.Stream()
+    buf = [torch.zeros(M, N, device=dev) for _ in range(2)]
+
+    def extra(b):
+        if kind == "zeros":
+            torch.zeros(M, N, device=dev)
+        elif kind == "zero_":
+            buf[b].zero_()
+        elif kind == "copy":
+            buf[b].copy_(C[b])
+        elif kind == "add":
+            buf[b].add_(C[b])
+        elif kind == "empty":
+            torch.empty(M, N, device=dev)
+
+    def body():
+        cur = torch.cuda.current_stream()
+        side.wait_stream(cur)
+        for i in range(NL // 2):
+            g(i); extra(0)
+        with torch.cuda.stream(side):
+            for i in range(NL // 2, NL):
+                g(i); extra(1)
+        cur.wait_stream(side)
+    return body
+
+
 print("shape", M, N, K)
 print("serial 64           : %8.1f us" % timeit(capture(serial)))
 for nb in (2, 4, 8):
     print("%d branches          : %8.1f us" % (nb, timeit(capture(branches(nb)))))
 print("fork+join each pair : %8.1f us" % timeit(capture(forkjoin_each())))
 print("fork each, join end : %8.1f us" % timeit(capture(fork_only())))
+for kind in ("empty", "add", "zero_", "zeros", "copy"):
+    print("2 branches + %-6s per step: %8.1f us" % (kind, timeit(capture(branches_with(kind)))))
+print("early event, late enqueue: %8.1f us" % timeit(capture(early_event_late_enqueue())))
+print("interleaved enqueue      : %8.1f us" % timeit(capture(interleaved_enqueue())))
