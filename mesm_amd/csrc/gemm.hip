@@ -594,6 +594,66 @@ __device__ __forceinline__ void ksplit_epilogue(const MesmGemmArgs& p, const f32
   if (p.e_actgrad == MESM_ACT_PRELU && p.dslope) dslope_store(p, dslope_part, Red, slot);
 }
 
+// Epilogue of ONE wave-owned 32 x 32 tile held in 16 accumulator registers (register r <-> row
+// 4h + (r & 3) + 8 (r >> 2), column lane & 31): bias / activation / dropout / activation-gradient /
+// residual / accumulate, side loads issued in groups of four rows.
+__device__ __forceinline__ void tile16_epilogue(const MesmGemmArgs& p, const f32x16& acc, int row0, int col0,
+                                                float slope, uint32_t seed_off, int bz, float* sh4,
+                                                int64_t slot) {
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 31, h = lane >> 5;
+  const bool first_split = (p.split_k <= 1) || (bz == 0);
+  const uint32_t e_thresh = p.e_drop_p > 0.f ? mesm_drop_threshold(p.e_drop_p) : 0u;
+  const float e_inv_keep = 1.0f / (1.0f - p.e_drop_p);
+  const bool use_bias = p.bias != nullptr && first_split;
+  const bool use_res = p.residual != nullptr && first_split;
+  const bool use_aux = p.e_actgrad != MESM_ACT_NONE;
+  const bool rmw = p.accumulate == 1;
+  float dslope_part = 0.0f;
+  const int col = col0 + li;
+  const bool colok = col < p.N;
+  const int colc = colok ? col : p.N - 1;
+  const int rbase = row0 + 4 * h;
+  const float bias_v = use_bias ? p.bias[colc] : 0.0f;
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    float resv[4], auxv[4], oldv[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      int row = rbase + rr + 8 * g4;
+      row = row < p.M ? row : p.M - 1;
+      resv[rr] = use_res ? p.residual[(int64_t)row * p.ldr + colc] : 0.0f;
+      auxv[rr] = use_aux ? p.aux[(int64_t)row * p.ldaux + colc] : 0.0f;
+      oldv[rr] = rmw ? p.C[(int64_t)row * p.ldc + colc] : 0.0f;
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int row = rbase + rr + 8 * g4;
+      float t = acc[4 * g4 + rr] * p.out_scale + bias_v;
+      t = mesm_act(t, p.e_act, slope);
+      if (e_thresh)
+        t = mesm_dropout_apply(t, (uint32_t)((int64_t)row * p.N + col), p.e_drop_seed + seed_off, e_thresh,
+                               e_inv_keep);
+      if (use_aux) {
+        const float z = auxv[rr];
+        if (p.e_actgrad == MESM_ACT_RELU) {
+          t = z > 0.0f ? t : 0.0f;
+        } else if (z <= 0.0f) {
+          if (row < p.M && colok) dslope_part += t * z;
+          t *= slope;
+        }
+      }
+      t += resv[rr] + oldv[rr];
+      if (row < p.M && colok) {
+        float* c = p.C + (int64_t)row * p.ldc + col;
+        if (p.accumulate == 2) atomicAdd(c, t);
+        else *c = t;
+      }
+    }
+  }
+  if (p.e_actgrad == MESM_ACT_PRELU && p.dslope) dslope_store(p, dslope_part, sh4, slot);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Small-problem kernel ("frag"): one 32x32 output tile per workgroup, the reduce range split over
 // the four waves, MFMA operand fragments loaded STRAIGHT from global memory into registers -- no
@@ -1089,6 +1149,184 @@ bool wstage_ok(const MesmGemmArgs& a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// "wstage64": the k-split idea on a 64 x 64 tile.  Each of the four waves computes the WHOLE tile
+// (2 x 2 accumulators) over its quarter of the reduce range, staged wave-privately by LDS-DMA like
+// wstage.  Per 32-deep stage a wave loads 16 KB and issues 64 MFMAs (wstage: 8 KB for 16), so the
+// L2 traffic per flop halves and one stage of MFMAs (4096 cycles) covers the latency of the next
+// stage's loads: a single LDS buffer per wave suffices, because all fragments of a stage are in
+// registers before its refill is issued.  Used when the problem has enough 64 x 64 tiles to occupy
+// the chip (the 2400- and 4800-row d x d GEMMs, the split-K weight gradients).
+template <int LA, int LB, bool XF>
+__device__ __forceinline__ void wstage64_body(const MesmGemmArgs& p, const Blk blk, float* L) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int m0 = blk.x * 64, n0 = blk.y * 64;
+
+  int kbeg = 0, kend = p.K;
+  if (p.split_k > 1) {
+    int chunk = (p.K + p.split_k - 1) / p.split_k;
+    chunk = ((chunk + BK_MAX - 1) / BK_MAX) * BK_MAX;
+    kbeg = blk.z * chunk;
+    kend = kbeg + chunk < p.K ? kbeg + chunk : p.K;
+    if (kbeg >= p.K) return;
+  }
+  const int kw = (((kend - kbeg + 3) >> 2) + 31) & ~31;
+  const int k0 = kbeg + wave * kw;
+  const int k1 = k0 + kw < kend ? k0 + kw : kend;
+  const int nst = k1 > k0 ? (k1 - k0 + 31) >> 5 : 0;
+
+  const float slope = p.slope ? *p.slope : 0.0f;
+  const uint32_t seed_off = p.seed_offset ? *p.seed_offset : 0u;
+  XForm xa, xb;
+  xa.act = p.a_act; xa.slope = slope; xa.thresh = p.a_drop_p > 0.f ? mesm_drop_threshold(p.a_drop_p) : 0u;
+  xa.seed = p.a_drop_seed + seed_off; xa.inv_keep = 1.0f / (1.0f - p.a_drop_p);
+  xa.lld = LA == MESM_LAYOUT_REDUCE_CONTIG ? p.K : p.M;
+  xb.act = p.b_act; xb.slope = slope; xb.thresh = p.b_drop_p > 0.f ? mesm_drop_threshold(p.b_drop_p) : 0u;
+  xb.seed = p.b_drop_seed + seed_off; xb.inv_keep = 1.0f / (1.0f - p.b_drop_p);
+  xb.lld = LB == MESM_LAYOUT_REDUCE_CONTIG ? p.K : p.N;
+
+  float* mine = L + wave * (4 * WS_SLAB);  // A rows 0-31, A rows 32-63, B rows 0-31, B rows 32-63
+  auto issue = [&](int st) {
+    const int kb = k0 + 32 * st;
+    ws_issue<LA>(p.A, p.lda, m0, p.M, kb, k1, mine, lane);
+    ws_issue<LA>(p.A, p.lda, m0 + 32, p.M, kb, k1, mine + WS_SLAB, lane);
+    ws_issue<LB>(p.B, p.ldb, n0, p.N, kb, k1, mine + 2 * WS_SLAB, lane);
+    ws_issue<LB>(p.B, p.ldb, n0 + 32, p.N, kb, k1, mine + 3 * WS_SLAB, lane);
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  float csum[2] = {0.0f, 0.0f};
+  const bool do_colsum = (p.colsum != nullptr) && (blk.y == 0);
+
+  if (nst > 0) issue(0);
+  for (int st = 0; st < nst; ++st) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float a[2][4][4], b[2][4][4];
+    ws_read<LA>(mine, li, h, a[0]);
+    ws_read<LA>(mine + WS_SLAB, li, h, a[1]);
+    ws_read<LB>(mine + 2 * WS_SLAB, li, h, b[0]);
+    ws_read<LB>(mine + 3 * WS_SLAB, li, h, b[1]);
+    const int kb = k0 + 32 * st;
+    if (st + 1 < nst) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments are in registers: refill the slabs
+      issue(st + 1);
+    }
+    if (kb + 32 > k1) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool ok = kb + 8 * s_ + 4 * h + j < k1;
+            a[t][s_][j] = ok ? a[t][s_][j] : 0.0f;
+            b[t][s_][j] = ok ? b[t][s_][j] : 0.0f;
+          }
+    }
+    if (XF) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int gk = kb + 8 * s_ + 4 * h + j;
+            const int gm = m0 + 32 * t + li, gn = n0 + 32 * t + li;
+            float x = mesm_act(a[t][s_][j], xa.act, xa.slope);
+            if (xa.thresh)
+              x = mesm_dropout_apply(x, (uint32_t)(LA == MESM_LAYOUT_REDUCE_CONTIG ? (int64_t)gm * xa.lld + gk : (int64_t)gk * xa.lld + gm),
+                                     xa.seed, xa.thresh, xa.inv_keep);
+            a[t][s_][j] = x;
+            float y = mesm_act(b[t][s_][j], xb.act, xb.slope);
+            if (xb.thresh)
+              y = mesm_dropout_apply(y, (uint32_t)(LB == MESM_LAYOUT_REDUCE_CONTIG ? (int64_t)gn * xb.lld + gk : (int64_t)gk * xb.lld + gn),
+                                     xb.seed, xb.thresh, xb.inv_keep);
+            b[t][s_][j] = y;
+          }
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+          for (int tj = 0; tj < 2; ++tj)
+            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti][s_][j], b[tj][s_][j], acc[ti][tj], 0, 0, 0);
+    if (do_colsum) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) csum[t] += a[t][s_][j];
+    }
+  }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+
+  if (do_colsum) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float c = csum[t] + __shfl_xor(csum[t], 32, 64);
+      const int gm = m0 + 32 * t + li;
+      if (h == 0 && gm < p.M && c != 0.0f) atomicAdd(p.colsum + gm, c);
+    }
+  }
+  __syncthreads();  // every wave is done with its slabs: the reduction buffer aliases them
+  // the four partial 64 x 64 tiles meet in LDS; wave w then owns sub-tile (w >> 1, w & 1)
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) L[((wave * 4 + ti * 2 + tj) * 16 + r) * 64 + lane] = acc[ti][tj][r];
+  __syncthreads();
+  f32x16 sum;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float t = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) t += L[((w * 4 + wave) * 16 + r) * 64 + lane];
+    sum[r] = t;
+  }
+  __syncthreads();  // dslope_store reuses the head of L
+  tile16_epilogue(p, sum, m0 + 32 * (wave >> 1), n0 + 32 * (wave & 1), slope, seed_off, blk.z, L, blk.slot);
+}
+
+template <int LA, int LB, bool XF>
+__global__ __launch_bounds__(NTHREADS) void gemm_wstage64_kernel(const MesmGemmArgs p) {
+  __shared__ __attribute__((aligned(16))) float L[WS_LDS_FLOATS];  // 4 waves x 4 slabs = 64 KB
+  Blk blk;
+  blk.x = blockIdx.x; blk.y = blockIdx.y; blk.z = blockIdx.z; blk.slot = linear_block();
+  wstage64_body<LA, LB, XF>(p, blk, L);
+}
+
+template <int LA, int LB>
+int launch_wstage64_l(const MesmGemmArgs& a, hipStream_t s) {
+  dim3 grid((a.M + 63) / 64, (a.N + 63) / 64, a.split_k > 1 ? a.split_k : 1);
+  const bool xf = a.a_act != MESM_ACT_NONE || a.b_act != MESM_ACT_NONE || a.a_drop_p > 0.f || a.b_drop_p > 0.f;
+  if (xf) hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, true>), grid, dim3(NTHREADS), 0, s, a);
+  else hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, false>), grid, dim3(NTHREADS), 0, s, a);
+  const int rc = mesm_launch_status();
+  return rc != MESM_OK ? rc : dslope_finish(a, grid, s);
+}
+
+int launch_wstage64(const MesmGemmArgs& a, hipStream_t s) {
+  constexpr int R = MESM_LAYOUT_REDUCE_CONTIG, O = MESM_LAYOUT_OUTER_CONTIG;
+  if (a.a_layout == R && a.b_layout == R) return launch_wstage64_l<R, R>(a, s);
+  if (a.a_layout == R && a.b_layout == O) return launch_wstage64_l<R, O>(a, s);
+  if (a.a_layout == O && a.b_layout == O) return launch_wstage64_l<O, O>(a, s);
+  return launch_wstage64_l<O, R>(a, s);
+}
+
+// ------------------------------------------------------------------------------------------------
 // "lds64" kernel for the large GEMMs of the step (FFN 4800 x 1024 x 256 and transposes, the 2818-wide
 // input projections, the vocabulary head): 64 x 64 tile, 2 x 2 waves of 32 x 32, k-tiles of 32 staged
 // by LDS-DMA in full 128-byte lines into a 3-deep ring (48 KB: three workgroups per CU), ONE raw
@@ -1243,57 +1481,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_lds64_kernel(const MesmGemmArgs
     if (h == 0 && gm < p.M && csum != 0.0f) atomicAdd(p.colsum + gm, csum);
   }
 
-  // ---- epilogue: this wave's 32 x 32 tile (accumulator register r <-> row 4h + (r & 3) + 8 (r >> 2)) ----
-  const bool first_split = (p.split_k <= 1) || (blockIdx.z == 0);
-  const uint32_t e_thresh = p.e_drop_p > 0.f ? mesm_drop_threshold(p.e_drop_p) : 0u;
-  const float e_inv_keep = 1.0f / (1.0f - p.e_drop_p);
-  const bool use_bias = p.bias != nullptr && first_split;
-  const bool use_res = p.residual != nullptr && first_split;
-  const bool use_aux = p.e_actgrad != MESM_ACT_NONE;
-  const bool rmw = p.accumulate == 1;
-  float dslope_part = 0.0f;
-  const int col = n0 + 32 * wn + li;
-  const bool colok = col < p.N;
-  const int colc = colok ? col : p.N - 1;
-  const int rbase = m0 + 32 * wm + 4 * h;
-  const float bias_v = use_bias ? p.bias[colc] : 0.0f;
-#pragma unroll
-  for (int g4 = 0; g4 < 4; ++g4) {  // groups of 4 rows: side loads of a group are issued together
-    float resv[4], auxv[4], oldv[4];
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      int row = rbase + rr + 8 * g4;
-      row = row < p.M ? row : p.M - 1;
-      resv[rr] = use_res ? p.residual[(int64_t)row * p.ldr + colc] : 0.0f;
-      auxv[rr] = use_aux ? p.aux[(int64_t)row * p.ldaux + colc] : 0.0f;
-      oldv[rr] = rmw ? p.C[(int64_t)row * p.ldc + colc] : 0.0f;
-    }
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int row = rbase + rr + 8 * g4;
-      float t = acc[4 * g4 + rr] * p.out_scale + bias_v;
-      t = mesm_act(t, p.e_act, slope);
-      if (e_thresh)
-        t = mesm_dropout_apply(t, (uint32_t)((int64_t)row * p.N + col), p.e_drop_seed + seed_off, e_thresh,
-                               e_inv_keep);
-      if (use_aux) {
-        const float z = auxv[rr];
-        if (p.e_actgrad == MESM_ACT_RELU) {
-          t = z > 0.0f ? t : 0.0f;
-        } else if (z <= 0.0f) {
-          if (row < p.M && colok) dslope_part += t * z;
-          t *= slope;
-        }
-      }
-      t += resv[rr] + oldv[rr];
-      if (row < p.M && colok) {
-        float* c = p.C + (int64_t)row * p.ldc + col;
-        if (p.accumulate == 2) atomicAdd(c, t);
-        else *c = t;
-      }
-    }
-  }
-  if (p.e_actgrad == MESM_ACT_PRELU && p.dslope) dslope_store(p, dslope_part, L, linear_block());
+  tile16_epilogue(p, acc, m0 + 32 * wm, n0 + 32 * wn, slope, seed_off, blockIdx.z, L, linear_block());
 }
 
 template <int LA, int LB>
@@ -1338,8 +1526,15 @@ int dispatch(const MesmGemmArgs& a, int vec, hipStream_t s) {
     const long b64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * z;
     const int force = env ? atoi(env) : 0;  // 1 = frag kernel, 32 | 64 | 128 = staged tile, 0 = auto
     // 1 = frag, 2 = wstage (k-split 32x32, wave-private LDS-DMA), 3 = lds64 (64x64, LDS-DMA ring),
+    // 4 = wstage64 (k-split 64x64),
     // 32 | 64 | 128 = register-staged tile, 0 = auto
     if ((force == 3 || (force == 0 && b64 >= 512)) && wstage_ok(a)) return launch_lds64(a, s);
+    // k-split 64 x 64 (half the L2 traffic per flop): wins only when its workgroups fit ONE round on the
+    // 256 CUs (300 workgroups = two rounds: 4800 x 256 x 1024 59 us vs 43 us with 32 x 32 tiles) and a
+    // wave has >= 4 stages to pipeline: the split-K FFN weight gradients and the 2400-row K = 1024 GEMMs
+    const long kper = ((a.K + z - 1) / z + 3) / 4;
+    if ((force == 4 || (force == 0 && b64 >= 128 && b64 <= 256 && kper >= 128)) && wstage_ok(a))
+      return launch_wstage64(a, s);
     if ((force == 2 || (force == 0 && b64 < 512)) && wstage_ok(a)) return launch_wstage(a, s);
     if ((force == 1 || (force == 0 && b64 < 512)) && frag_ok(a)) return launch_frag(a, s);
   }
@@ -1393,6 +1588,8 @@ bool groupable(const MesmGemmArgs& a) {
   if (force != 0 && force != 2) return false;
   const long z = a.split_k > 1 ? a.split_k : 1;
   const long b64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * z;
+  const long kper = ((a.K + z - 1) / z + 3) / 4;
+  if (force == 0 && b64 >= 128 && b64 <= 256 && kper >= 128) return false;  // goes to wstage64
   return (force == 2 || b64 < 512) && wstage_ok(a);
 }
 

@@ -146,7 +146,7 @@ def test_gemm_dropout_matches_materialised_mask():
     assert rel_err(dX, full * mask) < TOL
 
 
-@pytest.mark.parametrize("tile", ["0", "1", "2", "3", "32", "64"])
+@pytest.mark.parametrize("tile", ["0", "1", "2", "3", "4", "32", "64"])
 @pytest.mark.parametrize("M,N,K", [(2400, 256, 256), (190, 132, 300)])
 def test_gemm_operand_dropout_uses_the_stored_index(tile, M, N, K, monkeypatch):
     """The mask an epilogue wrote on Y (index row*N + col) is replayed when dY is an operand:
@@ -605,10 +605,10 @@ def test_gemm_group_matches_individual_launches():
                     assert rel_err(y, x) < 1e-4
 
 
-@pytest.mark.parametrize("tile", ["1", "2", "3"])
+@pytest.mark.parametrize("tile", ["1", "2", "3", "4"])
 def test_gemm_fuzz_forced_kernel(tile, monkeypatch):
     """The same fuzz with every launch forced onto one of the small-problem / LDS-DMA kernels
-    (1 = register fragments, 2 = wave-private LDS-DMA k-split, 3 = 64x64 LDS-DMA ring); launches a
+    (1 = register fragments, 2 = wave-private LDS-DMA k-split, 3 = 64x64 LDS-DMA ring, 4 = 64x64 k-split); launches a
     kernel cannot take (addend operands, unaligned rows) fall through to the auto dispatch."""
     import random
     from mesm_amd import kernels as kn

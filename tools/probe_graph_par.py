@@ -7,14 +7,15 @@ from mesm_amd import kernels as kn
 
 dev = torch.device("cuda:0")
 M, N, K = [int(x) for x in (sys.argv[1:4] if len(sys.argv) > 3 else (2400, 256, 256))]
-NL = 64
-A = [torch.randn(M, K, device=dev) for _ in range(NL)]
-W = [torch.randn(N, K, device=dev) for _ in range(NL)]
-C = [torch.zeros(M, N, device=dev) for _ in range(NL)]
+NL = int(os.environ.get('NL', '64'))
+NB = 64  # operand sets (rotated)
+A = [torch.randn(M, K, device=dev) for _ in range(NB)]
+W = [torch.randn(N, K, device=dev) for _ in range(NB)]
+C = [torch.zeros(M, N, device=dev) for _ in range(NB)]
 
 
 def g(i):
-    kn.gemm(A[i], W[i], C[i], trans_b=True)
+    kn.gemm(A[i % NB], W[i % NB], C[i % NB], trans_b=True)
 
 
 def capture(body):
@@ -93,6 +94,27 @@ def fork_only():
     return body
 
 
+def long_main_short_side(frac):
+    """main chain of NL launches, side chain of frac*NL forked after the first main launch and
+    enqueued after the whole main chain (the masked-word-branch pattern)"""
+    side = torch.cuda.Stream()
+    ns = int(NL * frac)
+
+    def body():
+        cur = torch.cuda.current_stream()
+        g(0)
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        for i in range(1, NL):
+            g(i)
+        side.wait_event(ev)
+        with torch.cuda.stream(side):
+            for i in range(ns):
+                g(NL + i)
+        cur.wait_stream(side)
+    return body
+
+
 def early_event_late_enqueue():
     """main: g0, record ev, g1..g31; THEN side (waits ev): g32..g63; join.  Same dependencies as two
     branches forked after g0, but the side work is enqueued after the main work in host order."""
@@ -166,5 +188,6 @@ print("fork+join each pair : %8.1f us" % timeit(capture(forkjoin_each())))
 print("fork each, join end : %8.1f us" % timeit(capture(fork_only())))
 for kind in ("empty", "add", "zero_", "zeros", "copy"):
     print("2 branches + %-6s per step: %8.1f us" % (kind, timeit(capture(branches_with(kind)))))
+print("main NL + side 0.2 NL (serial would be 1.2x): %8.1f us" % timeit(capture(long_main_short_side(0.2))))
 print("early event, late enqueue: %8.1f us" % timeit(capture(early_event_late_enqueue())))
 print("interleaved enqueue      : %8.1f us" % timeit(capture(interleaved_enqueue())))
