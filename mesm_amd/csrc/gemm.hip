@@ -212,7 +212,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const MesmGemmArgs p
   // conflict-free; +4 for outer-contiguous operands keeps rows 16-byte aligned for ds_write_b128
   // and avoids an exact power-of-two row stride (with stride 32 the 32x32 k-split configuration
   // read zeros for k >= 56 at columns 27/31 on gfx950 / ROCm 7.2 -- not understood, reproducible
-  // with tools/dbg_gemm3.py, gone with any padded stride).
+  // gone with any padded stride).
   constexpr int PA = (LA == MESM_LAYOUT_REDUCE_CONTIG) ? 2 : 4;
   constexpr int PB = (LB == MESM_LAYOUT_REDUCE_CONTIG) ? 2 : 4;
   constexpr int SA = BM + PA;
@@ -493,7 +493,7 @@ int launch_tile(const MesmGemmArgs& a, hipStream_t s) {
   const int add = a.A2 ? 1 : (a.B2 ? 2 : 0);
   const long z = a.split_k > 1 ? a.split_k : 1;
   auto blocks = [&](int t) { return (long)((a.M + t - 1) / t) * ((a.N + t - 1) / t) * z; };
-  // tuning knob (tools/gemm_bench3.py): MESM_GEMM_TILE=32|64|128 pins the configuration
+  // tuning knob (tools/gemm_bench4.py): MESM_GEMM_TILE=32|64|128 pins the configuration
   const char* force_env = getenv("MESM_GEMM_TILE");
   const int force_tile = force_env ? atoi(force_env) : 0;
   if (force_tile == 128 && add == 0) return launch_layout<128, 128, VEC, 0>(a, s);
