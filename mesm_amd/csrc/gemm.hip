@@ -1334,7 +1334,10 @@ int launch_wstage64(const MesmGemmArgs& a, hipStream_t s) {
 // bookkeeping does not drain the ring before every fragment read (it waits vmcnt(0) on any LDS access
 // that may alias an LDS-DMA it knows about): the only waits on the ring are the counted ones below.
 // Slab layouts / source-address swizzles are the wstage kernel's (ws_issue_asm mirrors ws_issue).
-constexpr int L64_STAGES = 3;
+#ifndef MESM_L64_STAGES
+#define MESM_L64_STAGES 3
+#endif
+constexpr int L64_STAGES = MESM_L64_STAGES;  // 3: two k-tiles in flight (48 KB); 2: one in flight (32 KB, more workgroups per CU)
 constexpr int L64_STAGE_FLOATS = 4 * WS_SLAB;  // A rows 0-31, A rows 32-63, B rows 0-31, B rows 32-63
 
 __device__ __forceinline__ void glds16(const float* g, float* lds_dst) {
@@ -1417,16 +1420,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_lds64_kernel(const MesmGemmArgs
   float csum = 0.0f;
   const bool do_colsum = (p.colsum != nullptr) && (blockIdx.y == 0) && (wn == 0);
 
+  constexpr int AHEAD = L64_STAGES - 1;  // k-tiles in flight behind the one being multiplied
   if (nst > 0) issue(0);
-  if (nst > 1) issue(1);
+  if (AHEAD > 1 && nst > 1) issue(1);
   for (int st = 0; st < nst; ++st) {
     // this wave's 4 LDS-DMA instructions of k-tile st have landed (k-tile st+1 may still fly) ...
-    if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    if (AHEAD > 1 && st + 1 < nst) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ... and so have the other waves': one barrier per k-tile.  It also orders the fragment reads of
     // k-tile st-1 (finished by every wave before it arrived here) ahead of the refill issued below.
     __builtin_amdgcn_s_barrier();
-    if (st + 2 < nst) issue(st + 2);
+    if (st + AHEAD < nst) issue(st + AHEAD);
     const float* buf = L + (st % L64_STAGES) * L64_STAGE_FLOATS;
     float a[4][4], b[4][4];
     ws_read<LA>(buf + wm * WS_SLAB, li, h, a);
