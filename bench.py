@@ -166,7 +166,9 @@ def main():
             tpath = os.path.join(ROOT, "profiles", "gemm_traffic.json")
             if os.path.exists(tpath):  # PMC FETCH_SIZE / WRITE_SIZE passes of this same command
                 with open(tpath) as f:
-                    traffic = json.load(f).get("hbm_bytes_per_launch")
+                    per_step = json.load(f).get("hbm_bytes_per_step")
+                if per_step:  # same "launch" as achieved: one mesm_gemm_f32 / mesm_gemm_group call
+                    traffic = per_step / (prof["launches"] / opt.steps)
             roofline = {"kernel": "mesm_gemm_f32 (gemm_wstage / gemm_lds64 / gemm_frag / gemm_f32 kernels, "
                                   "v_mfma_f32_32x32x2_f32)", "bound": "mfma",
                         "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -18,7 +18,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -o p -- python3 bench.py --steps 3 --warmup 1 --cpu-steps 0 --no-roofline > $out/pmc_$c.log 2>&1; echo "pmc $c rc=$?" | tee -a $out/summary.txt
   python3 tools/pmc_summary.py $out/pmc_$c/p_counter_collection.csv 60 > $out/pmc_${c}_summary.txt 2>&1
 done
-python3 tools/pmc_traffic.py $out/pmc_FETCH_SIZE/p_counter_collection.csv $out/pmc_WRITE_SIZE/p_counter_collection.csv $out/gemm_traffic.json
+python3 tools/pmc_traffic.py $out/pmc_FETCH_SIZE/p_counter_collection.csv $out/pmc_WRITE_SIZE/p_counter_collection.csv $out/gemm_traffic.json 7
 for c in FETCH_SIZE WRITE_SIZE; do rm -f $out/pmc_$c/p_counter_collection.csv $out/pmc_$c/p_kernel_trace.csv; done
 python3 tools/ablate.py > $out/ablation.txt 2>&1
 find $out -type f | xargs ls -la | head -40

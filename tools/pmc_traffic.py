@@ -2,7 +2,9 @@
 separate runs: they do not fit one pass on gfx950).  Units and corrections per
 MI355X_MICROARCH.md "HBM": both counters are in KiB; on gfx950 FETCH_SIZE reports exactly half of
 the bytes of wide coalesced reads (128-B requests tallied at 64 B), so it is doubled; WRITE_SIZE is
-exact.  Usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
+exact.  The profiled command executes `steps` training steps in total (bench.py --steps 3 --warmup 1
+= 3 eager warm-up steps before the capture + 1 + 3 replays = 7).
+Usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <steps>"""
 import csv, json, sys
 csv.field_size_limit(1 << 30)
 
@@ -18,7 +20,10 @@ def gemm_sum(path, counter):
 
 f, nf = gemm_sum(sys.argv[1], "FETCH_SIZE")
 w, nw = gemm_sum(sys.argv[2], "WRITE_SIZE")
+steps = int(sys.argv[4])
 out = {
+    "steps_profiled": steps, "gemm_kernel_launches_per_step": nf / steps,
+    "hbm_bytes_per_step": (2.0 * f + w) * 1024.0 / steps,
     "kernels": "every kernel whose name contains gemm_ (gemm_wstage / gemm_lds64 / gemm_frag / gemm_f32)",
     "launches_fetch_pass": nf, "launches_write_pass": nw,
     "fetch_kib_raw_per_launch": f / max(nf, 1), "write_kib_per_launch": w / max(nw, 1),
