@@ -40,6 +40,20 @@ __device__ __forceinline__ int64_t linear_block() {
   return ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
 }
 
+// XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (private 4 MB L2 each) by
+// their linear id.  With the natural (x = M-tile fastest) order the N-tiles of one M-tile land on 8
+// different XCDs whenever gridDim.x % 8 != 0, so every A tile was fetched into up to 8 L2s (PMC: 4 x the
+// algorithmic HBM-side traffic on the GEMMs).  Remap: XCD c owns a CONTIGUOUS range of logical tiles,
+// and logical tiles run N-fastest, so all column tiles of a row tile share one L2.
+__device__ __forceinline__ void xcd_tile(int lid, int mt, int nt, int& bx, int& by) {
+  const int total = mt * nt;
+  const int xcd = lid & 7, idx = lid >> 3;
+  const int q = total >> 3, r = total & 7;
+  const int t = xcd * q + (xcd < r ? xcd : r) + idx;  // bijection on [0, total)
+  bx = t / nt;
+  by = t - bx * nt;
+}
+
 __device__ __forceinline__ void dslope_store(const MesmGemmArgs& p, float part, float* sh4, int64_t slot) {
   part = wave_sum(part);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1075,7 +1089,8 @@ template <int LA, int LB, bool XF>
 __global__ __launch_bounds__(NTHREADS) void gemm_wstage_kernel(const MesmGemmArgs p) {
   __shared__ __attribute__((aligned(16))) float L[WS_LDS_FLOATS];
   Blk blk;
-  blk.x = blockIdx.x; blk.y = blockIdx.y; blk.z = blockIdx.z; blk.slot = linear_block();
+  xcd_tile(blockIdx.x, (p.M + 31) / 32, (p.N + 31) / 32, blk.x, blk.y);
+  blk.z = blockIdx.z; blk.slot = linear_block();
   wstage_body<LA, LB, XF>(p, blk, L);
 }
 
@@ -1101,7 +1116,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_wstage_group_kernel(const Group
   const int local = bid - g.start[gi];
   const int mt = (p.M + 31) / 32, nt = (p.N + 31) / 32;
   Blk blk;
-  blk.x = local % mt; blk.y = (local / mt) % nt; blk.z = local / (mt * nt); blk.slot = local;
+  blk.z = local / (mt * nt);
+  xcd_tile(local - blk.z * (mt * nt), mt, nt, blk.x, blk.y);
+  blk.slot = local;
   constexpr int R = MESM_LAYOUT_REDUCE_CONTIG, O = MESM_LAYOUT_OUTER_CONTIG;
   const bool xf = p.a_act != MESM_ACT_NONE || p.b_act != MESM_ACT_NONE || p.a_drop_p > 0.f || p.b_drop_p > 0.f;
   const int sel = (p.a_layout == O ? 2 : 0) + (p.b_layout == O ? 1 : 0);
@@ -1120,7 +1137,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_wstage_group_kernel(const Group
 
 template <int LA, int LB>
 int launch_wstage_l(const MesmGemmArgs& a, hipStream_t s) {
-  dim3 grid((a.M + 31) / 32, (a.N + 31) / 32, a.split_k > 1 ? a.split_k : 1);
+  dim3 grid(((a.M + 31) / 32) * ((a.N + 31) / 32), 1, a.split_k > 1 ? a.split_k : 1);  // 1-D: xcd_tile() maps it
   const bool xf = a.a_act != MESM_ACT_NONE || a.b_act != MESM_ACT_NONE || a.a_drop_p > 0.f || a.b_drop_p > 0.f;
   if (xf) hipLaunchKernelGGL((gemm_wstage_kernel<LA, LB, true>), grid, dim3(NTHREADS), 0, s, a);
   else hipLaunchKernelGGL((gemm_wstage_kernel<LA, LB, false>), grid, dim3(NTHREADS), 0, s, a);
@@ -1304,13 +1321,14 @@ template <int LA, int LB, bool XF>
 __global__ __launch_bounds__(NTHREADS) void gemm_wstage64_kernel(const MesmGemmArgs p) {
   __shared__ __attribute__((aligned(16))) float L[WS_LDS_FLOATS];  // 4 waves x 4 slabs = 64 KB
   Blk blk;
-  blk.x = blockIdx.x; blk.y = blockIdx.y; blk.z = blockIdx.z; blk.slot = linear_block();
+  xcd_tile(blockIdx.x, (p.M + 63) / 64, (p.N + 63) / 64, blk.x, blk.y);
+  blk.z = blockIdx.z; blk.slot = linear_block();
   wstage64_body<LA, LB, XF>(p, blk, L);
 }
 
 template <int LA, int LB>
 int launch_wstage64_l(const MesmGemmArgs& a, hipStream_t s) {
-  dim3 grid((a.M + 63) / 64, (a.N + 63) / 64, a.split_k > 1 ? a.split_k : 1);
+  dim3 grid(((a.M + 63) / 64) * ((a.N + 63) / 64), 1, a.split_k > 1 ? a.split_k : 1);  // 1-D: xcd_tile() maps it
   const bool xf = a.a_act != MESM_ACT_NONE || a.b_act != MESM_ACT_NONE || a.a_drop_p > 0.f || a.b_drop_p > 0.f;
   if (xf) hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, true>), grid, dim3(NTHREADS), 0, s, a);
   else hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, false>), grid, dim3(NTHREADS), 0, s, a);
@@ -1384,7 +1402,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_lds64_kernel(const MesmGemmArgs
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+  int tbx, tby;
+  xcd_tile(blockIdx.x, (p.M + 63) / 64, (p.N + 63) / 64, tbx, tby);
+  const int m0 = tbx * 64, n0 = tby * 64;
 
   int kbeg = 0, kend = p.K;
   if (p.split_k > 1) {
@@ -1418,7 +1438,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_lds64_kernel(const MesmGemmArgs
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
   float csum = 0.0f;
-  const bool do_colsum = (p.colsum != nullptr) && (blockIdx.y == 0) && (wn == 0);
+  const bool do_colsum = (p.colsum != nullptr) && (tby == 0) && (wn == 0);
 
   constexpr int AHEAD = L64_STAGES - 1;  // k-tiles in flight behind the one being multiplied
   if (nst > 0) issue(0);
@@ -1490,7 +1510,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_lds64_kernel(const MesmGemmArgs
 
 template <int LA, int LB>
 int launch_lds64_l(const MesmGemmArgs& a, hipStream_t s) {
-  dim3 grid((a.M + 63) / 64, (a.N + 63) / 64, a.split_k > 1 ? a.split_k : 1);
+  dim3 grid(((a.M + 63) / 64) * ((a.N + 63) / 64), 1, a.split_k > 1 ? a.split_k : 1);  // 1-D: xcd_tile() maps it
   const bool xf = a.a_act != MESM_ACT_NONE || a.b_act != MESM_ACT_NONE || a.a_drop_p > 0.f || a.b_drop_p > 0.f;
   if (xf) hipLaunchKernelGGL((gemm_lds64_kernel<LA, LB, true>), grid, dim3(NTHREADS), 0, s, a);
   else hipLaunchKernelGGL((gemm_lds64_kernel<LA, LB, false>), grid, dim3(NTHREADS), 0, s, a);
