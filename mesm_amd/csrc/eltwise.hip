@@ -116,18 +116,20 @@ __global__ __launch_bounds__(256) void act_dropout_kernel(const float* __restric
   }
 }
 
-constexpr int AB_ROWS = 32;  // rows per workgroup
+constexpr int AB_ROWS = 32;  // rows per workgroup when column sums are accumulated (few atomics);
+                             // 4 when there is nothing to reduce (row chains are dependent loads)
 
 __global__ __launch_bounds__(256) void act_bias_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ ref, float* __restrict__ dz,
     float* __restrict__ dbias, const float* __restrict__ slope_p, float* __restrict__ dslope,
-    int64_t rows, int cols, int act) {
+    int64_t rows, int cols, int act, int rpb) {
   const int c = blockIdx.y * 256 + threadIdx.x;
-  const int64_t r0 = (int64_t)blockIdx.x * AB_ROWS;
-  const int64_t r1 = (r0 + AB_ROWS) < rows ? (r0 + AB_ROWS) : rows;
+  const int64_t r0 = (int64_t)blockIdx.x * rpb;
+  const int64_t r1 = (r0 + rpb) < rows ? (r0 + rpb) : rows;
   const float slope = slope_p ? *slope_p : 0.0f;
   float colsum = 0.0f, ds = 0.0f;
   if (c < cols) {
+#pragma unroll 4
     for (int64_t r = r0; r < r1; ++r) {
       float g = dy[r * cols + c];
       if (act == MESM_ACT_RELU) {
@@ -197,9 +199,10 @@ extern "C" int mesm_act_bias_bwd(const float* dy, const float* ref, float* dz, f
   if (!dy || rows <= 0 || cols <= 0) return MESM_EINVAL;
   if (act != MESM_ACT_NONE && !ref) return MESM_EINVAL;
   if (act == MESM_ACT_PRELU && !slope) return MESM_EINVAL;
-  dim3 grid((unsigned)((rows + AB_ROWS - 1) / AB_ROWS), (cols + 255) / 256);
+  const int rpb = (dbias || dslope) ? AB_ROWS : 4;
+  dim3 grid((unsigned)((rows + rpb - 1) / rpb), (cols + 255) / 256);
   hipLaunchKernelGGL(act_bias_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, ref, dz,
-                     dbias, slope, dslope, rows, cols, act);
+                     dbias, slope, dslope, rows, cols, act, rpb);
   return mesm_launch_status();
 }
 
