@@ -234,3 +234,65 @@ def test_side_stream_branch_gives_the_same_step():
     assert set(res[0][1]) == set(res[1][1])
     for n, g in res[0][1].items():
         assert rel(res[1][1][n], g) < 1e-4, n
+
+
+# ----------------------------------------------------------------------------- full benchmark size
+@pytest.mark.parametrize("workload", ["C3a", "C3b"])
+def test_full_size_workload_against_cpu_oracle(workload):
+    """The bench.py workload itself (QVHighlights C+SF, 32 pairs, Lv=75, Dv=2818, C=5003; C3b = 8
+    groups x 4 queries) with dropout off: losses / logits within 1e-4 of the CPU oracle, matched
+    indices bit-exact, and gradient L2 error small on every parameter."""
+    from mesm_amd import build_criterion, build_model, synthetic
+    from oracle import mesm_oracle as O
+    args = synthetic.make_args(workload, device="cuda:0")
+    torch.manual_seed(1234)
+    model = build_model(args)
+    crit = build_criterion(args)
+    batch = synthetic.workload_batch(workload, seed=0)
+    neg, masked = synthetic.host_draws(batch, seed=0)
+    out, losses, total = run_step(model, crit, batch, vars(args), neg, masked)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    o_out, o_losses, o_total, o_grads, o_idx = O.train_step(sd, dict(vars(args)), batch, neg, masked)
+    for k in ("pred_logits", "pred_spans", "saliency_scores", "neg_saliency_scores", "recfw_words_logit"):
+        assert rel(out[k], o_out[k]) < TOL, k
+    for k, v in o_losses.items():
+        assert abs(float(losses[k]) - float(v)) < TOL * max(1.0, abs(float(v))), k
+    assert abs(float(total) - float(o_total)) < TOL * max(1.0, abs(float(o_total)))
+    mq = crit.last_match[0].cpu().tolist()
+    want = []
+    for q, t in o_idx[0]:
+        want += q[torch.argsort(t)].tolist()
+    assert mq == want
+    worst = 0.0
+    for n, p in model.named_parameters():
+        if n in o_grads:
+            a, b = p.grad.detach().double().cpu(), o_grads[n].double()
+            worst = max(worst, float((a - b).norm()) / max(float(b.norm()), 1e-3 * b.numel() ** 0.5))
+    assert worst < 1e-2, worst
+
+
+def test_graph_replay_equals_eager_step():
+    """One captured HIP graph per step (GraphedStep) reproduces the eager step: same loss and same
+    flat gradient buffer (dropout off so that both are deterministic functions of the inputs)."""
+    from mesm_amd import build_criterion, build_model, synthetic
+    from mesm_amd.graphed import GraphedStep
+    args = synthetic.make_args("C3a", device="cuda:0")
+    torch.manual_seed(7)
+    model = build_model(args)
+    crit = build_criterion(args)
+    args.dropout = 0.0
+    batch = synthetic.to_device(synthetic.workload_batch("C3a", seed=1), dev())
+    for m in model.modules():
+        if hasattr(m, "p"):
+            m.p = 0.0
+    g = GraphedStep(model, crit, batch, args.dataset_name, warmup=1)
+    total_g = float(g.run(redraw=False))
+    flat_g = model.gradbuf().flat.clone()
+    out = model(**batch, dataset_name=args.dataset_name, is_training=True, plan=g.plan)
+    _, total = crit(out, batch, True)
+    model.zero_grad(set_to_none=True)
+    total.backward()
+    torch.cuda.synchronize()
+    assert abs(float(total) - total_g) < 1e-5 * max(1.0, abs(total_g))
+    flat_e = model.gradbuf().flat
+    assert float((flat_e - flat_g).norm()) / max(float(flat_e.norm()), 1e-6) < 1e-4
