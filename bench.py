@@ -180,6 +180,21 @@ def main():
                         "gemm_ms_per_step": prof["ms"] / opt.steps,
                         "algorithmic_bytes_per_launch": prof.get("bytes", 0) / max(prof["launches"], 1)}
 
+    # informational (NOT part of the metric, which is fwd + bwd): the optimizer tail of train.py:70-72 on
+    # the flat buffers, global-norm clip + AdamW in two launches
+    opt_tail_ms = None
+    if rank == 0:
+        from mesm_amd.optim import FlatAdamW
+        fo = FlatAdamW(model, lr=1e-4, weight_decay=1e-4)
+        for _ in range(3):
+            fo.step(grad_clip=0.1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            fo.step(grad_clip=0.1)
+        torch.cuda.synchronize()
+        opt_tail_ms = (time.perf_counter() - t1) / 20 * 1e3
+
     cpu_baseline = None
     if rank == 0 and world == 1 and opt.cpu_steps > 0:
         from oracle import mesm_oracle as O
@@ -211,7 +226,8 @@ def main():
                                    % (opt.workload, n_pairs, len(wl["groups"]), wl["Lv"], wl["Lw"],
                                       wl["v_feat_dim"], wl["t_feat_dim"], wl["vocab_size"] + 1),
                        "global_pairs": n_pairs * world, "parallelism": "dp%d" % world,
-                       "launch": "eager" if opt.eager else "hip-graph"},
+                       "launch": "eager" if opt.eager else "hip-graph",
+                       "optimizer_tail_ms_not_in_metric": opt_tail_ms},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line), flush=True)

@@ -416,6 +416,30 @@ int mesm_weighted_sum(const float* vals, const float* weights, int32_t n, float*
                       void* stream);
 int mesm_scale_vec(const float* g, const float* weights, int32_t n, float* out, void* stream);
 
+/* ------------------------------------------------------------------------- */
+/*
+ * Optimizer tail on the flat buffers.  Replaces, for all trainable tensors at
+ * once, nn.utils.clip_grad_norm_(model.parameters(), grad_clip) + torch.optim.AdamW.step()
+ * (train.py:70-72, runner.py:348-352; amsgrad off, eps 1e-8):
+ *   mesm_grad_sumsq   partial sums of squares of g (n % 4 == 0), one per workgroup; *np_out (host)
+ *                     = number of partials (<= 1024); *step (device int32, may be NULL) += 1
+ *   mesm_clip_grad    g *= min(1, max_norm / (||g|| + 1e-6));  *norm_out = ||g|| (optional)
+ *   mesm_adamw_step   with coef = that clip factor when max_norm > 0 (1 otherwise), t = *step,
+ *                     lr = *lr (device scalars: graph-capturable, StepLR writes lr between steps):
+ *                       p *= 1 - lr*wd;  m = b1 m + (1-b1) coef g;  v = b2 v + (1-b2) (coef g)^2
+ *                       p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ *                     active4 (n/4 bytes, optional): groups of 4 elements with 0 are skipped (tensors
+ *                     whose gradient is None this step: no decay, no state update).
+ */
+int mesm_grad_sumsq(const float* g, int64_t n, float* partials, int32_t* np_out, int32_t* step,
+                    void* stream);
+int mesm_clip_grad(float* g, int64_t n, const float* partials, int32_t np, float max_norm,
+                   float* norm_out, void* stream);
+int mesm_adamw_step(float* p, const float* g, float* m, float* v, const uint8_t* active4, int64_t n,
+                    const float* partials, int32_t np, float max_norm, const float* lr, float beta1,
+                    float beta2, float eps, float weight_decay, const int32_t* step, float* norm_out,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

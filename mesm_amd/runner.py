@@ -109,8 +109,8 @@ def build_criterion(args):
 
 
 def build_optimizer(opt, model):
-    """runner.py:348-352."""
-    params = [{"params": [p for n, p in model.named_parameters() if p.requires_grad]}]
-    optimizer = torch.optim.AdamW(params, lr=opt.lr, weight_decay=opt.weight_decay)
-    lr_scheduler = torch.optim.lr_scheduler.StepLR(optimizer, opt.lr_drop, gamma=opt.gamma)
-    return optimizer, lr_scheduler
+    """runner.py:348-352: AdamW(lr, weight_decay) + StepLR(lr_drop, gamma), here on the flat parameter /
+    gradient buffers (mesm_amd/optim.py): `optimizer.step()` is one launch for all tensors, and
+    `optimizer.step(grad_clip=opt.grad_clip)` also absorbs train.py:70-71's clip_grad_norm_."""
+    from .optim import build_optimizer as _build
+    return _build(opt, model)
