@@ -263,6 +263,25 @@ int mesm_dropout(const float* x, float* y, int64_t n, float p, uint32_t seed,
                  const uint32_t* seed_offset, void* stream);
 
 /*
+ * Decoder reference-point arithmetic, fused (each was ~8 / ~5 ATen launches, twice that in backward):
+ *   ref_update   out = sigmoid(delta + inverse_sigmoid(ref)), inverse_sigmoid as transformer.py:36-40
+ *                (clamp to [0,1], eps 1e-3): transformer.py:392-394 (new reference points) and
+ *                model.py:250 (span head).  bwd: ddelta, dref (dref may be NULL).
+ *   qsine_scale  out[r,:] = qsine[r,:] * scale[r,:] * sigmoid(anchor[r]) / ref[r,1]
+ *                (transformer.py:370-376: query_scale modulation and the ref_anchor_head width
+ *                modulation; scale may be NULL = layer 0).  bwd: dqsine, dscale, danchor (R), dref (R,2).
+ */
+int mesm_ref_update_fwd(const float* delta, const float* ref, float* out, int64_t n, float eps,
+                        void* stream);
+int mesm_ref_update_bwd(const float* out, const float* ref, const float* dout, float* ddelta,
+                        float* dref, int64_t n, float eps, void* stream);
+int mesm_qsine_scale_fwd(const float* qsine, const float* scale, const float* anchor,
+                         const float* ref, float* out, int64_t R, int32_t D, void* stream);
+int mesm_qsine_scale_bwd(const float* qsine, const float* scale, const float* anchor,
+                         const float* ref, const float* dout, float* dqsine, float* dscale,
+                         float* danchor, float* dref, int64_t R, int32_t D, void* stream);
+
+/*
  * y = dropout(act(x)), flat index = element index (n % 4 == 0, 16-byte aligned): the FFN hidden
  * activation dropout(PReLU(linear1(.))) of transformer.py:537,603,608,647,794 written once.
  */

@@ -116,6 +116,84 @@ __global__ __launch_bounds__(256) void act_dropout_kernel(const float* __restric
   }
 }
 
+
+// ---- decoder reference-point arithmetic (transformer.py:36-40, 373-376, 392-397; model.py:250) ----
+// out = sigmoid(delta + inverse_sigmoid(ref)), inverse_sigmoid(x) = log(clamp(x01, eps) / clamp(1 - x01, eps)),
+// x01 = clamp(x, 0, 1), eps = 1e-3: eight ATen launches per call (and twice that in backward) as one.
+__device__ __forceinline__ float inv_sigmoid(float x, float eps, float& dinv) {
+  const float xc = fminf(fmaxf(x, 0.0f), 1.0f);
+  const float in01 = (x >= 0.0f && x <= 1.0f) ? 1.0f : 0.0f;  // clamp passes the gradient inside [0, 1]
+  const float x1 = fmaxf(xc, eps), x2 = fmaxf(1.0f - xc, eps);
+  dinv = in01 * ((xc >= eps ? 1.0f / x1 : 0.0f) + ((1.0f - xc) >= eps ? 1.0f / x2 : 0.0f));
+  return logf(x1 / x2);
+}
+
+__global__ __launch_bounds__(256) void ref_update_fwd_kernel(const float* __restrict__ delta,
+                                                            const float* __restrict__ ref, float* __restrict__ out,
+                                                            int64_t n, float eps) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float d;
+  const float t = delta[i] + inv_sigmoid(ref[i], eps, d);
+  out[i] = 1.0f / (1.0f + expf(-t));
+}
+
+__global__ __launch_bounds__(256) void ref_update_bwd_kernel(const float* __restrict__ out,
+                                                            const float* __restrict__ ref,
+                                                            const float* __restrict__ dout, float* __restrict__ ddelta,
+                                                            float* __restrict__ dref, int64_t n, float eps) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float s = out[i];
+  const float dpre = dout[i] * s * (1.0f - s);
+  float d;
+  inv_sigmoid(ref[i], eps, d);
+  ddelta[i] = dpre;
+  if (dref) dref[i] = dpre * d;
+}
+
+// out[r, :] = qsine[r, :] * (scale ? scale[r, :] : 1) * sigmoid(anchor[r]) / ref[r, 1]   (one wave per row)
+__global__ __launch_bounds__(256) void qsine_scale_fwd_kernel(const float* __restrict__ qsine,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ anchor,
+                                                             const float* __restrict__ ref, float* __restrict__ out,
+                                                             int64_t R, int D) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const float f = (1.0f / (1.0f + expf(-anchor[r]))) / ref[r * 2 + 1];
+  for (int c = lane; c < D; c += 64) {
+    const float q = qsine[r * D + c];
+    out[r * D + c] = q * (scale ? scale[r * D + c] : 1.0f) * f;
+  }
+}
+
+__global__ __launch_bounds__(256) void qsine_scale_bwd_kernel(
+    const float* __restrict__ qsine, const float* __restrict__ scale, const float* __restrict__ anchor,
+    const float* __restrict__ ref, const float* __restrict__ dout, float* __restrict__ dqsine,
+    float* __restrict__ dscale, float* __restrict__ danchor, float* __restrict__ dref, int64_t R, int D) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const float sg = 1.0f / (1.0f + expf(-anchor[r]));
+  const float w = ref[r * 2 + 1];
+  const float f = sg / w;
+  float df = 0.0f;
+  for (int c = lane; c < D; c += 64) {
+    const float q = qsine[r * D + c], g = dout[r * D + c];
+    const float sc = scale ? scale[r * D + c] : 1.0f;
+    dqsine[r * D + c] = g * sc * f;
+    if (dscale) dscale[r * D + c] = g * q * f;
+    df += g * q * sc;
+  }
+  df = wave_sum(df);
+  if (lane == 0) {
+    danchor[r] = df * sg * (1.0f - sg) / w;
+    dref[r * 2] = 0.0f;
+    dref[r * 2 + 1] = -df * sg / (w * w);
+  }
+}
+
 constexpr int AB_ROWS = 32;  // rows per workgroup when column sums are accumulated (few atomics);
                              // 4 when there is nothing to reduce (row chains are dependent loads)
 
@@ -203,6 +281,40 @@ extern "C" int mesm_act_bias_bwd(const float* dy, const float* ref, float* dz, f
   dim3 grid((unsigned)((rows + rpb - 1) / rpb), (cols + 255) / 256);
   hipLaunchKernelGGL(act_bias_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, ref, dz,
                      dbias, slope, dslope, rows, cols, act, rpb);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_ref_update_fwd(const float* delta, const float* ref, float* out, int64_t n, float eps,
+                                   void* stream) {
+  if (!delta || !ref || !out || n <= 0) return MESM_EINVAL;
+  hipLaunchKernelGGL(ref_update_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     delta, ref, out, n, eps);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_ref_update_bwd(const float* out, const float* ref, const float* dout, float* ddelta,
+                                   float* dref, int64_t n, float eps, void* stream) {
+  if (!out || !ref || !dout || !ddelta || n <= 0) return MESM_EINVAL;
+  hipLaunchKernelGGL(ref_update_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     out, ref, dout, ddelta, dref, n, eps);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_qsine_scale_fwd(const float* qsine, const float* scale, const float* anchor,
+                                    const float* ref, float* out, int64_t R, int32_t D, void* stream) {
+  if (!qsine || !anchor || !ref || !out || R <= 0 || D <= 0) return MESM_EINVAL;
+  hipLaunchKernelGGL(qsine_scale_fwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     qsine, scale, anchor, ref, out, R, D);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_qsine_scale_bwd(const float* qsine, const float* scale, const float* anchor,
+                                    const float* ref, const float* dout, float* dqsine, float* dscale,
+                                    float* danchor, float* dref, int64_t R, int32_t D, void* stream) {
+  if (!qsine || !anchor || !ref || !dout || !dqsine || !danchor || !dref || R <= 0 || D <= 0) return MESM_EINVAL;
+  if ((scale == nullptr) != (dscale == nullptr)) return MESM_EINVAL;
+  hipLaunchKernelGGL(qsine_scale_bwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     qsine, scale, anchor, ref, dout, dqsine, dscale, danchor, dref, R, D);
   return mesm_launch_status();
 }
 

@@ -255,25 +255,23 @@ class DecoderLayer(nn.Module):
         # query-position ones (13 launches of ~5 us otherwise); their sums follow the group
         with kn.gemm_group():
             q_c = L(tgt, self.sa_qcontent_proj.weight, self.sa_qcontent_proj.bias)
-            q_p = L(query_pos, self.sa_qpos_proj.weight, self.sa_qpos_proj.bias)
             k_c = L(tgt, self.sa_kcontent_proj.weight, self.sa_kcontent_proj.bias)
-            k_p = L(query_pos, self.sa_kpos_proj.weight, self.sa_kpos_proj.bias)
             v = L(tgt, self.sa_v_proj.weight, self.sa_v_proj.bias)
             kc = L(memory, self.ca_kcontent_proj.weight, self.ca_kcontent_proj.bias)
             cv = L(memory, self.ca_v_proj.weight, self.ca_v_proj.bias)
             kp = L(pos, self.ca_kpos_proj.weight, self.ca_kpos_proj.bias)
             qs = L(qsine, self.ca_qpos_sine_proj.weight, self.ca_qpos_sine_proj.bias)
             qpp = L(query_pos, self.ca_qpos_proj.weight, self.ca_qpos_proj.bias) if is_first else None
-        q = q_c + q_p
-        k = k_c + k_p
+        with kn.gemm_group():  # content + positional sums ride the residual epilogue of the second group
+            q = L(query_pos, self.sa_qpos_proj.weight, self.sa_qpos_proj.bias, residual=q_c)
+            k = L(query_pos, self.sa_kpos_proj.weight, self.sa_kpos_proj.bias, residual=k_c)
         a = ops.attention(q, k, v, h, drop=drop_state.next(self.p))
         so = self.self_attn.out_proj
         tgt = self.norm1(L(a, so.weight, so.bias, residual=tgt, out_drop=drop_state.next(self.p)))
 
-        qc = L(tgt, self.ca_qcontent_proj.weight, self.ca_qcontent_proj.bias)
+        qc = L(tgt, self.ca_qcontent_proj.weight, self.ca_qcontent_proj.bias, residual=qpp if is_first else None)
         v = cv
         if is_first:
-            qc = qc + qpp
             kc = kc + kp
         lm = memory.shape[1]
         q2 = torch.cat([qc.view(n, nq, h, dh), qs.view(n, nq, h, dh)], -1).view(n, nq, 2 * d)
@@ -324,12 +322,11 @@ class Decoder(nn.Module):
                 heads.append((self.query_scale, out))
             res = mlp_heads_grouped(heads)
             query_pos, anchor = res[0], res[1]
-            if li > 0:
-                qsine = qsine * res[2]
-            cond = torch.sigmoid(anchor)
-            qsine = qsine * (cond[..., 0] / ref[..., 1]).unsqueeze(-1)
+            # qsine * query_scale(out) * (sigmoid(ref_anchor_head(out)) / ref_width): one kernel
+            qsine = ops.qsine_scale(qsine, res[2] if li > 0 else None, anchor, ref)
             out = layer(out, memory, mem_pad, pos, query_pos, qsine, li == 0)
-            new_ref = torch.sigmoid(self.bbox_embed(out) + inverse_sigmoid(ref))
+            # sigmoid(bbox_embed(out) + inverse_sigmoid(ref)): one kernel
+            new_ref = ops.ref_update(self.bbox_embed(out), ref)
             if li != self.num_layers - 1:
                 refs.append(new_ref)
             ref = new_ref.detach()

@@ -376,7 +376,7 @@ class MESM(nn.Module):
                 sb = ops.linear(memory_g2, self.saliency_proj2.weight, self.saliency_proj2.bias)
             for i_, l_ in enumerate(self.span_embed.layers[1:], 1):
                 sp = ops.linear(sp, l_.weight, l_.bias, relu=i_ < len(self.span_embed.layers) - 1)
-            spans = torch.sigmoid(sp + inverse_sigmoid(refs))
+            spans = ops.ref_update(sp, refs)  # sigmoid(span_embed(hs) + inverse_sigmoid(refs)), model.py:250
             sal2 = ops.rowdot(sa, sb, 1.0 / float(np.sqrt(d)))
 
         out.update({"pred_logits": logits[-1], "pred_spans": spans[-1],

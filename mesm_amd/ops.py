@@ -519,3 +519,67 @@ class GatherRowsFn(Function):
 
 def gather_rows(x2d, idx):
     return GatherRowsFn.apply(x2d, idx)
+
+
+# ----------------------------------------------------------------------------- decoder reference points
+class RefUpdateFn(Function):
+    """sigmoid(delta + inverse_sigmoid(ref)) (transformer.py:36-40, 392-394; model.py:250)."""
+
+    @staticmethod
+    def forward(ctx, delta, ref, eps):
+        delta, ref = _c(delta), _c(ref)
+        out = torch.empty_like(delta)
+        kn.check(kn.lib().mesm_ref_update_fwd(kn.ptr(delta), kn.ptr(ref), kn.ptr(out), delta.numel(), float(eps),
+                                              kn.stream_ptr()), "mesm_ref_update_fwd")
+        ctx.save_for_backward(out, ref)
+        ctx.eps = eps
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        out, ref = ctx.saved_tensors
+        dout = _c(dout)
+        dd = torch.empty_like(out)
+        dr = torch.empty_like(out) if ctx.needs_input_grad[1] else None
+        kn.check(kn.lib().mesm_ref_update_bwd(kn.ptr(out), kn.ptr(ref), kn.ptr(dout), kn.ptr(dd), kn.ptr(dr),
+                                              out.numel(), float(ctx.eps), kn.stream_ptr()), "mesm_ref_update_bwd")
+        return dd, dr, None
+
+
+def ref_update(delta, ref, eps=1e-3):
+    return RefUpdateFn.apply(delta, ref, eps)
+
+
+class QSineScaleFn(Function):
+    """qsine * scale * (sigmoid(anchor) / ref[..., 1]) (transformer.py:370-376)."""
+
+    @staticmethod
+    def forward(ctx, qsine, scale, anchor, ref):
+        qsine, anchor, ref = _c(qsine), _c(anchor), _c(ref)
+        scale = _c(scale) if scale is not None else None
+        D = qsine.shape[-1]
+        R = qsine.numel() // D
+        out = torch.empty_like(qsine)
+        kn.check(kn.lib().mesm_qsine_scale_fwd(kn.ptr(qsine), kn.ptr(scale), kn.ptr(anchor), kn.ptr(ref), kn.ptr(out),
+                                               R, D, kn.stream_ptr()), "mesm_qsine_scale_fwd")
+        ctx.save_for_backward(qsine, scale, anchor, ref)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qsine, scale, anchor, ref = ctx.saved_tensors
+        dout = _c(dout)
+        D = qsine.shape[-1]
+        R = qsine.numel() // D
+        dq = torch.empty_like(qsine)
+        ds = torch.empty_like(qsine) if scale is not None else None
+        da = torch.empty_like(anchor)
+        dr = torch.empty_like(ref)
+        kn.check(kn.lib().mesm_qsine_scale_bwd(kn.ptr(qsine), kn.ptr(scale), kn.ptr(anchor), kn.ptr(ref), kn.ptr(dout),
+                                               kn.ptr(dq), kn.ptr(ds), kn.ptr(da), kn.ptr(dr), R, D,
+                                               kn.stream_ptr()), "mesm_qsine_scale_bwd")
+        return dq, ds, da, (dr if ctx.needs_input_grad[3] else None)
+
+
+def qsine_scale(qsine, scale, anchor, ref):
+    return QSineScaleFn.apply(qsine, scale, anchor, ref)
