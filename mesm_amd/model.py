@@ -242,11 +242,15 @@ class MESM(nn.Module):
                 for i, s in enumerate(seg):
                     pl.vid_src[i, :len(s)] = s
                     pl.vid_mask[i, :len(s)] = True
+                # every group is one full-length pair (the common QVH case): the gather is the identity
+                pl.vid_identity = bool(Lss == Lv and pl.vid_mask.all()
+                                       and torch.equal(pl.vid_src.reshape(-1), torch.arange(N * Lv)))
                 pl.vid_src = pl.vid_src.to(device)
                 pl.vid_pad = (~pl.vid_mask).to(device)
                 pl.vid_mask = pl.vid_mask.to(device)
             elif dataset_name in ("charades", "charades-cg", "charades-cd", "tacos"):
                 pl.vid_src = None
+                pl.vid_identity = False
             else:
                 raise NotImplementedError
             pl.sent_src = pl.sent_src.to(device)
@@ -337,9 +341,11 @@ class MESM(nn.Module):
         out = {}
         with _scope("ss"):
             if self.rec_ss:
-                if plan.vid_src is not None:
+                if plan.vid_src is not None and not plan.vid_identity:
                     bvid = video_feat.reshape(N * Lv, -1)[plan.vid_src] * plan.vid_mask.unsqueeze(-1)
                     bvid_pad = plan.vid_pad
+                elif plan.vid_src is not None:
+                    bvid, bvid_pad = video_feat, plan.vid_pad  # 27 MB gather + mask multiply skipped
                 else:
                     bvid, bvid_pad = video_feat, vid_pad
                 bsent = sent[plan.sent_src] * plan.sent_mask.unsqueeze(-1)
