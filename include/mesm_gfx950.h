@@ -263,6 +263,13 @@ int mesm_dropout(const float* x, float* y, int64_t n, float p, uint32_t seed,
                  const uint32_t* seed_offset, void* stream);
 
 /*
+ * Inference windows (eval.py:63-78): out (N, Q, 3) = [ (cx - w/2) * duration[n], (cx + w/2) * duration[n],
+ * softmax(logits)[0] ] from logits (N, Q, 2), spans (N, Q, 2) = (centre, width), duration (N).
+ */
+int mesm_windows(const float* logits, const float* spans, const float* duration, float* out, int32_t N,
+                 int32_t Q, void* stream);
+
+/*
  * Decoder reference-point arithmetic, fused (each was ~8 / ~5 ATen launches, twice that in backward):
  *   ref_update   out = sigmoid(delta + inverse_sigmoid(ref)), inverse_sigmoid as transformer.py:36-40
  *                (clamp to [0,1], eps 1e-3): transformer.py:392-394 (new reference points) and

@@ -284,6 +284,34 @@ extern "C" int mesm_act_bias_bwd(const float* dy, const float* ref, float* dz, f
   return mesm_launch_status();
 }
 
+// ---- inference windows (eval.py:63-78): [start, end, foreground score] per (pair, query) ----
+__global__ __launch_bounds__(256) void windows_kernel(const float* __restrict__ logits,
+                                                     const float* __restrict__ spans,
+                                                     const float* __restrict__ duration, float* __restrict__ out,
+                                                     int N, int Q) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * Q) return;
+  const float l0 = logits[2 * i], l1 = logits[2 * i + 1];
+  const float m = fmaxf(l0, l1);
+  const float e0 = expf(l0 - m), e1 = expf(l1 - m);
+  const float cx = spans[2 * i], w = spans[2 * i + 1];
+  const float d = duration[i / Q];
+  // separately rounded operations, like the reference's tensor ops (no fused multiply-add contraction:
+  // the rows are rounded to 4 decimals / clip multiples afterwards and compared exactly)
+  const float hw = __fmul_rn(0.5f, w);
+  out[3 * i] = __fmul_rn(__fsub_rn(cx, hw), d);
+  out[3 * i + 1] = __fmul_rn(__fadd_rn(cx, hw), d);
+  out[3 * i + 2] = e0 / (e0 + e1);
+}
+
+extern "C" int mesm_windows(const float* logits, const float* spans, const float* duration, float* out,
+                            int32_t N, int32_t Q, void* stream) {
+  if (!logits || !spans || !duration || !out || N <= 0 || Q <= 0) return MESM_EINVAL;
+  hipLaunchKernelGGL(windows_kernel, dim3((N * Q + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, spans,
+                     duration, out, N, Q);
+  return mesm_launch_status();
+}
+
 extern "C" int mesm_ref_update_fwd(const float* delta, const float* ref, float* out, int64_t n, float eps,
                                    void* stream) {
   if (!delta || !ref || !out || n <= 0) return MESM_EINVAL;
