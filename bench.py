@@ -195,6 +195,23 @@ def main():
         torch.cuda.synchronize()
         opt_tail_ms = (time.perf_counter() - t1) / 20 * 1e3
 
+    # informational: the same steps with every batch arriving from HOST memory (PCIe-inclusive rate;
+    # never `value`): host batch copied into the graph static inputs between replays (mesm_amd/feeder.py)
+    pcie = None
+    if rank == 0 and not opt.eager:
+        from mesm_amd.feeder import BatchFeeder
+        feeder = BatchFeeder(gstep, keys=("video_feat", "words_id", "video_mask", "saliency_label", "clip_mask",
+                                          "unknown_mask", "words_label"))
+        for _ in range(3):
+            feeder.feed(batch_cpu); gstep.run(redraw=True)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(opt.steps):
+            feeder.feed(batch_cpu); gstep.run(redraw=True)
+        torch.cuda.synchronize()
+        pdt = (time.perf_counter() - t2) / opt.steps
+        pcie = {"pairs_per_s": n_pairs / pdt, "ms_per_step": pdt * 1e3, "host_bytes_per_step": feeder.bytes}
+
     cpu_baseline = None
     if rank == 0 and world == 1 and opt.cpu_steps > 0:
         from oracle import mesm_oracle as O
@@ -227,7 +244,8 @@ def main():
                                       wl["v_feat_dim"], wl["t_feat_dim"], wl["vocab_size"] + 1),
                        "global_pairs": n_pairs * world, "parallelism": "dp%d" % world,
                        "launch": "eager" if opt.eager else "hip-graph",
-                       "optimizer_tail_ms_not_in_metric": opt_tail_ms},
+                       "optimizer_tail_ms_not_in_metric": opt_tail_ms,
+                       "pcie_inclusive_not_in_metric": pcie},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(line), flush=True)

@@ -64,6 +64,7 @@ class GraphedStep:
             if instrument:
                 kn.gemm_tape(False)
         self.reducer = None
+        self._pins, self._pin_turn = {}, {}
 
     def _words_mask_cpu(self):
         w = self.batch["words_id"]
@@ -94,14 +95,33 @@ class GraphedStep:
                                      % (k, tuple(cur.shape), tuple(v.shape)))
                 cur.copy_(v, non_blocking=True)
 
+    def _pinned_h2d(self, name, host, dst):
+        """host tensor -> static device tensor through one of two pinned staging buffers (a pageable
+        source makes the copy synchronous with everything in flight; with pinned memory the host
+        only waits for the copy that used the same staging buffer two redraws ago)."""
+        slots = self._pins.setdefault(name, [])
+        if not slots:
+            for _ in range(2):
+                slots.append([torch.empty(host.shape, dtype=host.dtype, pin_memory=True), None])
+        i = self._pin_turn.get(name, 0)
+        self._pin_turn[name] = i ^ 1
+        buf, ev = slots[i]
+        if ev is not None:
+            ev.synchronize()
+        buf.copy_(host)
+        dst.copy_(buf, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        slots[i][1] = ev
+
     def redraw(self):
         """New negative-query indices and MLM word choices (host RNG, like the reference does on
         every forward), copied into the static index tensors the graph reads."""
         m = self.model
-        self.plan.neg_index.copy_(m.draw_neg_index(self._groups), non_blocking=True)
+        self._pinned_h2d("neg", m.draw_neg_index(self._groups), self.plan.neg_index)
         if hasattr(self.plan, "masked_words"):
             mw = m.draw_masked_words(self._wm_cpu, self.batch["words_weight"]).bool()
-            self.plan.masked_words.copy_(mw, non_blocking=True)
+            self._pinned_h2d("mw", mw, self.plan.masked_words)
 
     def run(self, redraw=True):
         if redraw:
