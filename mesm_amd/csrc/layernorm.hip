@@ -270,12 +270,18 @@ int bwd_launch(const float* dy, const float* x, const float* gamma, const float*
                int acc, LnDrop dr, hipStream_t s) {
   int64_t blocks = (rows + LN_WAVES - 1) / LN_WAVES;
   if (D <= 1024) {
-    if (blocks > 128) blocks = 128;
+    // every workgroup pays 2 D float atomics for dgamma / dbeta, rows per wave are a dependent chain:
+    // measured optimum (tools/ln_bench.py) 64 workgroups up to ~1k rows, 128 beyond
+    const int64_t cap = rows >= 2000 ? 128 : 64;
+    if (blocks > cap) blocks = cap;
     size_t lds = (size_t)LN_WAVES * D * sizeof(float);
     hipLaunchKernelGGL((ln_bwd_kernel<VEC, NCH, true>), dim3((unsigned)blocks), dim3(LN_THREADS),
                        lds, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, acc, dr);
   } else {
-    if (blocks > 64) blocks = 64;
+    // every workgroup pays 2 D float atomics for dgamma / dbeta, rows per wave are a dependent chain:
+    // measured optimum (tools/ln_bench.py) 64 workgroups up to ~1k rows, 128 beyond
+    const int64_t cap = rows >= 2000 ? 128 : 64;
+    if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL((ln_bwd_kernel<VEC, NCH, false>), dim3((unsigned)blocks),
                        dim3(LN_THREADS), 0, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows,
                        D, acc, dr);
