@@ -134,8 +134,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const MesmAttnArgs
       float acc = 0.0f;
 #pragma unroll 8
       for (int jj = g; jj < KT; jj += G) acc += Ps[wave * KT + jj] * Vs[jj * DV + d];
-#pragma unroll
-      for (int o = DV; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
+      acc = sum_across_groups<DV>(acc);
       if (g == 0) Os[r * DV + d] = Os[r * DV + d] * alpha + acc;
       if (lane == 0) { Ms[r] = m_new; Ls[r] = l_new; }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -241,8 +240,7 @@ __global__ __launch_bounds__(BW_THREADS) void attn_bwd_kernel(const MesmAttnArgs
       }
       *reinterpret_cast<float4*>(dOs + r * DV + c) = g;
       float part = g.x * o.x + g.y * o.y + g.z * o.z + g.w * o.w;
-#pragma unroll
-      for (int off = 1; off < DV / 4; off <<= 1) part += __shfl_xor(part, off, 64);
+      part = sum_within<DV / 4>(part);
       if ((idx % (DV / 4)) == 0) Dl[r] = part;
     }
     if (tid < QCB) Lse[tid] = (tid < nq) ? p.lse[(int64_t)bh * p.Lq + qc + tid] : 0.0f;
@@ -291,8 +289,7 @@ __global__ __launch_bounds__(BW_THREADS) void attn_bwd_kernel(const MesmAttnArgs
       float acc = 0.0f;
 #pragma unroll 8
       for (int jj = g; jj < KT; jj += GQ) acc += Ps[wave * KT + jj] * Ks[jj * SK + d];
-#pragma unroll
-      for (int o = DK; o < 64; o <<= 1) acc += __shfl_xor(acc, o, 64);
+      acc = sum_across_groups<DK>(acc);
       if (g == 0) {
         float* dst = dqb + (int64_t)i * p.q_ls + d;
         if (dq_atomic) atomicAdd(dst, acc);

@@ -41,14 +41,66 @@ __device__ __forceinline__ float mesm_act(float x, int act, float slope) {
   return x;
 }
 
+// Wave-wide reductions on the DPP path (gfx9 row operations): four in-row butterfly steps
+// (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), two row broadcasts (row_bcast:15 into rows
+// 1 and 3, row_bcast:31 into rows 2 and 3) and one v_readlane of lane 63 -- 7 VALU-rate instructions.
+// `__shfl_xor` compiles to ds_bpermute_b32 on gfx950 (an LDS-crossbar round trip per step, 6 steps per
+// reduction): the per-row softmax / LayerNorm statistics were latency chains of those.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float mesm_dpp(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += mesm_dpp<0xB1, 0xF>(0.0f, v);   // quad_perm [1,0,3,2]
+  v += mesm_dpp<0x4E, 0xF>(0.0f, v);   // quad_perm [2,3,0,1]
+  v += mesm_dpp<0x141, 0xF>(0.0f, v);  // row_half_mirror
+  v += mesm_dpp<0x140, 0xF>(0.0f, v);  // row_mirror: every lane holds its row-of-16 sum
+  v += mesm_dpp<0x142, 0xA>(0.0f, v);  // row_bcast:15 -> rows 1, 3
+  v += mesm_dpp<0x143, 0xC>(0.0f, v);  // row_bcast:31 -> rows 2, 3: row 3 holds the total
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  v = fmaxf(v, mesm_dpp<0xB1, 0xF>(v, v));
+  v = fmaxf(v, mesm_dpp<0x4E, 0xF>(v, v));
+  v = fmaxf(v, mesm_dpp<0x141, 0xF>(v, v));
+  v = fmaxf(v, mesm_dpp<0x140, 0xF>(v, v));
+  v = fmaxf(v, mesm_dpp<0x142, 0xA>(v, v));
+  v = fmaxf(v, mesm_dpp<0x143, 0xC>(v, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// v + the value held by lane (lane ^ 32) / (lane ^ 16): gfx950's v_permlane{32,16}_swap exchanges the
+// odd half (odd rows) of one register with the even half (even rows) of another in one VALU op.
+__device__ __forceinline__ float add_xor32(float v) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float add_xor16(float v) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// Sum over the 64 / W lane groups {lane % W} (every lane of a group ends with the group's total):
+// the lanes that differ only in bits >= log2(W).  In-row steps are DPP row rotations.
+template <int W>
+__device__ __forceinline__ float sum_across_groups(float v) {
+  static_assert(W == 4 || W == 8 || W == 16 || W == 32 || W == 64, "group width");
+  if (W <= 4) v += mesm_dpp<0x124, 0xF>(0.0f, v);  // row_ror:4
+  if (W <= 8) v += mesm_dpp<0x128, 0xF>(0.0f, v);  // row_ror:8
+  if (W <= 16) v = add_xor16(v);
+  if (W <= 32) v = add_xor32(v);
+  return v;
+}
+
+// Sum within aligned groups of N consecutive lanes (N in {2, 4, 8, 16}); all lanes get the total.
+template <int N>
+__device__ __forceinline__ float sum_within(float v) {
+  static_assert(N == 1 || N == 2 || N == 4 || N == 8 || N == 16, "group size");
+  if (N >= 2) v += mesm_dpp<0xB1, 0xF>(0.0f, v);
+  if (N >= 4) v += mesm_dpp<0x4E, 0xF>(0.0f, v);
+  if (N >= 8) v += mesm_dpp<0x141, 0xF>(0.0f, v);
+  if (N >= 16) v += mesm_dpp<0x140, 0xF>(0.0f, v);
   return v;
 }

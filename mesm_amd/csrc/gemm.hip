@@ -865,7 +865,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_frag_kernel(const MesmGemmArgs 
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
   if (do_colsum) {
-    csum += __shfl_xor(csum, 32, 64);
+    csum = add_xor32(csum);
     if (h == 0 && m0 + li < p.M && csum != 0.0f) atomicAdd(p.colsum + m0 + li, csum);
   }
 
@@ -1076,7 +1076,7 @@ __device__ __forceinline__ void wstage_body(const MesmGemmArgs& p, const Blk blk
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
   if (do_colsum) {
-    csum += __shfl_xor(csum, 32, 64);
+    csum = add_xor32(csum);
     if (h == 0 && m0 + li < p.M && csum != 0.0f) atomicAdd(p.colsum + m0 + li, csum);
   }
   __syncthreads();  // every wave is done with its slabs: the reduction buffer aliases them
@@ -1291,7 +1291,7 @@ __device__ __forceinline__ void wstage64_body(const MesmGemmArgs& p, const Blk b
   if (do_colsum) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      float c = csum[t] + __shfl_xor(csum[t], 32, 64);
+      float c = add_xor32(csum[t]);
       const int gm = m0 + 32 * t + li;
       if (h == 0 && gm < p.M && c != 0.0f) atomicAdd(p.colsum + gm, c);
     }
@@ -1500,7 +1500,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_lds64_kernel(const MesmGemmArgs
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 
   if (do_colsum) {
-    csum += __shfl_xor(csum, 32, 64);
+    csum = add_xor32(csum);
     const int gm = m0 + 32 * wm + li;
     if (h == 0 && gm < p.M && csum != 0.0f) atomicAdd(p.colsum + gm, csum);
   }
