@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmesm_gfx950.so")
+LIB_PATH = os.environ.get("MESM_LIB_PATH") or os.path.join(_HERE, "libmesm_gfx950.so")  # override: tuning builds (tools/build_variant.sh)
 
 ACT_NONE, ACT_RELU, ACT_PRELU = 0, 1, 2
 LAYOUT_REDUCE_CONTIG, LAYOUT_OUTER_CONTIG = 0, 1

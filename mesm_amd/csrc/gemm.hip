@@ -536,14 +536,103 @@ int launch_tile(const MesmGemmArgs& a, hipStream_t s) {
 
 inline bool aligned_to(const void* p, size_t b) { return p == nullptr || ((uintptr_t)p % b) == 0; }
 
+// Epilogue of NV accumulator values per lane: value i belongs to row rbase + RO(i) (RO = row offset
+// table of the MFMA 32x32 accumulator layout) and column col.  Written in STAGES over the whole
+// register array -- scale+bias, activation, dropout, activation-gradient, residual / read-modify-write,
+// store -- so that every run-time flag of MesmGemmArgs is tested once per wave, not once per element, and
+// the side loads of a stage are all in flight together; row addresses are one per-lane 64-bit base plus
+// wave-uniform multiples of the leading dimension.  (In-kernel stamps, tools/l64_trace.py: the
+// per-element form took ~8,000 cycles per 32x32 tile, as long as 3.5 k-tiles of MFMA work.)
+// FULL: the wave's 32 x 32 tile lies inside C, no bounds handling at all.
+template <int NV, bool FULL, typename RowOff>
+__device__ __forceinline__ float staged_epilogue(const MesmGemmArgs& p, float (&t)[NV], int rbase, int col,
+                                                 float slope, uint32_t seed_off, bool first_split, RowOff RO) {
+  const bool colok = FULL || col < p.N;
+  const int colc = colok ? col : p.N - 1;
+  bool ok[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) ok[i] = FULL || (colok && rbase + RO(i) < p.M);
+  // element offset of value i in a row-major side matrix with leading dimension ld, clamped into the matrix
+  auto off = [&](int i, int64_t lane_base, int64_t ld) -> int64_t {
+    const int64_t o = lane_base + (int64_t)RO(i) * ld;
+    if (FULL) return o;
+    const int64_t last = (int64_t)(p.M - 1) * ld + colc;
+    return o < last ? o : last;
+  };
+
+  const float bias_v = (p.bias != nullptr && first_split) ? p.bias[colc] : 0.0f;
+  const float sc = p.out_scale;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) t[i] = t[i] * sc + bias_v;
+  if (p.e_act != MESM_ACT_NONE) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) t[i] = mesm_act(t[i], p.e_act, slope);
+  }
+  if (p.e_drop_p > 0.f) {
+    const uint32_t thresh = mesm_drop_threshold(p.e_drop_p);
+    const float inv_keep = 1.0f / (1.0f - p.e_drop_p);
+    const uint32_t seed = p.e_drop_seed + seed_off;
+    const uint32_t idx0 = (uint32_t)rbase * (uint32_t)p.N + (uint32_t)col;  // dense index of C, modulo 2^32
+#pragma unroll
+    for (int i = 0; i < NV; ++i) t[i] = mesm_dropout_apply(t[i], idx0 + (uint32_t)RO(i) * (uint32_t)p.N, seed, thresh, inv_keep);
+  }
+  float dslope_part = 0.0f;
+  if (p.e_actgrad != MESM_ACT_NONE) {
+    const int64_t lb = (int64_t)rbase * p.ldaux + colc;
+    float z[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) z[i] = p.aux[off(i, lb, p.ldaux)];
+    if (p.e_actgrad == MESM_ACT_RELU) {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) t[i] = z[i] > 0.0f ? t[i] : 0.0f;
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i)
+        if (z[i] <= 0.0f) {
+          if (ok[i]) dslope_part += t[i] * z[i];
+          t[i] *= slope;
+        }
+    }
+  }
+  const bool use_res = p.residual != nullptr && first_split;
+  const bool rmw = p.accumulate == 1;
+  if (use_res || rmw) {
+    float add[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) add[i] = 0.0f;
+    if (use_res) {
+      const int64_t lb = (int64_t)rbase * p.ldr + colc;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) add[i] = p.residual[off(i, lb, p.ldr)];
+    }
+    if (rmw) {
+      const int64_t lb = (int64_t)rbase * p.ldc + colc;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) add[i] += p.C[off(i, lb, p.ldc)];
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) t[i] += add[i];
+  }
+  float* cp = p.C + ((int64_t)rbase * p.ldc + col);
+  if (p.accumulate == 2) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (ok[i]) atomicAdd(cp + (int64_t)RO(i) * p.ldc, t[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (ok[i]) cp[(int64_t)RO(i) * p.ldc] = t[i];
+  }
+  return dslope_part;
+}
+
 // Epilogue shared by the k-split kernels: the four waves hold partial sums of the same 32x32 tile;
 // they meet in LDS (Red: 4 x 16 x 64 floats) and wave w takes accumulator registers [4w, 4w+4)
-// through bias / activation / dropout / activation-gradient / residual / accumulate.
+// (rows 4h + rr + 8w) through the staged epilogue.
 __device__ __forceinline__ void ksplit_epilogue(const MesmGemmArgs& p, const f32x16& acc, float* Red, int m0,
                                                 int n0, float slope, uint32_t seed_off, int bz, int64_t slot) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 31, h = lane >> 5;
-  // sum the four partial tiles; wave w takes accumulator registers [4w, 4w+4) through the epilogue
 #pragma unroll
   for (int r = 0; r < 16; ++r) Red[(wave * 16 + r) * 64 + lane] = acc[r];
   __syncthreads();
@@ -556,115 +645,34 @@ __device__ __forceinline__ void ksplit_epilogue(const MesmGemmArgs& p, const f32
     for (int w = 0; w < 4; ++w) t += Red[(w * 16 + r0 + rr) * 64 + lane];
     vals[rr] = t;
   }
-
   const bool first_split = (p.split_k <= 1) || (bz == 0);
-  const uint32_t e_thresh = p.e_drop_p > 0.f ? mesm_drop_threshold(p.e_drop_p) : 0u;
-  const float e_inv_keep = 1.0f / (1.0f - p.e_drop_p);
-  const bool use_bias = p.bias != nullptr && first_split;
-  const bool use_res = p.residual != nullptr && first_split;
-  const bool use_aux = p.e_actgrad != MESM_ACT_NONE;
-  const bool rmw = p.accumulate == 1;
-  float dslope_part = 0.0f;
-  const int col = n0 + li;
-  const bool colok = col < p.N;
-  const int colc = colok ? col : p.N - 1;
-  const int rbase = m0 + 4 * h;
-  float resv[4], auxv[4], oldv[4];
-  const float bias_v = use_bias ? p.bias[colc] : 0.0f;
-#pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    const int r = r0 + rr;
-    int row = rbase + (r & 3) + 8 * (r >> 2);
-    row = row < p.M ? row : p.M - 1;
-    resv[rr] = use_res ? p.residual[(int64_t)row * p.ldr + colc] : 0.0f;
-    auxv[rr] = use_aux ? p.aux[(int64_t)row * p.ldaux + colc] : 0.0f;
-    oldv[rr] = rmw ? p.C[(int64_t)row * p.ldc + colc] : 0.0f;
-  }
-#pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    const int r = r0 + rr;
-    const int row = rbase + (r & 3) + 8 * (r >> 2);
-    float t = vals[rr] * p.out_scale + bias_v;
-    t = mesm_act(t, p.e_act, slope);
-    if (e_thresh)
-      t = mesm_dropout_apply(t, (uint32_t)((int64_t)row * p.N + col), p.e_drop_seed + seed_off, e_thresh,
-                             e_inv_keep);
-    if (use_aux) {
-      const float z = auxv[rr];
-      if (p.e_actgrad == MESM_ACT_RELU) {
-        t = z > 0.0f ? t : 0.0f;
-      } else if (z <= 0.0f) {
-        if (row < p.M && colok) dslope_part += t * z;
-        t *= slope;
-      }
-    }
-    t += resv[rr] + oldv[rr];
-    if (row < p.M && colok) {
-      float* c = p.C + (int64_t)row * p.ldc + col;
-      if (p.accumulate == 2) atomicAdd(c, t);
-      else *c = t;
-    }
-  }
+  const int rbase = m0 + 4 * h + 8 * wave;
+  auto RO = [](int i) { return i; };
+  float dslope_part;
+  if (m0 + 32 <= p.M && n0 + 32 <= p.N)
+    dslope_part = staged_epilogue<4, true>(p, vals, rbase, n0 + li, slope, seed_off, first_split, RO);
+  else
+    dslope_part = staged_epilogue<4, false>(p, vals, rbase, n0 + li, slope, seed_off, first_split, RO);
   if (p.e_actgrad == MESM_ACT_PRELU && p.dslope) dslope_store(p, dslope_part, Red, slot);
 }
 
 // Epilogue of ONE wave-owned 32 x 32 tile held in 16 accumulator registers (register r <-> row
-// 4h + (r & 3) + 8 (r >> 2), column lane & 31): bias / activation / dropout / activation-gradient /
-// residual / accumulate, side loads issued in groups of four rows.
+// 4h + (r & 3) + 8 (r >> 2), column lane & 31).
 __device__ __forceinline__ void tile16_epilogue(const MesmGemmArgs& p, const f32x16& acc, int row0, int col0,
                                                 float slope, uint32_t seed_off, int bz, float* sh4,
                                                 int64_t slot) {
   const int lane = threadIdx.x & 63;
   const int li = lane & 31, h = lane >> 5;
   const bool first_split = (p.split_k <= 1) || (bz == 0);
-  const uint32_t e_thresh = p.e_drop_p > 0.f ? mesm_drop_threshold(p.e_drop_p) : 0u;
-  const float e_inv_keep = 1.0f / (1.0f - p.e_drop_p);
-  const bool use_bias = p.bias != nullptr && first_split;
-  const bool use_res = p.residual != nullptr && first_split;
-  const bool use_aux = p.e_actgrad != MESM_ACT_NONE;
-  const bool rmw = p.accumulate == 1;
-  float dslope_part = 0.0f;
-  const int col = col0 + li;
-  const bool colok = col < p.N;
-  const int colc = colok ? col : p.N - 1;
-  const int rbase = row0 + 4 * h;
-  const float bias_v = use_bias ? p.bias[colc] : 0.0f;
+  float t[16];
 #pragma unroll
-  for (int g4 = 0; g4 < 4; ++g4) {
-    float resv[4], auxv[4], oldv[4];
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      int row = rbase + rr + 8 * g4;
-      row = row < p.M ? row : p.M - 1;
-      resv[rr] = use_res ? p.residual[(int64_t)row * p.ldr + colc] : 0.0f;
-      auxv[rr] = use_aux ? p.aux[(int64_t)row * p.ldaux + colc] : 0.0f;
-      oldv[rr] = rmw ? p.C[(int64_t)row * p.ldc + colc] : 0.0f;
-    }
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int row = rbase + rr + 8 * g4;
-      float t = acc[4 * g4 + rr] * p.out_scale + bias_v;
-      t = mesm_act(t, p.e_act, slope);
-      if (e_thresh)
-        t = mesm_dropout_apply(t, (uint32_t)((int64_t)row * p.N + col), p.e_drop_seed + seed_off, e_thresh,
-                               e_inv_keep);
-      if (use_aux) {
-        const float z = auxv[rr];
-        if (p.e_actgrad == MESM_ACT_RELU) {
-          t = z > 0.0f ? t : 0.0f;
-        } else if (z <= 0.0f) {
-          if (row < p.M && colok) dslope_part += t * z;
-          t *= slope;
-        }
-      }
-      t += resv[rr] + oldv[rr];
-      if (row < p.M && colok) {
-        float* c = p.C + (int64_t)row * p.ldc + col;
-        if (p.accumulate == 2) atomicAdd(c, t);
-        else *c = t;
-      }
-    }
-  }
+  for (int i = 0; i < 16; ++i) t[i] = acc[i];
+  auto RO = [](int i) { return (i & 3) + 8 * (i >> 2); };
+  float dslope_part;
+  if (row0 + 32 <= p.M && col0 + 32 <= p.N)
+    dslope_part = staged_epilogue<16, true>(p, t, row0 + 4 * h, col0 + li, slope, seed_off, first_split, RO);
+  else
+    dslope_part = staged_epilogue<16, false>(p, t, row0 + 4 * h, col0 + li, slope, seed_off, first_split, RO);
   if (p.e_actgrad == MESM_ACT_PRELU && p.dslope) dslope_store(p, dslope_part, sh4, slot);
 }
 
@@ -1355,23 +1363,66 @@ int launch_wstage64(const MesmGemmArgs& a, hipStream_t s) {
 #ifndef MESM_L64_STAGES
 #define MESM_L64_STAGES 3
 #endif
-constexpr int L64_STAGES = MESM_L64_STAGES;  // 3: two k-tiles in flight (48 KB); 2: one in flight (32 KB, more workgroups per CU)
+#ifndef MESM_L64_WAVES
+#define MESM_L64_WAVES 0
+#endif
+#if MESM_L64_WAVES > 0
+#define L64_BOUNDS __launch_bounds__(NTHREADS, MESM_L64_WAVES)  // second argument = waves per SIMD the register budget must admit
+#else
+#define L64_BOUNDS __launch_bounds__(NTHREADS)
+#endif
+constexpr int L64_STAGES = MESM_L64_STAGES;  // ring depth: STAGES - 1 k-tiles in flight behind the one being multiplied (16 KB each; at most 8)
+static_assert(L64_STAGES >= 2 && L64_STAGES <= 8, "ring depth");
 constexpr int L64_STAGE_FLOATS = 4 * WS_SLAB;  // A rows 0-31, A rows 32-63, B rows 0-31, B rows 32-63
 
-__device__ __forceinline__ void glds16(const float* g, float* lds_dst) {
+__device__ __forceinline__ void glds16(const float* g, unsigned lds_byte_addr) {
   // LDS-DMA: 16 bytes per lane, destination = wave-uniform LDS byte address (M0) + lane * 16
-  const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds_dst;
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
-               : "v"(g), "s"(__builtin_amdgcn_readfirstlane(dst))
+               : "v"(g), "s"(lds_byte_addr)
                : "memory");
 }
+
+// Per-lane source addresses of the 4 LDS-DMA instructions a wave issues per k-tile for its 32-row slab,
+// computed ONCE (row clamp, swizzle, 64-bit row * ld): inside the k loop a full k-tile only adds the
+// wave-uniform k advance.  Address rules are ws_issue's.
+template <int LAYOUT>
+struct L64Src {
+  const float* ptr[4];  // k-tile 0 of the workgroup's reduce range
+  int64_t kstep;        // elements per k-tile: 32 (reduce-contiguous) or 32 * ld (outer-contiguous)
+  __device__ __forceinline__ void init(const float* __restrict__ base, int64_t ld, int o0, int extent, int kbeg,
+                                       int lane) {
+    const int sr = lane >> 3, pos = lane & 7;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (LAYOUT == MESM_LAYOUT_REDUCE_CONTIG) {
+        const int r = 8 * q + sr;
+        int row = o0 + r;
+        row = row < extent ? row : extent - 1;
+        const int c = pos ^ ((r >> 1) & 7);
+        ptr[q] = base + (int64_t)row * ld + (kbeg + 4 * c);
+      } else {
+        const int k = kbeg + 8 * q + (((sr & 1) << 2) | (sr >> 1));
+        int o = o0 + 4 * pos;
+        o = o + 4 <= extent ? o : extent - 4;
+        ptr[q] = base + (int64_t)k * ld + o;
+      }
+    }
+    kstep = LAYOUT == MESM_LAYOUT_REDUCE_CONTIG ? 32 : 32 * ld;
+  }
+  // k-tile st lies entirely inside the reduce range
+  __device__ __forceinline__ void issue_full(int st, unsigned slab_byte_addr) const {
+    const int64_t adv = (int64_t)st * kstep;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) glds16(ptr[q] + adv, slab_byte_addr + q * 1024);
+  }
+};
 
 // one 32-row slab of a k-tile: 4 LDS-DMA instructions of this wave (same address rules as ws_issue)
 template <int LAYOUT>
 __device__ __forceinline__ void l64_issue(const float* __restrict__ base, int64_t ld, int o0, int extent,
-                                          int kb, int kend, float* slab, int lane) {
+                                          int kb, int kend, unsigned slab_byte_addr, int lane) {
   const int sr = lane >> 3, pos = lane & 7;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -1391,17 +1442,36 @@ __device__ __forceinline__ void l64_issue(const float* __restrict__ base, int64_
       o = o + 4 <= extent ? o : extent - 4;
       g = base + (int64_t)k * ld + o;
     }
-    glds16(g, slab + q * 256);
+    glds16(g, slab_byte_addr + q * 1024);
   }
 }
 
+#ifdef MESM_L64_TRACE
+// in-kernel time stamps (s_memtime, shader cycles) of wave 0 of the first 1024 workgroups: 32 slots each
+__device__ unsigned long long l64_trace[1024 * 32];
+__device__ __forceinline__ void l64_stamp(int slot) {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  if (threadIdx.x == 0 && blockIdx.x < 1024 && blockIdx.z == 0 && slot < 32) l64_trace[blockIdx.x * 32 + slot] = t;
+}
+#define L64_STAMP(i) l64_stamp(i)
+#else
+#define L64_STAMP(i)
+#endif
+
+// Tuning builds (tools/build_variant.sh): -DMESM_L64_STAGES / -DMESM_L64_WAVES change ring depth and the
+// occupancy target; -DMESM_L64_NO_LOAD / _NO_MFMA / _NO_STORE are kill switches that remove one phase
+// (wrong results, timing only) -- the decomposition quoted in DESIGN.md section 8 comes from them.
 template <int LA, int LB, bool XF>
-__global__ __launch_bounds__(NTHREADS) void gemm_lds64_kernel(const MesmGemmArgs p) {
+__global__ L64_BOUNDS void gemm_lds64_kernel(const MesmGemmArgs p) {
   __shared__ __attribute__((aligned(16))) float L[L64_STAGES * L64_STAGE_FLOATS];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
+  L64_STAMP(0);
   int tbx, tby;
   xcd_tile(blockIdx.x, (p.M + 63) / 64, (p.N + 63) / 64, tbx, tby);
   const int m0 = tbx * 64, n0 = tby * 64;
@@ -1426,12 +1496,30 @@ __global__ __launch_bounds__(NTHREADS) void gemm_lds64_kernel(const MesmGemmArgs
   xb.seed = p.b_drop_seed + seed_off; xb.inv_keep = 1.0f / (1.0f - p.b_drop_p);
   xb.lld = LB == MESM_LAYOUT_REDUCE_CONTIG ? p.K : p.N;
 
-  // wave w stages slab w of every k-tile: 0/1 = A rows [0,32) / [32,64), 2/3 = B rows [0,32) / [32,64)
+  // wave w stages slab w of every k-tile: 0/1 = A rows [0,32) / [32,64), 2/3 = B rows [0,32) / [32,64).
+  // wave_u / L_base are wave-uniform scalars, so every LDS-DMA destination is SALU arithmetic.
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned L_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)L;
+  L64Src<LA> srcA;
+  L64Src<LB> srcB;
+  if (wave_u < 2) srcA.init(p.A, p.lda, m0 + 32 * wave_u, p.M, kbeg, lane);
+  else srcB.init(p.B, p.ldb, n0 + 32 * (wave_u - 2), p.N, kbeg, lane);
+  int i_slot = 0;  // ring slot of the next k-tile to issue
   auto issue = [&](int st) {
-    float* slab = L + (st % L64_STAGES) * L64_STAGE_FLOATS + wave * WS_SLAB;
+#ifdef MESM_L64_NO_LOAD
+    return;
+#endif
+    const unsigned slab = L_base + (unsigned)(i_slot * L64_STAGE_FLOATS + wave_u * WS_SLAB) * 4u;
+    i_slot = i_slot + 1 == L64_STAGES ? 0 : i_slot + 1;
     const int kb = kbeg + 32 * st;
-    if (wave < 2) l64_issue<LA>(p.A, p.lda, m0 + 32 * wave, p.M, kb, kend, slab, lane);
-    else l64_issue<LB>(p.B, p.ldb, n0 + 32 * (wave - 2), p.N, kb, kend, slab, lane);
+    if (kb + 32 <= kend) {
+      if (wave_u < 2) srcA.issue_full(st, slab);
+      else srcB.issue_full(st, slab);
+    } else if (wave_u < 2) {
+      l64_issue<LA>(p.A, p.lda, m0 + 32 * wave_u, p.M, kb, kend, slab, lane);
+    } else {
+      l64_issue<LB>(p.B, p.ldb, n0 + 32 * (wave_u - 2), p.N, kb, kend, slab, lane);
+    }
   };
 
   f32x16 acc;
@@ -1441,17 +1529,35 @@ __global__ __launch_bounds__(NTHREADS) void gemm_lds64_kernel(const MesmGemmArgs
   const bool do_colsum = (p.colsum != nullptr) && (tby == 0) && (wn == 0);
 
   constexpr int AHEAD = L64_STAGES - 1;  // k-tiles in flight behind the one being multiplied
-  if (nst > 0) issue(0);
-  if (AHEAD > 1 && nst > 1) issue(1);
+  int c_slot = 0;                        // ring slot of the k-tile being multiplied
+  L64_STAMP(1);
+#pragma unroll
+  for (int i = 0; i < AHEAD; ++i)
+    if (i < nst) issue(i);
+  L64_STAMP(2);
   for (int st = 0; st < nst; ++st) {
-    // this wave's 4 LDS-DMA instructions of k-tile st have landed (k-tile st+1 may still fly) ...
-    if (AHEAD > 1 && st + 1 < nst) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // this wave's 4 LDS-DMA instructions of k-tile st have landed; the min(AHEAD - 1, nst - 1 - st)
+    // k-tiles issued after it may still fly (4 instructions each, returned in issue order) ...
+    {
+      const int later = nst - 1 - st < AHEAD - 1 ? nst - 1 - st : AHEAD - 1;
+      switch (later) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+      }
+    }
+    L64_STAMP(3 + 3 * st);  // this wave's loads of k-tile st landed
     // ... and so have the other waves': one barrier per k-tile.  It also orders the fragment reads of
     // k-tile st-1 (finished by every wave before it arrived here) ahead of the refill issued below.
     __builtin_amdgcn_s_barrier();
+    L64_STAMP(4 + 3 * st);  // every wave's landed
     if (st + AHEAD < nst) issue(st + AHEAD);
-    const float* buf = L + (st % L64_STAGES) * L64_STAGE_FLOATS;
+    const float* buf = L + c_slot * L64_STAGE_FLOATS;
+    c_slot = c_slot + 1 == L64_STAGES ? 0 : c_slot + 1;
     float a[4][4], b[4][4];
     ws_read<LA>(buf + wm * WS_SLAB, li, h, a);
     ws_read<LB>(buf + (2 + wn) * WS_SLAB, li, h, b);
@@ -1485,19 +1591,31 @@ __global__ __launch_bounds__(NTHREADS) void gemm_lds64_kernel(const MesmGemmArgs
           b[s_][j] = y;
         }
     }
+#ifdef MESM_L64_NO_MFMA
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[4 * s_ + j] += a[s_][j] * b[s_][j];
+#else
 #pragma unroll
     for (int s_ = 0; s_ < 4; ++s_)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s_][j], b[s_][j], acc, 0, 0, 0);
+#endif
     if (do_colsum) {
 #pragma unroll
       for (int s_ = 0; s_ < 4; ++s_)
 #pragma unroll
         for (int j = 0; j < 4; ++j) csum += a[s_][j];
     }
+    L64_STAMP(5 + 3 * st);  // MFMAs of k-tile st issued
   }
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  L64_STAMP(28);
+#ifdef MESM_L64_NO_STORE
+  if (acc[0] != 12345.678f) return;
+#endif
 
   if (do_colsum) {
     csum = add_xor32(csum);
@@ -1506,7 +1624,25 @@ __global__ __launch_bounds__(NTHREADS) void gemm_lds64_kernel(const MesmGemmArgs
   }
 
   tile16_epilogue(p, acc, m0 + 32 * wm, n0 + 32 * wn, slope, seed_off, blockIdx.z, L, linear_block());
+  L64_STAMP(29);  // stores issued
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  L64_STAMP(30);  // stores acknowledged
+#ifdef MESM_L64_TRACE
+  {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    if (threadIdx.x == 0 && blockIdx.x < 1024 && blockIdx.z == 0) l64_trace[blockIdx.x * 32 + 31] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
 }
+
+#ifdef MESM_L64_TRACE
+extern "C" int mesm_l64_trace_read(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(l64_trace), sizeof(unsigned long long) * 1024 * 32);
+}
+#endif
 
 template <int LA, int LB>
 int launch_lds64_l(const MesmGemmArgs& a, hipStream_t s) {
