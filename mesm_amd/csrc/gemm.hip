@@ -14,6 +14,7 @@
 #include <utility>
 #include <vector>
 
+#include <cstddef>
 #include "common.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -1120,8 +1121,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_wstage_group_kernel(const Group
 #pragma unroll
   for (int k = 1; k < GROUP_MAX; ++k)
     if (k < g.n && bid >= g.start[k]) gi = k;
-  const MesmGemmArgs& p = g.p[gi];
-  const int local = bid - g.start[gi];
+  // The selected problem is read from the kernarg segment with a wave-uniform DYNAMIC offset (scalar
+  // loads).  Indexing the by-value parameter itself (g.p[gi]) made hipcc copy all of GroupArgs into
+  // per-lane scratch first: 1,840 bytes of private memory per lane, written and re-read by every workgroup.
+  const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+  const MesmGemmArgs p = *reinterpret_cast<const MesmGemmArgs*>(ka + offsetof(GroupArgs, p) + (size_t)gi * sizeof(MesmGemmArgs));
+  const int first = *reinterpret_cast<const int*>(ka + offsetof(GroupArgs, start) + (size_t)gi * sizeof(int));
+  const int local = bid - first;
   const int mt = (p.M + 31) / 32, nt = (p.N + 31) / 32;
   Blk blk;
   blk.z = local / (mt * nt);
