@@ -2,25 +2,31 @@
 separate runs: they do not fit one pass on gfx950).  Units and corrections per
 MI355X_MICROARCH.md "HBM": both counters are in KiB; on gfx950 FETCH_SIZE reports exactly half of
 the bytes of wide coalesced reads (128-B requests tallied at 64 B), so it is doubled; WRITE_SIZE is
-exact.  The profiled command executes `steps` training steps in total (bench.py --steps 3 --warmup 1
-= 3 eager warm-up steps before the capture + 1 + 3 replays = 7).
-Usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> <steps>"""
+exact.  The number of training steps the profiled command executed is counted from the trace itself:
+saliency_fwd_kernel runs exactly once per step (eager warm-up, capture, replays and the PCIe-inclusive
+leg of bench.py all included); the 4th argument is only the fallback when that kernel is absent.
+Usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [steps]"""
 import csv, json, sys
 csv.field_size_limit(1 << 30)
 
 
 def gemm_sum(path, counter):
-    tot, n = 0.0, 0
+    tot, n, steps = 0.0, 0, 0
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == counter and "gemm_" in r["Kernel_Name"]:
+        if r["Counter_Name"] != counter:
+            continue
+        if "gemm_" in r["Kernel_Name"]:
             tot += float(r["Counter_Value"])
             n += 1
-    return tot, n
+        elif "saliency_fwd_kernel" in r["Kernel_Name"]:
+            steps += 1
+    return tot, n, steps
 
 
-f, nf = gemm_sum(sys.argv[1], "FETCH_SIZE")
-w, nw = gemm_sum(sys.argv[2], "WRITE_SIZE")
-steps = int(sys.argv[4])
+f, nf, sf = gemm_sum(sys.argv[1], "FETCH_SIZE")
+w, nw, sw = gemm_sum(sys.argv[2], "WRITE_SIZE")
+assert sf == sw, (sf, sw)
+steps = sf if sf > 0 else int(sys.argv[4])
 out = {
     "steps_profiled": steps, "gemm_kernel_launches_per_step": nf / steps,
     "hbm_bytes_per_step": (2.0 * f + w) * 1024.0 / steps,
