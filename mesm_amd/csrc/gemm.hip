@@ -253,13 +253,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const MesmGemmArgs p
   const int m0 = blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
 
-  int kbeg = 0, kend = p.K;
+  const int KM = p.K;  // this kernel stages every reduce index itself
+  int kbeg = 0, kend = KM;
   if (p.split_k > 1) {
     int chunk = (p.K + p.split_k - 1) / p.split_k;
     chunk = ((chunk + BK_MAX - 1) / BK_MAX) * BK_MAX;
     kbeg = blockIdx.z * chunk;
-    kend = kbeg + chunk < p.K ? kbeg + chunk : p.K;
-    if (kbeg >= p.K) return;
+    kend = kbeg + chunk < KM ? kbeg + chunk : KM;
+    if (kbeg >= KM) {
+      if (blockIdx.z > 0) return;
+      kbeg = kend = KM;
+    }
   }
 
   const float slope = p.slope ? *p.slope : 0.0f;
@@ -537,6 +541,52 @@ int launch_tile(const MesmGemmArgs& a, hipStream_t s) {
 
 inline bool aligned_to(const void* p, size_t b) { return p == nullptr || ((uintptr_t)p % b) == 0; }
 
+// Reduce indices [gemm_kmain, K) are NOT staged by the LDS-DMA kernels (wstage / wstage64 / lds64):
+//  * a reduce-contiguous operand is staged in 16-byte chunks along k: the main loop ends at K & ~3;
+//  * an outer-contiguous operand whose outer extent is not a multiple of 4 has one chunk per reduce row
+//    that runs 1-3 floats into the NEXT reduce row (harmless: those outer positions are never stored);
+//    for the last reduce row that would be past the end of the matrix, so the main loop stops before it.
+// The remaining 1-4 indices are added to the accumulators by scalar loads (tail_accumulate).
+__device__ __forceinline__ int gemm_kmain(const MesmGemmArgs& p) {
+  const bool a_red = p.a_layout == MESM_LAYOUT_REDUCE_CONTIG, b_red = p.b_layout == MESM_LAYOUT_REDUCE_CONTIG;
+  int km = p.K;
+  if (a_red || b_red) km &= ~3;
+  if ((!a_red && (p.M & 3)) || (!b_red && (p.N & 3))) {
+    const int lim = (p.K - 1) & ~3;
+    km = km < lim ? km : lim;
+  }
+  return km;
+}
+
+// operand element (outer index o, reduce index k) with the operand transform of the main loop
+template <int LAYOUT, bool XF>
+__device__ __forceinline__ float tail_elem(const float* __restrict__ base, int64_t ld, int o, int k, const XForm& xf) {
+  float x = LAYOUT == MESM_LAYOUT_REDUCE_CONTIG ? base[(int64_t)o * ld + k] : base[(int64_t)k * ld + o];
+  if (XF) {
+    x = mesm_act(x, xf.act, xf.slope);
+    if (xf.thresh)
+      x = mesm_dropout_apply(x, (uint32_t)(LAYOUT == MESM_LAYOUT_REDUCE_CONTIG ? (int64_t)o * xf.lld + k : (int64_t)k * xf.lld + o),
+                             xf.seed, xf.thresh, xf.inv_keep);
+  }
+  return x;
+}
+
+// t[i] += sum over k in [km, K) of A(rbase + RO(i), k) * B(col, k)   (rows / columns clamped into the matrix)
+template <int NV, int LA, int LB, bool XF, typename RowOff>
+__device__ __forceinline__ void tail_accumulate(const MesmGemmArgs& p, float (&t)[NV], int rbase, int col, int km,
+                                                const XForm& xa, const XForm& xb, RowOff RO) {
+  const int colc = col < p.N ? col : p.N - 1;
+  for (int k = km; k < p.K; ++k) {
+    const float y = tail_elem<LB, XF>(p.B, p.ldb, colc, k, xb);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int row = rbase + RO(i);
+      row = row < p.M ? row : p.M - 1;
+      t[i] += tail_elem<LA, XF>(p.A, p.lda, row, k, xa) * y;
+    }
+  }
+}
+
 // Epilogue of NV accumulator values per lane: value i belongs to row rbase + RO(i) (RO = row offset
 // table of the MFMA 32x32 accumulator layout) and column col.  Written in STAGES over the whole
 // register array -- scale+bias, activation, dropout, activation-gradient, residual / read-modify-write,
@@ -630,8 +680,10 @@ __device__ __forceinline__ float staged_epilogue(const MesmGemmArgs& p, float (&
 // Epilogue shared by the k-split kernels: the four waves hold partial sums of the same 32x32 tile;
 // they meet in LDS (Red: 4 x 16 x 64 floats) and wave w takes accumulator registers [4w, 4w+4)
 // (rows 4h + rr + 8w) through the staged epilogue.
+template <int LA, int LB, bool XF>
 __device__ __forceinline__ void ksplit_epilogue(const MesmGemmArgs& p, const f32x16& acc, float* Red, int m0,
-                                                int n0, float slope, uint32_t seed_off, int bz, int64_t slot) {
+                                                int n0, float slope, uint32_t seed_off, int bz, int64_t slot,
+                                                int km, const XForm& xa, const XForm& xb) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 31, h = lane >> 5;
 #pragma unroll
@@ -649,6 +701,7 @@ __device__ __forceinline__ void ksplit_epilogue(const MesmGemmArgs& p, const f32
   const bool first_split = (p.split_k <= 1) || (bz == 0);
   const int rbase = m0 + 4 * h + 8 * wave;
   auto RO = [](int i) { return i; };
+  if (first_split && km < p.K) tail_accumulate<4, LA, LB, XF>(p, vals, rbase, n0 + li, km, xa, xb, RO);
   float dslope_part;
   if (m0 + 32 <= p.M && n0 + 32 <= p.N)
     dslope_part = staged_epilogue<4, true>(p, vals, rbase, n0 + li, slope, seed_off, first_split, RO);
@@ -659,9 +712,10 @@ __device__ __forceinline__ void ksplit_epilogue(const MesmGemmArgs& p, const f32
 
 // Epilogue of ONE wave-owned 32 x 32 tile held in 16 accumulator registers (register r <-> row
 // 4h + (r & 3) + 8 (r >> 2), column lane & 31).
+template <int LA, int LB, bool XF>
 __device__ __forceinline__ void tile16_epilogue(const MesmGemmArgs& p, const f32x16& acc, int row0, int col0,
                                                 float slope, uint32_t seed_off, int bz, float* sh4,
-                                                int64_t slot) {
+                                                int64_t slot, int km, const XForm& xa, const XForm& xb) {
   const int lane = threadIdx.x & 63;
   const int li = lane & 31, h = lane >> 5;
   const bool first_split = (p.split_k <= 1) || (bz == 0);
@@ -669,12 +723,22 @@ __device__ __forceinline__ void tile16_epilogue(const MesmGemmArgs& p, const f32
 #pragma unroll
   for (int i = 0; i < 16; ++i) t[i] = acc[i];
   auto RO = [](int i) { return (i & 3) + 8 * (i >> 2); };
+  if (first_split && km < p.K) tail_accumulate<16, LA, LB, XF>(p, t, row0 + 4 * h, col0 + li, km, xa, xb, RO);
   float dslope_part;
   if (row0 + 32 <= p.M && col0 + 32 <= p.N)
     dslope_part = staged_epilogue<16, true>(p, t, row0 + 4 * h, col0 + li, slope, seed_off, first_split, RO);
   else
     dslope_part = staged_epilogue<16, false>(p, t, row0 + 4 * h, col0 + li, slope, seed_off, first_split, RO);
   if (p.e_actgrad == MESM_ACT_PRELU && p.dslope) dslope_store(p, dslope_part, sh4, slot);
+}
+
+// column-sum share of the tail reduce indices for output row gm (added by the lanes that own the atomics)
+template <int LA, bool XF>
+__device__ __forceinline__ float tail_colsum(const MesmGemmArgs& p, int gm, int km, const XForm& xa) {
+  float c = 0.0f;
+  if (gm < p.M)
+    for (int k = km; k < p.K; ++k) c += tail_elem<LA, XF>(p.A, p.lda, gm, k, xa);
+  return c;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -775,13 +839,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_frag_kernel(const MesmGemmArgs 
   const int li = lane & 31, h = lane >> 5;
   const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
 
-  int kbeg = 0, kend = p.K;
+  const int KM = p.K;  // this kernel stages every reduce index itself
+  int kbeg = 0, kend = KM;
   if (p.split_k > 1) {
     int chunk = (p.K + p.split_k - 1) / p.split_k;
     chunk = ((chunk + BK_MAX - 1) / BK_MAX) * BK_MAX;
     kbeg = blockIdx.z * chunk;
-    kend = kbeg + chunk < p.K ? kbeg + chunk : p.K;
-    if (kbeg >= p.K) return;
+    kend = kbeg + chunk < KM ? kbeg + chunk : KM;
+    if (kbeg >= KM) {
+      if (blockIdx.z > 0) return;
+      kbeg = kend = KM;
+    }
   }
   // this wave's slice of [kbeg, kend): a multiple of 32 long except for the last wave's tail
   const int kw = (((kend - kbeg + 3) >> 2) + 31) & ~31;
@@ -878,7 +946,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_frag_kernel(const MesmGemmArgs 
     if (h == 0 && m0 + li < p.M && csum != 0.0f) atomicAdd(p.colsum + m0 + li, csum);
   }
 
-  ksplit_epilogue(p, acc, Red, m0, n0, slope, seed_off, blockIdx.z, linear_block());
+  ksplit_epilogue<LA, LB, XF>(p, acc, Red, m0, n0, slope, seed_off, blockIdx.z, linear_block(), p.K, XForm{}, XForm{});
 }
 
 template <int LA, int LB>
@@ -954,7 +1022,8 @@ __device__ __forceinline__ void ws_issue(const float* __restrict__ base, int64_t
       int k = kb + 8 * q + (((sr & 1) << 2) | (sr >> 1));
       k = k < k1 ? k : k1 - 1;
       int o = o0 + 4 * pos;
-      o = o + 4 <= extent ? o : extent - 4;  // extent % 4 == 0: a chunk is all in or all out
+      const int e4 = (extent + 3) & ~3;  // a chunk may straddle the extent (into the next reduce row: gemm_kmain)
+      o = o + 4 <= e4 ? o : e4 - 4;
       g = base + (int64_t)k * ld + o;
     }
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -990,13 +1059,17 @@ __device__ __forceinline__ void wstage_body(const MesmGemmArgs& p, const Blk blk
   const int li = lane & 31, h = lane >> 5;
   const int m0 = blk.x * 32, n0 = blk.y * 32;
 
-  int kbeg = 0, kend = p.K;
+  const int KM = gemm_kmain(p);  // reduce indices [KM, K) are added in the epilogue of the first k-slice
+  int kbeg = 0, kend = KM;
   if (p.split_k > 1) {
     int chunk = (p.K + p.split_k - 1) / p.split_k;
     chunk = ((chunk + BK_MAX - 1) / BK_MAX) * BK_MAX;
     kbeg = blk.z * chunk;
-    kend = kbeg + chunk < p.K ? kbeg + chunk : p.K;
-    if (kbeg >= p.K) return;
+    kend = kbeg + chunk < KM ? kbeg + chunk : KM;
+    if (kbeg >= KM) {
+      if (blk.z > 0) return;
+      kbeg = kend = KM;
+    }
   }
   const int kw = (((kend - kbeg + 3) >> 2) + 31) & ~31;
   const int k0 = kbeg + wave * kw;
@@ -1086,10 +1159,11 @@ __device__ __forceinline__ void wstage_body(const MesmGemmArgs& p, const Blk blk
 
   if (do_colsum) {
     csum = add_xor32(csum);
+    if (wave == 0 && blk.z == 0 && KM < p.K) csum += tail_colsum<LA, XF>(p, m0 + li, KM, xa);
     if (h == 0 && m0 + li < p.M && csum != 0.0f) atomicAdd(p.colsum + m0 + li, csum);
   }
   __syncthreads();  // every wave is done with its slabs: the reduction buffer aliases them
-  ksplit_epilogue(p, acc, L, m0, n0, slope, seed_off, blk.z, blk.slot);
+  ksplit_epilogue<LA, LB, XF>(p, acc, L, m0, n0, slope, seed_off, blk.z, blk.slot, KM, xa, xb);
 }
 
 constexpr int WS_LDS_FLOATS = 4 * 2 * 2 * WS_SLAB;  // [wave][stage][operand], 64 KB
@@ -1167,16 +1241,19 @@ int launch_wstage(const MesmGemmArgs& a, hipStream_t s) {
   return launch_wstage_l<O, R>(a, s);
 }
 
-// LDS-DMA moves 16-byte chunks: no addend operand; reduce-contiguous operands need K % 4 == 0 and
-// 16-byte aligned rows, outer-contiguous ones an outer extent that is a multiple of 4.
+// LDS-DMA moves 16-byte chunks, from ANY 4-byte aligned address (measured: rows of 2818 or 5003 floats,
+// 8- and 4-byte aligned, give exact results and 51 us instead of 78 for 2400 x 256 x 2818): no alignment
+// rule on pointers or leading dimensions.  What 16-byte granularity cannot express is handled outside
+// the MFMA loop (gemm_kmain / tail_accumulate): the last K % 4 reduce indices of reduce-contiguous
+// operands, and the last reduce row when an outer-contiguous operand's chunk would straddle past the
+// end of the matrix.  No addend operands (A2 / B2) on this path.
 bool wstage_ok(const MesmGemmArgs& a) {
   if (a.A2 || a.B2) return false;
-  auto ok = [&](int layout, const float* p, int64_t ld, int extent) {
-    if (!aligned_to(p, 16) || ld % 4 != 0) return false;
-    if (layout == MESM_LAYOUT_REDUCE_CONTIG) return a.K % 4 == 0 && a.K >= 4;
-    return extent % 4 == 0 && extent >= 4;
+  auto ok = [&](int layout, int extent) {
+    if (layout == MESM_LAYOUT_REDUCE_CONTIG) return a.K >= 4;
+    return extent >= 4;
   };
-  return ok(a.a_layout, a.A, a.lda, a.M) && ok(a.b_layout, a.B, a.ldb, a.N);
+  return ok(a.a_layout, a.M) && ok(a.b_layout, a.N);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1194,13 +1271,17 @@ __device__ __forceinline__ void wstage64_body(const MesmGemmArgs& p, const Blk b
   const int li = lane & 31, h = lane >> 5;
   const int m0 = blk.x * 64, n0 = blk.y * 64;
 
-  int kbeg = 0, kend = p.K;
+  const int KM = gemm_kmain(p);  // reduce indices [KM, K) are added in the epilogue of the first k-slice
+  int kbeg = 0, kend = KM;
   if (p.split_k > 1) {
     int chunk = (p.K + p.split_k - 1) / p.split_k;
     chunk = ((chunk + BK_MAX - 1) / BK_MAX) * BK_MAX;
     kbeg = blk.z * chunk;
-    kend = kbeg + chunk < p.K ? kbeg + chunk : p.K;
-    if (kbeg >= p.K) return;
+    kend = kbeg + chunk < KM ? kbeg + chunk : KM;
+    if (kbeg >= KM) {
+      if (blk.z > 0) return;
+      kbeg = kend = KM;
+    }
   }
   const int kw = (((kend - kbeg + 3) >> 2) + 31) & ~31;
   const int k0 = kbeg + wave * kw;
@@ -1307,6 +1388,7 @@ __device__ __forceinline__ void wstage64_body(const MesmGemmArgs& p, const Blk b
     for (int t = 0; t < 2; ++t) {
       float c = add_xor32(csum[t]);
       const int gm = m0 + 32 * t + li;
+      if (wave == 0 && blk.z == 0 && KM < p.K) c += tail_colsum<LA, XF>(p, gm, KM, xa);
       if (h == 0 && gm < p.M && c != 0.0f) atomicAdd(p.colsum + gm, c);
     }
   }
@@ -1328,7 +1410,8 @@ __device__ __forceinline__ void wstage64_body(const MesmGemmArgs& p, const Blk b
     sum[r] = t;
   }
   __syncthreads();  // dslope_store reuses the head of L
-  tile16_epilogue(p, sum, m0 + 32 * (wave >> 1), n0 + 32 * (wave & 1), slope, seed_off, blk.z, L, blk.slot);
+  tile16_epilogue<LA, LB, XF>(p, sum, m0 + 32 * (wave >> 1), n0 + 32 * (wave & 1), slope, seed_off, blk.z, L, blk.slot,
+                              KM, xa, xb);
 }
 
 template <int LA, int LB, bool XF>
@@ -1411,7 +1494,8 @@ struct L64Src {
       } else {
         const int k = kbeg + 8 * q + (((sr & 1) << 2) | (sr >> 1));
         int o = o0 + 4 * pos;
-        o = o + 4 <= extent ? o : extent - 4;
+        const int e4 = (extent + 3) & ~3;
+        o = o + 4 <= e4 ? o : e4 - 4;
         ptr[q] = base + (int64_t)k * ld + o;
       }
     }
@@ -1445,7 +1529,8 @@ __device__ __forceinline__ void l64_issue(const float* __restrict__ base, int64_
       int k = kb + 8 * q + (((sr & 1) << 2) | (sr >> 1));
       k = k < kend ? k : kend - 1;
       int o = o0 + 4 * pos;
-      o = o + 4 <= extent ? o : extent - 4;
+      const int e4 = (extent + 3) & ~3;
+      o = o + 4 <= e4 ? o : e4 - 4;
       g = base + (int64_t)k * ld + o;
     }
     glds16(g, slab_byte_addr + q * 1024);
@@ -1482,13 +1567,17 @@ __global__ L64_BOUNDS void gemm_lds64_kernel(const MesmGemmArgs p) {
   xcd_tile(blockIdx.x, (p.M + 63) / 64, (p.N + 63) / 64, tbx, tby);
   const int m0 = tbx * 64, n0 = tby * 64;
 
-  int kbeg = 0, kend = p.K;
+  const int KM = gemm_kmain(p);  // reduce indices [KM, K) are added in the epilogue of the first k-slice
+  int kbeg = 0, kend = KM;
   if (p.split_k > 1) {
     int chunk = (p.K + p.split_k - 1) / p.split_k;
     chunk = ((chunk + BK_MAX - 1) / BK_MAX) * BK_MAX;
     kbeg = blockIdx.z * chunk;
-    kend = kbeg + chunk < p.K ? kbeg + chunk : p.K;
-    if (kbeg >= p.K) return;
+    kend = kbeg + chunk < KM ? kbeg + chunk : KM;
+    if (kbeg >= KM) {
+      if (blockIdx.z > 0) return;
+      kbeg = kend = KM;
+    }
   }
   const int nst = (kend - kbeg + 31) >> 5;
 
@@ -1626,10 +1715,12 @@ __global__ L64_BOUNDS void gemm_lds64_kernel(const MesmGemmArgs p) {
   if (do_colsum) {
     csum = add_xor32(csum);
     const int gm = m0 + 32 * wm + li;
+    if (blockIdx.z == 0 && KM < p.K) csum += tail_colsum<LA, XF>(p, gm, KM, xa);
     if (h == 0 && gm < p.M && csum != 0.0f) atomicAdd(p.colsum + gm, csum);
   }
 
-  tile16_epilogue(p, acc, m0 + 32 * wm, n0 + 32 * wn, slope, seed_off, blockIdx.z, L, linear_block());
+  tile16_epilogue<LA, LB, XF>(p, acc, m0 + 32 * wm, n0 + 32 * wn, slope, seed_off, blockIdx.z, L, linear_block(), KM, xa,
+                              xb);
   L64_STAMP(29);  // stores issued
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   L64_STAMP(30);  // stores acknowledged

@@ -147,7 +147,7 @@ def test_gemm_dropout_matches_materialised_mask():
 
 
 @pytest.mark.parametrize("tile", ["0", "1", "2", "3", "4", "32", "64"])
-@pytest.mark.parametrize("M,N,K", [(2400, 256, 256), (190, 132, 300)])
+@pytest.mark.parametrize("M,N,K", [(2400, 256, 256), (190, 132, 300), (130, 70, 262), (66, 129, 35)])
 def test_gemm_operand_dropout_uses_the_stored_index(tile, M, N, K, monkeypatch):
     """The mask an epilogue wrote on Y (index row*N + col) is replayed when dY is an operand:
     as A of dX = drop(dY) @ W and as A^T of dW = drop(dY)^T @ X (+ the bias column sums)."""
@@ -605,6 +605,34 @@ def test_gemm_group_matches_individual_launches():
                     assert rel_err(y, x) < 1e-4
 
 
+@pytest.mark.parametrize("tile", ["0", "2", "3", "4"])
+def test_gemm_reference_widths_on_the_lds_dma_kernels(tile, monkeypatch):
+    """Dv = 2818 and the 5003-word vocabulary: rows 8- / 4-byte aligned, K % 4 = 2 / 3, outer extents that
+    are not multiples of 4 -- forward, input-gradient and weight-gradient forms, plus strided views."""
+    from mesm_amd import kernels as kn
+    monkeypatch.setenv("MESM_GEMM_TILE", tile)
+    for (rows, wide, d) in [(300, 2818, 256), (200, 5003, 64)]:
+        X = gen((rows, wide), 1); W = gen((d, wide), 2, 0.1); b = gen((d,), 3)
+        Y = torch.empty(rows, d, device=dev())
+        kn.gemm(X, W, Y, trans_b=True, bias=b, e_act=kn.ACT_RELU)                       # K = wide
+        assert rel_err(Y, (X.double() @ W.double().t() + b.double()).clamp(min=0)) < TOL
+        dY = gen((rows, d), 4)
+        dX = torch.empty(rows, wide, device=dev())
+        kn.gemm(dY, W, dX)                                                               # N = wide (outer-contiguous B)
+        assert rel_err(dX, dY.double() @ W.double()) < TOL
+        dW = torch.zeros(d, wide, device=dev()); db = torch.zeros(d, device=dev())
+        kn.gemm(dY, X, dW, trans_a=True, colsum=db, split_k=4, accumulate=2)             # dW = dY^T X
+        assert rel_err(dW, dY.double().t() @ X.double()) < TOL
+        assert rel_err(db, dY.double().sum(0)) < TOL
+        dWt = torch.zeros(wide, d, device=dev()); dbt = torch.zeros(wide, device=dev())
+        kn.gemm(X, dY, dWt, trans_a=True, colsum=dbt, split_k=2, accumulate=2)           # M = wide (outer-contiguous A)
+        assert rel_err(dWt, X.double().t() @ dY.double()) < TOL
+        assert rel_err(dbt, X.double().sum(0)) < TOL
+        Xv = X[:, 1:wide - 2]                                                            # odd start, K = wide - 3
+        kn.gemm(Xv, W[:, 1:wide - 2], Y, trans_b=True)
+        assert rel_err(Y, Xv.double() @ W[:, 1:wide - 2].double().t()) < TOL
+
+
 @pytest.mark.parametrize("tile", ["1", "2", "3", "4"])
 def test_gemm_fuzz_forced_kernel(tile, monkeypatch):
     """The same fuzz with every launch forced onto one of the small-problem / LDS-DMA kernels
@@ -625,9 +653,9 @@ def test_gemm_fuzz_activations():
     rng = random.Random(77)
     slope = torch.tensor([0.2], device=dev())
     for it in range(200):
-        M = rng.choice([7, 24, 32, 80, 256, 264, 600, 608])
-        N = rng.choice([32, 64, 256, 1024])
-        K = rng.choice([24, 64, 256, 1024])
+        M = rng.choice([7, 24, 32, 80, 130, 256, 264, 600, 608])
+        N = rng.choice([32, 64, 130, 256, 1024])
+        K = rng.choice([24, 64, 70, 130, 256, 1024])
         A = gen((M, K), rng.randrange(10 ** 6))
         tb = rng.random() < 0.5
         B = gen((N, K) if tb else (K, N), rng.randrange(10 ** 6), 0.1)
