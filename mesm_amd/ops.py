@@ -62,7 +62,7 @@ def _dw_split(n_out, k_in, rows):
     elif t64 <= 128:
         s = 256 // t64
     else:
-        s = 4
+        s = 4 if t64 < 256 else 2  # 256 x 2818 x 2400: 49 us at 4 (52 at 1); 5003 x 256 x 1024: 37 us at 2 (43 at 1 or 4)
     return max(1, min(s, rows // 64, 32))
 
 
