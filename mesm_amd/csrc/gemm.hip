@@ -1002,6 +1002,14 @@ bool frag_ok(const MesmGemmArgs& a) {
 //   outer-contiguous operand: LDS row 8q + sr holds reduce index 8q + (((sr & 1) << 2) | (sr >> 1)), so
 //     that k and k + 4 (the two lane halves) sit in opposite bank halves; read with ds_read_b32.
 constexpr int WS_SLAB = 32 * 32;  // floats
+#ifndef MESM_WS_WAVES
+#define MESM_WS_WAVES 0
+#endif
+#if MESM_WS_WAVES > 0
+#define WS_BOUNDS __launch_bounds__(NTHREADS, MESM_WS_WAVES)
+#else
+#define WS_BOUNDS __launch_bounds__(NTHREADS)
+#endif
 
 template <int LAYOUT>
 __device__ __forceinline__ void ws_issue(const float* __restrict__ base, int64_t ld, int o0, int extent,
@@ -1052,7 +1060,12 @@ struct Blk {
   int64_t slot;   // linear id inside its problem (dslope workspace slot)
 };
 
-template <int LA, int LB, bool XF>
+// WS_STAGES: wave-private k-tiles resident in LDS per operand pair.  2 = double buffer (64 KB per workgroup,
+// 2 workgroups per CU), 1 = load / read / refill in place (32 KB, 5 per CU).  Measured (tools/gemm_sweep.py):
+// the single stage wins wherever a wave has at most 2 k-tiles or the launch is a single round
+// (2400 x 256 x 256 9.6 -> 8.5 us, 4800 x 256 x 256 14.2 -> 13.0, 256 x 256 x 2400 split 4 8.1 -> 7.6),
+// the double buffer on long k loops over many rounds (4800 x 256 x 1024: 35.7 vs 38.9 us).
+template <int LA, int LB, bool XF, int WS_STAGES>
 __device__ __forceinline__ void wstage_body(const MesmGemmArgs& p, const Blk blk, float* L) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -1086,9 +1099,9 @@ __device__ __forceinline__ void wstage_body(const MesmGemmArgs& p, const Blk blk
   xb.seed = p.b_drop_seed + seed_off; xb.inv_keep = 1.0f / (1.0f - p.b_drop_p);
   xb.lld = LB == MESM_LAYOUT_REDUCE_CONTIG ? p.K : p.N;
 
-  float* mine = L + wave * (2 * 2 * WS_SLAB);
+  float* mine = L + wave * (WS_STAGES * 2 * WS_SLAB);
   auto issue = [&](int st) {
-    float* buf = mine + (st & 1) * (2 * WS_SLAB);
+    float* buf = mine + (st % WS_STAGES) * (2 * WS_SLAB);
     const int kb = k0 + 32 * st;
     ws_issue<LA>(p.A, p.lda, m0, p.M, kb, k1, buf, lane);
     ws_issue<LB>(p.B, p.ldb, n0, p.N, kb, k1, buf + WS_SLAB, lane);
@@ -1101,19 +1114,19 @@ __device__ __forceinline__ void wstage_body(const MesmGemmArgs& p, const Blk blk
   const bool do_colsum = (p.colsum != nullptr) && (blk.y == 0);
 
   if (nst > 0) issue(0);
-  if (nst > 1) issue(1);
+  if (WS_STAGES > 1 && nst > 1) issue(1);
   for (int st = 0; st < nst; ++st) {
     // each stage is 8 LDS-DMA instructions; leave the next stage in flight
-    if (st + 1 < nst) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (WS_STAGES > 1 && st + 1 < nst) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const float* buf = mine + (st & 1) * (2 * WS_SLAB);
+    const float* buf = mine + (st % WS_STAGES) * (2 * WS_SLAB);
     float a[4][4], b[4][4];
     ws_read<LA>(buf, li, h, a);
     ws_read<LB>(buf + WS_SLAB, li, h, b);
     const int kb = k0 + 32 * st;
-    if (st + 2 < nst) {
+    if (st + WS_STAGES < nst) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments are in registers: slab is free
-      issue(st + 2);
+      issue(st + WS_STAGES);
     }
     if (kb + 32 > k1) {  // partial last stage: reduce indices >= k1 contribute zeros
 #pragma unroll
@@ -1166,15 +1179,23 @@ __device__ __forceinline__ void wstage_body(const MesmGemmArgs& p, const Blk blk
   ksplit_epilogue<LA, LB, XF>(p, acc, L, m0, n0, slope, seed_off, blk.z, blk.slot, KM, xa, xb);
 }
 
-constexpr int WS_LDS_FLOATS = 4 * 2 * 2 * WS_SLAB;  // [wave][stage][operand], 64 KB
+constexpr int ws_lds_floats(int stages) { return 4 * stages * 2 * WS_SLAB; }  // [wave][stage][operand]: 64 KB at 2 stages, 32 KB at 1
 
-template <int LA, int LB, bool XF>
-__global__ __launch_bounds__(NTHREADS) void gemm_wstage_kernel(const MesmGemmArgs p) {
-  __shared__ __attribute__((aligned(16))) float L[WS_LDS_FLOATS];
+// which staging depth a problem gets (host side): k-tiles per wave and workgroups of the launch
+inline int ws_stages_for(const MesmGemmArgs& a) {
+  const long z = a.split_k > 1 ? a.split_k : 1;
+  const long kper_wave = ((a.K + z - 1) / z + 3) / 4;
+  const long wgs = (long)((a.M + 31) / 32) * ((a.N + 31) / 32) * z;
+  return (kper_wave <= 64 || wgs <= 512) ? 1 : 2;
+}
+
+template <int LA, int LB, bool XF, int STAGES>
+__global__ WS_BOUNDS void gemm_wstage_kernel(const MesmGemmArgs p) {
+  __shared__ __attribute__((aligned(16))) float L[ws_lds_floats(STAGES)];
   Blk blk;
   xcd_tile(blockIdx.x, (p.M + 31) / 32, (p.N + 31) / 32, blk.x, blk.y);
   blk.z = blockIdx.z; blk.slot = linear_block();
-  wstage_body<LA, LB, XF>(p, blk, L);
+  wstage_body<LA, LB, XF, STAGES>(p, blk, L);
 }
 
 // Grouped launch: up to GROUP_MAX independent small problems in ONE kernel (a launch costs 1.66 us of
@@ -1188,8 +1209,9 @@ struct GroupArgs {
   int n;
 };
 
-__global__ __launch_bounds__(NTHREADS) void gemm_wstage_group_kernel(const GroupArgs g) {
-  __shared__ __attribute__((aligned(16))) float L[WS_LDS_FLOATS];
+template <int STAGES>
+__global__ WS_BOUNDS void gemm_wstage_group_kernel(const GroupArgs g) {
+  __shared__ __attribute__((aligned(16))) float L[ws_lds_floats(STAGES)];
   const int bid = blockIdx.x;
   int gi = 0;
 #pragma unroll
@@ -1211,15 +1233,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_wstage_group_kernel(const Group
   const bool xf = p.a_act != MESM_ACT_NONE || p.b_act != MESM_ACT_NONE || p.a_drop_p > 0.f || p.b_drop_p > 0.f;
   const int sel = (p.a_layout == O ? 2 : 0) + (p.b_layout == O ? 1 : 0);
   if (!xf) {
-    if (sel == 0) wstage_body<R, R, false>(p, blk, L);
-    else if (sel == 1) wstage_body<R, O, false>(p, blk, L);
-    else if (sel == 2) wstage_body<O, R, false>(p, blk, L);
-    else wstage_body<O, O, false>(p, blk, L);
+    if (sel == 0) wstage_body<R, R, false, STAGES>(p, blk, L);
+    else if (sel == 1) wstage_body<R, O, false, STAGES>(p, blk, L);
+    else if (sel == 2) wstage_body<O, R, false, STAGES>(p, blk, L);
+    else wstage_body<O, O, false, STAGES>(p, blk, L);
   } else {
-    if (sel == 0) wstage_body<R, R, true>(p, blk, L);
-    else if (sel == 1) wstage_body<R, O, true>(p, blk, L);
-    else if (sel == 2) wstage_body<O, R, true>(p, blk, L);
-    else wstage_body<O, O, true>(p, blk, L);
+    if (sel == 0) wstage_body<R, R, true, STAGES>(p, blk, L);
+    else if (sel == 1) wstage_body<R, O, true, STAGES>(p, blk, L);
+    else if (sel == 2) wstage_body<O, R, true, STAGES>(p, blk, L);
+    else wstage_body<O, O, true, STAGES>(p, blk, L);
   }
 }
 
@@ -1227,8 +1249,11 @@ template <int LA, int LB>
 int launch_wstage_l(const MesmGemmArgs& a, hipStream_t s) {
   dim3 grid(((a.M + 31) / 32) * ((a.N + 31) / 32), 1, a.split_k > 1 ? a.split_k : 1);  // 1-D: xcd_tile() maps it
   const bool xf = a.a_act != MESM_ACT_NONE || a.b_act != MESM_ACT_NONE || a.a_drop_p > 0.f || a.b_drop_p > 0.f;
-  if (xf) hipLaunchKernelGGL((gemm_wstage_kernel<LA, LB, true>), grid, dim3(NTHREADS), 0, s, a);
-  else hipLaunchKernelGGL((gemm_wstage_kernel<LA, LB, false>), grid, dim3(NTHREADS), 0, s, a);
+  const bool one = ws_stages_for(a) == 1;
+  if (xf && one) hipLaunchKernelGGL((gemm_wstage_kernel<LA, LB, true, 1>), grid, dim3(NTHREADS), 0, s, a);
+  else if (xf) hipLaunchKernelGGL((gemm_wstage_kernel<LA, LB, true, 2>), grid, dim3(NTHREADS), 0, s, a);
+  else if (one) hipLaunchKernelGGL((gemm_wstage_kernel<LA, LB, false, 1>), grid, dim3(NTHREADS), 0, s, a);
+  else hipLaunchKernelGGL((gemm_wstage_kernel<LA, LB, false, 2>), grid, dim3(NTHREADS), 0, s, a);
   const int rc = mesm_launch_status();
   return rc != MESM_OK ? rc : dslope_finish(a, grid, s);
 }
@@ -1416,7 +1441,7 @@ __device__ __forceinline__ void wstage64_body(const MesmGemmArgs& p, const Blk b
 
 template <int LA, int LB, bool XF>
 __global__ __launch_bounds__(NTHREADS) void gemm_wstage64_kernel(const MesmGemmArgs p) {
-  __shared__ __attribute__((aligned(16))) float L[WS_LDS_FLOATS];  // 4 waves x 4 slabs = 64 KB
+  __shared__ __attribute__((aligned(16))) float L[4 * 4 * WS_SLAB];  // 4 waves x 4 slabs = 64 KB
   Blk blk;
   xcd_tile(blockIdx.x, (p.M + 63) / 64, (p.N + 63) / 64, blk.x, blk.y);
   blk.z = blockIdx.z; blk.slot = linear_block();
@@ -1874,7 +1899,10 @@ int launch_group(const MesmGemmArgs* list, const int* vecs, int n, hipStream_t s
     if (g.n == 1) {
       rc = launch_wstage(g.p[0], s);
     } else {
-      hipLaunchKernelGGL(gemm_wstage_group_kernel, dim3(g.start[g.n]), dim3(NTHREADS), 0, s, g);
+      bool one = true;  // single-stage staging only if every problem of the group wants it
+      for (int k = 0; k < g.n; ++k) one = one && ws_stages_for(g.p[k]) == 1;
+      if (one) hipLaunchKernelGGL(gemm_wstage_group_kernel<1>, dim3(g.start[g.n]), dim3(NTHREADS), 0, s, g);
+      else hipLaunchKernelGGL(gemm_wstage_group_kernel<2>, dim3(g.start[g.n]), dim3(NTHREADS), 0, s, g);
       rc = mesm_launch_status();
       for (int k = 0; k < g.n && rc == MESM_OK; ++k) {
         const MesmGemmArgs& a = g.p[k];
