@@ -1001,6 +1001,21 @@ bool frag_ok(const MesmGemmArgs& a) {
 //     the reader (row i, chunk c = 2s + h) finds it at position c ^ ((i >> 1) & 7) with one ds_read_b128;
 //   outer-contiguous operand: LDS row 8q + sr holds reduce index 8q + (((sr & 1) << 2) | (sr >> 1)), so
 //     that k and k + 4 (the two lane halves) sit in opposite bank halves; read with ds_read_b32.
+#ifdef MESM_L64_TRACE
+// in-kernel time stamps (s_memtime, shader cycles) of wave 0 of the first 1024 workgroups: 32 slots each
+__device__ unsigned long long l64_trace[1024 * 32];
+__device__ __forceinline__ void l64_stamp(int slot) {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  if (threadIdx.x == 0 && blockIdx.x < 1024 && blockIdx.z == 0 && slot < 32) l64_trace[blockIdx.x * 32 + slot] = t;
+}
+#define L64_STAMP(i) l64_stamp(i)
+#else
+#define L64_STAMP(i)
+#endif
+
 constexpr int WS_SLAB = 32 * 32;  // floats
 #ifndef MESM_WS_WAVES
 #define MESM_WS_WAVES 0
@@ -1071,6 +1086,7 @@ __device__ __forceinline__ void wstage_body(const MesmGemmArgs& p, const Blk blk
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, h = lane >> 5;
   const int m0 = blk.x * 32, n0 = blk.y * 32;
+  L64_STAMP(0);
 
   const int KM = gemm_kmain(p);  // reduce indices [KM, K) are added in the epilogue of the first k-slice
   int kbeg = 0, kend = KM;
@@ -1113,12 +1129,15 @@ __device__ __forceinline__ void wstage_body(const MesmGemmArgs& p, const Blk blk
   float csum = 0.0f;
   const bool do_colsum = (p.colsum != nullptr) && (blk.y == 0);
 
+  L64_STAMP(1);
   if (nst > 0) issue(0);
   if (WS_STAGES > 1 && nst > 1) issue(1);
+  L64_STAMP(2);
   for (int st = 0; st < nst; ++st) {
     // each stage is 8 LDS-DMA instructions; leave the next stage in flight
     if (WS_STAGES > 1 && st + 1 < nst) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    L64_STAMP(3 + 3 * st);
     const float* buf = mine + (st % WS_STAGES) * (2 * WS_SLAB);
     float a[4][4], b[4][4];
     ws_read<LA>(buf, li, h, a);
@@ -1167,8 +1186,10 @@ __device__ __forceinline__ void wstage_body(const MesmGemmArgs& p, const Blk blk
 #pragma unroll
         for (int j = 0; j < 4; ++j) csum += a[s_][j];
     }
+    L64_STAMP(5 + 3 * st);
   }
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  L64_STAMP(28);
 
   if (do_colsum) {
     csum = add_xor32(csum);
@@ -1177,6 +1198,9 @@ __device__ __forceinline__ void wstage_body(const MesmGemmArgs& p, const Blk blk
   }
   __syncthreads();  // every wave is done with its slabs: the reduction buffer aliases them
   ksplit_epilogue<LA, LB, XF>(p, acc, L, m0, n0, slope, seed_off, blk.z, blk.slot, KM, xa, xb);
+  L64_STAMP(29);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  L64_STAMP(30);
 }
 
 constexpr int ws_lds_floats(int stages) { return 4 * stages * 2 * WS_SLAB; }  // [wave][stage][operand]: 64 KB at 2 stages, 32 KB at 1
@@ -1562,20 +1586,6 @@ __device__ __forceinline__ void l64_issue(const float* __restrict__ base, int64_
   }
 }
 
-#ifdef MESM_L64_TRACE
-// in-kernel time stamps (s_memtime, shader cycles) of wave 0 of the first 1024 workgroups: 32 slots each
-__device__ unsigned long long l64_trace[1024 * 32];
-__device__ __forceinline__ void l64_stamp(int slot) {
-  unsigned long long t;
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-  __builtin_amdgcn_sched_barrier(0);
-  if (threadIdx.x == 0 && blockIdx.x < 1024 && blockIdx.z == 0 && slot < 32) l64_trace[blockIdx.x * 32 + slot] = t;
-}
-#define L64_STAMP(i) l64_stamp(i)
-#else
-#define L64_STAMP(i)
-#endif
 
 // Tuning builds (tools/build_variant.sh): -DMESM_L64_STAGES / -DMESM_L64_WAVES change ring depth and the
 // occupancy target; -DMESM_L64_NO_LOAD / _NO_MFMA / _NO_STORE are kill switches that remove one phase

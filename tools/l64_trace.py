@@ -2,7 +2,7 @@
 run with MESM_LIB_PATH=mesm_amd/variants/libmesm_trace.so).  usage: l64_trace.py M N K ta tb [split]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["MESM_GEMM_TILE"] = "3"
+os.environ.setdefault("MESM_GEMM_TILE", "3")
 import numpy as np
 import torch
 from mesm_amd import kernels as kn
