@@ -26,8 +26,10 @@ constexpr int AT_WAVES = 4;
 constexpr int BW_THREADS = 512;
 constexpr int BW_WAVES = 8;
 constexpr int KT = 64;   // keys per tile (one per lane)
-constexpr int QCH = 16;  // query rows per forward workgroup
-constexpr int QCB = 32;  // query rows staged per backward chunk
+constexpr int QCH = 16;  // query rows per forward workgroup (4 per wave: the P V sweep handles 4 rows at once)
+static_assert(QCH / AT_WAVES == 4, "the batched sweeps read one float4 of row slots per key");
+constexpr int QCB = 32;  // query rows staged per backward chunk (4 per wave)
+static_assert(QCB / BW_WAVES == 4, "the batched sweeps read one float4 of row slots per key");
 
 struct MaskCtx {
   bool kp;   // kpad[b, j]
@@ -43,7 +45,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const MesmAttnArgs
   __shared__ __attribute__((aligned(16))) float Qs[QCH * DK];
   __shared__ __attribute__((aligned(16))) float Os[QCH * DV];
   __shared__ float Ms[QCH], Ls[QCH];
-  __shared__ float Ps[AT_WAVES * KT];
+  __shared__ __attribute__((aligned(16))) float Ps[AT_WAVES * KT * (QCH / AT_WAVES)];  // [wave][key][row slot]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bh = blockIdx.x;
@@ -102,44 +104,69 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const MesmAttnArgs
       kreg[c] = x.x; kreg[c + 1] = x.y; kreg[c + 2] = x.z; kreg[c + 3] = x.w;
     }
 
-    for (int r = wave; r < nq; r += AT_WAVES) {
-      const int i = q0 + r;
-      float s = 0.0f;
+    // A wave owns rows wave, wave + 4, wave + 8, wave + 12 of the chunk.  Phase 1, per row: scores,
+    // online-softmax state, (dropped) probabilities into Ps[key][row slot].  Phase 2, ONE sweep over the
+    // keys for all four rows: a V element is read once and multiplied into four accumulators (the
+    // per-row sweep was half of the row's instructions; the kernel is VALU-issue bound).
+    constexpr int RW = QCH / AT_WAVES;
+    float alpha4[RW];
 #pragma unroll
-      for (int c = 0; c < DK; c += 4) {
-        float4 qv = *reinterpret_cast<const float4*>(Qs + r * DK + c);
-        s += qv.x * kreg[c] + qv.y * kreg[c + 1] + qv.z * kreg[c + 2] + qv.w * kreg[c + 3];
+    for (int rr = 0; rr < RW; ++rr) {
+      const int r = wave + rr * AT_WAVES;
+      float pd = 0.0f;
+      alpha4[rr] = 0.0f;
+      if (r < nq) {
+        const int i = q0 + r;
+        float s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < DK; c += 4) {
+          float4 qv = *reinterpret_cast<const float4*>(Qs + r * DK + c);
+          s += qv.x * kreg[c] + qv.y * kreg[c + 1] + qv.z * kreg[c + 2] + qv.w * kreg[c + 3];
+        }
+        s *= p.scale;
+        bool masked = kp;
+        if (quirk) {
+          bool qp = p.qpad[(int64_t)b2 * p.Lq + i] != 0;
+          masked = masked || (qp && kp2);
+        }
+        if (masked) s = -INFINITY;
+        const float m_old = Ms[r];
+        const float m_new = fmaxf(m_old, wave_max(s));
+        const float pj = (m_new == -INFINITY) ? 0.0f : __expf(s - m_new);
+        const float alpha = (m_old == -INFINITY) ? 0.0f : __expf(m_old - m_new);
+        const float l_new = Ls[r] * alpha + wave_sum(pj);
+        pd = pj;
+        if (thresh) {
+          uint32_t idx = (uint32_t)(((int64_t)bh * p.Lq + i) * p.Lk + j);
+          pd = mesm_dropout_apply(pj, idx, drop_seed, thresh, inv_keep);
+        }
+        alpha4[rr] = alpha;
+        if (lane == 0) { Ms[r] = m_new; Ls[r] = l_new; }
       }
-      s *= p.scale;
-      bool masked = kp;
-      if (quirk) {
-        bool qp = p.qpad[(int64_t)b2 * p.Lq + i] != 0;
-        masked = masked || (qp && kp2);
-      }
-      if (masked) s = -INFINITY;
-      const float m_old = Ms[r];
-      const float m_new = fmaxf(m_old, wave_max(s));
-      const float pj = (m_new == -INFINITY) ? 0.0f : __expf(s - m_new);
-      const float alpha = (m_old == -INFINITY) ? 0.0f : __expf(m_old - m_new);
-      const float l_new = Ls[r] * alpha + wave_sum(pj);
-      float pd = pj;
-      if (thresh) {
-        uint32_t idx = (uint32_t)(((int64_t)bh * p.Lq + i) * p.Lk + j);
-        pd = mesm_dropout_apply(pj, idx, drop_seed, thresh, inv_keep);
-      }
-      Ps[wave * KT + lane] = pd;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      const int d = lane % DV, g = lane / DV;
-      float acc = 0.0f;
-#pragma unroll 8
-      for (int jj = g; jj < KT; jj += G) acc += Ps[wave * KT + jj] * Vs[jj * DV + d];
-      acc = sum_across_groups<DV>(acc);
-      if (g == 0) Os[r * DV + d] = Os[r * DV + d] * alpha + acc;
-      if (lane == 0) { Ms[r] = m_new; Ls[r] = l_new; }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      Ps[(wave * KT + lane) * RW + rr] = pd;
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    {
+      const int d = lane % DV, g = lane / DV;
+      float acc[RW];
+#pragma unroll
+      for (int rr = 0; rr < RW; ++rr) acc[rr] = 0.0f;
+#pragma unroll 4
+      for (int jj = g; jj < KT; jj += G) {
+        const float4 pr = *reinterpret_cast<const float4*>(Ps + (wave * KT + jj) * RW);
+        const float v = Vs[jj * DV + d];
+        acc[0] += pr.x * v; acc[1] += pr.y * v; acc[2] += pr.z * v; acc[3] += pr.w * v;
+      }
+#pragma unroll
+      for (int rr = 0; rr < RW; ++rr) {
+        const int r = wave + rr * AT_WAVES;
+        const float t = sum_across_groups<DV>(acc[rr]);
+        if (g == 0 && r < nq) Os[r * DV + d] = Os[r * DV + d] * alpha4[rr] + t;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 
   // finalise this wave's rows
@@ -163,7 +190,7 @@ __global__ __launch_bounds__(BW_THREADS) void attn_bwd_kernel(const MesmAttnArgs
   __shared__ __attribute__((aligned(16))) float Qs[QCB * DK];
   __shared__ __attribute__((aligned(16))) float dOs[QCB * DV];
   __shared__ float Dl[QCB], Lse[QCB];
-  __shared__ float Ps[BW_WAVES * KT];
+  __shared__ __attribute__((aligned(16))) float Ps[BW_WAVES * KT * (QCB / BW_WAVES)];  // [wave][key][row slot]
   __shared__ __attribute__((aligned(16))) float Red[KT * DR];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -246,58 +273,78 @@ __global__ __launch_bounds__(BW_THREADS) void attn_bwd_kernel(const MesmAttnArgs
     if (tid < QCB) Lse[tid] = (tid < nq) ? p.lse[(int64_t)bh * p.Lq + qc + tid] : 0.0f;
     __syncthreads();
 
-    for (int r = wave; r < nq; r += BW_WAVES) {
-      const int i = qc + r;
-      float s = 0.0f;
+    // rows wave, wave + 8, wave + 16, wave + 24 of the chunk: per-row phase (P recomputed, dV, dS, dK
+    // in registers; dS into Ps[key][row slot]), then ONE dQ sweep over the keys for the four rows
+    constexpr int RB = QCB / BW_WAVES;
 #pragma unroll
-      for (int c = 0; c < DK; c += 4) {
-        float4 qv = *reinterpret_cast<const float4*>(Qs + r * DK + c);
-        s += qv.x * kreg[c] + qv.y * kreg[c + 1] + qv.z * kreg[c + 2] + qv.w * kreg[c + 3];
-      }
-      s *= p.scale;
-      bool masked = kp;
-      if (quirk) {
-        bool qp = p.qpad[(int64_t)b2 * p.Lq + i] != 0;
-        masked = masked || (qp && kp2);
-      }
-      float pj = masked ? 0.0f : __expf(s - Lse[r]);
-      float km = 1.0f;
-      if (thresh) {
-        uint32_t idx = (uint32_t)(((int64_t)bh * p.Lq + i) * p.Lk + j);
-        km = mesm_hash32(idx, drop_seed) >= thresh ? inv_keep : 0.0f;
-      }
-      const float pd = pj * km;
-      float dp = 0.0f;
+    for (int rr = 0; rr < RB; ++rr) {
+      const int r = wave + rr * BW_WAVES;
+      float ds = 0.0f;
+      if (r < nq) {
+        const int i = qc + r;
+        float s = 0.0f;
 #pragma unroll
-      for (int c = 0; c < DV; c += 4) {
-        float4 g = *reinterpret_cast<const float4*>(dOs + r * DV + c);
-        dp += g.x * vreg[c] + g.y * vreg[c + 1] + g.z * vreg[c + 2] + g.w * vreg[c + 3];
-        dvacc[c] += pd * g.x; dvacc[c + 1] += pd * g.y;
-        dvacc[c + 2] += pd * g.z; dvacc[c + 3] += pd * g.w;
-      }
-      const float ds = pj * (dp * km - Dl[r]) * p.scale;
+        for (int c = 0; c < DK; c += 4) {
+          float4 qv = *reinterpret_cast<const float4*>(Qs + r * DK + c);
+          s += qv.x * kreg[c] + qv.y * kreg[c + 1] + qv.z * kreg[c + 2] + qv.w * kreg[c + 3];
+        }
+        s *= p.scale;
+        bool masked = kp;
+        if (quirk) {
+          bool qp = p.qpad[(int64_t)b2 * p.Lq + i] != 0;
+          masked = masked || (qp && kp2);
+        }
+        float pj = masked ? 0.0f : __expf(s - Lse[r]);
+        float km = 1.0f;
+        if (thresh) {
+          uint32_t idx = (uint32_t)(((int64_t)bh * p.Lq + i) * p.Lk + j);
+          km = mesm_hash32(idx, drop_seed) >= thresh ? inv_keep : 0.0f;
+        }
+        const float pd = pj * km;
+        float dp = 0.0f;
 #pragma unroll
-      for (int c = 0; c < DK; c += 4) {
-        float4 qv = *reinterpret_cast<const float4*>(Qs + r * DK + c);
-        dkacc[c] += ds * qv.x; dkacc[c + 1] += ds * qv.y;
-        dkacc[c + 2] += ds * qv.z; dkacc[c + 3] += ds * qv.w;
+        for (int c = 0; c < DV; c += 4) {
+          float4 g = *reinterpret_cast<const float4*>(dOs + r * DV + c);
+          dp += g.x * vreg[c] + g.y * vreg[c + 1] + g.z * vreg[c + 2] + g.w * vreg[c + 3];
+          dvacc[c] += pd * g.x; dvacc[c + 1] += pd * g.y;
+          dvacc[c + 2] += pd * g.z; dvacc[c + 3] += pd * g.w;
+        }
+        ds = pj * (dp * km - Dl[r]) * p.scale;
+#pragma unroll
+        for (int c = 0; c < DK; c += 4) {
+          float4 qv = *reinterpret_cast<const float4*>(Qs + r * DK + c);
+          dkacc[c] += ds * qv.x; dkacc[c + 1] += ds * qv.y;
+          dkacc[c + 2] += ds * qv.z; dkacc[c + 3] += ds * qv.w;
+        }
       }
-      Ps[wave * KT + lane] = ds;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      const int d = lane % DK, g = lane / DK;
-      float acc = 0.0f;
-#pragma unroll 8
-      for (int jj = g; jj < KT; jj += GQ) acc += Ps[wave * KT + jj] * Ks[jj * SK + d];
-      acc = sum_across_groups<DK>(acc);
-      if (g == 0) {
-        float* dst = dqb + (int64_t)i * p.q_ls + d;
-        if (dq_atomic) atomicAdd(dst, acc);
-        else *dst = acc;
-      }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      Ps[(wave * KT + lane) * RB + rr] = ds;
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    {
+      const int d = lane % DK, g = lane / DK;
+      float acc[RB];
+#pragma unroll
+      for (int rr = 0; rr < RB; ++rr) acc[rr] = 0.0f;
+#pragma unroll 4
+      for (int jj = g; jj < KT; jj += GQ) {
+        const float4 pr = *reinterpret_cast<const float4*>(Ps + (wave * KT + jj) * RB);
+        const float kv = Ks[jj * SK + d];
+        acc[0] += pr.x * kv; acc[1] += pr.y * kv; acc[2] += pr.z * kv; acc[3] += pr.w * kv;
+      }
+#pragma unroll
+      for (int rr = 0; rr < RB; ++rr) {
+        const int r = wave + rr * BW_WAVES;
+        const float t = sum_across_groups<DK>(acc[rr]);
+        if (g == 0 && r < nq) {
+          float* dst = dqb + (int64_t)(qc + r) * p.q_ls + d;
+          if (dq_atomic) atomicAdd(dst, t);
+          else *dst = t;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
 
   // deterministic cross-wave reduction of dK then dV through LDS, wave by wave
