@@ -1,5 +1,6 @@
 """In-kernel phase timing of the lds64 GEMM kernel (trace build: tools/build_variant.sh trace -DMESM_L64_TRACE,
-run with MESM_LIB_PATH=mesm_amd/variants/libmesm_trace.so).  usage: l64_trace.py M N K ta tb [split]"""
+run with MESM_LIB_PATH=mesm_amd/variants/libmesm_trace.so; MESM_GEMM_TILE=3 (default) stamps the lds64 kernel,
+MESM_GEMM_TILE=2 the wstage kernel, whose stamp slots have the same meaning).  usage: l64_trace.py M N K ta tb [split]"""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("MESM_GEMM_TILE", "3")

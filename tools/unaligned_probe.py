@@ -1,4 +1,6 @@
-"""Does 16-byte LDS-DMA work from rows that are only 8-byte aligned (ld = 2818)?  correctness + time."""
+"""16-byte LDS-DMA from rows that are only 8- / 4-byte aligned (ld = 2818 / 5003): correctness and time per
+forced kernel.  (The experiment that removed the alignment rule from wstage_ok: 78 -> 51 us at Dv = 2818.)
+usage: unaligned_probe.py [M N ld K]   (operands are [:, :K] views of ld-wide matrices)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,7 +11,7 @@ M, N, KF, K = [int(x) for x in sys.argv[1:5]] if len(sys.argv) > 4 else (2400, 2
 Af = torch.randn(M, KF, device=dev); Bf = torch.randn(N, KF, device=dev)
 A, B = Af[:, :K], Bf[:, :K]
 ref = (A.double() @ B.double().t()).float()
-relax = os.environ.get("MESM_GEMM_RELAX_ALIGN", "")
+relax = ""
 if True:
     for tile in ("0", "3", "4", "2"):
         os.environ["MESM_GEMM_TILE"] = tile
