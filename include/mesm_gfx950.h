@@ -170,6 +170,15 @@ int mesm_layernorm_bwd(const float* dy, const float* x, const float* gamma,
                        float* dbeta, int64_t rows, int32_t D, int32_t accumulate_dx,
                        float drop_p, uint32_t drop_seed, const uint32_t* seed_offset,
                        void* stream);
+/* Same, with a second output dx2 = dropout(dx; drop2_p, drop2_seed) (NULL = off): the mask of the block
+ * whose output (+ residual) the LayerNorm normalised -- `norm(x + dropout(sublayer(x)))`,
+ * transformer.py:534-539, 645-649, 753-754, 792-796 -- so that block's backward gets mask * dx without an
+ * element-wise launch of its own.  Mask index = row * D + col (the sublayer output's dense index). */
+int mesm_layernorm_bwd2(const float* dy, const float* x, const float* gamma,
+                        const float* mean, const float* rstd, float* dx, float* dgamma,
+                        float* dbeta, int64_t rows, int32_t D, int32_t accumulate_dx,
+                        float drop_p, uint32_t drop_seed, const uint32_t* seed_offset,
+                        float* dx2, float drop2_p, uint32_t drop2_seed, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /*

@@ -73,6 +73,7 @@ PROTOTYPES = {
                                              ctypes.POINTER(ctypes.c_double)]),
     "mesm_layernorm_fwd": (ctypes.c_int, [c_ptr] * 6 + [_i64, _i32, _f32, _f32, _u32, c_ptr, c_ptr]),
     "mesm_layernorm_bwd": (ctypes.c_int, [c_ptr] * 8 + [_i64, _i32, _i32, _f32, _u32, c_ptr, c_ptr]),
+    "mesm_layernorm_bwd2": (ctypes.c_int, [c_ptr] * 8 + [_i64, _i32, _i32, _f32, _u32, c_ptr, c_ptr, _f32, _u32, c_ptr]),
     "mesm_attn_fwd": (ctypes.c_int, [ctypes.POINTER(AttnArgs), c_ptr]),
     "mesm_attn_bwd": (ctypes.c_int, [ctypes.POINTER(AttnArgs), c_ptr]),
     "mesm_sine_pos_fwd": (ctypes.c_int, [c_ptr, c_ptr, _i32, _i32, _i32, c_ptr]),

@@ -117,9 +117,14 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x,
     const float* __restrict__ gamma, const float* __restrict__ mean,
     const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ dgamma,
-    float* __restrict__ dbeta, int64_t rows, int D, int accumulate_dx, LnDrop dr) {
+    float* __restrict__ dbeta, int64_t rows, int D, int accumulate_dx, LnDrop dr,
+    float* __restrict__ dx2, LnDrop dr2) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // LN_WAVES * D when LDS_REDUCE
   const uint32_t dseed = dr.seed + (dr.seed_offset ? *dr.seed_offset : 0u);
+  // second output: dx under the dropout mask of the block that PRODUCED the LayerNorm input
+  // (y = LN(res + dropout(block(.)))): that block's backward wants mask * dx, which used to be a separate
+  // element-wise launch (30 per step); the mask index is the block output's dense index row * D + col
+  const uint32_t dseed2 = dr2.seed + (dr2.seed_offset ? *dr2.seed_offset : 0u);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int64_t wave_global = (int64_t)blockIdx.x * LN_WAVES + wave;
@@ -182,6 +187,12 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
           for (int e = 0; e < VEC; ++e) o[e] += old[e];
         }
         st_vec<VEC>(dxr + col, o);
+        if (dx2) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e)
+            o[e] = mesm_dropout_apply(o[e], (uint32_t)(row * D + col + e), dseed2, dr2.thresh, dr2.inv_keep);
+          st_vec<VEC>(dx2 + row * D + col, o);
+        }
       }
     }
   }
@@ -267,7 +278,7 @@ int fwd_launch(const float* x, const float* gamma, const float* beta, float* y, 
 template <int VEC, int NCH>
 int bwd_launch(const float* dy, const float* x, const float* gamma, const float* mean,
                const float* rstd, float* dx, float* dgamma, float* dbeta, int64_t rows, int D,
-               int acc, LnDrop dr, hipStream_t s) {
+               int acc, LnDrop dr, float* dx2, LnDrop dr2, hipStream_t s) {
   int64_t blocks = (rows + LN_WAVES - 1) / LN_WAVES;
   if (D <= 1024) {
     // every workgroup pays 2 D float atomics for dgamma / dbeta, rows per wave are a dependent chain:
@@ -276,7 +287,7 @@ int bwd_launch(const float* dy, const float* x, const float* gamma, const float*
     if (blocks > cap) blocks = cap;
     size_t lds = (size_t)LN_WAVES * D * sizeof(float);
     hipLaunchKernelGGL((ln_bwd_kernel<VEC, NCH, true>), dim3((unsigned)blocks), dim3(LN_THREADS),
-                       lds, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, acc, dr);
+                       lds, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, acc, dr, dx2, dr2);
   } else {
     // every workgroup pays 2 D float atomics for dgamma / dbeta, rows per wave are a dependent chain:
     // measured optimum (tools/ln_bench.py) 64 workgroups up to ~1k rows, 128 beyond
@@ -284,7 +295,7 @@ int bwd_launch(const float* dy, const float* x, const float* gamma, const float*
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL((ln_bwd_kernel<VEC, NCH, false>), dim3((unsigned)blocks),
                        dim3(LN_THREADS), 0, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows,
-                       D, acc, dr);
+                       D, acc, dr, dx2, dr2);
   }
   return mesm_launch_status();
 }
@@ -319,14 +330,17 @@ extern "C" int mesm_layernorm_fwd(const float* x, const float* gamma, const floa
   LN_DISPATCH(fwd_launch, 1, x, gamma, beta, y, mean, rstd, rows, D, eps, dr, s);
 }
 
-extern "C" int mesm_layernorm_bwd(const float* dy, const float* x, const float* gamma,
-                                  const float* mean, const float* rstd, float* dx,
-                                  float* dgamma, float* dbeta, int64_t rows, int32_t D,
-                                  int32_t accumulate_dx, float drop_p, uint32_t drop_seed,
-                                  const uint32_t* seed_offset, void* stream) {
+extern "C" int mesm_layernorm_bwd2(const float* dy, const float* x, const float* gamma,
+                                   const float* mean, const float* rstd, float* dx,
+                                   float* dgamma, float* dbeta, int64_t rows, int32_t D,
+                                   int32_t accumulate_dx, float drop_p, uint32_t drop_seed,
+                                   const uint32_t* seed_offset, float* dx2, float drop2_p,
+                                   uint32_t drop2_seed, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dgamma || !dbeta || rows < 0 || D <= 0)
     return MESM_EINVAL;
-  if (drop_p < 0.f || drop_p >= 1.f) return MESM_EINVAL;
+  if (drop_p < 0.f || drop_p >= 1.f || drop2_p < 0.f || drop2_p >= 1.f) return MESM_EINVAL;
+  if (dx2 && !dx) return MESM_EINVAL;
+  const LnDrop dr2 = make_drop(drop2_p, drop2_seed, seed_offset);
   if (rows == 0) return MESM_OK;
   hipStream_t s = (hipStream_t)stream;
   const LnDrop dr = make_drop(drop_p, drop_seed, seed_offset);
@@ -343,8 +357,17 @@ extern "C" int mesm_layernorm_bwd(const float* dy, const float* x, const float* 
   }
   int vec = pick_vec(D, x, dy, dx, gamma);
   if (vec == 4)
-    LN_DISPATCH(bwd_launch, 4, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, accumulate_dx, dr, s);
+    LN_DISPATCH(bwd_launch, 4, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, accumulate_dx, dr, dx2, dr2, s);
   if (vec == 2)
-    LN_DISPATCH(bwd_launch, 2, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, accumulate_dx, dr, s);
-  LN_DISPATCH(bwd_launch, 1, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, accumulate_dx, dr, s);
+    LN_DISPATCH(bwd_launch, 2, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, accumulate_dx, dr, dx2, dr2, s);
+  LN_DISPATCH(bwd_launch, 1, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, accumulate_dx, dr, dx2, dr2, s);
+}
+
+extern "C" int mesm_layernorm_bwd(const float* dy, const float* x, const float* gamma,
+                                  const float* mean, const float* rstd, float* dx,
+                                  float* dgamma, float* dbeta, int64_t rows, int32_t D,
+                                  int32_t accumulate_dx, float drop_p, uint32_t drop_seed,
+                                  const uint32_t* seed_offset, void* stream) {
+  return mesm_layernorm_bwd2(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, accumulate_dx, drop_p,
+                             drop_seed, seed_offset, nullptr, 0.0f, 0u, stream);
 }

@@ -171,9 +171,10 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, drop=(0.0, 0)):
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx=None, accumulate_dx=False, need_dx=True,
-                  drop=(0.0, 0)):
+                  drop=(0.0, 0), drop2=None):
     """dgamma/dbeta are ACCUMULATED into (flat-gradient views).  need_dx=False: parameter
-    gradients only (returns None).  drop: the (p, seed) the forward fused; dy is masked on load."""
+    gradients only (returns None).  drop: the (p, seed) the forward fused; dy is masked on load.
+    drop2 = (p, seed): also return dropout(dx; p, seed) as a second tensor -> (dx, dx2)."""
     dp, dseed = float(drop[0]), int(drop[1]) & 0xFFFFFFFF
     require_gpu(dy, x, gamma)
     D = x.shape[-1]
@@ -181,6 +182,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx=None, accumulate_d
     dy2 = dy.reshape(-1, D)
     assert x2.is_contiguous() and dy2.is_contiguous()
     if not need_dx:
+        assert drop2 is None
         check(lib().mesm_layernorm_bwd(ptr(dy2), ptr(x2), ptr(gamma), ptr(mean), ptr(rstd), None,
                                        ptr(dgamma), ptr(dbeta), x2.shape[0], D, 0, dp, dseed,
                                        ptr(_seed_offset), stream_ptr()),
@@ -190,11 +192,19 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx=None, accumulate_d
         assert not accumulate_dx
         dx = torch.empty_like(x2)
     dx2 = dx.view(-1, D)
-    check(lib().mesm_layernorm_bwd(ptr(dy2), ptr(x2), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx2),
-                                   ptr(dgamma), ptr(dbeta), x2.shape[0], D,
-                                   1 if accumulate_dx else 0, dp, dseed, ptr(_seed_offset), stream_ptr()),
-          "mesm_layernorm_bwd")
-    return dx2.view(x.shape)
+    if drop2 is None:
+        check(lib().mesm_layernorm_bwd(ptr(dy2), ptr(x2), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx2),
+                                       ptr(dgamma), ptr(dbeta), x2.shape[0], D,
+                                       1 if accumulate_dx else 0, dp, dseed, ptr(_seed_offset), stream_ptr()),
+              "mesm_layernorm_bwd")
+        return dx2.view(x.shape)
+    dxm = torch.empty_like(dx2)
+    check(lib().mesm_layernorm_bwd2(ptr(dy2), ptr(x2), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx2),
+                                    ptr(dgamma), ptr(dbeta), x2.shape[0], D,
+                                    1 if accumulate_dx else 0, dp, dseed, ptr(_seed_offset), ptr(dxm),
+                                    float(drop2[0]), int(drop2[1]) & 0xFFFFFFFF, stream_ptr()),
+          "mesm_layernorm_bwd2")
+    return dx2.view(x.shape), dxm.view(x.shape)
 
 
 def _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop, group=0):

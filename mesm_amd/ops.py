@@ -78,6 +78,41 @@ def _rows(t, rows):
     return t if rows is None else t[rows[0]:rows[1]]
 
 
+class DropSink:
+    """Hand-over of `mask * dY` for the post-norm pattern y = LayerNorm(res + dropout(block(.))).
+    The block's wrapper hangs a sink on its output tensor; the LayerNorm that consumes that tensor
+    makes its backward kernel write dropout(dX; p, seed) as a second output (mesm_layernorm_bwd2) and
+    parks it here; the block's backward, which autograd runs next and which receives that same dX as
+    its dY, takes it instead of launching an element-wise mask kernel.  Any other dataflow (output
+    consumed elsewhere, views in between, eval mode) simply never fills the sink and the block falls
+    back to kn.dropout."""
+    __slots__ = ("p", "seed", "src", "dz")
+
+    def __init__(self, drop):
+        self.p, self.seed = drop
+        self.src = self.dz = None
+
+
+def _sink_for(out_drop):
+    return DropSink(out_drop) if out_drop[0] > 0 else None
+
+
+def _tag(y, sink):
+    if sink is not None:
+        y._mesm_sink = sink
+    return y
+
+
+def _masked_dy(sink, dy2, out_drop):
+    """dropout-mask replay on the incoming gradient of a block whose output went through `out_drop`"""
+    if sink is not None and sink.dz is not None and sink.src is not None \
+            and sink.src.data_ptr() == dy2.data_ptr() and sink.src.numel() == dy2.numel():
+        dz = sink.dz
+        sink.src = sink.dz = None
+        return _2d(dz)
+    return kn.dropout(dy2, *out_drop)
+
+
 # ----------------------------------------------------------------------------- Linear
 class LinearFn(Function):
     """y = dropout_out( relu?( dropout_in(x [+ x2]) @ W[rows]^T + b[rows] ) ) [+ residual].
@@ -88,7 +123,8 @@ class LinearFn(Function):
     """
 
     @staticmethod
-    def forward(ctx, x, x2, residual, w, b, rows, relu, in_drop, out_drop):
+    def forward(ctx, x, x2, residual, w, b, rows, relu, in_drop, out_drop, sink=None):
+        ctx.sink = sink
         wv, bv = _rows(w, rows), (_rows(b, rows) if b is not None else None)
         x = _c(x)
         x2c = _c(x2) if x2 is not None else None
@@ -112,7 +148,7 @@ class LinearFn(Function):
         dy = _c(dy)
         dy2 = _2d(dy)
         if ctx.out_drop[0] > 0:
-            dz = kn.dropout(dy2, *ctx.out_drop)
+            dz = _masked_dy(ctx.sink, dy2, ctx.out_drop)
         elif ctx.relu:
             dz = kn.act_bias_bwd(dy2, _2d(y), ACT_RELU)
         else:
@@ -131,12 +167,13 @@ class LinearFn(Function):
                 dx if (x2 is not None and ctx.needs_input_grad[1]) else None,
                 dy if ctx.has_res and ctx.needs_input_grad[2] else None,
                 None if wdirect else gw, None if (b is None or bdirect) else gb,
-                None, None, None, None)
+                None, None, None, None, None)
 
 
 def linear(x, w, b, *, x2=None, residual=None, rows=None, relu=False, in_drop=NO_DROP,
            out_drop=NO_DROP):
-    return LinearFn.apply(x, x2, residual, w, b, rows, relu, in_drop, out_drop)
+    sink = _sink_for(out_drop)
+    return _tag(LinearFn.apply(x, x2, residual, w, b, rows, relu, in_drop, out_drop, sink), sink)
 
 
 # ----------------------------------------------------------------------------- FFN
@@ -151,7 +188,8 @@ class FFNFn(Function):
     """
 
     @staticmethod
-    def forward(ctx, x, residual, w1, b1, slope, w2, b2, mid_drop, out_drop):
+    def forward(ctx, x, residual, w1, b1, slope, w2, b2, mid_drop, out_drop, sink=None):
+        ctx.sink = sink
         x = _c(x)
         F_ = w1.shape[0]
         z = torch.empty(x.shape[:-1] + (F_,), device=x.device, dtype=torch.float32)
@@ -173,7 +211,7 @@ class FFNFn(Function):
         w1, b1, slope, w2, b2 = ctx.params
         dy = _c(dy)
         dy2 = _2d(dy)
-        dz2 = kn.dropout(dy2, *ctx.out_drop) if ctx.out_drop[0] > 0 else dy2
+        dz2 = _masked_dy(ctx.sink, dy2, ctx.out_drop) if ctx.out_drop[0] > 0 else dy2
         gw2, d_w2 = grad_target(w2)
         gb2, d_b2 = grad_target(b2)
         gw1, d_w1 = grad_target(w1)
@@ -195,11 +233,12 @@ class FFNFn(Function):
         flush_ready()
         return (dx, dy if ctx.has_res and ctx.needs_input_grad[1] and not fold_res else None,
                 None if d_w1 else gw1, None if d_b1 else gb1, None if d_s else gs,
-                None if d_w2 else gw2, None if d_b2 else gb2, None, None)
+                None if d_w2 else gw2, None if d_b2 else gb2, None, None, None)
 
 
 def ffn(x, residual, w1, b1, slope, w2, b2, mid_drop=NO_DROP, out_drop=NO_DROP):
-    return FFNFn.apply(x, residual, w1, b1, slope, w2, b2, mid_drop, out_drop)
+    sink = _sink_for(out_drop)
+    return _tag(FFNFn.apply(x, residual, w1, b1, slope, w2, b2, mid_drop, out_drop, sink), sink)
 
 
 # ----------------------------------------------------------------------------- LayerNorm
@@ -208,11 +247,12 @@ class LayerNormFn(Function):
     model.py:430)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, drop=NO_DROP):
+    def forward(ctx, x, gamma, beta, eps, drop=NO_DROP, sink=None):
         x = _c(x)
         y, mean, rstd = kn.layernorm_fwd(x, gamma, beta, eps, drop)
         ctx.save_for_backward(x, mean, rstd)
         ctx.gamma, ctx.beta, ctx.drop = gamma, beta, drop
+        ctx.sink = sink  # DropSink of the block that produced x (post-norm pattern), or None
         return y
 
     @staticmethod
@@ -220,15 +260,19 @@ class LayerNormFn(Function):
         x, mean, rstd = ctx.saved_tensors
         gg, dg = grad_target(ctx.gamma)
         gb, db = grad_target(ctx.beta)
+        sink = ctx.sink if ctx.needs_input_grad[0] else None
         dx = kn.layernorm_bwd(_c(dy), x, ctx.gamma, mean, rstd, gg, gb, need_dx=ctx.needs_input_grad[0],
-                              drop=ctx.drop)
+                              drop=ctx.drop, drop2=(sink.p, sink.seed) if sink is not None else None)
+        if sink is not None:
+            dx, sink.dz = dx
+            sink.src = dx
         flush_ready()
-        return (dx, None if dg else gg, None if db else gb, None, None)
+        return (dx, None if dg else gg, None if db else gb, None, None, None)
 
 
 def layer_norm(x, gamma, beta, eps=1e-5, drop=NO_DROP):
     """drop = (p, seed): the Dropout that follows the LayerNorm (LinearLayer) rides the same kernels."""
-    return LayerNormFn.apply(x, gamma, beta, eps, drop)
+    return LayerNormFn.apply(x, gamma, beta, eps, drop, getattr(x, "_mesm_sink", None))
 
 
 # ----------------------------------------------------------------------------- attention core
@@ -275,7 +319,8 @@ class MHAFn(Function):
 
     @staticmethod
     def forward(ctx, xq, pq, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad, qpad, attn_drop,
-                out_drop, self_attn, group=0):
+                out_drop, self_attn, group=0, sink=None):
+        ctx.sink = sink
         xq = _c(xq)
         pq = _c(pq) if pq is not None else None
         d = xq.shape[-1]
@@ -325,7 +370,7 @@ class MHAFn(Function):
         dev = xq.device
         dy = _c(dy)
         dy2 = _2d(dy)
-        dz = kn.dropout(dy2, *out_drop) if out_drop[0] > 0 else dy2
+        dz = _masked_dy(ctx.sink, dy2, out_drop) if out_drop[0] > 0 else dy2
         gwo, d_wo = grad_target(w_out)
         gbo, d_bo = grad_target(b_out)
         gwi, d_wi = grad_target(w_in)
@@ -403,14 +448,15 @@ class MHAFn(Function):
         flush_ready()
         return (dxq, dpq, dxk, dpk, dy if has_res and ctx.needs_input_grad[4] and not fold_res else None,
                 None if d_wi else gwi, None if d_bi else gbi, None if d_wo else gwo,
-                None if d_bo else gbo, None, None, None, None, None, None, None)
+                None if d_bo else gbo, None, None, None, None, None, None, None, None)
 
 
 def mha(xq, pq, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad=None, qpad=None,
         attn_drop=NO_DROP, out_drop=NO_DROP, self_attn=False, group=0):
     """group: rows per independent batch when several batches are stacked (mask quirk Q1)."""
-    return MHAFn.apply(xq, pq, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad, qpad, attn_drop,
-                       out_drop, self_attn, group)
+    sink = _sink_for(out_drop)
+    return _tag(MHAFn.apply(xq, pq, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad, qpad, attn_drop,
+                            out_drop, self_attn, group, sink), sink)
 
 
 # ----------------------------------------------------------------------------- sine embeddings

@@ -74,3 +74,70 @@ def test_ffn_block_with_dropout():
     ref.backward(dy.double())
     for got, want, name in zip((x, res, w1, b1, slope, w2, b2), dd, "x res w1 b1 slope w2 b2".split()):
         assert rel(got.grad, want.grad) < 2e-4, name
+
+
+@pytest.mark.parametrize("rows,D", [(2400, 256), (77, 300), (300, 2818)])
+def test_layernorm_backward_second_output_is_the_masked_dx(rows, D):
+    """mesm_layernorm_bwd2: dx2 == dropout(dx; p, seed) element for element."""
+    from mesm_amd import kernels as kn
+    x = gen((rows, D), 11, 2.0)
+    g = gen((D,), 12) * 0.2 + 1.0
+    b = gen((D,), 13) * 0.1
+    dy = gen((rows, D), 14)
+    _, mean, rstd = kn.layernorm_fwd(x, g, b)
+    dg1, db1 = torch.zeros(D, device=dev()), torch.zeros(D, device=dev())
+    dg2, db2 = torch.zeros(D, device=dev()), torch.zeros(D, device=dev())
+    dx_ref = kn.layernorm_bwd(dy, x, g, mean, rstd, dg1, db1)
+    dx, dxm = kn.layernorm_bwd(dy, x, g, mean, rstd, dg2, db2, drop2=(0.1, 777))
+    assert torch.equal(dx, dx_ref)
+    assert torch.equal(dxm, kn.dropout(dx_ref, 0.1, 777))
+    assert rel(dg2, dg1) < 1e-5 and rel(db2, db1) < 1e-5
+
+
+@pytest.mark.parametrize("block", ["linear", "ffn", "mha"])
+def test_post_norm_blocks_take_the_masked_gradient_from_the_layernorm(block, monkeypatch):
+    """y = LayerNorm(res + dropout(block(x))): with the DropSink hand-over the block's backward launches no
+    mask kernel of its own, and every gradient equals the hand-over-free path (split-K atomics make the
+    weight gradients order-dependent in the last bits, hence a tolerance)."""
+    from mesm_amd import kernels as kn, ops
+    N, L, d = 8, 75, 256
+    x0 = gen((N, L, d), 1)
+    w = gen((d, d), 2, 0.05); bb = gen((d,), 3, 0.05)
+    w1 = gen((4 * d, d), 4, 0.05); b1 = gen((4 * d,), 5, 0.05); w2 = gen((d, 4 * d), 6, 0.05); b2 = gen((d,), 7, 0.05)
+    slope = torch.tensor([0.25], device=dev())
+    w_in = gen((3 * d, d), 8, 0.05); b_in = gen((3 * d,), 9, 0.05)
+    gam = gen((d,), 10) * 0.2 + 1.0; bet = gen((d,), 11) * 0.1
+    up = gen((N, L, d), 12)
+
+    def run(use_sink):
+        calls = {"n": 0}
+        orig = kn.dropout
+
+        def counting(*a, **k):
+            calls["n"] += 1
+            return orig(*a, **k)
+        monkeypatch.setattr(kn, "dropout", counting)
+        if not use_sink:
+            monkeypatch.setattr(ops, "_sink_for", lambda out_drop: None)
+        leaves = [t.clone().requires_grad_() for t in (x0, w, bb, w1, b1, w2, b2, slope, w_in, b_in, gam, bet)]
+        x, w_, bb_, w1_, b1_, w2_, b2_, sl_, wi_, bi_, g_, be_ = leaves
+        od = (0.1, 4321)
+        if block == "linear":
+            y = ops.linear(x, w_, bb_, residual=x, out_drop=od)
+        elif block == "ffn":
+            y = ops.ffn(x, x, w1_, b1_, sl_, w2_, b2_, mid_drop=(0.1, 99), out_drop=od)
+        else:
+            y = ops.mha(x, None, x, None, x, wi_, bi_, w_, bb_, 8, attn_drop=(0.1, 5), out_drop=od, self_attn=True)
+        z = ops.layer_norm(y, g_, be_)
+        (z * up).sum().backward()
+        torch.cuda.synchronize()
+        monkeypatch.undo()
+        return calls["n"], [t.grad.clone() if t.grad is not None else None for t in leaves]
+
+    n_sink, g_sink = run(True)
+    n_plain, g_plain = run(False)
+    assert n_sink == 0 and n_plain == 1, (n_sink, n_plain)
+    for a, b_ in zip(g_sink, g_plain):
+        assert (a is None) == (b_ is None)
+        if a is not None:
+            assert rel(a, b_) < 1e-5
