@@ -12,7 +12,7 @@ from mesm_amd.graphed import GraphedStep
 FAMILIES = {
     "gemm": ["mesm_gemm_f32", "mesm_gemm_group"],
     "attn": ["mesm_attn_fwd", "mesm_attn_bwd"],
-    "ln": ["mesm_layernorm_fwd", "mesm_layernorm_bwd"],
+    "ln": ["mesm_layernorm_fwd", "mesm_layernorm_bwd", "mesm_layernorm_bwd2"],
     "loss": ["mesm_set_loss_fwd", "mesm_set_loss_bwd", "mesm_rec_ss_fwd", "mesm_rec_ss_bwd", "mesm_rec_fw_reduce",
              "mesm_rec_fw_rowgrad", "mesm_nll_smooth_fwd", "mesm_nll_smooth_bwd", "mesm_saliency_loss_fwd",
              "mesm_saliency_loss_bwd", "mesm_weighted_sum", "mesm_scale_vec", "mesm_rowdot_fwd", "mesm_rowdot_bwd"],
