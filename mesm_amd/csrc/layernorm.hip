@@ -9,6 +9,19 @@ namespace {
 
 constexpr int LN_THREADS = 256;
 constexpr int LN_WAVES = LN_THREADS / 64;
+// backward: workgroup size and cap are tuning knobs (tools/ln_bench.py): every workgroup ends with 2 D float
+// atomics onto the same dgamma / dbeta addresses, so fewer, fatter workgroups trade tail contention
+// against rows in flight
+// against rows in flight.  Measured, 4800 / 2400 / 1024 / 320 rows of 256: 256 threads x 128 workgroups
+// 11.4 / 8.0 / 5.6 / 4.1 us; 1024 threads, 128 workgroups from 4000 rows and 64 below: 8.1 / 5.9 / 4.8 / 3.8 us.
+#ifndef MESM_LNB_THREADS
+#define MESM_LNB_THREADS 1024
+#endif
+#ifndef MESM_LNB_CAP
+#define MESM_LNB_CAP 128
+#endif
+constexpr int LNB_THREADS = MESM_LNB_THREADS;
+constexpr int LNB_WAVES = LNB_THREADS / 64;
 
 // optional dropout fused behind the normalisation (LinearLayer: LN -> Dropout -> Linear,
 // model.py:421-431): the forward writes dropout(LN(x)), the backward masks dy while loading it.
@@ -113,13 +126,13 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
 }
 
 template <int VEC, int NCH, bool LDS_REDUCE>
-__global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
+__global__ __launch_bounds__(LNB_THREADS) void ln_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x,
     const float* __restrict__ gamma, const float* __restrict__ mean,
     const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ dgamma,
     float* __restrict__ dbeta, int64_t rows, int D, int accumulate_dx, LnDrop dr,
     float* __restrict__ dx2, LnDrop dr2) {
-  extern __shared__ __attribute__((aligned(16))) float red[];  // LN_WAVES * D when LDS_REDUCE
+  extern __shared__ __attribute__((aligned(16))) float red[];  // LNB_WAVES * D when LDS_REDUCE
   const uint32_t dseed = dr.seed + (dr.seed_offset ? *dr.seed_offset : 0u);
   // second output: dx under the dropout mask of the block that PRODUCED the LayerNorm input
   // (y = LN(res + dropout(block(.)))): that block's backward wants mask * dx, which used to be a separate
@@ -127,8 +140,8 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
   const uint32_t dseed2 = dr2.seed + (dr2.seed_offset ? *dr2.seed_offset : 0u);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int64_t wave_global = (int64_t)blockIdx.x * LN_WAVES + wave;
-  const int64_t nwaves = (int64_t)gridDim.x * LN_WAVES;
+  const int64_t wave_global = (int64_t)blockIdx.x * LNB_WAVES + wave;
+  const int64_t nwaves = (int64_t)gridDim.x * LNB_WAVES;
   const float invD = 1.0f / (float)D;
 
   float g[NCH][VEC];
@@ -198,7 +211,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
   }
 
   if (LDS_REDUCE) {
-    // two rounds (dgamma, dbeta) through one LN_WAVES x D buffer
+    // two rounds (dgamma, dbeta) through one LNB_WAVES x D buffer
 #pragma unroll
     for (int round = 0; round < 2; ++round) {
 #pragma unroll
@@ -208,10 +221,10 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(
       }
       __syncthreads();
       float* dst = round == 0 ? dgamma : dbeta;
-      for (int col = threadIdx.x; col < D; col += LN_THREADS) {
+      for (int col = threadIdx.x; col < D; col += LNB_THREADS) {
         float t = 0.0f;
 #pragma unroll
-        for (int w = 0; w < LN_WAVES; ++w) t += red[w * D + col];
+        for (int w = 0; w < LNB_WAVES; ++w) t += red[w * D + col];
         atomicAdd(dst + col, t);
       }
       __syncthreads();
@@ -279,22 +292,20 @@ template <int VEC, int NCH>
 int bwd_launch(const float* dy, const float* x, const float* gamma, const float* mean,
                const float* rstd, float* dx, float* dgamma, float* dbeta, int64_t rows, int D,
                int acc, LnDrop dr, float* dx2, LnDrop dr2, hipStream_t s) {
-  int64_t blocks = (rows + LN_WAVES - 1) / LN_WAVES;
+  int64_t blocks = (rows + LNB_WAVES - 1) / LNB_WAVES;
   if (D <= 1024) {
-    // every workgroup pays 2 D float atomics for dgamma / dbeta, rows per wave are a dependent chain:
-    // measured optimum (tools/ln_bench.py) 64 workgroups up to ~1k rows, 128 beyond
-    const int64_t cap = rows >= 2000 ? 128 : 64;
+    // workgroup cap: see the note at LNB_THREADS
+    const int64_t cap = rows >= 4000 ? MESM_LNB_CAP : MESM_LNB_CAP / 2;
     if (blocks > cap) blocks = cap;
-    size_t lds = (size_t)LN_WAVES * D * sizeof(float);
-    hipLaunchKernelGGL((ln_bwd_kernel<VEC, NCH, true>), dim3((unsigned)blocks), dim3(LN_THREADS),
+    size_t lds = (size_t)LNB_WAVES * D * sizeof(float);
+    hipLaunchKernelGGL((ln_bwd_kernel<VEC, NCH, true>), dim3((unsigned)blocks), dim3(LNB_THREADS),
                        lds, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, acc, dr, dx2, dr2);
   } else {
-    // every workgroup pays 2 D float atomics for dgamma / dbeta, rows per wave are a dependent chain:
-    // measured optimum (tools/ln_bench.py) 64 workgroups up to ~1k rows, 128 beyond
-    const int64_t cap = rows >= 2000 ? 128 : 64;
+    // workgroup cap: see the note at LNB_THREADS
+    const int64_t cap = rows >= 4000 ? MESM_LNB_CAP : MESM_LNB_CAP / 2;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL((ln_bwd_kernel<VEC, NCH, false>), dim3((unsigned)blocks),
-                       dim3(LN_THREADS), 0, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows,
+                       dim3(LNB_THREADS), 0, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows,
                        D, acc, dr, dx2, dr2);
   }
   return mesm_launch_status();
