@@ -21,15 +21,14 @@ namespace {
 // exchanges and a P V / dQ sweep, ~1.5-2k cycles), so the lever is rows per wave: the forward
 // splits the queries into chunks of 16 (4 rows per wave; K/V tiles are L2-resident, re-staging
 // them per chunk is cheap), the backward sweeps all queries with 8 waves per workgroup.
-constexpr int AT_THREADS = 256;
-constexpr int AT_WAVES = 4;
-constexpr int BW_THREADS = 512;
-constexpr int BW_WAVES = 8;
+#ifndef MESM_AT_WAVES
+#define MESM_AT_WAVES 4
+#endif
+constexpr int AT_WAVES = MESM_AT_WAVES;  // forward workgroup: AT_WAVES waves x 4 query rows each
+constexpr int AT_THREADS = 64 * AT_WAVES;
 constexpr int KT = 64;   // keys per tile (one per lane)
-constexpr int QCH = 16;  // query rows per forward workgroup (4 per wave: the P V sweep handles 4 rows at once)
+constexpr int QCH = 4 * AT_WAVES;  // query rows per forward workgroup (4 per wave: the P V sweep handles 4 rows at once)
 static_assert(QCH / AT_WAVES == 4, "the batched sweeps read one float4 of row slots per key");
-constexpr int QCB = 32;  // query rows staged per backward chunk (4 per wave)
-static_assert(QCB / BW_WAVES == 4, "the batched sweeps read one float4 of row slots per key");
 
 struct MaskCtx {
   bool kp;   // kpad[b, j]
@@ -179,8 +178,13 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const MesmAttnArgs
   }
 }
 
-template <int DK, int DV>
-__global__ __launch_bounds__(BW_THREADS) void attn_bwd_kernel(const MesmAttnArgs p) {
+// BW_WAVES waves per workgroup, 4 query rows per wave per staged chunk.  Measured (tools/attn_bench.py, 64 x 8
+// heads): 8 waves 42 / 79 / 57 us for (Lq 75, Lk 33) / (76, 76) / (33, 75); 4 waves 32 / 58 / 36; 2 waves
+// 50 / 53 / 29 -- 4 waves when there is one key tile, 2 when there are several (twice the workgroups).
+template <int DK, int DV, int BW_WAVES>
+__global__ __launch_bounds__(64 * BW_WAVES) void attn_bwd_kernel(const MesmAttnArgs p) {
+  constexpr int BW_THREADS = 64 * BW_WAVES;
+  constexpr int QCB = 4 * BW_WAVES;  // query rows staged per chunk
   constexpr int SK = DK + 4;
   constexpr int SV = DV + 4;
   constexpr int GQ = 64 / DK >= 1 ? 64 / DK : 1;  // key phases in the dQ step (DK <= 64)
@@ -398,15 +402,15 @@ int check_common(const MesmAttnArgs& a) {
   return MESM_OK;
 }
 
-#define ATTN_DISPATCH(KERNEL, GRID, AT_THREADS)                                            \
+#define ATTN_DISPATCH(KERNEL, GRID, AT_THREADS, ...)                                          \
   do {                                                                                     \
-    if (a.dk == 32 && a.dv == 32) hipLaunchKernelGGL((KERNEL<32, 32>), GRID, dim3(AT_THREADS), 0, s, a); \
-    else if (a.dk == 64 && a.dv == 32) hipLaunchKernelGGL((KERNEL<64, 32>), GRID, dim3(AT_THREADS), 0, s, a); \
-    else if (a.dk == 8 && a.dv == 8) hipLaunchKernelGGL((KERNEL<8, 8>), GRID, dim3(AT_THREADS), 0, s, a); \
-    else if (a.dk == 16 && a.dv == 8) hipLaunchKernelGGL((KERNEL<16, 8>), GRID, dim3(AT_THREADS), 0, s, a); \
-    else if (a.dk == 16 && a.dv == 16) hipLaunchKernelGGL((KERNEL<16, 16>), GRID, dim3(AT_THREADS), 0, s, a); \
-    else if (a.dk == 32 && a.dv == 16) hipLaunchKernelGGL((KERNEL<32, 16>), GRID, dim3(AT_THREADS), 0, s, a); \
-    else if (a.dk == 64 && a.dv == 64) hipLaunchKernelGGL((KERNEL<64, 64>), GRID, dim3(AT_THREADS), 0, s, a); \
+    if (a.dk == 32 && a.dv == 32) hipLaunchKernelGGL((KERNEL<32, 32 __VA_OPT__(,) __VA_ARGS__>), GRID, dim3(AT_THREADS), 0, s, a); \
+    else if (a.dk == 64 && a.dv == 32) hipLaunchKernelGGL((KERNEL<64, 32 __VA_OPT__(,) __VA_ARGS__>), GRID, dim3(AT_THREADS), 0, s, a); \
+    else if (a.dk == 8 && a.dv == 8) hipLaunchKernelGGL((KERNEL<8, 8 __VA_OPT__(,) __VA_ARGS__>), GRID, dim3(AT_THREADS), 0, s, a); \
+    else if (a.dk == 16 && a.dv == 8) hipLaunchKernelGGL((KERNEL<16, 8 __VA_OPT__(,) __VA_ARGS__>), GRID, dim3(AT_THREADS), 0, s, a); \
+    else if (a.dk == 16 && a.dv == 16) hipLaunchKernelGGL((KERNEL<16, 16 __VA_OPT__(,) __VA_ARGS__>), GRID, dim3(AT_THREADS), 0, s, a); \
+    else if (a.dk == 32 && a.dv == 16) hipLaunchKernelGGL((KERNEL<32, 16 __VA_OPT__(,) __VA_ARGS__>), GRID, dim3(AT_THREADS), 0, s, a); \
+    else if (a.dk == 64 && a.dv == 64) hipLaunchKernelGGL((KERNEL<64, 64 __VA_OPT__(,) __VA_ARGS__>), GRID, dim3(AT_THREADS), 0, s, a); \
     else return MESM_EINVAL;                                                               \
   } while (0)
 
@@ -434,6 +438,7 @@ extern "C" int mesm_attn_bwd(const MesmAttnArgs* args, void* stream) {
     if (((uintptr_t)ptr % 16) != 0) return MESM_EALIGN;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(a.B * a.H, (a.Lk + KT - 1) / KT);
-  ATTN_DISPATCH(attn_bwd_kernel, grid, BW_THREADS);
+  if (grid.y > 1) ATTN_DISPATCH(attn_bwd_kernel, grid, 128, 2);  // several key tiles: 2 waves per workgroup
+  else ATTN_DISPATCH(attn_bwd_kernel, grid, 256, 4);
   return mesm_launch_status();
 }
