@@ -1,7 +1,10 @@
 """In-situ cost of a kernel family: time the captured training step with that family's launches
 turned into no-ops (results are garbage; only the step time matters).  rocprofv3 inflates short
 kernels by ~2 us each, so this is the attribution that adds up to the real step time.
-Usage: python tools/ablate.py [families...]   families: gemm attn ln loss elt  (default: each in turn)"""
+Usage: python tools/ablate.py [families...]   families: gemm attn ln loss elt  (default: each in turn)
+Caveat: with the attention core ablated its outputs are uninitialised memory, and the data-dependent
+assignment loop of the criterion runs longer or shorter on garbage -- price attention from the kernel trace
+(tools/trace_summary.py) or tools/attn_bench.py instead."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
