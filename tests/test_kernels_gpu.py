@@ -568,7 +568,7 @@ def test_gemm_group_matches_individual_launches():
     for rep in range(6):
         calls = []
         for k in range(rng.choice([2, 5, 11])):
-            M = rng.choice([32, 320, 1024, 2400, 4800]); N = rng.choice([4, 256, 512, 1024]); K = rng.choice([64, 256, 320, 1024])
+            M = rng.choice([32, 33, 320, 1024, 2400, 4800]); N = rng.choice([4, 130, 256, 512, 1024]); K = rng.choice([64, 70, 256, 320, 1024])
             ta, tb = rng.random() < 0.4, rng.random() < 0.5
             A = gen((K, M) if ta else (M, K), rng.randrange(10 ** 6))
             B = gen((N, K) if tb else (K, N), rng.randrange(10 ** 6), 0.1)

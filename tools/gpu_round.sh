@@ -21,5 +21,7 @@ done
 python3 tools/pmc_traffic.py $out/pmc_FETCH_SIZE/p_counter_collection.csv $out/pmc_WRITE_SIZE/p_counter_collection.csv $out/gemm_traffic.json 7
 for c in FETCH_SIZE WRITE_SIZE; do rm -f $out/pmc_$c/p_counter_collection.csv $out/pmc_$c/p_kernel_trace.csv; done
 python3 tools/ablate.py > $out/ablation.txt 2>&1
+python3 tools/attn_bench.py > $out/attn_bench.txt 2>&1
+python3 tools/ln_bench.py > $out/ln_bench.txt 2>&1
 find $out -type f | xargs ls -la | head -40
 du -sh $out
