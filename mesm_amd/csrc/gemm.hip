@@ -61,7 +61,11 @@ __device__ __forceinline__ void dslope_store(const MesmGemmArgs& p, float part, 
   __syncthreads();
   if (lane == 0) sh4[wave] = part;
   __syncthreads();
-  if (threadIdx.x == 0) p.dslope_ws[slot] = sh4[0] + sh4[1] + sh4[2] + sh4[3];
+  if (threadIdx.x == 0) {
+    float t = 0.0f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh4[w];
+    p.dslope_ws[slot] = t;
+  }
 }
 
 __global__ __launch_bounds__(256) void dslope_reduce_kernel(const float* __restrict__ ws, int64_t n,
@@ -680,33 +684,41 @@ __device__ __forceinline__ float staged_epilogue(const MesmGemmArgs& p, float (&
 // Epilogue shared by the k-split kernels: the four waves hold partial sums of the same 32x32 tile;
 // they meet in LDS (Red: 4 x 16 x 64 floats) and wave w takes accumulator registers [4w, 4w+4)
 // (rows 4h + rr + 8w) through the staged epilogue.
-template <int LA, int LB, bool XF>
+template <int LA, int LB, bool XF, int NW = 4>
 __device__ __forceinline__ void ksplit_epilogue(const MesmGemmArgs& p, const f32x16& acc, float* Red, int m0,
                                                 int n0, float slope, uint32_t seed_off, int bz, int64_t slot,
                                                 int km, const XForm& xa, const XForm& xb) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 31, h = lane >> 5;
+  constexpr int NV = 16 / NW;  // accumulator registers per wave after the cross-wave sum
+  float vals[NV];
+  if (NW > 1) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) Red[(wave * 16 + r) * 64 + lane] = acc[r];
-  __syncthreads();
-  const int r0 = wave * 4;
-  float vals[4];
+    for (int r = 0; r < 16; ++r) Red[(wave * 16 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    const int r0 = wave * NV;
 #pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    float t = 0.0f;
+    for (int rr = 0; rr < NV; ++rr) {
+      float t = 0.0f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) t += Red[(w * 16 + r0 + rr) * 64 + lane];
-    vals[rr] = t;
+      for (int w = 0; w < NW; ++w) t += Red[(w * 16 + r0 + rr) * 64 + lane];
+      vals[rr] = t;
+    }
+  } else {
+#pragma unroll
+    for (int rr = 0; rr < NV; ++rr) vals[rr] = acc[rr];
   }
   const bool first_split = (p.split_k <= 1) || (bz == 0);
-  const int rbase = m0 + 4 * h + 8 * wave;
-  auto RO = [](int i) { return i; };
-  if (first_split && km < p.K) tail_accumulate<4, LA, LB, XF>(p, vals, rbase, n0 + li, km, xa, xb, RO);
+  // register r <-> row 4h + (r & 3) + 8 (r >> 2); this wave owns registers [wave * NV, wave * NV + NV)
+  const int r0 = wave * NV;
+  const int rbase = m0 + 4 * h + (r0 & 3) + 8 * (r0 >> 2);
+  auto RO = [](int i) { return NV <= 4 ? i : (i & 3) + 8 * (i >> 2); };
+  if (first_split && km < p.K) tail_accumulate<NV, LA, LB, XF>(p, vals, rbase, n0 + li, km, xa, xb, RO);
   float dslope_part;
   if (m0 + 32 <= p.M && n0 + 32 <= p.N)
-    dslope_part = staged_epilogue<4, true>(p, vals, rbase, n0 + li, slope, seed_off, first_split, RO);
+    dslope_part = staged_epilogue<NV, true>(p, vals, rbase, n0 + li, slope, seed_off, first_split, RO);
   else
-    dslope_part = staged_epilogue<4, false>(p, vals, rbase, n0 + li, slope, seed_off, first_split, RO);
+    dslope_part = staged_epilogue<NV, false>(p, vals, rbase, n0 + li, slope, seed_off, first_split, RO);
   if (p.e_actgrad == MESM_ACT_PRELU && p.dslope) dslope_store(p, dslope_part, Red, slot);
 }
 
@@ -1017,13 +1029,21 @@ __device__ __forceinline__ void l64_stamp(int slot) {
 #endif
 
 constexpr int WS_SLAB = 32 * 32;  // floats
+#ifndef MESM_WS_NW
+#define MESM_WS_NW 4
+#endif
+constexpr int WS_NW = MESM_WS_NW;  // waves per wstage workgroup = k-split factor inside the workgroup (1, 2, 4, 8).
+// Measured (tools/gemm_sweep.py, 2400 x 256 x 256 / 4800 x 256 x 256 / 256 x 256 x 2400 split 4):
+// 4 waves 8.6 / 13.3 / 7.6 us; 2 waves 9.3 / 15.8 / 10.6; 8 waves 9.3 / 14.4 / 8.5; 1 wave 9.6 / 14.4 / 17.1.
+static_assert(WS_NW == 1 || WS_NW == 2 || WS_NW == 4 || WS_NW == 8, "wstage waves");
+constexpr int WS_THREADS = 64 * WS_NW;
 #ifndef MESM_WS_WAVES
 #define MESM_WS_WAVES 0
 #endif
 #if MESM_WS_WAVES > 0
-#define WS_BOUNDS __launch_bounds__(NTHREADS, MESM_WS_WAVES)
+#define WS_BOUNDS __launch_bounds__(WS_THREADS, MESM_WS_WAVES)
 #else
-#define WS_BOUNDS __launch_bounds__(NTHREADS)
+#define WS_BOUNDS __launch_bounds__(WS_THREADS)
 #endif
 
 template <int LAYOUT>
@@ -1100,7 +1120,7 @@ __device__ __forceinline__ void wstage_body(const MesmGemmArgs& p, const Blk blk
       kbeg = kend = KM;
     }
   }
-  const int kw = (((kend - kbeg + 3) >> 2) + 31) & ~31;
+  const int kw = (((kend - kbeg + WS_NW - 1) / WS_NW) + 31) & ~31;
   const int k0 = kbeg + wave * kw;
   const int k1 = k0 + kw < kend ? k0 + kw : kend;
   const int nst = k1 > k0 ? (k1 - k0 + 31) >> 5 : 0;
@@ -1197,18 +1217,20 @@ __device__ __forceinline__ void wstage_body(const MesmGemmArgs& p, const Blk blk
     if (h == 0 && m0 + li < p.M && csum != 0.0f) atomicAdd(p.colsum + m0 + li, csum);
   }
   __syncthreads();  // every wave is done with its slabs: the reduction buffer aliases them
-  ksplit_epilogue<LA, LB, XF>(p, acc, L, m0, n0, slope, seed_off, blk.z, blk.slot, KM, xa, xb);
+  ksplit_epilogue<LA, LB, XF, WS_NW>(p, acc, L, m0, n0, slope, seed_off, blk.z, blk.slot, KM, xa, xb);
   L64_STAMP(29);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   L64_STAMP(30);
 }
 
-constexpr int ws_lds_floats(int stages) { return 4 * stages * 2 * WS_SLAB; }  // [wave][stage][operand]: 64 KB at 2 stages, 32 KB at 1
+constexpr int ws_lds_floats(int stages) {  // [wave][stage][operand]; at least the cross-wave reduction buffer
+  return WS_NW * stages * 2 * WS_SLAB > WS_NW * 16 * 64 ? WS_NW * stages * 2 * WS_SLAB : WS_NW * 16 * 64;
+}  // [wave][stage][operand]: 64 KB at 2 stages, 32 KB at 1
 
 // which staging depth a problem gets (host side): k-tiles per wave and workgroups of the launch
 inline int ws_stages_for(const MesmGemmArgs& a) {
   const long z = a.split_k > 1 ? a.split_k : 1;
-  const long kper_wave = ((a.K + z - 1) / z + 3) / 4;
+  const long kper_wave = ((a.K + z - 1) / z + WS_NW - 1) / WS_NW;
   const long wgs = (long)((a.M + 31) / 32) * ((a.N + 31) / 32) * z;
   return (kper_wave <= 64 || wgs <= 512) ? 1 : 2;
 }
@@ -1274,10 +1296,10 @@ int launch_wstage_l(const MesmGemmArgs& a, hipStream_t s) {
   dim3 grid(((a.M + 31) / 32) * ((a.N + 31) / 32), 1, a.split_k > 1 ? a.split_k : 1);  // 1-D: xcd_tile() maps it
   const bool xf = a.a_act != MESM_ACT_NONE || a.b_act != MESM_ACT_NONE || a.a_drop_p > 0.f || a.b_drop_p > 0.f;
   const bool one = ws_stages_for(a) == 1;
-  if (xf && one) hipLaunchKernelGGL((gemm_wstage_kernel<LA, LB, true, 1>), grid, dim3(NTHREADS), 0, s, a);
-  else if (xf) hipLaunchKernelGGL((gemm_wstage_kernel<LA, LB, true, 2>), grid, dim3(NTHREADS), 0, s, a);
-  else if (one) hipLaunchKernelGGL((gemm_wstage_kernel<LA, LB, false, 1>), grid, dim3(NTHREADS), 0, s, a);
-  else hipLaunchKernelGGL((gemm_wstage_kernel<LA, LB, false, 2>), grid, dim3(NTHREADS), 0, s, a);
+  if (xf && one) hipLaunchKernelGGL((gemm_wstage_kernel<LA, LB, true, 1>), grid, dim3(WS_THREADS), 0, s, a);
+  else if (xf) hipLaunchKernelGGL((gemm_wstage_kernel<LA, LB, true, 2>), grid, dim3(WS_THREADS), 0, s, a);
+  else if (one) hipLaunchKernelGGL((gemm_wstage_kernel<LA, LB, false, 1>), grid, dim3(WS_THREADS), 0, s, a);
+  else hipLaunchKernelGGL((gemm_wstage_kernel<LA, LB, false, 2>), grid, dim3(WS_THREADS), 0, s, a);
   const int rc = mesm_launch_status();
   return rc != MESM_OK ? rc : dslope_finish(a, grid, s);
 }
@@ -1911,8 +1933,8 @@ int launch_group(const MesmGemmArgs* list, const int* vecs, int n, hipStream_t s
     } else {
       bool one = true;  // single-stage staging only if every problem of the group wants it
       for (int k = 0; k < g.n; ++k) one = one && ws_stages_for(g.p[k]) == 1;
-      if (one) hipLaunchKernelGGL(gemm_wstage_group_kernel<1>, dim3(g.start[g.n]), dim3(NTHREADS), 0, s, g);
-      else hipLaunchKernelGGL(gemm_wstage_group_kernel<2>, dim3(g.start[g.n]), dim3(NTHREADS), 0, s, g);
+      if (one) hipLaunchKernelGGL(gemm_wstage_group_kernel<1>, dim3(g.start[g.n]), dim3(WS_THREADS), 0, s, g);
+      else hipLaunchKernelGGL(gemm_wstage_group_kernel<2>, dim3(g.start[g.n]), dim3(WS_THREADS), 0, s, g);
       rc = mesm_launch_status();
       for (int k = 0; k < g.n && rc == MESM_OK; ++k) {
         const MesmGemmArgs& a = g.p[k];
