@@ -326,12 +326,15 @@ class MHAFn(Function):
         d = xq.shape[-1]
         N, Lq = xq.shape[0], xq.shape[1]
         dev = xq.device
+        # query side: x + pos is materialised ONCE (one element-wise launch) and feeds the forward GEMM and,
+        # saved, the weight-gradient GEMM as a plain operand: with the addend fused (A2 / B2) both ran on
+        # the fragment / register-staged kernels at 32-40 TF (19 + 17 us at 4800 rows against 13 + 13)
+        xqp = (xq + pq) if pq is not None else xq
         if self_attn:
             Lk = Lq
             qkv = torch.empty(N, Lq, 3 * d, device=dev, dtype=torch.float32)
             q2 = _2d(qkv)
-            kn.gemm(_2d(xq), w_in[:2 * d], q2[:, :2 * d], trans_b=True,
-                    A2=_2d(pq) if pq is not None else None, bias=b_in[:2 * d])
+            kn.gemm(_2d(xqp), w_in[:2 * d], q2[:, :2 * d], trans_b=True, bias=b_in[:2 * d])
             kn.gemm(_2d(xq), w_in[2 * d:], q2[:, 2 * d:], trans_b=True, bias=b_in[2 * d:])
             q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
             xk = pk = None
@@ -340,8 +343,7 @@ class MHAFn(Function):
             pk = _c(pk) if pk is not None else None
             Lk = xk.shape[1]
             q = torch.empty(N, Lq, d, device=dev, dtype=torch.float32)
-            kn.gemm(_2d(xq), w_in[:d], _2d(q), trans_b=True, A2=_2d(pq) if pq is not None else None,
-                    bias=b_in[:d])
+            kn.gemm(_2d(xqp), w_in[:d], _2d(q), trans_b=True, bias=b_in[:d])
             kv = torch.empty(N, Lk, 2 * d, device=dev, dtype=torch.float32)
             kv2 = _2d(kv)
             if pk is None:
@@ -354,7 +356,7 @@ class MHAFn(Function):
         out = torch.empty(N, Lq, d, device=dev, dtype=torch.float32)
         kn.gemm(_2d(o), w_out, _2d(out), trans_b=True, bias=b_out, e_drop=out_drop,
                 residual=_2d(_c(residual)) if residual is not None else None)
-        ctx.save_for_backward(xq, pq, xk, pk, q, k, v, o, lse)
+        ctx.save_for_backward(xq, xqp if pq is not None else None, xk, pk, q, k, v, o, lse)
         ctx.params = (w_in, b_in, w_out, b_out)
         ctx.res_is_xq = residual is not None and residual.data_ptr() == xq.data_ptr() and residual.shape == xq.shape
         ctx.cfg = (H, kpad, qpad, attn_drop, out_drop, self_attn, residual is not None, group)
@@ -362,7 +364,9 @@ class MHAFn(Function):
 
     @staticmethod
     def backward(ctx, dy):
-        xq, pq, xk, pk, q, k, v, o, lse = ctx.saved_tensors
+        xq, xqp, xk, pk, q, k, v, o, lse = ctx.saved_tensors
+        if xqp is None:
+            xqp = xq
         w_in, b_in, w_out, b_out = ctx.params
         H, kpad, qpad, attn_drop, out_drop, self_attn, has_res, group = ctx.cfg
         d = xq.shape[-1]
@@ -390,8 +394,7 @@ class MHAFn(Function):
                              dqkv[..., 2 * d:], kpad=kpad, qpad=qpad, drop=attn_drop, group=group)
             g2 = _2d(dqkv)
             with kn.gemm_group():
-                _accum_dw(g2[:, :2 * d], _2d(xq), gwi[:2 * d], gbi[:2 * d],
-                          x2=_2d(pq) if pq is not None else None)
+                _accum_dw(g2[:, :2 * d], _2d(xqp), gwi[:2 * d], gbi[:2 * d])
                 _accum_dw(g2[:, 2 * d:], _2d(xq), gwi[2 * d:], gbi[2 * d:])
                 if need_q or need_pq:
                     dqk_in = torch.empty_like(xq)  # gradient of (xq + pq) through q and k
@@ -414,7 +417,7 @@ class MHAFn(Function):
             g2 = _2d(dkv)
             add_dy = False
             with kn.gemm_group():  # dWq, dWkv, dX(query side), dX(key side): all independent
-                _accum_dw(_2d(dq), _2d(xq), gwi[:d], gbi[:d], x2=_2d(pq) if pq is not None else None)
+                _accum_dw(_2d(dq), _2d(xqp), gwi[:d], gbi[:d])
                 if pk is None:
                     _accum_dw(g2, _2d(xk), gwi[d:], gbi[d:])
                 else:
