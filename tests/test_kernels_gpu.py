@@ -633,6 +633,30 @@ def test_gemm_reference_widths_on_the_lds_dma_kernels(tile, monkeypatch):
         assert rel_err(Y, Xv.double() @ W[:, 1:wide - 2].double().t()) < TOL
 
 
+@pytest.mark.parametrize("tile", ["0", "2", "3", "4"])
+def test_gemm_tiny_reduce_ranges_on_the_lds_dma_kernels(tile, monkeypatch):
+    """K of 4..9 with outer extents that are not multiples of 4: the MFMA loop may be EMPTY (gemm_kmain = 0)
+    and everything comes from the scalar tail, alone or split over k-slices, with bias column sums."""
+    from mesm_amd import kernels as kn
+    monkeypatch.setenv("MESM_GEMM_TILE", tile)
+    seed = 0
+    for K in (4, 5, 6, 7, 9):
+        for (M, N) in ((33, 130), (66, 67), (130, 34)):
+            for ta in (False, True):
+                for tb in (False, True):
+                    seed += 1
+                    A = gen((K, M) if ta else (M, K), seed)
+                    B = gen((N, K) if tb else (K, N), seed + 1000)
+                    ref = (A.t() if ta else A).double() @ (B.t() if tb else B).double()
+                    C = torch.empty(M, N, device=dev())
+                    kn.gemm(A, B, C, trans_a=ta, trans_b=tb)
+                    assert rel_err(C, ref) < TOL, (K, M, N, ta, tb)
+                    C2 = torch.zeros(M, N, device=dev()); cs = torch.zeros(M, device=dev())
+                    kn.gemm(A, B, C2, trans_a=ta, trans_b=tb, split_k=2, accumulate=2, colsum=cs)
+                    assert rel_err(C2, ref) < TOL, (K, M, N, ta, tb, "split")
+                    assert rel_err(cs, (A.t() if ta else A).double().sum(1)) < TOL, (K, M, N, ta, tb, "colsum")
+
+
 @pytest.mark.parametrize("tile", ["1", "2", "3", "4"])
 def test_gemm_fuzz_forced_kernel(tile, monkeypatch):
     """The same fuzz with every launch forced onto one of the small-problem / LDS-DMA kernels
