@@ -1341,6 +1341,7 @@ __device__ __forceinline__ void wstage64_body(const MesmGemmArgs& p, const Blk b
   const int lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, h = lane >> 5;
   const int m0 = blk.x * 64, n0 = blk.y * 64;
+  L64_STAMP(0);
 
   const int KM = gemm_kmain(p);  // reduce indices [KM, K) are added in the epilogue of the first k-slice
   int kbeg = 0, kend = KM;
@@ -1388,9 +1389,12 @@ __device__ __forceinline__ void wstage64_body(const MesmGemmArgs& p, const Blk b
   float csum[2] = {0.0f, 0.0f};
   const bool do_colsum = (p.colsum != nullptr) && (blk.y == 0);
 
+  L64_STAMP(1);
   if (nst > 0) issue(0);
+  L64_STAMP(2);
   for (int st = 0; st < nst; ++st) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    L64_STAMP(3 + 3 * st);
     float a[2][4][4], b[2][4][4];
     ws_read<LA>(mine, li, h, a[0]);
     ws_read<LA>(mine + WS_SLAB, li, h, a[1]);
@@ -1451,8 +1455,10 @@ __device__ __forceinline__ void wstage64_body(const MesmGemmArgs& p, const Blk b
 #pragma unroll
           for (int j = 0; j < 4; ++j) csum[t] += a[t][s_][j];
     }
+    L64_STAMP(5 + 3 * st);
   }
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  L64_STAMP(28);
 
   if (do_colsum) {
 #pragma unroll
@@ -1483,6 +1489,9 @@ __device__ __forceinline__ void wstage64_body(const MesmGemmArgs& p, const Blk b
   __syncthreads();  // dslope_store reuses the head of L
   tile16_epilogue<LA, LB, XF>(p, sum, m0 + 32 * (wave >> 1), n0 + 32 * (wave & 1), slope, seed_off, blk.z, L, blk.slot,
                               KM, xa, xb);
+  L64_STAMP(29);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  L64_STAMP(30);
 }
 
 template <int LA, int LB, bool XF>
