@@ -208,6 +208,9 @@ int mesm_layernorm_bwd2(const float* dy, const float* x, const float* gamma,
  */
 #define MESM_MASK_KPAD 0
 #define MESM_MASK_T2V_QUIRK 1
+/* kpad (optional) plus the causal rule of the CLIP text transformer (text_encoder.py:325-331, the additive
+ * -inf upper triangle passed as attn_mask at :184): key j of query i is masked iff j > i.  Forward only. */
+#define MESM_MASK_CAUSAL 2
 
 typedef struct MesmAttnArgs {
   const float* q;
@@ -450,6 +453,38 @@ int mesm_text_prep(const float* x, int32_t N, int32_t Lw, int32_t D, int32_t nor
 int mesm_weighted_sum(const float* vals, const float* weights, int32_t n, float* out,
                       void* stream);
 int mesm_scale_vec(const float* g, const float* weights, int32_t n, float* out, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/*
+ * Frozen text encoders (forward only, the reference runs them under no_grad).
+ * fp16 tensors travel as void* (IEEE binary16, row-major).
+ *
+ * mesm_clip_embed      x[r, :] = fp16(tok[ids[r], :]) + fp16(pos[r % L, :])           (rows = N*L, fp16 out)
+ *                      CLIPTextEncoder.forward, text_encoder.py:342-344 (fp32 tables, .type(fp16))
+ * mesm_layernorm_f16   y = fp16(LayerNorm_fp32(float(x)))                              text_encoder.py:154-160
+ * mesm_gemm_f16        C[M,N] = epi(A[M,K] @ W[N,K]^T + bias): fp16 operands, fp32 accumulation on
+ *                      v_mfma_f32_32x32x8_f16, ONE rounding to fp16 after the bias, then optionally
+ *                      QuickGELU (x * sigmoid(1.702 x), each fp16 op rounded, :163-165) and the residual add
+ *                      (x = x + ..., :187-188).  A may be fp32 (a_is_f32: rounded to fp16 while staged -- the
+ *                      attention output); C may be written as fp32 (c_is_f32: the fp16-rounded values widened,
+ *                      input of mesm_attn_fwd).  K % 32 == 0; lda, ldw % 8 == 0.  Replaces the nn.Linear sites
+ *                      of ResidualAttentionBlock (:172-177) and nn.MultiheadAttention's in/out projections.
+ * mesm_text_pool       MESM.CLIP_encode_text / GloVe_encode_text tail (model.py:118-134, 138-143): first Lw
+ *                      tokens of x (N, Lx, D) (fp16 or fp32), pads zeroed by mask (N, Lm) uint8, sentence =
+ *                      masked mean of the un-normalised words, both L2-normalised (eps 1e-5) if normalize.
+ * mesm_embed_rows      out[r, :] = table[ids[r], :]   GloveTextEncoder.forward (text_encoder.py:446-454)
+ */
+int mesm_clip_embed(const int64_t* ids, const float* tok, const float* pos, void* x, int64_t rows, int32_t L,
+                    int32_t D, int32_t vocab, void* stream);
+int mesm_layernorm_f16(const void* x, const float* gamma, const float* beta, void* y, int64_t rows, int32_t D,
+                       float eps, void* stream);
+int mesm_gemm_f16(const void* A, int32_t a_is_f32, int64_t lda, const void* W, int64_t ldw, const void* bias,
+                  const void* residual, int64_t ldr, void* C, int32_t c_is_f32, int64_t ldc, int32_t M,
+                  int32_t N, int32_t K, int32_t quick_gelu, void* stream);
+int mesm_text_pool(const void* x, int32_t x_is_f16, const uint8_t* mask, int32_t N, int32_t Lx, int32_t Lm,
+                   int32_t Lw, int32_t D, int32_t normalize, float* words, float* sent, void* stream);
+int mesm_embed_rows(const int64_t* ids, const float* table, float* out, int64_t rows, int32_t D, int32_t vocab,
+                    void* stream);
 
 /* ------------------------------------------------------------------------- */
 /*

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("MESM_LIB_PATH") or os.path.join(_HERE, "libmesm_gfx95
 
 ACT_NONE, ACT_RELU, ACT_PRELU = 0, 1, 2
 LAYOUT_REDUCE_CONTIG, LAYOUT_OUTER_CONTIG = 0, 1
-MASK_KPAD, MASK_T2V_QUIRK = 0, 1
+MASK_KPAD, MASK_T2V_QUIRK, MASK_CAUSAL = 0, 1, 2
 
 c_f32p = ctypes.c_void_p  # device pointers travel as opaque addresses
 c_ptr = ctypes.c_void_p
@@ -105,6 +105,12 @@ PROTOTYPES = {
     "mesm_rowdot_fwd": (ctypes.c_int, [c_ptr, c_ptr, _i32, _i32, _i32, _f32, c_ptr, c_ptr]),
     "mesm_rowdot_bwd": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, _i32, _i32, _i32, _f32, c_ptr, c_ptr, c_ptr]),
     "mesm_text_prep": (ctypes.c_int, [c_ptr, _i32, _i32, _i32, _i32, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "mesm_clip_embed": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, _i64, _i32, _i32, _i32, c_ptr]),
+    "mesm_layernorm_f16": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, _i64, _i32, _f32, c_ptr]),
+    "mesm_gemm_f16": (ctypes.c_int, [c_ptr, _i32, _i64, c_ptr, _i64, c_ptr, c_ptr, _i64, c_ptr, _i32, _i64,
+                                     _i32, _i32, _i32, _i32, c_ptr]),
+    "mesm_text_pool": (ctypes.c_int, [c_ptr, _i32, c_ptr, _i32, _i32, _i32, _i32, _i32, _i32, c_ptr, c_ptr, c_ptr]),
+    "mesm_embed_rows": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, _i64, _i32, _i32, c_ptr]),
     "mesm_weighted_sum": (ctypes.c_int, [c_ptr, c_ptr, _i32, c_ptr, c_ptr]),
     "mesm_scale_vec": (ctypes.c_int, [c_ptr, c_ptr, _i32, c_ptr, c_ptr]),
 }

@@ -34,7 +34,10 @@ class TargetPlan:
     uint8, the positives of loss_rec_ss (criterion.py:224-238: block-diagonal gIoU of the
     merged moments >= gamma) — target-only, so it is evaluated on the host in fp32."""
 
-    def __init__(self, targets, multi_clip, device, gamma=0.9):
+    def __init__(self, targets, multi_clip, device, gamma=0.9, T_cap=None, Tmax_cap=None):
+        """T_cap / Tmax_cap: pad the flattened targets to T_cap rows and report Tmax_cap as the matcher's
+        work-array extent (a captured HIP graph bakes both in, graphed.py); the kernels read the true
+        counts from tgt_off, so padding changes no result."""
         if multi_clip:
             sizes = [len(t["spans"]) for t in targets["norm_span"]]
             cxw = torch.cat([t["spans"] for t in targets["norm_span"]]).float().cpu()
@@ -46,16 +49,26 @@ class TargetPlan:
             xx = targets["norm_moment"].float().cpu()
             sizes = [1] * cxw.shape[0]
             mom = xx
-        self.tgt_cxw = cxw.contiguous().to(device)
-        self.tgt_xx = xx.contiguous().to(device)
         self.sizes = sizes
         self.N = len(sizes)
         self.Tmax = max(sizes)
+        self.sumT = cxw.shape[0]
+        if Tmax_cap is not None:
+            if self.Tmax > Tmax_cap:
+                raise ValueError("TargetPlan: a pair has %d target windows > Tmax_cap %d" % (self.Tmax, Tmax_cap))
+            self.Tmax = Tmax_cap
+        if T_cap is not None:
+            if self.sumT > T_cap:
+                raise ValueError("TargetPlan: %d target windows > T_cap %d" % (self.sumT, T_cap))
+            pad = T_cap - self.sumT
+            cxw = torch.cat([cxw, torch.tensor([[0.5, 1.0]]).expand(pad, 2)])
+            xx = torch.cat([xx, torch.tensor([[0.0, 1.0]]).expand(pad, 2)])
+        self.tgt_cxw = cxw.contiguous().to(device)
+        self.tgt_xx = xx.contiguous().to(device)
         off = [0]
         for s in sizes:
             off.append(off[-1] + s)
         self.tgt_off = torch.tensor(off, dtype=torch.int32, device=device)
-        self.pair_of_t = torch.repeat_interleave(torch.arange(self.N), torch.tensor(sizes)).to(device)
         groups = [int(g) for g in targets["num_clips"].tolist()]
         gid = torch.repeat_interleave(torch.arange(len(groups)), torch.tensor(groups))
         gmask = gid[:, None] == gid[None, :]

@@ -54,6 +54,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const MesmAttnArgs
   const int mg = p.mask_group > 0 ? p.mask_group : p.B;
   const int b2 = (b / mg) * mg + ((b % mg) * p.H + h) % mg;
   const bool quirk = (p.mask_mode == MESM_MASK_T2V_QUIRK) && p.qpad && p.kpad;
+  const bool causal = p.mask_mode == MESM_MASK_CAUSAL;
 
   const float* qb = p.q + (int64_t)b * p.q_bs + (int64_t)h * DK;
   const float* kb = p.k + (int64_t)b * p.k_bs + (int64_t)h * DK;
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const MesmAttnArgs
           bool qp = p.qpad[(int64_t)b2 * p.Lq + i] != 0;
           masked = masked || (qp && kp2);
         }
+        if (causal && j > i) masked = true;
         if (masked) s = -INFINITY;
         const float m_old = Ms[r];
         const float m_new = fmaxf(m_old, wave_max(s));
@@ -433,6 +435,7 @@ extern "C" int mesm_attn_bwd(const MesmAttnArgs* args, void* stream) {
   int rc = check_common(a);
   if (rc != MESM_OK) return rc;
   if (!a.lse || !a.d_o || !a.dq || !a.dk_ || !a.dv_) return MESM_EINVAL;
+  if (a.mask_mode == MESM_MASK_CAUSAL) return MESM_EINVAL;  // the causal text encoder is frozen: forward only
   const void* ptrs[4] = {a.d_o, a.dq, a.dk_, a.dv_};
   for (const void* ptr : ptrs)
     if (((uintptr_t)ptr % 16) != 0) return MESM_EALIGN;

@@ -1,38 +1,86 @@
-"""Data-parallel gradient reduction over the flat gradient buffer (new functionality: the
-reference is single-process).
+"""Data-parallel training over the flat gradient buffer (new functionality: the reference is
+single-process; insertion point train.py:68-72).
 
-One process per GPU; every rank runs the same model on its own video groups; gradients are
-averaged with a few large all-reduces (RCCL over xGMI when the backend is "nccl") of
-contiguous slices of the ONE flat fp32 buffer (gradbuf.py), launched asynchronously from
-inside backward as soon as every parameter of a slice has received all its contributions,
-so the collective overlaps the rest of backward.  `finish()` runs automatically at the end
-of backward (autograd engine callback): it waits for the collectives and scales by 1/world.
+One process per GPU.  The path shards by VIDEO GROUP (`shard_groups`: rank r takes groups r::W of the
+global batch, at least two per rank because the negatives come from another group of the local batch,
+SURVEY Q5); negatives, the in-batch rec_ss contrast and the Q1 mask leakage stay per-rank, so the
+parity target is: gradient == mean over ranks of the single-process gradient on each rank's shard.
 
-Parameters that never receive a gradient (e.g. txt_position_embed.*, output_sent_proj.*) keep
-.grad = None on every rank and their (zero) slices are reduced harmlessly.
+The one exchange step is a sum-all-reduce (then x 1/W) of contiguous slices ("buckets") of the ONE flat
+fp32 gradient buffer (gradbuf.py) -- RCCL over xGMI when the backend is "nccl".  In hook mode the
+collectives are launched asynchronously from INSIDE backward, as soon as every parameter of a bucket has
+received all its contributions, so they overlap the rest of backward on the process group's side
+stream; `finish()` runs at the end of backward (autograd engine callback): it launches what is left,
+waits, and scales.  Under HIP-graph capture (graphed.GraphedStep(reducer=...)) the same calls are
+recorded into the step's graph: fork to the collective stream at the launch point, join at finish().
 
-The number of contributions per parameter (weights shared by the positive / negative / MLM
-passes get several) is learnt during the first backward, which reduces everything at the end.
+Every rank issues the bucket collectives in the SAME order -- highest bucket first (backward produces
+gradients in reverse parameter order), bucket k only after bucket k+1 -- whatever order its own
+gradients become ready in; the per-parameter contribution counts that define "ready" are learnt on the
+first backward and agreed across ranks (element-wise MAX), so a rank that sees fewer contributions (no
+out-of-vocabulary word in its shard, say) just launches later, never differently.  If a gradient still
+arrives after its bucket was sent, the step's result would be wrong: all ranks agree on that through a
+flag reduced with the last bucket and raise together.
+
+Parameters that never receive a gradient (txt_position_embed.*, output_sent_proj.*) keep .grad = None
+on every rank and their (zero) slices are reduced harmlessly.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 
+def shard_groups(batch, rank, world, min_groups=2):
+    """The rows of `batch` (collate output, dataset/base.py:326-355 / qvhighlights.py:252-284) that
+    belong to video groups rank, rank + world, ...: tensors whose first extent is the number of pairs
+    are row-selected, per-pair lists are sub-listed, `num_clips` keeps the selected groups."""
+    groups = [int(g) for g in batch["num_clips"].tolist()]
+    G, N = len(groups), sum(groups)
+    mine = list(range(rank, G, world))
+    if len(mine) < min_groups:
+        raise ValueError("shard_groups: rank %d of %d gets %d of %d video groups; negatives are drawn from "
+                         "ANOTHER group of the local batch, so every rank needs >= %d"
+                         % (rank, world, len(mine), G, min_groups))
+    starts = [0]
+    for g in groups:
+        starts.append(starts[-1] + g)
+    rows = [i for gi in mine for i in range(starts[gi], starts[gi + 1])]
+    idx = torch.tensor(rows, dtype=torch.int64)
+    out = {}
+    for k, v in batch.items():
+        if k == "num_clips":
+            out[k] = torch.tensor([groups[gi] for gi in mine], dtype=v.dtype)
+        elif torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == N:
+            out[k] = v[idx.to(v.device)]
+        elif isinstance(v, (list, tuple)) and len(v) == N:
+            out[k] = [v[i] for i in rows]
+        else:
+            out[k] = v
+    return out
+
+
 class GradReducer:
-    def __init__(self, gradbuf, process_group=None, n_buckets=6, hook=True):
+    def __init__(self, gradbuf, process_group=None, n_buckets=6, hook=True, force=False):
+        """force: issue the collectives even in a 1-rank group (exercises the RCCL / capture path on one GPU)"""
         self.gb = gradbuf
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())
         self.n_buckets = n_buckets
         self.expected = None        # contributions per parameter, learnt on the first backward
         self.counts = {}
         self.works = []
-        self.launched = set()
+        self.next_bucket = -1       # buckets are launched from the last one down to 0, in this order only
+        self.ready = set()
         self.callback_queued = False
         self.stale = False
         self.buckets = None         # list of (lo, hi, [param ids])
         self.bucket_left = None
         self.param_bucket = {}
+        self.flag = None            # 1-element tensor reduced after the last bucket: "a late gradient somewhere"
+        self.hook = hook
+        self.launch_log = []        # bucket indices in launch order (tests)
         if hook:  # overlap mode: collectives are launched from inside backward
             gradbuf.on_ready = self._on_ready
 
@@ -52,9 +100,10 @@ class GradReducer:
         for b, (_, _, pids) in enumerate(self.buckets):
             for pid in pids:
                 self.param_bucket[pid] = b
+        self.next_bucket = len(self.buckets) - 1
 
     def _on_ready(self, p):
-        if self.world == 1:
+        if not self.active:
             return
         if not self.callback_queued:
             self.callback_queued = True
@@ -63,60 +112,84 @@ class GradReducer:
         self.counts[pid] = self.counts.get(pid, 0) + 1
         if self.expected is None:
             return
-        if self.counts[pid] > self.expected.get(pid, 0) and self.param_bucket[pid] in self.launched:
-            self.stale = True  # a gradient arrived after its slice was sent: pattern changed
+        b = self.param_bucket[pid]
+        if self.counts[pid] > self.expected.get(pid, 0) and b > self.next_bucket:
+            self.stale = True  # a gradient arrived after its slice was sent: this step's mean is wrong
         if self.counts[pid] == self.expected.get(pid, -1):
-            b = self.param_bucket[pid]
             self.bucket_left[b] -= 1
             if self.bucket_left[b] == 0:
-                self._launch(b)
+                self.ready.add(b)
+                self._launch_ready()
+
+    def _launch_ready(self):
+        while self.next_bucket >= 0 and self.next_bucket in self.ready:
+            self._launch(self.next_bucket)
 
     def _launch(self, b):
+        assert b == self.next_bucket
         lo, hi, _ = self.buckets[b]
-        self.launched.add(b)
+        self.next_bucket -= 1
+        self.launch_log.append(b)
         self.works.append(dist.all_reduce(self.gb.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg,
                                           async_op=True))
 
     def _reset_step(self):
         self.counts = {}
         self.works = []
-        self.launched = set()
+        self.ready = set()
+        self.next_bucket = len(self.buckets) - 1 if self.buckets is not None else -1
         self.callback_queued = False
+        self.stale = False
         if self.expected is not None:
             self.bucket_left = [sum(1 for pid in pids if self.expected.get(pid, 0) > 0)
                                 for _, _, pids in self.buckets]
+            # a bucket none of whose parameters ever gets a gradient is ready from the start
+            self.ready = {b for b, n in enumerate(self.bucket_left) if n == 0}
+
+    def _agree_expected(self):
+        """element-wise MAX over ranks of the learnt contribution counts (same parameter order everywhere)"""
+        gb = self.gb
+        dev = gb.flat.device
+        v = torch.tensor([self.counts.get(id(p), 0) for p in gb.params], dtype=torch.int32, device=dev)
+        dist.all_reduce(v, op=dist.ReduceOp.MAX, group=self.pg)
+        self.expected = {id(p): int(c) for p, c in zip(gb.params, v.tolist())}
 
     def finish(self):
-        """Wait for the bucket collectives (launching the ones not yet started) and average."""
-        if self.world == 1:
+        """Launch the buckets not yet started (in order), wait for all of them and average."""
+        if not self.active:
             return
         if self.buckets is None:
             self._make_buckets()
-        for b in range(len(self.buckets)):
-            if b not in self.launched:
-                self._launch(b)
+        while self.next_bucket >= 0:
+            self._launch(self.next_bucket)
+        capturing = self.gb.flat.is_cuda and torch.cuda.is_current_stream_capturing()
+        if self.hook and self.expected is not None and not capturing:
+            # late-gradient flag, agreed across ranks (MAX) so that every rank raises, or none does
+            if self.flag is None:
+                self.flag = torch.zeros(1, device=self.gb.flat.device, dtype=torch.float32)
+            self.flag.fill_(1.0 if self.stale else 0.0)
+            self.works.append(dist.all_reduce(self.flag, op=dist.ReduceOp.MAX, group=self.pg, async_op=True))
         for w in self.works:
             w.wait()
-        if self.stale:
-            raise RuntimeError("GradReducer: the per-parameter contribution pattern changed between "
-                               "steps; create a new GradReducer (or call relearn()) after changing the "
-                               "forward configuration")
         self.gb.flat.mul_(1.0 / self.world)
-        if self.expected is None:
-            self.expected = dict(self.counts)
+        if self.hook and self.expected is not None and not capturing and float(self.flag) > 0:
+            self._reset_step()
+            raise RuntimeError("GradReducer: on some rank a gradient arrived after its bucket had been "
+                               "all-reduced (the contribution pattern changed between steps); the reduced "
+                               "gradients of this step are incomplete.  Call relearn() after changing the "
+                               "forward configuration.")
+        if self.hook and self.expected is None:
+            self._agree_expected()
         self._reset_step()
-
 
     def relearn(self):
         self.expected = None
-        self.stale = False
         self._reset_step()
 
 
 def init_process_group_from_env(device=None):
     """RANK / WORLD_SIZE / MASTER_* from the environment (torchrun contract).  backend 'nccl' is
     RCCL on ROCm; 'gloo' for the CPU tests."""
-    import os
     if dist.is_initialized():
         return
     backend = "nccl" if (device is not None and device.type == "cuda") else "gloo"

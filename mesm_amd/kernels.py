@@ -9,7 +9,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_NONE, ACT_PRELU, ACT_RELU, LAYOUT_OUTER_CONTIG,
-                   LAYOUT_REDUCE_CONTIG, MASK_KPAD, MASK_T2V_QUIRK, AttnArgs, GemmArgs,
+                   LAYOUT_REDUCE_CONTIG, MASK_CAUSAL, MASK_KPAD, MASK_T2V_QUIRK, AttnArgs, GemmArgs,
                    check, lib, ptr, require_gpu, stream_ptr)
 
 __all__ = [
@@ -207,7 +207,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx=None, accumulate_d
     return dx2.view(x.shape), dxm.view(x.shape)
 
 
-def _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop, group=0):
+def _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop, group=0, causal=False):
     B, Lq, Eq = q.shape
     _, Lk, Ek = k.shape
     Ev = v.shape[2]
@@ -231,6 +231,9 @@ def _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop, group=0):
         a.mask_mode = MASK_T2V_QUIRK
     else:
         a.mask_mode = MASK_KPAD
+    if causal:
+        assert qpad is None
+        a.mask_mode = MASK_CAUSAL
     a.scale = float(scale)
     a.drop_p, a.drop_seed = float(drop[0]), int(drop[1]) & 0xFFFFFFFF
     a.seed_offset = _seed_off_ptr()
@@ -238,15 +241,16 @@ def _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop, group=0):
     return a
 
 
-def attn_fwd(q, k, v, H, kpad=None, qpad=None, scale=None, drop=(0.0, 0), group=0):
-    """q (B,Lq,H*dk), k (B,Lk,H*dk), v (B,Lk,H*dv) -> o (B,Lq,H*dv), lse (B,H,Lq)."""
+def attn_fwd(q, k, v, H, kpad=None, qpad=None, scale=None, drop=(0.0, 0), group=0, causal=False, want_lse=True):
+    """q (B,Lq,H*dk), k (B,Lk,H*dk), v (B,Lk,H*dv) -> o (B,Lq,H*dv), lse (B,H,Lq).
+    causal: key j of query i is masked iff j > i (frozen CLIP text transformer; forward only)."""
     require_gpu(q, k, v)
     B, Lq, Eq = q.shape
     if scale is None:
         scale = (Eq // H) ** -0.5
     o = torch.empty(B, Lq, v.shape[2], device=q.device, dtype=torch.float32)
-    lse = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32)
-    a = _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop, group)
+    lse = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32) if want_lse else None
+    a = _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop, group, causal)
     check(lib().mesm_attn_fwd(ctypes.byref(a), stream_ptr()), "mesm_attn_fwd")
     return o, lse
 
@@ -532,6 +536,72 @@ def scale_vec(g, weights):
     out = torch.empty_like(weights)
     check(lib().mesm_scale_vec(ptr(g), ptr(weights), weights.numel(), ptr(out), stream_ptr()),
           "mesm_scale_vec")
+    return out
+
+
+# ----------------------------------------------------------------------------- frozen text encoders
+def clip_embed(ids, tok, pos):
+    """ids (N, L) int64, tok (V, D) f32, pos (L, D) f32 -> (N, L, D) fp16."""
+    require_gpu(ids, tok, pos)
+    N, L = ids.shape
+    D = tok.shape[1]
+    assert ids.dtype == torch.int64 and tok.dtype == pos.dtype == torch.float32 and pos.shape == (L, D)
+    x = torch.empty(N, L, D, device=ids.device, dtype=torch.float16)
+    check(lib().mesm_clip_embed(ptr(ids.contiguous()), ptr(tok.contiguous()), ptr(pos.contiguous()), ptr(x), N * L, L,
+                                D, tok.shape[0], stream_ptr()), "mesm_clip_embed")
+    return x
+
+
+def layernorm_f16(x, gamma, beta, eps=1e-5):
+    require_gpu(x, gamma, beta)
+    assert x.dtype == torch.float16 and x.is_contiguous() and gamma.dtype == beta.dtype == torch.float32
+    D = x.shape[-1]
+    y = torch.empty_like(x)
+    check(lib().mesm_layernorm_f16(ptr(x), ptr(gamma), ptr(beta), ptr(y), x.numel() // D, D, float(eps), stream_ptr()),
+          "mesm_layernorm_f16")
+    return y
+
+
+def gemm_f16(A, W, bias=None, residual=None, out_f32=False, quick_gelu=False):
+    """A (M, K) fp16 or fp32 (rounded to fp16 on load), W (N, K) fp16 -> (M, N) fp16, or the fp16-rounded
+    values as fp32 (out_f32)."""
+    require_gpu(A, W)
+    assert A.dim() == 2 and W.dim() == 2 and A.shape[1] == W.shape[1] and W.dtype == torch.float16
+    assert A.stride(1) == 1 and W.stride(1) == 1 and A.dtype in (torch.float16, torch.float32)
+    M, K = A.shape
+    N = W.shape[0]
+    C = torch.empty(M, N, device=A.device, dtype=torch.float32 if out_f32 else torch.float16)
+    if bias is not None:
+        assert bias.dtype == torch.float16 and bias.numel() == N and bias.is_contiguous()
+    if residual is not None:
+        assert residual.dtype == torch.float16 and residual.shape == (M, N) and residual.stride(1) == 1
+    check(lib().mesm_gemm_f16(ptr(A), 1 if A.dtype == torch.float32 else 0, A.stride(0), ptr(W), W.stride(0), ptr(bias),
+                              ptr(residual), residual.stride(0) if residual is not None else 0, ptr(C),
+                              1 if out_f32 else 0, C.stride(0), M, N, K, 1 if quick_gelu else 0, stream_ptr()),
+          "mesm_gemm_f16")
+    return C
+
+
+def text_pool(x, mask, Lw, normalize=True):
+    """x (N, Lx, D) fp16 / fp32, mask (N, Lm) bool -> words (N, Lw, D) f32, sentence (N, D) f32."""
+    require_gpu(x, mask)
+    assert x.is_contiguous() and x.dtype in (torch.float16, torch.float32)
+    N, Lx, D = x.shape
+    m = mask.contiguous()
+    assert m.dtype in (torch.bool, torch.uint8) and m.shape[0] == N
+    words = torch.empty(N, Lw, D, device=x.device, dtype=torch.float32)
+    sent = torch.empty(N, D, device=x.device, dtype=torch.float32)
+    check(lib().mesm_text_pool(ptr(x), 1 if x.dtype == torch.float16 else 0, ptr(m), N, Lx, m.shape[1], Lw, D,
+                               1 if normalize else 0, ptr(words), ptr(sent), stream_ptr()), "mesm_text_pool")
+    return words, sent
+
+
+def embed_rows(ids, table):
+    require_gpu(ids, table)
+    assert ids.dtype == torch.int64 and table.dtype == torch.float32 and table.is_contiguous()
+    out = torch.empty(*ids.shape, table.shape[1], device=ids.device, dtype=torch.float32)
+    check(lib().mesm_embed_rows(ptr(ids.contiguous()), ptr(table), ptr(out), ids.numel(), table.shape[1],
+                                table.shape[0], stream_ptr()), "mesm_embed_rows")
     return out
 
 

@@ -24,6 +24,7 @@ from .gradbuf import GradBuffer
 from .layers import (LinearLayer, MLPHead, ParamLayerNorm, ParamLinear, T2VLayer, T2VStack,
                      inverse_sigmoid)
 from .ops import drop_state
+from .text_encoder import CLIPTextEncoder, GloveTextEncoder
 
 
 _SCOPES = os.environ.get("MESM_SCOPES") == "1"
@@ -68,15 +69,16 @@ class MESM(nn.Module):
                  use_txt_pos=False, span_loss_type="l1", n_input_proj=2, rec_fw=False,
                  vocab_size=1111, rec_ss=False, num_recss_layers=2, share_MLP=True):
         super().__init__()
-        if text_encoder is not None:
-            raise NotImplementedError(
-                "text encoders are outside this build's hot path: pass pre-extracted word features "
-                "as a 3-D words_id (tokenizer_type='GloVeNLTK', load_vocab_pkl=True — model.py:160-161)")
+        if text_encoder is not None and not isinstance(text_encoder, (CLIPTextEncoder, GloveTextEncoder)):
+            raise NotImplementedError("text_encoder must be a mesm_amd CLIPTextEncoder / GloveTextEncoder or None")
         if use_txt_pos:
             raise NotImplementedError("use_txt_pos=True is not used by any shipped config")
         if span_loss_type != "l1":
             raise NotImplementedError("span_loss_type 'ce' raises in the reference as well")
-        self.text_encoder = None
+        self.text_encoder = text_encoder  # frozen (model.py:30-33)
+        if text_encoder is not None:
+            for p in text_encoder.parameters():
+                p.requires_grad_(False)
         self.enhance_encoder = enhance_encoder
         self.t2v_encoder = t2v_encoder
         self.transformer = transformer
@@ -108,7 +110,8 @@ class MESM(nn.Module):
         self.global_rep_token = nn.Parameter(torch.randn(d))
         self.global_rep_pos = nn.Parameter(torch.randn(d))
         self.rec_fw = rec_fw
-        num_classes = vocab_size + 1  # text_encoder is None (model.py:76-77)
+        # model.py:73-79: CLIP's BPE vocabulary carries three special ids, the GloVe / feature path one
+        num_classes = vocab_size + 3 if isinstance(text_encoder, CLIPTextEncoder) else vocab_size + 1
         if rec_fw:
             self.masked_token = nn.Parameter(torch.zeros(txt_dim))
             self.unknown_token = nn.Parameter(torch.zeros(txt_dim))
@@ -119,13 +122,8 @@ class MESM(nn.Module):
             self.ss_reconstructor = SegSenRecon(input_dropout, d, transformer.nhead, num_recss_layers,
                                                 transformer.dim_feedforward, transformer.dropout)
         self._gradbuf = None
+        self._flat_params = None
         self._step = 0
-        # run the FW-MESM masked-word branch on a second HIP stream (mesm_amd/sidecall.py).  Off by
-        # default: correct (tests run both ways) but the captured graph executes it serially on
-        # ROCm 7.2 (tools/side_probe.py), although plain two-branch graphs do overlap
-        # (tools/probe_graph_par.py) -- kept as the place to continue from
-        self.side_streams = os.environ.get("MESM_SIDE_STREAMS", "0") == "1"
-        self._branches = {}
 
     # ------------------------------------------------------------------ infrastructure
     def gradbuf(self):
@@ -133,19 +131,27 @@ class MESM(nn.Module):
             self._gradbuf = GradBuffer([(n, p) for n, p in self.named_parameters() if p.requires_grad])
         return self._gradbuf
 
-    def _branch(self, name, device):
-        from .sidecall import Branch
-        key = (name, device)
-        br = self._branches.get(key)
-        if br is None:
-            gb = self.gradbuf()
+    def flat_params(self):
+        """Move every trainable parameter into ONE flat fp32 buffer with the layout of the flat gradient
+        buffer (gradbuf.py); every `param.data` becomes a view, so modules, state_dict() and checkpoints
+        are unaffected.  The fused optimizer (optim.FlatAdamW) updates this buffer in one launch.  Done
+        eagerly by build_model, i.e. BEFORE any HIP-graph capture: a captured step bakes the parameter
+        addresses in, and GraphedStep refuses to replay once they have moved."""
+        gb = self.gradbuf()
+        dev = gb.params[0].device
+        fp = self._flat_params
+        if fp is not None and fp.device == dev and all(
+                p.data_ptr() == fp.data_ptr() + 4 * off for p, off in zip(gb.params, gb.offsets)):
+            return fp
+        fp = torch.zeros(gb.numel, device=dev, dtype=torch.float32)
+        with torch.no_grad():
+            for p, off in zip(gb.params, gb.offsets):
+                view = fp[off:off + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+        self._flat_params = fp
+        return fp
 
-            def on_fork():  # the flat gradient buffer must be zeroed on the MAIN stream before the fork
-                if gb.pending:
-                    gb._open()
-            br = self._branches[key] = Branch(device, on_fork)
-        br.in_grads.clear()
-        return br
 
     def _begin(self, device, is_training):
         if not device.type == "cuda":
@@ -163,6 +169,21 @@ class MESM(nn.Module):
         for m in seq:
             x = m(x)
         return x
+
+    # ------------------------------------------------------------------ text encoding (model.py:103-152)
+    def CLIP_encode_text(self, words_id, words_mask):
+        """model.py:103-134: fp16 CLIP transformer -> fp32, first max_words_l tokens, pads zeroed, sentence =
+        masked mean of the un-normalised words, both L2-normalised (eps 1e-5).  (The reference's detour through
+        "cuda" for CPU inputs, quirk Q10, has no counterpart: this model only runs on the GPU.)"""
+        hid = self.text_encoder(words_id)["last_hidden_state"]
+        Lw = min(self.max_words_l, hid.shape[1])
+        words, sent = kn.text_pool(hid, words_mask, Lw, self.normalize_txt)
+        return words, sent, words_id[:, :Lw], words_mask[:, :Lw]
+
+    def GloVe_encode_text(self, words_id, words_mask):
+        """model.py:136-143."""
+        emb = self.text_encoder(words_id)
+        return kn.text_pool(emb, words_mask, emb.shape[1], self.normalize_txt)
 
     # ------------------------------------------------------------------ host RNG draws
     @staticmethod
@@ -199,9 +220,14 @@ class MESM(nn.Module):
     # ------------------------------------------------------------------ host-side plan
     @torch.no_grad()
     def make_plan(self, video_mask, words_mask, num_clips, dataset_name, is_training, words_weight=None,
-                  clip_mask=None, neg_index=None, masked_words=None, device=None):
+                  clip_mask=None, neg_index=None, masked_words=None, device=None, Lc_cap=None, Lss_cap=None):
         """All data-dependent host decisions of model.py:184-207, :260, :307-325 in one place.
-        Inputs may live on any device; one D2H copy of the (small) masks is made."""
+        Inputs may live on any device; one D2H copy of the (small) masks is made.
+
+        Lc_cap / Lss_cap: pad the GT-clip gather (MLM branch) / the group-video gather (SS branch) to a
+        fixed key length; the padding slots are masked keys, so the results do not change, and a HIP
+        graph captured with such a plan replays for every batch that fits (graphed.py).  A batch that
+        does not fit raises ValueError."""
         device = device or video_mask.device
         vm = video_mask.cpu()
         wm = words_mask.cpu()
@@ -237,6 +263,10 @@ class MESM(nn.Module):
                     seg += [idx] * g
                     start += g
                 Lss = max(len(s) for s in seg)
+                if Lss_cap is not None:
+                    if Lss > Lss_cap:
+                        raise ValueError("make_plan: the longest group video has %d clips > Lss_cap %d" % (Lss, Lss_cap))
+                    Lss = Lss_cap
                 pl.vid_src = torch.zeros(N, Lss, dtype=torch.int64)
                 pl.vid_mask = torch.zeros(N, Lss, dtype=torch.bool)
                 for i, s in enumerate(seg):
@@ -261,6 +291,10 @@ class MESM(nn.Module):
             cm = clip_mask.cpu()
             lens = cm.sum(1)
             Lc = int(lens.max())
+            if Lc_cap is not None:
+                if Lc > Lc_cap:
+                    raise ValueError("make_plan: a pair has %d ground-truth clips > Lc_cap %d" % (Lc, Lc_cap))
+                Lc = Lc_cap
             flat = cm.reshape(-1).nonzero().squeeze(1)
             offs = torch.cat([torch.zeros(1, dtype=torch.int64), lens.cumsum(0)])
             src = torch.zeros(N, Lc, dtype=torch.int64)
@@ -279,8 +313,6 @@ class MESM(nn.Module):
 
     # ------------------------------------------------------------------ forward
     def forward(self, video_feat, video_mask, words_id, words_mask, words_weight, num_clips, **kwargs):
-        if words_id.dim() != 3:
-            raise NotImplementedError("token ids need a text encoder; pass (N, Lw, Dt) word features")
         dev = video_feat.device
         is_training = kwargs["is_training"]
         self._begin(dev, is_training)
@@ -288,8 +320,15 @@ class MESM(nn.Module):
         N, Lv = video_mask.shape
 
         with _scope("text"):
-            # post_process_text (model.py:145-152), one kernel; word features carry no gradient
-            words, words_mask, sent = kn.text_prep(words_id, self.normalize_txt)
+            if isinstance(self.text_encoder, CLIPTextEncoder):
+                words, sent, words_id, words_mask = self.CLIP_encode_text(words_id, words_mask)
+            elif isinstance(self.text_encoder, GloveTextEncoder):
+                words, sent = self.GloVe_encode_text(words_id, words_mask)
+            else:
+                if words_id.dim() != 3:
+                    raise NotImplementedError("token ids need a text encoder; pass (N, Lw, Dt) word features")
+                # post_process_text (model.py:145-152), one kernel; word features carry no gradient
+                words, words_mask, sent = kn.text_prep(words_id, self.normalize_txt)
 
         plan = kwargs.get("plan")
         if plan is None:
@@ -304,17 +343,6 @@ class MESM(nn.Module):
             pv = self._proj(self.input_vid_proj, video_feat)
             pw = self._proj(self.input_txt_proj, words)
             vpos = kn.sine_pos(video_mask, d)
-
-        mlm_side = self.side_streams and self.rec_fw and is_training and torch.is_grad_enabled()
-        if mlm_side:
-            # FW-MESM masked-word branch: depends on pv / pw only and feeds only the criterion, so it
-            # runs on a second stream next to the whole main path, forward and backward (sidecall.py);
-            # the JoinGrad blocks are created HERE so that their backward (the join) runs last
-            from .sidecall import JoinGrad
-            mlm_br = self._branch("mlm", dev)
-            mlm_br.mark_fork()
-            pv_mlm = JoinGrad.apply(pv, mlm_br, 0)
-            pw_mlm = JoinGrad.apply(pw, mlm_br, 1)
 
         # The positive and the negative pass (model.py:260-299) run the SAME weights over the same
         # video with different queries: they are stacked along the batch (rows [0, N) positive,
@@ -405,14 +433,7 @@ class MESM(nn.Module):
                     head = self.output_txt_proj[1]
                     return ops.linear(hid, head.weight, head.bias)
 
-            if mlm_side:
-                from .sidecall import side_call
-                for t_ in (vpos, words_pad, kwargs["unknown_mask"]):
-                    t_.record_stream(mlm_br.stream)
-                (out["recfw_words_logit"],) = side_call(mlm_br, mlm_branch, [(0, pv_mlm), (1, pw_mlm)])
-                torch.cuda.current_stream().wait_event(mlm_br.done_fwd)  # join: the criterion is next
-            else:
-                out["recfw_words_logit"] = mlm_branch(pv, pw)
+            out["recfw_words_logit"] = mlm_branch(pv, pw)
             out["words_mask"] = words_mask
         if self.rec_ss:
             out.update({"projed_video_feat": pv, "recon_feat": recon, "projed_recon_feat": projed_recon,

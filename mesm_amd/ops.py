@@ -170,8 +170,15 @@ class LinearFn(Function):
                 None, None, None, None, None)
 
 
+# Test switch (tests/test_model_gpu.py, kink control run): drop every ReLU of the Linear blocks so that the
+# full-width gradient comparison with the oracle has no activation kinks to flip.  Never set in production.
+TEST_NO_RELU = False
+
+
 def linear(x, w, b, *, x2=None, residual=None, rows=None, relu=False, in_drop=NO_DROP,
            out_drop=NO_DROP):
+    if TEST_NO_RELU:
+        relu = False
     sink = _sink_for(out_drop)
     return _tag(LinearFn.apply(x, x2, residual, w, b, rows, relu, in_drop, out_drop, sink), sink)
 

@@ -63,19 +63,21 @@ class FlatAdamW(torch.optim.Optimizer):
         self._active = None
         self._active_key = None
         self.last_norm = None
+        if params[0].is_cuda:
+            # the flat state is created NOW, not at the first step(): a HIP graph captured after this
+            # constructor sees the final parameter addresses (model.flat_params is idempotent and
+            # build_model has normally done it already)
+            self._ensure()
 
     # ------------------------------------------------------------------ flat state
     def _ensure(self):
         gb = self.gb
         dev = next(iter(gb.params)).device
         gb.ensure(dev)
-        if self.flat_p is not None and self.flat_p.device == dev:
+        flat = self.model.flat_params()  # every param.data is a view of it (no-op when already flat)
+        if self.flat_p is flat:
             return
-        self.flat_p = torch.zeros(gb.numel, device=dev, dtype=torch.float32)
-        for p, off in zip(gb.params, gb.offsets):
-            view = self.flat_p[off:off + p.numel()].view(p.shape)
-            view.copy_(p.data)
-            p.data = view  # modules / state_dict keep working on the same Parameter objects
+        self.flat_p = flat
         self.exp_avg = torch.zeros_like(self.flat_p)
         self.exp_avg_sq = torch.zeros_like(self.flat_p)
         self.step_t = torch.zeros(1, device=dev, dtype=torch.int32)

@@ -51,12 +51,13 @@ def build_position_encoding(args):
 def build_model(args, vocab=None):
     """runner.py:255-298."""
     logger.info("Building model...")
-    if args.tokenizer_type == "GloVeNLTK" and args.load_vocab_pkl:
-        text_encoder = None
-    elif args.tokenizer_type in ("GloVeSimple", "CLIP", "GloVeNLTK"):
-        raise NotImplementedError(
-            "text encoders (frozen GloVe / CLIP) are not part of this build; use pre-extracted word "
-            "features (tokenizer_type='GloVeNLTK', load_vocab_pkl=True)")
+    from .text_encoder import build_CLIP_text_encoder, build_GloVe_text_encoder
+    if args.tokenizer_type == "GloVeSimple":
+        text_encoder = build_GloVe_text_encoder(args.text_model_path, vocab)
+    elif args.tokenizer_type == "CLIP":
+        text_encoder = build_CLIP_text_encoder(args.text_model_path)
+    elif args.tokenizer_type == "GloVeNLTK":
+        text_encoder = None if args.load_vocab_pkl else build_GloVe_text_encoder(args.text_model_path, vocab)
     else:
         raise NotImplementedError
     vid_pos, txt_pos = build_position_encoding(args)
@@ -70,6 +71,8 @@ def build_model(args, vocab=None):
                  vocab_size=args.vocab_size, rec_ss=args.rec_ss, num_recss_layers=args.num_recss_layers,
                  share_MLP=args.share_MLP)
     model.to(args.device)
+    if torch.device(args.device).type == "cuda":
+        model.flat_params()  # final parameter addresses before any optimizer / HIP-graph capture
     return model
 
 

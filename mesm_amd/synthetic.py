@@ -188,3 +188,23 @@ def to_device(batch, device):
         else:
             out[k] = v
     return out
+
+
+def with_clip_tokens(batch, vocab, ctx=77, seed=0):
+    """The same batch in the form the CLIP tokenizer path collates (dataset/base.py:326-355 with
+    tokenizer_type 'CLIP'): words_id (N, ctx) int64 token ids, words_mask (N, ctx) bool.  Sentence i has
+    len_i + (3 if i odd) tokens, so some run past max_words_l and are cut by CLIP_encode_text
+    (model.py:114-116); the per-word tensors (weight, unknown mask, labels) keep their (N, Lw) shape."""
+    g = torch.Generator().manual_seed(4000 + seed)
+    wm = batch["words_id"].abs().sum(-1) != 0
+    N, Lw = wm.shape
+    tl = wm.sum(1) + torch.tensor([3 if i % 2 else 0 for i in range(N)])
+    mask = torch.arange(ctx)[None, :] < tl[:, None]
+    ids = torch.randint(1, vocab - 1, (N, ctx), generator=g) * mask
+    ids[torch.arange(N), tl - 1] = vocab - 1  # EOT = the highest id
+    cut = mask[:, :Lw]
+    out = dict(batch)
+    out["words_id"], out["words_mask"] = ids, mask
+    out["words_weight"] = (1 + (torch.arange(N)[:, None] + torch.arange(Lw)[None, :]) % 2).long() * cut
+    out["unknown_mask"] = batch["unknown_mask"] & cut
+    return out

@@ -54,13 +54,21 @@ def _l2norm(x, eps):
     return x / x.norm(dim=-1, keepdim=True).clamp_min(eps)
 
 
+# Test switch mirrored by mesm_amd.ops.TEST_NO_RELU: the kink control run of tests/test_model_gpu.py.
+NO_RELU = False
+
+
+def _relu(x):
+    return x if NO_RELU else torch.relu(x)
+
+
 def linear_layer_stack(x, sd, prefix, n, relu_flags):
     """nn.Sequential of LinearLayer (model.py:412-434): LN -> [dropout] -> Linear -> [ReLU]."""
     for i in range(n):
         x = _ln(x, sd, "%s.%d.LayerNorm" % (prefix, i))
         x = _lin(x, sd, "%s.%d.net.1" % (prefix, i))
         if relu_flags[i]:
-            x = torch.relu(x)
+            x = _relu(x)
     return x
 
 
@@ -69,7 +77,7 @@ def mlp(x, sd, prefix, n):
     for i in range(n):
         x = _lin(x, sd, "%s.layers.%d" % (prefix, i))
         if i < n - 1:
-            x = torch.relu(x)
+            x = _relu(x)
     return x
 
 
@@ -292,7 +300,9 @@ def _mix_token(x, where, token):
 
 
 def mesm_forward(sd, cfg, batch, neg_index, masked_words=None, is_training=True):
-    """MESM.forward (model.py:154-359) for text_encoder=None (words_id holds (N,Lw,Dt) features).
+    """MESM.forward (model.py:154-359).  Text: words_id holds (N,Lw,Dt) features (text_encoder=None,
+    post_process_text) unless sd carries a frozen encoder: `text_encoder.*` CLIP tensors -> CLIP_encode_text,
+    `text_encoder.emb.weight` -> GloVe_encode_text (oracle/clip_text_oracle.py).
 
     batch: video_feat (N,Lv,Dv), video_mask (N,Lv) bool, words_id (N,Lw,Dt), num_clips (G,),
            unknown_mask (N,Lw), clip_mask (N,Lv) for the MLM branch.
@@ -308,14 +318,27 @@ def mesm_forward(sd, cfg, batch, neg_index, masked_words=None, is_training=True)
     num_clips = batch["num_clips"]
     n = video_feat.shape[0]
 
-    # post_process_text, model.py:145-152
-    words = batch["words_id"]
-    if cfg.get("normalize_txt", True):
-        words = _l2norm(words, 1e-5)
-    words_mask = words.sum(-1) != 0
-    sent = words.sum(1) / words_mask.sum(1)[:, None]
-    if cfg.get("normalize_txt", True):
-        sent = _l2norm(sent, 1e-5)
+    if "text_encoder.ln_final.weight" in sd:  # CLIP_encode_text, model.py:103-134
+        from .clip_text_oracle import clip_encode_text
+        te = {k[len("text_encoder."):]: v.detach() for k, v in sd.items() if k.startswith("text_encoder.")}
+        with torch.no_grad():
+            words, sent, _, words_mask = clip_encode_text(te, batch["words_id"], batch["words_mask"],
+                                                          cfg["max_words_l"], cfg.get("normalize_txt", True))
+    elif "text_encoder.emb.weight" in sd:  # GloVe_encode_text, model.py:136-143
+        from .clip_text_oracle import glove_encode_text
+        words_mask = batch["words_mask"]
+        with torch.no_grad():
+            words, sent = glove_encode_text(sd["text_encoder.emb.weight"].detach(), batch["words_id"], words_mask,
+                                            cfg.get("normalize_txt", True))
+    else:
+        # post_process_text, model.py:145-152
+        words = batch["words_id"]
+        if cfg.get("normalize_txt", True):
+            words = _l2norm(words, 1e-5)
+        words_mask = words.sum(-1) != 0
+        sent = words.sum(1) / words_mask.sum(1)[:, None]
+        if cfg.get("normalize_txt", True):
+            sent = _l2norm(sent, 1e-5)
 
     pv = linear_layer_stack(video_feat, sd, "input_vid_proj", nproj, relu_flags)
     pw = linear_layer_stack(words, sd, "input_txt_proj", nproj, relu_flags)

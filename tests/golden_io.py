@@ -7,6 +7,7 @@ import torch
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = ["charades_tiny", "qvh_tiny", "tacos_tiny"]
+CLIP_CASES = ["qvh_clip_tiny"]  # reference built with tokenizer_type="CLIP" (fp16 text tower, token ids in)
 
 
 class Fixture:
@@ -33,7 +34,7 @@ class Fixture:
                 sizes = z["batch.%s.sizes" % key].tolist()
                 cat = torch.from_numpy(z["batch.%s.cat" % key].copy())
                 batch[key] = [{field: c} for c in torch.split(cat, sizes)]
-        batch["words_mask"] = None
+        batch.setdefault("words_mask", None)
         self.batch = batch
 
     def matched_pairs(self, layer="main"):
@@ -45,3 +46,29 @@ class Fixture:
                 res.add((b, int(q[k]), int(t[k]) if self.cfg["dataset_name"] == "qvhighlights" else 0))
                 k += 1
         return res
+
+
+class EvalFixture:
+    """<case>_eval.npz (tools/gen_golden_r2.py): the reference's inference call (eval.py:63,102) on the
+    weights / batch of <case>.npz."""
+
+    def __init__(self, name):
+        z = np.load(os.path.join(GOLDEN, name + "_eval.npz"))
+        self.out = {k[4:]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith("out.")}
+        self.losses = {k[5:]: float(z[k]) for k in z.files if k.startswith("loss.")}
+        self.neg_index = torch.from_numpy(z["neg_index"].copy())
+        self.keys = json.loads(bytes(z["keys.json"]).decode())
+
+
+def draw_cases():
+    """draws.npz: [(groups, words_mask, words_weight, seed, {tag: (neg_index, masked_words)})]."""
+    z = np.load(os.path.join(GOLDEN, "draws.npz"))
+    res = []
+    for ci in range(int(z["n_cases"])):
+        got = {}
+        for tag in ("w", "u"):
+            got[tag] = (torch.from_numpy(z["c%d.%s.neg_index" % (ci, tag)].copy()),
+                        torch.from_numpy(z["c%d.%s.masked_words" % (ci, tag)].copy()))
+        res.append((z["c%d.groups" % ci].tolist(), torch.from_numpy(z["c%d.words_mask" % ci].copy()),
+                    torch.from_numpy(z["c%d.words_weight" % ci].copy()), int(z["c%d.seed" % ci]), got))
+    return res

@@ -1,0 +1,67 @@
+"""Batch assembly (mesm_amd/batching.py) against fixtures produced by the REAL reference
+functions (tools/gen_golden_io.py -> tests/golden/collate.npz): dataset/base.py `collate`,
+dataset/qvhighlights.py `collate`, `prepare_batch_input`, `pad_sequences_1d`.  Exact equality, dtypes included."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_io import GOLDEN
+from io_cases import group_samples
+
+Z = np.load(os.path.join(GOLDEN, "collate.npz"))
+META = json.loads(bytes(Z["meta.json"]).decode())
+
+
+def check(prefix, got):
+    keys = {k[len(prefix):].split(".")[0] for k in list(Z.files) + list(META) if k.startswith(prefix)}
+    assert set(got) == keys, (sorted(got), sorted(keys))
+    for k, v in got.items():
+        if torch.is_tensor(v):
+            want = torch.from_numpy(Z[prefix + k])
+            assert v.dtype == want.dtype and v.shape == want.shape and torch.equal(v, want), k
+        elif isinstance(v, list) and v and isinstance(v[0], dict):
+            f = META[prefix + k]
+            assert [len(x[f]) for x in v] == Z[prefix + k + ".sizes"].tolist(), k
+            assert torch.equal(torch.cat([x[f] for x in v]), torch.from_numpy(Z[prefix + k + ".cat"])), k
+        else:
+            assert v == META[prefix + k], k
+
+
+@pytest.mark.parametrize("kind", ["base", "qvh"])
+def test_collate_and_prepare_match_the_reference(kind):
+    from mesm_amd import batching as B
+    fn = B.collate if kind == "base" else B.collate_qvh
+    out = fn(group_samples(kind, META[kind + ".seed"]))
+    check(kind + ".out.", out)
+    prep = B.prepare_batch_input(dict(out), torch.device("cpu"))
+    check(kind + ".prep.", prep)
+
+
+def test_pad_sequences_1d():
+    from mesm_amd.batching import pad_sequences_1d
+    p, m = pad_sequences_1d([[1, 2, 3], [1, 2], [3, 4, 7, 9]], dtype=torch.long)
+    assert p.tolist() == [[1, 2, 3, 0], [1, 2, 0, 0], [3, 4, 7, 9]] and m.dtype == torch.bool
+    assert m.tolist() == [[True] * 3 + [False], [True] * 2 + [False] * 2, [True] * 4]
+    seqs = [torch.randn(2, 3, 4), torch.randn(4, 3, 4), torch.randn(0, 3, 4), torch.randn(1, 3, 4)]
+    p, m = pad_sequences_1d(seqs, dtype=torch.float32, fixed_length=5)
+    assert p.shape == (4, 5, 3, 4) and m.sum(1).tolist() == [2, 4, 0, 1]
+    for i, s in enumerate(seqs):
+        assert torch.equal(p[i, :len(s)], s) and float(p[i, len(s):].abs().sum()) == 0.0
+
+
+@pytest.mark.gpu
+def test_prepare_batch_input_packs_one_transfer():
+    from mesm_amd import batching as B
+    out = B.collate_qvh(group_samples("qvh", META["qvh.seed"]))
+    host = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in out.items()}
+    prep = B.prepare_batch_input(out, torch.device("cuda:0"))
+    assert not prep["words_weight"].is_cuda  # stays on the host (base.py:360-361)
+    for k, v in host.items():
+        if torch.is_tensor(v) and k != "words_weight":
+            assert prep[k].is_cuda and prep[k].dtype == v.dtype and torch.equal(prep[k].cpu(), v), k
+    assert all(e["spans"].is_cuda for e in prep["norm_span"])
+    assert torch.equal(torch.cat([e["moments"] for e in prep["norm_moment"]]).cpu(),
+                       torch.cat([e["moments"] for e in host["norm_moment"]]))

@@ -1,7 +1,11 @@
-"""Data-parallel reduction on CPU with gloo, world_size 2: the flat gradient buffer +
-GradReducer must leave every rank with the MEAN over ranks of the per-rank gradients, both
-on the learning step (everything reduced at the end) and on later steps (bucket collectives
-launched from inside backward)."""
+"""Data-parallel reduction on CPU with gloo, world_size 2.
+
+  * parity target of the sharded path: every rank ends with the MEAN over ranks of the single-process
+    (oracle) gradient on each rank's shard of video groups -- driven through shard_groups, the flat
+    gradient buffer and the hooked GradReducer with the real model's parameter set (qvh_tiny weights);
+  * a toy autograd model: learning step, overlapped steps, unused parameters;
+  * bucket layout and launch order.
+"""
 import os
 import socket
 
@@ -10,6 +14,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 from torch import nn
+
+GROUPS = [2, 1, 2, 1, 1]  # 5 video groups, 7 pairs: rank 0 gets groups 0,2,4, rank 1 gets 1,3
 
 
 class Toy(nn.Module):
@@ -36,11 +42,16 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out):
+def _init(rank, world, port):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    from mesm_amd.ddp import GradReducer, init_process_group_from_env
-    from mesm_amd.gradbuf import GradBuffer
+    from mesm_amd.ddp import init_process_group_from_env
     init_process_group_from_env(torch.device("cpu"))
+
+
+def _worker(rank, world, port, out):
+    _init(rank, world, port)
+    from mesm_amd.ddp import GradReducer
+    from mesm_amd.gradbuf import GradBuffer
     m = Toy()
     gb = GradBuffer([(n, p) for n, p in m.named_parameters()])
     gb.ensure(torch.device("cpu"))
@@ -81,6 +92,115 @@ def test_gloo_world2_mean_of_rank_gradients():
                 mean = sum(w[n] for w in want) / world
                 assert torch.allclose(got[n], mean, atol=1e-6), (step, r, n)
             assert got["unused"] is None  # never touched -> stays None, like under autograd
+
+
+# ----------------------------------------------------------------------------- the real parameter set
+def _tiny_global_batch():
+    from golden_io import Fixture
+    from mesm_amd import synthetic
+    fx = Fixture("qvh_tiny")
+    c = fx.cfg
+    batch = synthetic.make_batch("qvhighlights", GROUPS, c["Lv"], c["Lw"], c["v_feat_dim"], c["t_feat_dim"],
+                                 c["vocab_size"] + 1, seed=21, ragged=True)
+    return fx, batch
+
+
+def _shard_oracle_grads(fx, batch, rank, world):
+    from mesm_amd import synthetic
+    from mesm_amd.ddp import shard_groups
+    from oracle import mesm_oracle as O
+    shard = shard_groups(batch, rank, world)
+    neg, masked = synthetic.host_draws(shard, seed=rank)  # per-rank RNG streams
+    _, _, total, grads, _ = O.train_step(fx.sd, fx.cfg, shard, neg, masked)
+    return shard, grads, float(total)
+
+
+def _worker_real(rank, world, port, out):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    _init(rank, world, port)
+    torch.set_num_threads(2)
+    from mesm_amd.ddp import GradReducer
+    from mesm_amd.gradbuf import GradBuffer, flush_ready, grad_target
+    fx, batch = _tiny_global_batch()
+    _, grads, _ = _shard_oracle_grads(fx, batch, rank, world)
+    params = [(n, nn.Parameter(v.clone())) for n, v in fx.sd.items() if v.is_floating_point()]
+    gb = GradBuffer(params)
+    gb.ensure(torch.device("cpu"))
+    red = GradReducer(gb, n_buckets=5)
+
+    class Emit(torch.autograd.Function):
+        """stands in for the model's backward blocks: gradients arrive in reverse parameter order, the
+        shared encoder weights in two contributions (positive + negative pass), and on rank 1 one
+        parameter gets NO contribution at all (like unknown_token without an OOV word)."""
+
+        @staticmethod
+        def forward(ctx, x):
+            return x.clone()
+
+        @staticmethod
+        def backward(ctx, g):
+            for n, p in reversed(params):
+                if n not in grads:
+                    continue
+                if n == "unknown_token" and rank == 1:
+                    continue
+                parts = 2 if n.startswith("enhance_encoder") else 1
+                for _ in range(parts):
+                    v, direct = grad_target(p)
+                    assert direct
+                    v.add_(grads[n] / parts)
+                    flush_ready()
+            return g
+
+    res = []
+    for step in range(3):
+        gb.begin_step()
+        for _, p in params:
+            p.grad = None
+        x = torch.zeros(1, requires_grad=True)
+        Emit.apply(x).sum().backward()
+        res.append({n: p.grad.clone() for n, p in params if p.grad is not None})
+    out[rank] = (res, list(red.launch_log), len(red.buckets))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_gloo_world2_sharded_oracle_gradients_are_averaged():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_real, args=(world, port, out), nprocs=world, join=True)
+    fx, batch = _tiny_global_batch()
+    per_rank = [_shard_oracle_grads(fx, batch, r, world)[1] for r in range(world)]
+    per_rank[1] = {k: v for k, v in per_rank[1].items() if k != "unknown_token"}
+    names = set(per_rank[0]) | set(per_rank[1])
+    for r in range(world):
+        steps, log, nb = out[r]
+        # same bucket order on both ranks in every step: last bucket first, then downwards
+        assert log == list(range(nb - 1, -1, -1)) * 3, log
+        for got in steps:
+            for n in names:
+                mean = sum(g.get(n, torch.zeros_like(fx.sd[n])) for g in per_rank) / world
+                assert n in got or (r == 1 and n == "unknown_token"), n
+                if n in got:
+                    assert torch.allclose(got[n], mean, rtol=1e-5, atol=1e-7), (r, n)
+
+
+def test_shard_groups_partitions_rows_by_video_group():
+    from mesm_amd.ddp import shard_groups
+    fx, batch = _tiny_global_batch()
+    N = sum(GROUPS)
+    batch["qid"] = list(range(N))
+    s0, s1 = shard_groups(batch, 0, 2), shard_groups(batch, 1, 2)
+    assert s0["num_clips"].tolist() == [2, 2, 1] and s1["num_clips"].tolist() == [1, 1]
+    assert s0["qid"] == [0, 1, 3, 4, 6] and s1["qid"] == [2, 5]
+    assert torch.equal(s0["video_feat"], batch["video_feat"][[0, 1, 3, 4, 6]])
+    assert len(s1["norm_span"]) == 2 and torch.equal(s1["norm_span"][1]["spans"], batch["norm_span"][5]["spans"])
+    assert torch.equal(s1["saliency_label"], batch["saliency_label"][[2, 5]])
+    with pytest.raises(ValueError):  # 5 groups over 3 ranks leaves rank 2 with one group: no negatives
+        shard_groups(batch, 2, 3)
 
 
 def test_buckets_cover_the_flat_buffer():

@@ -1,0 +1,253 @@
+"""GPU tests of the step drivers around the hot path:
+
+  * GraphedStep.load_batch: a captured step replayed on a DIFFERENT batch (other masks, GT clips, target
+    windows, group video lengths) equals the eager step on that batch;
+  * GraphedStep + FlatAdamW over several steps equals eager + FlatAdamW (parameters really update through
+    the graph), and a parameter that moves after capture is refused;
+  * StepCache captures one graph per shape bucket and reuses it;
+  * the sharded (DDP) parity target on one GPU: the mean of the HIP gradients of two group shards equals
+    the mean of the oracle's per-shard gradients;
+  * the bucketed all-reduce captured inside the step graph (1-rank RCCL group).
+"""
+import argparse
+import os
+
+import pytest
+import torch
+
+from golden_io import Fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-3)
+
+
+def _no_dropout(model):
+    for m in model.modules():
+        if hasattr(m, "p"):
+            m.p = 0.0
+
+
+def _build(workload, seed=7, **over):
+    from mesm_amd import build_criterion, build_model, synthetic
+    args = synthetic.make_args(workload, device="cuda:0", **over)
+    torch.manual_seed(seed)
+    model = build_model(args)
+    crit = build_criterion(args)
+    _no_dropout(model)
+    return args, model, crit
+
+
+def _eager(model, crit, batch, name, plan):
+    out = model(**batch, dataset_name=name, is_training=True, plan=plan)
+    _, total = crit(out, batch, True)
+    model.zero_grad(set_to_none=True)
+    total.backward()
+    torch.cuda.synchronize()
+    return float(total), model.gradbuf().flat.clone()
+
+
+@pytest.mark.parametrize("workload,ragged2", [("C3a", True), ("C3b", True), ("C2", False)])
+def test_load_batch_replays_a_different_batch(workload, ragged2):
+    from mesm_amd import synthetic
+    from mesm_amd.graphed import GraphedStep
+    args, model, crit = _build(workload)
+    b1 = synthetic.to_device(synthetic.workload_batch(workload, seed=1, ragged=ragged2), dev())
+    g = GraphedStep(model, crit, b1, args.dataset_name, warmup=1, caps="auto")
+    # a batch with other features, lengths, GT runs, saliency labels and target windows
+    b2_cpu = synthetic.workload_batch(workload, seed=2, ragged=ragged2)
+    N = b2_cpu["video_feat"].shape[0]
+    b2_cpu = {k: (torch.flip(v, [0]) if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == N and k != "num_clips"
+                  else (v[::-1] if isinstance(v, list) else v)) for k, v in b2_cpu.items()}
+    g.load_batch(b2_cpu)  # host tensors: copied into the static inputs, plans rebuilt on the host
+    total_g = float(g.run(redraw=False))
+    torch.cuda.synchronize()
+    flat_g = model.gradbuf().flat.clone()
+    b2 = synthetic.to_device(b2_cpu, dev())
+    plan = model.make_plan(b2["video_mask"], g._wm_cpu, b2["num_clips"], args.dataset_name, True,
+                           words_weight=b2["words_weight"], clip_mask=b2["clip_mask"],
+                           neg_index=g.plan.neg_index, masked_words=g.plan.masked_words, device=dev())
+    total_e, flat_e = _eager(model, crit, b2, args.dataset_name, plan)
+    assert abs(total_e - total_g) < 1e-5 * max(1.0, abs(total_e)), (total_e, total_g)
+    assert float((flat_e - flat_g).norm()) / max(float(flat_e.norm()), 1e-6) < 1e-4
+    # and it differs from the first batch's step (the stale-plan defect would reproduce batch 1's targets)
+    g.load_batch(synthetic.workload_batch(workload, seed=1, ragged=ragged2))
+    total_1 = float(g.run(redraw=False))
+    assert abs(total_1 - total_g) > 1e-3
+
+
+def test_load_batch_rejects_what_does_not_fit():
+    from mesm_amd import synthetic
+    from mesm_amd.graphed import GraphedStep
+    args, model, crit = _build("C3a")
+    b1 = synthetic.to_device(synthetic.workload_batch("C3a", seed=1), dev())
+    g = GraphedStep(model, crit, b1, args.dataset_name, warmup=1)  # exact extents, no head-room
+    b2 = synthetic.workload_batch("C3a", seed=1)
+    b2["clip_mask"] = b2["clip_mask"].clone()
+    b2["clip_mask"][0, :40] = True  # 40 GT clips > the captured Lc
+    with pytest.raises(ValueError):
+        g.load_batch(b2)
+    b3 = synthetic.workload_batch("C3b", seed=1)  # other group sizes
+    with pytest.raises(ValueError):
+        g.load_batch(b3)
+
+
+def test_graph_with_flat_adamw_trains_like_eager():
+    """capture, then optimizer steps through the graph must move the weights the graph reads."""
+    from mesm_amd import synthetic
+    from mesm_amd.graphed import GraphedStep
+    from mesm_amd.optim import FlatAdamW
+    fx = Fixture("qvh_tiny")
+    res = []
+    for mode in ("graph", "eager"):
+        a = argparse.Namespace(**fx.cfg)
+        a.device = "cuda:0"
+        from mesm_amd import build_criterion, build_model
+        model = build_model(a)
+        model.load_state_dict(fx.sd)
+        crit = build_criterion(a)
+        _no_dropout(model)
+        model.train()
+        batch = synthetic.to_device(fx.batch, dev())
+        if mode == "graph":
+            # the order INTEGRATION.md used to show: graph first, optimizer second
+            g = GraphedStep(model, crit, batch, fx.cfg["dataset_name"], warmup=1)
+            g.plan.neg_index.copy_(fx.neg_index)
+            g.plan.masked_words.copy_(fx.masked_words)
+            opt = FlatAdamW(model, lr=1e-3, weight_decay=1e-2)
+            losses = []
+            for _ in range(4):
+                losses.append(float(g.run(redraw=False)))
+                opt.step(grad_clip=0.1)
+        else:
+            opt = FlatAdamW(model, lr=1e-3, weight_decay=1e-2)
+            plan = model.make_plan(batch["video_mask"], batch["words_id"].abs().sum(-1).ne(0).cpu(),
+                                   batch["num_clips"], fx.cfg["dataset_name"], True,
+                                   words_weight=batch["words_weight"], clip_mask=batch["clip_mask"],
+                                   neg_index=fx.neg_index, masked_words=fx.masked_words, device=dev())
+            losses = []
+            for _ in range(4):
+                losses.append(_eager(model, crit, batch, fx.cfg["dataset_name"], plan)[0])
+                opt.step(grad_clip=0.1)
+        torch.cuda.synchronize()
+        res.append((losses, {n: p.detach().clone() for n, p in model.named_parameters()}))
+    (lg, pg), (le, pe) = res
+    assert lg[0] != lg[3]  # the loss moves: the graph sees the updated weights
+    for a_, b_ in zip(lg, le):
+        assert abs(a_ - b_) < 1e-4 * max(1.0, abs(b_)), (lg, le)
+    # AdamW normalises every gradient element by its own running magnitude, so elements whose gradient is
+    # analytically zero (softmax-invariant key biases: pure rounding noise) still move by ~lr per step in a
+    # noise-determined direction: the bound is absolute, 1 % of one step of lr = 1e-3
+    for n in pg:
+        a_, b_ = pg[n].double(), pe[n].double()
+        assert float((a_ - b_).abs().max()) < 1e-5 + 1e-4 * float(b_.abs().max()), n
+
+
+def test_graph_refuses_to_replay_after_parameters_moved():
+    from mesm_amd import synthetic
+    from mesm_amd.graphed import GraphedStep
+    fx = Fixture("qvh_tiny")
+    from mesm_amd import build_criterion, build_model
+    a = argparse.Namespace(**fx.cfg)
+    a.device = "cuda:0"
+    model = build_model(a)
+    crit = build_criterion(a)
+    batch = synthetic.to_device(fx.batch, dev())
+    g = GraphedStep(model, crit, batch, fx.cfg["dataset_name"], warmup=1)
+    g.run()
+    p = next(model.parameters())
+    p.data = p.data.clone()  # what a lazily flattening optimizer used to do
+    with pytest.raises(RuntimeError):
+        g.run()
+
+
+def test_step_cache_buckets_shapes():
+    from mesm_amd import synthetic
+    from mesm_amd.graphed import StepCache
+    args, model, crit = _build("C3a")
+    cache = StepCache(model, crit, args.dataset_name)
+    b1 = synthetic.workload_batch("C3a", seed=1, ragged=True)
+    b2 = synthetic.workload_batch("C3a", seed=2, ragged=True)
+    t1, gs1 = cache.run(b1, redraw=False)
+    t1 = float(t1)
+    t2, gs2 = cache.run(b2, redraw=False)
+    assert gs1 is gs2 and cache.captures == 1  # same bucket: one graph
+    t2 = float(t2)
+    b2d = synthetic.to_device(b2, dev())
+    plan = model.make_plan(b2d["video_mask"], gs2._wm_cpu, b2d["num_clips"], args.dataset_name, True,
+                           words_weight=b2d["words_weight"], clip_mask=b2d["clip_mask"],
+                           neg_index=gs2.plan.neg_index, masked_words=gs2.plan.masked_words, device=dev())
+    te, _ = _eager(model, crit, b2d, args.dataset_name, plan)
+    assert abs(te - t2) < 1e-5 * max(1.0, abs(te))
+    b3 = synthetic.workload_batch("C3b", seed=1)  # other group sizes: a second graph
+    cache.run(b3, redraw=False)
+    assert cache.captures == 2
+    assert abs(float(cache.run(b1, redraw=False)[0]) - t1) < 1e-5 * max(1.0, abs(t1)) and cache.captures == 2
+
+
+def test_two_shards_mean_equals_oracle_mean():
+    """SURVEY 8e parity target on one GPU: shards r::2 by video group run one after the other through the
+    HIP model; the mean of their gradients equals the mean of the oracle's per-shard gradients."""
+    from mesm_amd import build_criterion, build_model, synthetic
+    from mesm_amd.ddp import shard_groups
+    from oracle import mesm_oracle as O
+    fx = Fixture("qvh_tiny")
+    c = fx.cfg
+    batch = synthetic.make_batch("qvhighlights", [2, 1, 2, 1, 1], c["Lv"], c["Lw"], c["v_feat_dim"],
+                                 c["t_feat_dim"], c["vocab_size"] + 1, seed=21, ragged=True)
+    a = argparse.Namespace(**c)
+    a.device = "cuda:0"
+    model = build_model(a)
+    model.load_state_dict(fx.sd)
+    crit = build_criterion(a)
+    model.eval()
+    hip, ora = [], []
+    for r in range(2):
+        shard = shard_groups(batch, r, 2)
+        neg, masked = synthetic.host_draws(shard, seed=r)
+        sb = synthetic.to_device(shard, dev())
+        out = model(**sb, dataset_name="qvhighlights", is_training=True, neg_index=neg, masked_words=masked)
+        _, total = crit(out, sb, True)
+        model.zero_grad(set_to_none=True)
+        total.backward()
+        hip.append({n: p.grad.detach().cpu().clone() for n, p in model.named_parameters() if p.grad is not None})
+        ora.append(O.train_step(fx.sd, c, shard, neg, masked)[3])
+    assert set(hip[0]) == set(ora[0]) and set(hip[1]) == set(ora[1])
+    for n in hip[0]:
+        assert rel((hip[0][n] + hip[1][n]) / 2, (ora[0][n] + ora[1][n]) / 2) < 5e-4, n
+
+
+def test_allreduce_captured_inside_the_step_graph():
+    """The hooked GradReducer under HIP-graph capture on a 1-rank RCCL group (`force=True`): the bucket
+    collectives are recorded on the process group's stream inside the step graph and the replayed step gives
+    the eager gradients (x 1/1)."""
+    import torch.distributed as dist
+    from mesm_amd import synthetic
+    from mesm_amd.ddp import GradReducer
+    from mesm_amd.graphed import GraphedStep
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev())
+    try:
+        args, model, crit = _build("C3a")
+        batch = synthetic.to_device(synthetic.workload_batch("C3a", seed=1), dev())
+        red = GradReducer(model.gradbuf(), n_buckets=6, force=True)
+        g = GraphedStep(model, crit, batch, args.dataset_name, warmup=2, reducer=red)
+        total_g = float(g.run(redraw=False))
+        torch.cuda.synchronize()
+        flat_g = model.gradbuf().flat.clone()
+        assert red.launch_log[-6:] == [5, 4, 3, 2, 1, 0]
+        model.gradbuf().on_ready = None
+        total_e, flat_e = _eager(model, crit, batch, args.dataset_name, g.plan)
+        assert abs(total_e - total_g) < 1e-5 * max(1.0, abs(total_e))
+        assert float((flat_e - flat_g).norm()) / max(float(flat_e.norm()), 1e-6) < 1e-4
+    finally:
+        dist.destroy_process_group()

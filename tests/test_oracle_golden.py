@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from golden_io import CASES, GOLDEN, Fixture
+from golden_io import CASES, CLIP_CASES, GOLDEN, Fixture
 from oracle import mesm_oracle as O
 
 TOL = 2e-5
@@ -17,7 +17,7 @@ def close(a, b, tol=TOL):
     return float((a - b).abs().max()) / scale < tol
 
 
-@pytest.fixture(scope="module", params=CASES)
+@pytest.fixture(scope="module", params=CASES + CLIP_CASES)
 def step(request):
     fx = Fixture(request.param)
     out, losses, total, grads, idx = O.train_step(fx.sd, fx.cfg, fx.batch, fx.neg_index, fx.masked_words)

@@ -5,7 +5,8 @@ the bytes of wide coalesced reads (128-B requests tallied at 64 B), so it is dou
 exact.  The number of training steps the profiled command executed is counted from the trace itself:
 saliency_fwd_kernel runs exactly once per step (eager warm-up, capture, replays and the PCIe-inclusive
 leg of bench.py all included); the 4th argument is only the fallback when that kernel is absent.
-Usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [steps]"""
+Usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [steps] [bench.json] [tag]
+(bench.json of the same round: its roofline.launches_per_step is recorded so bench.py can tell a stale file)"""
 import csv, json, sys
 csv.field_size_limit(1 << 30)
 
@@ -36,5 +37,13 @@ out = {
     "correction": "FETCH_SIZE x2 (gfx950: 128-B requests tallied at 64 B), WRITE_SIZE x1, KiB -> bytes",
     "hbm_bytes_per_launch": (2.0 * f / max(nf, 1) + w / max(nw, 1)) * 1024.0,
 }
+if len(sys.argv) > 5:
+    try:
+        line = json.loads(open(sys.argv[5]).read().strip().splitlines()[-1])
+        out["launch_calls_per_step"] = line["roofline"]["launches_per_step"]
+    except Exception as e:  # noqa: BLE001
+        out["launch_calls_per_step"] = None
+if len(sys.argv) > 6:
+    out["profile"] = sys.argv[6]
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out))
