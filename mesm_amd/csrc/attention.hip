@@ -137,6 +137,9 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const MesmAttnArgs
         const float alpha = (m_old == -INFINITY) ? 0.0f : __expf(m_old - m_new);
         const float l_new = Ls[r] * alpha + wave_sum(pj);
         pd = pj;
+        // the fp16 SDPA of the frozen CLIP tower hands the probabilities to P V in fp16 while the row sum keeps
+        // the fp32 values (ATen's CPU flash kernel for reduced types): same rounding point here
+        if (causal) pd = (float)(_Float16)pj;
         if (thresh) {
           uint32_t idx = (uint32_t)(((int64_t)bh * p.Lq + i) * p.Lk + j);
           pd = mesm_dropout_apply(pj, idx, drop_seed, thresh, inv_keep);
@@ -153,8 +156,9 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const MesmAttnArgs
       float acc[RW];
 #pragma unroll
       for (int rr = 0; rr < RW; ++rr) acc[rr] = 0.0f;
+      const int kend = (p.Lk - k0) < KT ? (p.Lk - k0) : KT;  // keys beyond Lk carry p = 0: skip them (Lk = 33: 17 steps, not 32)
 #pragma unroll 4
-      for (int jj = g; jj < KT; jj += G) {
+      for (int jj = g; jj < kend; jj += G) {
         const float4 pr = *reinterpret_cast<const float4*>(Ps + (wave * KT + jj) * RW);
         const float v = Vs[jj * DV + d];
         acc[0] += pr.x * v; acc[1] += pr.y * v; acc[2] += pr.z * v; acc[3] += pr.w * v;
@@ -332,8 +336,9 @@ __global__ __launch_bounds__(64 * BW_WAVES) void attn_bwd_kernel(const MesmAttnA
       float acc[RB];
 #pragma unroll
       for (int rr = 0; rr < RB; ++rr) acc[rr] = 0.0f;
+      const int kend = (p.Lk - k0) < KT ? (p.Lk - k0) : KT;  // dS of the keys beyond Lk is 0
 #pragma unroll 4
-      for (int jj = g; jj < KT; jj += GQ) {
+      for (int jj = g; jj < kend; jj += GQ) {
         const float4 pr = *reinterpret_cast<const float4*>(Ps + (wave * KT + jj) * RB);
         const float kv = Ks[jj * SK + d];
         acc[0] += pr.x * kv; acc[1] += pr.y * kv; acc[2] += pr.z * kv; acc[3] += pr.w * kv;

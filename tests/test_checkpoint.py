@@ -65,13 +65,13 @@ def test_resume_all_continues_like_the_reference():
     torch.cuda.synchronize()
     assert abs(float(total) - float(Z["losses"][2])) < 1e-4 * abs(float(Z["losses"][2]))
     sd = model.state_dict()
-    worst = 0.0
+    # AdamW moves every element by ~lr in the direction of g / sqrt(v): the key biases (softmax-invariant, their
+    # gradient is rounding noise) may end anywhere within one step of lr = 1e-4; everything else within 2e-4
     for k in sd:
         a, b = sd[k].double().cpu(), torch.from_numpy(Z["after." + k]).double()
-        worst = max(worst, float((a - b).abs().max()) / max(float(b.abs().max()), 1e-3))
-    # AdamW moves every element by ~lr in the direction of g / sqrt(v): elements whose gradient is rounding noise
-    # may differ by a fraction of one step (lr = 1e-4 here)
-    assert worst < 2e-4, worst
+        err = float((a - b).abs().max())
+        key_bias = k.endswith("in_proj_bias") or k.endswith(("kcontent_proj.bias", "kpos_proj.bias"))
+        assert err < (0.5 * 1e-4 if key_bias else 2e-4 * max(float(b.abs().max()), 1e-3)), (k, err)
     # and what this build saves has the reference's layout
     import tempfile
     path = os.path.join(tempfile.mkdtemp(), "x.ckpt")

@@ -143,11 +143,14 @@ def test_graph_with_flat_adamw_trains_like_eager():
     for a_, b_ in zip(lg, le):
         assert abs(a_ - b_) < 1e-4 * max(1.0, abs(b_)), (lg, le)
     # AdamW normalises every gradient element by its own running magnitude, so elements whose gradient is
-    # analytically zero (softmax-invariant key biases: pure rounding noise) still move by ~lr per step in a
-    # noise-determined direction: the bound is absolute, 1 % of one step of lr = 1e-3
+    # analytically zero (the key biases: softmax is invariant to them, their gradient is pure rounding noise)
+    # still move by up to lr per step in a noise-determined direction: for those the bound is 5 % of the
+    # 4 x lr the element can have moved; every other tensor is held to 1e-4
     for n in pg:
         a_, b_ = pg[n].double(), pe[n].double()
-        assert float((a_ - b_).abs().max()) < 1e-5 + 1e-4 * float(b_.abs().max()), n
+        key_bias = n.endswith("in_proj_bias") or n.endswith(("kcontent_proj.bias", "kpos_proj.bias"))
+        tol = 0.05 * 4 * 1e-3 if key_bias else 1e-5 + 1e-4 * float(b_.abs().max())
+        assert float((a_ - b_).abs().max()) < tol, n
 
 
 def test_graph_refuses_to_replay_after_parameters_moved():
@@ -227,27 +230,18 @@ def test_two_shards_mean_equals_oracle_mean():
 def test_allreduce_captured_inside_the_step_graph():
     """The hooked GradReducer under HIP-graph capture on a 1-rank RCCL group (`force=True`): the bucket
     collectives are recorded on the process group's stream inside the step graph and the replayed step gives
-    the eager gradients (x 1/1)."""
-    import torch.distributed as dist
-    from mesm_amd import synthetic
-    from mesm_amd.ddp import GradReducer
-    from mesm_amd.graphed import GraphedStep
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
-    if not dist.is_initialized():
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev())
-    try:
-        args, model, crit = _build("C3a")
-        batch = synthetic.to_device(synthetic.workload_batch("C3a", seed=1), dev())
-        red = GradReducer(model.gradbuf(), n_buckets=6, force=True)
-        g = GraphedStep(model, crit, batch, args.dataset_name, warmup=2, reducer=red)
-        total_g = float(g.run(redraw=False))
-        torch.cuda.synchronize()
-        flat_g = model.gradbuf().flat.clone()
-        assert red.launch_log[-6:] == [5, 4, 3, 2, 1, 0]
-        model.gradbuf().on_ready = None
-        total_e, flat_e = _eager(model, crit, batch, args.dataset_name, g.plan)
-        assert abs(total_e - total_g) < 1e-5 * max(1.0, abs(total_e))
-        assert float((flat_e - flat_g).norm()) / max(float(flat_e.norm()), 1e-6) < 1e-4
-    finally:
-        dist.destroy_process_group()
+    the eager gradients (x 1/1).  Runs in a child process (tests/ddp_capture_worker.py): tearing a RCCL
+    communicator down next to a live graph that holds its work can abort the interpreter, which must not take
+    the test session with it; the worker leaves through os._exit after printing its result."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(here, "ddp_capture_worker.py")], env=env, capture_output=True,
+                       text=True, timeout=600)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+    assert lines, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    res = json.loads(lines[-1][7:])
+    assert res["launch_log_tail"] == [5, 4, 3, 2, 1, 0], res
+    assert res["loss_err"] < 1e-5 and res["grad_err"] < 1e-4, res

@@ -56,6 +56,35 @@ for e in cpu:
         continue
     kern[name] += len(e.kernels)
     ktime[name] += sum(k.duration for k in e.kernels)
+# backward kernels by the model REGION whose forward created the autograd node (sequence numbers link the two)
+seq_scope = {}
+regions = [e for e in cpu if e.name.startswith("R:") or e.name == "CRIT"]
+for e in cpu:
+    sq = getattr(e, "sequence_nr", -1)
+    if sq is None or sq < 0 or e.name.startswith("autograd::engine"):
+        continue
+    best = None
+    for s in regions:
+        if s.thread == e.thread and s.time_range.start <= e.time_range.start and e.time_range.end <= s.time_range.end:
+            if best is None or s.time_range.start >= best.time_range.start:
+                best = s
+    if best is not None and sq not in seq_scope:
+        seq_scope[sq] = best.name
+rk, rt = collections.Counter(), collections.Counter()
+for e in cpu:
+    if not e.name.startswith("autograd::engine::evaluate_function"):
+        continue
+    reg = seq_scope.get(getattr(e, "sequence_nr", -1), "?")
+    stack = [e]
+    while stack:
+        x = stack.pop()
+        if x.kernels and not any(c.kernels for c in x.cpu_children):
+            rk["bwd@" + reg] += len(x.kernels)
+            rt["bwd@" + reg] += sum(k.duration for k in x.kernels)
+        stack.extend(x.cpu_children)
+print("backward kernels by forward region:")
+for n, c in rk.most_common(20):
+    print("%-60s %5d  %8.1f us" % (n, c, rt[n]))
 tot = sum(kern.values())
 print("total kernels in step: %d" % tot)
 for n, c in kern.most_common(70):
