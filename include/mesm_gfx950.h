@@ -180,6 +180,20 @@ int mesm_layernorm_bwd2(const float* dy, const float* x, const float* gamma,
                         float drop_p, uint32_t drop_seed, const uint32_t* seed_offset,
                         float* dx2, float drop2_p, uint32_t drop2_seed, void* stream);
 
+/* Forward with a second output y2 = y + add (add, y2: rows x D, both NULL = off): the `with_pos_embed` query
+ * (transformer.py:512, 577, 640) of the attention block that consumes y, written by the LayerNorm that produces y
+ * instead of an element-wise launch.  Backward counterpart: dyb (NULL = off) is the gradient of that second
+ * consumer, added to dy on load; addend (NULL = off) is a gradient that reaches x on another route -- the residual
+ * branch of `x + FFN(LN(x))` (transformer.py:536-538, 601-609) -- added to dx on store. */
+int mesm_layernorm_fwd2(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                        float* rstd, int64_t rows, int32_t D, float eps, float drop_p, uint32_t drop_seed,
+                        const uint32_t* seed_offset, const float* add, float* y2, void* stream);
+int mesm_layernorm_bwd3(const float* dy, const float* x, const float* gamma, const float* mean,
+                        const float* rstd, float* dx, float* dgamma, float* dbeta, int64_t rows, int32_t D,
+                        int32_t accumulate_dx, float drop_p, uint32_t drop_seed, const uint32_t* seed_offset,
+                        float* dx2, float drop2_p, uint32_t drop2_seed, const float* dyb, const float* addend,
+                        void* stream);
+
 /* ------------------------------------------------------------------------- */
 /*
  * Multi-head attention core: scores = scale * Q K^T -> mask(-inf) -> softmax ->
@@ -236,6 +250,15 @@ typedef struct MesmAttnArgs {
      one launch): the batch index wraps inside groups of mask_group rows,
      b2 = (b / G) * G + ((b % G) * H + h) mod G.  0 = one group of B rows. */
   int32_t mask_group;
+  /* Split heads (NULL = off): head h's dk features are [ q[.., h*dk/2 : (h+1)*dk/2] || q2[.., same columns] ],
+     i.e. q and q2 are (B, Lq, H*dk/2) tensors with the strides q_bs / q_ls (k, k2 likewise with k_bs / k_ls):
+     the decoder cross-attention's per-head [content || position] queries and keys (transformer.py:778-784,
+     attention.py embed_dim 2d) without materialising the interleaved (B, L, 2d) copies.  The backward writes
+     the two halves of dq / dk into dq, dq2 / dk_, dk2 (same layouts). */
+  const float* q2;
+  const float* k2;
+  float* dq2;
+  float* dk2;
 } MesmAttnArgs;
 
 int mesm_attn_fwd(const MesmAttnArgs* args, void* stream);

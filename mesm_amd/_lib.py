@@ -57,6 +57,7 @@ class AttnArgs(ctypes.Structure):
         ("drop_seed", ctypes.c_uint32),
         ("d_o", c_ptr), ("dq", c_ptr), ("dk_", c_ptr), ("dv_", c_ptr),
         ("seed_offset", c_ptr), ("mask_group", ctypes.c_int32),
+        ("q2", c_ptr), ("k2", c_ptr), ("dq2", c_ptr), ("dk2", c_ptr),
     ]
 
 
@@ -74,6 +75,9 @@ PROTOTYPES = {
     "mesm_layernorm_fwd": (ctypes.c_int, [c_ptr] * 6 + [_i64, _i32, _f32, _f32, _u32, c_ptr, c_ptr]),
     "mesm_layernorm_bwd": (ctypes.c_int, [c_ptr] * 8 + [_i64, _i32, _i32, _f32, _u32, c_ptr, c_ptr]),
     "mesm_layernorm_bwd2": (ctypes.c_int, [c_ptr] * 8 + [_i64, _i32, _i32, _f32, _u32, c_ptr, c_ptr, _f32, _u32, c_ptr]),
+    "mesm_layernorm_fwd2": (ctypes.c_int, [c_ptr] * 6 + [_i64, _i32, _f32, _f32, _u32, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "mesm_layernorm_bwd3": (ctypes.c_int, [c_ptr] * 8 + [_i64, _i32, _i32, _f32, _u32, c_ptr, c_ptr, _f32, _u32,
+                                                        c_ptr, c_ptr, c_ptr]),
     "mesm_attn_fwd": (ctypes.c_int, [ctypes.POINTER(AttnArgs), c_ptr]),
     "mesm_attn_bwd": (ctypes.c_int, [ctypes.POINTER(AttnArgs), c_ptr]),
     "mesm_sine_pos_fwd": (ctypes.c_int, [c_ptr, c_ptr, _i32, _i32, _i32, c_ptr]),

@@ -56,15 +56,22 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const MesmAttnArgs
   const bool quirk = (p.mask_mode == MESM_MASK_T2V_QUIRK) && p.qpad && p.kpad;
   const bool causal = p.mask_mode == MESM_MASK_CAUSAL;
 
-  const float* qb = p.q + (int64_t)b * p.q_bs + (int64_t)h * DK;
-  const float* kb = p.k + (int64_t)b * p.k_bs + (int64_t)h * DK;
+  // split heads (q2 / k2 given): the head's DK features are [ q[h*DK/2 ...] || q2[h*DK/2 ...] ], two tensors of
+  // H * DK/2 columns with the same strides -- the decoder's per-head [content || position] queries and keys
+  // (transformer.py:778-784) read in place instead of from an interleaved copy
+  constexpr int DKH = DK / 2;
+  const bool split = p.q2 != nullptr;
+  const float* qb = p.q + (int64_t)b * p.q_bs + (int64_t)h * (split ? DKH : DK);
+  const float* kb = p.k + (int64_t)b * p.k_bs + (int64_t)h * (split ? DKH : DK);
+  const float* qb2 = split ? p.q2 + (int64_t)b * p.q_bs + (int64_t)h * DKH - DKH : qb;  // indexed with c >= DKH
+  const float* kb2 = split ? p.k2 + (int64_t)b * p.k_bs + (int64_t)h * DKH - DKH : kb;
   const float* vb = p.v + (int64_t)b * p.v_bs + (int64_t)h * DV;
 
   // stage the query chunk and reset the row state
   for (int idx = tid; idx < QCH * (DK / 4); idx += AT_THREADS) {
     int r = idx / (DK / 4), c = (idx % (DK / 4)) * 4;
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (r < nq) t = *reinterpret_cast<const float4*>(qb + (int64_t)(q0 + r) * p.q_ls + c);
+    if (r < nq) t = *reinterpret_cast<const float4*>((c >= DKH ? qb2 : qb) + (int64_t)(q0 + r) * p.q_ls + c);
     *reinterpret_cast<float4*>(Qs + r * DK + c) = t;
   }
   for (int idx = tid; idx < QCH * DV; idx += AT_THREADS) Os[idx] = 0.0f;
@@ -81,7 +88,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const MesmAttnArgs
     for (int idx = tid; idx < KT * (DK / 4); idx += AT_THREADS) {
       int r = idx / (DK / 4), c = (idx % (DK / 4)) * 4;
       float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k0 + r < p.Lk) x = *reinterpret_cast<const float4*>(kb + (int64_t)(k0 + r) * p.k_ls + c);
+      if (k0 + r < p.Lk) x = *reinterpret_cast<const float4*>((c >= DKH ? kb2 : kb) + (int64_t)(k0 + r) * p.k_ls + c);
       *reinterpret_cast<float4*>(Ks + r * SK + c) = x;
     }
     for (int idx = tid; idx < KT * (DV / 4); idx += AT_THREADS) {
@@ -212,19 +219,26 @@ __global__ __launch_bounds__(64 * BW_WAVES) void attn_bwd_kernel(const MesmAttnA
   const bool quirk = (p.mask_mode == MESM_MASK_T2V_QUIRK) && p.qpad && p.kpad;
   const bool dq_atomic = gridDim.y > 1;
 
-  const float* qb = p.q + (int64_t)b * p.q_bs + (int64_t)h * DK;
-  const float* kb = p.k + (int64_t)b * p.k_bs + (int64_t)h * DK;
+  constexpr int DKH = DK / 2;  // split heads: see attn_fwd_kernel
+  const bool split = p.q2 != nullptr;
+  const int hq = h * (split ? DKH : DK);
+  const float* qb = p.q + (int64_t)b * p.q_bs + hq;
+  const float* kb = p.k + (int64_t)b * p.k_bs + hq;
+  const float* qb2 = split ? p.q2 + (int64_t)b * p.q_bs + hq - DKH : qb;
+  const float* kb2 = split ? p.k2 + (int64_t)b * p.k_bs + hq - DKH : kb;
   const float* vb = p.v + (int64_t)b * p.v_bs + (int64_t)h * DV;
   const float* ob = p.o + (int64_t)b * p.o_bs + (int64_t)h * DV;
   const float* dob = p.d_o + (int64_t)b * p.o_bs + (int64_t)h * DV;
-  float* dqb = p.dq + (int64_t)b * p.q_bs + (int64_t)h * DK;
-  float* dkb = p.dk_ + (int64_t)b * p.k_bs + (int64_t)h * DK;
+  float* dqb = p.dq + (int64_t)b * p.q_bs + hq;
+  float* dkb = p.dk_ + (int64_t)b * p.k_bs + hq;
+  float* dqb2 = split ? p.dq2 + (int64_t)b * p.q_bs + hq - DKH : dqb;
+  float* dkb2 = split ? p.dk2 + (int64_t)b * p.k_bs + hq - DKH : dkb;
   float* dvb = p.dv_ + (int64_t)b * p.v_bs + (int64_t)h * DV;
 
   for (int idx = tid; idx < KT * (DK / 4); idx += BW_THREADS) {
     int r = idx / (DK / 4), c = (idx % (DK / 4)) * 4;
     float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (k0 + r < p.Lk) x = *reinterpret_cast<const float4*>(kb + (int64_t)(k0 + r) * p.k_ls + c);
+    if (k0 + r < p.Lk) x = *reinterpret_cast<const float4*>((c >= DKH ? kb2 : kb) + (int64_t)(k0 + r) * p.k_ls + c);
     *reinterpret_cast<float4*>(Ks + r * SK + c) = x;
   }
   for (int idx = tid; idx < KT * (DV / 4); idx += BW_THREADS) {
@@ -264,7 +278,7 @@ __global__ __launch_bounds__(64 * BW_WAVES) void attn_bwd_kernel(const MesmAttnA
     for (int idx = tid; idx < QCB * (DK / 4); idx += BW_THREADS) {
       int r = idx / (DK / 4), c = (idx % (DK / 4)) * 4;
       float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < nq) x = *reinterpret_cast<const float4*>(qb + (int64_t)(qc + r) * p.q_ls + c);
+      if (r < nq) x = *reinterpret_cast<const float4*>((c >= DKH ? qb2 : qb) + (int64_t)(qc + r) * p.q_ls + c);
       *reinterpret_cast<float4*>(Qs + r * DK + c) = x;
     }
     // dO chunk + delta_i = sum_d dO[i,d] * O[i,d]; DV/4 consecutive threads share a row
@@ -348,7 +362,7 @@ __global__ __launch_bounds__(64 * BW_WAVES) void attn_bwd_kernel(const MesmAttnA
         const int r = wave + rr * BW_WAVES;
         const float t = sum_across_groups<DK>(acc[rr]);
         if (g == 0 && r < nq) {
-          float* dst = dqb + (int64_t)(qc + r) * p.q_ls + d;
+          float* dst = (d >= DKH ? dqb2 : dqb) + (int64_t)(qc + r) * p.q_ls + d;
           if (dq_atomic) atomicAdd(dst, t);
           else *dst = t;
         }
@@ -373,7 +387,7 @@ __global__ __launch_bounds__(64 * BW_WAVES) void attn_bwd_kernel(const MesmAttnA
   __syncthreads();
   for (int idx = tid; idx < KT * DK; idx += BW_THREADS) {
     int r = idx / DK, c = idx % DK;
-    if (k0 + r < p.Lk) dkb[(int64_t)(k0 + r) * p.k_ls + c] = Red[r * DR + c];
+    if (k0 + r < p.Lk) (c >= DKH ? dkb2 : dkb)[(int64_t)(k0 + r) * p.k_ls + c] = Red[r * DR + c];
   }
   for (int w = 0; w < BW_WAVES; ++w) {
     __syncthreads();
@@ -406,6 +420,8 @@ int check_common(const MesmAttnArgs& a) {
   for (const void* ptr : ptrs)
     if (((uintptr_t)ptr % 16) != 0) return MESM_EALIGN;
   if (a.dk % 4 != 0 || a.dv % 4 != 0) return MESM_EINVAL;
+  if ((a.q2 == nullptr) != (a.k2 == nullptr)) return MESM_EINVAL;
+  if (a.q2 && (a.dk % 8 != 0 || ((uintptr_t)a.q2 % 16) != 0 || ((uintptr_t)a.k2 % 16) != 0)) return MESM_EALIGN;
   return MESM_OK;
 }
 
@@ -441,6 +457,7 @@ extern "C" int mesm_attn_bwd(const MesmAttnArgs* args, void* stream) {
   if (rc != MESM_OK) return rc;
   if (!a.lse || !a.d_o || !a.dq || !a.dk_ || !a.dv_) return MESM_EINVAL;
   if (a.mask_mode == MESM_MASK_CAUSAL) return MESM_EINVAL;  // the causal text encoder is frozen: forward only
+  if (a.q2 && (!a.dq2 || !a.dk2 || ((uintptr_t)a.dq2 % 16) != 0 || ((uintptr_t)a.dk2 % 16) != 0)) return MESM_EINVAL;
   const void* ptrs[4] = {a.d_o, a.dq, a.dk_, a.dv_};
   for (const void* ptr : ptrs)
     if (((uintptr_t)ptr % 16) != 0) return MESM_EALIGN;

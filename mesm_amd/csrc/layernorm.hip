@@ -65,7 +65,8 @@ template <int VEC, int NCH>
 __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ y, float* __restrict__ mean,
-    float* __restrict__ rstd, int64_t rows, int D, float eps, LnDrop dr) {
+    float* __restrict__ rstd, int64_t rows, int D, float eps, LnDrop dr,
+    const float* __restrict__ add, float* __restrict__ y2) {
   const int lane = threadIdx.x & 63;
   const int64_t wave_global = (int64_t)blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * LN_WAVES;
@@ -116,6 +117,13 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
           if (dr.thresh) o[e] = mesm_dropout_apply(o[e], (uint32_t)(row * D + col + e), dseed, dr.thresh, dr.inv_keep);
         }
         st_vec<VEC>(yr + col, o);
+        if (y2) {  // y + add: the `with_pos_embed` query of the attention block that consumes y
+          float a[VEC];
+          ld_vec<VEC>(add + row * D + col, a);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) o[e] += a[e];
+          st_vec<VEC>(y2 + row * D + col, o);
+        }
       }
     }
     if (lane == 0) {
@@ -131,7 +139,7 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_bwd_kernel(
     const float* __restrict__ gamma, const float* __restrict__ mean,
     const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ dgamma,
     float* __restrict__ dbeta, int64_t rows, int D, int accumulate_dx, LnDrop dr,
-    float* __restrict__ dx2, LnDrop dr2) {
+    float* __restrict__ dx2, LnDrop dr2, const float* __restrict__ dyb, const float* __restrict__ addend) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // LNB_WAVES * D when LDS_REDUCE
   const uint32_t dseed = dr.seed + (dr.seed_offset ? *dr.seed_offset : 0u);
   // second output: dx under the dropout mask of the block that PRODUCED the LayerNorm input
@@ -168,6 +176,12 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_bwd_kernel(
         float xv[VEC];
         ld_vec<VEC>(xr + col, xv);
         ld_vec<VEC>(dyr + col, dv[c]);
+        if (dyb) {  // y had a second consumer (y + pos went to an attention block): its gradient joins here
+          float t2[VEC];
+          ld_vec<VEC>(dyb + row * D + col, t2);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) dv[c][e] += t2[e];
+        }
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           if (dr.thresh) dv[c][e] = mesm_dropout_apply(dv[c][e], (uint32_t)(row * D + col + e), dseed, dr.thresh, dr.inv_keep);
@@ -193,9 +207,9 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_bwd_kernel(
         float o[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) o[e] = rs * (dv[c][e] * g[c][e] - c2 - xh[c][e] * c1);
-        if (accumulate_dx) {
+        if (accumulate_dx || addend) {  // + the gradient that reaches x on another route (a residual branch)
           float old[VEC];
-          ld_vec<VEC>(dxr + col, old);
+          ld_vec<VEC>((addend ? addend + row * D : dxr) + col, old);
 #pragma unroll
           for (int e = 0; e < VEC; ++e) o[e] += old[e];
         }
@@ -280,18 +294,19 @@ inline int pick_vec(int D, const void* a, const void* b, const void* c, const vo
 
 template <int VEC, int NCH>
 int fwd_launch(const float* x, const float* gamma, const float* beta, float* y, float* mean,
-               float* rstd, int64_t rows, int D, float eps, LnDrop dr, hipStream_t s) {
+               float* rstd, int64_t rows, int D, float eps, LnDrop dr, const float* add, float* y2,
+               hipStream_t s) {
   int64_t blocks = (rows + LN_WAVES - 1) / LN_WAVES;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL((ln_fwd_kernel<VEC, NCH>), dim3((unsigned)blocks), dim3(LN_THREADS), 0, s, x,
-                     gamma, beta, y, mean, rstd, rows, D, eps, dr);
+                     gamma, beta, y, mean, rstd, rows, D, eps, dr, add, y2);
   return mesm_launch_status();
 }
 
 template <int VEC, int NCH>
 int bwd_launch(const float* dy, const float* x, const float* gamma, const float* mean,
                const float* rstd, float* dx, float* dgamma, float* dbeta, int64_t rows, int D,
-               int acc, LnDrop dr, float* dx2, LnDrop dr2, hipStream_t s) {
+               int acc, LnDrop dr, float* dx2, LnDrop dr2, const float* dyb, const float* addend, hipStream_t s) {
   int64_t blocks = (rows + LNB_WAVES - 1) / LNB_WAVES;
   if (D <= 1024) {
     // workgroup cap: see the note at LNB_THREADS
@@ -299,14 +314,14 @@ int bwd_launch(const float* dy, const float* x, const float* gamma, const float*
     if (blocks > cap) blocks = cap;
     size_t lds = (size_t)LNB_WAVES * D * sizeof(float);
     hipLaunchKernelGGL((ln_bwd_kernel<VEC, NCH, true>), dim3((unsigned)blocks), dim3(LNB_THREADS),
-                       lds, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, acc, dr, dx2, dr2);
+                       lds, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, acc, dr, dx2, dr2, dyb, addend);
   } else {
     // workgroup cap: see the note at LNB_THREADS
     const int64_t cap = rows >= 4000 ? MESM_LNB_CAP : MESM_LNB_CAP / 2;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL((ln_bwd_kernel<VEC, NCH, false>), dim3((unsigned)blocks),
                        dim3(LNB_THREADS), 0, s, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows,
-                       D, acc, dr, dx2, dr2);
+                       D, acc, dr, dx2, dr2, dyb, addend);
   }
   return mesm_launch_status();
 }
@@ -326,27 +341,37 @@ int bwd_launch(const float* dy, const float* x, const float* gamma, const float*
 
 }  // namespace
 
-extern "C" int mesm_layernorm_fwd(const float* x, const float* gamma, const float* beta,
-                                  float* y, float* mean, float* rstd, int64_t rows, int32_t D,
-                                  float eps, float drop_p, uint32_t drop_seed,
-                                  const uint32_t* seed_offset, void* stream) {
+extern "C" int mesm_layernorm_fwd2(const float* x, const float* gamma, const float* beta,
+                                   float* y, float* mean, float* rstd, int64_t rows, int32_t D,
+                                   float eps, float drop_p, uint32_t drop_seed,
+                                   const uint32_t* seed_offset, const float* add, float* y2, void* stream) {
   if (!x || !gamma || !beta || !y || !mean || !rstd || rows < 0 || D <= 0) return MESM_EINVAL;
   if (drop_p < 0.f || drop_p >= 1.f) return MESM_EINVAL;
+  if ((add == nullptr) != (y2 == nullptr)) return MESM_EINVAL;
   if (rows == 0) return MESM_OK;
   hipStream_t s = (hipStream_t)stream;
   const LnDrop dr = make_drop(drop_p, drop_seed, seed_offset);
   int vec = pick_vec(D, x, y, gamma, beta);
-  if (vec == 4) LN_DISPATCH(fwd_launch, 4, x, gamma, beta, y, mean, rstd, rows, D, eps, dr, s);
-  if (vec == 2) LN_DISPATCH(fwd_launch, 2, x, gamma, beta, y, mean, rstd, rows, D, eps, dr, s);
-  LN_DISPATCH(fwd_launch, 1, x, gamma, beta, y, mean, rstd, rows, D, eps, dr, s);
+  if (add && vec > pick_vec(D, add, y2, nullptr, nullptr)) vec = pick_vec(D, add, y2, nullptr, nullptr);
+  if (vec == 4) LN_DISPATCH(fwd_launch, 4, x, gamma, beta, y, mean, rstd, rows, D, eps, dr, add, y2, s);
+  if (vec == 2) LN_DISPATCH(fwd_launch, 2, x, gamma, beta, y, mean, rstd, rows, D, eps, dr, add, y2, s);
+  LN_DISPATCH(fwd_launch, 1, x, gamma, beta, y, mean, rstd, rows, D, eps, dr, add, y2, s);
 }
 
-extern "C" int mesm_layernorm_bwd2(const float* dy, const float* x, const float* gamma,
+extern "C" int mesm_layernorm_fwd(const float* x, const float* gamma, const float* beta,
+                                  float* y, float* mean, float* rstd, int64_t rows, int32_t D,
+                                  float eps, float drop_p, uint32_t drop_seed,
+                                  const uint32_t* seed_offset, void* stream) {
+  return mesm_layernorm_fwd2(x, gamma, beta, y, mean, rstd, rows, D, eps, drop_p, drop_seed, seed_offset, nullptr,
+                             nullptr, stream);
+}
+
+extern "C" int mesm_layernorm_bwd3(const float* dy, const float* x, const float* gamma,
                                    const float* mean, const float* rstd, float* dx,
                                    float* dgamma, float* dbeta, int64_t rows, int32_t D,
                                    int32_t accumulate_dx, float drop_p, uint32_t drop_seed,
                                    const uint32_t* seed_offset, float* dx2, float drop2_p,
-                                   uint32_t drop2_seed, void* stream) {
+                                   uint32_t drop2_seed, const float* dyb, const float* addend, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dgamma || !dbeta || rows < 0 || D <= 0)
     return MESM_EINVAL;
   if (drop_p < 0.f || drop_p >= 1.f || drop2_p < 0.f || drop2_p >= 1.f) return MESM_EINVAL;
@@ -356,7 +381,7 @@ extern "C" int mesm_layernorm_bwd2(const float* dy, const float* x, const float*
   hipStream_t s = (hipStream_t)stream;
   const LnDrop dr = make_drop(drop_p, drop_seed, seed_offset);
   if (!dx) {
-    if (accumulate_dx) return MESM_EINVAL;
+    if (accumulate_dx || dyb || addend) return MESM_EINVAL;
     const int cb = (D + 255) / 256;
     int rb = (int)((1024 + cb - 1) / cb);  // about 1024 workgroups
     if (rb > rows) rb = (int)rows;
@@ -367,11 +392,23 @@ extern "C" int mesm_layernorm_bwd2(const float* dy, const float* x, const float*
     return mesm_launch_status();
   }
   int vec = pick_vec(D, x, dy, dx, gamma);
+  const int vec2 = pick_vec(D, dyb, addend, dx2, nullptr);
+  if (vec2 < vec) vec = vec2;
   if (vec == 4)
-    LN_DISPATCH(bwd_launch, 4, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, accumulate_dx, dr, dx2, dr2, s);
+    LN_DISPATCH(bwd_launch, 4, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, accumulate_dx, dr, dx2, dr2, dyb, addend, s);
   if (vec == 2)
-    LN_DISPATCH(bwd_launch, 2, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, accumulate_dx, dr, dx2, dr2, s);
-  LN_DISPATCH(bwd_launch, 1, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, accumulate_dx, dr, dx2, dr2, s);
+    LN_DISPATCH(bwd_launch, 2, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, accumulate_dx, dr, dx2, dr2, dyb, addend, s);
+  LN_DISPATCH(bwd_launch, 1, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, accumulate_dx, dr, dx2, dr2, dyb, addend, s);
+}
+
+extern "C" int mesm_layernorm_bwd2(const float* dy, const float* x, const float* gamma,
+                                   const float* mean, const float* rstd, float* dx,
+                                   float* dgamma, float* dbeta, int64_t rows, int32_t D,
+                                   int32_t accumulate_dx, float drop_p, uint32_t drop_seed,
+                                   const uint32_t* seed_offset, float* dx2, float drop2_p,
+                                   uint32_t drop2_seed, void* stream) {
+  return mesm_layernorm_bwd3(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, accumulate_dx, drop_p, drop_seed,
+                             seed_offset, dx2, drop2_p, drop2_seed, nullptr, nullptr, stream);
 }
 
 extern "C" int mesm_layernorm_bwd(const float* dy, const float* x, const float* gamma,

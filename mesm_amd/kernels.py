@@ -154,8 +154,9 @@ def flush_gemms(items):
         check(lib().mesm_gemm_group(arr, len(chunk), stream_ptr()), "mesm_gemm_group")
 
 
-def layernorm_fwd(x, gamma, beta, eps=1e-5, drop=(0.0, 0)):
-    """y = dropout(LN(x)) (drop = (p, seed); p = 0: plain LayerNorm), mean, rstd."""
+def layernorm_fwd(x, gamma, beta, eps=1e-5, drop=(0.0, 0), add=None):
+    """y = dropout(LN(x)) (drop = (p, seed); p = 0: plain LayerNorm), mean, rstd.
+    add (same shape as x): also return y + add as a fourth value (one extra store stream)."""
     require_gpu(x, gamma, beta)
     D = x.shape[-1]
     x2 = x.reshape(-1, D)
@@ -164,23 +165,45 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, drop=(0.0, 0)):
     y = torch.empty_like(x2)
     mean = torch.empty(rows, device=x.device, dtype=torch.float32)
     rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
-    check(lib().mesm_layernorm_fwd(ptr(x2), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd),
-                                   rows, D, eps, float(drop[0]), int(drop[1]) & 0xFFFFFFFF,
-                                   ptr(_seed_offset), stream_ptr()), "mesm_layernorm_fwd")
+    y2 = None
+    if add is not None:
+        assert add.is_contiguous() and add.numel() == x2.numel()
+        y2 = torch.empty_like(x2)
+    check(lib().mesm_layernorm_fwd2(ptr(x2), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd),
+                                    rows, D, eps, float(drop[0]), int(drop[1]) & 0xFFFFFFFF,
+                                    ptr(_seed_offset), ptr(add), ptr(y2), stream_ptr()), "mesm_layernorm_fwd2")
+    if add is not None:
+        return y.view(x.shape), mean, rstd, y2.view(x.shape)
     return y.view(x.shape), mean, rstd
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx=None, accumulate_dx=False, need_dx=True,
-                  drop=(0.0, 0), drop2=None):
+                  drop=(0.0, 0), drop2=None, dyb=None, addend=None):
     """dgamma/dbeta are ACCUMULATED into (flat-gradient views).  need_dx=False: parameter
     gradients only (returns None).  drop: the (p, seed) the forward fused; dy is masked on load.
-    drop2 = (p, seed): also return dropout(dx; p, seed) as a second tensor -> (dx, dx2)."""
+    drop2 = (p, seed): also return dropout(dx; p, seed) as a second tensor -> (dx, dx2).
+    dyb: gradient of a second consumer of y (added to dy on load); addend: a gradient reaching x on
+    another route (added to dx on store)."""
     dp, dseed = float(drop[0]), int(drop[1]) & 0xFFFFFFFF
     require_gpu(dy, x, gamma)
     D = x.shape[-1]
     x2 = x.reshape(-1, D)
     dy2 = dy.reshape(-1, D)
     assert x2.is_contiguous() and dy2.is_contiguous()
+    if dyb is not None or addend is not None:
+        assert need_dx
+        for t_ in (dyb, addend):
+            assert t_ is None or (t_.is_contiguous() and t_.numel() == x2.numel())
+        if dx is None:
+            dx = torch.empty_like(x2)
+        dxv = dx.view(-1, D)
+        dxm = torch.empty_like(dxv) if drop2 is not None else None
+        check(lib().mesm_layernorm_bwd3(ptr(dy2), ptr(x2), ptr(gamma), ptr(mean), ptr(rstd), ptr(dxv),
+                                        ptr(dgamma), ptr(dbeta), x2.shape[0], D, 1 if accumulate_dx else 0, dp, dseed,
+                                        ptr(_seed_offset), ptr(dxm), float(drop2[0]) if drop2 else 0.0,
+                                        (int(drop2[1]) & 0xFFFFFFFF) if drop2 else 0, ptr(dyb), ptr(addend),
+                                        stream_ptr()), "mesm_layernorm_bwd3")
+        return (dxv.view(x.shape), dxm.view(x.shape)) if drop2 is not None else dxv.view(x.shape)
     if not need_dx:
         assert drop2 is None
         check(lib().mesm_layernorm_bwd(ptr(dy2), ptr(x2), ptr(gamma), ptr(mean), ptr(rstd), None,
@@ -207,7 +230,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx=None, accumulate_d
     return dx2.view(x.shape), dxm.view(x.shape)
 
 
-def _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop, group=0, causal=False):
+def _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop, group=0, causal=False, q2=None, k2=None):
     B, Lq, Eq = q.shape
     _, Lk, Ek = k.shape
     Ev = v.shape[2]
@@ -217,6 +240,10 @@ def _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop, group=0, causal=Fals
     a = AttnArgs()
     a.q, a.k, a.v, a.o = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr()
     a.lse = lse.data_ptr() if lse is not None else None
+    if q2 is not None:  # split heads: [q || q2] per head (see MesmAttnArgs.q2)
+        assert q2.shape == q.shape and q2.stride() == q.stride() and k2.shape == k.shape and k2.stride() == k.stride()
+        a.q2, a.k2 = q2.data_ptr(), k2.data_ptr()
+        Eq *= 2
     a.B, a.H, a.Lq, a.Lk, a.dk, a.dv = B, H, Lq, Lk, Eq // H, Ev // H
     a.q_bs, a.q_ls = q.stride(0), q.stride(1)
     a.k_bs, a.k_ls = k.stride(0), k.stride(1)
@@ -241,23 +268,30 @@ def _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop, group=0, causal=Fals
     return a
 
 
-def attn_fwd(q, k, v, H, kpad=None, qpad=None, scale=None, drop=(0.0, 0), group=0, causal=False, want_lse=True):
+def attn_fwd(q, k, v, H, kpad=None, qpad=None, scale=None, drop=(0.0, 0), group=0, causal=False, want_lse=True,
+             q2=None, k2=None):
     """q (B,Lq,H*dk), k (B,Lk,H*dk), v (B,Lk,H*dv) -> o (B,Lq,H*dv), lse (B,H,Lq).
-    causal: key j of query i is masked iff j > i (frozen CLIP text transformer; forward only)."""
+    causal: key j of query i is masked iff j > i (frozen CLIP text transformer; forward only).
+    q2 / k2: split heads, the head's features are [q || q2] / [k || k2] (each half H*dk/2 columns)."""
     require_gpu(q, k, v)
     B, Lq, Eq = q.shape
+    if q2 is not None:
+        Eq *= 2
     if scale is None:
         scale = (Eq // H) ** -0.5
     o = torch.empty(B, Lq, v.shape[2], device=q.device, dtype=torch.float32)
     lse = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32) if want_lse else None
-    a = _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop, group, causal)
+    a = _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop, group, causal, q2, k2)
     check(lib().mesm_attn_fwd(ctypes.byref(a), stream_ptr()), "mesm_attn_fwd")
     return o, lse
 
 
-def attn_bwd(do, q, k, v, o, lse, H, kpad=None, qpad=None, scale=None, drop=(0.0, 0), group=0):
+def attn_bwd(do, q, k, v, o, lse, H, kpad=None, qpad=None, scale=None, drop=(0.0, 0), group=0, q2=None, k2=None):
+    """-> dq, dk, dv (and dq2, dk2 with split heads)."""
     require_gpu(do, q, k, v, o, lse)
     B, Lq, Eq = q.shape
+    if q2 is not None:
+        Eq *= 2
     if scale is None:
         scale = (Eq // H) ** -0.5
     do = do.contiguous() if do.stride() != o.stride() else do
@@ -269,9 +303,16 @@ def attn_bwd(do, q, k, v, o, lse, H, kpad=None, qpad=None, scale=None, drop=(0.0
     qc, kc, vc = q, k, v
     # gradients are written with the strides of q/k/v: require the packed layout
     assert q.is_contiguous() and k.is_contiguous() and v.is_contiguous()
-    a = _attn_args(qc, kc, vc, o, lse, H, kpad, qpad, scale, drop, group)
+    a = _attn_args(qc, kc, vc, o, lse, H, kpad, qpad, scale, drop, group, False, q2, k2)
     a.d_o, a.dq, a.dk_, a.dv_ = do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    if q2 is not None:
+        assert q2.is_contiguous() and k2.is_contiguous()
+        dq2 = torch.zeros(q2.shape, device=q.device, dtype=torch.float32)
+        dk2 = torch.empty(k2.shape, device=q.device, dtype=torch.float32)
+        a.dq2, a.dk2 = dq2.data_ptr(), dk2.data_ptr()
     check(lib().mesm_attn_bwd(ctypes.byref(a), stream_ptr()), "mesm_attn_bwd")
+    if q2 is not None:
+        return dq, dk, dv, dq2, dk2
     return dq, dk, dv
 
 

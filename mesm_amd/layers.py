@@ -135,17 +135,23 @@ class T2VLayer(nn.Module):
         self.nhead = h
         self.p = dropout
 
-    def forward(self, txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm=False, group=0):
+    def forward(self, txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm=False, group=0, vid_p=None,
+                out_pos=None):
+        """vid_p: vid + pos_vid when the producer of vid has already written it (None: formed here).
+        out_pos: also return output + out_pos (the next block's query) -> (out, out_p)."""
         sa = self.self_attn
-        x = ops.mha(vid, pos_vid, txt, pos_txt, vid, sa.in_proj_weight, sa.in_proj_bias,
+        if vid_p is None and pos_vid is not None:
+            vid_p = vid + pos_vid
+        x = ops.mha(vid, vid_p, txt, pos_txt, vid, sa.in_proj_weight, sa.in_proj_bias,
                     sa.out_proj.weight, sa.out_proj.bias, self.nhead, kpad=txt_pad, qpad=vid_pad,
                     attn_drop=drop_state.next(self.p), out_drop=drop_state.next(self.p), group=group)
         alt = self.two_mlp and is_mlm
         n1, n2 = (self.norm1_1, self.norm2_1) if alt else (self.norm1, self.norm2)
         l1, l2 = (self.linear1_1, self.linear2_1) if alt else (self.linear1, self.linear2)
-        y = ops.ffn(n1(x), x, l1.weight, l1.bias, self.activation.weight, l2.weight, l2.bias,
-                    mid_drop=drop_state.next(self.p), out_drop=drop_state.next(self.p))
-        return n2(y)
+        # x + FFN(LN1(x)) (pre-norm FFN, transformer.py:536-538): one block, the two routes of dx meet in-kernel
+        y = ops.norm_ffn(x, n1.weight, n1.bias, l1.weight, l1.bias, self.activation.weight, l2.weight, l2.bias,
+                         mid_drop=drop_state.next(self.p), out_drop=drop_state.next(self.p))
+        return ops.layer_norm(y, n2.weight, n2.bias, add=out_pos)
 
 
 def _clones(m, n):
@@ -159,10 +165,14 @@ class T2VStack(nn.Module):
         super().__init__()
         self.layers = _clones(layer, n)
 
-    def forward(self, txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm=False, group=0):
-        for l in self.layers:
-            vid = l(txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm, group)
-        return vid
+    def forward(self, txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm=False, group=0, vid_p=None,
+                out_pos=None):
+        n = len(self.layers)
+        for i, l in enumerate(self.layers):
+            op = out_pos if i == n - 1 else pos_vid
+            res = l(txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm, group, vid_p=vid_p, out_pos=op)
+            vid, vid_p = res if op is not None else (res, None)
+        return (vid, vid_p) if out_pos is not None else vid
 
 
 def _xavier_(module):
@@ -180,10 +190,12 @@ class T2VEncoder(nn.Module):
         _xavier_(self)
         self.d_model, self.nhead = d, h
 
-    def forward(self, txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm=False, group=0):
+    def forward(self, txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm=False, group=0, vid_p=None,
+                out_pos=None):
         """group: rows per independent batch when the positive and the negative pass are stacked
-        along the batch dimension (the Q1 mask rule wraps inside a group)."""
-        return self.t2v_encoder(txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm, group)
+        along the batch dimension (the Q1 mask rule wraps inside a group).  vid_p / out_pos: see T2VLayer."""
+        return self.t2v_encoder(txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm, group, vid_p=vid_p,
+                                out_pos=out_pos)
 
 
 class EncoderLayer(nn.Module):
@@ -199,9 +211,11 @@ class EncoderLayer(nn.Module):
         self.activation = PReLUParam()
         self.nhead, self.p = h, dropout
 
-    def forward(self, src, pos, pad):
+    def forward(self, src, pos, pad, src_p=None, out_pos=None):
         sa = self.self_attn
-        x = ops.mha(src, pos, None, None, src, sa.in_proj_weight, sa.in_proj_bias,
+        if src_p is None and pos is not None:
+            src_p = src + pos
+        x = ops.mha(src, src_p, None, None, src, sa.in_proj_weight, sa.in_proj_bias,
                     sa.out_proj.weight, sa.out_proj.bias, self.nhead, kpad=pad,
                     attn_drop=drop_state.next(self.p), out_drop=drop_state.next(self.p),
                     self_attn=True)
@@ -209,7 +223,7 @@ class EncoderLayer(nn.Module):
         y = ops.ffn(x, x, self.linear1.weight, self.linear1.bias, self.activation.weight,
                     self.linear2.weight, self.linear2.bias, mid_drop=drop_state.next(self.p),
                     out_drop=drop_state.next(self.p))
-        return self.norm2(y)
+        return ops.layer_norm(y, self.norm2.weight, self.norm2.bias, add=out_pos)
 
 
 class EncoderStack(nn.Module):
@@ -217,9 +231,12 @@ class EncoderStack(nn.Module):
         super().__init__()
         self.layers = _clones(layer, n)
 
-    def forward(self, src, pos, pad):
-        for l in self.layers:
-            src = l(src, pos, pad)
+    def forward(self, src, pos, pad, src_p=None):
+        n = len(self.layers)
+        for i, l in enumerate(self.layers):
+            op = pos if i < n - 1 else None  # the next layer's query = this output + pos, from the same kernel
+            res = l(src, pos, pad, src_p=src_p, out_pos=op)
+            src, src_p = res if op is not None else (res, None)
         return src
 
 
@@ -273,10 +290,9 @@ class DecoderLayer(nn.Module):
         v = cv
         if is_first:
             kc = kc + kp
-        lm = memory.shape[1]
-        q2 = torch.cat([qc.view(n, nq, h, dh), qs.view(n, nq, h, dh)], -1).view(n, nq, 2 * d)
-        k2 = torch.cat([kc.view(n, lm, h, dh), kp.view(n, lm, h, dh)], -1).view(n, lm, 2 * d)
-        a = ops.attention(q2, k2, v, h, kpad=mem_pad, drop=drop_state.next(self.p))
+        # per-head [content || position] queries and keys (transformer.py:778-784): the attention kernel reads
+        # the two halves of every head from the two tensors in place (split heads), nothing is interleaved
+        a = ops.attention(qc, kc, v, h, kpad=mem_pad, drop=drop_state.next(self.p), q2=qs, k2=kp)
         co = self.cross_attn.out_proj
         tgt = self.norm2(L(a, co.weight, co.bias, residual=tgt, out_drop=drop_state.next(self.p)))
         y = ops.ffn(tgt, tgt, self.linear1.weight, self.linear1.bias, self.activation.weight,

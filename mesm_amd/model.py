@@ -360,10 +360,13 @@ class MESM(nn.Module):
                 # negative query (the SS token is stripped again, model.py:264-266)
                 pw2 = torch.cat([pw, ops.gather_rows(pw.reshape(N, -1), ni).view(N, -1, d)], 0)
                 wpad2 = torch.cat([words_pad, words_pad[ni]], 0)
-                enhanced2 = enc(pw2, pv2, None, vpos2, wpad2, vid_pad2, group=N)
+                # every block hands its output + position embedding to the next one (second output of its last
+                # LayerNorm), so only the very first query is formed by an element-wise add
+                enhanced2, enhanced2_p = enc(pw2, pv2, None, vpos2, wpad2, vid_pad2, group=N, vid_p=pv2 + vpos2,
+                                             out_pos=vpos2)
                 enhanced = enhanced2[:N]
             else:
-                enhanced2 = pv2
+                enhanced2, enhanced2_p = pv2, pv2 + vpos2
                 enhanced = pv
 
         out = {}
@@ -394,7 +397,7 @@ class MESM(nn.Module):
         with _scope("t2v"):
             ewords2 = torch.cat([ewords, ops.gather_rows(ewords.reshape(N, -1), ni).view(N, -1, d)], 0)
             epad2 = torch.cat([epad, epad[ni]], 0)
-            encoded2 = self.t2v_encoder(ewords2, enhanced2, None, vpos2, epad2, vid_pad2, group=N)
+            encoded2 = self.t2v_encoder(ewords2, enhanced2, None, vpos2, epad2, vid_pad2, group=N, vid_p=enhanced2_p)
         with _scope("transformer"):
             hs, refs, memory2, memory_g2 = self.transformer(
                 encoded2, vid_pad2, self.query_embed.weight, vpos2, self.global_rep_token,

@@ -277,72 +277,188 @@ class LayerNormFn(Function):
         return (dx, None if dg else gg, None if db else gb, None, None, None)
 
 
-def layer_norm(x, gamma, beta, eps=1e-5, drop=NO_DROP):
-    """drop = (p, seed): the Dropout that follows the LayerNorm (LinearLayer) rides the same kernels."""
+class LayerNormPosFn(Function):
+    """(y, y + add) = LayerNorm(x): the second output is the `with_pos_embed` query of the attention block
+    that consumes y (transformer.py:512, 577, 640), written by the same kernel; the backward adds the two
+    incoming gradients while loading them."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, add, sink):
+        ctx.set_materialize_grads(False)
+        x, add = _c(x), _c(add)
+        y, mean, rstd, y2 = kn.layernorm_fwd(x, gamma, beta, eps, NO_DROP, add=add)
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.gamma, ctx.beta, ctx.sink = gamma, beta, sink
+        return y, y2
+
+    @staticmethod
+    def backward(ctx, dy, dy2):
+        x, mean, rstd = ctx.saved_tensors
+        if dy is None:
+            dy, dyb = dy2, None
+        else:
+            dyb = dy2
+        gg, dg = grad_target(ctx.gamma)
+        gb, db = grad_target(ctx.beta)
+        sink = ctx.sink if ctx.needs_input_grad[0] else None
+        dx = kn.layernorm_bwd(_c(dy), x, ctx.gamma, mean, rstd, gg, gb, need_dx=ctx.needs_input_grad[0],
+                              drop2=(sink.p, sink.seed) if sink is not None else None,
+                              dyb=_c(dyb) if (dyb is not None and ctx.needs_input_grad[0]) else None)
+        if not ctx.needs_input_grad[0] and dyb is not None:
+            # parameter gradients of the second consumer's share (no dx requested: rare, tiny tensors)
+            kn.layernorm_bwd(_c(dyb), x, ctx.gamma, mean, rstd, gg, gb, need_dx=False)
+        if sink is not None:
+            dx, sink.dz = dx
+            sink.src = dx
+        flush_ready()
+        return (dx, None if dg else gg, None if db else gb, None, dy2 if ctx.needs_input_grad[4] else None, None)
+
+
+def layer_norm(x, gamma, beta, eps=1e-5, drop=NO_DROP, add=None):
+    """drop = (p, seed): the Dropout that follows the LayerNorm (LinearLayer) rides the same kernels.
+    add: also return y + add (-> tuple)."""
+    if add is not None:
+        assert drop[0] == 0.0
+        return LayerNormPosFn.apply(x, gamma, beta, eps, add, getattr(x, "_mesm_sink", None))
     return LayerNormFn.apply(x, gamma, beta, eps, drop, getattr(x, "_mesm_sink", None))
+
+
+# ----------------------------------------------------------------------------- LN -> FFN -> + x
+class NormFFNFn(Function):
+    """y = x + dropout_out( dropout_mid(prelu(LN(x) W1^T + b1)) W2^T + b2 ): the pre-norm feed-forward block of
+    the T2V layers (transformer.py:536-538, 601-609) as ONE autograd block.  x reaches y on two routes; the
+    LayerNorm backward kernel adds the residual route's gradient (dy) while it stores dx, and also emits dx
+    under the dropout mask of the block that produced x (sink_in), so neither an element-wise add nor a mask
+    kernel is launched."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, w1, b1, slope, w2, b2, mid_drop, out_drop, sink, sink_in):
+        x = _c(x)
+        h, mean, rstd = kn.layernorm_fwd(x, gamma, beta, eps)
+        F_ = w1.shape[0]
+        z = torch.empty(x.shape[:-1] + (F_,), device=x.device, dtype=torch.float32)
+        kn.gemm(_2d(h), w1, _2d(z), trans_b=True, bias=b1)
+        a = kn.act_dropout(z, ACT_PRELU, slope, *mid_drop)
+        y = torch.empty_like(x)
+        kn.gemm(_2d(a), w2, _2d(y), trans_b=True, bias=b2, e_drop=out_drop, residual=_2d(x))
+        ctx.save_for_backward(x, mean, rstd, h, z, a)
+        ctx.params = (gamma, beta, w1, b1, slope, w2, b2)
+        ctx.mid_drop, ctx.out_drop = mid_drop, out_drop
+        ctx.sink, ctx.sink_in = sink, sink_in
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, h, z, a = ctx.saved_tensors
+        gamma, beta, w1, b1, slope, w2, b2 = ctx.params
+        dy = _c(dy)
+        dy2 = _2d(dy)
+        dz2 = _masked_dy(ctx.sink, dy2, ctx.out_drop) if ctx.out_drop[0] > 0 else dy2
+        gw2, d_w2 = grad_target(w2)
+        gb2, d_b2 = grad_target(b2)
+        gw1, d_w1 = grad_target(w1)
+        gb1, d_b1 = grad_target(b1)
+        gs, d_s = grad_target(slope)
+        gg, d_g = grad_target(gamma)
+        gbt, d_bt = grad_target(beta)
+        dz1 = torch.empty_like(z)
+        with kn.gemm_group():
+            _accum_dw(dz2, _2d(a), gw2, gb2)
+            kn.gemm(dz2, w2, _2d(dz1), e_drop=ctx.mid_drop, aux=_2d(z), e_actgrad=ACT_PRELU, slope=slope, dslope=gs)
+        dh = torch.empty_like(h)
+        with kn.gemm_group():
+            _accum_dw(_2d(dz1), _2d(h), gw1, gb1)
+            kn.gemm(_2d(dz1), w1, _2d(dh))
+        dx = None
+        if ctx.needs_input_grad[0]:
+            sink = ctx.sink_in
+            dx = kn.layernorm_bwd(dh, x, gamma, mean, rstd, gg, gbt, addend=dy,
+                                  drop2=(sink.p, sink.seed) if sink is not None else None)
+            if sink is not None:
+                dx, sink.dz = dx
+                sink.src = dx
+        else:
+            kn.layernorm_bwd(dh, x, gamma, mean, rstd, gg, gbt, need_dx=False)
+        flush_ready()
+        return (dx, None if d_g else gg, None if d_bt else gbt, None, None if d_w1 else gw1, None if d_b1 else gb1,
+                None if d_s else gs, None if d_w2 else gw2, None if d_b2 else gb2, None, None, None, None)
+
+
+def norm_ffn(x, gamma, beta, w1, b1, slope, w2, b2, eps=1e-5, mid_drop=NO_DROP, out_drop=NO_DROP):
+    sink = _sink_for(out_drop)
+    return _tag(NormFFNFn.apply(x, gamma, beta, eps, w1, b1, slope, w2, b2, mid_drop, out_drop, sink,
+                                getattr(x, "_mesm_sink", None)), sink)
 
 
 # ----------------------------------------------------------------------------- attention core
 class AttentionFn(Function):
     """softmax(scale * q k^T, masks) -> dropout -> @ v for packed heads, no projections:
-    the core of attention.py:329-386 (decoder self / cross attention, dk may differ from dv)."""
+    the core of attention.py:329-386 (decoder self / cross attention, dk may differ from dv).
+    q2 / k2 (optional): split heads, head h sees [q_h || q2_h] and [k_h || k2_h] -- the cross attention's
+    per-head [content || position] concatenation (transformer.py:778-784) read in place."""
 
     @staticmethod
-    def forward(ctx, q, k, v, H, kpad, qpad, scale, drop):
+    def forward(ctx, q, k, v, H, kpad, qpad, scale, drop, q2, k2):
         q, k, v = _c(q), _c(k), _c(v)
-        o, lse = kn.attn_fwd(q, k, v, H, kpad=kpad, qpad=qpad, scale=scale, drop=drop)
-        ctx.save_for_backward(q, k, v, o, lse)
+        if q2 is not None:
+            q2, k2 = _c(q2), _c(k2)
+        o, lse = kn.attn_fwd(q, k, v, H, kpad=kpad, qpad=qpad, scale=scale, drop=drop, q2=q2, k2=k2)
+        ctx.save_for_backward(q, k, v, o, lse, q2, k2)
         ctx.cfg = (H, kpad, qpad, scale, drop)
         return o
 
     @staticmethod
     def backward(ctx, do):
-        q, k, v, o, lse = ctx.saved_tensors
+        q, k, v, o, lse, q2, k2 = ctx.saved_tensors
         H, kpad, qpad, scale, drop = ctx.cfg
-        dq, dk, dv = kn.attn_bwd(_c(do), q, k, v, o, lse, H, kpad=kpad, qpad=qpad, scale=scale,
-                                 drop=drop)
-        return dq, dk, dv, None, None, None, None, None
+        res = kn.attn_bwd(_c(do), q, k, v, o, lse, H, kpad=kpad, qpad=qpad, scale=scale, drop=drop, q2=q2, k2=k2)
+        dq, dk, dv = res[:3]
+        dq2, dk2 = (res[3], res[4]) if q2 is not None else (None, None)
+        return dq, dk, dv, None, None, None, None, None, dq2, dk2
 
 
-def attention(q, k, v, H, kpad=None, qpad=None, scale=None, drop=NO_DROP):
+def attention(q, k, v, H, kpad=None, qpad=None, scale=None, drop=NO_DROP, q2=None, k2=None):
     if scale is None:
-        scale = (q.shape[-1] // H) ** -0.5
-    return AttentionFn.apply(q, k, v, H, kpad, qpad, scale, drop)
+        scale = ((q.shape[-1] * (2 if q2 is not None else 1)) // H) ** -0.5
+    return AttentionFn.apply(q, k, v, H, kpad, qpad, scale, drop, q2, k2)
 
 
 # ----------------------------------------------------------------------------- packed MHA
 class MHAFn(Function):
     """A whole nn.MultiheadAttention call plus its residual:
 
-        out = residual + dropout_out( out_proj( attn( (xq+pq) Wq, (xk+pk) Wk, xk Wv ) ) )
+        out = residual + dropout_out( out_proj( attn( xqp Wq, (xk+pk) Wk, xk Wv ) ) )
 
-    (transformer.py:523-534 cross-attention of the T2V layers, :642-645 encoder self
-    attention; in_proj_weight rows are q,k,v — torch/nn/functional.py multi_head_attention_forward).
-    `self_attn=True`: xq is xk (query = key input incl. pos, value = xq without pos): Q and
-    K projections run as ONE GEMM over in_proj_weight[0:2d].  Otherwise, when the key has no
-    positional term (use_txt_pos=False in every shipped config; SegSenRecon passes None),
-    K and V run as ONE GEMM over in_proj_weight[d:3d].
+    (transformer.py:523-534 cross-attention of the T2V layers, :642-645 encoder self attention; in_proj_weight
+    rows are q,k,v -- torch/nn/functional.py multi_head_attention_forward).  xqp = xq + pos is handed in
+    ready-made (the LayerNorm / assembly kernel that produced xq wrote it as a second output; None = no
+    positional term, xqp is xq) and is an autograd input of its own, so the two routes of the query gradient
+    are returned separately and summed by the consumer's kernel, not by an element-wise launch.
+    `self_attn=True`: Q and K come from xqp, V from xq: Q and K projections run as ONE GEMM over
+    in_proj_weight[0:2d].  Otherwise, when the key has no positional term (use_txt_pos=False in every shipped
+    config; SegSenRecon passes None), K and V run as ONE GEMM over in_proj_weight[d:3d].
     """
 
     @staticmethod
-    def forward(ctx, xq, pq, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad, qpad, attn_drop,
+    def forward(ctx, xq, xqp, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad, qpad, attn_drop,
                 out_drop, self_attn, group=0, sink=None):
+        ctx.set_materialize_grads(False)
         ctx.sink = sink
         xq = _c(xq)
-        pq = _c(pq) if pq is not None else None
+        has_p = xqp is not None
+        xqp = _c(xqp) if has_p else xq
         d = xq.shape[-1]
         N, Lq = xq.shape[0], xq.shape[1]
         dev = xq.device
-        # query side: x + pos is materialised ONCE (one element-wise launch) and feeds the forward GEMM and,
-        # saved, the weight-gradient GEMM as a plain operand: with the addend fused (A2 / B2) both ran on
-        # the fragment / register-staged kernels at 32-40 TF (19 + 17 us at 4800 rows against 13 + 13)
-        xqp = (xq + pq) if pq is not None else xq
         if self_attn:
             Lk = Lq
             qkv = torch.empty(N, Lq, 3 * d, device=dev, dtype=torch.float32)
             q2 = _2d(qkv)
-            kn.gemm(_2d(xqp), w_in[:2 * d], q2[:, :2 * d], trans_b=True, bias=b_in[:2 * d])
-            kn.gemm(_2d(xq), w_in[2 * d:], q2[:, 2 * d:], trans_b=True, bias=b_in[2 * d:])
+            if has_p:
+                kn.gemm(_2d(xqp), w_in[:2 * d], q2[:, :2 * d], trans_b=True, bias=b_in[:2 * d])
+                kn.gemm(_2d(xq), w_in[2 * d:], q2[:, 2 * d:], trans_b=True, bias=b_in[2 * d:])
+            else:
+                kn.gemm(_2d(xq), w_in, q2, trans_b=True, bias=b_in)
             q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
             xk = pk = None
         else:
@@ -363,19 +479,19 @@ class MHAFn(Function):
         out = torch.empty(N, Lq, d, device=dev, dtype=torch.float32)
         kn.gemm(_2d(o), w_out, _2d(out), trans_b=True, bias=b_out, e_drop=out_drop,
                 residual=_2d(_c(residual)) if residual is not None else None)
-        ctx.save_for_backward(xq, xqp if pq is not None else None, xk, pk, q, k, v, o, lse)
+        ctx.save_for_backward(xq, xqp if has_p else None, xk, pk, q, k, v, o, lse)
         ctx.params = (w_in, b_in, w_out, b_out)
         ctx.res_is_xq = residual is not None and residual.data_ptr() == xq.data_ptr() and residual.shape == xq.shape
-        ctx.cfg = (H, kpad, qpad, attn_drop, out_drop, self_attn, residual is not None, group)
+        ctx.cfg = (H, kpad, qpad, attn_drop, out_drop, self_attn, residual is not None, group, has_p)
         return out
 
     @staticmethod
     def backward(ctx, dy):
         xq, xqp, xk, pk, q, k, v, o, lse = ctx.saved_tensors
+        w_in, b_in, w_out, b_out = ctx.params
+        H, kpad, qpad, attn_drop, out_drop, self_attn, has_res, group, has_p = ctx.cfg
         if xqp is None:
             xqp = xq
-        w_in, b_in, w_out, b_out = ctx.params
-        H, kpad, qpad, attn_drop, out_drop, self_attn, has_res, group = ctx.cfg
         d = xq.shape[-1]
         N, Lq = xq.shape[0], xq.shape[1]
         dev = xq.device
@@ -390,10 +506,11 @@ class MHAFn(Function):
         with kn.gemm_group():
             _accum_dw(dz, _2d(o), gwo, gbo)
             kn.gemm(dz, w_out, _2d(do))
-        need_q, need_pq = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_q = ctx.needs_input_grad[0]
+        need_qp = has_p and ctx.needs_input_grad[1]
         need_k, need_pk = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
-        fold_res = ctx.res_is_xq and need_q and ctx.needs_input_grad[4]
-        dxq = dpq = dxk = dpk = None
+        fold = ctx.res_is_xq and need_q and ctx.needs_input_grad[4]  # the residual input IS xq: dy joins d xq
+        dxq = dxqp = dxk = dpk = None
         if self_attn:
             # dq is added atomically only when several 64-key tiles contribute
             dqkv = (torch.zeros if Lq > 64 else torch.empty)(N, Lq, 3 * d, device=dev, dtype=torch.float32)
@@ -401,20 +518,20 @@ class MHAFn(Function):
                              dqkv[..., 2 * d:], kpad=kpad, qpad=qpad, drop=attn_drop, group=group)
             g2 = _2d(dqkv)
             with kn.gemm_group():
-                _accum_dw(g2[:, :2 * d], _2d(xqp), gwi[:2 * d], gbi[:2 * d])
-                _accum_dw(g2[:, 2 * d:], _2d(xq), gwi[2 * d:], gbi[2 * d:])
-                if need_q or need_pq:
-                    dqk_in = torch.empty_like(xq)  # gradient of (xq + pq) through q and k
-                    early = fold_res and not need_pq  # residual input IS xq: dy rides this epilogue
-                    kn.gemm(g2[:, :2 * d], w_in[:2 * d], _2d(dqk_in), residual=dy2 if early else None)
-            if need_q or need_pq:
-                if need_pq:
-                    dpq = dqk_in
-                if need_q:
-                    dxq = torch.empty_like(xq)
-                    kn.gemm(g2[:, 2 * d:], w_in[2 * d:], _2d(dxq), residual=_2d(dqk_in))
-                    if fold_res and not early:
-                        dxq.add_(dy)
+                if has_p:
+                    _accum_dw(g2[:, :2 * d], _2d(xqp), gwi[:2 * d], gbi[:2 * d])
+                    _accum_dw(g2[:, 2 * d:], _2d(xq), gwi[2 * d:], gbi[2 * d:])
+                    if need_qp:
+                        dxqp = torch.empty_like(xq)
+                        kn.gemm(g2[:, :2 * d], w_in[:2 * d], _2d(dxqp))
+                    if need_q:
+                        dxq = torch.empty_like(xq)
+                        kn.gemm(g2[:, 2 * d:], w_in[2 * d:], _2d(dxq), residual=dy2 if fold else None)
+                else:
+                    _accum_dw(g2, _2d(xq), gwi, gbi)
+                    if need_q:
+                        dxq = torch.empty_like(xq)
+                        kn.gemm(g2, w_in, _2d(dxq), residual=dy2 if fold else None)
         else:
             Lk = xk.shape[1]
             dq = (torch.zeros if Lk > 64 else torch.empty)(N, Lq, d, device=dev, dtype=torch.float32)
@@ -422,7 +539,6 @@ class MHAFn(Function):
             kn.attn_bwd_into(do, q, k, v, o, lse, H, dq, dkv[..., :d], dkv[..., d:], kpad=kpad,
                              qpad=qpad, drop=attn_drop, group=group)
             g2 = _2d(dkv)
-            add_dy = False
             with kn.gemm_group():  # dWq, dWkv, dX(query side), dX(key side): all independent
                 _accum_dw(_2d(dq), _2d(xqp), gwi[:d], gbi[:d])
                 if pk is None:
@@ -430,14 +546,15 @@ class MHAFn(Function):
                 else:
                     _accum_dw(g2[:, :d], _2d(xk), gwi[d:2 * d], gbi[d:2 * d], x2=_2d(pk))
                     _accum_dw(g2[:, d:], _2d(xk), gwi[2 * d:], gbi[2 * d:])
-                if need_q or need_pq:
+                if has_p:
+                    if need_qp:
+                        dxqp = torch.empty_like(xq)
+                        kn.gemm(_2d(dq), w_in[:d], _2d(dxqp))
+                    if fold:
+                        dxq = dy  # the only route from xq itself is the residual
+                elif need_q:
                     dxq = torch.empty_like(xq)
-                    if fold_res and not need_pq:
-                        # the residual input IS xq: its gradient (dy) rides the epilogue of this GEMM
-                        kn.gemm(_2d(dq), w_in[:d], _2d(dxq), residual=dy2)
-                    else:
-                        kn.gemm(_2d(dq), w_in[:d], _2d(dxq))
-                        add_dy = fold_res
+                    kn.gemm(_2d(dq), w_in[:d], _2d(dxq), residual=dy2 if fold else None)
                 if need_k or need_pk:
                     if pk is None:
                         dxk = torch.empty_like(xk)
@@ -445,27 +562,23 @@ class MHAFn(Function):
                     else:
                         dk_in = torch.empty_like(xk)
                         kn.gemm(g2[:, :d], w_in[d:2 * d], _2d(dk_in))
-            if need_q or need_pq:
-                if add_dy:
-                    dxq = dxq + dy
-                dpq = dxq if need_pq else None
-                dxq = dxq if need_q else None
             if (need_k or need_pk) and pk is not None:
                 dpk = dk_in if need_pk else None
                 if need_k:
                     dxk = torch.empty_like(xk)
                     kn.gemm(g2[:, d:], w_in[2 * d:], _2d(dxk), residual=_2d(dk_in))
         flush_ready()
-        return (dxq, dpq, dxk, dpk, dy if has_res and ctx.needs_input_grad[4] and not fold_res else None,
+        return (dxq, dxqp, dxk, dpk, dy if has_res and ctx.needs_input_grad[4] and not fold else None,
                 None if d_wi else gwi, None if d_bi else gbi, None if d_wo else gwo,
                 None if d_bo else gbo, None, None, None, None, None, None, None, None)
 
 
-def mha(xq, pq, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad=None, qpad=None,
+def mha(xq, xqp, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad=None, qpad=None,
         attn_drop=NO_DROP, out_drop=NO_DROP, self_attn=False, group=0):
-    """group: rows per independent batch when several batches are stacked (mask quirk Q1)."""
+    """xqp: xq + its position embedding, ready-made (None: no positional term).
+    group: rows per independent batch when several batches are stacked (mask quirk Q1)."""
     sink = _sink_for(out_drop)
-    return _tag(MHAFn.apply(xq, pq, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad, qpad, attn_drop,
+    return _tag(MHAFn.apply(xq, xqp, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad, qpad, attn_drop,
                             out_drop, self_attn, group, sink), sink)
 
 

@@ -715,3 +715,46 @@ def test_gemm_fuzz_activations():
                 kn.gemm(A, B, C, trans_b=tb, aux=aux, e_actgrad=kn.ACT_RELU)
                 ref = torch.where(aux > 0, full, torch.zeros_like(full))
         assert rel_err(C, ref) < TOL, tag
+
+
+# --------------------------------------------------------------------------- round-2 fusions
+@pytest.mark.parametrize("B,H,Lq,Lk,dh,dv", [(32, 8, 10, 75, 32, 32), (3, 4, 7, 130, 8, 8), (2, 2, 20, 33, 16, 16)])
+def test_attention_split_heads_equal_the_interleaved_copy(B, H, Lq, Lk, dh, dv):
+    """q2 / k2 (MesmAttnArgs): head h sees [q_h || q2_h], [k_h || k2_h] -- the decoder's per-head
+    [content || position] concatenation (transformer.py:778-784) -- forward and all five gradients equal the
+    kernel run on the materialised (B, L, 2d) tensors."""
+    from mesm_amd import kernels as kn
+    d = H * dh
+    qc, qs = gen((B, Lq, d), 1), gen((B, Lq, d), 2)
+    kc, kp = gen((B, Lk, d), 3), gen((B, Lk, d), 4)
+    v, do = gen((B, Lk, H * dv), 5), gen((B, Lq, H * dv), 6)
+    kpad = (torch.arange(Lk, device=dev())[None, :] >= torch.tensor([Lk - (i % 3) for i in range(B)], device=dev())[:, None])
+    cat = lambda a, b, L: torch.cat([a.view(B, L, H, dh), b.view(B, L, H, dh)], -1).reshape(B, L, 2 * d)
+    q_i, k_i = cat(qc, qs, Lq), cat(kc, kp, Lk)
+    drop = (0.1, 77)
+    o_ref, lse_ref = kn.attn_fwd(q_i, k_i, v, H, kpad=kpad, drop=drop)
+    o, lse = kn.attn_fwd(qc, kc, v, H, kpad=kpad, drop=drop, q2=qs, k2=kp)
+    assert torch.equal(o, o_ref) and torch.equal(lse, lse_ref)
+    dq_i, dk_i, dv_ref = kn.attn_bwd(do, q_i, k_i, v, o_ref, lse_ref, H, kpad=kpad, drop=drop)
+    dq, dk, dvv, dq2, dk2 = kn.attn_bwd(do, qc, kc, v, o, lse, H, kpad=kpad, drop=drop, q2=qs, k2=kp)
+    assert rel_err(dvv, dv_ref) < 1e-6
+    assert rel_err(cat(dq, dq2, Lq), dq_i) < 1e-5 and rel_err(cat(dk, dk2, Lk), dk_i) < 1e-5
+
+
+@pytest.mark.parametrize("rows,D", [(4800, 256), (33, 32), (70, 300)])
+def test_layernorm_second_output_and_gradient_joins(rows, D):
+    """mesm_layernorm_fwd2 / _bwd3: y2 = y + add; dy <- dy + dyb on load; dx <- dx + addend on store; with the
+    dropout-masked copy of dx as second gradient output."""
+    from mesm_amd import kernels as kn
+    x, g, b, add = gen((rows, D), 1), gen((D,), 2), gen((D,), 3), gen((rows, D), 4)
+    y, mean, rstd, y2 = kn.layernorm_fwd(x, g, b, add=add)
+    y0, _, _ = kn.layernorm_fwd(x, g, b)
+    assert torch.equal(y, y0) and rel_err(y2, y0 + add) < 1e-6
+    dy, dyb, addend = gen((rows, D), 5), gen((rows, D), 6), gen((rows, D), 7)
+    dg_ref, db_ref = torch.zeros(D, device=dev()), torch.zeros(D, device=dev())
+    dx_ref = kn.layernorm_bwd(dy + dyb, x, g, mean, rstd, dg_ref, db_ref)
+    dg, db = torch.zeros(D, device=dev()), torch.zeros(D, device=dev())
+    dx, dxm = kn.layernorm_bwd(dy, x, g, mean, rstd, dg, db, dyb=dyb, addend=addend, drop2=(0.1, 9))
+    assert rel_err(dx, dx_ref + addend) < 1e-5
+    assert rel_err(dg, dg_ref) < 1e-4 and rel_err(db, db_ref) < 1e-4
+    assert rel_err(dxm, kn.dropout(dx, 0.1, 9)) < 1e-6

