@@ -74,6 +74,7 @@ const char* mesm_arch(void);
  * Epilogue, in this order (each step optional):
  *   t = acc * out_scale
  *   t += bias[n]
+ *   pre_out[m,n] = t                 (optional second output, see the field)
  *   t = act(t)                       e_act in {NONE, RELU, PRELU(*slope)}
  *   t = dropout(t)                   e_drop_p > 0, index m*N + n
  *   t *= act'(aux[m,n])              e_actgrad in {NONE, RELU, PRELU}; for PRELU also
@@ -120,6 +121,12 @@ typedef struct MesmGemmArgs {
      required when e_actgrad == PRELU and dslope != NULL (one plain store per workgroup, then a
      1-workgroup reduction adds the sum into *dslope) */
   float* dslope_ws;
+  /* optional second output (NULL = off): pre_out[m,n] = acc * out_scale + bias, i.e. the value BEFORE
+     e_act / e_drop, leading dimension ldpre.  The FFN's first GEMM writes z = x W1^T + b1 (kept for the
+     backward's PReLU gradient) and a = dropout(prelu(z)) (the second GEMM's operand) in one pass
+     (transformer.py:537, 603, 608, 647, 794).  Not with split_k / accumulate. */
+  float* pre_out;
+  int64_t ldpre;
 } MesmGemmArgs;
 
 int mesm_gemm_f32(const MesmGemmArgs* args, void* stream);
@@ -476,6 +483,56 @@ int mesm_text_prep(const float* x, int32_t N, int32_t Lw, int32_t D, int32_t nor
 int mesm_weighted_sum(const float* vals, const float* weights, int32_t n, float* out,
                       void* stream);
 int mesm_scale_vec(const float* g, const float* weights, int32_t n, float* out, void* stream);
+
+/* ------------------------------------------------------------------------- */
+/*
+ * Assembly kernels of MESM.forward (csrc/glue.hip): the concatenations, repeats, selections and masked
+ * replacements between the transformer blocks, one launch each, with the matching gradient joins.
+ *
+ * mesm_stack_rows      n <= 8 tensors at once: dst_t (2N rows) = [ src_t ; src_t[idx] ] (gather[t] = 1) or
+ *                      [ src_t ; src_t ] (0); row_bytes[t] bytes per row, any dtype.  The positive and the
+ *                      negative pass stacked along the batch: model.py:260-299 with neg_index from
+ *                      sample_outclass_neg (data_utils.py:113-124).  src / dst / row_bytes / gather: HOST arrays.
+ * mesm_unstack_rows    its backward for one float tensor (R floats per row, R % 4 == 0):
+ *                      dx[i] = d2[i] + sum_{j: idx[j] == i} d2[N + j]   (idx NULL: j == i)
+ * mesm_prepend_fwd     xo (B, L+1, D) = [tok ; x]; optional po = [ptok ; pos], xp = xo + po and the key padding
+ *                      mask pado = [first_pad ; pad].  tok_per_row: tok is (B, D) (the reconstructed sentence token in
+ *                      front of the words, model.py:221-224) instead of (D) (global token + its position,
+ *                      transformer.py:185-188, model.py:236-238).
+ * mesm_prepend_bwd     g = dxo + dxp: dx = g[:, 1:]; dtok = g[:, 0] (per row: stored; shared: atomically ADDED over
+ *                      b into the gradient view); dptok += (dxp + dpo)[:, 0].  NULL inputs count as zero.
+ * mesm_split_token_*   mem (B, L+1, D) -> g = mem[:, 0], loc = mem[:, 1:], dec = loc[:Bd] (transformer.py:196-198; the
+ *                      decoder sees the positive half only); backward dmem = assembled sum, missing parts zero.
+ * mesm_token_mix_*     y[r] = m2[r] ? tok2 : (m1[r] ? tok1 : x[r])  (model.py:361-394 _replace_unknown / _mask_words,
+ *                      :493-501 masked sentence slot); backward dx = dy on unmasked rows else 0, dtok1 / dtok2 += the
+ *                      column sums of dy over their rows (atomic, into the gradient views).
+ * mesm_gather_rows_*   y[j] = valid[j] ? x[idx[j]] : 0, optionally L2-normalised like F.normalize (eps 1e-12; rnorm[j]
+ *                      keeps the norm).  Backward through the host-built inverse map inv (source row -> j or -1):
+ *                      every source row is written once (zeros where not gathered): model.py:312-325, :485-486.
+ * mesm_add_wrap        out[i] = a[i] + b[i mod nb]  (n, nb element counts, % 4 == 0)
+ */
+int mesm_stack_rows(const void* const* src, void* const* dst, const int64_t* row_bytes, const int32_t* gather,
+                    int32_t n, const int64_t* idx, int32_t N, void* stream);
+int mesm_unstack_rows(const float* d2, const int64_t* idx, float* dx, int32_t N, int64_t R, void* stream);
+int mesm_prepend_fwd(const float* tok, const float* x, const float* ptok, const float* pos, const uint8_t* pad,
+                     float* xo, float* po, float* xp, uint8_t* pado, int32_t B, int32_t L, int32_t D,
+                     int32_t tok_per_row, int32_t first_pad, void* stream);
+int mesm_prepend_bwd(const float* dxo, const float* dxp, const float* dpo, float* dx, float* dtok, float* dptok,
+                     int32_t B, int32_t L, int32_t D, int32_t tok_per_row, void* stream);
+int mesm_split_token_fwd(const float* mem, float* g, float* loc, float* dec, int32_t B, int32_t L, int32_t D,
+                         int32_t Bd, void* stream);
+int mesm_split_token_bwd(const float* dg, const float* dloc, const float* ddec, float* dmem, int32_t B, int32_t L,
+                         int32_t D, int32_t Bd, void* stream);
+int mesm_token_mix_fwd(const float* x, const uint8_t* m1, const float* tok1, const uint8_t* m2, const float* tok2,
+                       float* y, int64_t rows, int32_t D, void* stream);
+int mesm_token_mix_bwd(const float* dy, const uint8_t* m1, const uint8_t* m2, float* dx, float* dtok1, float* dtok2,
+                       int64_t rows, int32_t D, void* stream);
+int mesm_gather_rows_fwd(const float* x, const int64_t* idx, const uint8_t* valid, float* y, float* rnorm,
+                         int64_t rows, int32_t D, int32_t normalize, void* stream);
+int mesm_gather_rows_bwd(const float* dy, const float* y, const float* rnorm, const int64_t* inv,
+                         const uint8_t* valid, float* dx, int64_t src_rows, int32_t D, int32_t normalize,
+                         void* stream);
+int mesm_add_wrap(const float* a, const float* b, float* out, int64_t n, int64_t nb, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /*

@@ -40,6 +40,7 @@ class GemmArgs(ctypes.Structure):
         ("out_scale", ctypes.c_float),
         ("accumulate", ctypes.c_int32), ("split_k", ctypes.c_int32),
         ("seed_offset", c_ptr), ("dslope_ws", c_ptr),
+        ("pre_out", c_ptr), ("ldpre", ctypes.c_int64),
     ]
 
 
@@ -109,6 +110,17 @@ PROTOTYPES = {
     "mesm_rowdot_fwd": (ctypes.c_int, [c_ptr, c_ptr, _i32, _i32, _i32, _f32, c_ptr, c_ptr]),
     "mesm_rowdot_bwd": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, _i32, _i32, _i32, _f32, c_ptr, c_ptr, c_ptr]),
     "mesm_text_prep": (ctypes.c_int, [c_ptr, _i32, _i32, _i32, _i32, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "mesm_stack_rows": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, _i32, c_ptr, _i32, c_ptr]),
+    "mesm_unstack_rows": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, _i32, _i64, c_ptr]),
+    "mesm_prepend_fwd": (ctypes.c_int, [c_ptr] * 9 + [_i32, _i32, _i32, _i32, _i32, c_ptr]),
+    "mesm_prepend_bwd": (ctypes.c_int, [c_ptr] * 6 + [_i32, _i32, _i32, _i32, c_ptr]),
+    "mesm_split_token_fwd": (ctypes.c_int, [c_ptr] * 4 + [_i32, _i32, _i32, _i32, c_ptr]),
+    "mesm_split_token_bwd": (ctypes.c_int, [c_ptr] * 4 + [_i32, _i32, _i32, _i32, c_ptr]),
+    "mesm_token_mix_fwd": (ctypes.c_int, [c_ptr] * 6 + [_i64, _i32, c_ptr]),
+    "mesm_token_mix_bwd": (ctypes.c_int, [c_ptr] * 6 + [_i64, _i32, c_ptr]),
+    "mesm_gather_rows_fwd": (ctypes.c_int, [c_ptr] * 5 + [_i64, _i32, _i32, c_ptr]),
+    "mesm_gather_rows_bwd": (ctypes.c_int, [c_ptr] * 6 + [_i64, _i32, _i32, c_ptr]),
+    "mesm_add_wrap": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, _i64, _i64, c_ptr]),
     "mesm_clip_embed": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, _i64, _i32, _i32, _i32, c_ptr]),
     "mesm_layernorm_f16": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, _i64, _i32, _f32, c_ptr]),
     "mesm_gemm_f16": (ctypes.c_int, [c_ptr, _i32, _i64, c_ptr, _i64, c_ptr, c_ptr, _i64, c_ptr, _i32, _i64,

@@ -619,6 +619,12 @@ __device__ __forceinline__ float staged_epilogue(const MesmGemmArgs& p, float (&
   const float sc = p.out_scale;
 #pragma unroll
   for (int i = 0; i < NV; ++i) t[i] = t[i] * sc + bias_v;
+  if (p.pre_out != nullptr) {  // second output: the pre-activation (what the backward's e_actgrad reads as aux)
+    float* pp = p.pre_out + ((int64_t)rbase * p.ldpre + col);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (ok[i]) pp[(int64_t)RO(i) * p.ldpre] = t[i];
+  }
   if (p.e_act != MESM_ACT_NONE) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) t[i] = mesm_act(t[i], p.e_act, slope);
@@ -1873,6 +1879,7 @@ int prepare(MesmGemmArgs& a, int& vec) {
   if (a.a_layout < 0 || a.a_layout > 1 || a.b_layout < 0 || a.b_layout > 1) return MESM_EINVAL;
   if (a.e_actgrad != MESM_ACT_NONE && !a.aux) return MESM_EINVAL;
   if (a.e_actgrad == MESM_ACT_PRELU && a.dslope && !a.dslope_ws) return MESM_EINVAL;
+  if (a.pre_out && (a.split_k > 1 || a.accumulate != 0 || !aligned_to(a.pre_out, 4))) return MESM_EINVAL;
   if ((a.a_act == MESM_ACT_PRELU || a.b_act == MESM_ACT_PRELU || a.e_act == MESM_ACT_PRELU ||
        a.e_actgrad == MESM_ACT_PRELU) && !a.slope)
     return MESM_EINVAL;

@@ -1,0 +1,376 @@
+// Assembly kernels of MESM.forward: the places where the reference concatenates, repeats, selects and masks
+// tensors between the transformer blocks (model/model.py:184-207, 260-299, 307-325; model/transformer.py:174-205)
+// and where autograd would otherwise add the gradients of the pieces back together.  Each of these was 2-8
+// element-wise / copy launches per site (~220 per step, 12 % of the step for no arithmetic); here every site is
+// ONE launch forward and ONE backward, and the gradient sums happen while the data moves.
+// All HBM-bound byte movers: rows are copied with 16-byte accesses, one workgroup per (row, tensor).
+#include "common.hpp"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------
+// stack_rows: dst (2N rows) = [ src ; src[idx] ]  for up to 8 tensors of any row size in one launch
+// (idx == NULL: the second half repeats the first).  The positive and the negative pass of the model run
+// stacked along the batch: rows [0, N) = the pairs, rows [N, 2N) = every pair's video with the
+// words / mask of its negative query (model.py:260-299, neg_index from sample_outclass_neg).
+constexpr int STACK_MAX = 8;
+struct StackArgs {
+  const unsigned char* src[STACK_MAX];
+  unsigned char* dst[STACK_MAX];
+  int64_t row_bytes[STACK_MAX];
+  int gather[STACK_MAX];  // second half: 1 = src[idx[j]], 0 = src[j]
+  const int64_t* idx;
+  int N, n;
+};
+
+__global__ __launch_bounds__(256) void stack_rows_kernel(const StackArgs a) {
+  const int t = blockIdx.y, r = blockIdx.x;
+  int sr = r < a.N ? r : r - a.N;
+  if (r >= a.N && a.gather[t]) sr = (int)a.idx[r - a.N];
+  const int64_t rb = a.row_bytes[t];
+  const unsigned char* s = a.src[t] + (int64_t)sr * rb;
+  unsigned char* d = a.dst[t] + (int64_t)r * rb;
+  if ((rb & 15) == 0 && ((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0) {
+    const int64_t n16 = rb >> 4;
+    for (int64_t i = threadIdx.x; i < n16; i += 256) reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+  } else {
+    for (int64_t i = threadIdx.x; i < rb; i += 256) d[i] = s[i];
+  }
+}
+
+// backward of one float tensor: dx[i, :] = d2[i, :] + sum over j with idx[j] == i of d2[N + j, :]
+// (idx == NULL: j == i).  Deterministic: every output row gathers its contributors (N <= a few hundred).
+__global__ __launch_bounds__(256) void unstack_rows_kernel(const float* __restrict__ d2, const int64_t* __restrict__ idx,
+                                                           float* __restrict__ dx, int N, int64_t R) {
+  const int i = blockIdx.x;
+  const int64_t c0 = ((int64_t)blockIdx.y * 256 + threadIdx.x) * 4;
+  if (c0 >= R) return;
+  float4 acc = *reinterpret_cast<const float4*>(d2 + (int64_t)i * R + c0);
+  if (idx == nullptr) {
+    const float4 b = *reinterpret_cast<const float4*>(d2 + (int64_t)(N + i) * R + c0);
+    acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+  } else {
+    for (int j = 0; j < N; ++j)
+      if ((int)idx[j] == i) {
+        const float4 b = *reinterpret_cast<const float4*>(d2 + (int64_t)(N + j) * R + c0);
+        acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+      }
+  }
+  *reinterpret_cast<float4*>(dx + (int64_t)i * R + c0) = acc;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// prepend_token: xo (B, L+1, D) = [ tok ; x ],  optionally po = [ ptok ; pos ] and xp = xo + po, and the key
+// padding mask [ first ; pad ].  tok / ptok are one D-vector for all rows (tok_per_row = 0: the global token
+// and its position embedding, transformer.py:185-188) or one per batch row (tok_per_row = 1: the reconstructed
+// sentence token in front of the words, model.py:221-224).
+__global__ __launch_bounds__(256) void prepend_fwd_kernel(const float* __restrict__ tok, const float* __restrict__ x,
+                                                          const float* __restrict__ ptok, const float* __restrict__ pos,
+                                                          const uint8_t* __restrict__ pad, float* __restrict__ xo,
+                                                          float* __restrict__ po, float* __restrict__ xp,
+                                                          uint8_t* __restrict__ pado, int L, int D, int tok_per_row,
+                                                          int first_pad) {
+  const int b = blockIdx.x, l = blockIdx.y;  // l in [0, L]
+  const int64_t orow = ((int64_t)b * (L + 1) + l) * D;
+  const float* xs = l == 0 ? tok + (tok_per_row ? (int64_t)b * D : 0) : x + ((int64_t)b * L + l - 1) * D;
+  const float* ps = nullptr;
+  if (po || xp) ps = l == 0 ? ptok : pos + ((int64_t)b * L + l - 1) * D;
+  for (int c = threadIdx.x * 4; c < D; c += (int)blockDim.x * 4) {
+    const float4 v = *reinterpret_cast<const float4*>(xs + c);
+    *reinterpret_cast<float4*>(xo + orow + c) = v;
+    if (ps) {
+      const float4 q = *reinterpret_cast<const float4*>(ps + c);
+      if (po) *reinterpret_cast<float4*>(po + orow + c) = q;
+      if (xp) *reinterpret_cast<float4*>(xp + orow + c) = make_float4(v.x + q.x, v.y + q.y, v.z + q.z, v.w + q.w);
+    }
+  }
+  if (pado && threadIdx.x == 0) pado[(int64_t)b * (L + 1) + l] = l == 0 ? (uint8_t)first_pad : pad[(int64_t)b * L + l - 1];
+}
+
+// backward: g = dxo (+ dxp) [+ dpo for the position outputs]
+//   dx[b, l]   = g[b, 1 + l]                               (rows of the sequence)
+//   dtok       (+)= g[b, 0]          per row: plain store;  shared: atomic add over b into the gradient view
+//   dptok      (+)= (dxp + dpo)[b, 0]
+__global__ __launch_bounds__(256) void prepend_bwd_kernel(const float* __restrict__ dxo, const float* __restrict__ dxp,
+                                                          const float* __restrict__ dpo, float* __restrict__ dx,
+                                                          float* __restrict__ dtok, float* __restrict__ dptok, int L, int D,
+                                                          int tok_per_row) {
+  const int b = blockIdx.x, l = blockIdx.y;
+  const int64_t orow = ((int64_t)b * (L + 1) + l) * D;
+  for (int c = threadIdx.x * 4; c < D; c += (int)blockDim.x * 4) {
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f), gp = g;
+    if (dxo) g = *reinterpret_cast<const float4*>(dxo + orow + c);
+    if (dxp) {
+      gp = *reinterpret_cast<const float4*>(dxp + orow + c);
+      g.x += gp.x; g.y += gp.y; g.z += gp.z; g.w += gp.w;
+    }
+    if (l > 0) {
+      if (dx) *reinterpret_cast<float4*>(dx + ((int64_t)b * L + l - 1) * D + c) = g;
+    } else {
+      if (dtok) {
+        if (tok_per_row) {
+          *reinterpret_cast<float4*>(dtok + (int64_t)b * D + c) = g;
+        } else {
+          atomicAdd(dtok + c, g.x); atomicAdd(dtok + c + 1, g.y); atomicAdd(dtok + c + 2, g.z); atomicAdd(dtok + c + 3, g.w);
+        }
+      }
+      if (dptok) {
+        if (dpo) {
+          const float4 q = *reinterpret_cast<const float4*>(dpo + orow + c);
+          gp.x += q.x; gp.y += q.y; gp.z += q.z; gp.w += q.w;
+        }
+        atomicAdd(dptok + c, gp.x); atomicAdd(dptok + c + 1, gp.y); atomicAdd(dptok + c + 2, gp.z); atomicAdd(dptok + c + 3, gp.w);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// split_token: mem (B, L+1, D) -> g (B, D) = mem[:, 0], loc (B, L, D) = mem[:, 1:], and dec (Bd, L, D) = loc[:Bd]
+// (the decoder only sees the positive half, model.py:295).  Backward: dmem[b, 0] = dg[b];
+// dmem[b, 1 + l] = dloc[b, l] + (b < Bd ? ddec[b, l] : 0); missing gradients count as zero.
+__global__ __launch_bounds__(256) void split_fwd_kernel(const float* __restrict__ mem, float* __restrict__ g,
+                                                        float* __restrict__ loc, float* __restrict__ dec, int L, int D,
+                                                        int Bd) {
+  const int b = blockIdx.x, l = blockIdx.y;
+  const float* s = mem + ((int64_t)b * (L + 1) + l) * D;
+  for (int c = threadIdx.x * 4; c < D; c += (int)blockDim.x * 4) {
+    const float4 v = *reinterpret_cast<const float4*>(s + c);
+    if (l == 0) {
+      *reinterpret_cast<float4*>(g + (int64_t)b * D + c) = v;
+    } else {
+      *reinterpret_cast<float4*>(loc + ((int64_t)b * L + l - 1) * D + c) = v;
+      if (dec && b < Bd) *reinterpret_cast<float4*>(dec + ((int64_t)b * L + l - 1) * D + c) = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void split_bwd_kernel(const float* __restrict__ dg, const float* __restrict__ dloc,
+                                                        const float* __restrict__ ddec, float* __restrict__ dmem, int L,
+                                                        int D, int Bd) {
+  const int b = blockIdx.x, l = blockIdx.y;
+  float* d = dmem + ((int64_t)b * (L + 1) + l) * D;
+  for (int c = threadIdx.x * 4; c < D; c += (int)blockDim.x * 4) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (l == 0) {
+      if (dg) v = *reinterpret_cast<const float4*>(dg + (int64_t)b * D + c);
+    } else {
+      const int64_t o = ((int64_t)b * L + l - 1) * D + c;
+      if (dloc) v = *reinterpret_cast<const float4*>(dloc + o);
+      if (ddec && b < Bd) {
+        const float4 w = *reinterpret_cast<const float4*>(ddec + o);
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+      }
+    }
+    *reinterpret_cast<float4*>(d + c) = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// token_mix: y[r, :] = m2[r] ? tok2 : (m1[r] ? tok1 : x[r, :])  -- MESM._replace_unknown + _mask_words
+// (model.py:361-394: unknown words, then the drawn MLM positions, are replaced by learned tokens) and
+// SegSenRecon's masked sentence slot (model.py:493-501).  m2 / tok2 optional.  Backward: dx = dy where neither
+// mask is set, else 0; dtok1 += sum of dy over (m1 & ~m2) rows, dtok2 += sum over m2 rows (atomics, one
+// partial per workgroup of 32 rows).
+constexpr int TM_ROWS = 32;
+__global__ __launch_bounds__(256) void token_mix_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ m1,
+                                                            const float* __restrict__ tok1, const uint8_t* __restrict__ m2,
+                                                            const float* __restrict__ tok2, float* __restrict__ y,
+                                                            int64_t rows, int D) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* s = x + r * D;
+  if (m2 && m2[r]) s = tok2;
+  else if (m1[r]) s = tok1;
+  for (int c = (threadIdx.x & 63) * 4; c < D; c += 256)
+    *reinterpret_cast<float4*>(y + r * D + c) = *reinterpret_cast<const float4*>(s + c);
+}
+
+__global__ __launch_bounds__(256) void token_mix_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ m1,
+                                                            const uint8_t* __restrict__ m2, float* __restrict__ dx,
+                                                            float* __restrict__ dtok1, float* __restrict__ dtok2,
+                                                            int64_t rows, int D) {
+  const int64_t r0 = (int64_t)blockIdx.x * TM_ROWS;
+  const int64_t r1 = (r0 + TM_ROWS) < rows ? (r0 + TM_ROWS) : rows;
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float s1 = 0.0f, s2 = 0.0f;
+    for (int64_t r = r0; r < r1; ++r) {
+      const float g = dy[r * D + c];
+      const bool b2 = m2 && m2[r], b1 = m1[r] != 0;
+      if (dx) dx[r * D + c] = (b1 || b2) ? 0.0f : g;
+      if (b2) s2 += g;
+      else if (b1) s1 += g;
+    }
+    if (dtok1 && s1 != 0.0f) atomicAdd(dtok1 + c, s1);
+    if (dtok2 && s2 != 0.0f) atomicAdd(dtok2 + c, s2);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// gather_rows: y[j, :] = valid[j] ? x[idx[j], :] : 0 (valid == NULL: all), optionally L2-normalised with
+// F.normalize's eps (norm = 1: y / max(||y||, 1e-12), the reconstructed sentence token model.py:486).
+// Gathers the ground-truth clips for the MLM branch (model.py:312-325: projed_video_feat[clip_mask] re-padded)
+// and the masked slot of every pair (model.py:485).  Backward scatters through the INVERSE map built on the
+// host (inv[i] = j with idx[j] == i, or -1): dx[i, :] = inv[i] >= 0 ? dy-through-the-normalisation : 0, every
+// source row written exactly once -- no zero fill, no atomics.  (Rows gathered more than once are not
+// supported by this kernel; those sites keep index_add.)
+__global__ __launch_bounds__(256) void gather_rows_fwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx,
+                                                              const uint8_t* __restrict__ valid, float* __restrict__ y,
+                                                              float* __restrict__ rnorm, int64_t rows, int D, int norm) {
+  const int lane = threadIdx.x & 63;
+  const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= rows) return;
+  const bool ok = valid == nullptr || valid[j] != 0;
+  const float* s = x + idx[j] * D;
+  float inv = 1.0f;
+  if (norm) {
+    float q = 0.0f;
+    if (ok)
+      for (int c = lane; c < D; c += 64) q += s[c] * s[c];
+    const float nrm = fmaxf(sqrtf(wave_sum(q)), 1e-12f);
+    inv = 1.0f / nrm;
+    if (lane == 0 && rnorm) rnorm[j] = nrm;
+  }
+  for (int c = lane; c < D; c += 64) y[j * D + c] = ok ? s[c] * inv : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                              const float* __restrict__ rnorm, const int64_t* __restrict__ inv,
+                                                              const uint8_t* __restrict__ valid, float* __restrict__ dx,
+                                                              int64_t src_rows, int D, int norm) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= src_rows) return;
+  const int64_t j = inv[i];
+  const bool ok = j >= 0 && (valid == nullptr || valid[j] != 0);
+  if (!ok) {
+    for (int c = lane; c < D; c += 64) dx[i * D + c] = 0.0f;
+    return;
+  }
+  if (!norm) {
+    for (int c = lane; c < D; c += 64) dx[i * D + c] = dy[j * D + c];
+    return;
+  }
+  // y = x / n  (n = max(||x||, eps)): dx = (dy - y <dy, y>) / n   (for ||x|| < eps the clamp is constant: dx = dy / n)
+  const float n = rnorm[j];
+  float dot = 0.0f;
+  for (int c = lane; c < D; c += 64) dot += dy[j * D + c] * y[j * D + c];
+  dot = wave_sum(dot);
+  if (n <= 1e-12f) dot = 0.0f;
+  for (int c = lane; c < D; c += 64) dx[i * D + c] = (dy[j * D + c] - y[j * D + c] * dot) / n;
+}
+
+// out[i, :] = a[i, :] + b[i % rows_b, :]  (one float4 per thread): the first query of the enhance encoder,
+// projected video + sine position embedding for both stacked passes (model.py:175-180, 281-286)
+__global__ __launch_bounds__(256) void add_wrap_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                       float* __restrict__ out, int64_t n4, int64_t nb4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 u = reinterpret_cast<const float4*>(a)[i], v = reinterpret_cast<const float4*>(b)[i % nb4];
+    reinterpret_cast<float4*>(out)[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+  }
+}
+
+}  // namespace
+
+extern "C" int mesm_stack_rows(const void* const* src, void* const* dst, const int64_t* row_bytes, const int32_t* gather,
+                               int32_t n, const int64_t* idx, int32_t N, void* stream) {
+  if (!src || !dst || !row_bytes || !gather || n <= 0 || n > STACK_MAX || N <= 0) return MESM_EINVAL;
+  StackArgs a;
+  for (int t = 0; t < n; ++t) {
+    if (!src[t] || !dst[t] || row_bytes[t] <= 0) return MESM_EINVAL;
+    if (gather[t] && !idx) return MESM_EINVAL;
+    a.src[t] = (const unsigned char*)src[t];
+    a.dst[t] = (unsigned char*)dst[t];
+    a.row_bytes[t] = row_bytes[t];
+    a.gather[t] = gather[t];
+  }
+  a.idx = idx;
+  a.N = N;
+  a.n = n;
+  hipLaunchKernelGGL(stack_rows_kernel, dim3(2 * N, n), dim3(256), 0, (hipStream_t)stream, a);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_unstack_rows(const float* d2, const int64_t* idx, float* dx, int32_t N, int64_t R, void* stream) {
+  if (!d2 || !dx || N <= 0 || R <= 0 || (R & 3)) return MESM_EINVAL;
+  if ((((uintptr_t)d2) | ((uintptr_t)dx)) & 15) return MESM_EALIGN;
+  hipLaunchKernelGGL(unstack_rows_kernel, dim3(N, (unsigned)((R / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     d2, idx, dx, N, R);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_prepend_fwd(const float* tok, const float* x, const float* ptok, const float* pos,
+                                const uint8_t* pad, float* xo, float* po, float* xp, uint8_t* pado, int32_t B,
+                                int32_t L, int32_t D, int32_t tok_per_row, int32_t first_pad, void* stream) {
+  if (!tok || !x || !xo || B <= 0 || L <= 0 || D <= 0 || (D & 3)) return MESM_EINVAL;
+  if ((po || xp) && (!ptok || !pos)) return MESM_EINVAL;
+  if (pado && !pad) return MESM_EINVAL;
+  hipLaunchKernelGGL(prepend_fwd_kernel, dim3(B, L + 1), dim3(64), 0, (hipStream_t)stream, tok, x, ptok, pos, pad, xo,
+                     po, xp, pado, L, D, tok_per_row, first_pad);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_prepend_bwd(const float* dxo, const float* dxp, const float* dpo, float* dx, float* dtok,
+                                float* dptok, int32_t B, int32_t L, int32_t D, int32_t tok_per_row, void* stream) {
+  if ((!dxo && !dxp) || B <= 0 || L <= 0 || D <= 0 || (D & 3)) return MESM_EINVAL;
+  hipLaunchKernelGGL(prepend_bwd_kernel, dim3(B, L + 1), dim3(64), 0, (hipStream_t)stream, dxo, dxp, dpo, dx, dtok,
+                     dptok, L, D, tok_per_row);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_split_token_fwd(const float* mem, float* g, float* loc, float* dec, int32_t B, int32_t L, int32_t D,
+                                    int32_t Bd, void* stream) {
+  if (!mem || !g || !loc || B <= 0 || L <= 0 || D <= 0 || (D & 3) || Bd < 0 || Bd > B) return MESM_EINVAL;
+  hipLaunchKernelGGL(split_fwd_kernel, dim3(B, L + 1), dim3(64), 0, (hipStream_t)stream, mem, g, loc, dec, L, D, Bd);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_split_token_bwd(const float* dg, const float* dloc, const float* ddec, float* dmem, int32_t B,
+                                    int32_t L, int32_t D, int32_t Bd, void* stream) {
+  if (!dmem || B <= 0 || L <= 0 || D <= 0 || (D & 3) || Bd < 0 || Bd > B) return MESM_EINVAL;
+  hipLaunchKernelGGL(split_bwd_kernel, dim3(B, L + 1), dim3(64), 0, (hipStream_t)stream, dg, dloc, ddec, dmem, L, D, Bd);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_token_mix_fwd(const float* x, const uint8_t* m1, const float* tok1, const uint8_t* m2,
+                                  const float* tok2, float* y, int64_t rows, int32_t D, void* stream) {
+  if (!x || !m1 || !tok1 || !y || rows <= 0 || D <= 0 || (D & 3)) return MESM_EINVAL;
+  if ((m2 == nullptr) != (tok2 == nullptr)) return MESM_EINVAL;
+  hipLaunchKernelGGL(token_mix_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, m1,
+                     tok1, m2, tok2, y, rows, D);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_token_mix_bwd(const float* dy, const uint8_t* m1, const uint8_t* m2, float* dx, float* dtok1,
+                                  float* dtok2, int64_t rows, int32_t D, void* stream) {
+  if (!dy || !m1 || rows <= 0 || D <= 0) return MESM_EINVAL;
+  hipLaunchKernelGGL(token_mix_bwd_kernel, dim3((unsigned)((rows + TM_ROWS - 1) / TM_ROWS)), dim3(256), 0,
+                     (hipStream_t)stream, dy, m1, m2, dx, dtok1, dtok2, rows, D);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_gather_rows_fwd(const float* x, const int64_t* idx, const uint8_t* valid, float* y, float* rnorm,
+                                    int64_t rows, int32_t D, int32_t normalize, void* stream) {
+  if (!x || !idx || !y || rows <= 0 || D <= 0 || (normalize && !rnorm)) return MESM_EINVAL;
+  hipLaunchKernelGGL(gather_rows_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, idx,
+                     valid, y, rnorm, rows, D, normalize);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_gather_rows_bwd(const float* dy, const float* y, const float* rnorm, const int64_t* inv,
+                                    const uint8_t* valid, float* dx, int64_t src_rows, int32_t D, int32_t normalize,
+                                    void* stream) {
+  if (!dy || !inv || !dx || src_rows <= 0 || D <= 0 || (normalize && (!y || !rnorm))) return MESM_EINVAL;
+  hipLaunchKernelGGL(gather_rows_bwd_kernel, dim3((unsigned)((src_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dy,
+                     y, rnorm, inv, valid, dx, src_rows, D, normalize);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_add_wrap(const float* a, const float* b, float* out, int64_t n, int64_t nb, void* stream) {
+  if (!a || !b || !out || n <= 0 || nb <= 0 || (n & 3) || (nb & 3) || (n % nb)) return MESM_EINVAL;
+  if ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)out)) & 15) return MESM_EALIGN;
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(add_wrap_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, out, n / 4, nb / 4);
+  return mesm_launch_status();
+}

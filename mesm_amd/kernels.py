@@ -46,7 +46,7 @@ def _mat(t):
 def gemm(A, B, C, *, trans_a=False, trans_b=False, A2=None, B2=None, bias=None, residual=None,
          aux=None, slope=None, dslope=None, colsum=None, a_act=ACT_NONE, b_act=ACT_NONE,
          a_drop=(0.0, 0), b_drop=(0.0, 0), e_act=ACT_NONE, e_actgrad=ACT_NONE,
-         e_drop=(0.0, 0), out_scale=1.0, accumulate=0, split_k=1):
+         e_drop=(0.0, 0), out_scale=1.0, accumulate=0, split_k=1, pre_out=None):
     """C[M,N] (+)= epi( op(A) @ op(B) ).
 
     A is (M,K) (or (K,M) with trans_a), B is (K,N) (or (N,K) with trans_b); both are
@@ -108,11 +108,14 @@ def gemm(A, B, C, *, trans_a=False, trans_b=False, A2=None, B2=None, bias=None, 
     g.e_drop_p, g.e_drop_seed = float(e_drop[0]), int(e_drop[1]) & 0xFFFFFFFF
     g.out_scale = float(out_scale)
     g.accumulate, g.split_k = int(accumulate), int(split_k)
+    if pre_out is not None:
+        assert pre_out.shape == (M, N) and pre_out.stride(1) == 1
+        g.pre_out, g.ldpre = pre_out.data_ptr(), pre_out.stride(0)
     g.seed_offset = _seed_off_ptr()
     if _pending is not None:
         # inside gemm_group(): queued; the tensors stay referenced until the group is launched
         _pending.append((g, (A, B, C, A2, B2, bias, residual, aux, slope, dslope, colsum,
-                             ws if dslope is not None else None)))
+                             ws if dslope is not None else None, pre_out)))
         return C
     check(lib().mesm_gemm_f32(ctypes.byref(g), stream_ptr()), "mesm_gemm_f32")
     return C
@@ -577,6 +580,124 @@ def scale_vec(g, weights):
     out = torch.empty_like(weights)
     check(lib().mesm_scale_vec(ptr(g), ptr(weights), weights.numel(), ptr(out), stream_ptr()),
           "mesm_scale_vec")
+    return out
+
+
+# ----------------------------------------------------------------------------- assembly kernels (csrc/glue.hip)
+def _u8(t):
+    return t if t.dtype == torch.uint8 else t.view(torch.uint8)
+
+
+def stack_rows(tensors, gather, idx):
+    """[t ; t[idx]] (gather flag 1) or [t ; t] (0) along dim 0 for up to 8 tensors of N rows, one launch."""
+    require_gpu(*tensors)
+    n, N = len(tensors), tensors[0].shape[0]
+    srcs = [t.contiguous() for t in tensors]
+    outs = [torch.empty((2 * N,) + tuple(t.shape[1:]), device=t.device, dtype=t.dtype) for t in srcs]
+    rb = [t[0].numel() * t.element_size() for t in srcs]
+    arr_s = (ctypes.c_void_p * n)(*[t.data_ptr() for t in srcs])
+    arr_d = (ctypes.c_void_p * n)(*[t.data_ptr() for t in outs])
+    arr_b = (ctypes.c_int64 * n)(*rb)
+    arr_g = (ctypes.c_int32 * n)(*[int(g) for g in gather])
+    assert all(t.shape[0] == N for t in srcs) and (idx is None or (idx.dtype == torch.int64 and idx.numel() == N))
+    check(lib().mesm_stack_rows(arr_s, arr_d, arr_b, arr_g, n, ptr(idx), N, stream_ptr()), "mesm_stack_rows")
+    return outs
+
+
+def unstack_rows(d2, idx, N):
+    require_gpu(d2)
+    d2 = d2.contiguous()
+    R = d2[0].numel()
+    dx = torch.empty((N,) + tuple(d2.shape[1:]), device=d2.device, dtype=torch.float32)
+    check(lib().mesm_unstack_rows(ptr(d2), ptr(idx), ptr(dx), N, R, stream_ptr()), "mesm_unstack_rows")
+    return dx
+
+
+def prepend_fwd(tok, x, ptok=None, pos=None, pad=None, first_pad=True):
+    """-> xo (B, L+1, D) [, po, xp] [, pado]; tok (D,) shared or (B, D) per row."""
+    require_gpu(tok, x)
+    B, L, D = x.shape
+    assert x.is_contiguous() and tok.is_contiguous() and tok.numel() in (D, B * D)
+    per_row = 1 if (tok.numel() == B * D and tok.dim() == 2) else 0
+    xo = torch.empty(B, L + 1, D, device=x.device, dtype=torch.float32)
+    po = xp = pado = None
+    if ptok is not None:
+        assert pos.is_contiguous() and pos.shape == x.shape and ptok.numel() == D
+        po, xp = torch.empty_like(xo), torch.empty_like(xo)
+    if pad is not None:
+        assert pad.is_contiguous() and pad.shape == (B, L)
+        pado = torch.empty(B, L + 1, device=x.device, dtype=pad.dtype)
+    check(lib().mesm_prepend_fwd(ptr(tok), ptr(x), ptr(ptok), ptr(pos), ptr(pad), ptr(xo), ptr(po), ptr(xp),
+                                 ptr(pado), B, L, D, per_row, 1 if first_pad else 0, stream_ptr()), "mesm_prepend_fwd")
+    return xo, po, xp, pado
+
+
+def prepend_bwd(dxo, dxp, dpo, dx, dtok, dptok, B, L, D, per_row):
+    check(lib().mesm_prepend_bwd(ptr(dxo), ptr(dxp), ptr(dpo), ptr(dx), ptr(dtok), ptr(dptok), B, L, D,
+                                 1 if per_row else 0, stream_ptr()), "mesm_prepend_bwd")
+
+
+def split_token_fwd(mem, Bd):
+    require_gpu(mem)
+    B, S, D = mem.shape
+    assert mem.is_contiguous()
+    g = torch.empty(B, D, device=mem.device, dtype=torch.float32)
+    loc = torch.empty(B, S - 1, D, device=mem.device, dtype=torch.float32)
+    dec = torch.empty(Bd, S - 1, D, device=mem.device, dtype=torch.float32) if Bd else None
+    check(lib().mesm_split_token_fwd(ptr(mem), ptr(g), ptr(loc), ptr(dec), B, S - 1, D, Bd, stream_ptr()),
+          "mesm_split_token_fwd")
+    return g, loc, dec
+
+
+def split_token_bwd(dg, dloc, ddec, B, L, D, Bd, device):
+    dmem = torch.empty(B, L + 1, D, device=device, dtype=torch.float32)
+    check(lib().mesm_split_token_bwd(ptr(dg), ptr(dloc), ptr(ddec), ptr(dmem), B, L, D, Bd, stream_ptr()),
+          "mesm_split_token_bwd")
+    return dmem
+
+
+def token_mix_fwd(x, m1, tok1, m2=None, tok2=None):
+    require_gpu(x, m1, tok1)
+    D = x.shape[-1]
+    assert x.is_contiguous() and m1.is_contiguous() and m1.numel() * D == x.numel()
+    y = torch.empty_like(x)
+    check(lib().mesm_token_mix_fwd(ptr(x), ptr(m1), ptr(tok1), ptr(m2), ptr(tok2), ptr(y), m1.numel(), D, stream_ptr()),
+          "mesm_token_mix_fwd")
+    return y
+
+
+def token_mix_bwd(dy, m1, m2, dx, dtok1, dtok2):
+    D = dy.shape[-1]
+    check(lib().mesm_token_mix_bwd(ptr(dy), ptr(m1), ptr(m2), ptr(dx), ptr(dtok1), ptr(dtok2), m1.numel(), D,
+                                   stream_ptr()), "mesm_token_mix_bwd")
+
+
+def gather_rows_fwd(x2d, idx, valid=None, normalize=False):
+    """y[j] = valid[j] ? x2d[idx[j]] : 0 (optionally L2-normalised) -> y (*idx.shape, D), rnorm or None."""
+    require_gpu(x2d, idx)
+    assert x2d.dim() == 2 and x2d.is_contiguous() and idx.dtype == torch.int64 and idx.is_contiguous()
+    D = x2d.shape[1]
+    y = torch.empty(*idx.shape, D, device=x2d.device, dtype=torch.float32)
+    rn = torch.empty(idx.numel(), device=x2d.device, dtype=torch.float32) if normalize else None
+    check(lib().mesm_gather_rows_fwd(ptr(x2d), ptr(idx), ptr(valid), ptr(y), ptr(rn), idx.numel(), D,
+                                     1 if normalize else 0, stream_ptr()), "mesm_gather_rows_fwd")
+    return y, rn
+
+
+def gather_rows_bwd(dy, y, rnorm, inv, valid, src_rows, normalize):
+    D = dy.shape[-1]
+    dx = torch.empty(src_rows, D, device=dy.device, dtype=torch.float32)
+    check(lib().mesm_gather_rows_bwd(ptr(dy), ptr(y), ptr(rnorm), ptr(inv), ptr(valid), ptr(dx), src_rows, D,
+                                     1 if normalize else 0, stream_ptr()), "mesm_gather_rows_bwd")
+    return dx
+
+
+def add_wrap(a, b):
+    """a + b with b repeated along dim 0 (a.numel() a multiple of b.numel())."""
+    require_gpu(a, b)
+    assert a.is_contiguous() and b.is_contiguous()
+    out = torch.empty_like(a)
+    check(lib().mesm_add_wrap(ptr(a), ptr(b), ptr(out), a.numel(), b.numel(), stream_ptr()), "mesm_add_wrap")
     return out
 
 

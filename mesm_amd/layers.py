@@ -369,17 +369,15 @@ class Transformer(nn.Module):
         n_dec rows of the batch go through the decoder (the negative pass stacked behind them
         stops after the encoder: its decoder output is discarded at model.py:295)."""
         n = src.shape[0]
-        d = self.d_model
-        x = torch.cat([g_tok.view(1, 1, d).expand(n, 1, d), src], 1)
-        p = torch.cat([g_pos.view(1, 1, d).expand(n, 1, d), pos], 1)
-        pad = torch.cat([torch.ones(n, 1, dtype=torch.bool, device=src.device), vid_pad], 1)
-        mem = self.encoder(x, p, pad.contiguous())
-        mem_g, mem_l = mem[:, 0], mem[:, 1:]
+        # [global token ; video], its position embeddings, their sum (the first layer's query) and the key
+        # padding mask [True ; vid_pad] from one launch (transformer.py:185-188, model.py:236-238)
+        x, p, xp, pad = ops.prepend(g_tok, src, ptok=g_pos, pos=pos, pad=vid_pad, first_pad=True)
+        mem = self.encoder(x, p, pad, src_p=xp)
+        nd = n if n_dec is None else n_dec
         if not run_decoder:
+            mem_g, mem_l = ops.split_token(mem)
             return None, None, mem_l, mem_g
-        if n_dec is None or n_dec == n:
-            hs, refs = self.decoder(mem_l.contiguous(), vid_pad, pos, query_embed)
-        else:
-            hs, refs = self.decoder(mem_l[:n_dec].contiguous(), vid_pad[:n_dec].contiguous(),
-                                    pos[:n_dec].contiguous(), query_embed)
+        # memory_global, memory_local and the decoder's (positive-half) copy of memory_local, one launch
+        mem_g, mem_l, mem_d = ops.split_token(mem, nd)
+        hs, refs = self.decoder(mem_d, vid_pad[:nd].contiguous(), pos[:nd].contiguous(), query_embed)
         return hs, refs, mem_l, mem_g

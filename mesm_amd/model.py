@@ -57,6 +57,18 @@ class SegSenRecon(nn.Module):
                                               LinearLayer(d, d, input_dropout, False))
 
 
+class _AddPos(torch.autograd.Function):
+    """x + pos (pos carries no gradient): d x = d out."""
+
+    @staticmethod
+    def forward(ctx, x, pos):
+        return kn.add_wrap(x.contiguous(), pos.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
 class Plan:
     """Host-side decisions of one forward call, as device index tensors."""
     pass
@@ -253,6 +265,11 @@ class MESM(nn.Module):
             pl.sent_loc[torch.arange(N), slot] = True
             pl.sent_slot = slot.to(device)
             pl.rows = torch.arange(N, device=device)
+            # the masked slot of every pair in the (N * M)-row output of the reconstructor, and its inverse map
+            ridx = torch.arange(N) * M + slot
+            rinv = torch.full((N * M,), -1, dtype=torch.int64)
+            rinv[ridx] = torch.arange(N)
+            pl.recon_idx, pl.recon_inv = ridx.to(device), rinv.to(device)
             if dataset_name == "qvhighlights":
                 flat_valid = vm.reshape(-1).nonzero().squeeze(1)  # rows of (N*Lv) that are valid
                 counts = vm.sum(1)
@@ -303,7 +320,12 @@ class MESM(nn.Module):
                 li = int(lens[i])
                 src[i, :li] = flat[offs[i]:offs[i + 1]]
                 cmask[i, :li] = True
+            # inverse of the GT-clip gather: source row (pair, clip) -> its slot in (N, Lc), -1 = not gathered
+            # (the padding slots point at row 0 but are invalid: they must not claim it)
+            cinv = torch.full((N * Lv,), -1, dtype=torch.int64)
+            cinv[src[cmask]] = torch.arange(N * Lc).view(N, Lc)[cmask]
             pl.clip_src = src.to(device)
+            pl.clip_inv = cinv.to(device)
             pl.clip_mask = cmask.to(device)
             pl.clip_pad = (~cmask).to(device)
             if masked_words is None:
@@ -352,21 +374,20 @@ class MESM(nn.Module):
         # positive half only: the reference discards the negative decoder output (model.py:295).
         enc = self.enhance_encoder
         ni = plan.neg_index
-        two = lambda t_: torch.cat([t_, t_], 0)
-        pv2, vpos2, vid_pad2 = two(pv), two(vpos), two(vid_pad)
         with _scope("enhance"):
+            # one launch builds every stacked tensor of the stage: [x ; x] for the video side, [x ; x[neg_index]]
+            # for the words (neg_words_feat = expanded_words_feat[neg_index][:, 1:] = projected words of the
+            # negative query; the SS token is stripped again, model.py:264-266)
+            pv2, vpos2, vid_pad2, pw2, wpad2 = ops.stack_rows([pv, vpos, vid_pad, pw, words_pad], [0, 0, 0, 1, 1], ni)
+            pvp2 = kn.add_wrap(pv2, vpos2) if not pv2.requires_grad else _AddPos.apply(pv2, vpos2)
             if self.rec_fw:
-                # neg_words_feat = expanded_words_feat[neg_index][:, 1:] = projected words of the
-                # negative query (the SS token is stripped again, model.py:264-266)
-                pw2 = torch.cat([pw, ops.gather_rows(pw.reshape(N, -1), ni).view(N, -1, d)], 0)
-                wpad2 = torch.cat([words_pad, words_pad[ni]], 0)
                 # every block hands its output + position embedding to the next one (second output of its last
-                # LayerNorm), so only the very first query is formed by an element-wise add
-                enhanced2, enhanced2_p = enc(pw2, pv2, None, vpos2, wpad2, vid_pad2, group=N, vid_p=pv2 + vpos2,
+                # LayerNorm), so only this very first query is formed by an element-wise launch
+                enhanced2, enhanced2_p = enc(pw2, pv2, None, vpos2, wpad2, vid_pad2, group=N, vid_p=pvp2,
                                              out_pos=vpos2)
                 enhanced = enhanced2[:N]
             else:
-                enhanced2, enhanced2_p = pv2, pv2 + vpos2
+                enhanced2, enhanced2_p = pv2, pvp2
                 enhanced = pv
 
         out = {}
@@ -379,24 +400,26 @@ class MESM(nn.Module):
                     bvid, bvid_pad = video_feat, plan.vid_pad  # 27 MB gather + mask multiply skipped
                 else:
                     bvid, bvid_pad = video_feat, vid_pad
-                bsent = sent[plan.sent_src] * plan.sent_mask.unsqueeze(-1)
+                # the group's sentences per pair (zeros in the padding slots), model.py:199 split_expand_and_pad
+                bsent = kn.gather_rows_fwd(sent, plan.sent_src, plan.sent_mask)[0]
                 bvid = self._proj(self.input_vid_proj, bvid)
                 bsent = self._proj(self.input_txt_proj, bsent)
-                tok = self.ss_reconstructor.masked_sent_token.view(1, 1, d)
-                q_tok = torch.where(plan.sent_loc.unsqueeze(-1), tok, bsent)
+                # the pair's own sentence slot is replaced by the learned token (model.py:493-501)
+                q_tok = ops.token_mix(bsent, plan.sent_loc, self.ss_reconstructor.masked_sent_token)
                 rec = self.ss_reconstructor.recon_trans(bvid, q_tok, None, None, bvid_pad, plan.sent_pad)
-                recon = F.normalize(ops.gather_rows(rec.reshape(-1, d), plan.rows * rec.shape[1] + plan.sent_slot))  # the masked slot of every pair
+                # the masked slot of every pair, L2-normalised (model.py:485-486): one kernel
+                recon = ops.gather_rows2(rec.reshape(-1, d), plan.recon_idx, plan.recon_inv, normalize=True)
                 # projed_recon_feat feeds no loss (criterion.py:246-255) but is part of the returned dict
                 projed_recon = self._proj(self.ss_reconstructor.output_sent_proj, recon)
-                ewords = torch.cat([recon.unsqueeze(1), pw], dim=1)
-                emask = torch.cat([torch.ones(N, 1, dtype=torch.bool, device=dev), words_mask], dim=1)
+                # [recon ; words] and its padding mask (model.py:221-224), one launch
+                ewords, epad = ops.prepend(recon, pw, pad=words_pad, first_pad=False)
+                emask = ~epad
             else:
                 ewords, emask = pw, words_mask
-            epad = (~emask).contiguous()
+                epad = words_pad
 
         with _scope("t2v"):
-            ewords2 = torch.cat([ewords, ops.gather_rows(ewords.reshape(N, -1), ni).view(N, -1, d)], 0)
-            epad2 = torch.cat([epad, epad[ni]], 0)
+            ewords2, epad2 = ops.stack_rows([ewords, epad], [1, 1], ni)
             encoded2 = self.t2v_encoder(ewords2, enhanced2, None, vpos2, epad2, vid_pad2, group=N, vid_p=enhanced2_p)
         with _scope("transformer"):
             hs, refs, memory2, memory_g2 = self.transformer(
@@ -427,10 +450,12 @@ class MESM(nn.Module):
                 with _scope("mlm"):
                     unk = self._proj(self.input_txt_proj, self.unknown_token.view(1, 1, -1))
                     msk = self._proj(self.input_txt_proj, self.masked_token.view(1, 1, -1))
-                    w = torch.where(kwargs["unknown_mask"].unsqueeze(-1), unk, pw_)
-                    w = torch.where(plan.masked_words.unsqueeze(-1), msk, w)
-                    cfeat = ops.gather_rows(pv_.reshape(N * Lv, d), plan.clip_src) * plan.clip_mask.unsqueeze(-1)
-                    cpos = vpos.reshape(N * Lv, d)[plan.clip_src] * plan.clip_mask.unsqueeze(-1)
+                    # unknown words, then the drawn positions, become learned tokens (model.py:361-394): one launch
+                    w = ops.token_mix(pw_, kwargs["unknown_mask"], unk, plan.masked_words, msk)
+                    # the ground-truth clips of every pair re-padded to Lc, and their position embeddings
+                    # (model.py:312-325)
+                    cfeat = ops.gather_rows2(pv_.reshape(N * Lv, d), plan.clip_src, plan.clip_inv, plan.clip_mask)
+                    cpos = kn.gather_rows_fwd(vpos.reshape(N * Lv, d), plan.clip_src, plan.clip_mask)[0]
                     rec_w = enc(cfeat, w, cpos, None, plan.clip_pad, words_pad, is_mlm=True)
                     hid = self.output_txt_proj[0](rec_w)
                     head = self.output_txt_proj[1]

@@ -200,8 +200,10 @@ class FFNFn(Function):
         x = _c(x)
         F_ = w1.shape[0]
         z = torch.empty(x.shape[:-1] + (F_,), device=x.device, dtype=torch.float32)
-        kn.gemm(_2d(x), w1, _2d(z), trans_b=True, bias=b1)
-        h = kn.act_dropout(z, ACT_PRELU, slope, *mid_drop)
+        h = torch.empty_like(z)
+        # one pass writes z (pre-activation, kept for the PReLU gradient) and h = dropout(prelu(z))
+        kn.gemm(_2d(x), w1, _2d(h), trans_b=True, bias=b1, e_act=ACT_PRELU, slope=slope, e_drop=mid_drop,
+                pre_out=_2d(z))
         y = torch.empty_like(x)
         kn.gemm(_2d(h), w2, _2d(y), trans_b=True, bias=b2, e_drop=out_drop,
                 residual=_2d(_c(residual)) if residual is not None else None)
@@ -337,8 +339,10 @@ class NormFFNFn(Function):
         h, mean, rstd = kn.layernorm_fwd(x, gamma, beta, eps)
         F_ = w1.shape[0]
         z = torch.empty(x.shape[:-1] + (F_,), device=x.device, dtype=torch.float32)
-        kn.gemm(_2d(h), w1, _2d(z), trans_b=True, bias=b1)
-        a = kn.act_dropout(z, ACT_PRELU, slope, *mid_drop)
+        a = torch.empty_like(z)
+        # one pass writes z (pre-activation, kept for the PReLU gradient) and a = dropout(prelu(z))
+        kn.gemm(_2d(h), w1, _2d(a), trans_b=True, bias=b1, e_act=ACT_PRELU, slope=slope, e_drop=mid_drop,
+                pre_out=_2d(z))
         y = torch.empty_like(x)
         kn.gemm(_2d(a), w2, _2d(y), trans_b=True, bias=b2, e_drop=out_drop, residual=_2d(x))
         ctx.save_for_backward(x, mean, rstd, h, z, a)
@@ -699,6 +703,184 @@ class GatherRowsFn(Function):
 
 def gather_rows(x2d, idx):
     return GatherRowsFn.apply(x2d, idx)
+
+
+# ----------------------------------------------------------------------------- assembly blocks (csrc/glue.hip)
+class StackRowsFn(Function):
+    """outs[t] = [x_t ; x_t[idx]] or [x_t ; x_t]: the negative pass stacked behind the positive one
+    (model.py:260-299), every tensor of the stage in one launch; backward = one gather-sum per float tensor."""
+
+    @staticmethod
+    def forward(ctx, idx, gather, *xs):
+        ctx.set_materialize_grads(False)
+        outs = kn.stack_rows(list(xs), gather, idx)
+        ctx.idx, ctx.gather, ctx.N = idx, gather, xs[0].shape[0]
+        for o, x in zip(outs, xs):
+            if not x.is_floating_point():
+                ctx.mark_non_differentiable(o)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        res = []
+        for i, g in enumerate(gs):
+            if g is None or not ctx.needs_input_grad[2 + i]:
+                res.append(None)
+            else:
+                res.append(kn.unstack_rows(_c(g), ctx.idx if ctx.gather[i] else None, ctx.N))
+        return (None, None) + tuple(res)
+
+
+def stack_rows(xs, gather, idx):
+    return StackRowsFn.apply(idx, tuple(gather), *xs)
+
+
+class PrependFn(Function):
+    """xo = [tok ; x] along the sequence (+ po = [ptok ; pos], xp = xo + po, pado = [first ; pad]).  Gradients of
+    parameter tokens (global token / its position embedding) are added by the kernel into the flat gradient
+    buffer; a per-row token (reconstructed sentence) gets its gradient as a tensor."""
+
+    @staticmethod
+    def forward(ctx, tok, x, ptok, pos, pad, first_pad):
+        ctx.set_materialize_grads(False)
+        x = _c(x)
+        tokc = _c(tok)
+        xo, po, xp, pado = kn.prepend_fwd(tokc, x, _c(ptok) if ptok is not None else None,
+                                          _c(pos) if pos is not None else None, pad, first_pad)
+        ctx.per_row = tokc.dim() == 2 and tokc.shape[0] == x.shape[0] and tokc.numel() == x.shape[0] * x.shape[2]
+        ctx.tok, ctx.ptok, ctx.shape = tok, ptok, x.shape
+        outs = [xo]
+        if po is not None:
+            outs += [po, xp]
+        if pado is not None:
+            ctx.mark_non_differentiable(pado)
+            outs.append(pado)
+        ctx.n_out = len(outs)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        B, L, D = ctx.shape
+        dxo = gs[0]
+        dpo = dxp = None
+        if ctx.ptok is not None:
+            dpo, dxp = gs[1], gs[2]
+        dxo = _c(dxo) if dxo is not None else None
+        dxp = _c(dxp) if dxp is not None else None
+        dpo = _c(dpo) if dpo is not None else None
+        dev = (dxo if dxo is not None else dxp).device
+        dx = torch.empty(B, L, D, device=dev, dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        dtok_ret = dptok_ret = None
+        if ctx.per_row:
+            dtok = torch.empty(B, D, device=dev, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+            dtok_ret = dtok
+        else:
+            dtok, direct = grad_target(ctx.tok) if ctx.needs_input_grad[0] else (None, True)
+            dtok_ret = None if direct else dtok
+        dptok = None
+        if ctx.ptok is not None and ctx.needs_input_grad[2]:
+            dptok, direct = grad_target(ctx.ptok)
+            dptok_ret = None if direct else dptok
+        kn.prepend_bwd(dxo, dxp, dpo, dx, dtok, dptok, B, L, D, ctx.per_row)
+        flush_ready()
+        return dtok_ret, dx, dptok_ret, None, None, None
+
+
+def prepend(tok, x, ptok=None, pos=None, pad=None, first_pad=True):
+    """-> xo [, po, xp] [, pado]"""
+    return PrependFn.apply(tok, x, ptok, pos, pad, first_pad)
+
+
+class SplitTokenFn(Function):
+    """(mem[:, 0], mem[:, 1:], mem[:Bd, 1:]) as contiguous tensors, one launch; the backward assembles d mem from
+    whichever of the three gradients exist (transformer.py:196-198)."""
+
+    @staticmethod
+    def forward(ctx, mem, Bd):
+        ctx.set_materialize_grads(False)
+        mem = _c(mem)
+        g, loc, dec = kn.split_token_fwd(mem, Bd)
+        ctx.shape, ctx.Bd = mem.shape, Bd
+        return (g, loc, dec) if Bd else (g, loc)
+
+    @staticmethod
+    def backward(ctx, dg, dloc, ddec=None):
+        B, S, D = ctx.shape
+        t = next(x for x in (dg, dloc, ddec) if x is not None)
+        dmem = kn.split_token_bwd(_c(dg) if dg is not None else None, _c(dloc) if dloc is not None else None,
+                                  _c(ddec) if ddec is not None else None, B, S - 1, D, ctx.Bd, t.device)
+        return dmem, None
+
+
+def split_token(mem, Bd=0):
+    return SplitTokenFn.apply(mem, Bd)
+
+
+class TokenMixFn(Function):
+    """y[r] = m2[r] ? tok2 : (m1[r] ? tok1 : x[r])  (model.py:361-394, 493-501)."""
+
+    @staticmethod
+    def forward(ctx, x, m1, tok1, m2, tok2):
+        ctx.set_materialize_grads(False)
+        x = _c(x)
+        m1 = _c(m1)
+        m2 = _c(m2) if m2 is not None else None
+        y = kn.token_mix_fwd(x, m1, _c(tok1).reshape(-1), m2, _c(tok2).reshape(-1) if tok2 is not None else None)
+        ctx.m1, ctx.m2, ctx.tok1, ctx.tok2 = m1, m2, tok1, tok2
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        D = dy.shape[-1]
+        dx = torch.empty_like(dy) if ctx.needs_input_grad[0] else None
+        rets = []
+        bufs = []
+        for slot, tok in ((2, ctx.tok1), (4, ctx.tok2)):
+            if tok is None or not ctx.needs_input_grad[slot]:
+                bufs.append(None)
+                rets.append(None)
+                continue
+            if getattr(tok, "_mesm_gb", None) is not None:  # a parameter: straight into the flat gradient buffer
+                g, direct = grad_target(tok)
+                bufs.append(g)
+                rets.append(None if direct else g)
+            else:
+                g = torch.zeros(D, device=dy.device, dtype=torch.float32)
+                bufs.append(g)
+                rets.append(g.view(tok.shape))
+        kn.token_mix_bwd(dy, ctx.m1, ctx.m2, dx, bufs[0], bufs[1])
+        flush_ready()
+        return dx, None, rets[0], None, rets[1]
+
+
+def token_mix(x, m1, tok1, m2=None, tok2=None):
+    return TokenMixFn.apply(x, m1, tok1, m2, tok2)
+
+
+class GatherRows2Fn(Function):
+    """y[j] = valid[j] ? x2d[idx[j]] : 0, optionally L2-normalised; backward through the inverse map `inv`
+    (source row -> gathered position or -1) built on the host: no zero fill, no atomics."""
+
+    @staticmethod
+    def forward(ctx, x2d, idx, inv, valid, normalize):
+        x2d = _c(x2d)
+        y, rn = kn.gather_rows_fwd(x2d, idx, valid, normalize)
+        ctx.save_for_backward(y if normalize else None, rn)
+        ctx.idx_shape, ctx.inv, ctx.valid, ctx.rows, ctx.normalize = idx.shape, inv, valid, x2d.shape[0], normalize
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, rn = ctx.saved_tensors
+        dx = kn.gather_rows_bwd(_c(dy), y, rn, ctx.inv, ctx.valid, ctx.rows, ctx.normalize)
+        return dx, None, None, None, None
+
+
+def gather_rows2(x2d, idx, inv, valid=None, normalize=False):
+    if not (torch.is_grad_enabled() and x2d.requires_grad):
+        return kn.gather_rows_fwd(_c(x2d), idx, valid, normalize)[0]
+    return GatherRows2Fn.apply(x2d, idx, inv, valid, normalize)
 
 
 # ----------------------------------------------------------------------------- decoder reference points
