@@ -266,6 +266,10 @@ typedef struct MesmAttnArgs {
   const float* k2;
   float* dq2;
   float* dk2;
+  /* with split heads: added to the FIRST half of every key head while it is staged (same layout / strides as k):
+     decoder layer 0's key content = ca_kcontent_proj(memory) + ca_kpos_proj(pos) (transformer.py:773-776).  The
+     backward's dk_ is then the gradient of that sum, i.e. of both terms. */
+  const float* k_add;
 } MesmAttnArgs;
 
 int mesm_attn_fwd(const MesmAttnArgs* args, void* stream);

@@ -58,7 +58,7 @@ class AttnArgs(ctypes.Structure):
         ("drop_seed", ctypes.c_uint32),
         ("d_o", c_ptr), ("dq", c_ptr), ("dk_", c_ptr), ("dv_", c_ptr),
         ("seed_offset", c_ptr), ("mask_group", ctypes.c_int32),
-        ("q2", c_ptr), ("k2", c_ptr), ("dq2", c_ptr), ("dk2", c_ptr),
+        ("q2", c_ptr), ("k2", c_ptr), ("dq2", c_ptr), ("dk2", c_ptr), ("k_add", c_ptr),
     ]
 
 

@@ -65,6 +65,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const MesmAttnArgs
   const float* kb = p.k + (int64_t)b * p.k_bs + (int64_t)h * (split ? DKH : DK);
   const float* qb2 = split ? p.q2 + (int64_t)b * p.q_bs + (int64_t)h * DKH - DKH : qb;  // indexed with c >= DKH
   const float* kb2 = split ? p.k2 + (int64_t)b * p.k_bs + (int64_t)h * DKH - DKH : kb;
+  const float* kadd = (split && p.k_add) ? p.k_add + (int64_t)b * p.k_bs + (int64_t)h * DKH : nullptr;
   const float* vb = p.v + (int64_t)b * p.v_bs + (int64_t)h * DV;
 
   // stage the query chunk and reset the row state
@@ -88,7 +89,13 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const MesmAttnArgs
     for (int idx = tid; idx < KT * (DK / 4); idx += AT_THREADS) {
       int r = idx / (DK / 4), c = (idx % (DK / 4)) * 4;
       float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k0 + r < p.Lk) x = *reinterpret_cast<const float4*>((c >= DKH ? kb2 : kb) + (int64_t)(k0 + r) * p.k_ls + c);
+      if (k0 + r < p.Lk) {
+        x = *reinterpret_cast<const float4*>((c >= DKH ? kb2 : kb) + (int64_t)(k0 + r) * p.k_ls + c);
+        if (kadd && c < DKH) {  // content half = kcontent + kpos (decoder layer 0, transformer.py:773-776)
+          const float4 y = *reinterpret_cast<const float4*>(kadd + (int64_t)(k0 + r) * p.k_ls + c);
+          x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+        }
+      }
       *reinterpret_cast<float4*>(Ks + r * SK + c) = x;
     }
     for (int idx = tid; idx < KT * (DV / 4); idx += AT_THREADS) {
@@ -226,6 +233,7 @@ __global__ __launch_bounds__(64 * BW_WAVES) void attn_bwd_kernel(const MesmAttnA
   const float* kb = p.k + (int64_t)b * p.k_bs + hq;
   const float* qb2 = split ? p.q2 + (int64_t)b * p.q_bs + hq - DKH : qb;
   const float* kb2 = split ? p.k2 + (int64_t)b * p.k_bs + hq - DKH : kb;
+  const float* kadd = (split && p.k_add) ? p.k_add + (int64_t)b * p.k_bs + hq : nullptr;
   const float* vb = p.v + (int64_t)b * p.v_bs + (int64_t)h * DV;
   const float* ob = p.o + (int64_t)b * p.o_bs + (int64_t)h * DV;
   const float* dob = p.d_o + (int64_t)b * p.o_bs + (int64_t)h * DV;
@@ -238,7 +246,13 @@ __global__ __launch_bounds__(64 * BW_WAVES) void attn_bwd_kernel(const MesmAttnA
   for (int idx = tid; idx < KT * (DK / 4); idx += BW_THREADS) {
     int r = idx / (DK / 4), c = (idx % (DK / 4)) * 4;
     float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (k0 + r < p.Lk) x = *reinterpret_cast<const float4*>((c >= DKH ? kb2 : kb) + (int64_t)(k0 + r) * p.k_ls + c);
+    if (k0 + r < p.Lk) {
+      x = *reinterpret_cast<const float4*>((c >= DKH ? kb2 : kb) + (int64_t)(k0 + r) * p.k_ls + c);
+      if (kadd && c < DKH) {
+        const float4 y = *reinterpret_cast<const float4*>(kadd + (int64_t)(k0 + r) * p.k_ls + c);
+        x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+      }
+    }
     *reinterpret_cast<float4*>(Ks + r * SK + c) = x;
   }
   for (int idx = tid; idx < KT * (DV / 4); idx += BW_THREADS) {
@@ -421,6 +435,7 @@ int check_common(const MesmAttnArgs& a) {
     if (((uintptr_t)ptr % 16) != 0) return MESM_EALIGN;
   if (a.dk % 4 != 0 || a.dv % 4 != 0) return MESM_EINVAL;
   if ((a.q2 == nullptr) != (a.k2 == nullptr)) return MESM_EINVAL;
+  if (a.k_add && (!a.k2 || ((uintptr_t)a.k_add % 16) != 0)) return MESM_EINVAL;
   if (a.q2 && (a.dk % 8 != 0 || ((uintptr_t)a.q2 % 16) != 0 || ((uintptr_t)a.k2 % 16) != 0)) return MESM_EALIGN;
   return MESM_OK;
 }

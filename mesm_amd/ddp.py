@@ -89,7 +89,7 @@ class GradReducer:
         gb = self.gb
         target = max(1, gb.numel // self.n_buckets)
         self.buckets, lo, ids = [], 0, []
-        for p, off in zip(gb.params, gb.offsets):
+        for off, p in sorted(zip(gb.offsets, gb.params), key=lambda t: t[0]):  # (packs permute the layout)
             ids.append(id(p))
             end = off + (p.numel() + 3) // 4 * 4
             if end - lo >= target:

@@ -17,16 +17,66 @@ Parameters that no kernel touches keep ``.grad = None`` exactly like under autog
 import torch
 
 
+class Pack:
+    """Several parameters laid out back to back in the flat buffers, seen as ONE matrix / vector: e.g. the
+    decoder's sa_qcontent / sa_kcontent / sa_v weights as a (3d, d) matrix, so that the three projections of the
+    same input are one GEMM forward, one dX GEMM and one dW GEMM backward (and autograd has no gradient fan-in to
+    add up).  `weight()` / `grad()` are views of the flat parameter / gradient buffers; a Pack quacks like a
+    parameter for ops.grad_target (it acquires every member)."""
+
+    def __init__(self, gb, members, shape):
+        self.gb, self.members, self.shape = gb, members, shape
+        self.offset = gb.offsets[next(i for i, q in enumerate(gb.params) if q is members[0])]
+        self.numel = sum(m.numel() for m in members)
+        self._w = None
+
+    @property
+    def flat(self):
+        return self.gb.flat
+
+    def weight(self, flat_params):
+        """view of the flat PARAMETER buffer (model.flat_params()); carries the hooks grad_target looks for"""
+        if self._w is None or self._w.data_ptr() != flat_params.data_ptr() + 4 * self.offset:
+            w = flat_params[self.offset:self.offset + self.numel].view(self.shape)
+            w._mesm_gb = self
+            self._w = w
+        return self._w
+
+    def acquire(self, _w):
+        for m in self.members:
+            self.gb.acquire(m)
+        return self.gb.flat[self.offset:self.offset + self.numel].view(self.shape)
+
+
 class GradBuffer:
-    def __init__(self, named_params):
+    def __init__(self, named_params, packs=None):
+        """packs: {key: [parameter names]} -- members are placed back to back (in the given order) in the
+        flat layout; every member's numel must be a multiple of 4.  The ORDER OF `params` (optimizer state
+        indices, checkpoints) is unaffected: only `offsets` are permuted."""
         self.names = [n for n, _ in named_params]
         self.params = [p for _, p in named_params]
-        self.offsets = []
+        by_name = dict(named_params)
+        first_of, member_of = {}, set()
+        for key, names in (packs or {}).items():
+            assert all(by_name[n].numel() % 4 == 0 for n in names), key
+            first_of[names[0]] = names
+            member_of.update(names)
+        off_of = {}
         off = 0
-        for p in self.params:
-            self.offsets.append(off)
-            off += (p.numel() + 3) // 4 * 4  # keep every view 16-byte aligned
+        for n, p in named_params:
+            if n in off_of:
+                continue
+            for m in first_of.get(n, [n] if n not in member_of else []):
+                off_of[m] = off
+                off += (by_name[m].numel() + 3) // 4 * 4  # keep every view 16-byte aligned
+        assert len(off_of) == len(self.params), "a pack's first member must come first in named_parameters order"
+        self.offsets = [off_of[n] for n in self.names]
         self.numel = off
+        self.packs = {}
+        for key, names in (packs or {}).items():
+            ms = [by_name[n] for n in names]
+            rows = sum(m.shape[0] for m in ms)
+            self.packs[key] = Pack(self, ms, (rows,) + tuple(ms[0].shape[1:]))
         self.flat = None
         self.pending = False
         self.on_ready = None  # optional callback(param) used by ddp.GradReducer

@@ -233,7 +233,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx=None, accumulate_d
     return dx2.view(x.shape), dxm.view(x.shape)
 
 
-def _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop, group=0, causal=False, q2=None, k2=None):
+def _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop, group=0, causal=False, q2=None, k2=None, k_add=None):
     B, Lq, Eq = q.shape
     _, Lk, Ek = k.shape
     Ev = v.shape[2]
@@ -246,6 +246,9 @@ def _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop, group=0, causal=Fals
     if q2 is not None:  # split heads: [q || q2] per head (see MesmAttnArgs.q2)
         assert q2.shape == q.shape and q2.stride() == q.stride() and k2.shape == k.shape and k2.stride() == k.stride()
         a.q2, a.k2 = q2.data_ptr(), k2.data_ptr()
+        if k_add is not None:
+            assert k_add.shape == k.shape and k_add.stride() == k.stride()
+            a.k_add = k_add.data_ptr()
         Eq *= 2
     a.B, a.H, a.Lq, a.Lk, a.dk, a.dv = B, H, Lq, Lk, Eq // H, Ev // H
     a.q_bs, a.q_ls = q.stride(0), q.stride(1)
@@ -272,7 +275,7 @@ def _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop, group=0, causal=Fals
 
 
 def attn_fwd(q, k, v, H, kpad=None, qpad=None, scale=None, drop=(0.0, 0), group=0, causal=False, want_lse=True,
-             q2=None, k2=None):
+             q2=None, k2=None, k_add=None):
     """q (B,Lq,H*dk), k (B,Lk,H*dk), v (B,Lk,H*dv) -> o (B,Lq,H*dv), lse (B,H,Lq).
     causal: key j of query i is masked iff j > i (frozen CLIP text transformer; forward only).
     q2 / k2: split heads, the head's features are [q || q2] / [k || k2] (each half H*dk/2 columns)."""
@@ -284,7 +287,7 @@ def attn_fwd(q, k, v, H, kpad=None, qpad=None, scale=None, drop=(0.0, 0), group=
         scale = (Eq // H) ** -0.5
     o = torch.empty(B, Lq, v.shape[2], device=q.device, dtype=torch.float32)
     lse = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32) if want_lse else None
-    a = _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop, group, causal, q2, k2)
+    a = _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop, group, causal, q2, k2, k_add)
     check(lib().mesm_attn_fwd(ctypes.byref(a), stream_ptr()), "mesm_attn_fwd")
     return o, lse
 
@@ -320,17 +323,20 @@ def attn_bwd(do, q, k, v, o, lse, H, kpad=None, qpad=None, scale=None, drop=(0.0
 
 
 def attn_bwd_into(do, q, k, v, o, lse, H, dq, dk, dv, kpad=None, qpad=None, scale=None,
-                  drop=(0.0, 0), group=0):
+                  drop=(0.0, 0), group=0, q2=None, k2=None, dq2=None, dk2=None, k_add=None):
     """attn_bwd writing into caller-provided gradient tensors whose strides equal those of
     q / k / v (e.g. column slices of one fused [dq|dk|dv] buffer).  dq must be zero-initialised
     when Lk > 64 (several key tiles add into it atomically)."""
     require_gpu(do, q, k, v, o, lse, dq, dk, dv)
     if scale is None:
-        scale = (q.shape[-1] // H) ** -0.5
+        scale = ((q.shape[-1] * (2 if q2 is not None else 1)) // H) ** -0.5
     assert do.stride() == o.stride()
     assert dq.stride() == q.stride() and dk.stride() == k.stride() and dv.stride() == v.stride()
-    a = _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop, group)
+    a = _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop, group, False, q2, k2, k_add)
     a.d_o, a.dq, a.dk_, a.dv_ = do.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    if q2 is not None:
+        assert dq2.stride() == q.stride() and dk2.stride() == k.stride()
+        a.dq2, a.dk2 = dq2.data_ptr(), dk2.data_ptr()
     check(lib().mesm_attn_bwd(ctypes.byref(a), stream_ptr()), "mesm_attn_bwd")
 
 

@@ -262,37 +262,28 @@ class DecoderLayer(nn.Module):
         self.activation = PReLUParam()
         self.nhead, self.p = h, dropout
 
-    def forward(self, tgt, memory, mem_pad, pos, query_pos, qsine, is_first):
+    # projections that share their input, fused by layout (mesm_amd/gradbuf.py Pack)
+    PACKS = {"sa_t": ("sa_qcontent_proj", "sa_kcontent_proj", "sa_v_proj"),
+             "sa_p": ("sa_qpos_proj", "sa_kpos_proj"),
+             "ca_kv": ("ca_kcontent_proj", "ca_v_proj")}
+
+    def forward(self, tgt, memory, mem_pad, pos, query_pos, qsine, is_first, pack):
+        """pack(key) -> (weight, bias) views of a parameter pack of THIS layer (MESM.pack)."""
         L = ops.linear
-        n, nq, d = tgt.shape
         h = self.nhead
-        dh = d // h
-        # every projection whose input exists at layer entry is issued in ONE grouped launch: the
-        # five self-attention projections, the three memory-side cross-attention projections and the
-        # query-position ones (13 launches of ~5 us otherwise); their sums follow the group
-        with kn.gemm_group():
-            q_c = L(tgt, self.sa_qcontent_proj.weight, self.sa_qcontent_proj.bias)
-            k_c = L(tgt, self.sa_kcontent_proj.weight, self.sa_kcontent_proj.bias)
-            v = L(tgt, self.sa_v_proj.weight, self.sa_v_proj.bias)
-            kc = L(memory, self.ca_kcontent_proj.weight, self.ca_kcontent_proj.bias)
-            cv = L(memory, self.ca_v_proj.weight, self.ca_v_proj.bias)
-            kp = L(pos, self.ca_kpos_proj.weight, self.ca_kpos_proj.bias)
-            qs = L(qsine, self.ca_qpos_sine_proj.weight, self.ca_qpos_sine_proj.bias)
-            qpp = L(query_pos, self.ca_qpos_proj.weight, self.ca_qpos_proj.bias) if is_first else None
-        with kn.gemm_group():  # content + positional sums ride the residual epilogue of the second group
-            q = L(query_pos, self.sa_qpos_proj.weight, self.sa_qpos_proj.bias, residual=q_c)
-            k = L(query_pos, self.sa_kpos_proj.weight, self.sa_kpos_proj.bias, residual=k_c)
-        a = ops.attention(q, k, v, h, drop=drop_state.next(self.p))
+        wt, bt = pack("sa_t")
+        wp, bp = pack("sa_p")
+        a = ops.dec_self_attn(tgt, query_pos, wt, bt, wp, bp, h, drop=drop_state.next(self.p))
         so = self.self_attn.out_proj
         tgt = self.norm1(L(a, so.weight, so.bias, residual=tgt, out_drop=drop_state.next(self.p)))
 
-        qc = L(tgt, self.ca_qcontent_proj.weight, self.ca_qcontent_proj.bias, residual=qpp if is_first else None)
-        v = cv
-        if is_first:
-            kc = kc + kp
-        # per-head [content || position] queries and keys (transformer.py:778-784): the attention kernel reads
-        # the two halves of every head from the two tensors in place (split heads), nothing is interleaved
-        a = ops.attention(qc, kc, v, h, kpad=mem_pad, drop=drop_state.next(self.p), q2=qs, k2=kp)
+        with kn.gemm_group():
+            qs = L(qsine, self.ca_qpos_sine_proj.weight, self.ca_qpos_sine_proj.bias)
+            qpp = L(query_pos, self.ca_qpos_proj.weight, self.ca_qpos_proj.bias) if is_first else None
+        wkv, bkv = pack("ca_kv")
+        a = ops.dec_cross_attn(tgt, qs, qpp, memory, pos, mem_pad, self.ca_qcontent_proj.weight,
+                               self.ca_qcontent_proj.bias, wkv, bkv, self.ca_kpos_proj.weight,
+                               self.ca_kpos_proj.bias, is_first, h, drop=drop_state.next(self.p))
         co = self.cross_attn.out_proj
         tgt = self.norm2(L(a, co.weight, co.bias, residual=tgt, out_drop=drop_state.next(self.p)))
         y = ops.ffn(tgt, tgt, self.linear1.weight, self.linear1.bias, self.activation.weight,
@@ -323,7 +314,7 @@ class Decoder(nn.Module):
         for i in range(1, n):
             self.layers[i].ca_qpos_proj = None
 
-    def forward(self, memory, mem_pad, pos, refpoints_unsigmoid):
+    def forward(self, memory, mem_pad, pos, refpoints_unsigmoid, pack):
         n = memory.shape[0]
         nq = refpoints_unsigmoid.shape[0]
         d = self.d_model
@@ -340,7 +331,8 @@ class Decoder(nn.Module):
             query_pos, anchor = res[0], res[1]
             # qsine * query_scale(out) * (sigmoid(ref_anchor_head(out)) / ref_width): one kernel
             qsine = ops.qsine_scale(qsine, res[2] if li > 0 else None, anchor, ref)
-            out = layer(out, memory, mem_pad, pos, query_pos, qsine, li == 0)
+            out = layer(out, memory, mem_pad, pos, query_pos, qsine, li == 0,
+                        lambda key, li=li: pack("dec%d.%s" % (li, key)))
             # sigmoid(bbox_embed(out) + inverse_sigmoid(ref)): one kernel
             new_ref = ops.ref_update(self.bbox_embed(out), ref)
             if li != self.num_layers - 1:
@@ -363,7 +355,7 @@ class Transformer(nn.Module):
         self.dim_feedforward, self.dropout = ff, dropout
         self.num_queries = num_queries
 
-    def forward(self, src, vid_pad, query_embed, pos, g_tok, g_pos, run_decoder=True, n_dec=None):
+    def forward(self, src, vid_pad, query_embed, pos, g_tok, g_pos, run_decoder=True, n_dec=None, pack=None):
         """src (N, L, d); vid_pad (N, L) True = padding.  The global token is prepended as a
         MASKED key (transformer.py:185-186): it pools, nobody attends to it.  n_dec: only the first
         n_dec rows of the batch go through the decoder (the negative pass stacked behind them
@@ -379,5 +371,5 @@ class Transformer(nn.Module):
             return None, None, mem_l, mem_g
         # memory_global, memory_local and the decoder's (positive-half) copy of memory_local, one launch
         mem_g, mem_l, mem_d = ops.split_token(mem, nd)
-        hs, refs = self.decoder(mem_d, vid_pad[:nd].contiguous(), pos[:nd].contiguous(), query_embed)
+        hs, refs = self.decoder(mem_d, vid_pad[:nd].contiguous(), pos[:nd].contiguous(), query_embed, pack)
         return hs, refs, mem_l, mem_g

@@ -140,8 +140,19 @@ class MESM(nn.Module):
     # ------------------------------------------------------------------ infrastructure
     def gradbuf(self):
         if self._gradbuf is None:
-            self._gradbuf = GradBuffer([(n, p) for n, p in self.named_parameters() if p.requires_grad])
+            packs = {}
+            for i, layer in enumerate(self.transformer.decoder.layers):
+                pre = "transformer.decoder.layers.%d." % i
+                for key, mods in layer.PACKS.items():  # projections of one input, fused by layout (gradbuf.Pack)
+                    for kind in ("weight", "bias"):
+                        packs["dec%d.%s.%s" % (i, key, kind)] = [pre + m + "." + kind for m in mods]
+            self._gradbuf = GradBuffer([(n, p) for n, p in self.named_parameters() if p.requires_grad], packs)
         return self._gradbuf
+
+    def pack(self, key):
+        """(weight, bias) views of a parameter pack in the flat parameter buffer (see gradbuf.Pack)."""
+        gb, fp = self.gradbuf(), self.flat_params()
+        return gb.packs[key + ".weight"].weight(fp), gb.packs[key + ".bias"].weight(fp)
 
     def flat_params(self):
         """Move every trainable parameter into ONE flat fp32 buffer with the layout of the flat gradient
@@ -424,7 +435,7 @@ class MESM(nn.Module):
         with _scope("transformer"):
             hs, refs, memory2, memory_g2 = self.transformer(
                 encoded2, vid_pad2, self.query_embed.weight, vpos2, self.global_rep_token,
-                self.global_rep_pos, n_dec=N)
+                self.global_rep_pos, n_dec=N, pack=self.pack)
         with _scope("heads"):
             # independent projections share one grouped launch: class head, first span-head layer,
             # and the two saliency projections (model.py:301-302, both passes in one go)

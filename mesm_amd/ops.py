@@ -427,6 +427,144 @@ def attention(q, k, v, H, kpad=None, qpad=None, scale=None, drop=NO_DROP, q2=Non
     return AttentionFn.apply(q, k, v, H, kpad, qpad, scale, drop, q2, k2)
 
 
+# ----------------------------------------------------------------------------- decoder attention blocks
+class DecSelfAttnFn(Function):
+    """Decoder self-attention up to the attention output (transformer.py:737-750):
+
+        q = sa_qcontent(tgt) + sa_qpos(query_pos);  k = sa_kcontent(tgt) + sa_kpos(query_pos);  v = sa_v(tgt)
+        a = softmax(q k^T / sqrt(dh)) v
+
+    wt / bt = the (3d, d) pack [sa_qcontent ; sa_kcontent ; sa_v], wp / bp = the (2d, d) pack [sa_qpos ; sa_kpos]
+    (gradbuf.Pack: the members sit back to back in the flat buffers).  Forward: ONE GEMM of tgt over wt, one of
+    query_pos over wp accumulated into its first 2d columns.  Backward: the attention gradients land in one
+    (rows, 3d) buffer; d tgt is ONE GEMM with K = 3d, d query_pos one with K = 2d, two weight-gradient GEMMs --
+    a single grouped launch, and no gradient fan-in left for autograd to add."""
+
+    @staticmethod
+    def forward(ctx, tgt, qpos, wt, bt, wp, bp, H, drop):
+        tgt, qpos = _c(tgt), _c(qpos)
+        n, nq, d = tgt.shape
+        qkv = torch.empty(n, nq, 3 * d, device=tgt.device, dtype=torch.float32)
+        q2 = _2d(qkv)
+        kn.gemm(_2d(tgt), wt, q2, trans_b=True, bias=bt)
+        kn.gemm(_2d(qpos), wp, q2[:, :2 * d], trans_b=True, bias=bp, accumulate=1)
+        q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+        o, lse = kn.attn_fwd(q, k, v, H, drop=drop)
+        ctx.save_for_backward(tgt, qpos, qkv, o, lse)
+        ctx.params = (wt, bt, wp, bp)
+        ctx.cfg = (H, drop)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        tgt, qpos, qkv, o, lse = ctx.saved_tensors
+        wt, bt, wp, bp = ctx.params
+        H, drop = ctx.cfg
+        n, nq, d = tgt.shape
+        q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
+        dqkv = (torch.zeros if nq > 64 else torch.empty)(n, nq, 3 * d, device=tgt.device, dtype=torch.float32)
+        kn.attn_bwd_into(_c(do), q, k, v, o, lse, H, dqkv[..., :d], dqkv[..., d:2 * d], dqkv[..., 2 * d:], drop=drop)
+        g2 = _2d(dqkv)
+        gwt, _ = grad_target(wt)
+        gbt, _ = grad_target(bt)
+        gwp, _ = grad_target(wp)
+        gbp, _ = grad_target(bp)
+        dtgt = dqp = None
+        with kn.gemm_group():
+            _accum_dw(g2, _2d(tgt), gwt, gbt)
+            _accum_dw(g2[:, :2 * d], _2d(qpos), gwp, gbp)
+            if ctx.needs_input_grad[0]:
+                dtgt = torch.empty_like(tgt)
+                kn.gemm(g2, wt, _2d(dtgt))
+            if ctx.needs_input_grad[1]:
+                dqp = torch.empty_like(qpos)
+                kn.gemm(g2[:, :2 * d], wp, _2d(dqp))
+        flush_ready()
+        return dtgt, dqp, None, None, None, None, None, None
+
+
+def dec_self_attn(tgt, qpos, wt, bt, wp, bp, H, drop=NO_DROP):
+    return DecSelfAttnFn.apply(tgt, qpos, wt, bt, wp, bp, H, drop)
+
+
+class DecCrossAttnFn(Function):
+    """Decoder cross-attention up to the attention output (transformer.py:757-789), conditional-DETR heads:
+
+        q_h = [ ca_qcontent(tgt) (+ ca_qpos(query_pos) on layer 0) ]_h || [ ca_qpos_sine(qsine) ]_h
+        k_h = [ ca_kcontent(memory) (+ ca_kpos(pos) on layer 0) ]_h   || [ ca_kpos(pos) ]_h
+        a   = softmax(q k^T / sqrt(2 dh), key padding) ca_v(memory)
+
+    wkv / bkv = the (2d, d) pack [ca_kcontent ; ca_v].  The memory-side projections land in one (rows, 3d) buffer
+    [kcontent | v | kpos] that the attention kernel reads as split heads (k, k2, + k_add on layer 0) in place;
+    backward: d memory is ONE GEMM with K = 2d, every weight gradient a split-K GEMM of the same grouped launch;
+    layer 0's kpos weights collect both routes by accumulation."""
+
+    @staticmethod
+    def forward(ctx, tgt, qs, qpp, memory, pos, mem_pad, wqc, bqc, wkv, bkv, wkp, bkp, first, H, drop):
+        ctx.set_materialize_grads(False)
+        tgt, qs, memory, pos = _c(tgt), _c(qs), _c(memory), _c(pos)
+        n, nq, d = tgt.shape
+        lm = memory.shape[1]
+        kvp = torch.empty(n, lm, 3 * d, device=tgt.device, dtype=torch.float32)
+        k3 = _2d(kvp)
+        qc = torch.empty_like(tgt)
+        with kn.gemm_group():
+            kn.gemm(_2d(memory), wkv, k3[:, :2 * d], trans_b=True, bias=bkv)
+            kn.gemm(_2d(pos), wkp, k3[:, 2 * d:], trans_b=True, bias=bkp)
+            kn.gemm(_2d(tgt), wqc, _2d(qc), trans_b=True, bias=bqc,
+                    residual=_2d(_c(qpp)) if (first and qpp is not None) else None)
+        kc, cv, kp = kvp[..., :d], kvp[..., d:2 * d], kvp[..., 2 * d:]
+        o, lse = kn.attn_fwd(qc, kc, cv, H, kpad=mem_pad, drop=drop, q2=qs, k2=kp, k_add=kp if first else None)
+        ctx.save_for_backward(tgt, qs, memory, pos, qc, kvp, o, lse)
+        ctx.params = (wqc, bqc, wkv, bkv, wkp, bkp)
+        ctx.cfg = (first, H, drop, mem_pad, qpp is not None)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        tgt, qs, memory, pos, qc, kvp, o, lse = ctx.saved_tensors
+        wqc, bqc, wkv, bkv, wkp, bkp = ctx.params
+        first, H, drop, mem_pad, has_qpp = ctx.cfg
+        n, nq, d = tgt.shape
+        lm = memory.shape[1]
+        dev = tgt.device
+        kc, cv, kp = kvp[..., :d], kvp[..., d:2 * d], kvp[..., 2 * d:]
+        # several 64-key tiles add into dq atomically: both query halves start from zero (one fill)
+        dq2x = (torch.zeros if lm > 64 else torch.empty)(2, n, nq, d, device=dev, dtype=torch.float32)
+        dqc, dqs = dq2x[0], dq2x[1]
+        dkvp = torch.empty(n, lm, 3 * d, device=dev, dtype=torch.float32)
+        kn.attn_bwd_into(_c(do), qc, kc, cv, o, lse, H, dqc, dkvp[..., :d], dkvp[..., d:2 * d], kpad=mem_pad,
+                         drop=drop, q2=qs, k2=kp, dq2=dqs, dk2=dkvp[..., 2 * d:], k_add=kp if first else None)
+        g3 = _2d(dkvp)
+        gwqc, _ = grad_target(wqc)
+        gbqc, _ = grad_target(bqc)
+        gwkv, _ = grad_target(wkv)
+        gbkv, _ = grad_target(bkv)
+        gwkp, _ = grad_target(wkp)
+        gbkp, _ = grad_target(bkp)
+        dtgt = dmem = None
+        with kn.gemm_group():
+            _accum_dw(_2d(dqc), _2d(tgt), gwqc, gbqc)
+            _accum_dw(g3[:, :2 * d], _2d(memory), gwkv, gbkv)
+            _accum_dw(g3[:, 2 * d:], _2d(pos), gwkp, gbkp)
+            if first:  # kpos also fed the content half of the keys
+                _accum_dw(g3[:, :d], _2d(pos), gwkp, gbkp)
+            if ctx.needs_input_grad[0]:
+                dtgt = torch.empty_like(tgt)
+                kn.gemm(_2d(dqc), wqc, _2d(dtgt))
+            if ctx.needs_input_grad[3]:
+                dmem = torch.empty_like(memory)
+                kn.gemm(g3[:, :2 * d], wkv, _2d(dmem))
+        flush_ready()
+        return (dtgt, dqs if ctx.needs_input_grad[1] else None,
+                dqc if (first and has_qpp and ctx.needs_input_grad[2]) else None, dmem,
+                None, None, None, None, None, None, None, None, None, None, None)
+
+
+def dec_cross_attn(tgt, qs, qpp, memory, pos, mem_pad, wqc, bqc, wkv, bkv, wkp, bkp, first, H, drop=NO_DROP):
+    return DecCrossAttnFn.apply(tgt, qs, qpp, memory, pos, mem_pad, wqc, bqc, wkv, bkv, wkp, bkp, first, H, drop)
+
+
 # ----------------------------------------------------------------------------- packed MHA
 class MHAFn(Function):
     """A whole nn.MultiheadAttention call plus its residual:
