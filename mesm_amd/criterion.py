@@ -29,15 +29,18 @@ def generalized_temporal_iou(a, b):
 
 class TargetPlan:
     """Flattened targets + host-built index tensors (built once per batch, reused for the aux
-    decoder layers): tgt_cxw / tgt_xx (sumT, 2), tgt_off (N+1) int32, pair_of_t (sumT) int64,
-    Tmax, group_mask (N, N) bool (True where two pairs share a video group) and ss_pos (N, N)
-    uint8, the positives of loss_rec_ss (criterion.py:224-238: block-diagonal gIoU of the
-    merged moments >= gamma) — target-only, so it is evaluated on the host in fp32."""
+    decoder layers): tgt_cxw / tgt_xx (sumT, 2), tgt_off (N+1) int32, Tmax, group_mask (N, N) bool (True where two
+    pairs share a video group) and ss_pos (N, N) uint8, the positives of loss_rec_ss (criterion.py:224-238:
+    block-diagonal gIoU of the merged moments >= gamma) -- target-only, so it is evaluated on the host in fp32.
+    Everything reaches the device in ONE transfer (arena.Arena); `arrays()` is the host half, which
+    graphed.GraphedStep.load_batch re-runs for every new batch."""
 
-    def __init__(self, targets, multi_clip, device, gamma=0.9, T_cap=None, Tmax_cap=None):
-        """T_cap / Tmax_cap: pad the flattened targets to T_cap rows and report Tmax_cap as the matcher's
-        work-array extent (a captured HIP graph bakes both in, graphed.py); the kernels read the true
-        counts from tgt_off, so padding changes no result."""
+    @staticmethod
+    def arrays(targets, multi_clip, gamma=0.9, T_cap=None, Tmax_cap=None):
+        """-> ({name: np.ndarray}, meta).  T_cap / Tmax_cap: pad the flattened targets to T_cap rows and report
+        Tmax_cap as the matcher's work-array extent (a captured HIP graph bakes both in, graphed.py); the kernels
+        read the true counts from tgt_off, so padding changes no result."""
+        import numpy as np
         if multi_clip:
             sizes = [len(t["spans"]) for t in targets["norm_span"]]
             cxw = torch.cat([t["spans"] for t in targets["norm_span"]]).float().cpu()
@@ -49,31 +52,36 @@ class TargetPlan:
             xx = targets["norm_moment"].float().cpu()
             sizes = [1] * cxw.shape[0]
             mom = xx
-        self.sizes = sizes
-        self.N = len(sizes)
-        self.Tmax = max(sizes)
-        self.sumT = cxw.shape[0]
+        N, Tmax, sumT = len(sizes), max(sizes), cxw.shape[0]
         if Tmax_cap is not None:
-            if self.Tmax > Tmax_cap:
-                raise ValueError("TargetPlan: a pair has %d target windows > Tmax_cap %d" % (self.Tmax, Tmax_cap))
-            self.Tmax = Tmax_cap
+            if Tmax > Tmax_cap:
+                raise ValueError("TargetPlan: a pair has %d target windows > Tmax_cap %d" % (Tmax, Tmax_cap))
+            Tmax = Tmax_cap
+        cxw, xx = cxw.numpy(), xx.numpy()
         if T_cap is not None:
-            if self.sumT > T_cap:
-                raise ValueError("TargetPlan: %d target windows > T_cap %d" % (self.sumT, T_cap))
-            pad = T_cap - self.sumT
-            cxw = torch.cat([cxw, torch.tensor([[0.5, 1.0]]).expand(pad, 2)])
-            xx = torch.cat([xx, torch.tensor([[0.0, 1.0]]).expand(pad, 2)])
-        self.tgt_cxw = cxw.contiguous().to(device)
-        self.tgt_xx = xx.contiguous().to(device)
-        off = [0]
-        for s in sizes:
-            off.append(off[-1] + s)
-        self.tgt_off = torch.tensor(off, dtype=torch.int32, device=device)
+            if sumT > T_cap:
+                raise ValueError("TargetPlan: %d target windows > T_cap %d" % (sumT, T_cap))
+            pad = T_cap - sumT
+            cxw = np.concatenate([cxw, np.tile(np.float32([[0.5, 1.0]]), (pad, 1))])
+            xx = np.concatenate([xx, np.tile(np.float32([[0.0, 1.0]]), (pad, 1))])
         groups = [int(g) for g in targets["num_clips"].tolist()]
-        gid = torch.repeat_interleave(torch.arange(len(groups)), torch.tensor(groups))
+        gid = np.repeat(np.arange(len(groups)), groups)
         gmask = gid[:, None] == gid[None, :]
-        self.group_mask = gmask.to(device)
-        self.ss_pos = ((generalized_temporal_iou(mom, mom) >= gamma) & gmask).to(torch.uint8).contiguous().to(device)
+        ss_pos = ((generalized_temporal_iou(mom, mom) >= gamma).numpy() & gmask).astype(np.uint8)
+        arr = {"tgt_cxw": np.ascontiguousarray(cxw, dtype=np.float32), "tgt_xx": np.ascontiguousarray(xx, dtype=np.float32),
+               "tgt_off": np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32), "group_mask": gmask, "ss_pos": ss_pos}
+        return arr, {"sizes": sizes, "N": N, "Tmax": Tmax, "sumT": sumT}
+
+    def __init__(self, targets, multi_clip, device, gamma=0.9, T_cap=None, Tmax_cap=None):
+        from .arena import Arena
+        arr, meta = self.arrays(targets, multi_clip, gamma, T_cap, Tmax_cap)
+        self.arena = Arena(arr, device)
+        self.adopt(self.arena.views, meta)
+
+    def adopt(self, views, meta):
+        for k, v in views.items():
+            setattr(self, k, v)
+        self.sizes, self.N, self.Tmax, self.sumT = meta["sizes"], meta["N"], meta["Tmax"], meta["sumT"]
 
 
 class HungarianMatcher(nn.Module):

@@ -40,24 +40,40 @@ def _round_up(x, m):
 
 
 class GraphedStep:
+    BIG = 1 << 20  # batch tensors above 1 MiB (video_feat, word features) are copied on their own
+
     def __init__(self, model, criterion, batch, dataset_name, warmup=3, instrument=False, reducer=None,
                  caps=None):
         """caps: None = exact extents of `batch` (benchmarks); "auto" = bucketed capacities so that other
         batches of the same (N, Lv, Lw, groups) replay; or a dict with any of Lc / Lss / T / Tmax."""
+        from .arena import Arena
         self.model, self.crit = model, criterion
         self.dataset_name = dataset_name
         dev = batch["video_feat"].device
         self.dev = dev
-        self.batch = batch  # static input buffers (device tensors)
+        self.batch = dict(batch)  # static inputs: big tensors as given, everything small re-homed in the arena
         self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
         self.reducer = reducer
         model.train()
         model.flat_params()
-        self._wm_cpu = self._words_mask_cpu()
         self._groups = [int(g) for g in batch["num_clips"].tolist()]
         self.caps = self._resolve_caps(caps, batch)
-        self.plan = self._make_plan(batch, self._wm_cpu)
-        self.tplan = self._make_tplan(batch)
+        # ONE device arena for: the forward's index plan, the criterion's target plan and the small batch tensors
+        host = {k: v.detach().cpu() for k, v in batch.items() if torch.is_tensor(v)}
+        for k in ("norm_span", "norm_moment"):
+            if isinstance(batch.get(k), list):
+                host[k] = [{kk: vv.detach().cpu() for kk, vv in d.items()} for d in batch[k]]
+        arr, self._pmeta, self._tmeta, self._wm_cpu = self._host_arrays(host, None, None)
+        self._arr = arr  # host mirror of the arena
+        self._draws = (arr["p.neg_index"], arr.get("p.masked_words"))
+        self.arena = Arena(arr, dev)
+        v = self.arena.views
+        self.plan = model.plan_from({k[2:]: t for k, t in v.items() if k.startswith("p.")}, self._pmeta)
+        self.tplan = TargetPlan.__new__(TargetPlan)
+        self.tplan.adopt({k[2:]: t for k, t in v.items() if k.startswith("t.")}, self._tmeta)
+        for k, t in v.items():
+            if k.startswith("b."):
+                self.batch[k[2:]] = t
         self.batch["_target_plan"] = self.tplan
         gb = model.gradbuf()
         gb.ensure(dev)
@@ -87,7 +103,6 @@ class GraphedStep:
             if instrument:
                 kn.gemm_tape(False)
         self._ptrs = self._param_ptrs()
-        self._pins, self._pin_turn = {}, {}
 
     # ------------------------------------------------------------------ capture-time capacities
     def _resolve_caps(self, caps, batch):
@@ -111,20 +126,39 @@ class GraphedStep:
                 caps["T"] = N * caps["Tmax"]
         return dict(caps)
 
-    def _words_mask_cpu(self):
-        w = self.batch["words_id"]
-        if w.dim() != 3:  # token ids (CLIP / GloVe encoders): the collate mask, cut like model.py:114-116
-            return self.batch["words_mask"][:, :self.model.max_words_l].cpu()
-        return kn.text_prep(w, self.model.normalize_txt)[1].cpu()
+    def _words_mask_host(self, host):
+        """validity of every word on the host: the collate mask for token ids (cut like model.py:114-116), the
+        non-zero rows of pre-extracted features (post_process_text, model.py:145-152)"""
+        w = host["words_id"]
+        if w.dim() != 3:
+            return host["words_mask"][:, :self.model.max_words_l]
+        # numpy on purpose: a multi-threaded torch CPU reduction stalls ~17 ms next to a busy HIP queue on this
+        # platform (measured, tools/load_batch_probe.py); these are 2 MB
+        import numpy as np
+        a = w.numpy()
+        if self.model.normalize_txt:
+            n = np.maximum(np.sqrt((a * a).sum(-1, keepdims=True)), 1e-5)
+            a = a / n
+        return torch.from_numpy(a.sum(-1) != 0)
 
-    def _make_plan(self, b, wm_cpu):
-        return self.model.make_plan(b["video_mask"], wm_cpu, b["num_clips"], self.dataset_name, True,
-                                    words_weight=b["words_weight"], clip_mask=b.get("clip_mask"),
-                                    device=self.dev, Lc_cap=self.caps.get("Lc"), Lss_cap=self.caps.get("Lss"))
-
-    def _make_tplan(self, b):
-        return TargetPlan(b, self.crit.multi_clip, self.dev, self.crit.gamma, T_cap=self.caps.get("T"),
-                          Tmax_cap=self.caps.get("Tmax"))
+    def _host_arrays(self, host, neg_index, masked_words):
+        """{name: numpy array} of everything small the captured step reads: "p." the forward's plan, "t." the
+        criterion's target plan, "b." batch tensors below BIG bytes; plus the two metas and the word mask."""
+        m = self.model
+        wm = self._words_mask_host(host)
+        parr, pmeta = m.plan_arrays(host["video_mask"].numpy(), wm.numpy(), self._groups, self.dataset_name, True,
+                                    clip_mask=host["clip_mask"].numpy() if "clip_mask" in host else None,
+                                    neg_index=neg_index, masked_words=masked_words,
+                                    words_weight=host.get("words_weight"), Lc_cap=self.caps.get("Lc"),
+                                    Lss_cap=self.caps.get("Lss"))
+        tarr, tmeta = TargetPlan.arrays(host, self.crit.multi_clip, self.crit.gamma, T_cap=self.caps.get("T"),
+                                        Tmax_cap=self.caps.get("Tmax"))
+        arr = {"p." + k: v for k, v in parr.items()}
+        arr.update({"t." + k: v for k, v in tarr.items()})
+        for k, v in host.items():
+            if torch.is_tensor(v) and k != "words_weight" and v.numel() * v.element_size() <= self.BIG:
+                arr["b." + k] = v.numpy()
+        return arr, pmeta, tmeta, wm
 
     def _param_ptrs(self):
         gb = self.model.gradbuf()
@@ -139,29 +173,12 @@ class GraphedStep:
         return total.detach(), {k: v.detach() for k, v in losses.items()}
 
     # ------------------------------------------------------------------ new batch, same graph
-    @staticmethod
-    def _copy_plan(dst, src, what, check_only=False):
-        """Copy every tensor attribute of the freshly built host plan `src` into the static tensors of
-        the captured plan `dst`; shapes and every non-tensor attribute must be identical."""
-        for k, v in vars(src).items():
-            cur = getattr(dst, k, None)
-            if torch.is_tensor(v):
-                if not torch.is_tensor(cur) or cur.shape != v.shape or cur.dtype != v.dtype:
-                    raise ValueError("GraphedStep.load_batch: %s.%s does not fit the captured graph (%s -> %s)"
-                                     % (what, k, tuple(cur.shape) if torch.is_tensor(cur) else cur, tuple(v.shape)))
-                if not check_only:
-                    cur.copy_(v, non_blocking=True)
-            elif k in ("sizes", "sumT"):  # per-batch bookkeeping the kernels read from tgt_off instead
-                if not check_only:
-                    setattr(dst, k, v)
-            elif cur != v:
-                raise ValueError("GraphedStep.load_batch: %s.%s changed (%r -> %r): needs its own graph"
-                                 % (what, k, cur, v))
-
     def load_batch(self, batch):
-        """Make the captured step run on `batch` (host or device tensors): same (N, Lv, Lw, Dv, Dt) and
-        the same group sizes; GT-clip counts, group video lengths and target windows may differ within
-        the capture-time capacities.  Raises ValueError (nothing is modified) when it does not fit."""
+        """Make the captured step run on `batch` (host tensors; device tensors are brought to the host first,
+        the plans are host work): same (N, Lv, Lw, Dv, Dt) and the same group sizes; GT-clip counts, group video
+        lengths and target windows may differ within the capture-time capacities.  Everything small -- index
+        plans, targets, masks, labels -- goes up in ONE pinned transfer (arena.Arena), the feature tensors in one
+        copy each.  Raises ValueError (nothing is modified) when it does not fit."""
         groups = [int(g) for g in batch["num_clips"].tolist()]
         if groups != self._groups:
             raise ValueError("GraphedStep.load_batch: group sizes changed %s -> %s" % (self._groups, groups))
@@ -170,61 +187,91 @@ class GraphedStep:
             if torch.is_tensor(cur) and torch.is_tensor(v) and cur.shape != v.shape:
                 raise ValueError("GraphedStep.load_batch: %s changed shape %s -> %s"
                                  % (k, tuple(cur.shape), tuple(v.shape)))
-        words = batch["words_id"]
-        if words.dim() != 3:
-            wm_cpu = batch["words_mask"][:, :self.model.max_words_l].cpu()
-        elif words.is_cuda:
-            wm_cpu = kn.text_prep(words, self.model.normalize_txt)[1].cpu()
-        else:  # host batch: post_process_text's mask rule (model.py:145-152) without a device round trip
-            w = torch.nn.functional.normalize(words, dim=-1, eps=1e-5) if self.model.normalize_txt else words
-            wm_cpu = w.sum(-1) != 0
-        drawn = self.plan  # keep the current host draws; redraw() replaces them
-        plan = self.model.make_plan(batch["video_mask"], wm_cpu, batch["num_clips"], self.dataset_name, True,
-                                    words_weight=batch["words_weight"], clip_mask=batch.get("clip_mask"),
-                                    neg_index=drawn.neg_index, masked_words=getattr(drawn, "masked_words", None),
-                                    device=self.dev, Lc_cap=self.caps.get("Lc"), Lss_cap=self.caps.get("Lss"))
-        tplan = self._make_tplan(batch)
-        self._copy_plan(self.plan, plan, "plan", check_only=True)
-        self._copy_plan(self.tplan, tplan, "targets", check_only=True)
-        # everything below only copies: the checks above and the two builders raise before any change
-        self._copy_plan(self.plan, plan, "plan")
-        self._copy_plan(self.tplan, tplan, "targets")
+        host = {k: (v.detach().cpu() if v.is_cuda and v.numel() * v.element_size() <= self.BIG else v)
+                for k, v in batch.items() if torch.is_tensor(v)}
+        for k in ("video_mask", "clip_mask"):
+            if k in host and host[k].is_cuda:
+                host[k] = host[k].cpu()
+        if host["words_id"].is_cuda:
+            host["words_id"] = host["words_id"].cpu()
+        for k in ("norm_span", "norm_moment"):
+            if isinstance(batch.get(k), list):
+                host[k] = [{kk: vv.detach().cpu() for kk, vv in d.items()} for d in batch[k]]
+        # keep the current host draws (redraw() replaces them)
+        arr, pmeta, tmeta, wm = self._host_arrays(host, self._draws[0], self._draws[1])
+        for k in ("vid_identity", "has_vid_src"):
+            if pmeta.get(k) != self._pmeta.get(k):
+                raise ValueError("GraphedStep.load_batch: plan.%s changed (%r -> %r): needs its own graph"
+                                 % (k, self._pmeta.get(k), pmeta.get(k)))
+        self.arena.check(arr)
+        # nothing above modified anything; from here on only copies
+        self._arr = arr
+        self.arena.upload(arr)
+        self.tplan.sizes, self.tplan.sumT = tmeta["sizes"], tmeta["sumT"]
         for k, cur in self.batch.items():
             v = batch.get(k)
-            if torch.is_tensor(cur) and torch.is_tensor(v):
-                if cur.is_cuda:
+            if torch.is_tensor(cur) and torch.is_tensor(v) and ("b." + k) not in arr:
+                if not cur.is_cuda:
+                    self.batch[k] = v  # host-side inputs (words_weight) are only read by redraw()
+                elif v.is_cuda:
                     cur.copy_(v, non_blocking=True)
                 else:
-                    self.batch[k] = v  # host-side inputs (words_weight) are only read by redraw()
-        self._wm_cpu = wm_cpu
+                    self._stage_big(k, cur, v)
+        self._turn ^= 1
+        self._wm_cpu = wm
 
-    def _pinned_h2d(self, name, host, dst):
-        """host tensor -> static device tensor through one of two pinned staging buffers (a pageable
-        source makes the copy synchronous with everything in flight; with pinned memory the host
-        only waits for the copy that used the same staging buffer two redraws ago)."""
-        slots = self._pins.setdefault(name, [])
-        if not slots:
-            for _ in range(2):
-                slots.append([torch.empty(host.shape, dtype=host.dtype, pin_memory=True), None])
-        i = self._pin_turn.get(name, 0)
-        self._pin_turn[name] = i ^ 1
-        buf, ev = slots[i]
-        if ev is not None:
-            ev.synchronize()
-        buf.copy_(host)
-        dst.copy_(buf, non_blocking=True)
+    _copy_stream = None
+    _turn = 0
+
+    def _stage_big(self, k, cur, v):
+        """host feature tensor -> static graph input without stalling the compute stream: the (pageable, hence
+        host-blocking) H2D runs on a copy stream into one of two device staging buffers while the previous
+        replay is still executing; the compute stream then only does a device-to-device copy (27 MB: ~10 us)
+        behind an event.  A staging buffer is rewritten only after the D2D copy that read it two batches ago."""
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=self.dev)
+            self._stages, self._d2d_done = {}, {}
+        j = self._turn
+        st = self._stages.setdefault(k, [None, None])
+        if st[j] is None:
+            st[j] = torch.empty_like(cur)
+        main, cs = torch.cuda.current_stream(), self._copy_stream
+        with torch.cuda.stream(cs):
+            ev = self._d2d_done.get((k, j))
+            if ev is not None:
+                cs.wait_event(ev)
+            st[j].copy_(v, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(cs)
+        main.wait_event(done)
+        cur.copy_(st[j], non_blocking=True)
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
-        slots[i][1] = ev
+        ev.record(main)
+        self._d2d_done[(k, j)] = ev
 
     def redraw(self):
-        """New negative-query indices and MLM word choices (host RNG, like the reference does on
-        every forward), copied into the static index tensors the graph reads."""
+        """New negative-query indices and MLM word choices (host RNG, like the reference does on every forward),
+        written into the static index tensors the graph reads (one arena upload)."""
         m = self.model
-        self._pinned_h2d("neg", m.draw_neg_index(self._groups), self.plan.neg_index)
+        neg = m.draw_neg_index(self._groups).numpy()
+        mw = None
         if hasattr(self.plan, "masked_words"):
-            mw = m.draw_masked_words(self._wm_cpu, self.batch["words_weight"]).bool()
-            self._pinned_h2d("mw", mw, self.plan.masked_words)
+            mw = m.draw_masked_words(self._wm_cpu, self.batch["words_weight"]).bool().numpy()
+        self._draws = (neg, mw)
+        self._arr["p.neg_index"] = neg
+        if mw is not None:
+            self._arr["p.masked_words"] = mw
+        self.arena.upload(self._arr)
+
+    def set_draws(self, neg_index, masked_words=None):
+        """replay with given host draws (tests / reproducing a recorded step)"""
+        neg = neg_index.cpu().numpy()
+        mw = masked_words.cpu().numpy().astype(bool) if masked_words is not None else self._draws[1]
+        self._draws = (neg, mw)
+        self._arr["p.neg_index"] = neg
+        if mw is not None:
+            self._arr["p.masked_words"] = mw
+        self.arena.upload(self._arr)
 
     def run(self, redraw=True):
         if self._param_ptrs() != self._ptrs:

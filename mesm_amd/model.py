@@ -241,107 +241,108 @@ class MESM(nn.Module):
         return masked
 
     # ------------------------------------------------------------------ host-side plan
-    @torch.no_grad()
-    def make_plan(self, video_mask, words_mask, num_clips, dataset_name, is_training, words_weight=None,
-                  clip_mask=None, neg_index=None, masked_words=None, device=None, Lc_cap=None, Lss_cap=None):
-        """All data-dependent host decisions of model.py:184-207, :260, :307-325 in one place.
-        Inputs may live on any device; one D2H copy of the (small) masks is made.
+    def plan_arrays(self, vm, wm, groups, dataset_name, is_training, clip_mask=None, neg_index=None,
+                    masked_words=None, words_weight=None, Lc_cap=None, Lss_cap=None):
+        """All data-dependent host decisions of model.py:184-207, :260, :307-325 as numpy arrays
+        ({name: array}, meta) -- pure host arithmetic on the (small) masks, no device work.
 
-        Lc_cap / Lss_cap: pad the GT-clip gather (MLM branch) / the group-video gather (SS branch) to a
-        fixed key length; the padding slots are masked keys, so the results do not change, and a HIP
-        graph captured with such a plan replays for every batch that fits (graphed.py).  A batch that
-        does not fit raises ValueError."""
-        device = device or video_mask.device
-        vm = video_mask.cpu()
-        wm = words_mask.cpu()
-        groups = [int(g) for g in num_clips.tolist()]
+        vm (N, Lv) / wm (N, Lw) bool arrays (video / word validity), groups = queries per video group.
+        Lc_cap / Lss_cap: pad the GT-clip gather (MLM branch) / the group-video gather (SS branch) to a fixed key
+        length; the padding slots are masked keys, so results do not change, and a HIP graph captured with such
+        a plan replays for every batch that fits (graphed.py).  A batch that does not fit raises ValueError."""
+        vm, wm = np.asarray(vm, dtype=bool), np.asarray(wm, dtype=bool)
         N, Lv = vm.shape
-        pl = Plan()
-        pl.groups = groups
+        arr, meta = {}, {"groups": list(groups)}
         if neg_index is None:
-            neg_index = self.draw_neg_index(groups)
-        pl.neg_index = neg_index.to(device)
+            neg_index = self.draw_neg_index(groups).numpy()
+        arr["neg_index"] = np.asarray(neg_index, dtype=np.int64)
         if self.rec_ss:
-            slot = torch.cat([torch.arange(g) for g in groups])
             M = max(groups)
-            pl.sent_src = torch.zeros(N, M, dtype=torch.int64)  # row of sentence_feat per slot
-            pl.sent_mask = torch.zeros(N, M, dtype=torch.bool)
-            start = 0
-            for g in groups:
-                for i in range(start, start + g):
-                    pl.sent_src[i, :g] = torch.arange(start, start + g)
-                    pl.sent_mask[i, :g] = True
-                start += g
-            pl.sent_loc = torch.zeros(N, M, dtype=torch.bool)
-            pl.sent_loc[torch.arange(N), slot] = True
-            pl.sent_slot = slot.to(device)
-            pl.rows = torch.arange(N, device=device)
+            starts = np.concatenate([[0], np.cumsum(groups)])
+            gid = np.repeat(np.arange(len(groups)), groups)          # group of every pair
+            slot = np.arange(N) - starts[gid]                        # position of the pair inside its group
+            cols = np.arange(M)[None, :]
+            sent_mask = cols < np.asarray(groups)[gid][:, None]
+            arr["sent_src"] = np.where(sent_mask, starts[gid][:, None] + cols, 0).astype(np.int64)
+            arr["sent_mask"] = sent_mask
+            arr["sent_pad"] = ~sent_mask
+            arr["sent_loc"] = cols == slot[:, None]
+            arr["sent_slot"] = slot.astype(np.int64)
+            arr["rows"] = np.arange(N, dtype=np.int64)
             # the masked slot of every pair in the (N * M)-row output of the reconstructor, and its inverse map
-            ridx = torch.arange(N) * M + slot
-            rinv = torch.full((N * M,), -1, dtype=torch.int64)
-            rinv[ridx] = torch.arange(N)
-            pl.recon_idx, pl.recon_inv = ridx.to(device), rinv.to(device)
+            ridx = np.arange(N) * M + slot
+            rinv = np.full(N * M, -1, dtype=np.int64)
+            rinv[ridx] = np.arange(N)
+            arr["recon_idx"], arr["recon_inv"] = ridx.astype(np.int64), rinv
             if dataset_name == "qvhighlights":
-                flat_valid = vm.reshape(-1).nonzero().squeeze(1)  # rows of (N*Lv) that are valid
-                counts = vm.sum(1)
-                offs = torch.cat([torch.zeros(1, dtype=torch.int64), counts.cumsum(0)])
-                seg, start = [], 0
-                for g in groups:
-                    idx = flat_valid[offs[start]:offs[start + g]]
-                    seg += [idx] * g
-                    start += g
-                Lss = max(len(s) for s in seg)
+                # all valid clips of the group's segments, concatenated, once per query (model.py:190-195)
+                flat_valid = np.flatnonzero(vm.reshape(-1))
+                offs = np.concatenate([[0], np.cumsum(vm.sum(1))])
+                seg_len = offs[starts[1:]] - offs[starts[:-1]]       # clips per group
+                Lss = int(seg_len.max())
                 if Lss_cap is not None:
                     if Lss > Lss_cap:
                         raise ValueError("make_plan: the longest group video has %d clips > Lss_cap %d" % (Lss, Lss_cap))
                     Lss = Lss_cap
-                pl.vid_src = torch.zeros(N, Lss, dtype=torch.int64)
-                pl.vid_mask = torch.zeros(N, Lss, dtype=torch.bool)
-                for i, s in enumerate(seg):
-                    pl.vid_src[i, :len(s)] = s
-                    pl.vid_mask[i, :len(s)] = True
+                c = np.arange(Lss)[None, :]
+                vid_mask = c < seg_len[gid][:, None]
+                src_pos = np.minimum(offs[starts[:-1]][gid][:, None] + c, len(flat_valid) - 1)
+                arr["vid_src"] = np.where(vid_mask, flat_valid[src_pos], 0).astype(np.int64)
+                arr["vid_mask"], arr["vid_pad"] = vid_mask, ~vid_mask
                 # every group is one full-length pair (the common QVH case): the gather is the identity
-                pl.vid_identity = bool(Lss == Lv and pl.vid_mask.all()
-                                       and torch.equal(pl.vid_src.reshape(-1), torch.arange(N * Lv)))
-                pl.vid_src = pl.vid_src.to(device)
-                pl.vid_pad = (~pl.vid_mask).to(device)
-                pl.vid_mask = pl.vid_mask.to(device)
+                meta["vid_identity"] = bool(Lss == Lv and vid_mask.all()
+                                            and np.array_equal(arr["vid_src"].reshape(-1), np.arange(N * Lv)))
+                meta["has_vid_src"] = True
             elif dataset_name in ("charades", "charades-cg", "charades-cd", "tacos"):
-                pl.vid_src = None
-                pl.vid_identity = False
+                meta["vid_identity"], meta["has_vid_src"] = False, False
             else:
                 raise NotImplementedError
-            pl.sent_src = pl.sent_src.to(device)
-            pl.sent_pad = (~pl.sent_mask).to(device)
-            pl.sent_mask = pl.sent_mask.to(device)
-            pl.sent_loc = pl.sent_loc.to(device)
         if self.rec_fw and is_training:
-            cm = clip_mask.cpu()
+            cm = np.asarray(clip_mask, dtype=bool)
             lens = cm.sum(1)
             Lc = int(lens.max())
             if Lc_cap is not None:
                 if Lc > Lc_cap:
                     raise ValueError("make_plan: a pair has %d ground-truth clips > Lc_cap %d" % (Lc, Lc_cap))
                 Lc = Lc_cap
-            flat = cm.reshape(-1).nonzero().squeeze(1)
-            offs = torch.cat([torch.zeros(1, dtype=torch.int64), lens.cumsum(0)])
-            src = torch.zeros(N, Lc, dtype=torch.int64)
-            cmask = torch.zeros(N, Lc, dtype=torch.bool)
-            for i in range(N):
-                li = int(lens[i])
-                src[i, :li] = flat[offs[i]:offs[i + 1]]
-                cmask[i, :li] = True
+            flat = np.flatnonzero(cm.reshape(-1))
+            offs = np.concatenate([[0], np.cumsum(lens)])
+            c = np.arange(Lc)[None, :]
+            cmask = c < lens[:, None]
+            src = np.where(cmask, flat[np.minimum(offs[:-1][:, None] + c, max(len(flat) - 1, 0))], 0).astype(np.int64)
             # inverse of the GT-clip gather: source row (pair, clip) -> its slot in (N, Lc), -1 = not gathered
             # (the padding slots point at row 0 but are invalid: they must not claim it)
-            cinv = torch.full((N * Lv,), -1, dtype=torch.int64)
-            cinv[src[cmask]] = torch.arange(N * Lc).view(N, Lc)[cmask]
-            pl.clip_src = src.to(device)
-            pl.clip_inv = cinv.to(device)
-            pl.clip_mask = cmask.to(device)
-            pl.clip_pad = (~cmask).to(device)
+            cinv = np.full(N * Lv, -1, dtype=np.int64)
+            cinv[src[cmask]] = np.arange(N * Lc).reshape(N, Lc)[cmask]
+            arr["clip_src"], arr["clip_inv"], arr["clip_mask"], arr["clip_pad"] = src, cinv, cmask, ~cmask
             if masked_words is None:
-                masked_words = self.draw_masked_words(wm, words_weight)
-            pl.masked_words = masked_words.bool().to(device)
+                masked_words = self.draw_masked_words(torch.from_numpy(wm), words_weight).numpy()
+            arr["masked_words"] = np.asarray(masked_words, dtype=bool)
+        return arr, meta
+
+    @staticmethod
+    def plan_from(views, meta):
+        pl = Plan()
+        for k, v in views.items():
+            setattr(pl, k, v)
+        pl.groups = meta["groups"]
+        pl.vid_identity = meta.get("vid_identity", False)
+        if not meta.get("has_vid_src", False):
+            pl.vid_src = None
+        return pl
+
+    @torch.no_grad()
+    def make_plan(self, video_mask, words_mask, num_clips, dataset_name, is_training, words_weight=None,
+                  clip_mask=None, neg_index=None, masked_words=None, device=None, Lc_cap=None, Lss_cap=None):
+        """plan_arrays on host copies of the masks, uploaded to `device` in one transfer (arena.Arena)."""
+        from .arena import Arena
+        device = device or video_mask.device
+        _np = lambda t: None if t is None else (t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t))
+        arr, meta = self.plan_arrays(_np(video_mask), _np(words_mask), [int(g) for g in num_clips.tolist()],
+                                     dataset_name, is_training, clip_mask=_np(clip_mask), neg_index=_np(neg_index),
+                                     masked_words=_np(masked_words), words_weight=words_weight, Lc_cap=Lc_cap,
+                                     Lss_cap=Lss_cap)
+        pl = self.plan_from(Arena(arr, device).views, meta)
         return pl
 
     # ------------------------------------------------------------------ forward

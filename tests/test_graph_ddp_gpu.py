@@ -119,8 +119,7 @@ def test_graph_with_flat_adamw_trains_like_eager():
         if mode == "graph":
             # the order INTEGRATION.md used to show: graph first, optimizer second
             g = GraphedStep(model, crit, batch, fx.cfg["dataset_name"], warmup=1)
-            g.plan.neg_index.copy_(fx.neg_index)
-            g.plan.masked_words.copy_(fx.masked_words)
+            g.set_draws(fx.neg_index, fx.masked_words)
             opt = FlatAdamW(model, lr=1e-3, weight_decay=1e-2)
             losses = []
             for _ in range(4):
