@@ -39,9 +39,15 @@ if ROOT not in sys.path:
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_HBM_TBS = 8.0            # MI355X_MICROARCH.md: HBM3E spec peak
-# SURVEY.md 8d closed form for C3a-type batches (kernel-boundary traffic / FLOPs of one step)
-STEP_BYTES = lambda n_pairs: 0.272e9 + n_pairs * 109.0e6
-STEP_FLOPS = lambda n_pairs: n_pairs * 6.22e9
+# algorithmic work of one step (kernel-boundary traffic / FLOPs); closed form for C3a-type batches,
+# the analytic model's totals for the other workloads
+STEP_WORK = {"C1": (0.48e9, 12.0e9), "C2": (3.49e9, 183.7e9), "C3b": (5.07e9, 257.9e9), "C5": (10.83e9, 646.2e9)}
+
+
+def step_work(workload, n_pairs):
+    if workload in STEP_WORK:
+        return STEP_WORK[workload]
+    return 0.272e9 + n_pairs * 109.0e6, n_pairs * 6.22e9
 
 
 def parse():
@@ -224,9 +230,10 @@ def main():
     roofline = {"bound": "mfma", "achieved": None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": None,
                 "traffic": None}
     # SURVEY 8d step-level definition (per rank: every rank runs the same per-GPU workload)
-    roofline["step_hbm_frac"] = STEP_BYTES(n_pairs) / t_step / (PEAK_HBM_TBS * 1e12)
-    roofline["step_mfma_frac"] = STEP_FLOPS(n_pairs) / t_step / (PEAK_F32_MFMA_TFLOPS * 1e12)
-    roofline["step_bytes"], roofline["step_flops"] = STEP_BYTES(n_pairs), STEP_FLOPS(n_pairs)
+    sbytes, sflops = step_work(opt.workload, n_pairs)
+    roofline["step_hbm_frac"] = sbytes / t_step / (PEAK_HBM_TBS * 1e12)
+    roofline["step_mfma_frac"] = sflops / t_step / (PEAK_F32_MFMA_TFLOPS * 1e12)
+    roofline["step_bytes"], roofline["step_flops"] = sbytes, sflops
     if not opt.no_roofline and rank == 0 and world == 1:
         # the GEMM launches of one captured step, replayed back to back from C++ with a HIP-event
         # pair around every launch (same arguments and buffers as the graph; see mesm_gemm_tape)
@@ -320,9 +327,11 @@ def main():
             "unit": "pairs/s", "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup,
             "ms_per_step": t_step * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s: QVHighlights C+SF, %d pairs/GPU (%d groups), Lv=%d, Lw=%d, "
+            "config": {"workload": "%s: %s, %d pairs/GPU (%d groups), Lv=%d, Lw=%d, "
                                    "Dv=%d, Dt=%d, C=%d, 10 moment queries, train mode (dropout on)"
-                                   % (opt.workload, n_pairs, len(wl["groups"]), wl["Lv"], wl["Lw"],
+                                   % (opt.workload, {"qvhighlights": "QVHighlights C+SF", "charades": "Charades-STA",
+                                                     "tacos": "TACoS C3D"}.get(wl["dataset_name"], wl["dataset_name"]),
+                                      n_pairs, len(wl["groups"]), wl["Lv"], wl["Lw"],
                                       wl["v_feat_dim"], wl["t_feat_dim"], wl["vocab_size"] + 1),
                        "global_pairs": n_pairs * world, "parallelism": "dp%d" % world,
                        "launch": "eager" if opt.eager else "hip-graph", "ddp": ddp_mode,

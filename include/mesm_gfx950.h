@@ -127,6 +127,11 @@ typedef struct MesmGemmArgs {
      (transformer.py:537, 603, 608, 647, 794).  Not with split_k / accumulate. */
   float* pre_out;
   int64_t ldpre;
+  /* row offset added to the epilogue-dropout index: the launch computes rows [e_drop_row0, e_drop_row0 + M) of
+     a taller output whose mask the backward replays over the whole tensor (a 4800-row FFN output issued as a
+     4096-row launch that fills the 256 CUs in one round plus a remainder launch, mesm_amd/kernels.py) */
+  int32_t e_drop_row0;
+  int32_t reserved0;
 } MesmGemmArgs;
 
 int mesm_gemm_f32(const MesmGemmArgs* args, void* stream);

@@ -41,6 +41,7 @@ class GemmArgs(ctypes.Structure):
         ("accumulate", ctypes.c_int32), ("split_k", ctypes.c_int32),
         ("seed_offset", c_ptr), ("dslope_ws", c_ptr),
         ("pre_out", c_ptr), ("ldpre", ctypes.c_int64),
+        ("e_drop_row0", ctypes.c_int32), ("reserved0", ctypes.c_int32),
     ]
 
 

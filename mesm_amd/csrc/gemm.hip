@@ -466,7 +466,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const MesmGemmArgs p
         float t = vals[i][j][rr] * p.out_scale + bias_v;
         t = mesm_act(t, p.e_act, slope);
         if (e_thresh)
-          t = mesm_dropout_apply(t, (uint32_t)((int64_t)row * p.N + col), p.e_drop_seed + seed_off, e_thresh,
+          t = mesm_dropout_apply(t, (uint32_t)((int64_t)(row + p.e_drop_row0) * p.N + col), p.e_drop_seed + seed_off, e_thresh,
                                  e_inv_keep);
         if (use_aux) {
           const float z = auxv[rr];
@@ -633,7 +633,8 @@ __device__ __forceinline__ float staged_epilogue(const MesmGemmArgs& p, float (&
     const uint32_t thresh = mesm_drop_threshold(p.e_drop_p);
     const float inv_keep = 1.0f / (1.0f - p.e_drop_p);
     const uint32_t seed = p.e_drop_seed + seed_off;
-    const uint32_t idx0 = (uint32_t)rbase * (uint32_t)p.N + (uint32_t)col;  // dense index of C, modulo 2^32
+    // dense index of C, modulo 2^32 (e_drop_row0: this launch computes rows [row0, row0 + M) of a taller C)
+    const uint32_t idx0 = (uint32_t)(rbase + p.e_drop_row0) * (uint32_t)p.N + (uint32_t)col;
 #pragma unroll
     for (int i = 0; i < NV; ++i) t[i] = mesm_dropout_apply(t[i], idx0 + (uint32_t)RO(i) * (uint32_t)p.N, seed, thresh, inv_keep);
   }

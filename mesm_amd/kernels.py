@@ -4,6 +4,7 @@ Every function launches on torch's current HIP stream and returns immediately.
 Tensors must live on the GPU, be fp32 and (unless stated) contiguous.
 """
 import ctypes
+import os
 
 import torch
 
@@ -46,13 +47,28 @@ def _mat(t):
 def gemm(A, B, C, *, trans_a=False, trans_b=False, A2=None, B2=None, bias=None, residual=None,
          aux=None, slope=None, dslope=None, colsum=None, a_act=ACT_NONE, b_act=ACT_NONE,
          a_drop=(0.0, 0), b_drop=(0.0, 0), e_act=ACT_NONE, e_actgrad=ACT_NONE,
-         e_drop=(0.0, 0), out_scale=1.0, accumulate=0, split_k=1, pre_out=None):
+         e_drop=(0.0, 0), out_scale=1.0, accumulate=0, split_k=1, pre_out=None, row0=0):
     """C[M,N] (+)= epi( op(A) @ op(B) ).
 
     A is (M,K) (or (K,M) with trans_a), B is (K,N) (or (N,K) with trans_b); both are
     2-D views whose last stride is 1.  C is (M,N) with unit column stride.
     """
     require_gpu(A, B, C)
+    if (_SPLIT_ROWS and row0 == 0 and not trans_a and C.shape[1] == 256 and A.shape[1] >= 1024
+            and 4096 < C.shape[0] <= 5120 and split_k == 1 and colsum is None and dslope is None and A2 is None):
+        # 4800 / 4864-row outputs of width 256: 300 tiles of 64 x 64 on 256 CUs are two rounds with the second 17 %
+        # full.  Rows [0, 4096) = 256 tiles = exactly one round of the k-split 64 x 64 kernel; the remainder goes
+        # to the 32 x 32 kernel (4800 x 256 x 1024: 37 us -> 30 us).  The epilogue-dropout mask index carries the
+        # row offset, every other epilogue term is row-local.
+        cut = 4096
+        sl = lambda t_, a_, b_: None if t_ is None else t_[a_:b_]
+        for lo, hi in ((0, cut), (cut, C.shape[0])):
+            gemm(A[lo:hi], B, C[lo:hi], trans_b=trans_b, B2=B2, bias=bias, residual=sl(residual, lo, hi),
+                 aux=sl(aux, lo, hi), slope=slope, a_act=a_act, b_act=b_act, a_drop=a_drop, b_drop=b_drop,
+                 e_act=e_act, e_actgrad=e_actgrad, e_drop=e_drop, out_scale=out_scale, accumulate=accumulate,
+                 pre_out=sl(pre_out, lo, hi), row0=lo if lo else -1)
+        return C
+    row0 = max(row0, 0)
     assert A.dtype == B.dtype == C.dtype == torch.float32
     assert A.dim() == 2 and B.dim() == 2 and C.dim() == 2
     assert A.stride(1) == 1 and B.stride(1) == 1 and C.stride(1) == 1
@@ -111,6 +127,7 @@ def gemm(A, B, C, *, trans_a=False, trans_b=False, A2=None, B2=None, bias=None, 
     if pre_out is not None:
         assert pre_out.shape == (M, N) and pre_out.stride(1) == 1
         g.pre_out, g.ldpre = pre_out.data_ptr(), pre_out.stride(0)
+    g.e_drop_row0 = int(row0)
     g.seed_offset = _seed_off_ptr()
     if _pending is not None:
         # inside gemm_group(): queued; the tensors stay referenced until the group is launched
@@ -122,6 +139,7 @@ def gemm(A, B, C, *, trans_a=False, trans_b=False, A2=None, B2=None, bias=None, 
 
 
 _pending = None
+_SPLIT_ROWS = os.environ.get("MESM_GEMM_SPLIT_ROWS", "1") == "1"
 
 
 class gemm_group:

@@ -37,7 +37,7 @@ def test_binding_covers_the_header():
 def test_struct_sizes_match_the_c_layout():
     # sizeof computed from the field lists of the header (LP64): guards against a drifting mirror
     from mesm_amd import _lib
-    assert ctypes.sizeof(_lib.GemmArgs) == 240
+    assert ctypes.sizeof(_lib.GemmArgs) == 248
     assert ctypes.sizeof(_lib.AttnArgs) == 248
 
 

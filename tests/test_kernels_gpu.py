@@ -758,3 +758,24 @@ def test_layernorm_second_output_and_gradient_joins(rows, D):
     assert rel_err(dx, dx_ref + addend) < 1e-5
     assert rel_err(dg, dg_ref) < 1e-4 and rel_err(db, db_ref) < 1e-4
     assert rel_err(dxm, kn.dropout(dx, 0.1, 9)) < 1e-6
+
+
+def test_gemm_row_split_keeps_the_dropout_mask_and_every_epilogue_term():
+    """kernels.gemm issues 4800-row x 256 outputs with K >= 1024 as a 4096-row launch (one full round of 64 x 64
+    tiles) plus a remainder; the epilogue-dropout index carries the row offset (MesmGemmArgs.e_drop_row0), so the
+    result -- mask included -- equals the single launch."""
+    from mesm_amd import kernels as kn
+    M, N, K = 4800, 256, 1024
+    A, W = gen((M, K), 1, 0.1), gen((N, K), 2, 0.1)
+    bias, res = gen((N,), 3), gen((M, N), 4)
+    outs = []
+    for split in (True, False):
+        kn._SPLIT_ROWS = split
+        try:
+            C = torch.empty(M, N, device=dev())
+            kn.gemm(A, W, C, trans_b=True, bias=bias, residual=res, e_drop=(0.1, 321))
+            outs.append(C)
+        finally:
+            kn._SPLIT_ROWS = True
+    assert rel_err(outs[0], outs[1]) < 1e-6
+    assert float((outs[0] == res).float().mean()) > 0.05  # dropped elements (only the residual survives) exist

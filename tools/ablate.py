@@ -1,7 +1,7 @@
 """In-situ cost of a kernel family: time the captured training step with that family's launches
 turned into no-ops (results are garbage; only the step time matters).  rocprofv3 inflates short
 kernels by ~2 us each, so this is the attribution that adds up to the real step time.
-Usage: python tools/ablate.py [families...]   families: gemm attn ln loss elt  (default: each in turn)
+Usage: python tools/ablate.py [families...]   families: gemm attn ln loss elt glue  (default: each in turn)
 Caveat: with the attention core ablated its outputs are uninitialised memory, and the data-dependent
 assignment loop of the criterion runs longer or shorter on garbage -- price attention from the kernel trace
 (tools/trace_summary.py) or tools/attn_bench.py instead."""
@@ -15,12 +15,17 @@ from mesm_amd.graphed import GraphedStep
 FAMILIES = {
     "gemm": ["mesm_gemm_f32", "mesm_gemm_group"],
     "attn": ["mesm_attn_fwd", "mesm_attn_bwd"],
-    "ln": ["mesm_layernorm_fwd", "mesm_layernorm_bwd", "mesm_layernorm_bwd2"],
+    "ln": ["mesm_layernorm_fwd", "mesm_layernorm_bwd", "mesm_layernorm_bwd2", "mesm_layernorm_fwd2",
+           "mesm_layernorm_bwd3"],
+    "glue": ["mesm_stack_rows", "mesm_unstack_rows", "mesm_prepend_fwd", "mesm_prepend_bwd", "mesm_split_token_fwd",
+             "mesm_split_token_bwd", "mesm_token_mix_fwd", "mesm_token_mix_bwd", "mesm_gather_rows_fwd",
+             "mesm_gather_rows_bwd", "mesm_add_wrap"],
     "loss": ["mesm_set_loss_fwd", "mesm_set_loss_bwd", "mesm_rec_ss_fwd", "mesm_rec_ss_bwd", "mesm_rec_fw_reduce",
              "mesm_rec_fw_rowgrad", "mesm_nll_smooth_fwd", "mesm_nll_smooth_bwd", "mesm_saliency_loss_fwd",
              "mesm_saliency_loss_bwd", "mesm_weighted_sum", "mesm_scale_vec", "mesm_rowdot_fwd", "mesm_rowdot_bwd"],
     "elt": ["mesm_dropout", "mesm_act_bias_bwd", "mesm_sine_pos_fwd", "mesm_query_sine_fwd", "mesm_query_sine_bwd",
-            "mesm_text_prep"],
+            "mesm_text_prep", "mesm_ref_update_fwd", "mesm_ref_update_bwd", "mesm_qsine_scale_fwd",
+            "mesm_qsine_scale_bwd", "mesm_act_dropout"],
 }
 L = _lib.lib()
 REAL = {n: getattr(L, n) for fam in FAMILIES.values() for n in fam}

@@ -18,10 +18,13 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $out/pmc_$c -o p -- python3 bench.py --steps 3 --warmup 1 --cpu-steps 0 --no-roofline > $out/pmc_$c.log 2>&1; echo "pmc $c rc=$?" | tee -a $out/summary.txt
   python3 tools/pmc_summary.py $out/pmc_$c/p_counter_collection.csv 60 > $out/pmc_${c}_summary.txt 2>&1
 done
-python3 tools/pmc_traffic.py $out/pmc_FETCH_SIZE/p_counter_collection.csv $out/pmc_WRITE_SIZE/p_counter_collection.csv $out/gemm_traffic.json 7
+python3 tools/pmc_traffic.py $out/pmc_FETCH_SIZE/p_counter_collection.csv $out/pmc_WRITE_SIZE/p_counter_collection.csv $out/gemm_traffic.json 7 $out/bench.json $tag
 for c in FETCH_SIZE WRITE_SIZE; do rm -f $out/pmc_$c/p_counter_collection.csv $out/pmc_$c/p_kernel_trace.csv; done
 python3 tools/ablate.py > $out/ablation.txt 2>&1
 python3 tools/attn_bench.py > $out/attn_bench.txt 2>&1
+python3 tools/gemm_census.py > $out/gemm_census.txt 2>&1
+python3 tools/load_batch_probe.py > $out/load_batch.txt 2>&1
+for w in C2 C3b C5; do python3 bench.py --workload $w --steps 10 --warmup 3 --cpu-steps 0 --no-roofline --no-extras 2>/dev/null | python3 -c "import json,sys; l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(\"$w %.3f ms/step %.0f pairs/s\" % (l[\"ms_per_step\"], l[\"value\"]))" >> $out/other_workloads.txt; done
 python3 tools/ln_bench.py > $out/ln_bench.txt 2>&1
 find $out -type f | xargs ls -la | head -40
 du -sh $out
