@@ -274,11 +274,11 @@ def main():
     pcie = None
     if extras and not opt.eager and world == 1:
         for _ in range(3):
-            gstep.load_batch(batch_cpu); gstep.run(redraw=True)
+            gstep.load_batch(batch_cpu, redraw=True); gstep.run(redraw=False)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         for _ in range(opt.steps):
-            gstep.load_batch(batch_cpu); gstep.run(redraw=True)
+            gstep.load_batch(batch_cpu, redraw=True); gstep.run(redraw=False)
         torch.cuda.synchronize()
         pdt = (time.perf_counter() - t2) / opt.steps
         hb = sum(v.numel() * v.element_size() for v in batch_cpu.values() if torch.is_tensor(v))

@@ -173,12 +173,13 @@ class GraphedStep:
         return total.detach(), {k: v.detach() for k, v in losses.items()}
 
     # ------------------------------------------------------------------ new batch, same graph
-    def load_batch(self, batch):
+    def load_batch(self, batch, redraw=False):
         """Make the captured step run on `batch` (host tensors; device tensors are brought to the host first,
         the plans are host work): same (N, Lv, Lw, Dv, Dt) and the same group sizes; GT-clip counts, group video
         lengths and target windows may differ within the capture-time capacities.  Everything small -- index
         plans, targets, masks, labels -- goes up in ONE pinned transfer (arena.Arena), the feature tensors in one
-        copy each.  Raises ValueError (nothing is modified) when it does not fit."""
+        copy each.  redraw: also draw new negatives / MLM words here (then call run(redraw=False): one upload per
+        step instead of two).  Raises ValueError (nothing is modified) when it does not fit."""
         groups = [int(g) for g in batch["num_clips"].tolist()]
         if groups != self._groups:
             raise ValueError("GraphedStep.load_batch: group sizes changed %s -> %s" % (self._groups, groups))
@@ -197,8 +198,9 @@ class GraphedStep:
         for k in ("norm_span", "norm_moment"):
             if isinstance(batch.get(k), list):
                 host[k] = [{kk: vv.detach().cpu() for kk, vv in d.items()} for d in batch[k]]
-        # keep the current host draws (redraw() replaces them)
-        arr, pmeta, tmeta, wm = self._host_arrays(host, self._draws[0], self._draws[1])
+        # keep the current host draws unless asked to redraw (plan_arrays draws when given None)
+        arr, pmeta, tmeta, wm = self._host_arrays(host, None if redraw else self._draws[0],
+                                                  None if redraw else self._draws[1])
         for k in ("vid_identity", "has_vid_src"):
             if pmeta.get(k) != self._pmeta.get(k):
                 raise ValueError("GraphedStep.load_batch: plan.%s changed (%r -> %r): needs its own graph"
@@ -206,6 +208,7 @@ class GraphedStep:
         self.arena.check(arr)
         # nothing above modified anything; from here on only copies
         self._arr = arr
+        self._draws = (arr["p.neg_index"], arr.get("p.masked_words"))
         self.arena.upload(arr)
         self.tplan.sizes, self.tplan.sumT = tmeta["sizes"], tmeta["sumT"]
         for k, cur in self.batch.items():
@@ -306,10 +309,10 @@ class StepCache:
         k = self.key(batch)
         for gs in self.steps.get(k, []):
             try:
-                gs.load_batch(batch)
+                gs.load_batch(batch, redraw=redraw)
             except ValueError:
                 continue
-            return gs.run(redraw=redraw), gs
+            return gs.run(redraw=False), gs
         if sum(len(v) for v in self.steps.values()) >= self.max_graphs:
             self.steps.pop(next(iter(self.steps)))
         from .synthetic import to_device
