@@ -121,6 +121,9 @@ def gemm(A, B, C, *, trans_a=False, trans_b=False, A2=None, B2=None, bias=None, 
     g.a_drop_p, g.a_drop_seed = float(a_drop[0]), int(a_drop[1]) & 0xFFFFFFFF
     g.b_drop_p, g.b_drop_seed = float(b_drop[0]), int(b_drop[1]) & 0xFFFFFFFF
     g.e_act, g.e_actgrad = e_act, e_actgrad
+    _check_drop_index(M * N, float(e_drop[0]))
+    _check_drop_index(M * K, float(a_drop[0]))
+    _check_drop_index(N * K, float(b_drop[0]))
     g.e_drop_p, g.e_drop_seed = float(e_drop[0]), int(e_drop[1]) & 0xFFFFFFFF
     g.out_scale = float(out_scale)
     g.accumulate, g.split_k = int(accumulate), int(split_k)
@@ -186,6 +189,7 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, drop=(0.0, 0), add=None):
     y = torch.empty_like(x2)
     mean = torch.empty(rows, device=x.device, dtype=torch.float32)
     rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    _check_drop_index(x2.numel(), float(drop[0]))
     y2 = None
     if add is not None:
         assert add.is_contiguous() and add.numel() == x2.numel()
@@ -286,6 +290,7 @@ def _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop, group=0, causal=Fals
         assert qpad is None
         a.mask_mode = MASK_CAUSAL
     a.scale = float(scale)
+    _check_drop_index(B * H * Lq * Lk, float(drop[0]))
     a.drop_p, a.drop_seed = float(drop[0]), int(drop[1]) & 0xFFFFFFFF
     a.seed_offset = _seed_off_ptr()
     a.mask_group = int(group)
@@ -389,9 +394,16 @@ def query_sine_bwd(ref, dout):
     return dref.view(ref.shape)
 
 
+def _check_drop_index(numel, p):
+    """every dropout site hashes a 32-bit element index: refuse tensors it would wrap on"""
+    if p > 0.0 and numel >= (1 << 32):
+        raise _lib.MesmError("dropout over %d elements: the counter-hash index is 32-bit" % numel)
+
+
 def dropout(x, p, seed, out=None):
     require_gpu(x)
     assert x.is_contiguous()
+    _check_drop_index(x.numel(), p)
     y = torch.empty_like(x) if out is None else out
     check(lib().mesm_dropout(ptr(x), ptr(y), x.numel(), float(p), int(seed) & 0xFFFFFFFF,
                              ptr(_seed_offset), stream_ptr()), "mesm_dropout")
@@ -478,12 +490,22 @@ def saliency_loss_bwd(s_pos, s_neg, label64, vmask, pos_idx, neg_idx, rank_coef,
     return ds_pos, ds_neg
 
 
+def _check_match_limits(Q, Tmax):
+    """The in-kernel assignment keeps its work arrays in LDS and the matched set in a 32-bit mask: say so here
+    instead of returning an opaque status code (the reference's scipy call has no such limits)."""
+    if Q > 32 or Tmax > 16 or Tmax > Q:
+        raise _lib.MesmError(
+            "Hungarian matching kernel: num_queries = %d (limit 32), target windows per pair = %d (limit 16 and "
+            "<= num_queries); the shipped configs use 10 queries and <= 5 windows (qvhighlights.py:148-150)" % (Q, Tmax))
+
+
 def match(logits, spans, tgt_cxw, tgt_xx, tgt_off, Tmax, w_span, w_giou, w_class, want_cost=False):
     """logits (N,Q,2), spans (N,Q,2), targets (sumT,2) x2, tgt_off (N+1) int32 ->
     match_q (sumT) int32 [, cost (N,Q,Tmax)]."""
     require_gpu(logits, spans, tgt_cxw, tgt_xx, tgt_off)
     N, Q, _ = logits.shape
     assert tgt_off.dtype == torch.int32
+    _check_match_limits(Q, Tmax)
     match_q = torch.empty(tgt_cxw.shape[0], device=logits.device, dtype=torch.int32)
     cost = torch.zeros(N, Q, Tmax, device=logits.device, dtype=torch.float32) if want_cost else None
     check(lib().mesm_match(ptr(logits.contiguous()), ptr(spans.contiguous()), ptr(tgt_cxw.contiguous()),
@@ -499,6 +521,7 @@ def set_loss_fwd(logits, spans, tgt_cxw, tgt_xx, tgt_off, Tmax, w_span, w_giou, 
     require_gpu(logits, spans, tgt_cxw, tgt_xx, tgt_off, out4)
     N, Q, _ = logits.shape
     assert logits.is_contiguous() and spans.is_contiguous() and tgt_off.dtype == torch.int32
+    _check_match_limits(Q, Tmax)
     match_q = torch.empty(tgt_cxw.shape[0], device=logits.device, dtype=torch.int32)
     check(lib().mesm_set_loss_fwd(ptr(logits), ptr(spans), ptr(tgt_cxw), ptr(tgt_xx), ptr(tgt_off), N, Q,
                                   int(Tmax), float(w_span), float(w_giou), float(w_class),

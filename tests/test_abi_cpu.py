@@ -57,3 +57,16 @@ def test_product_path_refuses_cpu_tensors():
     from mesm_amd import kernels as kn
     with pytest.raises(Exception):
         kn.layernorm_fwd(torch.zeros(4, 8), torch.ones(8), torch.zeros(8))
+
+
+def test_limits_are_reported_in_words():
+    """shapes the kernels cannot take raise a MesmError that says why (not a bare status code)."""
+    from mesm_amd import _lib
+    from mesm_amd import kernels as kn
+    kn._check_match_limits(10, 5)
+    for q, t in ((40, 3), (10, 17), (4, 5)):
+        with pytest.raises(_lib.MesmError, match="Hungarian matching kernel"):
+            kn._check_match_limits(q, t)
+    kn._check_drop_index(1 << 33, 0.0)
+    with pytest.raises(_lib.MesmError, match="32-bit"):
+        kn._check_drop_index(1 << 32, 0.1)
