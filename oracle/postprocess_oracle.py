@@ -10,7 +10,8 @@ Restates, in plain PyTorch-CPU / Python, how the reference turns model outputs i
                                                   score to 4 decimals
     /root/reference/utils/span_utils.py:26-42     span_cxw_to_xx
 
-Pinned by tests/golden/windows.npz, generated by tools/gen_golden_windows.py from the real reference.
+Pinned by tests/golden/mr_results.json: rows the real eval.compute_mr_results + PostProcessorDETR produced
+when driven with a stub model (tools/gen_golden_io.py).
 """
 import torch
 import torch.nn.functional as F
