@@ -1529,6 +1529,186 @@ int launch_wstage64(const MesmGemmArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// "wtall": the k-split idea on a TALL tile of RB x 1 blocks of 32 x 32 (RB = 3: 96 x 32).
+// The step's 2400 = 75 x 32 row activations with d = 256 columns make 152 workgroups of 64 x 64 (59 % of
+// one round); 96 x 32 makes 25 x 8 = 200, every workgroup the same size.  Each of
+// the four waves computes the whole tile over its quarter of the reduce range (RB accumulators), staged
+// wave-privately by LDS-DMA exactly like wstage64; the partial tiles meet in LDS and wave w takes
+// accumulator registers [4w, 4w + 4) of every block through the staged epilogue.
+template <int LA, int LB, bool XF, int RB>
+__device__ __forceinline__ void wtall_body(const MesmGemmArgs& p, const Blk blk, float* L) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  const int m0 = blk.x * (32 * RB), n0 = blk.y * 32;
+
+  const int KM = gemm_kmain(p);
+  int kbeg = 0, kend = KM;
+  if (p.split_k > 1) {
+    int chunk = (p.K + p.split_k - 1) / p.split_k;
+    chunk = ((chunk + BK_MAX - 1) / BK_MAX) * BK_MAX;
+    kbeg = blk.z * chunk;
+    kend = kbeg + chunk < KM ? kbeg + chunk : KM;
+    if (kbeg >= KM) {
+      if (blk.z > 0) return;
+      kbeg = kend = KM;
+    }
+  }
+  const int kw = (((kend - kbeg + 3) >> 2) + 31) & ~31;
+  const int k0 = kbeg + wave * kw;
+  const int k1 = k0 + kw < kend ? k0 + kw : kend;
+  const int nst = k1 > k0 ? (k1 - k0 + 31) >> 5 : 0;
+
+  const float slope = p.slope ? *p.slope : 0.0f;
+  const uint32_t seed_off = p.seed_offset ? *p.seed_offset : 0u;
+  XForm xa, xb;
+  xa.act = p.a_act; xa.slope = slope; xa.thresh = p.a_drop_p > 0.f ? mesm_drop_threshold(p.a_drop_p) : 0u;
+  xa.seed = p.a_drop_seed + seed_off; xa.inv_keep = 1.0f / (1.0f - p.a_drop_p);
+  xa.lld = LA == MESM_LAYOUT_REDUCE_CONTIG ? p.K : p.M;
+  xb.act = p.b_act; xb.slope = slope; xb.thresh = p.b_drop_p > 0.f ? mesm_drop_threshold(p.b_drop_p) : 0u;
+  xb.seed = p.b_drop_seed + seed_off; xb.inv_keep = 1.0f / (1.0f - p.b_drop_p);
+  xb.lld = LB == MESM_LAYOUT_REDUCE_CONTIG ? p.K : p.N;
+
+  float* mine = L + wave * ((RB + 1) * WS_SLAB);  // RB slabs of A rows, one slab of B rows
+  auto issue = [&](int st) {
+    const int kb = k0 + 32 * st;
+#pragma unroll
+    for (int t = 0; t < RB; ++t) ws_issue<LA>(p.A, p.lda, m0 + 32 * t, p.M, kb, k1, mine + t * WS_SLAB, lane);
+    ws_issue<LB>(p.B, p.ldb, n0, p.N, kb, k1, mine + RB * WS_SLAB, lane);
+  };
+
+  f32x16 acc[RB];
+#pragma unroll
+  for (int i = 0; i < RB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+  if (nst > 0) issue(0);
+  for (int st = 0; st < nst; ++st) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float a[RB][4][4], b[4][4];
+#pragma unroll
+    for (int t = 0; t < RB; ++t) ws_read<LA>(mine + t * WS_SLAB, li, h, a[t]);
+    ws_read<LB>(mine + RB * WS_SLAB, li, h, b);
+    const int kb = k0 + 32 * st;
+    if (st + 1 < nst) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments are in registers: refill the slabs
+      issue(st + 1);
+    }
+    if (kb + 32 > k1) {
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool ok = kb + 8 * s_ + 4 * h + j < k1;
+#pragma unroll
+          for (int t = 0; t < RB; ++t) a[t][s_][j] = ok ? a[t][s_][j] : 0.0f;
+          b[s_][j] = ok ? b[s_][j] : 0.0f;
+        }
+    }
+    if (XF) {
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int gk = kb + 8 * s_ + 4 * h + j;
+#pragma unroll
+          for (int t = 0; t < RB; ++t) {
+            const int gm = m0 + 32 * t + li;
+            float x = mesm_act(a[t][s_][j], xa.act, xa.slope);
+            if (xa.thresh)
+              x = mesm_dropout_apply(x, (uint32_t)(LA == MESM_LAYOUT_REDUCE_CONTIG ? (int64_t)gm * xa.lld + gk : (int64_t)gk * xa.lld + gm),
+                                     xa.seed, xa.thresh, xa.inv_keep);
+            a[t][s_][j] = x;
+          }
+          const int gn = n0 + li;
+          float y = mesm_act(b[s_][j], xb.act, xb.slope);
+          if (xb.thresh)
+            y = mesm_dropout_apply(y, (uint32_t)(LB == MESM_LAYOUT_REDUCE_CONTIG ? (int64_t)gn * xb.lld + gk : (int64_t)gk * xb.lld + gn),
+                                   xb.seed, xb.thresh, xb.inv_keep);
+          b[s_][j] = y;
+        }
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < RB; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][s_][j], b[s_][j], acc[t], 0, 0, 0);
+  }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+
+  __syncthreads();  // every wave is done with its slabs: the reduction buffer aliases them
+  // Red[w][t][r][lane]; wave w afterwards owns registers [4w, 4w + 4) of every block: rows 4h + 8w + i
+  // NOTE: a wave's own partial stays in registers (three quarters of the LDS traffic)
+#pragma unroll
+  for (int t = 0; t < RB; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if ((r >> 2) != wave) L[((wave * RB + t) * 16 + r) * 64 + lane] = acc[t][r];
+  __syncthreads();
+  constexpr int NV = 4 * RB;
+  float vals[NV];
+#pragma unroll
+  for (int t = 0; t < RB; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float own = 0.0f;
+      // acc[t][4 * wave + i] with a wave-uniform dynamic index: select instead of scratch
+#pragma unroll
+      for (int w = 0; w < 4; ++w) own = (w == wave) ? acc[t][4 * w + i] : own;
+      float sum = own;
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+        if (w != wave) sum += L[((w * RB + t) * 16 + 4 * wave + i) * 64 + lane];
+      vals[4 * t + i] = sum;
+    }
+  __syncthreads();  // dslope_store reuses the head of L
+  const bool first_split = (p.split_k <= 1) || (blk.z == 0);
+  const int rbase = m0 + 4 * h + 8 * wave;
+  auto RO = [](int i) { return (i & 3) + 32 * (i >> 2); };
+  if (first_split && KM < p.K) tail_accumulate<NV, LA, LB, XF>(p, vals, rbase, n0 + li, KM, xa, xb, RO);
+  float dslope_part;
+  if (m0 + 32 * RB <= p.M && n0 + 32 <= p.N)
+    dslope_part = staged_epilogue<NV, true>(p, vals, rbase, n0 + li, slope, seed_off, first_split, RO);
+  else
+    dslope_part = staged_epilogue<NV, false>(p, vals, rbase, n0 + li, slope, seed_off, first_split, RO);
+  if (p.e_actgrad == MESM_ACT_PRELU && p.dslope) dslope_store(p, dslope_part, L, blk.slot);
+}
+
+template <int LA, int LB, bool XF, int RB>
+__global__ __launch_bounds__(NTHREADS) void gemm_wtall_kernel(const MesmGemmArgs p) {
+  __shared__ __attribute__((aligned(16))) float L[4 * (RB + 1) * WS_SLAB];  // RB = 5: 96 KB, RB = 3: 64 KB
+  Blk blk;
+  xcd_tile(blockIdx.x, (p.M + 32 * RB - 1) / (32 * RB), (p.N + 31) / 32, blk.x, blk.y);
+  blk.z = blockIdx.z; blk.slot = linear_block();
+  wtall_body<LA, LB, XF, RB>(p, blk, L);
+}
+
+template <int LA, int LB, int RB>
+int launch_wtall_l(const MesmGemmArgs& a, hipStream_t s) {
+  dim3 grid(((a.M + 32 * RB - 1) / (32 * RB)) * ((a.N + 31) / 32), 1, a.split_k > 1 ? a.split_k : 1);
+  const bool xf = a.a_act != MESM_ACT_NONE || a.b_act != MESM_ACT_NONE || a.a_drop_p > 0.f || a.b_drop_p > 0.f;
+  if (xf) hipLaunchKernelGGL((gemm_wtall_kernel<LA, LB, true, RB>), grid, dim3(NTHREADS), 0, s, a);
+  else hipLaunchKernelGGL((gemm_wtall_kernel<LA, LB, false, RB>), grid, dim3(NTHREADS), 0, s, a);
+  const int rc = mesm_launch_status();
+  return rc != MESM_OK ? rc : dslope_finish(a, grid, s);
+}
+
+template <int RB>
+int launch_wtall(const MesmGemmArgs& a, hipStream_t s) {
+  constexpr int R = MESM_LAYOUT_REDUCE_CONTIG, O = MESM_LAYOUT_OUTER_CONTIG;
+  if (a.a_layout == R && a.b_layout == R) return launch_wtall_l<R, R, RB>(a, s);
+  if (a.a_layout == R && a.b_layout == O) return launch_wtall_l<R, O, RB>(a, s);
+  if (a.a_layout == O && a.b_layout == O) return launch_wtall_l<O, O, RB>(a, s);
+  return launch_wtall_l<O, R, RB>(a, s);
+}
+
+// wtall has no column-sum output (the bias-gradient side product of the weight-gradient GEMMs)
+bool wtall_ok(const MesmGemmArgs& a) { return wstage_ok(a) && a.colsum == nullptr; }
+
+// ------------------------------------------------------------------------------------------------
 // "lds64" kernel for the large GEMMs of the step (FFN 4800 x 1024 x 256 and transposes, the 2818-wide
 // input projections, the vocabulary head): 64 x 64 tile, 2 x 2 waves of 32 x 32, k-tiles of 32 staged
 // by LDS-DMA in full 128-byte lines into a 3-deep ring (48 KB: three workgroups per CU), ONE raw
@@ -1858,6 +2038,15 @@ int dispatch(const MesmGemmArgs& a, int vec, hipStream_t s) {
     // 1 = frag, 2 = wstage (k-split 32x32, wave-private LDS-DMA), 3 = lds64 (64x64, LDS-DMA ring),
     // 4 = wstage64 (k-split 64x64),
     // 32 | 64 | 128 = register-staged tile, 0 = auto
+    // tall 96 x 32 k-split tiles: the 2400-row, 256-wide GEMMs with a long reduce range (2400 x 256 x 2818 input
+    // projections 52 -> 43 us, x 1024 22.3 -> 19.2, x 512 13.4 -> 12.7): 25 x 8 = 200 equal workgroups in one
+    // round instead of 152.  (160 x 32 on the 4800-row GEMMs measured no gain: 14.1 vs 13.2 us at K = 256 --
+    // those are bound by launch + first-load + epilogue latency, not by the second round of tiles.)
+    {
+      const long t96 = (long)((a.M + 95) / 96) * ((a.N + 31) / 32);
+      if ((force == 6 || (force == 0 && z == 1 && a.K >= 512 && t96 >= 160 && t96 <= 256)) && wtall_ok(a))
+        return launch_wtall<3>(a, s);
+    }
     if ((force == 3 || (force == 0 && b64 >= 512)) && wstage_ok(a)) return launch_lds64(a, s);
     // k-split 64 x 64 (half the L2 traffic per flop): wins only when its workgroups fit ONE round on the
     // 256 CUs (300 workgroups = two rounds: 4800 x 256 x 1024 59 us vs 43 us with 32 x 32 tiles) and a

@@ -54,7 +54,9 @@ class GraphedStep:
         self.batch = dict(batch)  # static inputs: big tensors as given, everything small re-homed in the arena
         self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
         self.reducer = reducer
-        model.train()
+        # the step is captured in the model's CURRENT mode (train(): dropout on, fresh masks every replay;
+        # eval(): dropout off, e.g. to reproduce a recorded step) -- like the reference's loop, which calls
+        # model.train() itself (train.py:53)
         model.flat_params()
         self._groups = [int(g) for g in batch["num_clips"].tolist()]
         self.caps = self._resolve_caps(caps, batch)

@@ -8,6 +8,10 @@ import torch
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = ["charades_tiny", "qvh_tiny", "tacos_tiny"]
 CLIP_CASES = ["qvh_clip_tiny"]  # reference built with tokenizer_type="CLIP" (fp16 text tower, token ids in)
+# tools/gen_golden_variants.py: the switches no shipped config flips (FW-MESM / SS-MESM off, no auxiliary losses,
+# other layer counts and projection depths), run through the real reference at a very small width
+VARIANTS = ["variants/" + n for n in ("qvh_plain", "qvh_fw_only", "qvh_ss_only", "cha_plain", "cha_ss_only",
+                                      "qvh_no_aux", "qvh_depths", "cha_proj1")]
 
 
 class Fixture:
@@ -21,7 +25,7 @@ class Fixture:
         self.losses = {k[5:]: float(z[k]) for k in z.files if k.startswith("loss.")}
         self.match = {k[6:]: torch.from_numpy(z[k].copy()) for k in z.files if k.startswith("match.")}
         self.neg_index = torch.from_numpy(z["neg_index"].copy())
-        self.masked_words = torch.from_numpy(z["masked_words"].copy()).bool()
+        self.masked_words = torch.from_numpy(z["masked_words"].copy()).bool() if "masked_words" in z.files else None
         batch = {}
         for k in z.files:
             if not k.startswith("batch."):

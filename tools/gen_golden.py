@@ -65,11 +65,11 @@ def flatten_targets(batch):
     return flat
 
 
-def run_case(name, spec):
+def run_case(name, spec, tiny=None, out_dir=None):
     spec = dict(spec)
     ragged, seed = spec.pop("ragged"), spec.pop("seed")
     groups, Lv, Lw = spec.pop("groups"), spec.pop("Lv"), spec.pop("Lw")
-    over = dict(TINY)
+    over = dict(TINY if tiny is None else tiny)
     over.update(spec)
     args = synthetic.make_args(None, **over)
     torch.manual_seed(seed)
@@ -114,7 +114,7 @@ def run_case(name, spec):
         # matcher indices of the final layer and of the aux layer, for the record
         with torch.no_grad():
             idx_main = crit.matcher({k: v for k, v in outputs.items() if k != "aux_outputs"}, batch)
-            idx_aux = [crit.matcher(a, batch) for a in outputs["aux_outputs"]]
+            idx_aux = [crit.matcher(a, batch) for a in outputs.get("aux_outputs", [])]
     finally:
         ref_model_mod.sample_outclass_neg = orig_neg
 
@@ -135,11 +135,12 @@ def run_case(name, spec):
             blob["grad." + k] = p.grad.detach().numpy()
     blob.update(flatten_targets(batch))
     blob["neg_index"] = rec["neg_index"].numpy()
-    blob["masked_words"] = rec["masked_words"].numpy()
+    if "masked_words" in rec:  # drawn by the MLM branch only (rec_fw)
+        blob["masked_words"] = rec["masked_words"].numpy()
     for k, v in outputs.items():
         if isinstance(v, torch.Tensor):
             blob["out." + k] = v.detach().numpy()
-    for i, a in enumerate(outputs["aux_outputs"]):
+    for i, a in enumerate(outputs.get("aux_outputs", [])):
         for k, v in a.items():
             blob["out.aux%d.%s" % (i, k)] = v.detach().numpy()
     for k, v in losses.items():
@@ -153,8 +154,9 @@ def run_case(name, spec):
     cfg = dict(vars(args))
     cfg.update(groups=groups, Lv=Lv, Lw=Lw)
     blob["cfg.json"] = np.frombuffer(__import__("json").dumps(cfg).encode(), dtype=np.uint8)
-    os.makedirs(OUT, exist_ok=True)
-    path = os.path.join(OUT, name + ".npz")
+    out_dir = out_dir or OUT
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(out_dir, name + ".npz")
     np.savez_compressed(path, **blob)
     print("%s: total loss %.6f, %d tensors, %.1f KB" % (name, float(total), len(blob),
                                                        os.path.getsize(path) / 1024))
