@@ -36,14 +36,23 @@ def _scope(name):
 
 
 class TrainablePositionalEncoding(nn.Module):
-    """position_encoding.py:10-32.  Built for state_dict compatibility; bypassed while
-    use_txt_pos=False (model.py:169-172), like in the reference."""
+    """position_encoding.py:10-32: dropout(LayerNorm(x + E[0:L])).  Bypassed while use_txt_pos=False
+    (model.py:169-172, every shipped config), like in the reference."""
 
     def __init__(self, max_pos, d, dropout):
         super().__init__()
         self.position_embeddings = nn.Embedding(max_pos, d)
         self.LayerNorm = ParamLayerNorm(d)
         self.p = dropout
+
+    def forward(self, x):
+        L = x.shape[1]
+        if L > self.position_embeddings.num_embeddings:
+            raise IndexError("txt_position_embed: %d positions, sequence of %d"
+                             % (self.position_embeddings.num_embeddings, L))  # nn.Embedding's own error class
+        ln = self.LayerNorm
+        return ops.layer_norm(x + self.position_embeddings.weight[:L], ln.weight, ln.bias,
+                              drop=drop_state.next(self.p))
 
 
 class SegSenRecon(nn.Module):
@@ -83,8 +92,6 @@ class MESM(nn.Module):
         super().__init__()
         if text_encoder is not None and not isinstance(text_encoder, (CLIPTextEncoder, GloveTextEncoder)):
             raise NotImplementedError("text_encoder must be a mesm_amd CLIPTextEncoder / GloveTextEncoder or None")
-        if use_txt_pos:
-            raise NotImplementedError("use_txt_pos=True is not used by any shipped config")
         if span_loss_type != "l1":
             raise NotImplementedError("span_loss_type 'ce' raises in the reference as well")
         self.text_encoder = text_encoder  # frozen (model.py:30-33)
@@ -377,6 +384,8 @@ class MESM(nn.Module):
             pv = self._proj(self.input_vid_proj, video_feat)
             pw = self._proj(self.input_txt_proj, words)
             vpos = kn.sine_pos(video_mask, d)
+            tpos = self.txt_position_embed(pw) if self.use_txt_pos else None  # model.py:169-172
+            defer_enhance = False
 
         # The positive and the negative pass (model.py:260-299) run the SAME weights over the same
         # video with different queries: they are stacked along the batch (rows [0, N) positive,
@@ -393,11 +402,16 @@ class MESM(nn.Module):
             pv2, vpos2, vid_pad2, pw2, wpad2 = ops.stack_rows([pv, vpos, vid_pad, pw, words_pad], [0, 0, 0, 1, 1], ni)
             pvp2 = kn.add_wrap(pv2, vpos2) if not pv2.requires_grad else _AddPos.apply(pv2, vpos2)
             if self.rec_fw:
+                tpos2 = None
+                if self.use_txt_pos and not self.rec_ss:
+                    tpos2 = ops.stack_rows([tpos], [1], ni)[0]  # txt_position ; txt_position[neg_index]
+                elif self.use_txt_pos:
+                    defer_enhance = True  # the negative half takes positions 1.. of the EXPANDED words (below)
                 # every block hands its output + position embedding to the next one (second output of its last
                 # LayerNorm), so only this very first query is formed by an element-wise launch
-                enhanced2, enhanced2_p = enc(pw2, pv2, None, vpos2, wpad2, vid_pad2, group=N, vid_p=pvp2,
-                                             out_pos=vpos2)
-                enhanced = enhanced2[:N]
+                enhanced2, enhanced2_p = (None, None) if defer_enhance else \
+                    enc(pw2, pv2, tpos2, vpos2, wpad2, vid_pad2, group=N, vid_p=pvp2, out_pos=vpos2)
+                enhanced = enhanced2[:N] if not defer_enhance else None
             else:
                 enhanced2, enhanced2_p = pv2, pvp2
                 enhanced = pv
@@ -431,8 +445,21 @@ class MESM(nn.Module):
                 epad = words_pad
 
         with _scope("t2v"):
-            ewords2, epad2 = ops.stack_rows([ewords, epad], [1, 1], ni)
-            encoded2 = self.t2v_encoder(ewords2, enhanced2, None, vpos2, epad2, vid_pad2, group=N, vid_p=enhanced2_p)
+            if self.use_txt_pos:
+                # expanded_txt_position (model.py:225-226) and its negative gather (:263); with the sentence token in
+                # front the negative words of the enhance stage keep positions 1.. of it (:267), so that stage
+                # could not run before the SS branch
+                etpos = self.txt_position_embed(ewords)
+                ewords2, epad2, etpos2 = ops.stack_rows([ewords, epad, etpos], [1, 1, 1], ni)
+                if defer_enhance:
+                    tpos2 = torch.cat([tpos, etpos2[N:, 1:]], 0)
+                    enhanced2, enhanced2_p = enc(pw2, pv2, tpos2, vpos2, wpad2, vid_pad2, group=N, vid_p=pvp2,
+                                                 out_pos=vpos2)
+                    enhanced = enhanced2[:N]
+            else:
+                ewords2, epad2 = ops.stack_rows([ewords, epad], [1, 1], ni)
+                etpos2 = None
+            encoded2 = self.t2v_encoder(ewords2, enhanced2, etpos2, vpos2, epad2, vid_pad2, group=N, vid_p=enhanced2_p)
         with _scope("transformer"):
             hs, refs, memory2, memory_g2 = self.transformer(
                 encoded2, vid_pad2, self.query_embed.weight, vpos2, self.global_rep_token,
@@ -468,7 +495,7 @@ class MESM(nn.Module):
                     # (model.py:312-325)
                     cfeat = ops.gather_rows2(pv_.reshape(N * Lv, d), plan.clip_src, plan.clip_inv, plan.clip_mask)
                     cpos = kn.gather_rows_fwd(vpos.reshape(N * Lv, d), plan.clip_src, plan.clip_mask)[0]
-                    rec_w = enc(cfeat, w, cpos, None, plan.clip_pad, words_pad, is_mlm=True)
+                    rec_w = enc(cfeat, w, cpos, tpos, plan.clip_pad, words_pad, is_mlm=True)  # pos_vid = txt_position
                     hid = self.output_txt_proj[0](rec_w)
                     head = self.output_txt_proj[1]
                     return ops.linear(hid, head.weight, head.bias)

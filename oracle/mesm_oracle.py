@@ -343,8 +343,17 @@ def mesm_forward(sd, cfg, batch, neg_index, masked_words=None, is_training=True)
     pv = linear_layer_stack(video_feat, sd, "input_vid_proj", nproj, relu_flags)
     pw = linear_layer_stack(words, sd, "input_txt_proj", nproj, relu_flags)
     vpos = sine_position(video_mask, d)
-    tpos = torch.zeros_like(pw)  # use_txt_pos = False in every shipped config
-    assert not cfg.get("use_txt_pos", False)
+    use_tpos = cfg.get("use_txt_pos", False)  # False in every shipped config
+
+    def txt_position(x):
+        """TrainablePositionalEncoding.forward (position_encoding.py:19-32; dropout off): LN(x + E[0:L])"""
+        if not use_tpos:
+            return torch.zeros_like(x)  # model.py:171-172, 227-228
+        e = sd["txt_position_embed.position_embeddings.weight"][:x.shape[1]]
+        return F.layer_norm(x + e[None], (d,), sd["txt_position_embed.LayerNorm.weight"],
+                            sd["txt_position_embed.LayerNorm.bias"], 1e-5)
+
+    tpos = txt_position(pw)
 
     def enhance(txt, vid, txt_pad, vid_pad, ptxt, pvid, mlm=False):
         return t2v_stack(txt, vid, ptxt, pvid, txt_pad, vid_pad, sd, "enhance_encoder.t2v_encoder",
@@ -387,7 +396,7 @@ def mesm_forward(sd, cfg, batch, neg_index, masked_words=None, is_training=True)
         emask = torch.cat([torch.ones(n, 1, dtype=torch.bool), words_mask], 1)
     else:
         ewords, emask = pw, words_mask
-    epos = torch.zeros_like(ewords)
+    epos = txt_position(ewords)  # model.py:225-228 (of the EXPANDED words: the sentence token takes index 0)
 
     def align(txt, vid, txt_pad, ptxt):
         return t2v_stack(txt, vid, ptxt, vpos, txt_pad, ~video_mask, sd, "t2v_encoder.t2v_encoder",
@@ -399,14 +408,14 @@ def mesm_forward(sd, cfg, batch, neg_index, masked_words=None, is_training=True)
     spans = torch.sigmoid(mlp(hs, sd, "span_embed", 3) + inverse_sigmoid(refs))
 
     # negative pass (model.py:260-299); its decoder output is discarded (:295)
-    n_ewords, n_emask = ewords[neg_index], emask[neg_index]
+    n_ewords, n_emask, n_epos = ewords[neg_index], emask[neg_index], epos[neg_index]
     if cfg["rec_ss"]:
-        n_words, n_wmask = n_ewords[:, 1:], n_emask[:, 1:]
+        # (the negative words keep the positions 1.. of the expanded sequence, model.py:263-267)
+        n_words, n_wmask, n_tpos = n_ewords[:, 1:], n_emask[:, 1:], n_epos[:, 1:]
     else:
-        n_words, n_wmask = n_ewords, n_emask
-    n_enh = enhance(n_words, pv, ~n_wmask, ~video_mask, torch.zeros_like(n_words), vpos) \
-        if cfg["rec_fw"] else pv
-    n_enc = align(n_ewords, n_enh, ~n_emask, torch.zeros_like(n_ewords))
+        n_words, n_wmask, n_tpos = n_ewords, n_emask, n_epos
+    n_enh = enhance(n_words, pv, ~n_wmask, ~video_mask, n_tpos, vpos) if cfg["rec_fw"] else pv
+    n_enc = align(n_ewords, n_enh, ~n_emask, n_epos)
     _, _, n_memory, n_memory_g = detr_transformer(n_enc, video_mask, vpos, sd, cfg, run_decoder=False)
 
     def saliency(mem, mem_g):

@@ -11,7 +11,8 @@ CLIP_CASES = ["qvh_clip_tiny"]  # reference built with tokenizer_type="CLIP" (fp
 # tools/gen_golden_variants.py: the switches no shipped config flips (FW-MESM / SS-MESM off, no auxiliary losses,
 # other layer counts and projection depths), run through the real reference at a very small width
 VARIANTS = ["variants/" + n for n in ("qvh_plain", "qvh_fw_only", "qvh_ss_only", "cha_plain", "cha_ss_only",
-                                      "qvh_no_aux", "qvh_depths", "cha_proj1")]
+                                      "qvh_no_aux", "qvh_depths", "cha_proj1", "qvh_txt_pos",
+                                      "cha_txt_pos_fw_only")]
 
 
 class Fixture:

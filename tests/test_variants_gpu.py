@@ -59,7 +59,7 @@ def test_graph_replay_of_a_variant_equals_eager():
     """the captured step (arena plan, static buffers) on a model without the MLM / SS branches"""
     from mesm_amd import synthetic
     from mesm_amd.graphed import GraphedStep
-    for name in ("variants/qvh_plain", "variants/cha_ss_only", "variants/qvh_no_aux"):
+    for name in ("variants/qvh_plain", "variants/cha_ss_only", "variants/qvh_no_aux", "variants/qvh_txt_pos"):
         fx = Fixture(name)
         args, model, crit = build(fx.cfg, fx.sd)
         model.eval()  # dropout off; is_training=True keeps the MLM branch where the config has one
@@ -71,3 +71,16 @@ def test_graph_replay_of_a_variant_equals_eager():
         assert abs(total - fx.losses["total"]) < TOL * max(1.0, abs(fx.losses["total"])), (name, total)
         worst = max((rel(p.grad, fx.grads[n]), n) for n, p in model.named_parameters() if n in fx.grads)
         assert worst[0] < 5 * TOL, (name, worst)
+
+
+@pytest.mark.parametrize("name", VARIANTS)
+def test_train_mode_step_is_finite_and_touches_the_same_parameters(name):
+    """dropout on (no reference values to compare with): the step runs, stays finite, and the set of parameters
+    that receive a gradient is the reference's"""
+    fx = Fixture(name)
+    args, model, crit = build(fx.cfg, fx.sd)
+    out, losses, total = run_step(model, crit, fx.batch, fx.cfg, fx.neg_index, fx.masked_words, train=True)
+    assert torch.isfinite(total)
+    grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    assert set(grads) == set(fx.grads), sorted(set(grads) ^ set(fx.grads))
+    assert all(bool(torch.isfinite(g).all()) for g in grads.values())

@@ -32,10 +32,15 @@ VARIANTS = {
     "qvh_depths": dict(QVH, t2v_layers=1, enc_layers=3, dec_layers=3, num_recfw_layers=1, num_recss_layers=1,
                        n_input_proj=3, seed=27),
     "cha_proj1": dict(CHA, n_input_proj=1, dec_layers=1, share_MLP=False, seed=28),
+    # trainable text positions (model.py:169-170, 225-226, 263-267, 330): with and without the sentence token
+    "qvh_txt_pos": dict(QVH, use_txt_pos=True, seed=29),
+    "cha_txt_pos_fw_only": dict(CHA, use_txt_pos=True, rec_ss=False, share_MLP=False, seed=30),
 }
 
 if __name__ == "__main__":
     torch.set_num_threads(4)
     out = os.path.join(G.OUT, "variants")
+    only = sys.argv[1:]
     for name, spec in VARIANTS.items():
-        G.run_case(name, spec, tiny=WEE, out_dir=out)
+        if not only or name in only:
+            G.run_case(name, spec, tiny=WEE, out_dir=out)
