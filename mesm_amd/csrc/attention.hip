@@ -14,6 +14,8 @@
 // query rows (P is recomputed from the saved log-sum-exp).  dQ rows are reduced over
 // lanes through LDS and written (single key tile) or added atomically (several tiles).
 #include "common.hpp"
+#include "attention_mfma.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -460,6 +462,9 @@ extern "C" int mesm_attn_fwd(const MesmAttnArgs* args, void* stream) {
   int rc = check_common(a);
   if (rc != MESM_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
+  // the step's hot shapes run on the matrix cores (MESM_ATTN_LEGACY=1: this file's lane-per-key kernels, for A/B)
+  static const bool legacy = getenv("MESM_ATTN_LEGACY") != nullptr;
+  if (!legacy && mesm_attn_mfma_ok(a)) return mesm_attn_mfma_fwd(a, s);
   dim3 grid(a.B * a.H, (a.Lq + QCH - 1) / QCH);
   ATTN_DISPATCH(attn_fwd_kernel, grid, AT_THREADS);
   return mesm_launch_status();

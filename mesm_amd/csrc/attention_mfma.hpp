@@ -1,0 +1,6 @@
+// attention_mfma.hip: matrix-core attention for dk = dv = 32, Lk <= 128 (see the file header)
+#pragma once
+#include "common.hpp"
+
+bool mesm_attn_mfma_ok(const MesmAttnArgs& a);
+int mesm_attn_mfma_fwd(const MesmAttnArgs& a, hipStream_t s);

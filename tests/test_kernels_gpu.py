@@ -253,6 +253,14 @@ ATTN_CASES = [
     (3, 4, 7, 300, 8, 8, True, True),
     (2, 8, 130, 513, 32, 32, True, False),
     (5, 4, 9, 20, 16, 8, True, False),
+    # matrix-core kernels (dk = dv = 32, Lk <= 128): MLM shape, one query row, ragged last blocks, the Lk limit
+    (32, 8, 33, 75, 32, 32, True, True),
+    (6, 8, 1, 75, 32, 32, True, False),
+    (3, 4, 100, 128, 32, 32, True, True),
+    (3, 4, 65, 129, 32, 32, True, True),
+    (2, 2, 40, 2, 32, 32, False, False),
+    (4, 8, 75, 36, 32, 32, True, True),
+    (4, 8, 20, 67, 32, 32, True, False),
 ]
 
 
