@@ -146,7 +146,7 @@ def test_gemm_dropout_matches_materialised_mask():
     assert rel_err(dX, full * mask) < TOL
 
 
-@pytest.mark.parametrize("tile", ["0", "1", "2", "3", "4", "32", "64"])
+@pytest.mark.parametrize("tile", ["0", "1", "2", "3", "4", "6", "32", "64"])
 @pytest.mark.parametrize("M,N,K", [(2400, 256, 256), (190, 132, 300), (130, 70, 262), (66, 129, 35)])
 def test_gemm_operand_dropout_uses_the_stored_index(tile, M, N, K, monkeypatch):
     """The mask an epilogue wrote on Y (index row*N + col) is replayed when dY is an operand:
@@ -613,7 +613,7 @@ def test_gemm_group_matches_individual_launches():
                     assert rel_err(y, x) < 1e-4
 
 
-@pytest.mark.parametrize("tile", ["0", "2", "3", "4"])
+@pytest.mark.parametrize("tile", ["0", "2", "3", "4", "6"])
 def test_gemm_reference_widths_on_the_lds_dma_kernels(tile, monkeypatch):
     """Dv = 2818 and the 5003-word vocabulary: rows 8- / 4-byte aligned, K % 4 = 2 / 3, outer extents that
     are not multiples of 4 -- forward, input-gradient and weight-gradient forms, plus strided views."""
@@ -641,7 +641,7 @@ def test_gemm_reference_widths_on_the_lds_dma_kernels(tile, monkeypatch):
         assert rel_err(Y, Xv.double() @ W[:, 1:wide - 2].double().t()) < TOL
 
 
-@pytest.mark.parametrize("tile", ["0", "2", "3", "4"])
+@pytest.mark.parametrize("tile", ["0", "2", "3", "4", "6"])
 def test_gemm_tiny_reduce_ranges_on_the_lds_dma_kernels(tile, monkeypatch):
     """K of 4..9 with outer extents that are not multiples of 4: the MFMA loop may be EMPTY (gemm_kmain = 0)
     and everything comes from the scalar tail, alone or split over k-slices, with bias column sums."""
@@ -665,10 +665,11 @@ def test_gemm_tiny_reduce_ranges_on_the_lds_dma_kernels(tile, monkeypatch):
                     assert rel_err(cs, (A.t() if ta else A).double().sum(1)) < TOL, (K, M, N, ta, tb, "colsum")
 
 
-@pytest.mark.parametrize("tile", ["1", "2", "3", "4"])
+@pytest.mark.parametrize("tile", ["1", "2", "3", "4", "6"])
 def test_gemm_fuzz_forced_kernel(tile, monkeypatch):
     """The same fuzz with every launch forced onto one of the small-problem / LDS-DMA kernels
-    (1 = register fragments, 2 = wave-private LDS-DMA k-split, 3 = 64x64 LDS-DMA ring, 4 = 64x64 k-split); launches a
+    (1 = register fragments, 2 = wave-private LDS-DMA k-split, 3 = 64x64 LDS-DMA ring, 4 = 64x64 k-split,
+    6 = tall 96x32 k-split); launches a
     kernel cannot take (addend operands, unaligned rows) fall through to the auto dispatch."""
     import random
     from mesm_amd import kernels as kn
