@@ -5,7 +5,10 @@
 // and fp32 VALU have the same peak on this chip: the matrix cores buy fewer instructions and no cross-lane
 // traffic, not flops.  A matrix-core backward -- (query block, key block) pairs per wave, dQ / dK / dV summed in LDS
 // -- measured 27 / 37 us at 75 x 33 / 76 x 76 with plain LDS stores (wrong sums), 44 / 78 us with ds_add_f32, 30 / 43 us
-// with per-key-block barriers, against 30 / 52 us for the lane-per-key backward: dropped, profiles/r2n.)
+// with per-key-block barriers, 32 / 41 us with a wave per key block and private LDS slices (no atomics, no barriers
+// in the loop), against 30 / 52 us for the lane-per-key backward.  The ISA shows why: ~2,000 VALU instructions per
+// (query block, key block) pair -- 64-bit addresses of 68 loads, mask bits, exp, the three-multiply dropout hash,
+// LDS transposition -- next to 80 MFMAs.  Dropped; profiles/r2n.)
 //
 // One WAVE per (batch, head, 32-query block), no LDS, no cross-wave traffic.  The trick is to compute the
 // TRANSPOSED score block S^T = K Q^T with v_mfma_f32_32x32x2_f32 (A = K rows, B = Q rows): the accumulator then
