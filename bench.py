@@ -157,14 +157,21 @@ def main():
     else:
         # one HIP graph per step: forward + criterion + backward; fresh host draws + dropout masks every
         # replay; for N > 1 the bucket all-reduces are recorded INSIDE the graph on the collective stream
-        # (bucket k reduces while backward continues); MESM_DDP_MODE=after puts one reduce after the replay
+        # (bucket k reduces while backward continues); MESM_DDP_MODE=after puts one reduce after the replay,
+        # MESM_DDP_MODE=inline one blocking reduce inside the graph on the capture stream
         gstep, reducer, post = None, None, False
-        if world > 1 and os.environ.get("MESM_DDP_MODE", "captured") == "captured":
+        mode = os.environ.get("MESM_DDP_MODE", "captured")  # captured | inline | after
+        if world > 1 and mode in ("captured", "inline"):
             ok = 1
             try:
-                reducer = GradReducer(model.gradbuf(), hook=True)
+                # inline: blocking collectives on the capture stream itself -- the graph stays one linear chain
+                # (no second-queue toll) at the price of no overlap; one bucket then
+                reducer = GradReducer(model.gradbuf(), hook=True, inline=mode == "inline",
+                                      n_buckets=1 if mode == "inline" else 6)
                 gstep = GraphedStep(model, crit, batch, args.dataset_name, reducer=reducer)
-                ddp_mode = "bucketed all-reduce captured in the step graph, overlapped with backward"
+                ddp_mode = ("one all-reduce captured in line at the end of the step graph (no second queue, no overlap)"
+                            if mode == "inline" else
+                            "bucketed all-reduce captured in the step graph, overlapped with backward")
             except Exception as e:  # capture of collectives refused by the runtime: reduce after the replay
                 log("captured all-reduce failed (%s: %s); falling back to reduce-after-replay" % (type(e).__name__, e))
                 ok = 0

@@ -61,8 +61,12 @@ def shard_groups(batch, rank, world, min_groups=2):
 
 
 class GradReducer:
-    def __init__(self, gradbuf, process_group=None, n_buckets=6, hook=True, force=False):
-        """force: issue the collectives even in a 1-rank group (exercises the RCCL / capture path on one GPU)"""
+    def __init__(self, gradbuf, process_group=None, n_buckets=6, hook=True, force=False, inline=False):
+        """force: issue the collectives even in a 1-rank group (exercises the RCCL / capture path on one GPU)
+        inline: blocking collectives (async_op=False), which this torch issues on the CURRENT stream: under graph
+        capture the step stays ONE linear chain -- no second hardware queue, hence none of the ~1 us per kernel
+        boundary that any concurrently active queue costs the main chain on this runtime, but
+        no overlap with backward either.  Worth it when the wire time is shorter than that toll."""
         self.gb = gradbuf
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -80,6 +84,7 @@ class GradReducer:
         self.param_bucket = {}
         self.flag = None            # 1-element tensor reduced after the last bucket: "a late gradient somewhere"
         self.hook = hook
+        self.inline = inline
         self.launch_log = []        # bucket indices in launch order (tests)
         if hook:  # overlap mode: collectives are launched from inside backward
             gradbuf.on_ready = self._on_ready
@@ -130,8 +135,9 @@ class GradReducer:
         lo, hi, _ = self.buckets[b]
         self.next_bucket -= 1
         self.launch_log.append(b)
-        self.works.append(dist.all_reduce(self.gb.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg,
-                                          async_op=True))
+        w = dist.all_reduce(self.gb.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=not self.inline)
+        if w is not None:
+            self.works.append(w)
 
     def _reset_step(self):
         self.counts = {}

@@ -25,7 +25,8 @@ def main():
         if hasattr(m, "p"):
             m.p = 0.0
     batch = synthetic.to_device(synthetic.workload_batch("C3a", seed=1), dev)
-    red = GradReducer(model.gradbuf(), n_buckets=6, force=True)
+    inline = len(sys.argv) > 1 and sys.argv[1] == "inline"  # blocking collectives on the capture stream itself
+    red = GradReducer(model.gradbuf(), n_buckets=6, force=True, inline=inline)
     g = GraphedStep(model, crit, batch, args.dataset_name, warmup=2, reducer=red)
     total_g = float(g.run(redraw=False))
     torch.cuda.synchronize()

@@ -48,14 +48,14 @@ def _init(rank, world, port):
     init_process_group_from_env(torch.device("cpu"))
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, inline=False):
     _init(rank, world, port)
     from mesm_amd.ddp import GradReducer
     from mesm_amd.gradbuf import GradBuffer
     m = Toy()
     gb = GradBuffer([(n, p) for n, p in m.named_parameters()])
     gb.ensure(torch.device("cpu"))
-    red = GradReducer(gb, n_buckets=3)
+    red = GradReducer(gb, n_buckets=3, inline=inline)
     results = []
     for step in range(3):
         torch.manual_seed(100 * step + rank)
@@ -78,12 +78,14 @@ def _local_grads(step, rank):
 
 
 @pytest.mark.timeout(120)
-def test_gloo_world2_mean_of_rank_gradients():
+@pytest.mark.parametrize("inline", [False, True])
+def test_gloo_world2_mean_of_rank_gradients(inline):
+    """inline: blocking collectives issued from inside backward (the one-linear-chain mode of a captured step)"""
     world = 2
     port = _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, out, inline), nprocs=world, join=True)
     for step in range(3):
         want = [_local_grads(step, r) for r in range(world)]
         for r in range(world):

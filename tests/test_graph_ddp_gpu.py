@@ -226,10 +226,11 @@ def test_two_shards_mean_equals_oracle_mean():
         assert rel((hip[0][n] + hip[1][n]) / 2, (ora[0][n] + ora[1][n]) / 2) < 5e-4, n
 
 
-def test_allreduce_captured_inside_the_step_graph():
+@pytest.mark.parametrize("mode", ["overlapped", "inline"])
+def test_allreduce_captured_inside_the_step_graph(mode):
     """The hooked GradReducer under HIP-graph capture on a 1-rank RCCL group (`force=True`): the bucket
-    collectives are recorded on the process group's stream inside the step graph and the replayed step gives
-    the eager gradients (x 1/1).  Runs in a child process (tests/ddp_capture_worker.py): tearing a RCCL
+    collectives are recorded on the process group's stream inside the step graph (or, `inline`, as blocking calls
+    on the capture stream itself) and the replayed step gives the eager gradients (x 1/1).  Runs in a child process (tests/ddp_capture_worker.py): tearing a RCCL
     communicator down next to a live graph that holds its work can abort the interpreter, which must not take
     the test session with it; the worker leaves through os._exit after printing its result."""
     import json
@@ -237,8 +238,8 @@ def test_allreduce_captured_inside_the_step_graph():
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, os.path.join(here, "ddp_capture_worker.py")], env=env, capture_output=True,
-                       text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(here, "ddp_capture_worker.py"), mode], env=env,
+                       capture_output=True, text=True, timeout=600)
     lines = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
     assert lines, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
     res = json.loads(lines[-1][7:])

@@ -31,7 +31,7 @@ def main():
     torch.manual_seed(7)
     model = build_model(args); crit = build_criterion(args); model.train()
     batch = synthetic.to_device(synthetic.workload_batch("C3a", seed=1), dev)
-    mode = sys.argv[1] if len(sys.argv) > 1 else "a"   # one mode per process: a | c | b1 | b6
+    mode = sys.argv[1] if len(sys.argv) > 1 else "a"   # one mode per process: a | c | b1 | b6 | i1
     if mode in ("a", "c"):
         g0 = GraphedStep(model, crit, batch, args.dataset_name)
         if mode == "a":
@@ -44,8 +44,8 @@ def main():
                 red.finish()
             print("(c) one all-reduce after the replay:    %.3f ms/step" % bench(after), flush=True)
     else:
-        nb = int(mode[1:])
-        red2 = GradReducer(model.gradbuf(), n_buckets=nb, hook=True, force=True)
+        nb = int(mode[1:])   # b<n>: overlapped buckets on the collective stream; i<n>: blocking, on the capture stream
+        red2 = GradReducer(model.gradbuf(), n_buckets=nb, hook=True, force=True, inline=mode[0] == "i")
         g1 = GraphedStep(model, crit, batch, args.dataset_name, warmup=2, reducer=red2)
         print("(b) %d bucket(s) captured in the graph:   %.3f ms/step" % (nb, bench(lambda: g1.run())), flush=True)
 
