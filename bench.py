@@ -21,7 +21,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) including
                  duration, HIP events on the launch stream around back-to-back replays of the GEMM
                  launches of one captured step, right after the timed region; `traffic` = HBM bytes per
                  launch from the rocprofv3 PMC passes committed under profiles/ (null when that profile
-                 was taken with another launch count, i.e. is stale);
+                 was taken with another launch count, i.e. is stale); `families` = in-situ ms per kernel
+                 family (GEMM / attention / LayerNorm / losses / element-wise / assembly) by ablation;
   cpu_baseline — the CPU oracle (a port of the reference step, oracle/mesm_oracle.py) timed on
                  this box's host cores on the same workload (rank 0, N = 1 only): 2 warm-up steps,
                  median of 5.
@@ -305,6 +306,24 @@ def main():
             fo.step(grad_clip=0.1)
         torch.cuda.synchronize()
         opt_tail_ms = (time.perf_counter() - t1) / 20 * 1e3
+
+    # in-situ cost of each kernel family (tools/ablate.py): the captured step re-timed with that family's
+    # launches turned into no-ops -- the attribution that adds up to the real step time (a kernel trace inflates
+    # every short kernel by ~2 us).  Informational, after the timed region, default workload only.
+    families = None
+    if extras and not opt.eager and world == 1 and opt.workload == "C3a":
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import ablate
+            fc = ablate.family_costs(opt.workload, reps=10)
+            families = {"gemm_ms": fc["gemm"], "attention_ms": fc["attn"], "layernorm_ms": fc["ln"],
+                        "losses_ms": fc["loss"], "elementwise_ms": fc["elt"], "assembly_ms": fc["glue"],
+                        "aten_and_launch_floor_ms": fc["floor"], "step_ms": fc["full_step"],
+                        "method": "step time with the family's launches as no-ops (tools/ablate.py), dropout masks "
+                                  "not redrawn"}
+        except Exception as e:  # never let an informational section take the bench line down
+            log("family attribution skipped: %s: %s" % (type(e).__name__, e))
+    roofline["families"] = families
 
     cpu_baseline = None
     if rank == 0 and world == 1 and opt.cpu_steps > 0:

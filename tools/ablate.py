@@ -31,33 +31,46 @@ L = _lib.lib()
 REAL = {n: getattr(L, n) for fam in FAMILIES.values() for n in fam}
 
 
-def step_ms(skip):
+def step_ms(skip, workload="C3a", reps=20):
     for n, f in REAL.items():
         setattr(L, n, f)
     for fam in skip:
         for n in FAMILIES[fam]:
             setattr(L, n, lambda *a, **k: 0)
-    dev = torch.device("cuda:0")
-    args = synthetic.make_args("C3a", device=str(dev))
-    torch.manual_seed(1234)
-    model = build_model(args); crit = build_criterion(args); model.train()
-    batch = synthetic.to_device(synthetic.workload_batch("C3a", seed=0), dev)
-    g = GraphedStep(model, crit, batch, args.dataset_name, warmup=1)
-    for _ in range(3):
-        g.run(redraw=False)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(20):
-        g.run(redraw=False)
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / 20 * 1e3
+    try:
+        dev = torch.device("cuda", torch.cuda.current_device())
+        args = synthetic.make_args(workload, device=str(dev))
+        torch.manual_seed(1234)
+        model = build_model(args); crit = build_criterion(args); model.train()
+        batch = synthetic.to_device(synthetic.workload_batch(workload, seed=0), dev)
+        g = GraphedStep(model, crit, batch, args.dataset_name, warmup=1)
+        for _ in range(3):
+            g.run(redraw=False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            g.run(redraw=False)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+    finally:
+        for n, f in REAL.items():
+            setattr(L, n, f)
 
 
-base = step_ms([])
-print("full step            %.3f ms" % base)
-fams = sys.argv[1:] or list(FAMILIES)
-for f in fams:
-    t = step_ms([f])
-    print("without %-6s       %.3f ms   -> %-6s costs %.3f ms" % (f, t, f, base - t))
-t = step_ms(list(FAMILIES))
-print("without all of them  %.3f ms   (= ATen glue + launch floor)" % t)
+def family_costs(workload="C3a", families=None, reps=20):
+    """{family: ms it costs inside the captured step, ..., 'full_step': ms, 'floor': ms with all of them off}"""
+    base = step_ms([], workload, reps)
+    res = {"full_step": base}
+    for f in families or list(FAMILIES):
+        res[f] = base - step_ms([f], workload, reps)
+    res["floor"] = step_ms(list(FAMILIES), workload, reps)
+    return res
+
+
+if __name__ == "__main__":
+    fams = sys.argv[1:] or list(FAMILIES)
+    r = family_costs(families=fams)
+    print("full step            %.3f ms" % r["full_step"])
+    for f in fams:
+        print("without %-6s       %.3f ms   -> %-6s costs %.3f ms" % (f, r["full_step"] - r[f], f, r[f]))
+    print("without all of them  %.3f ms   (= ATen glue + launch floor)" % r["floor"])
