@@ -257,11 +257,17 @@ __global__ __launch_bounds__(256 * SSM_G) void ss_mean_fwd_kernel(
   __shared__ float part[2][SSM_G][1024];
   const int n = blockIdx.x;
   const int t = threadIdx.x & 255, g = threadIdx.x >> 8;
+  // valid clips / words of the pair, counted by the whole workgroup (a per-thread loop over the mask bytes was a
+  // chain of Lv + Le dependent loads in front of everything else)
   float ccnt = 0.0f, wcnt = 0.0f;
-  for (int l = 0; l < Lv; ++l) ccnt += cmask[(int64_t)n * Lv + l] ? 1.0f : 0.0f;
-  for (int l = 0; l < Le; ++l) wcnt += wmask[(int64_t)n * Le + l] ? 1.0f : 0.0f;
-  // D <= 4 * 256 handled per thread in registers
+  for (int l = threadIdx.x; l < Lv; l += 256 * SSM_G) ccnt += cmask[(int64_t)n * Lv + l] ? 1.0f : 0.0f;
+  for (int l = threadIdx.x; l < Le; l += 256 * SSM_G) wcnt += wmask[(int64_t)n * Le + l] ? 1.0f : 0.0f;
+  ccnt = block_sum(ccnt, sh);
+  wcnt = block_sum(wcnt, sh);
+  // D <= 4 * 256 handled per thread in registers; the row loops are unrolled so that several rows' loads are in
+  // flight together (one workgroup per pair: nothing else hides their latency)
   float cs[4] = {0, 0, 0, 0}, ws[4] = {0, 0, 0, 0};
+#pragma unroll 5
   for (int l = g; l < Lv; l += SSM_G) {
     const float m = cmask[(int64_t)n * Lv + l] ? 1.0f : 0.0f;
     const float* r = pv + ((int64_t)n * Lv + l) * D;
@@ -271,6 +277,7 @@ __global__ __launch_bounds__(256 * SSM_G) void ss_mean_fwd_kernel(
       if (c < D) cs[k] += m * r[c];
     }
   }
+#pragma unroll 5
   for (int l = g; l < Le; l += SSM_G) {
     const float m = wmask[(int64_t)n * Le + l] ? 1.0f : 0.0f;
     const float* r = ew + ((int64_t)n * Le + l) * D;
@@ -385,6 +392,7 @@ __global__ __launch_bounds__(256) void ss_bwd_kernel(
   }
   __syncthreads();
   float dc[4] = {0, 0, 0, 0}, dw[4] = {0, 0, 0, 0}, yc[4], yw[4];
+#pragma unroll 8
   for (int k = 0; k < N; ++k) {
     const float a = dsim[n * N + k], b = dsim[k * N + n];
 #pragma unroll
