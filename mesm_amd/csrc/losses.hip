@@ -92,27 +92,31 @@ __global__ __launch_bounds__(256) void nll_bwd_kernel(
 // criterion.py:139-221.  One workgroup, one wave per pair (rows strided over 4 waves).
 constexpr int SAL_STAGES = 11;   // rand_idx in range(1, 12)
 constexpr int SAL_MAXE = 20;     // elements of [pos || neg] per lane: 2L <= 1280
-
+// The per-lane arrays are sized by the template parameter NE (4: 2L <= 256, every QVHighlights / Charades batch;
+// 20: up to TACoS' 512 clips).  With the 20-element arrays the one-workgroup forward (1,024 threads, 128 VGPRs per
+// lane) spilled 336 bytes per lane to scratch memory and took 40 us for 32 rows of 150 elements.
+template <int NE>
 struct SalRow {
-  float x[SAL_MAXE];    // scores / tau after the -1e3 padding fill
-  float w[SAL_MAXE];    // sum_r [label >= r] * vmask / (cnt_r + 1e-6)
+  float x[NE];    // scores / tau after the -1e3 padding fill
+  float w[NE];    // sum_r [label >= r] * vmask / (cnt_r + 1e-6)
   float mx, T;          // row max, sum exp + 1e-6
   int amax;
   float rank;           // sum_r -(S_r / (cnt_r + 1e-6)) over stages with positives
   float wsum;
 };
 
+template <int NE>
 __device__ __forceinline__ void sal_row_stats(const float* sp, const float* sn, const double* lab,
-                                              const uint8_t* vm, int L, int lane, SalRow& R) {
+                                              const uint8_t* vm, int L, int lane, SalRow<NE>& R) {
   const int n2 = 2 * L;
   float cnt[SAL_STAGES];
 #pragma unroll
   for (int r = 0; r < SAL_STAGES; ++r) cnt[r] = 0.0f;
   float mx = -INFINITY;
   int amax = 0x7fffffff;
-  int stage_of[SAL_MAXE];  // number of stages r (1..11) with label >= r, for this element
+  int stage_of[NE];  // number of stages r (1..11) with label >= r, for this element
 #pragma unroll
-  for (int e = 0; e < SAL_MAXE; ++e) {
+  for (int e = 0; e < NE; ++e) {
     const int j = e * 64 + lane;
     float x = -INFINITY;
     int st = 0;
@@ -144,7 +148,7 @@ __device__ __forceinline__ void sal_row_stats(const float* sp, const float* sn, 
   }
   float se = 0.0f;
 #pragma unroll
-  for (int e = 0; e < SAL_MAXE; ++e) {
+  for (int e = 0; e < NE; ++e) {
     const int j = e * 64 + lane;
     if (j < n2) se += __expf(R.x[e] - mx);
   }
@@ -152,7 +156,7 @@ __device__ __forceinline__ void sal_row_stats(const float* sp, const float* sn, 
   const float logT = __logf(T);
   float rank = 0.0f, wsum = 0.0f;
 #pragma unroll
-  for (int e = 0; e < SAL_MAXE; ++e) {
+  for (int e = 0; e < NE; ++e) {
     const int j = e * 64 + lane;
     float w = 0.0f;
     if (j < n2) {
@@ -174,20 +178,22 @@ __device__ __forceinline__ void sal_row_stats(const float* sp, const float* sn, 
   R.wsum = wave_sum(wsum);
 }
 
-constexpr int SAL_FWD_WAVES = 16;  // one workgroup (deterministic sum), a wave per pair
-__global__ __launch_bounds__(64 * SAL_FWD_WAVES) void saliency_fwd_kernel(
+// one workgroup (deterministic sum) of NW waves, a wave per pair (16 waves; 8 with the 20-element arrays, whose
+// registers do not fit the 128-VGPR budget of a 1,024-thread workgroup)
+template <int NE, int NW>
+__global__ __launch_bounds__(64 * NW) void saliency_fwd_kernel(
     const float* __restrict__ s_pos, const float* __restrict__ s_neg,
     const double* __restrict__ label, const uint8_t* __restrict__ vmask,
     const int64_t* __restrict__ pos_idx, const int64_t* __restrict__ neg_idx, int N, int L, int P,
     float rank_coef, float margin, float* __restrict__ out_loss) {
-  __shared__ float part[SAL_FWD_WAVES];
+  __shared__ float part[NW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float acc = 0.0f;  // lane 0 of each wave accumulates its rows
-  for (int n = wave; n < N; n += SAL_FWD_WAVES) {
+  for (int n = wave; n < N; n += NW) {
     const float* sp = s_pos + (int64_t)n * L;
     const float* sn = s_neg + (int64_t)n * L;
     const uint8_t* vm = vmask + (int64_t)n * L;
-    SalRow R;
+    SalRow<NE> R;
     sal_row_stats(sp, sn, label + (int64_t)n * L, vm, L, lane, R);
     // neg-pair term: sum_l -log(1 - sigmoid(s_neg)) * vmask
     float np = 0.0f;
@@ -211,11 +217,12 @@ __global__ __launch_bounds__(64 * SAL_FWD_WAVES) void saliency_fwd_kernel(
   __syncthreads();
   if (threadIdx.x == 0) {
     float t = 0.0f;
-    for (int w = 0; w < SAL_FWD_WAVES; ++w) t += part[w];
+    for (int w = 0; w < NW; ++w) t += part[w];
     *out_loss = t;
   }
 }
 
+template <int NE>
 __global__ __launch_bounds__(256) void saliency_bwd_kernel(
     const float* __restrict__ s_pos, const float* __restrict__ s_neg,
     const double* __restrict__ label, const uint8_t* __restrict__ vmask,
@@ -229,12 +236,12 @@ __global__ __launch_bounds__(256) void saliency_bwd_kernel(
   const float* sp = s_pos + (int64_t)n * L;
   const float* sn = s_neg + (int64_t)n * L;
   const uint8_t* vm = vmask + (int64_t)n * L;
-  SalRow R;
+  SalRow<NE> R;
   sal_row_stats(sp, sn, label + (int64_t)n * L, vm, L, lane, R);
   const float k_rank = 1.0f / ((float)N * rank_coef);
   const float eps_over_T = 1e-6f / R.T;
 #pragma unroll
-  for (int e = 0; e < SAL_MAXE; ++e) {
+  for (int e = 0; e < NE; ++e) {
     const int j = e * 64 + lane;
     if (j < 2 * L) {
       const int l = j < L ? j : j - L;
@@ -373,8 +380,12 @@ extern "C" int mesm_saliency_loss_fwd(const float* s_pos, const float* s_neg, co
   if (2 * L > 64 * SAL_MAXE) return MESM_EINVAL;
   if ((pos_idx == nullptr) != (neg_idx == nullptr)) return MESM_EINVAL;
   if (pos_idx && (P <= 0 || P > 64)) return MESM_EINVAL;
-  hipLaunchKernelGGL(saliency_fwd_kernel, dim3(1), dim3(64 * SAL_FWD_WAVES), 0, (hipStream_t)stream, s_pos, s_neg,
-                     label, vmask, pos_idx, neg_idx, N, L, P, rank_coef, margin, out_loss);
+  if (2 * L <= 64 * 4)
+    hipLaunchKernelGGL((saliency_fwd_kernel<4, 16>), dim3(1), dim3(64 * 16), 0, (hipStream_t)stream, s_pos, s_neg,
+                       label, vmask, pos_idx, neg_idx, N, L, P, rank_coef, margin, out_loss);
+  else
+    hipLaunchKernelGGL((saliency_fwd_kernel<SAL_MAXE, 8>), dim3(1), dim3(64 * 8), 0, (hipStream_t)stream, s_pos,
+                       s_neg, label, vmask, pos_idx, neg_idx, N, L, P, rank_coef, margin, out_loss);
   return mesm_launch_status();
 }
 
@@ -388,9 +399,14 @@ extern "C" int mesm_saliency_loss_bwd(const float* s_pos, const float* s_neg, co
   if (2 * L > 64 * SAL_MAXE) return MESM_EINVAL;
   if ((pos_idx == nullptr) != (neg_idx == nullptr)) return MESM_EINVAL;
   if (pos_idx && (P <= 0 || P > 64)) return MESM_EINVAL;
-  hipLaunchKernelGGL(saliency_bwd_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                     s_pos, s_neg, label, vmask, pos_idx, neg_idx, N, L, P, rank_coef, margin,
-                     gscale, ds_pos, ds_neg);
+  if (2 * L <= 64 * 4)
+    hipLaunchKernelGGL(saliency_bwd_kernel<4>, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       s_pos, s_neg, label, vmask, pos_idx, neg_idx, N, L, P, rank_coef, margin,
+                       gscale, ds_pos, ds_neg);
+  else
+    hipLaunchKernelGGL(saliency_bwd_kernel<SAL_MAXE>, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       s_pos, s_neg, label, vmask, pos_idx, neg_idx, N, L, P, rank_coef, margin,
+                       gscale, ds_pos, ds_neg);
   return mesm_launch_status();
 }
 
