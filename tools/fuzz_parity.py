@@ -1,0 +1,128 @@
+"""Random-configuration parity sweep of the HIP path against the CPU oracle (which the reference fixtures pin):
+dataset, group sizes, sequence lengths, padding, widths / heads (incl. head dim 32: matrix-core attention), layer
+counts, projection depth and the ablation switches are drawn per case; outputs, losses, matcher indices and
+gradients are compared.  Not part of the test suite (minutes of CPU oracle time): a bug hunt.
+usage: fuzz_parity.py [n_cases] [seed]"""
+import os, random, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+from mesm_amd import build_criterion, build_model, synthetic
+from oracle import mesm_oracle as O
+
+dev = torch.device("cuda:0")
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-3)
+
+
+def l2(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm()) / max(float(b.norm()), 1e-3 * b.numel() ** 0.5)
+
+
+bad = 0
+for case in range(n_cases):
+    dataset = rng.choice(["qvhighlights", "charades", "tacos"])
+    ngroups = rng.randint(2, 5)
+    groups = [rng.randint(1, 3) for _ in range(ngroups)]
+    Lv = rng.choice([9, 20, 33, 64, 75, 90, 130])
+    Lw = rng.choice([4, 8, 16, 31, 32])
+    heads, dh = rng.choice([(2, 32), (4, 32), (4, 8), (2, 16), (8, 8), (1, 32)])
+    d = heads * dh
+    over = dict(dataset_name=dataset, hidden_dim=d, nheads=heads, dim_feedforward=rng.choice([32, 48, 2 * d]),
+                num_queries=rng.choice([3, 5, 10]), v_feat_dim=rng.choice([18, 34, 130]), t_feat_dim=rng.choice([12, 64]),
+                vocab_size=rng.choice([29, 301]), share_MLP=rng.random() < 0.5,
+                set_cost_class=4, loss_label_coef=4, rank_coef=12 if dataset == "qvhighlights" else 1,
+                use_triplet=dataset != "charades", loss_recfw_coef=0.5, loss_recss_coef=0.1,
+                max_video_l=Lv, max_words_l=Lw, device="cuda:0",
+                rec_fw=rng.random() < 0.75, rec_ss=rng.random() < 0.75, aux_loss=rng.random() < 0.8,
+                use_txt_pos=rng.random() < 0.3, n_input_proj=rng.choice([1, 2, 2, 3]),
+                t2v_layers=rng.choice([1, 2]), enc_layers=rng.choice([1, 2]), dec_layers=rng.choice([1, 2, 3]),
+                num_recfw_layers=rng.choice([1, 2]), num_recss_layers=rng.choice([1, 2]))
+    ragged = rng.random() < 0.7
+    seed = rng.randrange(10 ** 6)
+    tag = "case %d: %s groups=%s Lv=%d Lw=%d d=%d h=%d ff=%d q=%d fw=%d ss=%d aux=%d tpos=%d proj=%d layers=%d/%d/%d/%d/%d ragged=%d seed=%d" % (
+        case, dataset, groups, Lv, Lw, d, heads, over["dim_feedforward"], over["num_queries"], over["rec_fw"], over["rec_ss"],
+        over["aux_loss"], over["use_txt_pos"], over["n_input_proj"], over["t2v_layers"], over["enc_layers"], over["dec_layers"],
+        over["num_recfw_layers"], over["num_recss_layers"], ragged, seed)
+    try:
+        args = synthetic.make_args(None, **over)
+        torch.manual_seed(seed)
+        model = build_model(args)
+        with torch.no_grad():
+            for n_, p in model.named_parameters():
+                if n_.endswith("_token") or "masked_sent_token" in n_:
+                    p.normal_(0, 0.5)
+                if n_.endswith("activation.weight"):
+                    p.uniform_(0.1, 0.4)
+        crit = build_criterion(args)
+        batch = synthetic.make_batch(dataset, groups, Lv, Lw, over["v_feat_dim"], over["t_feat_dim"], over["vocab_size"] + 1,
+                                     seed=seed, ragged=ragged)
+        neg, masked = synthetic.host_draws(batch, seed=seed)
+        if not over["rec_fw"]:
+            masked = None
+        model.eval()
+        b = synthetic.to_device(batch, dev)
+        out = model(**b, dataset_name=dataset, is_training=True, neg_index=neg, masked_words=masked)
+        losses, total = crit(out, b, True)
+        model.zero_grad()
+        total.backward()
+        torch.cuda.synchronize()
+        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        o_out, o_losses, o_total, o_grads, o_idx = O.train_step(sd, dict(vars(args)), batch, neg, masked)
+        errs = []
+        for k, v in o_out.items():
+            if torch.is_tensor(v) and v.dtype != torch.bool:
+                e = rel(out[k], v)
+                if not e < 2e-4:
+                    errs.append("out %s %.2e" % (k, e))
+        if set(k for k, v in out.items() if torch.is_tensor(v)) != set(k for k, v in o_out.items() if torch.is_tensor(v)):
+            errs.append("output key set differs")
+        for k, v in o_losses.items():
+            lk = float(losses[k].detach())
+            if not abs(lk - float(v)) < 2e-4 * max(1.0, abs(float(v))):
+                errs.append("loss %s %.6f vs %.6f" % (k, lk, float(v)))
+        mq = crit.last_match[0].cpu().tolist()
+        want = []
+        for q, t in o_idx[0]:
+            want += q[torch.argsort(t)].tolist()
+        if mq != want:
+            # a different assignment is a defect only if it is WORSE under the oracle's own cost matrix; equal
+            # total cost (to rounding) is a tie that the two fp32 evaluation orders break differently
+            gap = None
+            if dataset == "qvhighlights":
+                tx = torch.cat([t["moments"] for t in batch["norm_moment"]]); tc = torch.cat([t["spans"] for t in batch["norm_span"]])
+                sizes = [len(t["spans"]) for t in batch["norm_span"]]
+            else:
+                tx, tc = batch["norm_moment"], batch["norm_span"]; sizes = [1] * len(tc)
+            C = O.match_cost(o_out["pred_logits"].detach(), o_out["pred_spans"].detach(), tc, tx, dict(vars(args)))
+            C = C.view(len(sizes), -1, C.shape[-1])
+            tot_h = tot_o = 0.0; k = 0; start = 0
+            for i, sz in enumerate(sizes):
+                for t in range(sz):
+                    tot_h += float(C[i, mq[k], start + t]); tot_o += float(C[i, want[k], start + t]); k += 1
+                start += sz
+            gap = tot_h - tot_o
+            if abs(gap) > 1e-5 * max(1.0, abs(tot_o)):
+                errs.append("matcher differs, cost gap %.3e" % gap)
+            else:
+                print("   (case %d: assignments differ at a cost tie, gap %.2e)" % (case, gap))
+        grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+        if set(grads) != set(o_grads):
+            errs.append("grad key set differs: %s" % sorted(set(grads) ^ set(o_grads))[:4])
+        else:
+            w = max((l2(grads[k], g), k) for k, g in o_grads.items())
+            if not w[0] < 5e-3:
+                errs.append("grad L2 %s %.2e" % (w[1], w[0]))
+        status = "ok" if not errs else "MISMATCH " + "; ".join(errs[:6])
+    except Exception as e:  # noqa: BLE001
+        status = "ERROR %s: %s" % (type(e).__name__, str(e)[:200])
+    if status != "ok":
+        bad += 1
+    print(tag, "->", status, flush=True)
+print("cases %d, not ok %d" % (n_cases, bad))
