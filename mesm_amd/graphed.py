@@ -115,6 +115,8 @@ class GraphedStep:
             N, Lv = batch["video_mask"].shape
             if self.model.rec_fw:
                 caps["Lc"] = min(Lv, _round_up(int(batch["clip_mask"].sum(1).max()), 8))
+            if self.model.rec_ss:
+                caps["M"] = max(self._groups)  # sentence slots per pair (SS branch): other groupings with <= M fit
             if self.model.rec_ss and self.dataset_name == "qvhighlights":
                 vm = batch["video_mask"].cpu()
                 lens = [int(c.sum()) for c in torch.split(vm, self._groups)]
@@ -152,13 +154,14 @@ class GraphedStep:
                                     clip_mask=host["clip_mask"].numpy() if "clip_mask" in host else None,
                                     neg_index=neg_index, masked_words=masked_words,
                                     words_weight=host.get("words_weight"), Lc_cap=self.caps.get("Lc"),
-                                    Lss_cap=self.caps.get("Lss"))
+                                    Lss_cap=self.caps.get("Lss"), M_cap=self.caps.get("M"))
         tarr, tmeta = TargetPlan.arrays(host, self.crit.multi_clip, self.crit.gamma, T_cap=self.caps.get("T"),
                                         Tmax_cap=self.caps.get("Tmax"))
         arr = {"p." + k: v for k, v in parr.items()}
         arr.update({"t." + k: v for k, v in tarr.items()})
         for k, v in host.items():
-            if torch.is_tensor(v) and k != "words_weight" and v.numel() * v.element_size() <= self.BIG:
+            # (num_clips has one entry per GROUP and is only read on the host: the step reads the plans)
+            if torch.is_tensor(v) and k not in ("words_weight", "num_clips") and v.numel() * v.element_size() <= self.BIG:
                 arr["b." + k] = v.numpy()
         return arr, pmeta, tmeta, wm
 
@@ -183,10 +186,22 @@ class GraphedStep:
         copy each.  redraw: also draw new negatives / MLM words here (then call run(redraw=False): one upload per
         step instead of two).  Raises ValueError (nothing is modified) when it does not fit."""
         groups = [int(g) for g in batch["num_clips"].tolist()]
-        if groups != self._groups:
+        if groups != self._groups and (self.caps.get("M") is None or sum(groups) != sum(self._groups)):
+            # exact-extent graphs (caps=None) are tied to their grouping; with capacities any grouping of the
+            # same number of pairs fits as long as its largest group does (checked by the plan below)
             raise ValueError("GraphedStep.load_batch: group sizes changed %s -> %s" % (self._groups, groups))
+        old_groups, self._groups = self._groups, groups
+        try:
+            self._load_batch(batch, redraw)
+        except ValueError:
+            self._groups = old_groups
+            raise
+
+    def _load_batch(self, batch, redraw):
         for k, cur in self.batch.items():
             v = batch.get(k)
+            if k == "num_clips":
+                continue
             if torch.is_tensor(cur) and torch.is_tensor(v) and cur.shape != v.shape:
                 raise ValueError("GraphedStep.load_batch: %s changed shape %s -> %s"
                                  % (k, tuple(cur.shape), tuple(v.shape)))
@@ -215,6 +230,9 @@ class GraphedStep:
         self.tplan.sizes, self.tplan.sumT = tmeta["sizes"], tmeta["sumT"]
         for k, cur in self.batch.items():
             v = batch.get(k)
+            if k == "num_clips":
+                self.batch[k] = v  # host-side bookkeeping only (the step reads the plans)
+                continue
             if torch.is_tensor(cur) and torch.is_tensor(v) and ("b." + k) not in arr:
                 if not cur.is_cuda:
                     self.batch[k] = v  # host-side inputs (words_weight) are only read by redraw()
@@ -291,23 +309,57 @@ class GraphedStep:
 
 
 class StepCache:
-    """One captured graph per batch-shape bucket: `run(batch)` replays the graph whose
-    key (N, Lv, Lw, feature dims, group sizes) and capacities fit the batch, capturing a new one when none
-    does.  Ragged real batches therefore stay on the graph path; `captures` counts the graphs built."""
+    """One captured graph per batch-shape bucket: `run(batch)` replays a graph whose shape key
+    (N, Lv, Lw, feature dims) and capture-time capacities (largest video group, GT-clip count, group video
+    length, target windows) fit the batch, capturing a new one when none does.  `pad=(Lv_cap, Lw_cap)` first
+    pads every batch to fixed clip / word extents (masked positions, what the reference's own collate does up to
+    the batch maximum), so that the key is the number of pairs alone: real loaders emit a different (N, Lv, Lw,
+    grouping) almost every batch -- items are videos with all their queries, dataset/base.py:164-207 -- and
+    only a handful of distinct N.  `captures` counts the graphs built."""
 
-    def __init__(self, model, criterion, dataset_name, reducer=None, max_graphs=16):
+    # batch entries with a clip / word axis at dim 1
+    CLIP_KEYS = ("video_feat", "video_mask", "clip_mask", "saliency_label")
+    WORD_KEYS = ("words_id", "words_mask", "words_weight", "unknown_mask", "words_label")
+
+    def __init__(self, model, criterion, dataset_name, reducer=None, max_graphs=16, pad=None):
         self.model, self.crit, self.dataset_name = model, criterion, dataset_name
         self.reducer = reducer
         self.steps = {}
         self.max_graphs = max_graphs
+        self.pad = pad
         self.captures = 0
 
     @staticmethod
     def key(batch):
-        return (tuple(batch["video_feat"].shape), tuple(batch["words_id"].shape),
-                tuple(int(g) for g in batch["num_clips"].tolist()))
+        return (tuple(batch["video_feat"].shape), tuple(batch["words_id"].shape))
+
+    @staticmethod
+    def _pad_dim1(t, L):
+        if t is None or not torch.is_tensor(t) or t.dim() < 2 or t.shape[1] >= L:
+            return t
+        out = t.new_zeros((t.shape[0], L) + tuple(t.shape[2:]))
+        out[:, :t.shape[1]] = t
+        return out
+
+    def padded(self, batch):
+        """the batch with its clip / word axes zero-padded to `pad` (new dict; tensors shared when nothing to do)"""
+        if self.pad is None:
+            return batch
+        Lv, Lw = self.pad
+        if batch["video_feat"].shape[1] > Lv or batch["words_id"].shape[1] > Lw:
+            raise ValueError("StepCache: batch extents (%d clips, %d words) exceed pad=%r"
+                             % (batch["video_feat"].shape[1], batch["words_id"].shape[1], self.pad))
+        b = dict(batch)
+        for k in self.CLIP_KEYS:
+            if k in b:
+                b[k] = self._pad_dim1(b[k], Lv)
+        for k in self.WORD_KEYS:
+            if k in b:
+                b[k] = self._pad_dim1(b[k], Lw)
+        return b
 
     def run(self, batch, redraw=True):
+        batch = self.padded(batch)
         k = self.key(batch)
         for gs in self.steps.get(k, []):
             try:

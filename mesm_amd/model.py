@@ -249,7 +249,7 @@ class MESM(nn.Module):
 
     # ------------------------------------------------------------------ host-side plan
     def plan_arrays(self, vm, wm, groups, dataset_name, is_training, clip_mask=None, neg_index=None,
-                    masked_words=None, words_weight=None, Lc_cap=None, Lss_cap=None):
+                    masked_words=None, words_weight=None, Lc_cap=None, Lss_cap=None, M_cap=None):
         """All data-dependent host decisions of model.py:184-207, :260, :307-325 as numpy arrays
         ({name: array}, meta) -- pure host arithmetic on the (small) masks, no device work.
 
@@ -265,6 +265,10 @@ class MESM(nn.Module):
         arr["neg_index"] = np.asarray(neg_index, dtype=np.int64)
         if self.rec_ss:
             M = max(groups)
+            if M_cap is not None:  # sentence slots per pair padded to a fixed extent (masked queries / keys)
+                if M > M_cap:
+                    raise ValueError("make_plan: a video group has %d queries > M_cap %d" % (M, M_cap))
+                M = M_cap
             starts = np.concatenate([[0], np.cumsum(groups)])
             gid = np.repeat(np.arange(len(groups)), groups)          # group of every pair
             slot = np.arange(N) - starts[gid]                        # position of the pair inside its group

@@ -51,7 +51,7 @@ def _eager(model, crit, batch, name, plan):
     model.zero_grad(set_to_none=True)
     total.backward()
     torch.cuda.synchronize()
-    return float(total), model.gradbuf().flat.clone()
+    return float(total.detach()), model.gradbuf().flat.clone()
 
 
 @pytest.mark.parametrize("workload,ragged2", [("C3a", True), ("C3b", True), ("C2", False)])
@@ -245,3 +245,40 @@ def test_allreduce_captured_inside_the_step_graph(mode):
     res = json.loads(lines[-1][7:])
     assert res["launch_log_tail"] == [5, 4, 3, 2, 1, 0], res
     assert res["loss_err"] < 1e-5 and res["grad_err"] < 1e-4, res
+
+
+@pytest.mark.parametrize("workload", ["C3b", "C2"])
+def test_step_cache_replays_other_groupings_and_padded_extents(workload):
+    """Real loaders emit a different (N, Lv, Lw, grouping) almost every batch (dataset/base.py:164-207: an item is
+    a video with all its queries).  With pad=(Lv, Lw) the cache keys on the number of pairs alone: batches of the
+    same N with other group sizes, clip counts and sentence lengths replay ONE graph and give the eager result of
+    the unpadded batch."""
+    from mesm_amd import synthetic
+    from mesm_amd.graphed import StepCache
+    args, model, crit = _build(workload)
+    w = synthetic.WORKLOADS[workload]
+    cache = StepCache(model, crit, args.dataset_name, pad=(w["Lv"], w["Lw"]))
+
+    def make(groups, Lv, Lw, seed):
+        return synthetic.make_batch(w["dataset_name"], groups, Lv, Lw, w["v_feat_dim"], w["t_feat_dim"],
+                                    w["vocab_size"] + 1, seed=seed, ragged=True)
+
+    first = make([4] * 8, w["Lv"], w["Lw"], 1)            # 32 pairs, the largest group of the three
+    cache.run(first, redraw=False)
+    for groups, Lv, Lw, seed in (([4, 3, 1, 2, 4, 4, 2, 4, 4, 4], 60, min(20, w["Lw"]), 2), ([2] * 16, w["Lv"], w["Lw"], 3)):
+        b = make(groups, Lv, Lw, seed)
+        tg, gs = cache.run(b, redraw=False)
+        tg = float(tg)
+        assert cache.captures == 1, (groups, cache.captures)
+        flat_g = model.gradbuf().flat.clone()
+        bd = synthetic.to_device(b, dev())  # the UNPADDED batch through the eager path, same host draws
+        wm = gs._wm_cpu[:, :Lw]
+        plan = model.make_plan(bd["video_mask"], wm, bd["num_clips"], args.dataset_name, True,
+                               words_weight=bd["words_weight"], clip_mask=bd["clip_mask"],
+                               neg_index=gs.plan.neg_index, masked_words=gs.plan.masked_words[:, :Lw], device=dev())
+        te, flat_e = _eager(model, crit, bd, args.dataset_name, plan)
+        assert abs(te - tg) < 2e-5 * max(1.0, abs(te)), (groups, te, tg)
+        assert float((flat_e - flat_g).norm()) / max(float(flat_e.norm()), 1e-6) < 2e-4, groups
+    # a grouping whose largest group exceeds the captured capacity needs its own graph
+    cache.run(make([6, 2] * 4, w["Lv"], w["Lw"], 4), redraw=False)
+    assert cache.captures == 2
