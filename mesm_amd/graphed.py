@@ -83,9 +83,20 @@ class GraphedStep:
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(max(warmup, 2 if reducer is not None else 1)):
-                    self._step_body()  # (a reducer learns its bucket schedule on the first one)
+            # A reducer learns its bucket schedule on its first step, so the first graph warms up with the
+            # collectives live (every rank is there together).  Later graphs of a StepCache are captured whenever
+            # a rank meets a new batch shape -- not at the same step on every rank -- so their warm-up steps must
+            # not issue collectives the other ranks do not match: the gradient hooks are detached for them.
+            learnt = reducer is not None and getattr(reducer, "expected", None) is not None
+            saved_hook = gb.on_ready
+            if learnt:
+                gb.on_ready = None
+            try:
+                with torch.cuda.stream(side):
+                    for _ in range(max(warmup, 2 if (reducer is not None and not learnt) else 1)):
+                        self._step_body()
+            finally:
+                gb.on_ready = saved_hook
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()

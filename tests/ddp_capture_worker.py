@@ -32,6 +32,14 @@ def main():
     torch.cuda.synchronize()
     flat_g = model.gradbuf().flat.clone()
     log = list(red.launch_log[-6:])
+    # a SECOND graph (another batch shape met later by this rank only): its warm-up must not issue collectives,
+    # only the capture records its six buckets
+    n_before = len(red.launch_log)
+    b2 = synthetic.to_device(synthetic.workload_batch("C3b", seed=2), dev)
+    g2 = GraphedStep(model, crit, b2, args.dataset_name, warmup=1, reducer=red)
+    g2.run(redraw=False)
+    torch.cuda.synchronize()
+    second_graph_launches = len(red.launch_log) - n_before
     model.gradbuf().on_ready = None
     out = model(**batch, dataset_name=args.dataset_name, is_training=True, plan=g.plan)
     _, total = crit(out, batch, True)
@@ -39,7 +47,7 @@ def main():
     total.backward()
     torch.cuda.synchronize()
     flat_e = model.gradbuf().flat
-    res = {"launch_log_tail": log,
+    res = {"launch_log_tail": log, "second_graph_launches": second_graph_launches,
            "loss_err": abs(float(total) - total_g) / max(1.0, abs(float(total))),
            "grad_err": float((flat_e - flat_g).norm()) / max(float(flat_e.norm()), 1e-6)}
     print("RESULT " + json.dumps(res), flush=True)

@@ -244,6 +244,8 @@ def test_allreduce_captured_inside_the_step_graph(mode):
     assert lines, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
     res = json.loads(lines[-1][7:])
     assert res["launch_log_tail"] == [5, 4, 3, 2, 1, 0], res
+    # the second graph's warm-up ran without collectives: only its capture recorded the six buckets
+    assert res["second_graph_launches"] == 6, res
     assert res["loss_err"] < 1e-5 and res["grad_err"] < 1e-4, res
 
 
