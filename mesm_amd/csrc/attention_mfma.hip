@@ -1,5 +1,6 @@
-// Attention core on the matrix cores for the step's hot shapes: head dims dk = dv = 32, at most 128 keys
-// (T2V 75 x 33, encoder 76 x 76, MLM 33 x 75, SS 1..8 x 75), every mask rule and the dropout hash of
+// Attention core on the matrix cores for the step's hot shapes: head dims dk = dv = 32 (T2V 75 x 33, encoder
+// 76 x 76, MLM 33 x 75, SS 1..8 x 75 with all scores in registers; longer key ranges, e.g. TACoS' 513 x 513
+// encoder, in a two-pass loop over key blocks, below), every mask rule and the dropout hash of
 // attention.hip.  mesm_attn_fwd hands these shapes over (attention.hip: dispatch); split heads, the causal CLIP
 // mode, other head dims, longer key ranges and the whole backward stay on the lane-per-key kernels.  (fp32 MFMA
 // and fp32 VALU have the same peak on this chip: the matrix cores buy fewer instructions and no cross-lane
@@ -201,10 +202,117 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const MesmAttnArgs p
   if (hf == 0 && ivalid && p.lse) p.lse[(int64_t)bh * p.Lq + i] = mx + __logf(l);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Forward for LONG key ranges (Lk > 128: TACoS' 513-clip encoder, group videos of several segments): the key
+// blocks are a run-time loop, one 32 x 32 score block in registers at a time, in TWO passes -- pass 1 finds the
+// row maxima (scores only), pass 2 recomputes the scores, exponentiates against the final maximum, sums the row
+// and accumulates the UN-normalised P V; the output is divided by the row sum at the end.  No running rescale of
+// the output accumulator (its rows live in registers of other lanes than the row's statistics): the second
+// score product is 16 MFMAs per block, cheaper than the exchanges.  The one exchange is the final 1 / l, through
+// a 64-float LDS line per wave.
+__global__ __launch_bounds__(256) void attn_mfma_fwd_long_kernel(const MesmAttnArgs p) {
+  __shared__ float Inv[4][32];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 31, hf = lane >> 5;
+  const int nqb = (p.Lq + 31) >> 5, nkb = (p.Lk + 31) >> 5;
+  const int item = blockIdx.x * 4 + wave;
+  if (item >= p.B * p.H * nqb) return;
+  const int bh = item / nqb, qb = item - bh * nqb;
+  const int b = bh / p.H, hd = bh - b * p.H;
+  const int q0 = qb * 32;
+  const int i = q0 + li;
+  const bool ivalid = i < p.Lq;
+  const int mg = p.mask_group > 0 ? p.mask_group : p.B;
+  const int b2 = (b / mg) * mg + ((b % mg) * p.H + hd) % mg;
+  const bool quirk = (p.mask_mode == MESM_MASK_T2V_QUIRK) && p.qpad && p.kpad;
+  const bool qp = quirk && ivalid && p.qpad[(int64_t)b2 * p.Lq + i] != 0;
+
+  float qf[16];
+  load_frag(p.q + (int64_t)b * p.q_bs + (int64_t)(ivalid ? i : p.Lq - 1) * p.q_ls + hd * 32 + 16 * hf, qf);
+  const float* kbase = p.k + (int64_t)b * p.k_bs + hd * 32 + 16 * hf;
+  const float* vb = p.v + (int64_t)b * p.v_bs + hd * 32 + li;
+
+  // masked, scaled scores of key block kb (registers = keys acc_row(r, hf))
+  auto scores = [&](int kb, f32x16& acc) {
+    const int j = 32 * kb + li;
+    float kf[16];
+    load_frag(kbase + (int64_t)(j < p.Lk ? j : p.Lk - 1) * p.k_ls, kf);
+    bool kp = j >= p.Lk, kp2 = false;
+    if (!kp && p.kpad) kp = p.kpad[(int64_t)b * p.Lk + j] != 0;
+    if (j < p.Lk && quirk) kp2 = p.kpad[(int64_t)b2 * p.Lk + j] != 0;
+    const uint32_t mk = (uint32_t)__ballot(kp), mk2 = (uint32_t)__ballot(kp2);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[s], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int jl = acc_row(r, hf);
+      const bool masked = ((mk >> jl) & 1u) || (qp && ((mk2 >> jl) & 1u));
+      acc[r] = masked ? -INFINITY : acc[r] * p.scale;
+    }
+  };
+
+  float mx = -INFINITY;
+  for (int kb = 0; kb < nkb; ++kb) {
+    f32x16 st;
+    scores(kb, st);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[r]);
+  }
+  mx = max_xor32(mx);
+
+  const uint32_t thresh = p.drop_p > 0.f ? mesm_drop_threshold(p.drop_p) : 0u;
+  const float inv_keep = 1.0f / (1.0f - p.drop_p);
+  const uint32_t drop_seed = p.drop_seed + (p.seed_offset ? *p.seed_offset : 0u);
+  const uint32_t row_idx = (uint32_t)(((int64_t)bh * p.Lq + i) * p.Lk);
+  float l = 0.0f;
+  f32x16 o;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.0f;
+  for (int kb = 0; kb < nkb; ++kb) {
+    float vf[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int j = 32 * kb + acc_row(r, hf);
+      vf[r] = j < p.Lk ? vb[(int64_t)j * p.v_ls] : 0.0f;
+    }
+    f32x16 st;
+    scores(kb, st);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float pj = (mx == -INFINITY) ? 0.0f : __expf(st[r] - mx);
+      l += pj;
+      st[r] = thresh ? mesm_dropout_apply(pj, row_idx + (uint32_t)(32 * kb + acc_row(r, hf)), drop_seed, thresh, inv_keep) : pj;
+    }
+    const int kvalid = p.Lk - 32 * kb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      if (acc_row(r, 0) >= kvalid) continue;
+      o = __builtin_amdgcn_mfma_f32_32x32x2f32(st[r], vf[r], o, 0, 0, 0);
+    }
+  }
+  l = sum_xor32(l);
+  // 1 / l of row i sits in lane i; the output accumulator holds rows acc_row(r, hf) in its registers
+  if (hf == 0) Inv[wave][li] = 1.0f / l;  // (all keys masked: 1 / 0 = inf, 0 * inf = NaN like the reference)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  float* ob = p.o + (int64_t)b * p.o_bs + hd * 32 + li;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int io = q0 + acc_row(r, hf);
+    if (io < p.Lq) ob[(int64_t)io * p.o_ls] = o[r] * Inv[wave][acc_row(r, hf)];
+  }
+  if (hf == 0 && ivalid && p.lse) p.lse[(int64_t)bh * p.Lq + i] = mx + __logf(l);
+}
+
 }  // namespace
 
 bool mesm_attn_mfma_ok(const MesmAttnArgs& a) {
-  return a.dk == 32 && a.dv == 32 && a.Lk <= 128 && !a.q2 && !a.k2 && !a.k_add && a.mask_mode != MESM_MASK_CAUSAL;
+  if (!(a.dk == 32 && a.dv == 32 && !a.q2 && !a.k2 && !a.k_add && a.mask_mode != MESM_MASK_CAUSAL)) return false;
+  // long key ranges: the two-pass kernel walks the key blocks serially per wave, which pays off only with enough
+  // query blocks to fill the chip (513 x 513: 398 -> 286 us; but 8 x 512: 25 -> 66 us, 16 x 200: 17 -> 31 us)
+  return a.Lk <= 128 || a.Lq >= 128;
 }
 
 int mesm_attn_mfma_fwd(const MesmAttnArgs& a, hipStream_t s) {
@@ -212,6 +320,10 @@ int mesm_attn_mfma_fwd(const MesmAttnArgs& a, hipStream_t s) {
   const long items = (long)a.B * a.H * nqb;
   dim3 grid((unsigned)((items + 3) / 4));
   const int nkb = (a.Lk + 31) / 32;
+  if (nkb > 4) {
+    hipLaunchKernelGGL(attn_mfma_fwd_long_kernel, grid, dim3(256), 0, s, a);
+    return mesm_launch_status();
+  }
   if (nkb == 1) hipLaunchKernelGGL(attn_mfma_fwd_kernel<1>, grid, dim3(256), 0, s, a);
   else if (nkb == 2) hipLaunchKernelGGL(attn_mfma_fwd_kernel<2>, grid, dim3(256), 0, s, a);
   else if (nkb == 3) hipLaunchKernelGGL(attn_mfma_fwd_kernel<3>, grid, dim3(256), 0, s, a);
