@@ -482,6 +482,8 @@ extern "C" int mesm_attn_bwd(const MesmAttnArgs* args, void* stream) {
   for (const void* ptr : ptrs)
     if (((uintptr_t)ptr % 16) != 0) return MESM_EALIGN;
   hipStream_t s = (hipStream_t)stream;
+  static const bool legacy = getenv("MESM_ATTN_LEGACY") != nullptr;
+  if (!legacy && mesm_attn_mfma_bwd_ok(a)) return mesm_attn_mfma_bwd(a, s);
   dim3 grid(a.B * a.H, (a.Lk + KT - 1) / KT);
   if (grid.y > 1) ATTN_DISPATCH(attn_bwd_kernel, grid, 128, 2);  // several key tiles: 2 waves per workgroup
   else ATTN_DISPATCH(attn_bwd_kernel, grid, 256, 4);

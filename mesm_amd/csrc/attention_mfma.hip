@@ -1,8 +1,8 @@
 // Attention core on the matrix cores for the step's hot shapes: head dims dk = dv = 32 (T2V 75 x 33, encoder
 // 76 x 76, MLM 33 x 75, SS 1..8 x 75 with all scores in registers; longer key ranges, e.g. TACoS' 513 x 513
 // encoder, in a two-pass loop over key blocks, below), every mask rule and the dropout hash of
-// attention.hip.  mesm_attn_fwd hands these shapes over (attention.hip: dispatch); split heads, the causal CLIP
-// mode, other head dims, longer key ranges and the whole backward stay on the lane-per-key kernels.  (fp32 MFMA
+// attention.hip.  mesm_attn_fwd / mesm_attn_bwd hand these shapes over (attention.hip: dispatch); split heads, the
+// causal CLIP mode, other head dims and the backward of short query ranges stay on the lane-per-key kernels.  (fp32 MFMA
 // and fp32 VALU have the same peak on this chip: the matrix cores buy fewer instructions and no cross-lane
 // traffic, not flops.  A matrix-core backward -- (query block, key block) pairs per wave, dQ / dK / dV summed in LDS
 // -- measured 27 / 37 us at 75 x 33 / 76 x 76 with plain LDS stores (wrong sums), 44 / 78 us with ds_add_f32, 30 / 43 us
@@ -306,6 +306,213 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_long_kernel(const MesmAttnA
   if (hf == 0 && ivalid && p.lse) p.lse[(int64_t)bh * p.Lq + i] = mx + __logf(l);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward for MANY query rows against few keys (TACoS: 512 clips x 17 words, where the lane-per-key backward
+// walks all 512 rows in one workgroup per head: 131 us).  One workgroup (4 waves) per (batch, head).  Wave w owns
+// key block kb = w % nkb for the whole kernel -- its K / V fragments, mask bits and the dK / dV accumulators stay
+// in registers -- and walks the 32-query blocks part, part + P, ... (part = w / nkb, P = 4 / nkb waves share a key
+// block).  Nothing is accumulated in shared memory: every partial block is written ONCE into an LDS slice private
+// to its producer (dQ blocks indexed by key block, dK / dV blocks by part when P > 1) and the workgroup adds the
+// slices while it writes the three matrices out in full 128-byte rows -- deterministic, no atomics, no
+// zero-initialised outputs.  Per (query block, key block):
+//   S^T = K Q^T, dP^T = V dO^T                (transposed layout: lane = query i, registers = keys j(r, half))
+//   p = exp(s - lse_i), keep-mask, ds = p (dp keep - delta_i) scale          (per-lane loops, like the forward)
+//   dQ  = dS K          A = dS^T registers, B = K rows j(r, half) read as coalesced 128-byte rows
+//   dV += P^T dO, dK += dS^T Q   need lane = key: the register block goes through a wave-private 32 x 33 LDS
+//                                tile (conflict-free both ways) and comes back as the A operand; B = dO / Q rows.
+// At the step's own shapes (75 x 33, 76 x 76, 33 x 75) this form measured 32 / 41 / 29 us against 30 / 52 / 29 us
+// for the lane-per-key kernel (VALU-issue bound either way), so it is dispatched for long query ranges only.
+__global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MesmAttnArgs p) {
+  __shared__ float Tr[4][32 * 33];  // per wave: P, then dS, on their way to the lane = key layout
+  extern __shared__ float Sl[];     // slices of 32 x 32: dQ [kb][qb], then (P > 1) dK [part][kb], dV [part][kb]
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 31, hf = lane >> 5;
+  const int bh = blockIdx.x;
+  const int b = bh / p.H, hd = bh - b * p.H;
+  const int nqb = (p.Lq + 31) >> 5, nkb = (p.Lk + 31) >> 5;
+  const int P = 4 / nkb;  // waves per key block (nkb <= 4)
+  const int kb = wave % nkb, part = wave / nkb;
+  const bool active = part < P;
+  const int mg = p.mask_group > 0 ? p.mask_group : p.B;
+  const int b2 = (b / mg) * mg + ((b % mg) * p.H + hd) % mg;
+  const bool quirk = (p.mask_mode == MESM_MASK_T2V_QUIRK) && p.qpad && p.kpad;
+  const uint32_t thresh = p.drop_p > 0.f ? mesm_drop_threshold(p.drop_p) : 0u;
+  const float inv_keep = 1.0f / (1.0f - p.drop_p);
+  const uint32_t drop_seed = p.drop_seed + (p.seed_offset ? *p.seed_offset : 0u);
+
+  float* SlQ = Sl;
+  float* SlK = Sl + nkb * nqb * 1024;
+  float* SlV = SlK + P * nkb * 1024;
+
+  const int64_t hcol = hd * 32;
+  const float* qb_ = p.q + (int64_t)b * p.q_bs + hcol;
+  const float* kb_ = p.k + (int64_t)b * p.k_bs + hcol;
+  const float* vb_ = p.v + (int64_t)b * p.v_bs + hcol;
+  const float* ob_ = p.o + (int64_t)b * p.o_bs + hcol;
+  const float* dob_ = p.d_o + (int64_t)b * p.o_bs + hcol;
+  float* tr = &Tr[wave][0];
+
+  if (active) {
+    const int k0 = 32 * kb;
+    const int kvalid = p.Lk - k0;  // keys of the block inside the sequence
+    const int j = k0 + li;
+    const int jc = j < p.Lk ? j : p.Lk - 1;
+    bool kp = j >= p.Lk, kp2 = false;
+    if (!kp && p.kpad) kp = p.kpad[(int64_t)b * p.Lk + j] != 0;
+    if (j < p.Lk && quirk) kp2 = p.kpad[(int64_t)b2 * p.Lk + j] != 0;
+    const uint32_t mk = (uint32_t)__ballot(kp), mk2 = (uint32_t)__ballot(kp2);
+    float kf[16], vf[16];
+    load_frag(kb_ + (int64_t)jc * p.k_ls + 16 * hf, kf);
+    load_frag(vb_ + (int64_t)jc * p.v_ls + 16 * hf, vf);
+    f32x16 dKa, dVa;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dKa[r] = dVa[r] = 0.0f;
+
+    for (int qb = part; qb < nqb; qb += P) {
+      const int q0 = 32 * qb;
+      const int i = q0 + li;
+      const bool ivalid = i < p.Lq;
+      const int ic = ivalid ? i : p.Lq - 1;
+      const int qvalid = p.Lq - q0;
+      f32x16 st, dpt;
+      float delta;
+      {
+        float qf[16], gf[16], of[16];
+        load_frag(qb_ + (int64_t)ic * p.q_ls + 16 * hf, qf);
+        load_frag(dob_ + (int64_t)ic * p.o_ls + 16 * hf, gf);
+        load_frag(ob_ + (int64_t)ic * p.o_ls + 16 * hf, of);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[r] = dpt[r] = 0.0f;
+#pragma unroll
+        for (int s_ = 0; s_ < 16; ++s_) {
+          st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s_], qf[s_], st, 0, 0, 0);
+          dpt = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[s_], gf[s_], dpt, 0, 0, 0);
+        }
+        delta = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) delta += gf[c] * of[c];
+        delta = sum_xor32(delta);
+      }
+      // rows of K, dO and Q read as columns (the B operands of dQ, dV, dK), requested now that the row fragments
+      // are dead: their latency hides behind the exp / hash loop
+      float gc[16], qc[16], kc[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int io = q0 + acc_row(r, hf), jo = k0 + acc_row(r, hf);
+        kc[r] = jo < p.Lk ? kb_[(int64_t)jo * p.k_ls + li] : 0.0f;
+        gc[r] = io < p.Lq ? dob_[(int64_t)io * p.o_ls + li] : 0.0f;
+        qc[r] = io < p.Lq ? qb_[(int64_t)io * p.q_ls + li] : 0.0f;
+      }
+      {
+        const float lse_i = ivalid ? p.lse[(int64_t)bh * p.Lq + i] : 0.0f;
+        const bool qp = quirk && ivalid && p.qpad[(int64_t)b2 * p.Lq + i] != 0;
+        const uint32_t row_idx = (uint32_t)(((int64_t)bh * p.Lq + i) * p.Lk);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int jl = acc_row(r, hf);
+          const bool masked = !ivalid || ((mk >> jl) & 1u) || (qp && ((mk2 >> jl) & 1u));
+          const float pj = masked ? 0.0f : __expf(st[r] * p.scale - lse_i);
+          float km = 1.0f;
+          if (thresh) km = mesm_hash32(row_idx + (uint32_t)(k0 + jl), drop_seed) >= thresh ? inv_keep : 0.0f;
+          st[r] = pj * km;                                // what multiplied V in the forward
+          dpt[r] = pj * (dpt[r] * km - delta) * p.scale;  // dS (scale folded in)
+        }
+      }
+      // P on its way to the lane = key layout (the tile is free: the previous block's reads are complete)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tr[acc_row(r, hf) * 33 + li] = st[r];
+      // dQ block of this key block: A = dS^T registers, B = K rows; stored once into slice [kb][qb]
+      {
+        f32x16 dQa;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dQa[r] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (acc_row(r, 0) >= kvalid) continue;  // both halves' keys are past Lk
+          dQa = __builtin_amdgcn_mfma_f32_32x32x2f32(dpt[r], kc[r], dQa, 0, 0, 0);
+        }
+        float* sq = SlQ + (kb * nqb + qb) * 1024 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sq[acc_row(r, hf) * 32] = dQa[r];
+      }
+      {
+        float pn[16];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pn[r] = tr[li * 33 + acc_row(r, hf)];
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tr[acc_row(r, hf) * 33 + li] = dpt[r];  // dS follows
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (acc_row(r, 0) >= qvalid) continue;  // both halves' query rows are past Lq
+          dVa = __builtin_amdgcn_mfma_f32_32x32x2f32(pn[r], gc[r], dVa, 0, 0, 0);
+        }
+      }
+      {
+        float sn[16];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sn[r] = tr[li * 33 + acc_row(r, hf)];
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if (acc_row(r, 0) >= qvalid) continue;
+          dKa = __builtin_amdgcn_mfma_f32_32x32x2f32(sn[r], qc[r], dKa, 0, 0, 0);
+        }
+      }
+    }
+    if (P == 1) {  // this wave alone owns the key block: straight to memory
+      float* dkb = p.dk_ + (int64_t)b * p.k_bs + hcol + li;
+      float* dvb = p.dv_ + (int64_t)b * p.v_bs + hcol + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int jo = k0 + acc_row(r, hf);
+        if (jo < p.Lk) {
+          dkb[(int64_t)jo * p.k_ls] = dKa[r];
+          dvb[(int64_t)jo * p.v_ls] = dVa[r];
+        }
+      }
+    } else {
+      float* sk = SlK + (part * nkb + kb) * 1024 + li;
+      float* sv = SlV + (part * nkb + kb) * 1024 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        sk[acc_row(r, hf) * 32] = dKa[r];
+        sv[acc_row(r, hf) * 32] = dVa[r];
+      }
+    }
+  }
+  __syncthreads();
+  // write-out, one 128-byte row per 32 threads, adding the producers' slices
+  {
+    const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+    float* dqb = p.dq + (int64_t)b * p.q_bs + hcol + c;
+    for (int r = r0; r < p.Lq; r += 8) {
+      float t = 0.0f;
+      for (int kk = 0; kk < nkb; ++kk) t += SlQ[(kk * nqb) * 1024 + r * 32 + c];
+      dqb[(int64_t)r * p.q_ls] = t;
+    }
+    if (P > 1) {
+      float* dkb = p.dk_ + (int64_t)b * p.k_bs + hcol + c;
+      float* dvb = p.dv_ + (int64_t)b * p.v_bs + hcol + c;
+      for (int r = r0; r < p.Lk; r += 8) {
+        float tk = 0.0f, tv = 0.0f;
+        for (int pp = 0; pp < P; ++pp) {
+          tk += SlK[pp * nkb * 1024 + r * 32 + c];
+          tv += SlV[pp * nkb * 1024 + r * 32 + c];
+        }
+        dkb[(int64_t)r * p.k_ls] = tk;
+        dvb[(int64_t)r * p.v_ls] = tv;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 bool mesm_attn_mfma_ok(const MesmAttnArgs& a) {
@@ -328,5 +535,30 @@ int mesm_attn_mfma_fwd(const MesmAttnArgs& a, hipStream_t s) {
   else if (nkb == 2) hipLaunchKernelGGL(attn_mfma_fwd_kernel<2>, grid, dim3(256), 0, s, a);
   else if (nkb == 3) hipLaunchKernelGGL(attn_mfma_fwd_kernel<3>, grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL(attn_mfma_fwd_kernel<4>, grid, dim3(256), 0, s, a);
+  return mesm_launch_status();
+}
+
+static size_t bwd_slices_bytes(const MesmAttnArgs& a) {
+  const int nqb = (a.Lq + 31) / 32, nkb = (a.Lk + 31) / 32;
+  const int P = 4 / nkb;
+  return (size_t)(nkb * nqb + (P > 1 ? 2 * P * nkb : 0)) * 1024 * sizeof(float);
+}
+
+// long query ranges against at most 128 keys, as far as the partial blocks fit in LDS (160 KB - 17 KB static)
+bool mesm_attn_mfma_bwd_ok(const MesmAttnArgs& a) {
+  return a.dk == 32 && a.dv == 32 && !a.q2 && !a.k2 && !a.k_add && a.mask_mode != MESM_MASK_CAUSAL &&
+         a.Lk <= 128 && a.Lq >= 256 && bwd_slices_bytes(a) <= 140 * 1024;
+}
+
+int mesm_attn_mfma_bwd(const MesmAttnArgs& a, hipStream_t s) {
+  const size_t lds = bwd_slices_bytes(a);
+  static bool raised = false;
+  if (!raised) {  // dynamic LDS beyond 64 KB has to be allowed once per function
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            140 * 1024) != hipSuccess)
+      return MESM_ELAUNCH;
+    raised = true;
+  }
+  hipLaunchKernelGGL(attn_mfma_bwd_kernel, dim3((unsigned)(a.B * a.H)), dim3(256), lds, s, a);
   return mesm_launch_status();
 }

@@ -4,3 +4,5 @@
 
 bool mesm_attn_mfma_ok(const MesmAttnArgs& a);
 int mesm_attn_mfma_fwd(const MesmAttnArgs& a, hipStream_t s);
+bool mesm_attn_mfma_bwd_ok(const MesmAttnArgs& a);
+int mesm_attn_mfma_bwd(const MesmAttnArgs& a, hipStream_t s);

@@ -261,6 +261,11 @@ ATTN_CASES = [
     (2, 2, 40, 2, 32, 32, False, False),
     (4, 8, 75, 36, 32, 32, True, True),
     (4, 8, 20, 67, 32, 32, True, False),
+    # long query ranges: matrix-core backward (Lq >= 256, Lk <= 128), two-pass forward (Lk > 128, Lq >= 128)
+    (4, 8, 512, 17, 32, 32, True, True),
+    (2, 8, 300, 128, 32, 32, True, False),
+    (2, 4, 257, 40, 32, 32, True, True),
+    (2, 4, 140, 200, 32, 32, True, True),
 ]
 
 
