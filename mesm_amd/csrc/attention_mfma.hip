@@ -329,7 +329,8 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MesmAttnArgs p
   const int li = lane & 31, hf = lane >> 5;
   const int bh = blockIdx.x;
   const int b = bh / p.H, hd = bh - b * p.H;
-  const int nqb = (p.Lq + 31) >> 5, nkb = (p.Lk + 31) >> 5;
+  const int Lq = p.Lq, Lk = p.Lk;
+  const int nqb = (Lq + 31) >> 5, nkb = (Lk + 31) >> 5;
   const int P = 4 / nkb;  // waves per key block (nkb <= 4)
   const int kb = wave % nkb, part = wave / nkb;
   const bool active = part < P;
@@ -339,48 +340,70 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MesmAttnArgs p
   const uint32_t thresh = p.drop_p > 0.f ? mesm_drop_threshold(p.drop_p) : 0u;
   const float inv_keep = 1.0f / (1.0f - p.drop_p);
   const uint32_t drop_seed = p.drop_seed + (p.seed_offset ? *p.seed_offset : 0u);
+  const float scale = p.scale;
 
   float* SlQ = Sl;
   float* SlK = Sl + nkb * nqb * 1024;
   float* SlV = SlK + P * nkb * 1024;
 
-  const int64_t hcol = hd * 32;
+  // Addressing: ONE 64-bit base per tensor (batch and head folded in, wave-uniform) and 32-bit element offsets
+  // built with 24-bit multiplies and adds -- row * stride products in 64 bits (v_mad_u64_u32, v_mul_lo_u32,
+  // quarter rate) were ~350 of the ~1,800 vector instructions of a block pair.  mesm_attn_mfma_bwd_ok() checks
+  // that a batch slice fits 2^24 elements per row stride and 2^31 in total.
+  const int hcol = hd * 32;
   const float* qb_ = p.q + (int64_t)b * p.q_bs + hcol;
   const float* kb_ = p.k + (int64_t)b * p.k_bs + hcol;
   const float* vb_ = p.v + (int64_t)b * p.v_bs + hcol;
   const float* ob_ = p.o + (int64_t)b * p.o_bs + hcol;
   const float* dob_ = p.d_o + (int64_t)b * p.o_bs + hcol;
+  const uint32_t qls = (uint32_t)p.q_ls, kls = (uint32_t)p.k_ls, vls = (uint32_t)p.v_ls, ols = (uint32_t)p.o_ls;
   float* tr = &Tr[wave][0];
+  // LDS offsets of the transposition tile: constant per lane
+  const int tw = (4 * hf) * 33 + li;   // + (r & 3) * 33 + (r >> 2) * 264 : write [key row][query col]
+  const int trd = li * 33 + 4 * hf;    // + (r & 3) + 8 (r >> 2)          : read  [key = lane][query row]
 
   if (active) {
     const int k0 = 32 * kb;
-    const int kvalid = p.Lk - k0;  // keys of the block inside the sequence
+    const int kvalid = Lk - k0;  // keys of the block inside the sequence
     const int j = k0 + li;
-    const int jc = j < p.Lk ? j : p.Lk - 1;
-    bool kp = j >= p.Lk, kp2 = false;
-    if (!kp && p.kpad) kp = p.kpad[(int64_t)b * p.Lk + j] != 0;
-    if (j < p.Lk && quirk) kp2 = p.kpad[(int64_t)b2 * p.Lk + j] != 0;
+    const uint32_t jc = (uint32_t)(j < Lk ? j : Lk - 1);
+    bool kp = j >= Lk, kp2 = false;
+    if (!kp && p.kpad) kp = p.kpad[(uint32_t)(b * Lk + j)] != 0;
+    if (j < Lk && quirk) kp2 = p.kpad[(uint32_t)(b2 * Lk + j)] != 0;
     const uint32_t mk = (uint32_t)__ballot(kp), mk2 = (uint32_t)__ballot(kp2);
     float kf[16], vf[16];
-    load_frag(kb_ + (int64_t)jc * p.k_ls + 16 * hf, kf);
-    load_frag(vb_ + (int64_t)jc * p.v_ls + 16 * hf, vf);
+    load_frag(kb_ + (__umul24(jc, kls) + 16 * hf), kf);
+    load_frag(vb_ + (__umul24(jc, vls) + 16 * hf), vf);
+    // rows k0 + j(r, half) of K read as columns: B operand of dQ, the same for every query block
+    float kc[16];
+    {
+      const uint32_t o0 = __umul24((uint32_t)(k0 + 4 * hf), kls) + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int jo = k0 + acc_row(r, hf);
+        const float x = kb_[o0 + (uint32_t)((r & 3) + 8 * (r >> 2)) * kls];
+        kc[r] = jo < Lk ? x : 0.0f;
+      }
+    }
     f32x16 dKa, dVa;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dKa[r] = dVa[r] = 0.0f;
+    const bool any_mask = (mk | mk2) != 0u;  // wave-uniform
 
     for (int qb = part; qb < nqb; qb += P) {
       const int q0 = 32 * qb;
       const int i = q0 + li;
-      const bool ivalid = i < p.Lq;
-      const int ic = ivalid ? i : p.Lq - 1;
-      const int qvalid = p.Lq - q0;
+      const bool ivalid = i < Lq;
+      const uint32_t ic = (uint32_t)(ivalid ? i : Lq - 1);
+      const int qvalid = Lq - q0;
       f32x16 st, dpt;
       float delta;
       {
         float qf[16], gf[16], of[16];
-        load_frag(qb_ + (int64_t)ic * p.q_ls + 16 * hf, qf);
-        load_frag(dob_ + (int64_t)ic * p.o_ls + 16 * hf, gf);
-        load_frag(ob_ + (int64_t)ic * p.o_ls + 16 * hf, of);
+        const uint32_t oo = __umul24(ic, ols) + 16 * hf;
+        load_frag(qb_ + (__umul24(ic, qls) + 16 * hf), qf);
+        load_frag(dob_ + oo, gf);
+        load_frag(ob_ + oo, of);
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[r] = dpt[r] = 0.0f;
 #pragma unroll
@@ -393,34 +416,45 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MesmAttnArgs p
         for (int c = 0; c < 16; ++c) delta += gf[c] * of[c];
         delta = sum_xor32(delta);
       }
-      // rows of K, dO and Q read as columns (the B operands of dQ, dV, dK), requested now that the row fragments
-      // are dead: their latency hides behind the exp / hash loop
-      float gc[16], qc[16], kc[16];
+      // rows q0 + j(r, half) of dO and Q read as columns (the B operands of dV, dK), requested now that the row
+      // fragments are dead: their latency hides behind the exp / hash loop.  Rows past Lq read row Lq - 1 (their
+      // A operands are zero).
+      float gc[16], qc[16];
+      {
+        const int rb = q0 + 4 * hf;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int io = q0 + acc_row(r, hf), jo = k0 + acc_row(r, hf);
-        kc[r] = jo < p.Lk ? kb_[(int64_t)jo * p.k_ls + li] : 0.0f;
-        gc[r] = io < p.Lq ? dob_[(int64_t)io * p.o_ls + li] : 0.0f;
-        qc[r] = io < p.Lq ? qb_[(int64_t)io * p.q_ls + li] : 0.0f;
+        for (int r = 0; r < 16; ++r) {
+          int io = rb + (r & 3) + 8 * (r >> 2);
+          io = io < Lq ? io : Lq - 1;
+          gc[r] = dob_[__umul24((uint32_t)io, ols) + li];
+          qc[r] = qb_[__umul24((uint32_t)io, qls) + li];
+        }
       }
       {
-        const float lse_i = ivalid ? p.lse[(int64_t)bh * p.Lq + i] : 0.0f;
-        const bool qp = quirk && ivalid && p.qpad[(int64_t)b2 * p.Lq + i] != 0;
-        const uint32_t row_idx = (uint32_t)(((int64_t)bh * p.Lq + i) * p.Lk);
+        const float lse_i = ivalid ? p.lse[(uint32_t)(bh * Lq + i)] : 0.0f;
+        const bool qp = quirk && ivalid && p.qpad[(uint32_t)(b2 * Lq + i)] != 0;
+        // dropout index ((bh Lq + i) Lk + j) * golden, formed by additions from one product per block pair
+        const uint32_t h0 = ((uint32_t)(bh * Lq + i) * (uint32_t)Lk + (uint32_t)(k0 + 4 * hf)) * 0x9E3779B9u + drop_seed;
+        const bool row_off = !ivalid || false;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int jl = acc_row(r, hf);
-          const bool masked = !ivalid || ((mk >> jl) & 1u) || (qp && ((mk2 >> jl) & 1u));
-          const float pj = masked ? 0.0f : __expf(st[r] * p.scale - lse_i);
+          bool masked = row_off;
+          if (any_mask) masked = masked || ((mk >> jl) & 1u) || (qp && ((mk2 >> jl) & 1u));
+          const float pj = masked ? 0.0f : __expf(st[r] * scale - lse_i);
           float km = 1.0f;
-          if (thresh) km = mesm_hash32(row_idx + (uint32_t)(k0 + jl), drop_seed) >= thresh ? inv_keep : 0.0f;
-          st[r] = pj * km;                                // what multiplied V in the forward
-          dpt[r] = pj * (dpt[r] * km - delta) * p.scale;  // dS (scale folded in)
+          if (thresh) {
+            uint32_t x = h0 + (uint32_t)((r & 3) + 8 * (r >> 2)) * 0x9E3779B9u;  // = mesm_hash32(idx, seed)
+            x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+            km = x >= thresh ? inv_keep : 0.0f;
+          }
+          st[r] = pj * km;                              // what multiplied V in the forward
+          dpt[r] = pj * (dpt[r] * km - delta) * scale;  // dS (scale folded in)
         }
       }
       // P on its way to the lane = key layout (the tile is free: the previous block's reads are complete)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) tr[acc_row(r, hf) * 33 + li] = st[r];
+      for (int r = 0; r < 16; ++r) tr[tw + (r & 3) * 33 + (r >> 2) * 264] = st[r];
       // dQ block of this key block: A = dS^T registers, B = K rows; stored once into slice [kb][qb]
       {
         f32x16 dQa;
@@ -431,20 +465,20 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MesmAttnArgs p
           if (acc_row(r, 0) >= kvalid) continue;  // both halves' keys are past Lk
           dQa = __builtin_amdgcn_mfma_f32_32x32x2f32(dpt[r], kc[r], dQa, 0, 0, 0);
         }
-        float* sq = SlQ + (kb * nqb + qb) * 1024 + li;
+        float* sq = SlQ + (kb * nqb + qb) * 1024 + (4 * hf) * 32 + li;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sq[acc_row(r, hf) * 32] = dQa[r];
+        for (int r = 0; r < 16; ++r) sq[((r & 3) + 8 * (r >> 2)) * 32] = dQa[r];
       }
       {
         float pn[16];
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) pn[r] = tr[li * 33 + acc_row(r, hf)];
+        for (int r = 0; r < 16; ++r) pn[r] = tr[trd + (r & 3) + 8 * (r >> 2)];
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) tr[acc_row(r, hf) * 33 + li] = dpt[r];  // dS follows
+        for (int r = 0; r < 16; ++r) tr[tw + (r & 3) * 33 + (r >> 2) * 264] = dpt[r];  // dS follows
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           if (acc_row(r, 0) >= qvalid) continue;  // both halves' query rows are past Lq
@@ -456,7 +490,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MesmAttnArgs p
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sn[r] = tr[li * 33 + acc_row(r, hf)];
+        for (int r = 0; r < 16; ++r) sn[r] = tr[trd + (r & 3) + 8 * (r >> 2)];
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -472,9 +506,9 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MesmAttnArgs p
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int jo = k0 + acc_row(r, hf);
-        if (jo < p.Lk) {
-          dkb[(int64_t)jo * p.k_ls] = dKa[r];
-          dvb[(int64_t)jo * p.v_ls] = dVa[r];
+        if (jo < Lk) {
+          dkb[__umul24((uint32_t)jo, kls)] = dKa[r];
+          dvb[__umul24((uint32_t)jo, vls)] = dVa[r];
         }
       }
     } else {
@@ -492,22 +526,22 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MesmAttnArgs p
   {
     const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
     float* dqb = p.dq + (int64_t)b * p.q_bs + hcol + c;
-    for (int r = r0; r < p.Lq; r += 8) {
+    for (int r = r0; r < Lq; r += 8) {
       float t = 0.0f;
       for (int kk = 0; kk < nkb; ++kk) t += SlQ[(kk * nqb) * 1024 + r * 32 + c];
-      dqb[(int64_t)r * p.q_ls] = t;
+      dqb[__umul24((uint32_t)r, qls)] = t;
     }
     if (P > 1) {
       float* dkb = p.dk_ + (int64_t)b * p.k_bs + hcol + c;
       float* dvb = p.dv_ + (int64_t)b * p.v_bs + hcol + c;
-      for (int r = r0; r < p.Lk; r += 8) {
+      for (int r = r0; r < Lk; r += 8) {
         float tk = 0.0f, tv = 0.0f;
         for (int pp = 0; pp < P; ++pp) {
           tk += SlK[pp * nkb * 1024 + r * 32 + c];
           tv += SlV[pp * nkb * 1024 + r * 32 + c];
         }
-        dkb[(int64_t)r * p.k_ls] = tk;
-        dvb[(int64_t)r * p.v_ls] = tv;
+        dkb[__umul24((uint32_t)r, kls)] = tk;
+        dvb[__umul24((uint32_t)r, vls)] = tv;
       }
     }
   }
@@ -538,6 +572,9 @@ int mesm_attn_mfma_fwd(const MesmAttnArgs& a, hipStream_t s) {
   return mesm_launch_status();
 }
 
+#ifndef MESM_ATTN_BWD_MIN_LQ
+#define MESM_ATTN_BWD_MIN_LQ 256
+#endif
 static size_t bwd_slices_bytes(const MesmAttnArgs& a) {
   const int nqb = (a.Lq + 31) / 32, nkb = (a.Lk + 31) / 32;
   const int P = 4 / nkb;
@@ -546,8 +583,15 @@ static size_t bwd_slices_bytes(const MesmAttnArgs& a) {
 
 // long query ranges against at most 128 keys, as far as the partial blocks fit in LDS (160 KB - 17 KB static)
 bool mesm_attn_mfma_bwd_ok(const MesmAttnArgs& a) {
-  return a.dk == 32 && a.dv == 32 && !a.q2 && !a.k2 && !a.k_add && a.mask_mode != MESM_MASK_CAUSAL &&
-         a.Lk <= 128 && a.Lq >= 256 && bwd_slices_bytes(a) <= 140 * 1024;
+  // 32-bit element offsets inside a batch slice, 24-bit row * stride products
+  const int64_t lim24 = 1 << 24;
+  const bool small = a.q_ls < lim24 && a.k_ls < lim24 && a.v_ls < lim24 && a.o_ls < lim24 && a.Lq < lim24 &&
+                     (int64_t)a.Lq * a.q_ls < (1ll << 31) && (int64_t)a.Lq * a.o_ls < (1ll << 31) &&
+                     (int64_t)a.Lk * a.k_ls < (1ll << 31) && (int64_t)a.Lk * a.v_ls < (1ll << 31) &&
+                     (int64_t)a.B * a.H * a.Lq < (1ll << 31) && (int64_t)a.B * a.Lk < (1ll << 31) &&
+                     (int64_t)a.B * a.Lq < (1ll << 31);
+  return small && a.dk == 32 && a.dv == 32 && !a.q2 && !a.k2 && !a.k_add && a.mask_mode != MESM_MASK_CAUSAL &&
+         a.Lk <= 128 && a.Lq >= MESM_ATTN_BWD_MIN_LQ && bwd_slices_bytes(a) <= 140 * 1024;
 }
 
 int mesm_attn_mfma_bwd(const MesmAttnArgs& a, hipStream_t s) {
