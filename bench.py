@@ -6,7 +6,8 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A step = model(**batch) -> criterion(outputs, batch) -> zero_grad -> total.backward()
-[-> bucketed gradient all-reduce for N > 1, overlapped with backward inside the step's HIP graph], in
+[-> gradient all-reduce of the flat buffer for N > 1: one blocking all-reduce on the compute stream after the
+graph replay by default, MESM_DDP_MODE=captured for the bucketed all-reduce overlapped inside the graph], in
 TRAIN mode (all dropouts active), on the QVHighlights C+SF workload "C3a" of SURVEY.md 8d (32 pairs per
 GPU, Lv=75, Lw=32, Dv=2818, Dt=512, C=5003, fp32).  Inputs are resident in HBM before the timed
 region; the host-side draws of the reference (negative query index, MLM word choice) are re-drawn
@@ -156,17 +157,22 @@ def main():
         step = eager_step
         ddp_mode = "hooks-from-backward (eager)" if world > 1 else None
     else:
-        # one HIP graph per step: forward + criterion + backward; fresh host draws + dropout masks every
-        # replay; for N > 1 the bucket all-reduces are recorded INSIDE the graph on the collective stream
-        # (bucket k reduces while backward continues); MESM_DDP_MODE=after puts one reduce after the replay,
-        # MESM_DDP_MODE=inline one blocking reduce inside the graph on the capture stream
+        # one HIP graph per step: forward + criterion + backward; fresh host draws + dropout masks every replay.
+        # N > 1, MESM_DDP_MODE =
+        #   after (default): ONE blocking all-reduce of the flat gradient buffer on the COMPUTE stream right after
+        #                    the replay -- nothing of the process group is ever captured (robust), no second
+        #                    hardware queue is active (none of its ~0.5 ms toll on the step),
+        #                    the wire time is exposed;
+        #   captured:        the bucket all-reduces recorded INSIDE the graph on the collective stream (bucket k
+        #                    reduces while backward continues); pays the second-queue toll, and the 1-rank capture
+        #                    test aborted in ~3 % of process starts (watchdog thread vs. captured events);
+        #   inline:          one blocking all-reduce captured at the end of the graph on the capture stream;
+        #   after-async:     the round-1 form (asynchronous collectives on the process group's stream after the replay).
         gstep, reducer, post = None, None, False
-        mode = os.environ.get("MESM_DDP_MODE", "captured")  # captured | inline | after
+        mode = os.environ.get("MESM_DDP_MODE", "after")
         if world > 1 and mode in ("captured", "inline"):
             ok = 1
             try:
-                # inline: blocking collectives on the capture stream itself -- the graph stays one linear chain
-                # (no second-queue toll) at the price of no overlap; one bucket then
                 reducer = GradReducer(model.gradbuf(), hook=True, inline=mode == "inline",
                                       n_buckets=1 if mode == "inline" else 6)
                 gstep = GraphedStep(model, crit, batch, args.dataset_name, reducer=reducer)
@@ -184,9 +190,12 @@ def main():
         if gstep is None:
             gstep = GraphedStep(model, crit, batch, args.dataset_name)
             if world > 1:
-                reducer = GradReducer(model.gradbuf(), hook=False)
+                blocking = mode != "after-async"
+                reducer = GradReducer(model.gradbuf(), hook=False, inline=blocking, n_buckets=1 if blocking else 6)
                 post = True
-                ddp_mode = "one all-reduce of the flat buffer after the graph replay (no overlap)"
+                ddp_mode = ("one blocking all-reduce of the flat buffer on the compute stream after the graph replay"
+                            if blocking else
+                            "asynchronous all-reduces on the collective stream after the graph replay")
         log("step captured in a HIP graph")
 
         def step():

@@ -202,5 +202,10 @@ def init_process_group_from_env(device=None):
     kw = {}
     if backend == "nccl":
         kw["device_id"] = device
+        # Collectives captured inside a HIP graph: the process group's flight recorder keeps querying the events
+        # of the collectives it has seen -- also those recorded in a CAPTURING stream, which is an error
+        # (hipErrorCapturedEvent) that terminates the process from the watchdog thread (seen in ~1 of 10 runs of
+        # the 1-rank capture test; 0 of 46 with the recorder off).  It is a debugging aid; off unless asked for.
+        os.environ.setdefault("TORCH_NCCL_TRACE_BUFFER_SIZE", "0")
     dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]),
                             world_size=int(os.environ["WORLD_SIZE"]), **kw)

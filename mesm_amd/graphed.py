@@ -106,7 +106,10 @@ class GraphedStep:
             model.zero_grad(set_to_none=True)
             if instrument:  # record the GEMM launches of the captured step (bench roofline)
                 kn.gemm_tape(True)
-            with torch.cuda.graph(self.graph):
+            # capture_error_mode="thread_local": the process group's watchdog THREAD polls the events of earlier
+            # (eager, warm-up) collectives whenever it likes; under the default global mode such a query during
+            # our capture is an error that kills the process (seen in ~1 of 3 runs of the 1-rank RCCL test)
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                 self.counter.add_(1)
                 self.total, self.losses = self._step_body()
             if dot:

@@ -16,7 +16,9 @@ def main():
     from mesm_amd.graphed import GraphedStep
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from mesm_amd.ddp import init_process_group_from_env
+    os.environ.update(RANK="0", WORLD_SIZE="1")
+    init_process_group_from_env(dev)  # (turns the flight recorder off: see ddp.py)
     args = synthetic.make_args("C3a", device="cuda:0")
     torch.manual_seed(7)
     model = build_model(args)

@@ -236,12 +236,25 @@ def test_allreduce_captured_inside_the_step_graph(mode):
     import json
     import subprocess
     import sys
+    import socket
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, os.path.join(here, "ddp_capture_worker.py"), mode], env=env,
-                       capture_output=True, text=True, timeout=600)
-    lines = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
-    assert lines, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    # Up to three attempts: with collectives captured in a graph, torch's process-group WATCHDOG thread now and
+    # then queries an event that was recorded in the capturing stream (hipErrorCapturedEvent) and terminates the
+    # child -- ~3 % of starts on this stack even with capture_error_mode="thread_local" and the flight recorder
+    # off (46 + 30 runs counted).  That race lives in the runtime, not in the reducer under test; it is the
+    # reason why bench.py's default for N > 1 keeps the collectives OUT of the graph.
+    lines, r = [], None
+    for _ in range(3):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run([sys.executable, os.path.join(here, "ddp_capture_worker.py"), mode], env=env,
+                           capture_output=True, text=True, timeout=600)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+        if lines or "CapturedEvent" not in r.stderr and "stream is capturing" not in r.stderr:
+            break
+    assert lines, (r.returncode, r.stdout[-3000:], r.stderr[-3000:])
     res = json.loads(lines[-1][7:])
     assert res["launch_log_tail"] == [5, 4, 3, 2, 1, 0], res
     # the second graph's warm-up ran without collectives: only its capture recorded the six buckets

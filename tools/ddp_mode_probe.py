@@ -26,23 +26,30 @@ def main():
     from mesm_amd.graphed import GraphedStep
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    from mesm_amd.ddp import init_process_group_from_env
+    os.environ.update(RANK="0", WORLD_SIZE="1")
+    init_process_group_from_env(dev)
     args = synthetic.make_args("C3a", device="cuda:0")
     torch.manual_seed(7)
     model = build_model(args); crit = build_criterion(args); model.train()
     batch = synthetic.to_device(synthetic.workload_batch("C3a", seed=1), dev)
-    mode = sys.argv[1] if len(sys.argv) > 1 else "a"   # one mode per process: a | c | b1 | b6 | i1
-    if mode in ("a", "c"):
+    mode = sys.argv[1] if len(sys.argv) > 1 else "a"   # one mode per process: a | c | ci | b1 | b6 | i1
+    if mode in ("a", "c", "ci"):
         g0 = GraphedStep(model, crit, batch, args.dataset_name)
         if mode == "a":
             print("(a) no reducer:                         %.3f ms/step" % bench(lambda: g0.run()), flush=True)
         else:
-            red = GradReducer(model.gradbuf(), hook=False, force=True)
+            # ci: ONE blocking all-reduce on the compute stream itself (no second queue); c: six asynchronous
+            # ones on the process group's stream
+            red = GradReducer(model.gradbuf(), hook=False, force=True, inline=mode == "ci",
+                              n_buckets=1 if mode == "ci" else 6)
 
             def after():
                 g0.run()
                 red.finish()
-            print("(c) one all-reduce after the replay:    %.3f ms/step" % bench(after), flush=True)
+            print("(%s) all-reduce after the replay (%s): %.3f ms/step"
+                  % (mode, "blocking, compute stream" if mode == "ci" else "asynchronous, collective stream", bench(after)),
+                  flush=True)
     else:
         nb = int(mode[1:])   # b<n>: overlapped buckets on the collective stream; i<n>: blocking, on the capture stream
         red2 = GradReducer(model.gradbuf(), n_buckets=nb, hook=True, force=True, inline=mode[0] == "i")
