@@ -377,7 +377,14 @@ def main():
         }
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist.destroy_process_group()
+        # leave together and without tearing the communicator down: destroying a RCCL process group next to live
+        # HIP graphs has aborted the interpreter on this stack (tests/ddp_capture_worker.py leaves the same way),
+        # and a crash after the result line would still fail the run
+        sys.stdout.flush()
+        sys.stderr.flush()
+        dist.barrier()
+        torch.cuda.synchronize()
+        os._exit(0)
 
 
 if __name__ == "__main__":
