@@ -206,6 +206,45 @@ int mesm_layernorm_bwd3(const float* dy, const float* x, const float* gamma, con
                         float* dx2, float drop2_p, uint32_t drop2_seed, const float* dyb, const float* addend,
                         void* stream);
 
+/*
+ * Grouped launches: n independent LayerNorm problems (the same launch phase of independent chains of the step:
+ * the enhance / SS-MESM / MLM stacks after the input projections, model.py:184-207, 307-332) in as few kernels
+ * as possible -- problems with D <= 256 (one float4 per lane) share launches of up to 8, the others run through
+ * the plain entry points.  One struct serves both directions: the forward reads x, gamma, beta, eps, drop_*, add
+ * and writes y, mean, rstd, y2; the backward reads dy, x, gamma, mean, rstd, drop_*, drop2_*, dyb, addend and
+ * writes dx, dx2, dgamma, dbeta (field meanings as in mesm_layernorm_fwd2 / mesm_layernorm_bwd3).
+ */
+typedef struct MesmLnArgs {
+  const float* x;
+  const float* gamma;
+  const float* beta;
+  float* y;
+  float* mean;
+  float* rstd;
+  int64_t rows;
+  int32_t D;
+  float eps;
+  float drop_p;
+  uint32_t drop_seed;
+  const uint32_t* seed_offset;
+  const float* add;
+  float* y2;
+  /* backward */
+  const float* dy;
+  float* dx;
+  float* dgamma;
+  float* dbeta;
+  int32_t accumulate_dx;
+  float drop2_p;
+  uint32_t drop2_seed;
+  int32_t reserved0;
+  float* dx2;
+  const float* dyb;
+  const float* addend;
+} MesmLnArgs;
+int mesm_layernorm_fwd_group(const MesmLnArgs* list, int32_t n, void* stream);
+int mesm_layernorm_bwd_group(const MesmLnArgs* list, int32_t n, void* stream);
+
 /* ------------------------------------------------------------------------- */
 /*
  * Multi-head attention core: scores = scale * Q K^T -> mask(-inf) -> softmax ->
@@ -280,6 +319,12 @@ typedef struct MesmAttnArgs {
 int mesm_attn_fwd(const MesmAttnArgs* args, void* stream);
 /* Needs q,k,v,o,lse from the forward plus d_o; writes dq,dk_,dv_. */
 int mesm_attn_bwd(const MesmAttnArgs* args, void* stream);
+/* Grouped launches of n independent attention problems (see mesm_layernorm_fwd_group): problems the matrix-core
+ * forward (dk = dv = 32, Lk <= 128, no split heads) / the lane-per-key backward (dk = dv = 32, no split heads)
+ * take share launches of up to 8, the others run through the plain entry points.  Same contracts as
+ * mesm_attn_fwd / mesm_attn_bwd per problem. */
+int mesm_attn_fwd_group(const MesmAttnArgs* list, int32_t n, void* stream);
+int mesm_attn_bwd_group(const MesmAttnArgs* list, int32_t n, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /*

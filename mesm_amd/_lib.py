@@ -63,6 +63,19 @@ class AttnArgs(ctypes.Structure):
     ]
 
 
+class LnArgs(ctypes.Structure):
+    _fields_ = [
+        ("x", c_ptr), ("gamma", c_ptr), ("beta", c_ptr), ("y", c_ptr), ("mean", c_ptr), ("rstd", c_ptr),
+        ("rows", ctypes.c_int64), ("D", ctypes.c_int32), ("eps", ctypes.c_float),
+        ("drop_p", ctypes.c_float), ("drop_seed", ctypes.c_uint32), ("seed_offset", c_ptr),
+        ("add", c_ptr), ("y2", c_ptr),
+        ("dy", c_ptr), ("dx", c_ptr), ("dgamma", c_ptr), ("dbeta", c_ptr),
+        ("accumulate_dx", ctypes.c_int32), ("drop2_p", ctypes.c_float), ("drop2_seed", ctypes.c_uint32),
+        ("reserved0", ctypes.c_int32),
+        ("dx2", c_ptr), ("dyb", c_ptr), ("addend", c_ptr),
+    ]
+
+
 # name -> (restype, argtypes); mirrors include/mesm_gfx950.h one to one.
 _i32, _i64, _f32, _u32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_uint32
 PROTOTYPES = {
@@ -80,6 +93,10 @@ PROTOTYPES = {
     "mesm_layernorm_fwd2": (ctypes.c_int, [c_ptr] * 6 + [_i64, _i32, _f32, _f32, _u32, c_ptr, c_ptr, c_ptr, c_ptr]),
     "mesm_layernorm_bwd3": (ctypes.c_int, [c_ptr] * 8 + [_i64, _i32, _i32, _f32, _u32, c_ptr, c_ptr, _f32, _u32,
                                                         c_ptr, c_ptr, c_ptr]),
+    "mesm_layernorm_fwd_group": (ctypes.c_int, [ctypes.POINTER(LnArgs), _i32, c_ptr]),
+    "mesm_layernorm_bwd_group": (ctypes.c_int, [ctypes.POINTER(LnArgs), _i32, c_ptr]),
+    "mesm_attn_fwd_group": (ctypes.c_int, [ctypes.POINTER(AttnArgs), _i32, c_ptr]),
+    "mesm_attn_bwd_group": (ctypes.c_int, [ctypes.POINTER(AttnArgs), _i32, c_ptr]),
     "mesm_attn_fwd": (ctypes.c_int, [ctypes.POINTER(AttnArgs), c_ptr]),
     "mesm_attn_bwd": (ctypes.c_int, [ctypes.POINTER(AttnArgs), c_ptr]),
     "mesm_sine_pos_fwd": (ctypes.c_int, [c_ptr, c_ptr, _i32, _i32, _i32, c_ptr]),

@@ -16,6 +16,7 @@
 #include "common.hpp"
 #include "attention_mfma.hpp"
 #include <cstdlib>
+#include <cstddef>
 
 namespace {
 
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const MesmAttnArgs
 // heads): 8 waves 42 / 79 / 57 us for (Lq 75, Lk 33) / (76, 76) / (33, 75); 4 waves 32 / 58 / 36; 2 waves
 // 50 / 53 / 29 -- 4 waves when there is one key tile, 2 when there are several (twice the workgroups).
 template <int DK, int DV, int BW_WAVES>
-__global__ __launch_bounds__(64 * BW_WAVES) void attn_bwd_kernel(const MesmAttnArgs p) {
+__device__ __forceinline__ void attn_bwd_body(const MesmAttnArgs& p, const int bh, const int ktile, const int ntiles) {
   constexpr int BW_THREADS = 64 * BW_WAVES;
   constexpr int QCB = 4 * BW_WAVES;  // query rows staged per chunk
   constexpr int SK = DK + 4;
@@ -220,13 +221,12 @@ __global__ __launch_bounds__(64 * BW_WAVES) void attn_bwd_kernel(const MesmAttnA
   __shared__ __attribute__((aligned(16))) float Red[KT * DR];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int bh = blockIdx.x;
   const int b = bh / p.H, h = bh % p.H;
-  const int k0 = blockIdx.y * KT;
+  const int k0 = ktile * KT;
   const int mg = p.mask_group > 0 ? p.mask_group : p.B;
   const int b2 = (b / mg) * mg + ((b % mg) * p.H + h) % mg;
   const bool quirk = (p.mask_mode == MESM_MASK_T2V_QUIRK) && p.qpad && p.kpad;
-  const bool dq_atomic = gridDim.y > 1;
+  const bool dq_atomic = ntiles > 1;
 
   constexpr int DKH = DK / 2;  // split heads: see attn_fwd_kernel
   const bool split = p.q2 != nullptr;
@@ -423,6 +423,35 @@ __global__ __launch_bounds__(64 * BW_WAVES) void attn_bwd_kernel(const MesmAttnA
   }
 }
 
+template <int DK, int DV, int BW_WAVES>
+__global__ __launch_bounds__(64 * BW_WAVES) void attn_bwd_kernel(const MesmAttnArgs p) {
+  attn_bwd_body<DK, DV, BW_WAVES>(p, blockIdx.x, blockIdx.y, gridDim.y);
+}
+
+// Grouped launch (see attn_mfma_fwd_group_kernel): up to 8 independent backward problems with dk = dv = 32 and
+// packed heads in ONE launch of 4-wave workgroups; workgroup -> (problem, batch * head, key tile).
+constexpr int ATTNB_GROUP_MAX = 8;
+struct AttnBGroup {
+  MesmAttnArgs p[ATTNB_GROUP_MAX];
+  int start[ATTNB_GROUP_MAX + 1];
+  int n;
+};
+
+__global__ __launch_bounds__(256) void attn_bwd_group_kernel(const AttnBGroup g) {
+  const int bid = blockIdx.x;
+  int gi = 0;
+#pragma unroll
+  for (int k = 1; k < ATTNB_GROUP_MAX; ++k)
+    if (k < g.n && bid >= g.start[k]) gi = k;
+  const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+  const MesmAttnArgs p = *reinterpret_cast<const MesmAttnArgs*>(ka + offsetof(AttnBGroup, p) + (size_t)gi * sizeof(MesmAttnArgs));
+  const int first = *reinterpret_cast<const int*>(ka + offsetof(AttnBGroup, start) + (size_t)gi * sizeof(int));
+  const int local = bid - first;
+  const int ntiles = (p.Lk + KT - 1) / KT;
+  const int bh = local / ntiles;
+  attn_bwd_body<32, 32, 4>(p, bh, local - bh * ntiles, ntiles);
+}
+
 int check_common(const MesmAttnArgs& a) {
   if (!a.q || !a.k || !a.v || !a.o) return MESM_EINVAL;
   if (a.B <= 0 || a.H <= 0 || a.Lq <= 0 || a.Lk <= 0) return MESM_EINVAL;
@@ -488,4 +517,78 @@ extern "C" int mesm_attn_bwd(const MesmAttnArgs* args, void* stream) {
   if (grid.y > 1) ATTN_DISPATCH(attn_bwd_kernel, grid, 128, 2);  // several key tiles: 2 waves per workgroup
   else ATTN_DISPATCH(attn_bwd_kernel, grid, 256, 4);
   return mesm_launch_status();
+}
+
+namespace {
+int check_bwd(const MesmAttnArgs& a) {
+  int rc = check_common(a);
+  if (rc != MESM_OK) return rc;
+  if (!a.lse || !a.d_o || !a.dq || !a.dk_ || !a.dv_) return MESM_EINVAL;
+  if (a.mask_mode == MESM_MASK_CAUSAL) return MESM_EINVAL;
+  if (a.q2 && (!a.dq2 || !a.dk2 || ((uintptr_t)a.dq2 % 16) != 0 || ((uintptr_t)a.dk2 % 16) != 0)) return MESM_EINVAL;
+  const void* ptrs[4] = {a.d_o, a.dq, a.dk_, a.dv_};
+  for (const void* ptr : ptrs)
+    if (((uintptr_t)ptr % 16) != 0) return MESM_EALIGN;
+  return MESM_OK;
+}
+}  // namespace
+
+extern "C" int mesm_attn_fwd_group(const MesmAttnArgs* list, int32_t n, void* stream) {
+  if (!list || n <= 0 || n > 64) return MESM_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  static const bool legacy = getenv("MESM_ATTN_LEGACY") != nullptr;
+  MesmAttnArgs grp[8];
+  int ng = 0, rc = MESM_OK;
+  auto flush = [&]() {
+    if (ng == 0) return;
+    rc = ng == 1 ? mesm_attn_mfma_fwd(grp[0], s) : mesm_attn_mfma_fwd_group(grp, ng, s);
+    ng = 0;
+  };
+  for (int i = 0; i < n && rc == MESM_OK; ++i) {
+    rc = check_common(list[i]);
+    if (rc != MESM_OK) return rc;
+    if (!legacy && mesm_attn_mfma_groupable(list[i])) {
+      grp[ng++] = list[i];
+      if (ng == 8) flush();
+    } else {
+      rc = mesm_attn_fwd(&list[i], stream);
+    }
+  }
+  if (rc == MESM_OK) flush();
+  return rc;
+}
+
+extern "C" int mesm_attn_bwd_group(const MesmAttnArgs* list, int32_t n, void* stream) {
+  if (!list || n <= 0 || n > 64) return MESM_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  static const bool legacy = getenv("MESM_ATTN_LEGACY") != nullptr;
+  AttnBGroup g;
+  g.n = 0;
+  g.start[0] = 0;
+  int rc = MESM_OK;
+  auto flush = [&]() {
+    if (g.n == 0) return;
+    if (g.n == 1) {
+      rc = mesm_attn_bwd(&g.p[0], stream);
+    } else {
+      hipLaunchKernelGGL(attn_bwd_group_kernel, dim3((unsigned)g.start[g.n]), dim3(256), 0, s, g);
+      rc = mesm_launch_status();
+    }
+    g.n = 0;
+  };
+  for (int i = 0; i < n && rc == MESM_OK; ++i) {
+    const MesmAttnArgs& a = list[i];
+    rc = check_bwd(a);
+    if (rc != MESM_OK) return rc;
+    const bool lane_per_key = legacy || !mesm_attn_mfma_bwd_ok(a);
+    if (lane_per_key && a.dk == 32 && a.dv == 32 && !a.q2) {
+      g.p[g.n] = a;
+      g.start[g.n + 1] = g.start[g.n] + a.B * a.H * ((a.Lk + KT - 1) / KT);
+      if (++g.n == ATTNB_GROUP_MAX) flush();
+    } else {
+      rc = mesm_attn_bwd(&a, stream);
+    }
+  }
+  if (rc == MESM_OK) flush();
+  return rc;
 }

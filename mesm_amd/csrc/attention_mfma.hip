@@ -21,6 +21,7 @@
 // (The lane-per-key kernel spent its time on ~17 cross-lane exchanges per query row and a P V sweep through LDS.)
 // Reduce-index order inside a dot product is free, so the Q / K fragments take features c = 16 half + step:
 // every lane reads 64 contiguous bytes of its row.
+#include <cstddef>
 #include "attention_mfma.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -113,11 +114,11 @@ __device__ __forceinline__ void score_blocks(const MesmAttnArgs& p, int b, int h
 }
 
 template <int NKB>
-__global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const MesmAttnArgs p) {
+__device__ __forceinline__ void attn_mfma_fwd_body(const MesmAttnArgs& p, int blk) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 31, hf = lane >> 5;
   const int nqb = (p.Lq + 31) >> 5;
-  const int item = blockIdx.x * 4 + wave;
+  const int item = blk * 4 + wave;
   if (item >= p.B * p.H * nqb) return;
   const int bh = item / nqb, qb = item - bh * nqb;
   const int b = bh / p.H, hd = bh - b * p.H;
@@ -200,6 +201,39 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const MesmAttnArgs p
     if (io < p.Lq) ob[(int64_t)io * p.o_ls] = o[r];
   }
   if (hf == 0 && ivalid && p.lse) p.lse[(int64_t)bh * p.Lq + i] = mx + __logf(l);
+}
+
+template <int NKB>
+__global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const MesmAttnArgs p) {
+  attn_mfma_fwd_body<NKB>(p, blockIdx.x);
+}
+
+// Grouped launch: up to ATTN_GROUP_MAX independent problems of this kernel's class in ONE launch (the lockstep
+// chains of ops.py: enhance / SS-MESM / MLM attention of the same phase).  MAXNKB = the largest key-block count of
+// the group (registers are sized for it); the problem is picked per workgroup, its key-block count per wave.
+constexpr int ATTN_GROUP_MAX = 8;
+struct AttnGroup {
+  MesmAttnArgs p[ATTN_GROUP_MAX];
+  int start[ATTN_GROUP_MAX + 1];
+  int n;
+};
+
+template <int MAXNKB>
+__global__ __launch_bounds__(256) void attn_mfma_fwd_group_kernel(const AttnGroup g) {
+  const int bid = blockIdx.x;
+  int gi = 0;
+#pragma unroll
+  for (int k = 1; k < ATTN_GROUP_MAX; ++k)
+    if (k < g.n && bid >= g.start[k]) gi = k;
+  // wave-uniform dynamic offset into the kernarg segment (indexing the by-value struct would copy it to scratch)
+  const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+  const MesmAttnArgs p = *reinterpret_cast<const MesmAttnArgs*>(ka + offsetof(AttnGroup, p) + (size_t)gi * sizeof(MesmAttnArgs));
+  const int first = *reinterpret_cast<const int*>(ka + offsetof(AttnGroup, start) + (size_t)gi * sizeof(int));
+  const int nkb = (p.Lk + 31) >> 5;
+  if (nkb == 1) attn_mfma_fwd_body<1>(p, bid - first);
+  else if (MAXNKB >= 2 && nkb == 2) attn_mfma_fwd_body<2>(p, bid - first);
+  else if (MAXNKB >= 3 && nkb == 3) attn_mfma_fwd_body<3>(p, bid - first);
+  else if (MAXNKB >= 4) attn_mfma_fwd_body<4>(p, bid - first);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -377,11 +411,11 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MesmAttnArgs p
     // rows k0 + j(r, half) of K read as columns: B operand of dQ, the same for every query block
     float kc[16];
     {
-      const uint32_t o0 = __umul24((uint32_t)(k0 + 4 * hf), kls) + li;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
+        // rows past Lk (a partial last key block) read row Lk - 1 and contribute zeros: no load leaves K
         const int jo = k0 + acc_row(r, hf);
-        const float x = kb_[o0 + (uint32_t)((r & 3) + 8 * (r >> 2)) * kls];
+        const float x = kb_[__umul24((uint32_t)(jo < Lk ? jo : Lk - 1), kls) + li];
         kc[r] = jo < Lk ? x : 0.0f;
       }
     }
@@ -572,6 +606,31 @@ int mesm_attn_mfma_fwd(const MesmAttnArgs& a, hipStream_t s) {
   return mesm_launch_status();
 }
 
+// problems of the register-resident forward (at most 4 key blocks) may share a launch
+bool mesm_attn_mfma_groupable(const MesmAttnArgs& a) { return mesm_attn_mfma_ok(a) && a.Lk <= 128; }
+
+int mesm_attn_mfma_fwd_group(const MesmAttnArgs* list, int n, hipStream_t s) {
+  AttnGroup g;
+  g.n = n;
+  g.start[0] = 0;
+  int maxnkb = 1;
+  for (int i = 0; i < n; ++i) {
+    const MesmAttnArgs& a = list[i];
+    const int nqb = (a.Lq + 31) / 32;
+    const long items = (long)a.B * a.H * nqb;
+    g.p[i] = a;
+    g.start[i + 1] = g.start[i] + (int)((items + 3) / 4);
+    const int nkb = (a.Lk + 31) / 32;
+    maxnkb = nkb > maxnkb ? nkb : maxnkb;
+  }
+  dim3 grid((unsigned)g.start[n]);
+  if (maxnkb == 1) hipLaunchKernelGGL(attn_mfma_fwd_group_kernel<1>, grid, dim3(256), 0, s, g);
+  else if (maxnkb == 2) hipLaunchKernelGGL(attn_mfma_fwd_group_kernel<2>, grid, dim3(256), 0, s, g);
+  else if (maxnkb == 3) hipLaunchKernelGGL(attn_mfma_fwd_group_kernel<3>, grid, dim3(256), 0, s, g);
+  else hipLaunchKernelGGL(attn_mfma_fwd_group_kernel<4>, grid, dim3(256), 0, s, g);
+  return mesm_launch_status();
+}
+
 #ifndef MESM_ATTN_BWD_MIN_LQ
 #define MESM_ATTN_BWD_MIN_LQ 256
 #endif
@@ -596,12 +655,16 @@ bool mesm_attn_mfma_bwd_ok(const MesmAttnArgs& a) {
 
 int mesm_attn_mfma_bwd(const MesmAttnArgs& a, hipStream_t s) {
   const size_t lds = bwd_slices_bytes(a);
-  static bool raised = false;
-  if (!raised) {  // dynamic LDS beyond 64 KB has to be allowed once per function
+  // dynamic LDS beyond 64 KB has to be allowed once per function AND per device (the attribute lives with the
+  // device's copy of the code object); the flags are only ever set, so a race between threads repeats the call
+  static bool raised[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return MESM_ELAUNCH;
+  if (dev < 0 || dev >= 64 || !raised[dev]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(attn_mfma_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             140 * 1024) != hipSuccess)
       return MESM_ELAUNCH;
-    raised = true;
+    if (dev >= 0 && dev < 64) raised[dev] = true;
   }
   hipLaunchKernelGGL(attn_mfma_bwd_kernel, dim3((unsigned)(a.B * a.H)), dim3(256), lds, s, a);
   return mesm_launch_status();

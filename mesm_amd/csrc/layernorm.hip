@@ -3,6 +3,7 @@
 // HBM-bound: fwd reads x once and writes y once (+2 floats/row); bwd reads dy, x once,
 // writes dx once; dgamma/dbeta are reduced per workgroup through LDS and added
 // atomically (few adders per address: the grid is capped).
+#include <cstddef>
 #include "common.hpp"
 
 namespace {
@@ -62,14 +63,14 @@ __device__ __forceinline__ void st_vec(float* __restrict__ p, const float* s) {
 }
 
 template <int VEC, int NCH>
-__global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
+__device__ __forceinline__ void ln_fwd_body(
     const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ y, float* __restrict__ mean,
     float* __restrict__ rstd, int64_t rows, int D, float eps, LnDrop dr,
-    const float* __restrict__ add, float* __restrict__ y2) {
+    const float* __restrict__ add, float* __restrict__ y2, int bid, int nblk) {
   const int lane = threadIdx.x & 63;
-  const int64_t wave_global = (int64_t)blockIdx.x * LN_WAVES + (threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * LN_WAVES;
+  const int64_t wave_global = (int64_t)bid * LN_WAVES + (threadIdx.x >> 6);
+  const int64_t nwaves = (int64_t)nblk * LN_WAVES;
   const float invD = 1.0f / (float)D;
   const uint32_t dseed = dr.seed + (dr.seed_offset ? *dr.seed_offset : 0u);
   for (int64_t row = wave_global; row < rows; row += nwaves) {
@@ -133,13 +134,72 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
   }
 }
 
+// one LayerNorm problem of a grouped launch (mesm_layernorm_{fwd,bwd}_group): the argument lists of the plain kernels
+struct LnProb {
+  const float *x, *gamma, *beta;
+  float *y, *mean, *rstd;
+  int64_t rows;
+  int D;
+  float eps;
+  LnDrop dr;
+  const float* add;
+  float* y2;
+  // backward
+  const float* dy;
+  float *dx, *dgamma, *dbeta;
+  int accumulate_dx;
+  float* dx2;
+  LnDrop dr2;
+  const float *dyb, *addend;
+};
+constexpr int LN_GROUP_MAX = 8;
+struct LnGroup {
+  LnProb p[LN_GROUP_MAX];
+  int start[LN_GROUP_MAX + 1];  // first workgroup of every problem
+  int n;
+};
+
+// the problem a workgroup of a grouped launch belongs to, read from the kernarg segment with a wave-uniform
+// dynamic offset (see gemm_wstage_group_kernel for why not g.p[gi])
+__device__ __forceinline__ LnProb ln_group_pick(const LnGroup& g, int& local, int& nblk) {
+  const int bid = blockIdx.x;
+  int gi = 0;
+#pragma unroll
+  for (int k = 1; k < LN_GROUP_MAX; ++k)
+    if (k < g.n && bid >= g.start[k]) gi = k;
+  const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+  const int first = *reinterpret_cast<const int*>(ka + offsetof(LnGroup, start) + (size_t)gi * sizeof(int));
+  const int next = *reinterpret_cast<const int*>(ka + offsetof(LnGroup, start) + (size_t)(gi + 1) * sizeof(int));
+  local = bid - first;
+  nblk = next - first;
+  return *reinterpret_cast<const LnProb*>(ka + offsetof(LnGroup, p) + (size_t)gi * sizeof(LnProb));
+}
+
+template <int VEC, int NCH>
+__global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ y, float* __restrict__ mean,
+    float* __restrict__ rstd, int64_t rows, int D, float eps, LnDrop dr,
+    const float* __restrict__ add, float* __restrict__ y2) {
+  ln_fwd_body<VEC, NCH>(x, gamma, beta, y, mean, rstd, rows, D, eps, dr, add, y2, blockIdx.x, gridDim.x);
+}
+
+// up to LN_GROUP_MAX independent LayerNorms (same VEC / NCH class) in ONE launch
+template <int VEC, int NCH>
+__global__ __launch_bounds__(LN_THREADS) void ln_fwd_group_kernel(const LnGroup g) {
+  int local, nblk;
+  const LnProb q = ln_group_pick(g, local, nblk);
+  ln_fwd_body<VEC, NCH>(q.x, q.gamma, q.beta, q.y, q.mean, q.rstd, q.rows, q.D, q.eps, q.dr, q.add, q.y2, local, nblk);
+}
+
 template <int VEC, int NCH, bool LDS_REDUCE>
-__global__ __launch_bounds__(LNB_THREADS) void ln_bwd_kernel(
+__device__ __forceinline__ void ln_bwd_body(
     const float* __restrict__ dy, const float* __restrict__ x,
     const float* __restrict__ gamma, const float* __restrict__ mean,
     const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ dgamma,
     float* __restrict__ dbeta, int64_t rows, int D, int accumulate_dx, LnDrop dr,
-    float* __restrict__ dx2, LnDrop dr2, const float* __restrict__ dyb, const float* __restrict__ addend) {
+    float* __restrict__ dx2, LnDrop dr2, const float* __restrict__ dyb, const float* __restrict__ addend,
+    int bid, int nblk) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // LNB_WAVES * D when LDS_REDUCE
   const uint32_t dseed = dr.seed + (dr.seed_offset ? *dr.seed_offset : 0u);
   // second output: dx under the dropout mask of the block that PRODUCED the LayerNorm input
@@ -148,8 +208,8 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_bwd_kernel(
   const uint32_t dseed2 = dr2.seed + (dr2.seed_offset ? *dr2.seed_offset : 0u);
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int64_t wave_global = (int64_t)blockIdx.x * LNB_WAVES + wave;
-  const int64_t nwaves = (int64_t)gridDim.x * LNB_WAVES;
+  const int64_t wave_global = (int64_t)bid * LNB_WAVES + wave;
+  const int64_t nwaves = (int64_t)nblk * LNB_WAVES;
   const float invD = 1.0f / (float)D;
 
   float g[NCH][VEC];
@@ -256,6 +316,25 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_bwd_kernel(
       }
     }
   }
+}
+
+template <int VEC, int NCH, bool LDS_REDUCE>
+__global__ __launch_bounds__(LNB_THREADS) void ln_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x,
+    const float* __restrict__ gamma, const float* __restrict__ mean,
+    const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ dgamma,
+    float* __restrict__ dbeta, int64_t rows, int D, int accumulate_dx, LnDrop dr,
+    float* __restrict__ dx2, LnDrop dr2, const float* __restrict__ dyb, const float* __restrict__ addend) {
+  ln_bwd_body<VEC, NCH, LDS_REDUCE>(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, accumulate_dx, dr, dx2, dr2, dyb,
+                                    addend, blockIdx.x, gridDim.x);
+}
+
+template <int VEC, int NCH>
+__global__ __launch_bounds__(LNB_THREADS) void ln_bwd_group_kernel(const LnGroup g) {
+  int local, nblk;
+  const LnProb q = ln_group_pick(g, local, nblk);
+  ln_bwd_body<VEC, NCH, true>(q.dy, q.x, q.gamma, q.mean, q.rstd, q.dx, q.dgamma, q.dbeta, q.rows, q.D, q.accumulate_dx,
+                              q.dr, q.dx2, q.dr2, q.dyb, q.addend, local, nblk);
 }
 
 // Parameter gradients only (dx == NULL: the input needs no gradient, e.g. the LayerNorm over the raw
@@ -418,4 +497,104 @@ extern "C" int mesm_layernorm_bwd(const float* dy, const float* x, const float* 
                                   const uint32_t* seed_offset, void* stream) {
   return mesm_layernorm_bwd2(dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, accumulate_dx, drop_p,
                              drop_seed, seed_offset, nullptr, 0.0f, 0u, stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Grouped launches: independent LayerNorms of one launch phase (the lockstep chains of ops.py) share ONE kernel.
+// Problems of the common class (D <= 256, D % 4 == 0, 16-byte aligned: one float4 chunk per lane) go into groups of up
+// to LN_GROUP_MAX; anything else runs through the plain entry points.
+namespace {
+
+bool ln_group_class(const MesmLnArgs& a, bool bwd) {
+  if (a.D > 256 || a.D % 4 != 0 || a.rows <= 0) return false;
+  const void* ps[] = {a.x, a.gamma, a.beta, a.y, a.add, a.y2, a.dy, a.dx, a.dx2, a.dyb, a.addend};
+  for (const void* q : ps)
+    if (q != nullptr && ((uintptr_t)q % 16) != 0) return false;
+  if (bwd && a.dx == nullptr) return false;  // parameter gradients only: the column-parallel kernel
+  return true;
+}
+
+LnProb ln_prob(const MesmLnArgs& a) {
+  LnProb q;
+  q.x = a.x; q.gamma = a.gamma; q.beta = a.beta; q.y = a.y; q.mean = a.mean; q.rstd = a.rstd;
+  q.rows = a.rows; q.D = a.D; q.eps = a.eps;
+  q.dr = make_drop(a.drop_p, a.drop_seed, a.seed_offset);
+  q.add = a.add; q.y2 = a.y2;
+  q.dy = a.dy; q.dx = a.dx; q.dgamma = a.dgamma; q.dbeta = a.dbeta; q.accumulate_dx = a.accumulate_dx;
+  q.dx2 = a.dx2; q.dr2 = make_drop(a.drop2_p, a.drop2_seed, a.seed_offset);
+  q.dyb = a.dyb; q.addend = a.addend;
+  return q;
+}
+
+}  // namespace
+
+extern "C" int mesm_layernorm_fwd_group(const MesmLnArgs* list, int32_t n, void* stream) {
+  if (!list || n <= 0 || n > 64) return MESM_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  LnGroup g;
+  g.n = 0;
+  g.start[0] = 0;
+  int rc = MESM_OK;
+  auto flush = [&]() {
+    if (g.n == 0) return;
+    hipLaunchKernelGGL((ln_fwd_group_kernel<4, 1>), dim3((unsigned)g.start[g.n]), dim3(LN_THREADS), 0, s, g);
+    rc = mesm_launch_status();
+    g.n = 0;
+  };
+  int ngroupable = 0;
+  for (int i = 0; i < n; ++i) ngroupable += ln_group_class(list[i], false) ? 1 : 0;
+  for (int i = 0; i < n && rc == MESM_OK; ++i) {
+    const MesmLnArgs& a = list[i];
+    if ((a.add == nullptr) != (a.y2 == nullptr) || a.drop_p < 0.f || a.drop_p >= 1.f) return MESM_EINVAL;
+    if (ngroupable >= 2 && ln_group_class(a, false)) {
+      if (!a.x || !a.gamma || !a.beta || !a.y || !a.mean || !a.rstd) return MESM_EINVAL;
+      int64_t blocks = (a.rows + LN_WAVES - 1) / LN_WAVES;
+      if (blocks > 4096) blocks = 4096;
+      g.p[g.n] = ln_prob(a);
+      g.start[g.n + 1] = g.start[g.n] + (int)blocks;
+      if (++g.n == LN_GROUP_MAX) flush();
+    } else {
+      rc = mesm_layernorm_fwd2(a.x, a.gamma, a.beta, a.y, a.mean, a.rstd, a.rows, a.D, a.eps, a.drop_p, a.drop_seed,
+                               a.seed_offset, a.add, a.y2, stream);
+    }
+  }
+  if (rc == MESM_OK) flush();
+  return rc;
+}
+
+extern "C" int mesm_layernorm_bwd_group(const MesmLnArgs* list, int32_t n, void* stream) {
+  if (!list || n <= 0 || n > 64) return MESM_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  LnGroup g;
+  g.n = 0;
+  g.start[0] = 0;
+  int rc = MESM_OK;
+  auto flush = [&]() {
+    if (g.n == 0) return;
+    hipLaunchKernelGGL((ln_bwd_group_kernel<4, 1>), dim3((unsigned)g.start[g.n]), dim3(LNB_THREADS),
+                       (size_t)LNB_WAVES * 256 * sizeof(float), s, g);
+    rc = mesm_launch_status();
+    g.n = 0;
+  };
+  int ngroupable = 0;
+  for (int i = 0; i < n; ++i) ngroupable += ln_group_class(list[i], true) ? 1 : 0;
+  for (int i = 0; i < n && rc == MESM_OK; ++i) {
+    const MesmLnArgs& a = list[i];
+    if (a.drop_p < 0.f || a.drop_p >= 1.f || a.drop2_p < 0.f || a.drop2_p >= 1.f) return MESM_EINVAL;
+    if (ngroupable >= 2 && ln_group_class(a, true)) {
+      if (!a.dy || !a.x || !a.gamma || !a.mean || !a.rstd || !a.dgamma || !a.dbeta) return MESM_EINVAL;
+      int64_t blocks = (a.rows + LNB_WAVES - 1) / LNB_WAVES;
+      const int64_t cap = a.rows >= 4000 ? MESM_LNB_CAP : MESM_LNB_CAP / 2;
+      if (blocks > cap) blocks = cap;
+      g.p[g.n] = ln_prob(a);
+      g.start[g.n + 1] = g.start[g.n] + (int)blocks;
+      if (++g.n == LN_GROUP_MAX) flush();
+    } else {
+      rc = mesm_layernorm_bwd3(a.dy, a.x, a.gamma, a.mean, a.rstd, a.dx, a.dgamma, a.dbeta, a.rows, a.D, a.accumulate_dx,
+                               a.drop_p, a.drop_seed, a.seed_offset, a.dx2, a.drop2_p, a.drop2_seed, a.dyb, a.addend,
+                               stream);
+    }
+  }
+  if (rc == MESM_OK) flush();
+  return rc;
 }

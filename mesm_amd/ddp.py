@@ -169,6 +169,14 @@ class GradReducer:
         while self.next_bucket >= 0:
             self._launch(self.next_bucket)
         capturing = self.gb.flat.is_cuda and torch.cuda.is_current_stream_capturing()
+        if capturing and self.hook and self.expected is not None and self.stale:
+            # no collective is needed to know it locally, and a graph captured now would replay a bucket
+            # all-reduce that was issued before every gradient of that bucket had been written -- on every step
+            self._reset_step()
+            raise RuntimeError("GradReducer: while capturing, a gradient arrived after its bucket had been "
+                               "all-reduced (the captured batch has another contribution pattern than the one "
+                               "learnt); the captured graph would average incomplete gradients.  relearn() on a "
+                               "batch of this kind, then capture again.")
         if self.hook and self.expected is not None and not capturing:
             # late-gradient flag, agreed across ranks (MAX) so that every rank raises, or none does
             if self.flag is None:

@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_NONE, ACT_PRELU, ACT_RELU, LAYOUT_OUTER_CONTIG,
-                   LAYOUT_REDUCE_CONTIG, MASK_CAUSAL, MASK_KPAD, MASK_T2V_QUIRK, AttnArgs, GemmArgs,
+                   LAYOUT_REDUCE_CONTIG, MASK_CAUSAL, MASK_KPAD, MASK_T2V_QUIRK, AttnArgs, GemmArgs, LnArgs,
                    check, lib, ptr, require_gpu, stream_ptr)
 
 __all__ = [
@@ -55,7 +55,8 @@ def gemm(A, B, C, *, trans_a=False, trans_b=False, A2=None, B2=None, bias=None, 
     """
     require_gpu(A, B, C)
     if (_SPLIT_ROWS and row0 == 0 and not trans_a and C.shape[1] == 256 and A.shape[1] >= 1024
-            and 4096 < C.shape[0] <= 5120 and split_k == 1 and colsum is None and dslope is None and A2 is None):
+            and 4096 < C.shape[0] <= 5120 and split_k == 1 and colsum is None and dslope is None and A2 is None
+            and float(a_drop[0]) == 0.0 and a_act == ACT_NONE):
         # 4800 / 4864-row outputs of width 256: 300 tiles of 64 x 64 on 256 CUs are two rounds with the second 17 %
         # full.  Rows [0, 4096) = 256 tiles = exactly one round of the k-split 64 x 64 kernel; the remainder goes
         # to the 32 x 32 kernel (4800 x 256 x 1024: 37 us -> 30 us).  The epilogue-dropout mask index carries the
@@ -132,50 +133,78 @@ def gemm(A, B, C, *, trans_a=False, trans_b=False, A2=None, B2=None, bias=None, 
         g.pre_out, g.ldpre = pre_out.data_ptr(), pre_out.stride(0)
     g.e_drop_row0 = int(row0)
     g.seed_offset = _seed_off_ptr()
-    if _pending is not None:
-        # inside gemm_group(): queued; the tensors stay referenced until the group is launched
-        _pending.append((g, (A, B, C, A2, B2, bias, residual, aux, slope, dslope, colsum,
-                             ws if dslope is not None else None, pre_out)))
+    if _phase is not None:
+        # inside a launch phase: queued; the tensors stay referenced until the phase is launched
+        _phase.add("gemm", g, (A, B, C, A2, B2, bias, residual, aux, slope, dslope, colsum,
+                               ws if dslope is not None else None, pre_out))
         return C
     check(lib().mesm_gemm_f32(ctypes.byref(g), stream_ptr()), "mesm_gemm_f32")
     return C
 
 
-_pending = None
 _SPLIT_ROWS = os.environ.get("MESM_GEMM_SPLIT_ROWS", "1") == "1"
 
 
-class gemm_group:
-    """Context manager: the gemm() calls made inside are INDEPENDENT of each other (none reads what
-    another writes; atomic accumulation into the same gradient view is fine) and are issued together
-    on exit through mesm_gemm_group: the small ones share launches of up to 8 problems.  Nothing
-    else may be enqueued inside the block that consumes their outputs."""
+class _Phase:
+    """Launches queued by kind; `flush` issues every kind through its grouped entry point."""
+    KINDS = (("gemm", GemmArgs, "mesm_gemm_group", "mesm_gemm_f32"),
+             ("ln_fwd", LnArgs, "mesm_layernorm_fwd_group", None),
+             ("ln_bwd", LnArgs, "mesm_layernorm_bwd_group", None),
+             ("attn_fwd", AttnArgs, "mesm_attn_fwd_group", "mesm_attn_fwd"),
+             ("attn_bwd", AttnArgs, "mesm_attn_bwd_group", "mesm_attn_bwd"))
+
+    def __init__(self):
+        self.q = {k[0]: [] for k in self.KINDS}
+        self.keep = []
+
+    def add(self, kind, args, keep):
+        self.q[kind].append(args)
+        self.keep.append(keep)
+
+    def flush(self):
+        L, st = lib(), stream_ptr()
+        for kind, struct, group_fn, single_fn in self.KINDS:
+            items = self.q[kind]
+            for i in range(0, len(items), 64):
+                chunk = items[i:i + 64]
+                if len(chunk) == 1 and single_fn is not None:
+                    check(getattr(L, single_fn)(ctypes.byref(chunk[0]), st), single_fn)
+                    continue
+                arr = (struct * len(chunk))(*chunk)
+                check(getattr(L, group_fn)(arr, len(chunk), st), group_fn)
+            self.q[kind] = []
+        self.keep = []
+
+
+_phase = None
+
+
+class phase:
+    """Context manager: ONE LAUNCH PHASE.  The gemm / layernorm / attention calls made inside are INDEPENDENT of
+    each other (none reads what another writes; atomic accumulation into the same gradient view is fine); they
+    are queued and issued together on exit, every kind through its grouped entry point (mesm_gemm_group,
+    mesm_layernorm_*_group, mesm_attn_*_group): problems of one kind share launches of up to 8.  Kernels of other
+    kinds called inside run immediately, i.e. BEFORE the queued ones.  Nothing may be enqueued inside the block
+    that consumes the outputs of a queued launch.  Nested phases join the outermost one."""
 
     def __enter__(self):
-        global _pending
-        self.outer = _pending
-        if _pending is None:
-            _pending = []
+        global _phase
+        self.outer = _phase
+        if _phase is None:
+            _phase = _Phase()
         return self
 
     def __exit__(self, et, ev, tb):
-        global _pending
-        if self.outer is not None:  # nested: the outermost group launches
+        global _phase
+        if self.outer is not None:  # nested: the outermost phase launches
             return False
-        items, _pending = _pending, None
-        if et is None and items:
-            flush_gemms(items)
+        ph, _phase = _phase, None
+        if et is None:
+            ph.flush()
         return False
 
 
-def flush_gemms(items):
-    for i in range(0, len(items), 64):
-        chunk = items[i:i + 64]
-        if len(chunk) == 1:
-            check(lib().mesm_gemm_f32(ctypes.byref(chunk[0][0]), stream_ptr()), "mesm_gemm_f32")
-            continue
-        arr = (GemmArgs * len(chunk))(*[c[0] for c in chunk])
-        check(lib().mesm_gemm_group(arr, len(chunk), stream_ptr()), "mesm_gemm_group")
+gemm_group = phase  # the older name: a phase that only holds GEMMs
 
 
 def layernorm_fwd(x, gamma, beta, eps=1e-5, drop=(0.0, 0), add=None):
@@ -194,6 +223,18 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, drop=(0.0, 0), add=None):
     if add is not None:
         assert add.is_contiguous() and add.numel() == x2.numel()
         y2 = torch.empty_like(x2)
+    if _phase is not None:
+        a = LnArgs()
+        a.x, a.gamma, a.beta, a.y, a.mean, a.rstd = (x2.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                                                     mean.data_ptr(), rstd.data_ptr())
+        a.rows, a.D, a.eps = rows, D, float(eps)
+        a.drop_p, a.drop_seed, a.seed_offset = float(drop[0]), int(drop[1]) & 0xFFFFFFFF, _seed_off_ptr()
+        if add is not None:
+            a.add, a.y2 = add.data_ptr(), y2.data_ptr()
+        _phase.add("ln_fwd", a, (x2, gamma, beta, y, mean, rstd, add, y2))
+        if add is not None:
+            return y.view(x.shape), mean, rstd, y2.view(x.shape)
+        return y.view(x.shape), mean, rstd
     check(lib().mesm_layernorm_fwd2(ptr(x2), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd),
                                     rows, D, eps, float(drop[0]), int(drop[1]) & 0xFFFFFFFF,
                                     ptr(_seed_offset), ptr(add), ptr(y2), stream_ptr()), "mesm_layernorm_fwd2")
@@ -215,6 +256,28 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx=None, accumulate_d
     x2 = x.reshape(-1, D)
     dy2 = dy.reshape(-1, D)
     assert x2.is_contiguous() and dy2.is_contiguous()
+    if _phase is not None and need_dx:
+        for t_ in (dyb, addend):
+            assert t_ is None or (t_.is_contiguous() and t_.numel() == x2.numel())
+        if dx is None:
+            assert not accumulate_dx
+            dx = torch.empty_like(x2)
+        dxv = dx.view(-1, D)
+        dxm = torch.empty_like(dxv) if drop2 is not None else None
+        a = LnArgs()
+        a.dy, a.x, a.gamma, a.mean, a.rstd = dy2.data_ptr(), x2.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+        a.dx, a.dgamma, a.dbeta = dxv.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr()
+        a.rows, a.D = x2.shape[0], D
+        a.accumulate_dx = 1 if accumulate_dx else 0
+        a.drop_p, a.drop_seed, a.seed_offset = dp, dseed, _seed_off_ptr()
+        if drop2 is not None:
+            a.dx2, a.drop2_p, a.drop2_seed = dxm.data_ptr(), float(drop2[0]), int(drop2[1]) & 0xFFFFFFFF
+        if dyb is not None:
+            a.dyb = dyb.data_ptr()
+        if addend is not None:
+            a.addend = addend.data_ptr()
+        _phase.add("ln_bwd", a, (dy2, x2, gamma, mean, rstd, dxv, dgamma, dbeta, dxm, dyb, addend))
+        return (dxv.view(x.shape), dxm.view(x.shape)) if drop2 is not None else dxv.view(x.shape)
     if dyb is not None or addend is not None:
         assert need_dx
         for t_ in (dyb, addend):
@@ -311,6 +374,9 @@ def attn_fwd(q, k, v, H, kpad=None, qpad=None, scale=None, drop=(0.0, 0), group=
     o = torch.empty(B, Lq, v.shape[2], device=q.device, dtype=torch.float32)
     lse = torch.empty(B, H, Lq, device=q.device, dtype=torch.float32) if want_lse else None
     a = _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop, group, causal, q2, k2, k_add)
+    if _phase is not None:
+        _phase.add("attn_fwd", a, (q, k, v, o, lse, kpad, qpad, q2, k2, k_add))
+        return o, lse
     check(lib().mesm_attn_fwd(ctypes.byref(a), stream_ptr()), "mesm_attn_fwd")
     return o, lse
 
@@ -360,6 +426,9 @@ def attn_bwd_into(do, q, k, v, o, lse, H, dq, dk, dv, kpad=None, qpad=None, scal
     if q2 is not None:
         assert dq2.stride() == q.stride() and dk2.stride() == k.stride()
         a.dq2, a.dk2 = dq2.data_ptr(), dk2.data_ptr()
+    if _phase is not None:
+        _phase.add("attn_bwd", a, (do, q, k, v, o, lse, dq, dk, dv, kpad, qpad, q2, k2, dq2, dk2, k_add))
+        return
     check(lib().mesm_attn_bwd(ctypes.byref(a), stream_ptr()), "mesm_attn_bwd")
 
 

@@ -108,11 +108,15 @@ class LinearLayer(nn.Module):
         self.p = dropout
         self.relu = relu
 
-    def forward(self, x):
+    def steps(self, x):
+        """the layer as a chain of block calls (ops.lockstep)"""
         ln = self.LayerNorm
-        x = ops.layer_norm(x, ln.weight, ln.bias, drop=drop_state.next(self.p))
+        x = yield ops.layer_norm_call(x, ln.weight, ln.bias, drop=drop_state.next(self.p))
         lin = self.net[1]
-        return ops.linear(x, lin.weight, lin.bias, relu=self.relu)
+        return (yield ops.linear_call(x, lin.weight, lin.bias, relu=self.relu))
+
+    def forward(self, x):
+        return ops.seq(self.steps(x))
 
 
 class T2VLayer(nn.Module):
@@ -135,23 +139,27 @@ class T2VLayer(nn.Module):
         self.nhead = h
         self.p = dropout
 
-    def forward(self, txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm=False, group=0, vid_p=None,
-                out_pos=None):
-        """vid_p: vid + pos_vid when the producer of vid has already written it (None: formed here).
+    def steps(self, txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm=False, group=0, vid_p=None,
+              out_pos=None):
+        """The layer as a chain of three block calls (ops.lockstep).
+        vid_p: vid + pos_vid when the producer of vid has already written it (None: formed here).
         out_pos: also return output + out_pos (the next block's query) -> (out, out_p)."""
         sa = self.self_attn
         if vid_p is None and pos_vid is not None:
             vid_p = vid + pos_vid
-        x = ops.mha(vid, vid_p, txt, pos_txt, vid, sa.in_proj_weight, sa.in_proj_bias,
-                    sa.out_proj.weight, sa.out_proj.bias, self.nhead, kpad=txt_pad, qpad=vid_pad,
-                    attn_drop=drop_state.next(self.p), out_drop=drop_state.next(self.p), group=group)
+        x = yield ops.mha_call(vid, vid_p, txt, pos_txt, vid, sa.in_proj_weight, sa.in_proj_bias,
+                               sa.out_proj.weight, sa.out_proj.bias, self.nhead, kpad=txt_pad, qpad=vid_pad,
+                               attn_drop=drop_state.next(self.p), out_drop=drop_state.next(self.p), group=group)
         alt = self.two_mlp and is_mlm
         n1, n2 = (self.norm1_1, self.norm2_1) if alt else (self.norm1, self.norm2)
         l1, l2 = (self.linear1_1, self.linear2_1) if alt else (self.linear1, self.linear2)
         # x + FFN(LN1(x)) (pre-norm FFN, transformer.py:536-538): one block, the two routes of dx meet in-kernel
-        y = ops.norm_ffn(x, n1.weight, n1.bias, l1.weight, l1.bias, self.activation.weight, l2.weight, l2.bias,
-                         mid_drop=drop_state.next(self.p), out_drop=drop_state.next(self.p))
-        return ops.layer_norm(y, n2.weight, n2.bias, add=out_pos)
+        y = yield ops.norm_ffn_call(x, n1.weight, n1.bias, l1.weight, l1.bias, self.activation.weight, l2.weight,
+                                    l2.bias, mid_drop=drop_state.next(self.p), out_drop=drop_state.next(self.p))
+        return (yield ops.layer_norm_call(y, n2.weight, n2.bias, add=out_pos))
+
+    def forward(self, *a, **kw):
+        return ops.seq(self.steps(*a, **kw))
 
 
 def _clones(m, n):
@@ -165,14 +173,18 @@ class T2VStack(nn.Module):
         super().__init__()
         self.layers = _clones(layer, n)
 
-    def forward(self, txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm=False, group=0, vid_p=None,
-                out_pos=None):
+    def steps(self, txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm=False, group=0, vid_p=None,
+              out_pos=None):
         n = len(self.layers)
         for i, l in enumerate(self.layers):
             op = out_pos if i == n - 1 else pos_vid
-            res = l(txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm, group, vid_p=vid_p, out_pos=op)
+            res = yield from l.steps(txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm, group, vid_p=vid_p,
+                                     out_pos=op)
             vid, vid_p = res if op is not None else (res, None)
         return (vid, vid_p) if out_pos is not None else vid
+
+    def forward(self, *a, **kw):
+        return ops.seq(self.steps(*a, **kw))
 
 
 def _xavier_(module):
@@ -196,6 +208,10 @@ class T2VEncoder(nn.Module):
         along the batch dimension (the Q1 mask rule wraps inside a group).  vid_p / out_pos: see T2VLayer."""
         return self.t2v_encoder(txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm, group, vid_p=vid_p,
                                 out_pos=out_pos)
+
+    def steps(self, txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm=False, group=0, vid_p=None, out_pos=None):
+        return self.t2v_encoder.steps(txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm, group, vid_p=vid_p,
+                                      out_pos=out_pos)
 
 
 class EncoderLayer(nn.Module):

@@ -382,46 +382,26 @@ class MESM(nn.Module):
                                   neg_index=kwargs.get("neg_index"),
                                   masked_words=kwargs.get("masked_words"), device=dev)
 
+        # The step's independent chains run SIDE BY SIDE (ops.lockstep): every round, the blocks the chains are at
+        # become one autograd node whose launch phases are shared -- the small problems of the SS-MESM / MLM stacks
+        # ride in the launches of the 4800-row enhance stack instead of queueing behind them as ~5 us launches of
+        # their own, forward and backward.  Stage A: the input projections of every modality.  Stage B: the enhance
+        # stack beside the SS-MESM stack, the MLM stack beside the SS-MESM layers the enhance stack leaves alone.
+        # Stage C: the t2v stack beside the MLM head and the (loss-free) sentence projection.
+        mlm = self.rec_fw and is_training
+        enc = self.enhance_encoder
+        ni = plan.neg_index
+
+        def proj_chain(seq, x):
+            for m in seq:
+                x = yield from m.steps(x)
+            return x
+
         with _scope("inproj"):
             vid_pad = (~video_mask).contiguous()
             words_pad = (~words_mask).contiguous()
-            pv = self._proj(self.input_vid_proj, video_feat)
-            pw = self._proj(self.input_txt_proj, words)
             vpos = kn.sine_pos(video_mask, d)
-            tpos = self.txt_position_embed(pw) if self.use_txt_pos else None  # model.py:169-172
-            defer_enhance = False
-
-        # The positive and the negative pass (model.py:260-299) run the SAME weights over the same
-        # video with different queries: they are stacked along the batch (rows [0, N) positive,
-        # [N, 2N) negative) so every layer is one launch over 2N rows instead of two over N --
-        # these kernels are far too small to fill 256 CUs, so rows are what buys efficiency.
-        # The Q1 mask rule wraps inside each group of N rows (group=N).  The decoder runs on the
-        # positive half only: the reference discards the negative decoder output (model.py:295).
-        enc = self.enhance_encoder
-        ni = plan.neg_index
-        with _scope("enhance"):
-            # one launch builds every stacked tensor of the stage: [x ; x] for the video side, [x ; x[neg_index]]
-            # for the words (neg_words_feat = expanded_words_feat[neg_index][:, 1:] = projected words of the
-            # negative query; the SS token is stripped again, model.py:264-266)
-            pv2, vpos2, vid_pad2, pw2, wpad2 = ops.stack_rows([pv, vpos, vid_pad, pw, words_pad], [0, 0, 0, 1, 1], ni)
-            pvp2 = kn.add_wrap(pv2, vpos2) if not pv2.requires_grad else _AddPos.apply(pv2, vpos2)
-            if self.rec_fw:
-                tpos2 = None
-                if self.use_txt_pos and not self.rec_ss:
-                    tpos2 = ops.stack_rows([tpos], [1], ni)[0]  # txt_position ; txt_position[neg_index]
-                elif self.use_txt_pos:
-                    defer_enhance = True  # the negative half takes positions 1.. of the EXPANDED words (below)
-                # every block hands its output + position embedding to the next one (second output of its last
-                # LayerNorm), so only this very first query is formed by an element-wise launch
-                enhanced2, enhanced2_p = (None, None) if defer_enhance else \
-                    enc(pw2, pv2, tpos2, vpos2, wpad2, vid_pad2, group=N, vid_p=pvp2, out_pos=vpos2)
-                enhanced = enhanced2[:N] if not defer_enhance else None
-            else:
-                enhanced2, enhanced2_p = pv2, pvp2
-                enhanced = pv
-
-        out = {}
-        with _scope("ss"):
+            chains = [proj_chain(self.input_vid_proj, video_feat), proj_chain(self.input_txt_proj, words)]
             if self.rec_ss:
                 if plan.vid_src is not None and not plan.vid_identity:
                     bvid = video_feat.reshape(N * Lv, -1)[plan.vid_src] * plan.vid_mask.unsqueeze(-1)
@@ -432,15 +412,76 @@ class MESM(nn.Module):
                     bvid, bvid_pad = video_feat, vid_pad
                 # the group's sentences per pair (zeros in the padding slots), model.py:199 split_expand_and_pad
                 bsent = kn.gather_rows_fwd(sent, plan.sent_src, plan.sent_mask)[0]
-                bvid = self._proj(self.input_vid_proj, bvid)
-                bsent = self._proj(self.input_txt_proj, bsent)
+                chains += [proj_chain(self.input_vid_proj, bvid), proj_chain(self.input_txt_proj, bsent)]
+            if mlm:
+                chains += [proj_chain(self.input_txt_proj, self.unknown_token.view(1, 1, -1)),
+                           proj_chain(self.input_txt_proj, self.masked_token.view(1, 1, -1))]
+            res = ops.lockstep(chains)
+            pv, pw = res[0], res[1]
+            if self.rec_ss:
+                bvid, bsent = res[2], res[3]
+            if mlm:
+                unk, msk = res[-2], res[-1]
+            tpos = self.txt_position_embed(pw) if self.use_txt_pos else None  # model.py:169-172
+            defer_enhance = False
+
+        # The positive and the negative pass (model.py:260-299) run the SAME weights over the same
+        # video with different queries: they are stacked along the batch (rows [0, N) positive,
+        # [N, 2N) negative) so every layer is one launch over 2N rows instead of two over N --
+        # these kernels are far too small to fill 256 CUs, so rows are what buys efficiency.
+        # The Q1 mask rule wraps inside each group of N rows (group=N).  The decoder runs on the
+        # positive half only: the reference discards the negative decoder output (model.py:295).
+        out = {}
+        with _scope("enhance"):
+            # one launch builds every stacked tensor of the stage: [x ; x] for the video side, [x ; x[neg_index]]
+            # for the words (neg_words_feat = expanded_words_feat[neg_index][:, 1:] = projected words of the
+            # negative query; the SS token is stripped again, model.py:264-266)
+            pv2, vpos2, vid_pad2, pw2, wpad2 = ops.stack_rows([pv, vpos, vid_pad, pw, words_pad], [0, 0, 0, 1, 1], ni)
+            pvp2 = kn.add_wrap(pv2, vpos2) if not pv2.requires_grad else _AddPos.apply(pv2, vpos2)
+            stage, names = [], []
+            tpos2 = None
+            if self.rec_fw:
+                if self.use_txt_pos and not self.rec_ss:
+                    tpos2 = ops.stack_rows([tpos], [1], ni)[0]  # txt_position ; txt_position[neg_index]
+                elif self.use_txt_pos:
+                    defer_enhance = True  # the negative half takes positions 1.. of the EXPANDED words (below)
+                # every block hands its output + position embedding to the next one (second output of its last
+                # LayerNorm), so only this very first query is formed by an element-wise launch
+                if not defer_enhance:
+                    stage.append(enc.steps(pw2, pv2, tpos2, vpos2, wpad2, vid_pad2, group=N, vid_p=pvp2, out_pos=vpos2))
+                    names.append("E")
+            if self.rec_ss:
                 # the pair's own sentence slot is replaced by the learned token (model.py:493-501)
                 q_tok = ops.token_mix(bsent, plan.sent_loc, self.ss_reconstructor.masked_sent_token)
-                rec = self.ss_reconstructor.recon_trans(bvid, q_tok, None, None, bvid_pad, plan.sent_pad)
+                stage.append(self.ss_reconstructor.recon_trans.steps(bvid, q_tok, None, None, bvid_pad, plan.sent_pad))
+                names.append("S")
+            if mlm:
+                # FW-MESM masked-language-model branch (model.py:307-332): unknown words, then the drawn positions,
+                # become learned tokens (model.py:361-394): one launch
+                w = ops.token_mix(pw, kwargs["unknown_mask"], unk, plan.masked_words, msk)
+                # the ground-truth clips of every pair re-padded to Lc, and their position embeddings (model.py:312-325)
+                cfeat = ops.gather_rows2(pv.reshape(N * Lv, d), plan.clip_src, plan.clip_inv, plan.clip_mask)
+                cpos = kn.gather_rows_fwd(vpos.reshape(N * Lv, d), plan.clip_src, plan.clip_mask)[0]
+                m_chain = enc.steps(cfeat, w, cpos, tpos, plan.clip_pad, words_pad, is_mlm=True)  # pos_vid = txt_position
+                # beside the SS-MESM layers that outlast the enhance stack (3 rounds per layer)
+                lag = 3 * len(enc.t2v_encoder.layers) if ("E" in names and "S" in names) else 0
+                stage.append(ops.delayed(m_chain, lag))
+                names.append("M")
+            res = dict(zip(names, ops.lockstep(stage)))
+            if "E" in res:
+                enhanced2, enhanced2_p = res["E"]
+                enhanced = enhanced2[:N]
+            elif not self.rec_fw:
+                enhanced2, enhanced2_p = pv2, pvp2
+                enhanced = pv
+            else:
+                enhanced2 = enhanced2_p = enhanced = None  # deferred (use_txt_pos with the sentence token)
+
+        with _scope("ss"):
+            if self.rec_ss:
+                rec = res["S"]
                 # the masked slot of every pair, L2-normalised (model.py:485-486): one kernel
                 recon = ops.gather_rows2(rec.reshape(-1, d), plan.recon_idx, plan.recon_inv, normalize=True)
-                # projed_recon_feat feeds no loss (criterion.py:246-255) but is part of the returned dict
-                projed_recon = self._proj(self.ss_reconstructor.output_sent_proj, recon)
                 # [recon ; words] and its padding mask (model.py:221-224), one launch
                 ewords, epad = ops.prepend(recon, pw, pad=words_pad, first_pad=False)
                 emask = ~epad
@@ -449,6 +490,7 @@ class MESM(nn.Module):
                 epad = words_pad
 
         with _scope("t2v"):
+            pre = None
             if self.use_txt_pos:
                 # expanded_txt_position (model.py:225-226) and its negative gather (:263); with the sentence token in
                 # front the negative words of the enhance stage keep positions 1.. of it (:267), so that stage
@@ -457,13 +499,37 @@ class MESM(nn.Module):
                 ewords2, epad2, etpos2 = ops.stack_rows([ewords, epad, etpos], [1, 1, 1], ni)
                 if defer_enhance:
                     tpos2 = torch.cat([tpos, etpos2[N:, 1:]], 0)
-                    enhanced2, enhanced2_p = enc(pw2, pv2, tpos2, vpos2, wpad2, vid_pad2, group=N, vid_p=pvp2,
-                                                 out_pos=vpos2)
-                    enhanced = enhanced2[:N]
+                    pre = enc.steps(pw2, pv2, tpos2, vpos2, wpad2, vid_pad2, group=N, vid_p=pvp2, out_pos=vpos2)
             else:
                 ewords2, epad2 = ops.stack_rows([ewords, epad], [1, 1], ni)
                 etpos2 = None
-            encoded2 = self.t2v_encoder(ewords2, enhanced2, etpos2, vpos2, epad2, vid_pad2, group=N, vid_p=enhanced2_p)
+
+            def t2v_chain():
+                e2, e2p = enhanced2, enhanced2_p
+                if pre is not None:
+                    e2, e2p = yield from pre
+                enc2 = yield from self.t2v_encoder.steps(ewords2, e2, etpos2, vpos2, epad2, vid_pad2, group=N, vid_p=e2p)
+                return e2, enc2
+
+            def mlm_head_chain():
+                hid = yield from self.output_txt_proj[0].steps(res["M"])
+                head = self.output_txt_proj[1]
+                return (yield ops.linear_call(hid, head.weight, head.bias))
+
+            stage, names = [t2v_chain()], ["T"]
+            if mlm:
+                stage.append(mlm_head_chain())
+                names.append("H")
+            if self.rec_ss:
+                # projed_recon_feat feeds no loss (criterion.py:246-255) but is part of the returned dict
+                stage.append(proj_chain(self.ss_reconstructor.output_sent_proj, recon))
+                names.append("R")
+            res2 = dict(zip(names, ops.lockstep(stage)))
+            e2_, encoded2 = res2["T"]
+            if enhanced is None:
+                enhanced = e2_[:N]
+            if self.rec_ss:
+                projed_recon = res2["R"]
         with _scope("transformer"):
             hs, refs, memory2, memory_g2 = self.transformer(
                 encoded2, vid_pad2, self.query_embed.weight, vpos2, self.global_rep_token,
@@ -487,24 +553,8 @@ class MESM(nn.Module):
         if self.aux_loss:
             out["aux_outputs"] = [{"pred_logits": a, "pred_spans": b} for a, b in zip(logits[:-1], spans[:-1])]
 
-        if self.rec_fw and is_training:
-            # FW-MESM masked-language-model branch (model.py:307-332)
-            def mlm_branch(pv_, pw_):
-                with _scope("mlm"):
-                    unk = self._proj(self.input_txt_proj, self.unknown_token.view(1, 1, -1))
-                    msk = self._proj(self.input_txt_proj, self.masked_token.view(1, 1, -1))
-                    # unknown words, then the drawn positions, become learned tokens (model.py:361-394): one launch
-                    w = ops.token_mix(pw_, kwargs["unknown_mask"], unk, plan.masked_words, msk)
-                    # the ground-truth clips of every pair re-padded to Lc, and their position embeddings
-                    # (model.py:312-325)
-                    cfeat = ops.gather_rows2(pv_.reshape(N * Lv, d), plan.clip_src, plan.clip_inv, plan.clip_mask)
-                    cpos = kn.gather_rows_fwd(vpos.reshape(N * Lv, d), plan.clip_src, plan.clip_mask)[0]
-                    rec_w = enc(cfeat, w, cpos, tpos, plan.clip_pad, words_pad, is_mlm=True)  # pos_vid = txt_position
-                    hid = self.output_txt_proj[0](rec_w)
-                    head = self.output_txt_proj[1]
-                    return ops.linear(hid, head.weight, head.bias)
-
-            out["recfw_words_logit"] = mlm_branch(pv, pw)
+        if mlm:
+            out["recfw_words_logit"] = res2["H"]
             out["words_mask"] = words_mask
         if self.rec_ss:
             out.update({"projed_video_feat": pv, "recon_feat": recon, "projed_recon_feat": projed_recon,

@@ -113,17 +113,255 @@ def _masked_dy(sink, dy2, out_drop):
     return kn.dropout(dy2, *out_drop)
 
 
+# ----------------------------------------------------------------------------- blocks, phases, lockstep
+# A BLOCK is a class with two static methods, fwd(ctx, *args) and bwd(ctx, *grads), written like the forward /
+# backward of a torch.autograd.Function -- except that they may be GENERATORS: every `yield` ends a LAUNCH PHASE
+# (kernels.phase: the gemm / layernorm / attention launches made since the previous yield are mutually
+# independent and are issued together, grouped by kind).  `make_fn(block)` wraps a block as an ordinary
+# autograd.Function (its phases run one after the other).  `par([...])` runs SEVERAL blocks as ONE autograd node
+# whose phases advance in LOCKSTEP: phase k of every block shares its grouped launches, forward and backward.
+# That is how the step's independent chains -- the enhance stack beside the SS-MESM stack, the MLM stack beside
+# the rest of the SS-MESM stack (model.py:184-207, 307-332) -- stop being one serial chain of latency-bound
+# launches: their small problems ride in the launches of the large ones, on the same hardware queue.
+import inspect
+
+
+def _drive(thunks):
+    """Run blocks in lockstep, one launch phase per round; returns their return values.  thunks: zero-argument
+    callables returning either the block's result (a single-phase block) or a generator (one `yield` per phase
+    boundary).  Parameter-gradient readiness (gradbuf.flush_ready, the hook a DDP reducer listens to) is reported
+    once every phase of every block has been ISSUED -- a block acquires its gradient views up front, their kernels
+    may sit in a later phase."""
+    n = len(thunks)
+    results = [None] * n
+    gens = [None] * n
+    outer = kn._phase is not None  # the caller's own phase (gemm_group) collects: only single-phase blocks fit in it
+    live = []
+    with kn.phase():
+        for i, t in enumerate(thunks):
+            r = t()
+            if inspect.isgenerator(r):
+                gens[i] = r
+                try:
+                    next(r)
+                    live.append(i)
+                except StopIteration as e:
+                    results[i] = e.value
+            else:
+                results[i] = r
+    while live:
+        assert not outer, "a multi-phase block was called inside an open launch phase"
+        nxt = []
+        with kn.phase():
+            for i in live:
+                try:
+                    next(gens[i])
+                    nxt.append(i)
+                except StopIteration as e:
+                    results[i] = e.value
+        live = nxt
+    if not outer:
+        flush_ready()
+    return results
+
+
+class _Sub:
+    """What a block sees as `ctx` when it runs inside a par() node."""
+
+    def __init__(self, needs):
+        self.needs_input_grad = tuple(needs)
+        self._saved = ()
+        self.materialize = True
+        self.nondiff = []
+
+    def save_for_backward(self, *ts):
+        self._saved = ts
+
+    @property
+    def saved_tensors(self):
+        return self._saved
+
+    def set_materialize_grads(self, v):
+        self.materialize = bool(v)
+
+    def mark_non_differentiable(self, *ts):
+        self.nondiff.extend(ts)
+
+
+def make_fn(block):
+    """A block as a stand-alone autograd.Function."""
+
+    class Fn(Function):
+        @staticmethod
+        def forward(ctx, *args):
+            return _drive([lambda: block.fwd(ctx, *args)])[0]
+
+        @staticmethod
+        def backward(ctx, *gs):
+            return _drive([lambda: block.bwd(ctx, *gs)])[0]
+
+    Fn.__name__ = Fn.__qualname__ = block.__name__.replace("Block", "Fn")
+    return Fn
+
+
+class ParFn(Function):
+    """Several blocks as one autograd node, phases in lockstep.  apply(spec, *flat): spec = ((block, nargs), ...),
+    flat = the blocks' arguments back to back; returns the blocks' outputs back to back."""
+
+    @staticmethod
+    def forward(ctx, spec, *flat):
+        ctx.set_materialize_grads(False)
+        subs, runs, pos = [], [], 0
+        for block, n in spec:
+            sub = _Sub(ctx.needs_input_grad[1 + pos:1 + pos + n])
+            subs.append(sub)
+            runs.append(lambda block=block, sub=sub, a=flat[pos:pos + n]: block.fwd(sub, *a))
+            pos += n
+        outs = _drive(runs)
+        flat_out, counts, saved, spans, meta, nondiff = [], [], [], [], [], []
+        for sub, o in zip(subs, outs):
+            t = o if isinstance(o, tuple) else (o,)
+            counts.append(len(t))
+            flat_out.extend(t)
+            meta.append([(x.shape, x.dtype, x.device) if torch.is_tensor(x) else None for x in t])
+            spans.append((len(saved), len(sub._saved)))
+            saved.extend(sub._saved)
+            sub._saved = ()
+            nondiff.extend(sub.nondiff)
+        ctx.save_for_backward(*saved)
+        if nondiff:
+            ctx.mark_non_differentiable(*nondiff)
+        ctx.subs, ctx.spec, ctx.counts, ctx.spans, ctx.meta = subs, spec, counts, spans, meta
+        return tuple(flat_out)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        saved = ctx.saved_tensors
+        runs, slots, pos = [], [], 0
+        res = [None] * len(ctx.spec)
+        for i, ((block, n), sub, cnt, (a, m)) in enumerate(zip(ctx.spec, ctx.subs, ctx.counts, ctx.spans)):
+            g = list(gs[pos:pos + cnt])
+            pos += cnt
+            if all(x is None for x in g):  # nothing reached this block's outputs: autograd would not call it
+                res[i] = (None,) * n
+                continue
+            if sub.materialize:
+                g = [torch.zeros(mt[0], dtype=mt[1], device=mt[2]) if (x is None and mt is not None) else x
+                     for x, mt in zip(g, ctx.meta[i])]
+            sub._saved = saved[a:a + m]
+            runs.append(lambda block=block, sub=sub, g=g: block.bwd(sub, *g))
+            slots.append(i)
+        for i, r in zip(slots, _drive(runs)):
+            res[i] = tuple(r) if isinstance(r, (tuple, list)) else (r,)
+        out = [None]
+        for r, (block, n) in zip(res, ctx.spec):
+            assert len(r) == n, (block.__name__, len(r), n)
+            out.extend(r)
+        return tuple(out)
+
+
+class Call:
+    """A deferred block invocation: run(call) executes it alone, par([calls]) in lockstep with others.
+    post(out) -> what the caller gets (sink tagging)."""
+    __slots__ = ("block", "args", "post")
+
+    def __init__(self, block, args, post=None):
+        self.block, self.args, self.post = block, tuple(args), post
+
+
+def par(calls):
+    """Run the calls as ONE autograd node with their launch phases in lockstep; returns one result per call."""
+    calls = [c for c in calls]
+    if len(calls) == 1:
+        return [run(calls[0])]
+    spec = tuple((c.block, len(c.args)) for c in calls)
+    flat = [a for c in calls for a in c.args]
+    outs = ParFn.apply(spec, *flat)
+    res, pos = [], 0
+    counts = ParFn_counts(outs, calls)
+    for c, n in zip(calls, counts):
+        o = outs[pos:pos + n]
+        pos += n
+        o = o[0] if n == 1 else tuple(o)
+        res.append(c.post(o) if c.post is not None else o)
+    return res
+
+
+def ParFn_counts(outs, calls):
+    """outputs per call: every block declares N_OUT (a number or a function of its arguments)"""
+    counts = []
+    for c in calls:
+        n = c.block.N_OUT
+        counts.append(n(*c.args) if callable(n) else n)
+    assert sum(counts) == len(outs), (counts, len(outs))
+    return counts
+
+
+def lockstep(chains):
+    """Run several CHAINS side by side.  A chain is a generator that yields ops.Call objects one at a time and
+    receives each call's result back (`x = yield ops.linear_call(...)`); `yield None` sits a round out.  Every round
+    the calls the chains have just yielded run as ONE autograd node with their launch phases in lockstep (par):
+    independent stacks -- enhance beside SS-MESM, MLM beside the rest of SS-MESM, the input projections of every
+    modality -- share their launches instead of queueing behind each other.  Returns the chains' return values."""
+    chains = list(chains)
+    n = len(chains)
+    results, send = [None] * n, [None] * n
+    live = list(range(n))
+    while live:
+        calls, who, nxt = [], [], []
+        for i in live:
+            try:
+                c = chains[i].send(send[i])
+            except StopIteration as e:
+                results[i] = e.value
+                continue
+            send[i] = None
+            nxt.append(i)
+            if c is not None:
+                calls.append(c)
+                who.append(i)
+        live = nxt
+        if calls:
+            for i, o in zip(who, par(calls)):
+                send[i] = o
+    return results
+
+
+def seq(chain):
+    """a chain on its own"""
+    return lockstep([chain])[0]
+
+
+def delayed(chain, rounds):
+    """the chain, starting `rounds` rounds later"""
+    for _ in range(rounds):
+        yield None
+    return (yield from chain)
+
+
+_FN_CACHE = {}
+
+
+def run(call):
+    fn = _FN_CACHE.get(call.block)
+    if fn is None:
+        fn = _FN_CACHE[call.block] = make_fn(call.block)
+    o = fn.apply(*call.args)
+    return call.post(o) if call.post is not None else o
+
+
 # ----------------------------------------------------------------------------- Linear
-class LinearFn(Function):
+class LinearBlock:
     """y = dropout_out( relu?( dropout_in(x [+ x2]) @ W[rows]^T + b[rows] ) ) [+ residual].
 
     Covers nn.Linear sites with their neighbours fused: with_pos_embed add (x2), the input
     dropout of LinearLayer (model.py:421-431), ReLU (model.py:408,432), and
     `residual + dropout(linear(.))` (transformer.py:534,538,645,648,753,792,795).
     """
+    N_OUT = 1
 
     @staticmethod
-    def forward(ctx, x, x2, residual, w, b, rows, relu, in_drop, out_drop, sink=None):
+    def fwd(ctx, x, x2, residual, w, b, rows, relu, in_drop, out_drop, sink=None):
         ctx.sink = sink
         wv, bv = _rows(w, rows), (_rows(b, rows) if b is not None else None)
         x = _c(x)
@@ -142,7 +380,7 @@ class LinearFn(Function):
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def bwd(ctx, dy):
         x, x2, y = ctx.saved_tensors
         w, b, rows = ctx.w, ctx.b, ctx.rows
         dy = _c(dy)
@@ -156,13 +394,12 @@ class LinearFn(Function):
         gw, wdirect = grad_target(w)
         gb, bdirect = grad_target(b) if b is not None else (None, True)
         dx = None
-        with kn.gemm_group():  # dW and dX are independent: one launch when both are small
-            _accum_dw(dz, _2d(x), _rows(gw, rows), _rows(gb, rows) if gb is not None else None,
-                      x2=_2d(x2) if x2 is not None else None, b_drop=ctx.in_drop)
-            if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-                dx = torch.empty_like(x)
-                kn.gemm(dz, _rows(w, rows), _2d(dx), e_drop=ctx.in_drop)
-        flush_ready()
+        # dW and dX are independent: one launch when both are small
+        _accum_dw(dz, _2d(x), _rows(gw, rows), _rows(gb, rows) if gb is not None else None,
+                  x2=_2d(x2) if x2 is not None else None, b_drop=ctx.in_drop)
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dx = torch.empty_like(x)
+            kn.gemm(dz, _rows(w, rows), _2d(dx), e_drop=ctx.in_drop)
         return (dx if ctx.needs_input_grad[0] else None,
                 dx if (x2 is not None and ctx.needs_input_grad[1]) else None,
                 dy if ctx.has_res and ctx.needs_input_grad[2] else None,
@@ -175,27 +412,32 @@ class LinearFn(Function):
 TEST_NO_RELU = False
 
 
-def linear(x, w, b, *, x2=None, residual=None, rows=None, relu=False, in_drop=NO_DROP,
-           out_drop=NO_DROP):
+def linear_call(x, w, b, *, x2=None, residual=None, rows=None, relu=False, in_drop=NO_DROP,
+                out_drop=NO_DROP):
     if TEST_NO_RELU:
         relu = False
     sink = _sink_for(out_drop)
-    return _tag(LinearFn.apply(x, x2, residual, w, b, rows, relu, in_drop, out_drop, sink), sink)
+    return Call(LinearBlock, (x, x2, residual, w, b, rows, relu, in_drop, out_drop, sink), lambda y: _tag(y, sink))
+
+
+def linear(x, w, b, **kw):
+    return run(linear_call(x, w, b, **kw))
 
 
 # ----------------------------------------------------------------------------- FFN
-class FFNFn(Function):
+class FFNBlock:
     """y = residual + dropout_out( dropout_mid(prelu(x W1^T + b1)) W2^T + b2 ).
 
     linear2(dropout(activation(linear1(.)))) with activation = nn.PReLU (one learnable
     slope) and the residual add: transformer.py:537-538, 603-604, 608-609, 647-648, 794-795.
-    The hidden activation h = dropout_mid(prelu(z)) is written once by an element-wise kernel and
+    The hidden activation h = dropout_mid(prelu(z)) is written once by the first GEMM's epilogue and
     saved next to z: as an operand transform of the second GEMM and of the dW2 GEMM the PReLU +
     mask hash was recomputed by every output tile (82 us vs 47 us for the 4800 x 256 x 1024 GEMM).
     """
+    N_OUT = 1
 
     @staticmethod
-    def forward(ctx, x, residual, w1, b1, slope, w2, b2, mid_drop, out_drop, sink=None):
+    def fwd(ctx, x, residual, w1, b1, slope, w2, b2, mid_drop, out_drop, sink=None):
         ctx.sink = sink
         x = _c(x)
         F_ = w1.shape[0]
@@ -204,6 +446,7 @@ class FFNFn(Function):
         # one pass writes z (pre-activation, kept for the PReLU gradient) and h = dropout(prelu(z))
         kn.gemm(_2d(x), w1, _2d(h), trans_b=True, bias=b1, e_act=ACT_PRELU, slope=slope, e_drop=mid_drop,
                 pre_out=_2d(z))
+        yield
         y = torch.empty_like(x)
         kn.gemm(_2d(h), w2, _2d(y), trans_b=True, bias=b2, e_drop=out_drop,
                 residual=_2d(_c(residual)) if residual is not None else None)
@@ -215,7 +458,7 @@ class FFNFn(Function):
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def bwd(ctx, dy):
         x, z, h = ctx.saved_tensors
         w1, b1, slope, w2, b2 = ctx.params
         dy = _c(dy)
@@ -227,36 +470,39 @@ class FFNFn(Function):
         gb1, d_b1 = grad_target(b1)
         gs, d_s = grad_target(slope)
         dz1 = torch.empty_like(z)
-        with kn.gemm_group():
-            _accum_dw(dz2, _2d(h), gw2, gb2)
-            kn.gemm(dz2, w2, _2d(dz1), e_drop=ctx.mid_drop, aux=_2d(z), e_actgrad=ACT_PRELU,
-                    slope=slope, dslope=gs)
+        _accum_dw(dz2, _2d(h), gw2, gb2)
+        kn.gemm(dz2, w2, _2d(dz1), e_drop=ctx.mid_drop, aux=_2d(z), e_actgrad=ACT_PRELU,
+                slope=slope, dslope=gs)
+        yield
         dx = None
         fold_res = ctx.res_is_x and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
-        with kn.gemm_group():
-            _accum_dw(_2d(dz1), _2d(x), gw1, gb1)
-            if ctx.needs_input_grad[0]:
-                dx = torch.empty_like(x)
-                # residual input IS x: its gradient (dy) rides the epilogue of the dX GEMM
-                kn.gemm(_2d(dz1), w1, _2d(dx), residual=dy2 if fold_res else None)
-        flush_ready()
+        _accum_dw(_2d(dz1), _2d(x), gw1, gb1)
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            # residual input IS x: its gradient (dy) rides the epilogue of the dX GEMM
+            kn.gemm(_2d(dz1), w1, _2d(dx), residual=dy2 if fold_res else None)
         return (dx, dy if ctx.has_res and ctx.needs_input_grad[1] and not fold_res else None,
                 None if d_w1 else gw1, None if d_b1 else gb1, None if d_s else gs,
                 None if d_w2 else gw2, None if d_b2 else gb2, None, None, None)
 
 
-def ffn(x, residual, w1, b1, slope, w2, b2, mid_drop=NO_DROP, out_drop=NO_DROP):
+def ffn_call(x, residual, w1, b1, slope, w2, b2, mid_drop=NO_DROP, out_drop=NO_DROP):
     sink = _sink_for(out_drop)
-    return _tag(FFNFn.apply(x, residual, w1, b1, slope, w2, b2, mid_drop, out_drop, sink), sink)
+    return Call(FFNBlock, (x, residual, w1, b1, slope, w2, b2, mid_drop, out_drop, sink), lambda y: _tag(y, sink))
+
+
+def ffn(x, residual, w1, b1, slope, w2, b2, mid_drop=NO_DROP, out_drop=NO_DROP):
+    return run(ffn_call(x, residual, w1, b1, slope, w2, b2, mid_drop, out_drop))
 
 
 # ----------------------------------------------------------------------------- LayerNorm
-class LayerNormFn(Function):
+class LayerNormBlock:
     """nn.LayerNorm over the last dim (transformer.py:536,539,646,649,754,793,796,400;
     model.py:430)."""
+    N_OUT = 1
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, drop=NO_DROP, sink=None):
+    def fwd(ctx, x, gamma, beta, eps, drop=NO_DROP, sink=None):
         x = _c(x)
         y, mean, rstd = kn.layernorm_fwd(x, gamma, beta, eps, drop)
         ctx.save_for_backward(x, mean, rstd)
@@ -265,7 +511,7 @@ class LayerNormFn(Function):
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def bwd(ctx, dy):
         x, mean, rstd = ctx.saved_tensors
         gg, dg = grad_target(ctx.gamma)
         gb, db = grad_target(ctx.beta)
@@ -275,17 +521,17 @@ class LayerNormFn(Function):
         if sink is not None:
             dx, sink.dz = dx
             sink.src = dx
-        flush_ready()
         return (dx, None if dg else gg, None if db else gb, None, None, None)
 
 
-class LayerNormPosFn(Function):
+class LayerNormPosBlock:
     """(y, y + add) = LayerNorm(x): the second output is the `with_pos_embed` query of the attention block
     that consumes y (transformer.py:512, 577, 640), written by the same kernel; the backward adds the two
     incoming gradients while loading them."""
+    N_OUT = 2
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, add, sink):
+    def fwd(ctx, x, gamma, beta, eps, add, sink):
         ctx.set_materialize_grads(False)
         x, add = _c(x), _c(add)
         y, mean, rstd, y2 = kn.layernorm_fwd(x, gamma, beta, eps, NO_DROP, add=add)
@@ -294,7 +540,7 @@ class LayerNormPosFn(Function):
         return y, y2
 
     @staticmethod
-    def backward(ctx, dy, dy2):
+    def bwd(ctx, dy, dy2):
         x, mean, rstd = ctx.saved_tensors
         if dy is None:
             dy, dyb = dy2, None
@@ -312,37 +558,43 @@ class LayerNormPosFn(Function):
         if sink is not None:
             dx, sink.dz = dx
             sink.src = dx
-        flush_ready()
         return (dx, None if dg else gg, None if db else gb, None, dy2 if ctx.needs_input_grad[4] else None, None)
+
+
+def layer_norm_call(x, gamma, beta, eps=1e-5, drop=NO_DROP, add=None):
+    if add is not None:
+        assert drop[0] == 0.0
+        return Call(LayerNormPosBlock, (x, gamma, beta, eps, add, getattr(x, "_mesm_sink", None)))
+    return Call(LayerNormBlock, (x, gamma, beta, eps, drop, getattr(x, "_mesm_sink", None)))
 
 
 def layer_norm(x, gamma, beta, eps=1e-5, drop=NO_DROP, add=None):
     """drop = (p, seed): the Dropout that follows the LayerNorm (LinearLayer) rides the same kernels.
     add: also return y + add (-> tuple)."""
-    if add is not None:
-        assert drop[0] == 0.0
-        return LayerNormPosFn.apply(x, gamma, beta, eps, add, getattr(x, "_mesm_sink", None))
-    return LayerNormFn.apply(x, gamma, beta, eps, drop, getattr(x, "_mesm_sink", None))
+    return run(layer_norm_call(x, gamma, beta, eps, drop, add))
 
 
 # ----------------------------------------------------------------------------- LN -> FFN -> + x
-class NormFFNFn(Function):
+class NormFFNBlock:
     """y = x + dropout_out( dropout_mid(prelu(LN(x) W1^T + b1)) W2^T + b2 ): the pre-norm feed-forward block of
     the T2V layers (transformer.py:536-538, 601-609) as ONE autograd block.  x reaches y on two routes; the
     LayerNorm backward kernel adds the residual route's gradient (dy) while it stores dx, and also emits dx
     under the dropout mask of the block that produced x (sink_in), so neither an element-wise add nor a mask
     kernel is launched."""
+    N_OUT = 1
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, w1, b1, slope, w2, b2, mid_drop, out_drop, sink, sink_in):
+    def fwd(ctx, x, gamma, beta, eps, w1, b1, slope, w2, b2, mid_drop, out_drop, sink, sink_in):
         x = _c(x)
         h, mean, rstd = kn.layernorm_fwd(x, gamma, beta, eps)
+        yield
         F_ = w1.shape[0]
         z = torch.empty(x.shape[:-1] + (F_,), device=x.device, dtype=torch.float32)
         a = torch.empty_like(z)
         # one pass writes z (pre-activation, kept for the PReLU gradient) and a = dropout(prelu(z))
         kn.gemm(_2d(h), w1, _2d(a), trans_b=True, bias=b1, e_act=ACT_PRELU, slope=slope, e_drop=mid_drop,
                 pre_out=_2d(z))
+        yield
         y = torch.empty_like(x)
         kn.gemm(_2d(a), w2, _2d(y), trans_b=True, bias=b2, e_drop=out_drop, residual=_2d(x))
         ctx.save_for_backward(x, mean, rstd, h, z, a)
@@ -352,7 +604,7 @@ class NormFFNFn(Function):
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def bwd(ctx, dy):
         x, mean, rstd, h, z, a = ctx.saved_tensors
         gamma, beta, w1, b1, slope, w2, b2 = ctx.params
         dy = _c(dy)
@@ -366,13 +618,13 @@ class NormFFNFn(Function):
         gg, d_g = grad_target(gamma)
         gbt, d_bt = grad_target(beta)
         dz1 = torch.empty_like(z)
-        with kn.gemm_group():
-            _accum_dw(dz2, _2d(a), gw2, gb2)
-            kn.gemm(dz2, w2, _2d(dz1), e_drop=ctx.mid_drop, aux=_2d(z), e_actgrad=ACT_PRELU, slope=slope, dslope=gs)
+        _accum_dw(dz2, _2d(a), gw2, gb2)
+        kn.gemm(dz2, w2, _2d(dz1), e_drop=ctx.mid_drop, aux=_2d(z), e_actgrad=ACT_PRELU, slope=slope, dslope=gs)
+        yield
         dh = torch.empty_like(h)
-        with kn.gemm_group():
-            _accum_dw(_2d(dz1), _2d(h), gw1, gb1)
-            kn.gemm(_2d(dz1), w1, _2d(dh))
+        _accum_dw(_2d(dz1), _2d(h), gw1, gb1)
+        kn.gemm(_2d(dz1), w1, _2d(dh))
+        yield
         dx = None
         if ctx.needs_input_grad[0]:
             sink = ctx.sink_in
@@ -383,15 +635,18 @@ class NormFFNFn(Function):
                 sink.src = dx
         else:
             kn.layernorm_bwd(dh, x, gamma, mean, rstd, gg, gbt, need_dx=False)
-        flush_ready()
         return (dx, None if d_g else gg, None if d_bt else gbt, None, None if d_w1 else gw1, None if d_b1 else gb1,
                 None if d_s else gs, None if d_w2 else gw2, None if d_b2 else gb2, None, None, None, None)
 
 
-def norm_ffn(x, gamma, beta, w1, b1, slope, w2, b2, eps=1e-5, mid_drop=NO_DROP, out_drop=NO_DROP):
+def norm_ffn_call(x, gamma, beta, w1, b1, slope, w2, b2, eps=1e-5, mid_drop=NO_DROP, out_drop=NO_DROP):
     sink = _sink_for(out_drop)
-    return _tag(NormFFNFn.apply(x, gamma, beta, eps, w1, b1, slope, w2, b2, mid_drop, out_drop, sink,
-                                getattr(x, "_mesm_sink", None)), sink)
+    return Call(NormFFNBlock, (x, gamma, beta, eps, w1, b1, slope, w2, b2, mid_drop, out_drop, sink,
+                               getattr(x, "_mesm_sink", None)), lambda y: _tag(y, sink))
+
+
+def norm_ffn(x, gamma, beta, w1, b1, slope, w2, b2, eps=1e-5, mid_drop=NO_DROP, out_drop=NO_DROP):
+    return run(norm_ffn_call(x, gamma, beta, w1, b1, slope, w2, b2, eps, mid_drop, out_drop))
 
 
 # ----------------------------------------------------------------------------- attention core
@@ -566,7 +821,7 @@ def dec_cross_attn(tgt, qs, qpp, memory, pos, mem_pad, wqc, bqc, wkv, bkv, wkp, 
 
 
 # ----------------------------------------------------------------------------- packed MHA
-class MHAFn(Function):
+class MHABlock:
     """A whole nn.MultiheadAttention call plus its residual:
 
         out = residual + dropout_out( out_proj( attn( xqp Wq, (xk+pk) Wk, xk Wv ) ) )
@@ -579,11 +834,13 @@ class MHAFn(Function):
     `self_attn=True`: Q and K come from xqp, V from xq: Q and K projections run as ONE GEMM over
     in_proj_weight[0:2d].  Otherwise, when the key has no positional term (use_txt_pos=False in every shipped
     config; SegSenRecon passes None), K and V run as ONE GEMM over in_proj_weight[d:3d].
+    Three launch phases forward (projections | attention core | output projection) and three backward.
     """
+    N_OUT = 1
 
     @staticmethod
-    def forward(ctx, xq, xqp, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad, qpad, attn_drop,
-                out_drop, self_attn, group=0, sink=None):
+    def fwd(ctx, xq, xqp, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad, qpad, attn_drop,
+            out_drop, self_attn, group=0, sink=None):
         ctx.set_materialize_grads(False)
         ctx.sink = sink
         xq = _c(xq)
@@ -604,11 +861,11 @@ class MHAFn(Function):
             q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
             xk = pk = None
         else:
+            q = torch.empty(N, Lq, d, device=dev, dtype=torch.float32)
+            kn.gemm(_2d(xqp), w_in[:d], _2d(q), trans_b=True, bias=b_in[:d])
             xk = _c(xk)
             pk = _c(pk) if pk is not None else None
             Lk = xk.shape[1]
-            q = torch.empty(N, Lq, d, device=dev, dtype=torch.float32)
-            kn.gemm(_2d(xqp), w_in[:d], _2d(q), trans_b=True, bias=b_in[:d])
             kv = torch.empty(N, Lk, 2 * d, device=dev, dtype=torch.float32)
             kv2 = _2d(kv)
             if pk is None:
@@ -617,7 +874,9 @@ class MHAFn(Function):
                 kn.gemm(_2d(xk), w_in[d:2 * d], kv2[:, :d], trans_b=True, A2=_2d(pk), bias=b_in[d:2 * d])
                 kn.gemm(_2d(xk), w_in[2 * d:], kv2[:, d:], trans_b=True, bias=b_in[2 * d:])
             k, v = kv[..., :d], kv[..., d:]
+        yield
         o, lse = kn.attn_fwd(q, k, v, H, kpad=kpad, qpad=qpad, drop=attn_drop, group=group)
+        yield
         out = torch.empty(N, Lq, d, device=dev, dtype=torch.float32)
         kn.gemm(_2d(o), w_out, _2d(out), trans_b=True, bias=b_out, e_drop=out_drop,
                 residual=_2d(_c(residual)) if residual is not None else None)
@@ -628,7 +887,7 @@ class MHAFn(Function):
         return out
 
     @staticmethod
-    def backward(ctx, dy):
+    def bwd(ctx, dy):
         xq, xqp, xk, pk, q, k, v, o, lse = ctx.saved_tensors
         w_in, b_in, w_out, b_out = ctx.params
         H, kpad, qpad, attn_drop, out_drop, self_attn, has_res, group, has_p = ctx.cfg
@@ -645,9 +904,9 @@ class MHAFn(Function):
         gwi, d_wi = grad_target(w_in)
         gbi, d_bi = grad_target(b_in)
         do = torch.empty_like(o)
-        with kn.gemm_group():
-            _accum_dw(dz, _2d(o), gwo, gbo)
-            kn.gemm(dz, w_out, _2d(do))
+        _accum_dw(dz, _2d(o), gwo, gbo)
+        kn.gemm(dz, w_out, _2d(do))
+        yield
         need_q = ctx.needs_input_grad[0]
         need_qp = has_p and ctx.needs_input_grad[1]
         need_k, need_pk = ctx.needs_input_grad[2], ctx.needs_input_grad[3]
@@ -658,70 +917,77 @@ class MHAFn(Function):
             dqkv = (torch.zeros if Lq > 64 else torch.empty)(N, Lq, 3 * d, device=dev, dtype=torch.float32)
             kn.attn_bwd_into(do, q, k, v, o, lse, H, dqkv[..., :d], dqkv[..., d:2 * d],
                              dqkv[..., 2 * d:], kpad=kpad, qpad=qpad, drop=attn_drop, group=group)
+            yield
             g2 = _2d(dqkv)
-            with kn.gemm_group():
-                if has_p:
-                    _accum_dw(g2[:, :2 * d], _2d(xqp), gwi[:2 * d], gbi[:2 * d])
-                    _accum_dw(g2[:, 2 * d:], _2d(xq), gwi[2 * d:], gbi[2 * d:])
-                    if need_qp:
-                        dxqp = torch.empty_like(xq)
-                        kn.gemm(g2[:, :2 * d], w_in[:2 * d], _2d(dxqp))
-                    if need_q:
-                        dxq = torch.empty_like(xq)
-                        kn.gemm(g2[:, 2 * d:], w_in[2 * d:], _2d(dxq), residual=dy2 if fold else None)
-                else:
-                    _accum_dw(g2, _2d(xq), gwi, gbi)
-                    if need_q:
-                        dxq = torch.empty_like(xq)
-                        kn.gemm(g2, w_in, _2d(dxq), residual=dy2 if fold else None)
+            if has_p:
+                _accum_dw(g2[:, :2 * d], _2d(xqp), gwi[:2 * d], gbi[:2 * d])
+                _accum_dw(g2[:, 2 * d:], _2d(xq), gwi[2 * d:], gbi[2 * d:])
+                if need_qp:
+                    dxqp = torch.empty_like(xq)
+                    kn.gemm(g2[:, :2 * d], w_in[:2 * d], _2d(dxqp))
+                if need_q:
+                    dxq = torch.empty_like(xq)
+                    kn.gemm(g2[:, 2 * d:], w_in[2 * d:], _2d(dxq), residual=dy2 if fold else None)
+            else:
+                _accum_dw(g2, _2d(xq), gwi, gbi)
+                if need_q:
+                    dxq = torch.empty_like(xq)
+                    kn.gemm(g2, w_in, _2d(dxq), residual=dy2 if fold else None)
         else:
-            Lk = xk.shape[1]
+            Lk = k.shape[1]
             dq = (torch.zeros if Lk > 64 else torch.empty)(N, Lq, d, device=dev, dtype=torch.float32)
             dkv = torch.empty(N, Lk, 2 * d, device=dev, dtype=torch.float32)
             kn.attn_bwd_into(do, q, k, v, o, lse, H, dq, dkv[..., :d], dkv[..., d:], kpad=kpad,
                              qpad=qpad, drop=attn_drop, group=group)
+            yield
             g2 = _2d(dkv)
-            with kn.gemm_group():  # dWq, dWkv, dX(query side), dX(key side): all independent
-                _accum_dw(_2d(dq), _2d(xqp), gwi[:d], gbi[:d])
+            # dWq, dWkv, dX(query side), dX(key side): all independent
+            _accum_dw(_2d(dq), _2d(xqp), gwi[:d], gbi[:d])
+            if pk is None:
+                _accum_dw(g2, _2d(xk), gwi[d:], gbi[d:])
+            else:
+                _accum_dw(g2[:, :d], _2d(xk), gwi[d:2 * d], gbi[d:2 * d], x2=_2d(pk))
+                _accum_dw(g2[:, d:], _2d(xk), gwi[2 * d:], gbi[2 * d:])
+            if has_p:
+                if need_qp:
+                    dxqp = torch.empty_like(xq)
+                    kn.gemm(_2d(dq), w_in[:d], _2d(dxqp))
+                if fold:
+                    dxq = dy  # the only route from xq itself is the residual
+            elif need_q:
+                dxq = torch.empty_like(xq)
+                kn.gemm(_2d(dq), w_in[:d], _2d(dxq), residual=dy2 if fold else None)
+            if need_k or need_pk:
                 if pk is None:
-                    _accum_dw(g2, _2d(xk), gwi[d:], gbi[d:])
+                    dxk = torch.empty_like(xk)
+                    kn.gemm(g2, w_in[d:], _2d(dxk))
                 else:
-                    _accum_dw(g2[:, :d], _2d(xk), gwi[d:2 * d], gbi[d:2 * d], x2=_2d(pk))
-                    _accum_dw(g2[:, d:], _2d(xk), gwi[2 * d:], gbi[2 * d:])
-                if has_p:
-                    if need_qp:
-                        dxqp = torch.empty_like(xq)
-                        kn.gemm(_2d(dq), w_in[:d], _2d(dxqp))
-                    if fold:
-                        dxq = dy  # the only route from xq itself is the residual
-                elif need_q:
-                    dxq = torch.empty_like(xq)
-                    kn.gemm(_2d(dq), w_in[:d], _2d(dxq), residual=dy2 if fold else None)
-                if need_k or need_pk:
-                    if pk is None:
-                        dxk = torch.empty_like(xk)
-                        kn.gemm(g2, w_in[d:], _2d(dxk))
-                    else:
-                        dk_in = torch.empty_like(xk)
-                        kn.gemm(g2[:, :d], w_in[d:2 * d], _2d(dk_in))
+                    dk_in = torch.empty_like(xk)
+                    kn.gemm(g2[:, :d], w_in[d:2 * d], _2d(dk_in))
             if (need_k or need_pk) and pk is not None:
+                yield
                 dpk = dk_in if need_pk else None
                 if need_k:
                     dxk = torch.empty_like(xk)
                     kn.gemm(g2[:, d:], w_in[2 * d:], _2d(dxk), residual=_2d(dk_in))
-        flush_ready()
         return (dxq, dxqp, dxk, dpk, dy if has_res and ctx.needs_input_grad[4] and not fold else None,
                 None if d_wi else gwi, None if d_bi else gbi, None if d_wo else gwo,
                 None if d_bo else gbo, None, None, None, None, None, None, None, None)
+
+
+def mha_call(xq, xqp, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad=None, qpad=None,
+             attn_drop=NO_DROP, out_drop=NO_DROP, self_attn=False, group=0):
+    sink = _sink_for(out_drop)
+    return Call(MHABlock, (xq, xqp, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad, qpad, attn_drop,
+                           out_drop, self_attn, group, sink), lambda y: _tag(y, sink))
 
 
 def mha(xq, xqp, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad=None, qpad=None,
         attn_drop=NO_DROP, out_drop=NO_DROP, self_attn=False, group=0):
     """xqp: xq + its position embedding, ready-made (None: no positional term).
     group: rows per independent batch when several batches are stacked (mask quirk Q1)."""
-    sink = _sink_for(out_drop)
-    return _tag(MHAFn.apply(xq, xqp, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad, qpad, attn_drop,
-                            out_drop, self_attn, group, sink), sink)
+    return run(mha_call(xq, xqp, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad, qpad, attn_drop, out_drop,
+                        self_attn, group))
 
 
 # ----------------------------------------------------------------------------- sine embeddings
