@@ -793,3 +793,93 @@ def test_gemm_row_split_keeps_the_dropout_mask_and_every_epilogue_term():
             kn._SPLIT_ROWS = True
     assert rel_err(outs[0], outs[1]) < 1e-6
     assert float((outs[0] == res).float().mean()) > 0.05  # dropped elements (only the residual survives) exist
+
+
+def test_layernorm_group_matches_individual_launches():
+    """mesm_layernorm_{fwd,bwd}_group: the LayerNorms of one launch phase (different row counts, fused dropout,
+    second output, gradient joins, masked second gradient) in shared launches give bit for bit what the plain
+    launches give; a wide problem (D = 2818) in the same phase falls through to its own launch."""
+    from mesm_amd import kernels as kn
+    D = 256
+    specs = [dict(rows=32), dict(rows=1024, add=True), dict(rows=4800, drop=(0.5, 11)), dict(rows=75, dyb=True, addend=True),
+             dict(rows=2400, drop2=(0.1, 5)), dict(rows=7, add=True, dyb=True), dict(rows=300, D=2818),
+             dict(rows=33), dict(rows=640, addend=True, drop2=(0.1, 77)), dict(rows=1), dict(rows=129)]
+    probs = []
+    for i, sp in enumerate(specs):
+        d = sp.get("D", D)
+        x = gen((sp["rows"], d), 100 + i)
+        g, b = gen((d,), 200 + i) + 1.0, gen((d,), 300 + i)
+        add = gen((sp["rows"], d), 400 + i) if sp.get("add") else None
+        dy = gen((sp["rows"], d), 500 + i)
+        dyb = gen((sp["rows"], d), 600 + i) if sp.get("dyb") else None
+        addend = gen((sp["rows"], d), 700 + i) if sp.get("addend") else None
+        probs.append((sp, x, g, b, add, dy, dyb, addend))
+
+    def run_all(grouped):
+        import contextlib
+        outs = []
+        ctx = kn.phase() if grouped else contextlib.nullcontext()
+        fw = []
+        with ctx:
+            for sp, x, g, b, add, dy, dyb, addend in probs:
+                fw.append(kn.layernorm_fwd(x, g, b, 1e-5, sp.get("drop", (0.0, 0)), add=add))
+        ctx = kn.phase() if grouped else contextlib.nullcontext()
+        with ctx:
+            for (sp, x, g, b, add, dy, dyb, addend), f in zip(probs, fw):
+                dg, db = torch.zeros_like(g), torch.zeros_like(b)
+                r = kn.layernorm_bwd(dy, x, g, f[1], f[2], dg, db, drop=sp.get("drop", (0.0, 0)), drop2=sp.get("drop2"),
+                                     dyb=dyb, addend=addend)
+                outs.append(list(f) + (list(r) if isinstance(r, tuple) else [r]) + [dg, db])
+        torch.cuda.synchronize()
+        return outs
+
+    ref, got = run_all(False), run_all(True)
+    for (sp, *_), a, b in zip(probs, ref, got):
+        for k, (x, y) in enumerate(zip(a, b)):
+            if k >= len(a) - 2:  # dgamma / dbeta: float atomics, the order of the adders is free
+                assert rel_err(y, x) < 1e-5, (sp, k)
+            else:
+                assert torch.equal(x, y), (sp, k)
+
+
+def test_attention_group_matches_individual_launches():
+    """mesm_attn_{fwd,bwd}_group: the attention cores of one launch phase (enhance 75 x 32, SS-MESM 1 x 75 and 4 x 300,
+    MLM 32 x 20, t2v 75 x 33; quirk masks, dropout, stacked passes) in shared launches against the plain launches."""
+    from mesm_amd import kernels as kn
+    H, d = 8, 256
+    cfgs = [(64, 75, 32, True, 32), (32, 1, 75, True, 0), (32, 32, 20, True, 0), (64, 75, 33, True, 32), (8, 4, 300, True, 0),
+            (16, 76, 76, False, 0), (4, 130, 17, False, 0)]
+    probs = []
+    for i, (B, Lq, Lk, quirk, group) in enumerate(cfgs):
+        q, k, v = gen((B, Lq, d), 10 + i), gen((B, Lk, d), 20 + i), gen((B, Lk, d), 30 + i)
+        g = torch.Generator().manual_seed(40 + i)
+        kpad = torch.rand(B, Lk, generator=g) < 0.2
+        kpad[:, 0] = False
+        qpad = (torch.rand(B, Lq, generator=g) < 0.2) if quirk else None
+        do = gen((B, Lq, d), 50 + i)
+        probs.append((q, k, v, kpad.to(dev()), qpad.to(dev()) if qpad is not None else None, group, do, (0.1, 1000 + i)))
+
+    def run_all(grouped):
+        import contextlib
+        ctx = kn.phase() if grouped else contextlib.nullcontext()
+        fw, outs = [], []
+        with ctx:
+            for q, k, v, kpad, qpad, group, do, drop in probs:
+                fw.append(kn.attn_fwd(q, k, v, H, kpad=kpad, qpad=qpad, drop=drop, group=group))
+        ctx = kn.phase() if grouped else contextlib.nullcontext()
+        with ctx:
+            for (q, k, v, kpad, qpad, group, do, drop), (o, lse) in zip(probs, fw):
+                dq, dk, dv = torch.zeros_like(q), torch.empty_like(k), torch.empty_like(v)
+                kn.attn_bwd_into(do, q, k, v, o, lse, H, dq, dk, dv, kpad=kpad, qpad=qpad, drop=drop, group=group)
+                outs.append([o, lse, dq, dk, dv])
+        torch.cuda.synchronize()
+        return outs
+
+    ref, got = run_all(False), run_all(True)
+    for cfg, a, b in zip(cfgs, ref, got):
+        for k, (x, y) in enumerate(zip(a, b)):
+            ok = ~torch.isnan(x)  # rows whose keys are all masked are NaN in both
+            assert torch.equal(torch.isnan(x), torch.isnan(y)), (cfg, k)
+            # forward: the same kernel body; backward: 4-wave workgroups for every key-tile count (2 alone) and
+            # float atomics into dq when there are several key tiles
+            assert rel_err(y[ok], x[ok]) < (1e-6 if k < 2 else 2e-5), (cfg, k)

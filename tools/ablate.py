@@ -14,9 +14,9 @@ from mesm_amd.graphed import GraphedStep
 
 FAMILIES = {
     "gemm": ["mesm_gemm_f32", "mesm_gemm_group"],
-    "attn": ["mesm_attn_fwd", "mesm_attn_bwd"],
+    "attn": ["mesm_attn_fwd", "mesm_attn_bwd", "mesm_attn_fwd_group", "mesm_attn_bwd_group"],
     "ln": ["mesm_layernorm_fwd", "mesm_layernorm_bwd", "mesm_layernorm_bwd2", "mesm_layernorm_fwd2",
-           "mesm_layernorm_bwd3"],
+           "mesm_layernorm_bwd3", "mesm_layernorm_fwd_group", "mesm_layernorm_bwd_group"],
     "glue": ["mesm_stack_rows", "mesm_unstack_rows", "mesm_prepend_fwd", "mesm_prepend_bwd", "mesm_split_token_fwd",
              "mesm_split_token_bwd", "mesm_token_mix_fwd", "mesm_token_mix_bwd", "mesm_gather_rows_fwd",
              "mesm_gather_rows_bwd", "mesm_add_wrap"],
