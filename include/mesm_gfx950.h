@@ -237,7 +237,8 @@ typedef struct MesmLnArgs {
   int32_t accumulate_dx;
   float drop2_p;
   uint32_t drop2_seed;
-  int32_t reserved0;
+  int32_t relu_in; /* backward, D <= 256 only: x = relu(z) came out of a Linear+ReLU; dx (and dx2) are written as d z,
+                      i.e. masked by x > 0, so that block's own mask launch goes away (model.py:408,432) */
   float* dx2;
   const float* dyb;
   const float* addend;

@@ -71,7 +71,7 @@ class LnArgs(ctypes.Structure):
         ("add", c_ptr), ("y2", c_ptr),
         ("dy", c_ptr), ("dx", c_ptr), ("dgamma", c_ptr), ("dbeta", c_ptr),
         ("accumulate_dx", ctypes.c_int32), ("drop2_p", ctypes.c_float), ("drop2_seed", ctypes.c_uint32),
-        ("reserved0", ctypes.c_int32),
+        ("relu_in", ctypes.c_int32),
         ("dx2", c_ptr), ("dyb", c_ptr), ("addend", c_ptr),
     ]
 

@@ -143,15 +143,20 @@ class CriterionFn(Function):
         lv = torch.empty(len(spec.names), device=dev, dtype=torch.float32)
         saved = {}
         matches = []
-        for li, (il, isp, slot) in enumerate(spec.set_layers):
-            logits, spans = t[il].contiguous(), t[isp].contiguous()
+        for li, (il, isp, slot, k) in enumerate(spec.set_layers):
+            # k: this layer's index in the stacked (layers, N, Q, 2) decoder outputs (None: a tensor of its own)
+            logits, spans = (t[il].contiguous(), t[isp].contiguous()) if k is None else (t[il][k], t[isp][k])
             mq = kn.set_loss_fwd(logits, spans, plan.tgt_cxw, plan.tgt_xx, plan.tgt_off, plan.Tmax,
                                  m.cost_span, m.cost_giou, m.cost_class, c.eos_coef, lv[slot:slot + 4])
             matches.append(mq)
             saved["set%d" % li] = (logits, spans, mq)
         if spec.sal is not None:
             ip, ineg, slot = spec.sal
-            sp, sn = t[ip].contiguous(), t[ineg].contiguous()
+            if ineg is None:  # both passes stacked in one (2N, L) tensor
+                half = t[ip].shape[0] // 2
+                sp, sn = t[ip][:half], t[ip][half:]
+            else:
+                sp, sn = t[ip].contiguous(), t[ineg].contiguous()
             kn.saliency_loss_fwd(sp, sn, spec.sal_label, spec.vmask, spec.pos_idx, spec.neg_idx,
                                  float(c.rank_coef), float(c.saliency_margin), out=lv[slot:slot + 1])
             saved["sal"] = (sp, sn)
@@ -182,16 +187,35 @@ class CriterionFn(Function):
         grads = [None] * ctx.n_in
         g = g_total.reshape(1).to(torch.float32).contiguous()
         gv = kn.scale_vec(g, spec.wv)
-        for li, (il, isp, slot) in enumerate(spec.set_layers):
+        stacked = {}
+        for li, (il, isp, slot, k) in enumerate(spec.set_layers):
             logits, spans, mq = saved["set%d" % li]
-            grads[il], grads[isp] = kn.set_loss_bwd(logits, spans, plan.tgt_cxw, plan.tgt_xx,
-                                                    plan.tgt_off, mq, c.eos_coef, gv[slot:slot + 3])
+            if k is None:
+                grads[il], grads[isp] = kn.set_loss_bwd(logits, spans, plan.tgt_cxw, plan.tgt_xx,
+                                                        plan.tgt_off, mq, c.eos_coef, gv[slot:slot + 3])
+                continue
+            # every layer writes its slice of ONE gradient of the stacked tensor: no select / stack backward
+            # launches.  Layers of the stack the criterion does not read (aux_loss off) keep a zero slice.
+            if il not in stacked:
+                full = spec.stack_layers == len([1 for x in spec.set_layers if x[0] == il])
+                stacked[il] = ((torch.empty_like if full else torch.zeros_like)(spec.stack_base[0]),
+                               (torch.empty_like if full else torch.zeros_like)(spec.stack_base[1]))
+                grads[il], grads[isp] = stacked[il]
+            kn.set_loss_bwd(logits, spans, plan.tgt_cxw, plan.tgt_xx, plan.tgt_off, mq, c.eos_coef,
+                            gv[slot:slot + 3], out=(stacked[il][0][k], stacked[il][1][k]))
         if spec.sal is not None:
             ip, ineg, slot = spec.sal
             sp, sn = saved["sal"]
-            grads[ip], grads[ineg] = kn.saliency_loss_bwd(
-                sp, sn, spec.sal_label, spec.vmask, spec.pos_idx, spec.neg_idx, float(c.rank_coef),
-                float(c.saliency_margin), gv[slot:slot + 1])
+            if ineg is None:
+                ds = torch.empty(2 * sp.shape[0], sp.shape[1], device=sp.device, dtype=torch.float32)
+                kn.saliency_loss_bwd(sp, sn, spec.sal_label, spec.vmask, spec.pos_idx, spec.neg_idx,
+                                     float(c.rank_coef), float(c.saliency_margin), gv[slot:slot + 1],
+                                     out=(ds[:sp.shape[0]], ds[sp.shape[0]:]))
+                grads[ip] = ds
+            else:
+                grads[ip], grads[ineg] = kn.saliency_loss_bwd(
+                    sp, sn, spec.sal_label, spec.vmask, spec.pos_idx, spec.neg_idx, float(c.rank_coef),
+                    float(c.saliency_margin), gv[slot:slot + 1])
         if spec.recfw is not None:
             il, slot = spec.recfw
             logit, row_lse = saved["recfw"]
@@ -267,8 +291,23 @@ class Criterion(nn.Module):
                    for i, a in enumerate(outputs.get("aux_outputs", []))]
         hidden = set()
         spec.sal = spec.recfw = spec.recss = None
+        # The model hands out per-layer views of the STACKED decoder outputs (model.py:246-258 slices `hs`) and tags
+        # them with their base (`_mesm_stack`): when every layer here is such a view of one base pair, the block takes
+        # the two stacked tensors and writes one stacked gradient instead of autograd's select / stack backward.
+        base = None
+        tags = [(getattr(lg, "_mesm_stack", None), getattr(sp_, "_mesm_stack", None)) for lg, sp_, _ in layers]
+        if all(a is not None and b is not None and a[1] == b[1] for a, b in tags) \
+                and all(a[0] is tags[0][0][0] and b[0] is tags[0][1][0] for a, b in tags) \
+                and len({a[1] for a, _ in tags}) == len(tags):
+            base = (tags[0][0][0], tags[0][1][0])
+            if not (base[0].is_contiguous() and base[1].is_contiguous()):
+                base = None
+        spec.stack_base = base
+        spec.stack_layers = base[0].shape[0] if base is not None else 0
+        base_idx = None
 
         def set_block(logits, spans, suffix):
+            nonlocal base_idx
             slot = len(names)
             block = ["loss_span", "loss_giou", "loss_label", "class_error"]
             names.extend(k + suffix for k in block)
@@ -276,7 +315,12 @@ class Criterion(nn.Module):
                 hidden.update({"loss_span" + suffix, "loss_giou" + suffix})
             if not want_label:
                 hidden.update({"loss_label" + suffix, "class_error" + suffix})
-            spec.set_layers.append((add(logits), add(spans), slot))
+            if base is not None:
+                if base_idx is None:
+                    base_idx = (add(base[0]), add(base[1]))
+                spec.set_layers.append((base_idx[0], base_idx[1], slot, logits._mesm_stack[1]))
+            else:
+                spec.set_layers.append((add(logits), add(spans), slot, None))
 
         if want_span or want_label:
             set_block(*layers[0])
@@ -288,7 +332,13 @@ class Criterion(nn.Module):
                 spec.vmask = vmask.contiguous()
                 spec.pos_idx = targets["pos_idx"].contiguous() if self.use_triplet else None
                 spec.neg_idx = targets["neg_idx"].contiguous() if self.use_triplet else None
-                spec.sal = (add(outputs["saliency_scores"]), add(outputs["neg_saliency_scores"]), len(names))
+                sp_, sn_ = outputs["saliency_scores"], outputs["neg_saliency_scores"]
+                ta, tb = getattr(sp_, "_mesm_stack", None), getattr(sn_, "_mesm_stack", None)
+                if ta is not None and tb is not None and ta[0] is tb[0] and (ta[1], tb[1]) == (0, 1) \
+                        and ta[0].is_contiguous():
+                    spec.sal = (add(ta[0]), None, len(names))  # both passes as the halves of one tensor
+                else:
+                    spec.sal = (add(sp_), add(sn_), len(names))
                 names.append("loss_saliency")
             elif loss == "rec_fw" and is_training:
                 spec.words_label = targets["words_label"].contiguous().view(-1)

@@ -151,6 +151,7 @@ struct LnProb {
   float* dx2;
   LnDrop dr2;
   const float *dyb, *addend;
+  int relu_in;
 };
 constexpr int LN_GROUP_MAX = 8;
 struct LnGroup {
@@ -199,7 +200,7 @@ __device__ __forceinline__ void ln_bwd_body(
     const float* __restrict__ rstd, float* __restrict__ dx, float* __restrict__ dgamma,
     float* __restrict__ dbeta, int64_t rows, int D, int accumulate_dx, LnDrop dr,
     float* __restrict__ dx2, LnDrop dr2, const float* __restrict__ dyb, const float* __restrict__ addend,
-    int bid, int nblk) {
+    int bid, int nblk, int relu_in = 0) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // LNB_WAVES * D when LDS_REDUCE
   const uint32_t dseed = dr.seed + (dr.seed_offset ? *dr.seed_offset : 0u);
   // second output: dx under the dropout mask of the block that PRODUCED the LayerNorm input
@@ -228,13 +229,20 @@ __device__ __forceinline__ void ln_bwd_body(
     const float* xr = x + row * D;
     const float* dyr = dy + row * D;
     float xh[NCH][VEC], dv[NCH][VEC];
+    bool xpos[NCH][VEC];  // x > 0: the ReLU that produced x (relu_in), applied to dx on store
     float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       int col = (c * 64 + lane) * VEC;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) xpos[c][e] = true;
       if (col < D) {
         float xv[VEC];
         ld_vec<VEC>(xr + col, xv);
+        if (relu_in) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) xpos[c][e] = xv[e] > 0.0f;
+        }
         ld_vec<VEC>(dyr + col, dv[c]);
         if (dyb) {  // y had a second consumer (y + pos went to an attention block): its gradient joins here
           float t2[VEC];
@@ -272,6 +280,10 @@ __device__ __forceinline__ void ln_bwd_body(
           ld_vec<VEC>((addend ? addend + row * D : dxr) + col, old);
 #pragma unroll
           for (int e = 0; e < VEC; ++e) o[e] += old[e];
+        }
+        if (relu_in) {  // x = relu(z): hand d z to the producing block (its own mask launch goes away)
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) o[e] = xpos[c][e] ? o[e] : 0.0f;
         }
         st_vec<VEC>(dxr + col, o);
         if (dx2) {
@@ -334,7 +346,7 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_bwd_group_kernel(const LnGroup
   int local, nblk;
   const LnProb q = ln_group_pick(g, local, nblk);
   ln_bwd_body<VEC, NCH, true>(q.dy, q.x, q.gamma, q.mean, q.rstd, q.dx, q.dgamma, q.dbeta, q.rows, q.D, q.accumulate_dx,
-                              q.dr, q.dx2, q.dr2, q.dyb, q.addend, local, nblk);
+                              q.dr, q.dx2, q.dr2, q.dyb, q.addend, local, nblk, q.relu_in);
 }
 
 // Parameter gradients only (dx == NULL: the input needs no gradient, e.g. the LayerNorm over the raw
@@ -523,6 +535,7 @@ LnProb ln_prob(const MesmLnArgs& a) {
   q.dy = a.dy; q.dx = a.dx; q.dgamma = a.dgamma; q.dbeta = a.dbeta; q.accumulate_dx = a.accumulate_dx;
   q.dx2 = a.dx2; q.dr2 = make_drop(a.drop2_p, a.drop2_seed, a.seed_offset);
   q.dyb = a.dyb; q.addend = a.addend;
+  q.relu_in = a.relu_in;
   return q;
 }
 
@@ -581,7 +594,8 @@ extern "C" int mesm_layernorm_bwd_group(const MesmLnArgs* list, int32_t n, void*
   for (int i = 0; i < n && rc == MESM_OK; ++i) {
     const MesmLnArgs& a = list[i];
     if (a.drop_p < 0.f || a.drop_p >= 1.f || a.drop2_p < 0.f || a.drop2_p >= 1.f) return MESM_EINVAL;
-    if (ngroupable >= 2 && ln_group_class(a, true)) {
+    if (a.relu_in && !ln_group_class(a, true)) return MESM_EINVAL;  // the ReLU mask exists on the grouped kernel only
+    if ((ngroupable >= 2 || a.relu_in) && ln_group_class(a, true)) {
       if (!a.dy || !a.x || !a.gamma || !a.mean || !a.rstd || !a.dgamma || !a.dbeta) return MESM_EINVAL;
       int64_t blocks = (a.rows + LNB_WAVES - 1) / LNB_WAVES;
       const int64_t cap = a.rows >= 4000 ? MESM_LNB_CAP : MESM_LNB_CAP / 2;

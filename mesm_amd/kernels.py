@@ -36,6 +36,47 @@ def _seed_off_ptr():
     return _seed_offset.data_ptr() if _seed_offset is not None else None
 
 
+class ZeroPool:
+    """Zero-initialised scratch of one step out of ONE buffer that ONE fill clears when the step begins (MESM._begin):
+    the gradient tensors that kernels accumulate into atomically (dq of an attention backward over several key tiles,
+    token gradients, ...) used to be ~20 `torch.zeros` fill launches per step.  Sizes are learnt on the first step
+    (served by plain torch.zeros, like anything that does not fit later); buffers that were ever handed out stay
+    referenced, so HIP graphs captured against them keep valid addresses when the pool grows."""
+
+    def __init__(self):
+        self.buf, self.off, self.asked, self.retired = None, 0, 0, []
+
+    def begin(self, device):
+        want = self.asked
+        if want > 0 and (self.buf is None or self.buf.numel() < want or self.buf.device != device):
+            if self.buf is not None:
+                self.retired.append(self.buf)
+            self.buf = torch.empty(want + want // 8, device=device, dtype=torch.float32)
+        self.off = self.asked = 0
+        if self.buf is not None:
+            self.buf.zero_()
+
+    def zeros(self, shape, device):
+        n = 1
+        for d_ in shape:
+            n *= int(d_)
+        span = (n + 63) // 64 * 64  # 256-byte granules: every view is aligned for the vector paths
+        self.asked += span
+        if self.buf is not None and self.buf.device == device and self.off + span <= self.buf.numel():
+            v = self.buf[self.off:self.off + n].view(shape)
+            self.off += span
+            return v
+        return torch.zeros(shape, device=device, dtype=torch.float32)
+
+
+zero_pool = ZeroPool()
+
+
+def zeros(shape, device):
+    """fp32 zeros that live until the next step begins (see ZeroPool)"""
+    return zero_pool.zeros(tuple(shape), device)
+
+
 def _mat(t):
     """(rows, cols, ld, layout_if_reduce_is_cols) view info of a 2-D tensor with one unit stride."""
     assert t.dim() == 2
@@ -244,7 +285,7 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5, drop=(0.0, 0), add=None):
 
 
 def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx=None, accumulate_dx=False, need_dx=True,
-                  drop=(0.0, 0), drop2=None, dyb=None, addend=None):
+                  drop=(0.0, 0), drop2=None, dyb=None, addend=None, relu_in=False):
     """dgamma/dbeta are ACCUMULATED into (flat-gradient views).  need_dx=False: parameter
     gradients only (returns None).  drop: the (p, seed) the forward fused; dy is masked on load.
     drop2 = (p, seed): also return dropout(dx; p, seed) as a second tensor -> (dx, dx2).
@@ -256,7 +297,8 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx=None, accumulate_d
     x2 = x.reshape(-1, D)
     dy2 = dy.reshape(-1, D)
     assert x2.is_contiguous() and dy2.is_contiguous()
-    if _phase is not None and need_dx:
+    assert not relu_in or (need_dx and D <= 256)
+    if (_phase is not None or relu_in) and need_dx:
         for t_ in (dyb, addend):
             assert t_ is None or (t_.is_contiguous() and t_.numel() == x2.numel())
         if dx is None:
@@ -276,7 +318,11 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx=None, accumulate_d
             a.dyb = dyb.data_ptr()
         if addend is not None:
             a.addend = addend.data_ptr()
-        _phase.add("ln_bwd", a, (dy2, x2, gamma, mean, rstd, dxv, dgamma, dbeta, dxm, dyb, addend))
+        a.relu_in = 1 if relu_in else 0
+        if _phase is not None:
+            _phase.add("ln_bwd", a, (dy2, x2, gamma, mean, rstd, dxv, dgamma, dbeta, dxm, dyb, addend))
+        else:
+            check(lib().mesm_layernorm_bwd_group(ctypes.byref(a), 1, stream_ptr()), "mesm_layernorm_bwd_group")
         return (dxv.view(x.shape), dxm.view(x.shape)) if drop2 is not None else dxv.view(x.shape)
     if dyb is not None or addend is not None:
         assert need_dx
@@ -457,7 +503,7 @@ def query_sine_bwd(ref, dout):
     D = dout.shape[-1]
     r2 = ref.reshape(-1, 2).contiguous()
     d2 = dout.reshape(-1, D).contiguous()
-    dref = torch.zeros_like(r2)
+    dref = zeros(r2.shape, r2.device)
     check(lib().mesm_query_sine_bwd(ptr(r2), ptr(d2), ptr(dref), r2.shape[0], D, stream_ptr()),
           "mesm_query_sine_bwd")
     return dref.view(ref.shape)
@@ -547,11 +593,12 @@ def saliency_loss_fwd(s_pos, s_neg, label64, vmask, pos_idx, neg_idx, rank_coef,
     return out
 
 
-def saliency_loss_bwd(s_pos, s_neg, label64, vmask, pos_idx, neg_idx, rank_coef, margin, gscale):
+def saliency_loss_bwd(s_pos, s_neg, label64, vmask, pos_idx, neg_idx, rank_coef, margin, gscale, out=None):
+    """out: (ds_pos, ds_neg) to write into (e.g. the two halves of one stacked gradient)"""
     N, L = s_pos.shape
     P = pos_idx.shape[1] if pos_idx is not None else 0
-    ds_pos = torch.empty_like(s_pos)
-    ds_neg = torch.empty_like(s_neg)
+    ds_pos, ds_neg = out if out is not None else (torch.empty_like(s_pos), torch.empty_like(s_neg))
+    assert ds_pos.is_contiguous() and ds_neg.is_contiguous()
     check(lib().mesm_saliency_loss_bwd(ptr(s_pos), ptr(s_neg), ptr(label64), ptr(vmask),
                                        ptr(pos_idx), ptr(neg_idx), N, L, P, float(rank_coef),
                                        float(margin), ptr(gscale), ptr(ds_pos), ptr(ds_neg),
@@ -599,10 +646,11 @@ def set_loss_fwd(logits, spans, tgt_cxw, tgt_xx, tgt_off, Tmax, w_span, w_giou, 
     return match_q
 
 
-def set_loss_bwd(logits, spans, tgt_cxw, tgt_xx, tgt_off, match_q, eos_coef, g3):
+def set_loss_bwd(logits, spans, tgt_cxw, tgt_xx, tgt_off, match_q, eos_coef, g3, out=None):
+    """out: (dlogits, dspans) to write into (e.g. one layer's slice of the stacked decoder outputs' gradient)"""
     N, Q, _ = logits.shape
-    dlogits = torch.empty_like(logits)
-    dspans = torch.empty_like(spans)
+    dlogits, dspans = out if out is not None else (torch.empty_like(logits), torch.empty_like(spans))
+    assert dlogits.is_contiguous() and dspans.is_contiguous()
     check(lib().mesm_set_loss_bwd(ptr(logits), ptr(spans), ptr(tgt_cxw), ptr(tgt_xx), ptr(tgt_off),
                                   ptr(match_q), N, Q, float(eos_coef), ptr(g3), ptr(dlogits),
                                   ptr(dspans), stream_ptr()), "mesm_set_loss_bwd")

@@ -194,6 +194,8 @@ class MESM(nn.Module):
             gb.begin_step()
         self._step += 1
         drop_state.begin(self.training, torch.initial_seed() + self._step)
+        if torch.is_grad_enabled():
+            kn.zero_pool.begin(device)  # ONE fill for every zero-initialised scratch tensor of the step
 
     def _proj(self, seq, x):
         for m in seq:
@@ -548,10 +550,21 @@ class MESM(nn.Module):
             spans = ops.ref_update(sp, refs)  # sigmoid(span_embed(hs) + inverse_sigmoid(refs)), model.py:250
             sal2 = ops.rowdot(sa, sb, 1.0 / float(np.sqrt(d)))
 
-        out.update({"pred_logits": logits[-1], "pred_spans": spans[-1],
-                    "saliency_scores": sal2[:N], "neg_saliency_scores": sal2[N:]})
+        def layer_of(stack, k):
+            # the reference's per-layer tensors, tagged with the stacked tensor they are a view of: the criterion
+            # block then reads the stack itself and returns ONE gradient for it (criterion.py: _mesm_stack)
+            v = stack[k]
+            v._mesm_stack = (stack, k)
+            return v
+
+        nl = logits.shape[0]
+        sal_p, sal_n = sal2[:N], sal2[N:]
+        sal_p._mesm_stack, sal_n._mesm_stack = (sal2, 0), (sal2, 1)
+        out.update({"pred_logits": layer_of(logits, nl - 1), "pred_spans": layer_of(spans, nl - 1),
+                    "saliency_scores": sal_p, "neg_saliency_scores": sal_n})
         if self.aux_loss:
-            out["aux_outputs"] = [{"pred_logits": a, "pred_spans": b} for a, b in zip(logits[:-1], spans[:-1])]
+            out["aux_outputs"] = [{"pred_logits": layer_of(logits, k), "pred_spans": layer_of(spans, k)}
+                                  for k in range(nl - 1)]
 
         if mlm:
             out["recfw_words_logit"] = res2["H"]

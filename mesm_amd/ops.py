@@ -93,6 +93,26 @@ class DropSink:
         self.src = self.dz = None
 
 
+class ReluSink:
+    """Hand-over of the ReLU mask for y = relu(linear(.)): the block that CONSUMES y (a Linear's dX GEMM epilogue, a
+    LayerNorm's backward store) writes its d y already masked by y > 0 and parks the tensor here; the producing
+    block's backward, which receives that same tensor as its gradient, then skips its own mask launch
+    (act_bias_bwd: 16 per step).  Any other dataflow -- y has several consumers, so autograd hands over a sum --
+    fails the identity check and the producer masks as before (masking twice is harmless: the mask is idempotent
+    and linear)."""
+    __slots__ = ("t",)
+
+    def __init__(self):
+        self.t = None
+
+
+def _relu_masked(rsink, dy2):
+    if rsink is not None and rsink.t is not None:
+        t, rsink.t = rsink.t, None
+        return t.data_ptr() == dy2.data_ptr() and t.numel() == dy2.numel()
+    return False
+
+
 def _sink_for(out_drop):
     return DropSink(out_drop) if out_drop[0] > 0 else None
 
@@ -361,8 +381,8 @@ class LinearBlock:
     N_OUT = 1
 
     @staticmethod
-    def fwd(ctx, x, x2, residual, w, b, rows, relu, in_drop, out_drop, sink=None):
-        ctx.sink = sink
+    def fwd(ctx, x, x2, residual, w, b, rows, relu, in_drop, out_drop, sink=None, rsink=None, in_relu=None):
+        ctx.sink, ctx.rsink, ctx.in_relu = sink, rsink, in_relu
         wv, bv = _rows(w, rows), (_rows(b, rows) if b is not None else None)
         x = _c(x)
         x2c = _c(x2) if x2 is not None else None
@@ -388,7 +408,7 @@ class LinearBlock:
         if ctx.out_drop[0] > 0:
             dz = _masked_dy(ctx.sink, dy2, ctx.out_drop)
         elif ctx.relu:
-            dz = kn.act_bias_bwd(dy2, _2d(y), ACT_RELU)
+            dz = dy2 if _relu_masked(ctx.rsink, dy2) else kn.act_bias_bwd(dy2, _2d(y), ACT_RELU)
         else:
             dz = dy2
         gw, wdirect = grad_target(w)
@@ -399,12 +419,17 @@ class LinearBlock:
                   x2=_2d(x2) if x2 is not None else None, b_drop=ctx.in_drop)
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             dx = torch.empty_like(x)
-            kn.gemm(dz, _rows(w, rows), _2d(dx), e_drop=ctx.in_drop)
+            ir = ctx.in_relu if (x2 is None and ctx.in_drop[0] == 0.0) else None
+            if ir is not None:  # x = relu(z) of the previous Linear: write d z (see ReluSink)
+                kn.gemm(dz, _rows(w, rows), _2d(dx), aux=_2d(x), e_actgrad=ACT_RELU)
+                ir.t = dx
+            else:
+                kn.gemm(dz, _rows(w, rows), _2d(dx), e_drop=ctx.in_drop)
         return (dx if ctx.needs_input_grad[0] else None,
                 dx if (x2 is not None and ctx.needs_input_grad[1]) else None,
                 dy if ctx.has_res and ctx.needs_input_grad[2] else None,
                 None if wdirect else gw, None if (b is None or bdirect) else gb,
-                None, None, None, None, None)
+                None, None, None, None, None, None, None)
 
 
 # Test switch (tests/test_model_gpu.py, kink control run): drop every ReLU of the Linear blocks so that the
@@ -417,7 +442,15 @@ def linear_call(x, w, b, *, x2=None, residual=None, rows=None, relu=False, in_dr
     if TEST_NO_RELU:
         relu = False
     sink = _sink_for(out_drop)
-    return Call(LinearBlock, (x, x2, residual, w, b, rows, relu, in_drop, out_drop, sink), lambda y: _tag(y, sink))
+    rsink = ReluSink() if (relu and out_drop[0] == 0.0 and residual is None) else None
+
+    def post(y):
+        if rsink is not None:
+            y._mesm_relu = rsink
+        return _tag(y, sink)
+
+    return Call(LinearBlock, (x, x2, residual, w, b, rows, relu, in_drop, out_drop, sink, rsink,
+                              getattr(x, "_mesm_relu", None)), post)
 
 
 def linear(x, w, b, **kw):
@@ -502,12 +535,13 @@ class LayerNormBlock:
     N_OUT = 1
 
     @staticmethod
-    def fwd(ctx, x, gamma, beta, eps, drop=NO_DROP, sink=None):
+    def fwd(ctx, x, gamma, beta, eps, drop=NO_DROP, sink=None, in_relu=None):
         x = _c(x)
         y, mean, rstd = kn.layernorm_fwd(x, gamma, beta, eps, drop)
         ctx.save_for_backward(x, mean, rstd)
         ctx.gamma, ctx.beta, ctx.drop = gamma, beta, drop
         ctx.sink = sink  # DropSink of the block that produced x (post-norm pattern), or None
+        ctx.in_relu = in_relu if x.shape[-1] <= 256 else None  # ReluSink of the Linear + ReLU that produced x
         return y
 
     @staticmethod
@@ -516,12 +550,16 @@ class LayerNormBlock:
         gg, dg = grad_target(ctx.gamma)
         gb, db = grad_target(ctx.beta)
         sink = ctx.sink if ctx.needs_input_grad[0] else None
+        ir = ctx.in_relu if (ctx.needs_input_grad[0] and sink is None) else None
         dx = kn.layernorm_bwd(_c(dy), x, ctx.gamma, mean, rstd, gg, gb, need_dx=ctx.needs_input_grad[0],
-                              drop=ctx.drop, drop2=(sink.p, sink.seed) if sink is not None else None)
+                              drop=ctx.drop, drop2=(sink.p, sink.seed) if sink is not None else None,
+                              relu_in=ir is not None)
         if sink is not None:
             dx, sink.dz = dx
             sink.src = dx
-        return (dx, None if dg else gg, None if db else gb, None, None, None)
+        if ir is not None:
+            ir.t = dx
+        return (dx, None if dg else gg, None if db else gb, None, None, None, None)
 
 
 class LayerNormPosBlock:
@@ -565,7 +603,8 @@ def layer_norm_call(x, gamma, beta, eps=1e-5, drop=NO_DROP, add=None):
     if add is not None:
         assert drop[0] == 0.0
         return Call(LayerNormPosBlock, (x, gamma, beta, eps, add, getattr(x, "_mesm_sink", None)))
-    return Call(LayerNormBlock, (x, gamma, beta, eps, drop, getattr(x, "_mesm_sink", None)))
+    return Call(LayerNormBlock, (x, gamma, beta, eps, drop, getattr(x, "_mesm_sink", None),
+                                 getattr(x, "_mesm_relu", None)))
 
 
 def layer_norm(x, gamma, beta, eps=1e-5, drop=NO_DROP, add=None):
@@ -717,7 +756,7 @@ class DecSelfAttnFn(Function):
         H, drop = ctx.cfg
         n, nq, d = tgt.shape
         q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
-        dqkv = (torch.zeros if nq > 64 else torch.empty)(n, nq, 3 * d, device=tgt.device, dtype=torch.float32)
+        dqkv = kn.zeros((n, nq, 3 * d), tgt.device) if nq > 64 else torch.empty(n, nq, 3 * d, device=tgt.device, dtype=torch.float32)
         kn.attn_bwd_into(_c(do), q, k, v, o, lse, H, dqkv[..., :d], dqkv[..., d:2 * d], dqkv[..., 2 * d:], drop=drop)
         g2 = _2d(dqkv)
         gwt, _ = grad_target(wt)
@@ -785,7 +824,7 @@ class DecCrossAttnFn(Function):
         dev = tgt.device
         kc, cv, kp = kvp[..., :d], kvp[..., d:2 * d], kvp[..., 2 * d:]
         # several 64-key tiles add into dq atomically: both query halves start from zero (one fill)
-        dq2x = (torch.zeros if lm > 64 else torch.empty)(2, n, nq, d, device=dev, dtype=torch.float32)
+        dq2x = kn.zeros((2, n, nq, d), dev) if lm > 64 else torch.empty(2, n, nq, d, device=dev, dtype=torch.float32)
         dqc, dqs = dq2x[0], dq2x[1]
         dkvp = torch.empty(n, lm, 3 * d, device=dev, dtype=torch.float32)
         kn.attn_bwd_into(_c(do), qc, kc, cv, o, lse, H, dqc, dkvp[..., :d], dkvp[..., d:2 * d], kpad=mem_pad,
@@ -821,6 +860,18 @@ def dec_cross_attn(tgt, qs, qpp, memory, pos, mem_pad, wqc, bqc, wkv, bkv, wkp, 
 
 
 # ----------------------------------------------------------------------------- packed MHA
+class GradShare:
+    """One gradient buffer for a tensor that n blocks of a chain read (the key / value source of every layer of a
+    T2V stack: transformer.py:216-242 hands the same `src_txt` to every layer): each block's dX GEMM accumulates into
+    the buffer through its read-modify-write epilogue, the block whose backward runs LAST (the first layer) returns the
+    total and the others return None -- autograd has no fan-in left to add with element-wise launches.  Only for
+    blocks that all take part in the backward (a chain: layer l + 1 consumes layer l)."""
+    __slots__ = ("n", "buf", "seen")
+
+    def __init__(self, n):
+        self.n, self.buf, self.seen = n, None, 0
+
+
 class MHABlock:
     """A whole nn.MultiheadAttention call plus its residual:
 
@@ -840,9 +891,10 @@ class MHABlock:
 
     @staticmethod
     def fwd(ctx, xq, xqp, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad, qpad, attn_drop,
-            out_drop, self_attn, group=0, sink=None):
+            out_drop, self_attn, group=0, sink=None, kv_share=None):
         ctx.set_materialize_grads(False)
         ctx.sink = sink
+        ctx.kv_share = kv_share
         xq = _c(xq)
         has_p = xqp is not None
         xqp = _c(xqp) if has_p else xq
@@ -914,7 +966,7 @@ class MHABlock:
         dxq = dxqp = dxk = dpk = None
         if self_attn:
             # dq is added atomically only when several 64-key tiles contribute
-            dqkv = (torch.zeros if Lq > 64 else torch.empty)(N, Lq, 3 * d, device=dev, dtype=torch.float32)
+            dqkv = kn.zeros((N, Lq, 3 * d), dev) if Lq > 64 else torch.empty(N, Lq, 3 * d, device=dev, dtype=torch.float32)
             kn.attn_bwd_into(do, q, k, v, o, lse, H, dqkv[..., :d], dqkv[..., d:2 * d],
                              dqkv[..., 2 * d:], kpad=kpad, qpad=qpad, drop=attn_drop, group=group)
             yield
@@ -935,7 +987,7 @@ class MHABlock:
                     kn.gemm(g2, w_in, _2d(dxq), residual=dy2 if fold else None)
         else:
             Lk = k.shape[1]
-            dq = (torch.zeros if Lk > 64 else torch.empty)(N, Lq, d, device=dev, dtype=torch.float32)
+            dq = kn.zeros((N, Lq, d), dev) if Lk > 64 else torch.empty(N, Lq, d, device=dev, dtype=torch.float32)
             dkv = torch.empty(N, Lk, 2 * d, device=dev, dtype=torch.float32)
             kn.attn_bwd_into(do, q, k, v, o, lse, H, dq, dkv[..., :d], dkv[..., d:], kpad=kpad,
                              qpad=qpad, drop=attn_drop, group=group)
@@ -958,7 +1010,15 @@ class MHABlock:
                 dxq = torch.empty_like(xq)
                 kn.gemm(_2d(dq), w_in[:d], _2d(dxq), residual=dy2 if fold else None)
             if need_k or need_pk:
-                if pk is None:
+                share = ctx.kv_share
+                if pk is None and share is not None:
+                    if share.seen == 0:
+                        share.buf = torch.empty_like(xk)
+                    kn.gemm(g2, w_in[d:], _2d(share.buf), accumulate=0 if share.seen == 0 else 1)
+                    share.seen += 1
+                    if share.seen == share.n:  # every reader has added its share
+                        dxk, share.buf, share.seen = share.buf, None, 0
+                elif pk is None:
                     dxk = torch.empty_like(xk)
                     kn.gemm(g2, w_in[d:], _2d(dxk))
                 else:
@@ -972,14 +1032,14 @@ class MHABlock:
                     kn.gemm(g2[:, d:], w_in[2 * d:], _2d(dxk), residual=_2d(dk_in))
         return (dxq, dxqp, dxk, dpk, dy if has_res and ctx.needs_input_grad[4] and not fold else None,
                 None if d_wi else gwi, None if d_bi else gbi, None if d_wo else gwo,
-                None if d_bo else gbo, None, None, None, None, None, None, None, None)
+                None if d_bo else gbo, None, None, None, None, None, None, None, None, None)
 
 
 def mha_call(xq, xqp, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad=None, qpad=None,
-             attn_drop=NO_DROP, out_drop=NO_DROP, self_attn=False, group=0):
+             attn_drop=NO_DROP, out_drop=NO_DROP, self_attn=False, group=0, kv_share=None):
     sink = _sink_for(out_drop)
     return Call(MHABlock, (xq, xqp, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad, qpad, attn_drop,
-                           out_drop, self_attn, group, sink), lambda y: _tag(y, sink))
+                           out_drop, self_attn, group, sink, kv_share), lambda y: _tag(y, sink))
 
 
 def mha(xq, xqp, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad=None, qpad=None,
@@ -1250,7 +1310,7 @@ class TokenMixFn(Function):
                 bufs.append(g)
                 rets.append(None if direct else g)
             else:
-                g = torch.zeros(D, device=dy.device, dtype=torch.float32)
+                g = kn.zeros((D,), dy.device)
                 bufs.append(g)
                 rets.append(g.view(tok.shape))
         kn.token_mix_bwd(dy, ctx.m1, ctx.m2, dx, bufs[0], bufs[1])
