@@ -109,7 +109,11 @@ class GraphedStep:
             # capture_error_mode="thread_local": the process group's watchdog THREAD polls the events of earlier
             # (eager, warm-up) collectives whenever it likes; under the default global mode such a query during
             # our capture is an error that kills the process (seen in ~1 of 3 runs of the 1-rank RCCL test)
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            # captured on the SAME stream the warm-up steps ran on: autograd pins every AccumulateGrad node (kept
+            # alive by gradbuf's hooks) to the stream of its first use, and a capture on another stream records the
+            # hand-over to that stream as a side branch of the graph -- a second hardware queue at replay, which
+            # costs every kernel boundary of the main chain (5.2 -> 5.5 ms per step)
+            with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
                 self.counter.add_(1)
                 self.total, self.losses = self._step_body()
             if dot:

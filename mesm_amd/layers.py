@@ -82,18 +82,36 @@ class MLPHead(nn.Module):
         return x
 
 
+def mlp_heads_steps(pairs, extra=()):
+    """Chain fragment: several independent MLPHeads (head, input) layer by layer, the i-th layers of all heads forked
+    in one round (one grouped launch forward AND backward); `extra`: further independent calls for the first round.
+    -> (outputs of the heads, results of the extra calls)"""
+    xs = [x for _, x in pairs]
+    depth = max(len(h.layers) for h, _ in pairs)
+    ex = []
+    for i in range(depth):
+        calls = []
+        for k, (h, _) in enumerate(pairs):
+            if i < len(h.layers):
+                l = h.layers[i]
+                calls.append(ops.linear_call(xs[k], l.weight, l.bias, relu=i < len(h.layers) - 1))
+            else:
+                calls.append(None)
+        if i == 0:
+            calls += list(extra)
+        res = yield calls
+        for k in range(len(pairs)):
+            if calls[k] is not None:
+                xs[k] = res[k]
+        if i == 0:
+            ex = res[len(pairs):]
+    return xs, ex
+
+
 def mlp_heads_grouped(pairs):
     """Run several independent MLPHeads (head, input) layer by layer, the i-th layers of all heads
     in one grouped GEMM launch."""
-    xs = [x for _, x in pairs]
-    depth = max(len(h.layers) for h, _ in pairs)
-    for i in range(depth):
-        with kn.gemm_group():
-            for k, (h, _) in enumerate(pairs):
-                if i < len(h.layers):
-                    l = h.layers[i]
-                    xs[k] = ops.linear(xs[k], l.weight, l.bias, relu=i < len(h.layers) - 1)
-    return xs
+    return ops.seq(mlp_heads_steps(pairs))[0]
 
 
 class LinearLayer(nn.Module):
@@ -287,29 +305,35 @@ class DecoderLayer(nn.Module):
              "sa_p": ("sa_qpos_proj", "sa_kpos_proj"),
              "ca_kv": ("ca_kcontent_proj", "ca_v_proj")}
 
-    def forward(self, tgt, memory, mem_pad, pos, query_pos, qsine, is_first, pack):
-        """pack(key) -> (weight, bias) views of a parameter pack of THIS layer (MESM.pack)."""
-        L = ops.linear
+    def steps(self, tgt, memory, mem_pad, pos, query_pos, qsine, is_first, pack):
+        """The layer as a chain (ops.lockstep).  pack(key) -> (weight, bias) views of a parameter pack of THIS layer
+        (MESM.pack).  The query-side position projections of the cross attention do not depend on the self-attention
+        block: they fork beside it."""
+        L = ops.linear_call
         h = self.nhead
         wt, bt = pack("sa_t")
         wp, bp = pack("sa_p")
-        a = ops.dec_self_attn(tgt, query_pos, wt, bt, wp, bp, h, drop=drop_state.next(self.p))
+        a, qs, qpp = yield [
+            ops.dec_self_attn_call(tgt, query_pos, wt, bt, wp, bp, h, drop=drop_state.next(self.p)),
+            L(qsine, self.ca_qpos_sine_proj.weight, self.ca_qpos_sine_proj.bias),
+            L(query_pos, self.ca_qpos_proj.weight, self.ca_qpos_proj.bias) if is_first else None]
         so = self.self_attn.out_proj
-        tgt = self.norm1(L(a, so.weight, so.bias, residual=tgt, out_drop=drop_state.next(self.p)))
-
-        with kn.gemm_group():
-            qs = L(qsine, self.ca_qpos_sine_proj.weight, self.ca_qpos_sine_proj.bias)
-            qpp = L(query_pos, self.ca_qpos_proj.weight, self.ca_qpos_proj.bias) if is_first else None
+        x = yield L(a, so.weight, so.bias, residual=tgt, out_drop=drop_state.next(self.p))
+        tgt = yield ops.layer_norm_call(x, self.norm1.weight, self.norm1.bias)
         wkv, bkv = pack("ca_kv")
-        a = ops.dec_cross_attn(tgt, qs, qpp, memory, pos, mem_pad, self.ca_qcontent_proj.weight,
-                               self.ca_qcontent_proj.bias, wkv, bkv, self.ca_kpos_proj.weight,
-                               self.ca_kpos_proj.bias, is_first, h, drop=drop_state.next(self.p))
+        a = yield ops.dec_cross_attn_call(tgt, qs, qpp, memory, pos, mem_pad, self.ca_qcontent_proj.weight,
+                                          self.ca_qcontent_proj.bias, wkv, bkv, self.ca_kpos_proj.weight,
+                                          self.ca_kpos_proj.bias, is_first, h, drop=drop_state.next(self.p))
         co = self.cross_attn.out_proj
-        tgt = self.norm2(L(a, co.weight, co.bias, residual=tgt, out_drop=drop_state.next(self.p)))
-        y = ops.ffn(tgt, tgt, self.linear1.weight, self.linear1.bias, self.activation.weight,
-                    self.linear2.weight, self.linear2.bias, mid_drop=drop_state.next(self.p),
-                    out_drop=drop_state.next(self.p))
-        return self.norm3(y)
+        x = yield L(a, co.weight, co.bias, residual=tgt, out_drop=drop_state.next(self.p))
+        tgt = yield ops.layer_norm_call(x, self.norm2.weight, self.norm2.bias)
+        y = yield ops.ffn_call(tgt, tgt, self.linear1.weight, self.linear1.bias, self.activation.weight,
+                               self.linear2.weight, self.linear2.bias, mid_drop=drop_state.next(self.p),
+                               out_drop=drop_state.next(self.p))
+        return (yield ops.layer_norm_call(y, self.norm3.weight, self.norm3.bias))
+
+    def forward(self, *a, **kw):
+        return ops.seq(self.steps(*a, **kw))
 
 
 def inverse_sigmoid(x, eps=1e-3):
@@ -334,7 +358,10 @@ class Decoder(nn.Module):
         for i in range(1, n):
             self.layers[i].ca_qpos_proj = None
 
-    def forward(self, memory, mem_pad, pos, refpoints_unsigmoid, pack):
+    def steps(self, memory, mem_pad, pos, refpoints_unsigmoid, pack):
+        """The decoder as a chain (ops.lockstep).  What depends on a layer's output only -- the box head, the final norm
+        of that output, and the NEXT layer's anchor / scale heads -- forks into shared rounds; the next layer's
+        reference-point head has to wait for the box head (its sine embedding comes from the refined reference)."""
         n = memory.shape[0]
         nq = refpoints_unsigmoid.shape[0]
         d = self.d_model
@@ -342,24 +369,34 @@ class Decoder(nn.Module):
         refs = [ref]
         out = kn.zeros((n, nq, d), memory.device) if torch.is_grad_enabled() else torch.zeros(n, nq, d, device=memory.device)
         inter = []
+        nl = len(self.layers)
+        # layer 0: anchor head beside the reference-point head (query_scale is 1 on layer 0, transformer.py:366-369)
+        qsine = ops.query_sine(ref, d)
+        (query_pos, anchor), _ = yield from mlp_heads_steps([(self.ref_point_head, qsine), (self.ref_anchor_head, out)])
+        scale = None
         for li, layer in enumerate(self.layers):
-            qsine = ops.query_sine(ref, d)
-            heads = [(self.ref_point_head, qsine), (self.ref_anchor_head, out)]
-            if li > 0:
-                heads.append((self.query_scale, out))
-            res = mlp_heads_grouped(heads)
-            query_pos, anchor = res[0], res[1]
             # qsine * query_scale(out) * (sigmoid(ref_anchor_head(out)) / ref_width): one kernel
-            qsine = ops.qsine_scale(qsine, res[2] if li > 0 else None, anchor, ref)
-            out = layer(out, memory, mem_pad, pos, query_pos, qsine, li == 0,
-                        lambda key, li=li: pack("dec%d.%s" % (li, key)))
+            qsine = ops.qsine_scale(qsine, scale, anchor, ref)
+            out = yield from layer.steps(out, memory, mem_pad, pos, query_pos, qsine, li == 0,
+                                         lambda key, li=li: pack("dec%d.%s" % (li, key)))
+            heads = [(self.bbox_embed, out)]
+            if li + 1 < nl:
+                heads += [(self.ref_anchor_head, out), (self.query_scale, out)]
+            res, ex = yield from mlp_heads_steps(heads, extra=[ops.layer_norm_call(out, self.norm.weight, self.norm.bias)])
+            inter.append(ex[0])
             # sigmoid(bbox_embed(out) + inverse_sigmoid(ref)): one kernel
-            new_ref = ops.ref_update(self.bbox_embed(out), ref)
+            new_ref = ops.ref_update(res[0], ref)
             if li != self.num_layers - 1:
                 refs.append(new_ref)
             ref = new_ref.detach()
-            inter.append(self.norm(out))
+            if li + 1 < nl:
+                anchor, scale = res[1], res[2]
+                qsine = ops.query_sine(ref, d)
+                (query_pos,), _ = yield from mlp_heads_steps([(self.ref_point_head, qsine)])
         return torch.stack(inter), torch.stack(refs)
+
+    def forward(self, *a, **kw):
+        return ops.seq(self.steps(*a, **kw))
 
 
 class Transformer(nn.Module):

@@ -539,14 +539,18 @@ class MESM(nn.Module):
         with _scope("heads"):
             # independent projections share one grouped launch: class head, first span-head layer,
             # and the two saliency projections (model.py:301-302, both passes in one go)
-            l0 = self.span_embed.layers[0]
-            with kn.gemm_group():
-                logits = ops.linear(hs, self.class_embed.weight, self.class_embed.bias)
-                sp = ops.linear(hs, l0.weight, l0.bias, relu=True)
-                sa = ops.linear(memory2, self.saliency_proj1.weight, self.saliency_proj1.bias)
-                sb = ops.linear(memory_g2, self.saliency_proj2.weight, self.saliency_proj2.bias)
-            for i_, l_ in enumerate(self.span_embed.layers[1:], 1):
-                sp = ops.linear(sp, l_.weight, l_.bias, relu=i_ < len(self.span_embed.layers) - 1)
+            def heads_chain():
+                l0 = self.span_embed.layers[0]
+                logits, sp, sa, sb = yield [
+                    ops.linear_call(hs, self.class_embed.weight, self.class_embed.bias),
+                    ops.linear_call(hs, l0.weight, l0.bias, relu=True),
+                    ops.linear_call(memory2, self.saliency_proj1.weight, self.saliency_proj1.bias),
+                    ops.linear_call(memory_g2, self.saliency_proj2.weight, self.saliency_proj2.bias)]
+                for i_, l_ in enumerate(self.span_embed.layers[1:], 1):
+                    sp = yield ops.linear_call(sp, l_.weight, l_.bias, relu=i_ < len(self.span_embed.layers) - 1)
+                return logits, sp, sa, sb
+
+            logits, sp, sa, sb = ops.seq(heads_chain())
             spans = ops.ref_update(sp, refs)  # sigmoid(span_embed(hs) + inverse_sigmoid(refs)), model.py:250
             sal2 = ops.rowdot(sa, sb, 1.0 / float(np.sqrt(d)))
 

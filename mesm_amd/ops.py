@@ -144,6 +144,7 @@ def _masked_dy(sink, dy2, out_drop):
 # the rest of the SS-MESM stack (model.py:184-207, 307-332) -- stop being one serial chain of latency-bound
 # launches: their small problems ride in the launches of the large ones, on the same hardware queue.
 import inspect
+import os
 
 
 def _drive(thunks):
@@ -289,11 +290,14 @@ class Call:
         self.block, self.args, self.post = block, tuple(args), post
 
 
+_SERIAL_PAR = os.environ.get("MESM_SERIAL_PAR") == "1"  # A/B switch: every call of a round as a node of its own
+
+
 def par(calls):
     """Run the calls as ONE autograd node with their launch phases in lockstep; returns one result per call."""
     calls = [c for c in calls]
-    if len(calls) == 1:
-        return [run(calls[0])]
+    if len(calls) == 1 or _SERIAL_PAR:
+        return [run(c) for c in calls]
     spec = tuple((c.block, len(c.args)) for c in calls)
     flat = [a for c in calls for a in c.args]
     outs = ParFn.apply(spec, *flat)
@@ -319,7 +323,8 @@ def ParFn_counts(outs, calls):
 
 def lockstep(chains):
     """Run several CHAINS side by side.  A chain is a generator that yields ops.Call objects one at a time and
-    receives each call's result back (`x = yield ops.linear_call(...)`); `yield None` sits a round out.  Every round
+    receives each call's result back (`x = yield ops.linear_call(...)`); a LIST of calls (entries may be None) forks
+    the chain for one round and comes back as the list of results; `yield None` sits a round out.  Every round
     the calls the chains have just yielded run as ONE autograd node with their launch phases in lockstep (par):
     independent stacks -- enhance beside SS-MESM, MLM beside the rest of SS-MESM, the input projections of every
     modality -- share their launches instead of queueing behind each other.  Returns the chains' return values."""
@@ -337,13 +342,22 @@ def lockstep(chains):
                 continue
             send[i] = None
             nxt.append(i)
-            if c is not None:
+            if isinstance(c, (list, tuple)):  # a chain forks: several independent calls in this round
+                send[i] = [None] * len(c)
+                for j, cj in enumerate(c):
+                    if cj is not None:
+                        calls.append(cj)
+                        who.append((i, j))
+            elif c is not None:
                 calls.append(c)
-                who.append(i)
+                who.append((i, None))
         live = nxt
         if calls:
-            for i, o in zip(who, par(calls)):
-                send[i] = o
+            for (i, j), o in zip(who, par(calls)):
+                if j is None:
+                    send[i] = o
+                else:
+                    send[i][j] = o
     return results
 
 
@@ -722,26 +736,31 @@ def attention(q, k, v, H, kpad=None, qpad=None, scale=None, drop=NO_DROP, q2=Non
 
 
 # ----------------------------------------------------------------------------- decoder attention blocks
-class DecSelfAttnFn(Function):
+class DecSelfAttnBlock:
     """Decoder self-attention up to the attention output (transformer.py:737-750):
 
         q = sa_qcontent(tgt) + sa_qpos(query_pos);  k = sa_kcontent(tgt) + sa_kpos(query_pos);  v = sa_v(tgt)
         a = softmax(q k^T / sqrt(dh)) v
 
     wt / bt = the (3d, d) pack [sa_qcontent ; sa_kcontent ; sa_v], wp / bp = the (2d, d) pack [sa_qpos ; sa_kpos]
-    (gradbuf.Pack: the members sit back to back in the flat buffers).  Forward: ONE GEMM of tgt over wt, one of
-    query_pos over wp accumulated into its first 2d columns.  Backward: the attention gradients land in one
-    (rows, 3d) buffer; d tgt is ONE GEMM with K = 3d, d query_pos one with K = 2d, two weight-gradient GEMMs --
-    a single grouped launch, and no gradient fan-in left for autograd to add."""
+    (gradbuf.Pack: the members sit back to back in the flat buffers).  Forward: the position term and the value
+    projection first (disjoint columns of one (rows, 3d) buffer), then the content projection accumulated onto the
+    position term, then the attention core.  Backward: the attention gradients land in one (rows, 3d) buffer; d tgt is
+    ONE GEMM with K = 3d, d query_pos one with K = 2d, two weight-gradient GEMMs -- a single grouped launch, and no
+    gradient fan-in left for autograd to add."""
+    N_OUT = 1
 
     @staticmethod
-    def forward(ctx, tgt, qpos, wt, bt, wp, bp, H, drop):
+    def fwd(ctx, tgt, qpos, wt, bt, wp, bp, H, drop):
         tgt, qpos = _c(tgt), _c(qpos)
         n, nq, d = tgt.shape
         qkv = torch.empty(n, nq, 3 * d, device=tgt.device, dtype=torch.float32)
         q2 = _2d(qkv)
-        kn.gemm(_2d(tgt), wt, q2, trans_b=True, bias=bt)
-        kn.gemm(_2d(qpos), wp, q2[:, :2 * d], trans_b=True, bias=bp, accumulate=1)
+        kn.gemm(_2d(qpos), wp, q2[:, :2 * d], trans_b=True, bias=bp)
+        kn.gemm(_2d(tgt), wt[2 * d:], q2[:, 2 * d:], trans_b=True, bias=bt[2 * d:])
+        yield
+        kn.gemm(_2d(tgt), wt[:2 * d], q2[:, :2 * d], trans_b=True, bias=bt[:2 * d], accumulate=1)
+        yield
         q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
         o, lse = kn.attn_fwd(q, k, v, H, drop=drop)
         ctx.save_for_backward(tgt, qpos, qkv, o, lse)
@@ -750,7 +769,7 @@ class DecSelfAttnFn(Function):
         return o
 
     @staticmethod
-    def backward(ctx, do):
+    def bwd(ctx, do):
         tgt, qpos, qkv, o, lse = ctx.saved_tensors
         wt, bt, wp, bp = ctx.params
         H, drop = ctx.cfg
@@ -758,30 +777,33 @@ class DecSelfAttnFn(Function):
         q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
         dqkv = kn.zeros((n, nq, 3 * d), tgt.device) if nq > 64 else torch.empty(n, nq, 3 * d, device=tgt.device, dtype=torch.float32)
         kn.attn_bwd_into(_c(do), q, k, v, o, lse, H, dqkv[..., :d], dqkv[..., d:2 * d], dqkv[..., 2 * d:], drop=drop)
+        yield
         g2 = _2d(dqkv)
         gwt, _ = grad_target(wt)
         gbt, _ = grad_target(bt)
         gwp, _ = grad_target(wp)
         gbp, _ = grad_target(bp)
         dtgt = dqp = None
-        with kn.gemm_group():
-            _accum_dw(g2, _2d(tgt), gwt, gbt)
-            _accum_dw(g2[:, :2 * d], _2d(qpos), gwp, gbp)
-            if ctx.needs_input_grad[0]:
-                dtgt = torch.empty_like(tgt)
-                kn.gemm(g2, wt, _2d(dtgt))
-            if ctx.needs_input_grad[1]:
-                dqp = torch.empty_like(qpos)
-                kn.gemm(g2[:, :2 * d], wp, _2d(dqp))
-        flush_ready()
+        _accum_dw(g2, _2d(tgt), gwt, gbt)
+        _accum_dw(g2[:, :2 * d], _2d(qpos), gwp, gbp)
+        if ctx.needs_input_grad[0]:
+            dtgt = torch.empty_like(tgt)
+            kn.gemm(g2, wt, _2d(dtgt))
+        if ctx.needs_input_grad[1]:
+            dqp = torch.empty_like(qpos)
+            kn.gemm(g2[:, :2 * d], wp, _2d(dqp))
         return dtgt, dqp, None, None, None, None, None, None
 
 
+def dec_self_attn_call(tgt, qpos, wt, bt, wp, bp, H, drop=NO_DROP):
+    return Call(DecSelfAttnBlock, (tgt, qpos, wt, bt, wp, bp, H, drop))
+
+
 def dec_self_attn(tgt, qpos, wt, bt, wp, bp, H, drop=NO_DROP):
-    return DecSelfAttnFn.apply(tgt, qpos, wt, bt, wp, bp, H, drop)
+    return run(dec_self_attn_call(tgt, qpos, wt, bt, wp, bp, H, drop))
 
 
-class DecCrossAttnFn(Function):
+class DecCrossAttnBlock:
     """Decoder cross-attention up to the attention output (transformer.py:757-789), conditional-DETR heads:
 
         q_h = [ ca_qcontent(tgt) (+ ca_qpos(query_pos) on layer 0) ]_h || [ ca_qpos_sine(qsine) ]_h
@@ -792,9 +814,10 @@ class DecCrossAttnFn(Function):
     [kcontent | v | kpos] that the attention kernel reads as split heads (k, k2, + k_add on layer 0) in place;
     backward: d memory is ONE GEMM with K = 2d, every weight gradient a split-K GEMM of the same grouped launch;
     layer 0's kpos weights collect both routes by accumulation."""
+    N_OUT = 1
 
     @staticmethod
-    def forward(ctx, tgt, qs, qpp, memory, pos, mem_pad, wqc, bqc, wkv, bkv, wkp, bkp, first, H, drop):
+    def fwd(ctx, tgt, qs, qpp, memory, pos, mem_pad, wqc, bqc, wkv, bkv, wkp, bkp, first, H, drop):
         ctx.set_materialize_grads(False)
         tgt, qs, memory, pos = _c(tgt), _c(qs), _c(memory), _c(pos)
         n, nq, d = tgt.shape
@@ -802,11 +825,11 @@ class DecCrossAttnFn(Function):
         kvp = torch.empty(n, lm, 3 * d, device=tgt.device, dtype=torch.float32)
         k3 = _2d(kvp)
         qc = torch.empty_like(tgt)
-        with kn.gemm_group():
-            kn.gemm(_2d(memory), wkv, k3[:, :2 * d], trans_b=True, bias=bkv)
-            kn.gemm(_2d(pos), wkp, k3[:, 2 * d:], trans_b=True, bias=bkp)
-            kn.gemm(_2d(tgt), wqc, _2d(qc), trans_b=True, bias=bqc,
-                    residual=_2d(_c(qpp)) if (first and qpp is not None) else None)
+        kn.gemm(_2d(memory), wkv, k3[:, :2 * d], trans_b=True, bias=bkv)
+        kn.gemm(_2d(pos), wkp, k3[:, 2 * d:], trans_b=True, bias=bkp)
+        kn.gemm(_2d(tgt), wqc, _2d(qc), trans_b=True, bias=bqc,
+                residual=_2d(_c(qpp)) if (first and qpp is not None) else None)
+        yield
         kc, cv, kp = kvp[..., :d], kvp[..., d:2 * d], kvp[..., 2 * d:]
         o, lse = kn.attn_fwd(qc, kc, cv, H, kpad=mem_pad, drop=drop, q2=qs, k2=kp, k_add=kp if first else None)
         ctx.save_for_backward(tgt, qs, memory, pos, qc, kvp, o, lse)
@@ -815,7 +838,7 @@ class DecCrossAttnFn(Function):
         return o
 
     @staticmethod
-    def backward(ctx, do):
+    def bwd(ctx, do):
         tgt, qs, memory, pos, qc, kvp, o, lse = ctx.saved_tensors
         wqc, bqc, wkv, bkv, wkp, bkp = ctx.params
         first, H, drop, mem_pad, has_qpp = ctx.cfg
@@ -829,6 +852,7 @@ class DecCrossAttnFn(Function):
         dkvp = torch.empty(n, lm, 3 * d, device=dev, dtype=torch.float32)
         kn.attn_bwd_into(_c(do), qc, kc, cv, o, lse, H, dqc, dkvp[..., :d], dkvp[..., d:2 * d], kpad=mem_pad,
                          drop=drop, q2=qs, k2=kp, dq2=dqs, dk2=dkvp[..., 2 * d:], k_add=kp if first else None)
+        yield
         g3 = _2d(dkvp)
         gwqc, _ = grad_target(wqc)
         gbqc, _ = grad_target(bqc)
@@ -837,26 +861,28 @@ class DecCrossAttnFn(Function):
         gwkp, _ = grad_target(wkp)
         gbkp, _ = grad_target(bkp)
         dtgt = dmem = None
-        with kn.gemm_group():
-            _accum_dw(_2d(dqc), _2d(tgt), gwqc, gbqc)
-            _accum_dw(g3[:, :2 * d], _2d(memory), gwkv, gbkv)
-            _accum_dw(g3[:, 2 * d:], _2d(pos), gwkp, gbkp)
-            if first:  # kpos also fed the content half of the keys
-                _accum_dw(g3[:, :d], _2d(pos), gwkp, gbkp)
-            if ctx.needs_input_grad[0]:
-                dtgt = torch.empty_like(tgt)
-                kn.gemm(_2d(dqc), wqc, _2d(dtgt))
-            if ctx.needs_input_grad[3]:
-                dmem = torch.empty_like(memory)
-                kn.gemm(g3[:, :2 * d], wkv, _2d(dmem))
-        flush_ready()
+        _accum_dw(_2d(dqc), _2d(tgt), gwqc, gbqc)
+        _accum_dw(g3[:, :2 * d], _2d(memory), gwkv, gbkv)
+        _accum_dw(g3[:, 2 * d:], _2d(pos), gwkp, gbkp)
+        if first:  # kpos also fed the content half of the keys
+            _accum_dw(g3[:, :d], _2d(pos), gwkp, gbkp)
+        if ctx.needs_input_grad[0]:
+            dtgt = torch.empty_like(tgt)
+            kn.gemm(_2d(dqc), wqc, _2d(dtgt))
+        if ctx.needs_input_grad[3]:
+            dmem = torch.empty_like(memory)
+            kn.gemm(g3[:, :2 * d], wkv, _2d(dmem))
         return (dtgt, dqs if ctx.needs_input_grad[1] else None,
                 dqc if (first and has_qpp and ctx.needs_input_grad[2]) else None, dmem,
                 None, None, None, None, None, None, None, None, None, None, None)
 
 
+def dec_cross_attn_call(tgt, qs, qpp, memory, pos, mem_pad, wqc, bqc, wkv, bkv, wkp, bkp, first, H, drop=NO_DROP):
+    return Call(DecCrossAttnBlock, (tgt, qs, qpp, memory, pos, mem_pad, wqc, bqc, wkv, bkv, wkp, bkp, first, H, drop))
+
+
 def dec_cross_attn(tgt, qs, qpp, memory, pos, mem_pad, wqc, bqc, wkv, bkv, wkp, bkp, first, H, drop=NO_DROP):
-    return DecCrossAttnFn.apply(tgt, qs, qpp, memory, pos, mem_pad, wqc, bqc, wkv, bkv, wkp, bkp, first, H, drop)
+    return run(dec_cross_attn_call(tgt, qs, qpp, memory, pos, mem_pad, wqc, bqc, wkv, bkv, wkp, bkp, first, H, drop))
 
 
 # ----------------------------------------------------------------------------- packed MHA
