@@ -333,6 +333,35 @@ def main():
         except Exception as e:  # never let an informational section take the bench line down
             log("family attribution skipped: %s: %s" % (type(e).__name__, e))
     roofline["families"] = families
+    if families is not None:
+        # SURVEY 8d byte split of C3a (kernel-boundary traffic per step): attention cores 0.45 GB, LayerNorm 0.65 GB;
+        # achieved fraction of the 8 TB/s HBM roofline of those two HBM-bound families, from their in-situ time
+        roofline["attention_hbm_frac"] = 0.45e9 / (families["attention_ms"] * 1e-3) / (PEAK_HBM_TBS * 1e12)
+        roofline["layernorm_hbm_frac"] = 0.65e9 / (families["layernorm_ms"] * 1e-3) / (PEAK_HBM_TBS * 1e12)
+
+    # EXPERIMENTAL, never the headline (value / dtype above are exact f32): the same step with the large GEMMs' products
+    # on v_mfma_f32_32x32x16_bf16 over operands split into bf16 terms (gemm.hip: SplitFrag; MESM_GEMM_BF16X = 6 | 3),
+    # each mode in a child process; `parity` = the GPU parity suite under that mode at unchanged tolerances
+    # (tools/experimental_parity.py, committed under profiles/)
+    if extras and not opt.eager and world == 1 and opt.workload == "C3a" and "MESM_GEMM_BF16X" not in os.environ:
+        exp = {}
+        ppath = os.path.join(ROOT, "profiles", "experimental_parity.json")
+        parity = json.load(open(ppath)) if os.path.exists(ppath) else {}
+        for mode in ("6", "3"):
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", str(opt.steps), "--warmup",
+                                    str(opt.warmup), "--cpu-steps", "0", "--no-extras"],
+                                   env=dict(os.environ, MESM_GEMM_BF16X=mode), capture_output=True, text=True, timeout=300)
+                lj = json.loads(r.stdout.strip().splitlines()[-1])
+                exp["bf16x" + mode] = {"ms_per_step": lj["ms_per_step"], "gemm_tflops": lj["roofline"]["achieved"],
+                                       "gemm_ms_per_step": lj["roofline"].get("gemm_ms_per_step"),
+                                       "parity": parity.get("bf16x" + mode, "not recorded")}
+            except Exception as e:
+                exp["bf16x" + mode] = {"error": "%s: %s" % (type(e).__name__, e)}
+        exp["note"] = ("experimental: GEMMs with >= 2400 output rows or reduce indices through split-bf16 MFMA products "
+                       "(6 = hi*hi+hi*mid+mid*hi+mid*mid+hi*lo+lo*hi, 3 = the first three), operands split in registers; "
+                       "headline value / dtype stay exact f32")
+        roofline["experimental"] = exp
 
     cpu_baseline = None
     if rank == 0 and world == 1 and opt.cpu_steps > 0:
@@ -343,18 +372,23 @@ def main():
         ncores = min(host_cores(), 64)
         torch.set_num_threads(ncores)
         log("cpu baseline on %d threads" % ncores)
-        for _ in range(2):
-            O.train_step(sd, cfg, batch_cpu, neg, masked)  # warm-up
-        log("cpu warm-up done")
-        ts = []
-        for _ in range(opt.cpu_steps):
-            c0 = time.perf_counter()
-            O.train_step(sd, cfg, batch_cpu, neg, masked)
-            ts.append(time.perf_counter() - c0)
+        # TRAIN mode like the GPU leg: every nn.Dropout of the reference active (CPU bernoulli masks)
+        O.DROPOUT = (float(args.dropout), float(args.input_dropout))
+        try:
+            for _ in range(2):
+                O.train_step(sd, cfg, batch_cpu, neg, masked)  # warm-up
+            log("cpu warm-up done")
+            ts = []
+            for _ in range(opt.cpu_steps):
+                c0 = time.perf_counter()
+                O.train_step(sd, cfg, batch_cpu, neg, masked)
+                ts.append(time.perf_counter() - c0)
+        finally:
+            O.DROPOUT = None
         med = sorted(ts)[len(ts) // 2]
         cpu_baseline = {"value": n_pairs / med, "unit": "pairs/s", "cores": ncores, "kind": "port",
-                        "sample": "median of %d fwd+bwd steps (after 2 warm-up) of %s (%d pairs each), dropout "
-                                  "off, torch-CPU fp32" % (opt.cpu_steps, opt.workload, n_pairs)}
+                        "sample": "median of %d fwd+bwd steps (after 2 warm-up) of %s (%d pairs each), train mode "
+                                  "(dropout on), torch-CPU fp32" % (opt.cpu_steps, opt.workload, n_pairs)}
 
     if rank == 0:
         line = {

@@ -1334,6 +1334,58 @@ bool wstage_ok(const MesmGemmArgs& a) {
   return ok(a.a_layout, a.M) && ok(a.b_layout, a.N);
 }
 
+// EXPERIMENTAL split-precision path (never the default, never the benchmark's headline): the products of a stage
+// on v_mfma_f32_32x32x16_bf16 (16x the f32 MFMA rate) with every f32 operand value split exactly into bf16 terms
+// x = hi + mid + lo (8 mantissa bits each; hi and mid by truncation, so x - hi and x - hi - mid are exact f32
+// subtractions) and the significant cross products accumulated in f32:
+//   BF = 6: hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi   (error ~2^-24 of |a||b|, the f32 product's own)
+//   BF = 3: hi*hi + hi*mid + mid*hi                              (error ~2^-16)
+// Selected at run time by MESM_GEMM_BF16X=6|3 (bench.py reports both under roofline.experimental with the parity
+// suite's verdict at unchanged tolerances); the split is done on the fragment registers (~6 VALU per value).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int BF>
+struct SplitFrag {
+  u32x4 hi[2], mid[2], lo[2];  // [bf16 k-step of 16][4 dwords = 8 bf16]
+  // v[s][j] = operand[outer][kb + 8 s + 4 h + j]: k-step t takes s = 2t, 2t + 1 (the same slot map on both operands)
+  __device__ __forceinline__ void make(const float (&v)[4][4]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float x0 = v[2 * t + (i >> 1)][2 * (i & 1)], x1 = v[2 * t + (i >> 1)][2 * (i & 1) + 1];
+        const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+        hi[t][i] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+        const float r0 = x0 - __uint_as_float(u0 & 0xFFFF0000u), r1 = x1 - __uint_as_float(u1 & 0xFFFF0000u);
+        const unsigned m0 = __float_as_uint(r0), m1 = __float_as_uint(r1);
+        mid[t][i] = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
+        if (BF == 6) {
+          const float q0 = r0 - __uint_as_float(m0 & 0xFFFF0000u), q1 = r1 - __uint_as_float(m1 & 0xFFFF0000u);
+          lo[t][i] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
+        }
+      }
+  }
+};
+
+template <int BF>
+__device__ __forceinline__ f32x16 split_mma(const SplitFrag<BF>& a, const SplitFrag<BF>& b, f32x16 acc) {
+#define MESM_BF(x) __builtin_bit_cast(bf16x8, x)
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    if (BF == 6) {  // smallest terms first
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MESM_BF(a.lo[t]), MESM_BF(b.hi[t]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MESM_BF(a.hi[t]), MESM_BF(b.lo[t]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MESM_BF(a.mid[t]), MESM_BF(b.mid[t]), acc, 0, 0, 0);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MESM_BF(a.mid[t]), MESM_BF(b.hi[t]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MESM_BF(a.hi[t]), MESM_BF(b.mid[t]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MESM_BF(a.hi[t]), MESM_BF(b.hi[t]), acc, 0, 0, 0);
+  }
+#undef MESM_BF
+  return acc;
+}
+
 // ------------------------------------------------------------------------------------------------
 // "wstage64": the k-split idea on a 64 x 64 tile.  Each of the four waves computes the WHOLE tile
 // (2 x 2 accumulators) over its quarter of the reduce range, staged wave-privately by LDS-DMA like
@@ -1342,7 +1394,7 @@ bool wstage_ok(const MesmGemmArgs& a) {
 // stage's loads: a single LDS buffer per wave suffices, because all fragments of a stage are in
 // registers before its refill is issued.  Used when the problem has enough 64 x 64 tiles to occupy
 // the chip (the 2400- and 4800-row d x d GEMMs, the split-K weight gradients).
-template <int LA, int LB, bool XF>
+template <int LA, int LB, bool XF, int BF = 0>
 __device__ __forceinline__ void wstage64_body(const MesmGemmArgs& p, const Blk blk, float* L) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -1445,15 +1497,28 @@ __device__ __forceinline__ void wstage64_body(const MesmGemmArgs& p, const Blk b
             b[t][s_][j] = y;
           }
     }
+    if (BF > 0) {
+      SplitFrag<BF> sa[2], sb[2];
 #pragma unroll
-    for (int s_ = 0; s_ < 4; ++s_)
+      for (int t = 0; t < 2; ++t) {
+        sa[t].make(a[t]);
+        sb[t].make(b[t]);
+      }
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
+        for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = split_mma<BF>(sa[ti], sb[tj], acc[ti][tj]);
+    } else {
 #pragma unroll
-          for (int tj = 0; tj < 2; ++tj)
-            acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti][s_][j], b[tj][s_][j], acc[ti][tj], 0, 0, 0);
+      for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+              acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ti][s_][j], b[tj][s_][j], acc[ti][tj], 0, 0, 0);
+    }
     if (do_colsum) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -1501,20 +1566,30 @@ __device__ __forceinline__ void wstage64_body(const MesmGemmArgs& p, const Blk b
   L64_STAMP(30);
 }
 
-template <int LA, int LB, bool XF>
+template <int LA, int LB, bool XF, int BF = 0>
 __global__ __launch_bounds__(NTHREADS) void gemm_wstage64_kernel(const MesmGemmArgs p) {
   __shared__ __attribute__((aligned(16))) float L[4 * 4 * WS_SLAB];  // 4 waves x 4 slabs = 64 KB
   Blk blk;
   xcd_tile(blockIdx.x, (p.M + 63) / 64, (p.N + 63) / 64, blk.x, blk.y);
   blk.z = blockIdx.z; blk.slot = linear_block();
-  wstage64_body<LA, LB, XF>(p, blk, L);
+  wstage64_body<LA, LB, XF, BF>(p, blk, L);
+}
+
+// MESM_GEMM_BF16X = 6 | 3: the experimental split-bf16 products (see SplitFrag); 0 / unset = exact f32
+inline int bf16x_mode() {
+  const char* e = getenv("MESM_GEMM_BF16X");
+  const int m = e ? atoi(e) : 0;
+  return (m == 3 || m == 6) ? m : 0;
 }
 
 template <int LA, int LB>
 int launch_wstage64_l(const MesmGemmArgs& a, hipStream_t s) {
   dim3 grid(((a.M + 63) / 64) * ((a.N + 63) / 64), 1, a.split_k > 1 ? a.split_k : 1);  // 1-D: xcd_tile() maps it
   const bool xf = a.a_act != MESM_ACT_NONE || a.b_act != MESM_ACT_NONE || a.a_drop_p > 0.f || a.b_drop_p > 0.f;
-  if (xf) hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, true>), grid, dim3(NTHREADS), 0, s, a);
+  const int bf = xf ? 0 : bf16x_mode();
+  if (bf == 6) hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, false, 6>), grid, dim3(NTHREADS), 0, s, a);
+  else if (bf == 3) hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, false, 3>), grid, dim3(NTHREADS), 0, s, a);
+  else if (xf) hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, true>), grid, dim3(NTHREADS), 0, s, a);
   else hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, false>), grid, dim3(NTHREADS), 0, s, a);
   const int rc = mesm_launch_status();
   return rc != MESM_OK ? rc : dslope_finish(a, grid, s);
@@ -2047,6 +2122,12 @@ int dispatch(const MesmGemmArgs& a, int vec, hipStream_t s) {
       if ((force == 6 || (force == 0 && z == 1 && a.K >= 512 && t96 >= 160 && t96 <= 256)) && wtall_ok(a))
         return launch_wtall<3>(a, s);
     }
+    // experimental split-bf16 mode: the 64 x 64-per-wave kernel is the one that carries it (the split costs VALU per
+    // fragment value, amortised over four products there) -- every problem of >= 2400 output rows or reduce indices
+    // with enough tiles goes there, whatever its round count
+    if (force == 0 && bf16x_mode() != 0 && wstage_ok(a) && b64 >= 128 && (a.M >= 2400 || a.K >= 2400) &&
+        a.a_act == MESM_ACT_NONE && a.b_act == MESM_ACT_NONE && a.a_drop_p == 0.f && a.b_drop_p == 0.f)
+      return launch_wstage64(a, s);
     if ((force == 3 || (force == 0 && b64 >= 512)) && wstage_ok(a)) return launch_lds64(a, s);
     // k-split 64 x 64 (half the L2 traffic per flop): wins only when its workgroups fit ONE round on the
     // 256 CUs (300 workgroups = two rounds: 4800 x 256 x 1024 59 us vs 43 us with 32 x 32 tiles) and a
@@ -2106,6 +2187,9 @@ bool groupable(const MesmGemmArgs& a) {
   const char* env = getenv("MESM_GEMM_TILE");
   const int force = env ? atoi(env) : 0;
   if (force != 0 && force != 2) return false;
+  if (force == 0 && bf16x_mode() != 0 && (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * (a.split_k > 1 ? a.split_k : 1) >= 128 &&
+      (a.M >= 2400 || a.K >= 2400))
+    return false;  // experimental mode: goes to the split-bf16 kernel on its own
   const long z = a.split_k > 1 ? a.split_k : 1;
   const long b64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * z;
   const long kper = ((a.K + z - 1) / z + 3) / 4;

@@ -58,6 +58,18 @@ def _l2norm(x, eps):
 NO_RELU = False
 
 
+# Train-mode dropout (bench.py's cpu_baseline times the step the way SURVEY.md 8d prescribes: dropout ON, like the
+# GPU leg).  None = off (every parity check: a CPU mask stream cannot match the GPU's counter hash anyway);
+# (p, p_input) = nn.Dropout(p) at the reference's transformer sites, nn.Dropout(p_input) inside LinearLayer.
+DROPOUT = None
+
+
+def _drop(x, which=0):
+    if DROPOUT is None or DROPOUT[which] <= 0.0:
+        return x
+    return torch.nn.functional.dropout(x, DROPOUT[which], training=True)
+
+
 def _relu(x):
     return x if NO_RELU else torch.relu(x)
 
@@ -65,7 +77,7 @@ def _relu(x):
 def linear_layer_stack(x, sd, prefix, n, relu_flags):
     """nn.Sequential of LinearLayer (model.py:412-434): LN -> [dropout] -> Linear -> [ReLU]."""
     for i in range(n):
-        x = _ln(x, sd, "%s.%d.LayerNorm" % (prefix, i))
+        x = _drop(_ln(x, sd, "%s.%d.LayerNorm" % (prefix, i)), 1)  # model.py:421-431
         x = _lin(x, sd, "%s.%d.net.1" % (prefix, i))
         if relu_flags[i]:
             x = _relu(x)
@@ -153,7 +165,7 @@ def attention_core(q, k, v, h, masked, scale):
     s = torch.einsum("nhqd,nhkd->nhqk", _heads(q, h) * scale, _heads(k, h))
     if masked is not None:
         s = s.masked_fill(masked, float("-inf"))
-    p = torch.softmax(s, -1)
+    p = _drop(torch.softmax(s, -1))  # attention-probability dropout (nn.MultiheadAttention / attention.py:382)
     o = torch.einsum("nhqk,nhkd->nhqd", p, _heads(v, h))
     return o.transpose(1, 2).reshape(q.shape[0], q.shape[1], -1)
 
@@ -184,12 +196,12 @@ def t2v_layer(txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, sd, prefix, h, mlm=F
     q = vid if pos_vid is None else vid + pos_vid
     k = txt if pos_txt is None else txt + pos_txt
     masked = t2v_mask(vid_pad, txt_pad, h)
-    x = vid + mha_packed(q, k, txt, sd, prefix + ".self_attn", h, masked)
+    x = vid + _drop(mha_packed(q, k, txt, sd, prefix + ".self_attn", h, masked))
     sfx = "_1" if mlm else ""
     y = _ln(x, sd, prefix + ".norm1" + sfx)
-    y = _lin(_prelu(_lin(y, sd, prefix + ".linear1" + sfx), sd[prefix + ".activation.weight"]),
+    y = _lin(_drop(_prelu(_lin(y, sd, prefix + ".linear1" + sfx), sd[prefix + ".activation.weight"])),
              sd, prefix + ".linear2" + sfx)
-    return _ln(x + y, sd, prefix + ".norm2" + sfx)
+    return _ln(x + _drop(y), sd, prefix + ".norm2" + sfx)
 
 
 def t2v_stack(txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, sd, prefix, nlayers, h, mlm=False):
@@ -202,11 +214,11 @@ def t2v_stack(txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, sd, prefix, nlayers,
 def encoder_layer(x, pos, pad, sd, prefix, h):
     """TransformerEncoderLayer.forward_post (transformer.py:637-650)."""
     qk = x + pos
-    x = _ln(x + mha_packed(qk, qk, x, sd, prefix + ".self_attn", h, pad[:, None, None, :]),
+    x = _ln(x + _drop(mha_packed(qk, qk, x, sd, prefix + ".self_attn", h, pad[:, None, None, :])),
             sd, prefix + ".norm1")
-    y = _lin(_prelu(_lin(x, sd, prefix + ".linear1"), sd[prefix + ".activation.weight"]),
+    y = _lin(_drop(_prelu(_lin(x, sd, prefix + ".linear1"), sd[prefix + ".activation.weight"])),
              sd, prefix + ".linear2")
-    return _ln(x + y, sd, prefix + ".norm2")
+    return _ln(x + _drop(y), sd, prefix + ".norm2")
 
 
 def decoder_layer(tgt, memory, mem_pad, pos, query_pos, qsine, sd, prefix, h, first):
@@ -217,7 +229,7 @@ def decoder_layer(tgt, memory, mem_pad, pos, query_pos, qsine, sd, prefix, h, fi
     k = _lin(tgt, sd, prefix + ".sa_kcontent_proj") + _lin(query_pos, sd, prefix + ".sa_kpos_proj")
     v = _lin(tgt, sd, prefix + ".sa_v_proj")
     sa = _lin(attention_core(q, k, v, h, None, (d // h) ** -0.5), sd, prefix + ".self_attn.out_proj")
-    tgt = _ln(tgt + sa, sd, prefix + ".norm1")
+    tgt = _ln(tgt + _drop(sa), sd, prefix + ".norm1")
 
     qc = _lin(tgt, sd, prefix + ".ca_qcontent_proj")
     kc = _lin(memory, sd, prefix + ".ca_kcontent_proj")
@@ -233,10 +245,10 @@ def decoder_layer(tgt, memory, mem_pad, pos, query_pos, qsine, sd, prefix, h, fi
     q2 = torch.cat([qc.view(n, nq, h, dh), qs.view(n, nq, h, dh)], -1).reshape(n, nq, 2 * d)
     k2 = torch.cat([kc.view(n, lm, h, dh), kp.view(n, lm, h, dh)], -1).reshape(n, lm, 2 * d)
     ca = attention_core(q2, k2, v, h, mem_pad[:, None, None, :], (2 * d // h) ** -0.5)
-    tgt = _ln(tgt + _lin(ca, sd, prefix + ".cross_attn.out_proj"), sd, prefix + ".norm2")
-    y = _lin(_prelu(_lin(tgt, sd, prefix + ".linear1"), sd[prefix + ".activation.weight"]),
+    tgt = _ln(tgt + _drop(_lin(ca, sd, prefix + ".cross_attn.out_proj")), sd, prefix + ".norm2")
+    y = _lin(_drop(_prelu(_lin(tgt, sd, prefix + ".linear1"), sd[prefix + ".activation.weight"])),
              sd, prefix + ".linear2")
-    return _ln(tgt + y, sd, prefix + ".norm3")
+    return _ln(tgt + _drop(y), sd, prefix + ".norm3")
 
 
 def detr_transformer(src, vid_mask, pos, sd, cfg, run_decoder=True):
