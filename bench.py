@@ -7,7 +7,7 @@
 
 A step = model(**batch) -> criterion(outputs, batch) -> zero_grad -> total.backward()
 [-> gradient all-reduce of the flat buffer for N > 1: one blocking all-reduce on the compute stream after the
-graph replay by default, MESM_DDP_MODE=captured for the bucketed all-reduce overlapped inside the graph], in
+this library's own RCCL communicator recorded inside the step graph, form chosen by a start-up probe; see MESM_DDP_MODE], in
 TRAIN mode (all dropouts active), on the QVHighlights C+SF workload "C3a" of SURVEY.md 8d (32 pairs per
 GPU, Lv=75, Lw=32, Dv=2818, Dt=512, C=5003, fp32).  Inputs are resident in HBM before the timed
 region; the host-side draws of the reference (negative query index, MLM word choice) are re-drawn
@@ -159,43 +159,94 @@ def main():
     else:
         # one HIP graph per step: forward + criterion + backward; fresh host draws + dropout masks every replay.
         # N > 1, MESM_DDP_MODE =
-        #   after (default): ONE blocking all-reduce of the flat gradient buffer on the COMPUTE stream right after
-        #                    the replay -- nothing of the process group is ever captured (robust), no second
-        #                    hardware queue is active (none of its ~0.5 ms toll on the step),
-        #                    the wire time is exposed;
-        #   captured:        the bucket all-reduces recorded INSIDE the graph on the collective stream (bucket k
-        #                    reduces while backward continues); pays the second-queue toll, and the 1-rank capture
-        #                    test aborted in ~3 % of process starts (watchdog thread vs. captured events);
-        #   inline:          one blocking all-reduce captured at the end of the graph on the capture stream;
-        #   after-async:     the round-1 form (asynchronous collectives on the process group's stream after the replay).
+        #   auto (default):  this library's OWN RCCL communicator (csrc/ddp.hip; no process-group watchdog next to the
+        #                    captured collectives), the 1 / N of the gradient mean folded into the loss gradient, and a
+        #                    start-up PROBE (before the timed region) of the two captured forms -- `own-inline`: one
+        #                    all-reduce of the flat buffer recorded at the end of the step graph on the compute stream
+        #                    (one queue, wire time exposed); `own-overlapped`: six buckets recorded on the
+        #                    communicator's stream from inside backward (wire time hidden, a second hardware queue is
+        #                    active: DESIGN.md section 5) -- keeps the faster one (max over ranks);
+        #   own-inline / own-overlapped: that form without the probe;
+        #   after:           torch.distributed: ONE blocking all-reduce on the compute stream after the graph replay
+        #                    (nothing captured; the round-2 default);  captured / inline / after-async: the torch
+        #                    process-group forms of round 2.
         gstep, reducer, post = None, None, False
-        mode = os.environ.get("MESM_DDP_MODE", "after")
-        if world > 1 and mode in ("captured", "inline"):
+        mode = os.environ.get("MESM_DDP_MODE", "auto")
+        force_ddp = os.environ.get("MESM_BENCH_FORCE_DDP") == "1"  # exercise the N > 1 code on one GPU (1-rank groups)
+        ddp_on = world > 1 or force_ddp
+        if ddp_on and mode in ("auto", "own-inline", "own-overlapped"):
+            from mesm_amd.ddp import RcclComm
+            ok, comm, cands = 1, None, {}
+            try:
+                comm = RcclComm(dev)
+                for c in (["own-inline", "own-overlapped"] if mode == "auto" else [mode]):
+                    inl = c == "own-inline"
+                    red = GradReducer(model.gradbuf(), hook=True, inline=inl, n_buckets=1 if inl else 6, comm=comm,
+                                      fold_scale=True, force=force_ddp)
+                    gs = GraphedStep(model, crit, batch, args.dataset_name, reducer=red)
+                    cands[c] = (gs, red)
+            except Exception as e:
+                log("own-communicator capture failed on this rank (%s: %s)" % (type(e).__name__, e))
+                ok = 0
+            if world > 1:  # every rank has to agree before anything else is issued (ADVICE: no asymmetric fallback)
+                flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+            if not ok:
+                raise SystemExit("bench: the captured data-parallel step could not be built on every rank; "
+                                 "restart with MESM_DDP_MODE=after")
+            probe = {}
+            for c, (gs, red) in cands.items():
+                for _ in range(2):
+                    gs.run(redraw=False)
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                p0 = time.perf_counter()
+                for _ in range(5):
+                    gs.run(redraw=False)
+                torch.cuda.synchronize()
+                pt = torch.tensor([(time.perf_counter() - p0) / 5 * 1e3], device=dev, dtype=torch.float64)
+                if world > 1:
+                    dist.all_reduce(pt, op=dist.ReduceOp.MAX)
+                probe[c] = float(pt.item())
+            best = min(probe, key=probe.get)
+            gstep, reducer = cands[best]
+            cands.clear()
+            what = {"own-inline": "one all-reduce of the flat gradient buffer recorded at the end of the step graph on the "
+                                  "compute stream (one queue, wire time exposed)",
+                    "own-overlapped": "six bucket all-reduces recorded inside the step graph on the communicator's own "
+                                      "stream, overlapped with backward"}[best]
+            ddp_mode = ("own RCCL communicator (mesm_ddp_*), 1/N folded into the loss gradient; %s; start-up probe, ms/step "
+                        "max over ranks: %s -> %s%s"
+                        % (what, ", ".join("%s %.3f" % kv for kv in sorted(probe.items())), best,
+                           "" if mode == "auto" else " (forced by MESM_DDP_MODE)"))
+        elif ddp_on and mode in ("captured", "inline"):
             ok = 1
             try:
                 reducer = GradReducer(model.gradbuf(), hook=True, inline=mode == "inline",
                                       n_buckets=1 if mode == "inline" else 6)
                 gstep = GraphedStep(model, crit, batch, args.dataset_name, reducer=reducer)
-                ddp_mode = ("one all-reduce captured in line at the end of the step graph (no second queue, no overlap)"
+                ddp_mode = ("torch process group: one all-reduce captured in line at the end of the step graph"
                             if mode == "inline" else
-                            "bucketed all-reduce captured in the step graph, overlapped with backward")
-            except Exception as e:  # capture of collectives refused by the runtime: reduce after the replay
-                log("captured all-reduce failed (%s: %s); falling back to reduce-after-replay" % (type(e).__name__, e))
+                            "torch process group: bucketed all-reduce captured in the step graph, overlapped with backward")
+            except Exception as e:
+                log("captured all-reduce failed (%s: %s)" % (type(e).__name__, e))
                 ok = 0
             flag = torch.tensor([ok], device=dev, dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 0:
-                model.gradbuf().on_ready = None
-                gstep = reducer = None
+                raise SystemExit("bench: the captured collectives could not be built on every rank; restart with "
+                                 "MESM_DDP_MODE=after")
         if gstep is None:
             gstep = GraphedStep(model, crit, batch, args.dataset_name)
-            if world > 1:
+            if ddp_on:
                 blocking = mode != "after-async"
                 reducer = GradReducer(model.gradbuf(), hook=False, inline=blocking, n_buckets=1 if blocking else 6)
                 post = True
-                ddp_mode = ("one blocking all-reduce of the flat buffer on the compute stream after the graph replay"
-                            if blocking else
-                            "asynchronous all-reduces on the collective stream after the graph replay")
+                ddp_mode = ("torch process group: one blocking all-reduce of the flat buffer on the compute stream after "
+                            "the graph replay" if blocking else
+                            "torch process group: asynchronous all-reduces on the collective stream after the graph replay")
         log("step captured in a HIP graph")
 
         def step():

@@ -645,6 +645,24 @@ int mesm_adamw_step(float* p, const float* g, float* m, float* v, const uint8_t*
                     float beta2, float eps, float weight_decay, const int32_t* step, float* norm_out,
                     void* stream);
 
+/* ------------------------------------------------------------------------- */
+/*
+ * Data-parallel gradient exchange over RCCL, owned by this library (new functionality: the reference is
+ * single-process; insertion point train.py:68-72, between loss.backward() and clip_grad_norm_).  One process per
+ * GPU.  Rank 0 draws the 128-byte unique id (mesm_ddp_unique_id) and hands it to the other ranks through any side
+ * channel (mesm_amd.ddp uses the torch.distributed store); every rank then calls mesm_ddp_init.
+ * mesm_ddp_allreduce sums buf[0, count) (fp32, in place) over the ranks: side = 0 on `stream` itself, side = 1 on the
+ * communicator's own stream behind everything enqueued on `stream` so far (overlap with the rest of backward);
+ * mesm_ddp_wait makes `stream` wait for the collectives issued with side = 1.  All three record into a HIP graph when
+ * `stream` is capturing.  RCCL is bound at run time (dlopen of librccl.so.1); mesm_ddp_last_error() names a failure.
+ */
+int mesm_ddp_unique_id(uint8_t* out128);
+int mesm_ddp_init(const uint8_t* id128, int32_t rank, int32_t world, void** handle);
+int mesm_ddp_allreduce(void* handle, float* buf, int64_t count, void* stream, int32_t side);
+int mesm_ddp_wait(void* handle, void* stream);
+int mesm_ddp_destroy(void* handle);
+const char* mesm_ddp_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

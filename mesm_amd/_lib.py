@@ -145,6 +145,12 @@ PROTOTYPES = {
                                      _i32, _i32, _i32, _i32, c_ptr]),
     "mesm_text_pool": (ctypes.c_int, [c_ptr, _i32, c_ptr, _i32, _i32, _i32, _i32, _i32, _i32, c_ptr, c_ptr, c_ptr]),
     "mesm_embed_rows": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, _i64, _i32, _i32, c_ptr]),
+    "mesm_ddp_unique_id": (ctypes.c_int, [c_ptr]),
+    "mesm_ddp_init": (ctypes.c_int, [c_ptr, _i32, _i32, ctypes.POINTER(ctypes.c_void_p)]),
+    "mesm_ddp_allreduce": (ctypes.c_int, [c_ptr, c_ptr, _i64, c_ptr, _i32]),
+    "mesm_ddp_wait": (ctypes.c_int, [c_ptr, c_ptr]),
+    "mesm_ddp_destroy": (ctypes.c_int, [c_ptr]),
+    "mesm_ddp_last_error": (ctypes.c_char_p, []),
     "mesm_weighted_sum": (ctypes.c_int, [c_ptr, c_ptr, _i32, c_ptr, c_ptr]),
     "mesm_scale_vec": (ctypes.c_int, [c_ptr, c_ptr, _i32, c_ptr, c_ptr]),
 }

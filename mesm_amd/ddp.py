@@ -60,8 +60,51 @@ def shard_groups(batch, rank, world, min_groups=2):
     return out
 
 
+class RcclComm:
+    """This library's OWN RCCL communicator (csrc/ddp.hip: mesm_ddp_*): collectives issued as raw ncclAllReduce on
+    HIP streams the library picks.  torch.distributed is only the rendezvous (rank 0's 128-byte unique id travels
+    through its object broadcast); no process-group watchdog ever sees these collectives, so recording them into the
+    step's HIP graph is safe (the torch process group aborted ~3 % of process starts doing that).
+    Without an initialised process group: a 1-rank communicator (tests on one GPU)."""
+
+    def __init__(self, device, process_group=None):
+        import ctypes
+        from . import _lib
+        self._lib, self._ct = _lib, ctypes
+        L = _lib.lib()
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        torch.cuda.set_device(device)
+        torch.zeros(1, device=device)  # the HIP context of this device exists before RCCL looks for it
+        buf = (ctypes.c_uint8 * 128)()
+        if self.rank == 0:
+            self._check(L.mesm_ddp_unique_id(buf), "mesm_ddp_unique_id")
+        if self.world > 1:
+            box = [bytes(buf)]
+            dist.broadcast_object_list(box, src=0, group=process_group, device=device)
+            buf = (ctypes.c_uint8 * 128)(*box[0])
+        h = ctypes.c_void_p()
+        self._check(L.mesm_ddp_init(buf, self.rank, self.world, ctypes.byref(h)), "mesm_ddp_init")
+        self.handle = h
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise self._lib.MesmError("%s failed with status %d: %s"
+                                      % (what, rc, self._lib.lib().mesm_ddp_last_error().decode(errors="replace")))
+
+    def allreduce(self, t, side):
+        """in-place sum of a contiguous fp32 tensor; side: on the communicator's own stream behind the current one"""
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        self._check(self._lib.lib().mesm_ddp_allreduce(self.handle, self._ct.c_void_p(t.data_ptr()), t.numel(),
+                                                       self._lib.stream_ptr(), 1 if side else 0), "mesm_ddp_allreduce")
+
+    def wait(self):
+        self._check(self._lib.lib().mesm_ddp_wait(self.handle, self._lib.stream_ptr()), "mesm_ddp_wait")
+
+
 class GradReducer:
-    def __init__(self, gradbuf, process_group=None, n_buckets=6, hook=True, force=False, inline=False):
+    def __init__(self, gradbuf, process_group=None, n_buckets=6, hook=True, force=False, inline=False, comm=None,
+                 fold_scale=False):
         """force: issue the collectives even in a 1-rank group (exercises the RCCL / capture path on one GPU)
         inline: blocking collectives (async_op=False), which this torch issues on the CURRENT stream: under graph
         capture the step stays ONE linear chain -- no second hardware queue, hence none of the ~1 us per kernel
@@ -69,8 +112,13 @@ class GradReducer:
         no overlap with backward either.  Worth it when the wire time is shorter than that toll."""
         self.gb = gradbuf
         self.pg = process_group
-        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.active = self.world > 1 or (force and dist.is_initialized())
+        # comm: an RcclComm -- the bucket collectives go through this library's own communicator (capturable without a
+        # watchdog); None: torch.distributed's process group.  fold_scale: the 1 / world factor is applied to the LOSS
+        # gradient by the caller (`backward_scale()`; graphed.GraphedStep does) instead of a pass over the flat buffer.
+        self.comm = comm
+        self.fold_scale = fold_scale
+        self.world = comm.world if comm is not None else (dist.get_world_size(process_group) if dist.is_initialized() else 1)
+        self.active = self.world > 1 or (force and (comm is not None or dist.is_initialized()))
         self.n_buckets = n_buckets
         self.expected = None        # contributions per parameter, learnt on the first backward
         self.counts = {}
@@ -135,6 +183,9 @@ class GradReducer:
         lo, hi, _ = self.buckets[b]
         self.next_bucket -= 1
         self.launch_log.append(b)
+        if self.comm is not None:
+            self.comm.allreduce(self.gb.flat[lo:hi], side=not self.inline)
+            return
         w = dist.all_reduce(self.gb.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.pg, async_op=not self.inline)
         if w is not None:
             self.works.append(w)
@@ -157,7 +208,8 @@ class GradReducer:
         gb = self.gb
         dev = gb.flat.device
         v = torch.tensor([self.counts.get(id(p), 0) for p in gb.params], dtype=torch.int32, device=dev)
-        dist.all_reduce(v, op=dist.ReduceOp.MAX, group=self.pg)
+        if dist.is_initialized():
+            dist.all_reduce(v, op=dist.ReduceOp.MAX, group=self.pg)
         self.expected = {id(p): int(c) for p, c in zip(gb.params, v.tolist())}
 
     def finish(self):
@@ -177,7 +229,8 @@ class GradReducer:
                                "all-reduced (the captured batch has another contribution pattern than the one "
                                "learnt); the captured graph would average incomplete gradients.  relearn() on a "
                                "batch of this kind, then capture again.")
-        if self.hook and self.expected is not None and not capturing:
+        agree = self.hook and self.expected is not None and not capturing and dist.is_initialized()
+        if agree:
             # late-gradient flag, agreed across ranks (MAX) so that every rank raises, or none does
             if self.flag is None:
                 self.flag = torch.zeros(1, device=self.gb.flat.device, dtype=torch.float32)
@@ -185,8 +238,11 @@ class GradReducer:
             self.works.append(dist.all_reduce(self.flag, op=dist.ReduceOp.MAX, group=self.pg, async_op=True))
         for w in self.works:
             w.wait()
-        self.gb.flat.mul_(1.0 / self.world)
-        if self.hook and self.expected is not None and not capturing and float(self.flag) > 0:
+        if self.comm is not None:
+            self.comm.wait()
+        if not self.fold_scale:
+            self.gb.flat.mul_(1.0 / self.world)
+        if agree and float(self.flag) > 0:
             self._reset_step()
             raise RuntimeError("GradReducer: on some rank a gradient arrived after its bucket had been "
                                "all-reduced (the contribution pattern changed between steps); the reduced "
@@ -195,6 +251,10 @@ class GradReducer:
         if self.hook and self.expected is None:
             self._agree_expected()
         self._reset_step()
+
+    def backward_scale(self):
+        """what to multiply the loss gradient with when fold_scale is on (1 / world), else 1"""
+        return 1.0 / self.world if (self.fold_scale and self.active) else 1.0
 
     def relearn(self):
         self.expected = None

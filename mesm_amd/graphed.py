@@ -39,6 +39,22 @@ def _round_up(x, m):
     return (x + m - 1) // m * m
 
 
+_CAPTURE_STREAMS = {}
+
+
+def capture_stream(dev):
+    """THE stream of this process on which steps are warmed up and captured (one per device).  Autograd pins an
+    AccumulateGrad node to the stream of its first use for as long as the node lives, and the graph of a warm-up step
+    can live on through reference cycles; a later capture on ANOTHER stream records the hand-over to that stream as a
+    side branch of the HIP graph -- a second hardware queue at replay, +0.3 ms per step.  With one stream for every
+    warm-up and capture of the process there is nothing to hand over, however many graphs are captured."""
+    key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+    st = _CAPTURE_STREAMS.get(key)
+    if st is None:
+        st = _CAPTURE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
 class GraphedStep:
     BIG = 1 << 20  # batch tensors above 1 MiB (video_feat, word features) are copied on their own
 
@@ -81,7 +97,7 @@ class GraphedStep:
         gb.ensure(dev)
         kn.set_seed_offset(self.counter)
         try:
-            side = torch.cuda.Stream()
+            side = capture_stream(dev)
             side.wait_stream(torch.cuda.current_stream())
             # A reducer learns its bucket schedule on its first step, so the first graph warms up with the
             # collectives live (every rank is there together).  Later graphs of a StepCache are captured whenever
@@ -192,7 +208,13 @@ class GraphedStep:
         out = self.model(**b, dataset_name=self.dataset_name, is_training=True, plan=self.plan)
         losses, total = self.crit(out, b, True)
         self.model.zero_grad(set_to_none=True)
-        total.backward()  # a hooked reducer launches its bucket collectives from inside and joins at the end
+        # a hooked reducer launches its bucket collectives from inside and joins at the end; with fold_scale the
+        # 1 / world of the gradient MEAN rides the loss gradient (one scalar) instead of a pass over the flat buffer
+        sc = self.reducer.backward_scale() if self.reducer is not None else 1.0
+        if sc != 1.0:
+            total.backward(torch.full_like(total, sc))
+        else:
+            total.backward()
         return total.detach(), {k: v.detach() for k, v in losses.items()}
 
     # ------------------------------------------------------------------ new batch, same graph

@@ -16,9 +16,15 @@ def main():
     from mesm_amd.graphed import GraphedStep
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    from mesm_amd.ddp import init_process_group_from_env
-    os.environ.update(RANK="0", WORLD_SIZE="1")
-    init_process_group_from_env(dev)  # (turns the flight recorder off: see ddp.py)
+    from mesm_amd.ddp import RcclComm, init_process_group_from_env
+    mode = sys.argv[1] if len(sys.argv) > 1 else "overlapped"
+    own = mode.startswith("own-")  # this library's own RCCL communicator (csrc/ddp.hip): no torch process group at all
+    comm = None
+    if own:
+        comm = RcclComm(dev)
+    else:
+        os.environ.update(RANK="0", WORLD_SIZE="1")
+        init_process_group_from_env(dev)  # (turns the flight recorder off: see ddp.py)
     args = synthetic.make_args("C3a", device="cuda:0")
     torch.manual_seed(7)
     model = build_model(args)
@@ -27,8 +33,8 @@ def main():
         if hasattr(m, "p"):
             m.p = 0.0
     batch = synthetic.to_device(synthetic.workload_batch("C3a", seed=1), dev)
-    inline = len(sys.argv) > 1 and sys.argv[1] == "inline"  # blocking collectives on the capture stream itself
-    red = GradReducer(model.gradbuf(), n_buckets=6, force=True, inline=inline)
+    inline = mode.endswith("inline")  # collectives on the capture stream itself
+    red = GradReducer(model.gradbuf(), n_buckets=6, force=True, inline=inline, comm=comm, fold_scale=own)
     g = GraphedStep(model, crit, batch, args.dataset_name, warmup=2, reducer=red)
     total_g = float(g.run(redraw=False))
     torch.cuda.synchronize()

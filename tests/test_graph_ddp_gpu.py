@@ -262,6 +262,28 @@ def test_allreduce_captured_inside_the_step_graph(mode):
     assert res["loss_err"] < 1e-5 and res["grad_err"] < 1e-4, res
 
 
+@pytest.mark.parametrize("mode", ["own-overlapped", "own-inline"])
+def test_own_communicator_allreduce_captured_inside_the_step_graph(mode):
+    """The same capture with this library's OWN RCCL communicator (csrc/ddp.hip, mesm_ddp_*: raw ncclAllReduce on the
+    communicator's stream forked from the capture stream, or on the capture stream itself) and the 1 / world factor
+    folded into the loss gradient.  No torch process group exists in the child, hence no watchdog thread and NO retry
+    loop: every start has to succeed (tools/ddp_capture_soak.py counts 100 starts into profiles/)."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for _ in range(2):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run([sys.executable, os.path.join(here, "ddp_capture_worker.py"), mode], env=env,
+                           capture_output=True, text=True, timeout=600)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+        assert lines, (r.returncode, r.stdout[-3000:], r.stderr[-3000:])
+        res = json.loads(lines[-1][7:])
+        assert res["launch_log_tail"] == [5, 4, 3, 2, 1, 0], res
+        assert res["second_graph_launches"] == 6, res
+        assert res["loss_err"] < 1e-5 and res["grad_err"] < 1e-4, res
+
+
 @pytest.mark.parametrize("workload", ["C3b", "C2"])
 def test_step_cache_replays_other_groupings_and_padded_extents(workload):
     """Real loaders emit a different (N, Lv, Lw, grouping) almost every batch (dataset/base.py:164-207: an item is
