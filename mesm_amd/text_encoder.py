@@ -130,7 +130,18 @@ class CLIPTextEncoder(nn.Module):
             x = blk(x)
         N, L, d = x.shape
         x = kn.layernorm_f16(x.view(N * L, d), self.ln_final.weight, self.ln_final.bias).view(N, L, d)
-        return dict(last_hidden_state=x, pooler_output=None)
+        # text_encoder.py:352-354: the features of the end-of-text token (the largest id) through text_projection,
+        # fp16 like the rest of the tower (MESM itself only reads last_hidden_state)
+        eos = x[torch.arange(N, device=x.device), text.argmax(dim=-1)]
+        pt = self._proj_t
+        if pt is None or pt.data_ptr() != self._proj_src or pt.device != x.device:
+            pt = self._proj_t = self.text_projection.detach().t().contiguous()
+            self._proj_src = pt.data_ptr()
+        pooled = kn.gemm_f16(eos.contiguous(), pt)
+        return dict(last_hidden_state=x, pooler_output=pooled)
+
+    _proj_t = None
+    _proj_src = None
 
 
 def convert_weights(model):

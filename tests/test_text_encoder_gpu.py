@@ -54,9 +54,14 @@ def test_clip_text_encoder_matches_reference_golden():
     enc = clip_text_encoder_from_state_dict(sd).to(dev())
     assert enc.transformer.resblocks[0].attn.in_proj_weight.dtype == torch.float16
     assert enc.token_embedding.weight.dtype == torch.float32
-    hid = enc(t("ids").to(dev()))["last_hidden_state"]
+    out = enc(t("ids").to(dev()))
+    hid = out["last_hidden_state"]
     assert hid.dtype == torch.float16
     check16(hid, t("hidden"), "last_hidden_state")
+    # the end-of-text features through text_projection (text_encoder.py:352-354), pinned by the real reference too
+    zp = np.load(os.path.join(GOLDEN, "clip_pooler_tiny.npz"))
+    assert out["pooler_output"].dtype == torch.float16
+    check16(out["pooler_output"], torch.from_numpy(zp["pooler_output"].copy()), "pooler_output")
 
 
 def test_clip_encode_text_wrapper_matches_reference_golden():

@@ -1,8 +1,8 @@
 """Random-configuration parity sweep of the HIP path against the CPU oracle (which the reference fixtures pin):
 dataset, group sizes, sequence lengths, padding, widths / heads (incl. head dim 32: matrix-core attention), layer
 counts, projection depth and the ablation switches are drawn per case; outputs, losses, matcher indices and
-gradients are compared.  Not part of the test suite (minutes of CPU oracle time): a bug hunt.
-usage: fuzz_parity.py [n_cases] [seed]"""
+gradients are compared.  A seeded 20-case slice runs in the GPU suite (tests/test_fuzz_gpu.py imports fuzz_case);
+the long sweeps are a bug hunt.  usage: fuzz_parity.py [n_cases] [seed]"""
 import os, random, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -11,8 +11,6 @@ from mesm_amd import build_criterion, build_model, synthetic
 from oracle import mesm_oracle as O
 
 dev = torch.device("cuda:0")
-n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 
 
 def rel(a, b):
@@ -25,8 +23,8 @@ def l2(a, b):
     return float((a - b).norm()) / max(float(b.norm()), 1e-3 * b.numel() ** 0.5)
 
 
-bad = 0
-for case in range(n_cases):
+def fuzz_case(rng, case):
+    """one random configuration -> (description, 'ok' | 'MISMATCH ...' | 'ERROR ...')"""
     dataset = rng.choice(["qvhighlights", "charades", "tacos"])
     ngroups = rng.randint(2, 5)
     groups = [rng.randint(1, 3) for _ in range(ngroups)]
@@ -122,7 +120,16 @@ for case in range(n_cases):
         status = "ok" if not errs else "MISMATCH " + "; ".join(errs[:6])
     except Exception as e:  # noqa: BLE001
         status = "ERROR %s: %s" % (type(e).__name__, str(e)[:200])
-    if status != "ok":
-        bad += 1
-    print(tag, "->", status, flush=True)
-print("cases %d, not ok %d" % (n_cases, bad))
+    return tag, status
+
+
+if __name__ == "__main__":
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    bad = 0
+    for case in range(n_cases):
+        tag, status = fuzz_case(rng, case)
+        if status != "ok":
+            bad += 1
+        print(tag, "->", status, flush=True)
+    print("cases %d, not ok %d" % (n_cases, bad))
