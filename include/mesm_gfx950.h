@@ -315,6 +315,10 @@ typedef struct MesmAttnArgs {
      decoder layer 0's key content = ca_kcontent_proj(memory) + ca_kpos_proj(pos) (transformer.py:773-776).  The
      backward's dk_ is then the gradient of that sum, i.e. of both terms. */
   const float* k_add;
+  /* T2V_QUIRK only, NULL = off: the modulus of the batch wrap read from DEVICE memory at run time -- the number of valid
+     pairs of a batch that was padded with dummy pairs up to a captured capacity; mask_group (or B) then is only the
+     stride between stacked batches, and rows at or beyond the modulus see their own masks. */
+  const int32_t* mask_mod;
 } MesmAttnArgs;
 
 int mesm_attn_fwd(const MesmAttnArgs* args, void* stream);
@@ -644,6 +648,39 @@ int mesm_adamw_step(float* p, const float* g, float* m, float* v, const uint8_t*
                     const float* partials, int32_t np, float max_norm, const float* lr, float beta1,
                     float beta2, float eps, float weight_decay, const int32_t* step, float* norm_out,
                     void* stream);
+
+/* ------------------------------------------------------------------------- */
+/*
+ * The loss blocks with a VALID-PAIR COUNT read from device memory (`n_valid`, NULL = N): the pairs [*n_valid, N)
+ * are padding that brought a batch up to the capacity a HIP graph was captured with (the reference's loaders emit a
+ * different number of pairs almost every batch, dataset/base.py:116-162).  Padding pairs take no part in the matching,
+ * in any sum or in any denominator (every mean is over *n_valid), and their gradient rows are written as zeros.
+ * Otherwise identical to the entry points of the same name without the suffix.
+ */
+int mesm_set_loss_fwd_nv(const float* logits, const float* spans, const float* tgt_cxw, const float* tgt_xx,
+                         const int32_t* tgt_off, int32_t N, int32_t Q, int32_t Tmax, float w_span, float w_giou,
+                         float w_class, float eos_coef, int32_t* match_q, float* out4, const int32_t* n_valid,
+                         void* stream);
+int mesm_set_loss_bwd_nv(const float* logits, const float* spans, const float* tgt_cxw, const float* tgt_xx,
+                         const int32_t* tgt_off, const int32_t* match_q, int32_t N, int32_t Q, float eos_coef,
+                         const float* g4, float* dlogits, float* dspans, const int32_t* n_valid, void* stream);
+int mesm_saliency_loss_fwd_nv(const float* s_pos, const float* s_neg, const double* label, const uint8_t* vmask,
+                              const int64_t* pos_idx, const int64_t* neg_idx, int32_t N, int32_t L, int32_t P,
+                              float rank_coef, float margin, float* out_loss, const int32_t* n_valid, void* stream);
+int mesm_saliency_loss_bwd_nv(const float* s_pos, const float* s_neg, const double* label, const uint8_t* vmask,
+                              const int64_t* pos_idx, const int64_t* neg_idx, int32_t N, int32_t L, int32_t P,
+                              float rank_coef, float margin, const float* gscale, float* ds_pos, float* ds_neg,
+                              const int32_t* n_valid, void* stream);
+int mesm_rec_ss_fwd_nv(const float* pv, const uint8_t* cmask, int32_t Lv, const float* ew, const uint8_t* wmask,
+                       int32_t Le, const uint8_t* pos, int32_t N, int32_t D, float tau, float* cn, float* wn,
+                       float* stats, float* sim, float* out, const int32_t* n_valid, void* stream);
+int mesm_rec_ss_bwd_nv(const float* cn, const float* wn, const uint8_t* pos, const float* sim, const float* stats,
+                       const uint8_t* cmask, const uint8_t* wmask, int32_t N, int32_t D, int32_t Lv, int32_t Le,
+                       float tau, const float* g, float* dpv, float* dew, const int32_t* n_valid, void* stream);
+int mesm_rec_fw_reduce_nv(const float* row_loss, const uint8_t* correct, const uint8_t* mask, int32_t N, int32_t Lw,
+                          float* out2, const int32_t* n_valid, void* stream);
+int mesm_rec_fw_rowgrad_nv(const uint8_t* mask, int32_t N, int32_t Lw, const float* g, float* row_grad,
+                           const int32_t* n_valid, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /*

@@ -60,6 +60,7 @@ class AttnArgs(ctypes.Structure):
         ("d_o", c_ptr), ("dq", c_ptr), ("dk_", c_ptr), ("dv_", c_ptr),
         ("seed_offset", c_ptr), ("mask_group", ctypes.c_int32),
         ("q2", c_ptr), ("k2", c_ptr), ("dq2", c_ptr), ("dk2", c_ptr), ("k_add", c_ptr),
+        ("mask_mod", c_ptr),
     ]
 
 
@@ -145,6 +146,14 @@ PROTOTYPES = {
                                      _i32, _i32, _i32, _i32, c_ptr]),
     "mesm_text_pool": (ctypes.c_int, [c_ptr, _i32, c_ptr, _i32, _i32, _i32, _i32, _i32, _i32, c_ptr, c_ptr, c_ptr]),
     "mesm_embed_rows": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, _i64, _i32, _i32, c_ptr]),
+    "mesm_set_loss_fwd_nv": (ctypes.c_int, [c_ptr] * 5 + [_i32, _i32, _i32, _f32, _f32, _f32, _f32, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "mesm_set_loss_bwd_nv": (ctypes.c_int, [c_ptr] * 6 + [_i32, _i32, _f32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "mesm_saliency_loss_fwd_nv": (ctypes.c_int, [c_ptr] * 6 + [_i32, _i32, _i32, _f32, _f32, c_ptr, c_ptr, c_ptr]),
+    "mesm_saliency_loss_bwd_nv": (ctypes.c_int, [c_ptr] * 6 + [_i32, _i32, _i32, _f32, _f32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "mesm_rec_ss_fwd_nv": (ctypes.c_int, [c_ptr, c_ptr, _i32, c_ptr, c_ptr, _i32, c_ptr, _i32, _i32, _f32] + [c_ptr] * 7),
+    "mesm_rec_ss_bwd_nv": (ctypes.c_int, [c_ptr] * 7 + [_i32, _i32, _i32, _i32, _f32] + [c_ptr] * 5),
+    "mesm_rec_fw_reduce_nv": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, _i32, _i32, c_ptr, c_ptr, c_ptr]),
+    "mesm_rec_fw_rowgrad_nv": (ctypes.c_int, [c_ptr, _i32, _i32, c_ptr, c_ptr, c_ptr, c_ptr]),
     "mesm_ddp_unique_id": (ctypes.c_int, [c_ptr]),
     "mesm_ddp_init": (ctypes.c_int, [c_ptr, _i32, _i32, ctypes.POINTER(ctypes.c_void_p)]),
     "mesm_ddp_allreduce": (ctypes.c_int, [c_ptr, c_ptr, _i64, c_ptr, _i32]),

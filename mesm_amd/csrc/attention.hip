@@ -54,8 +54,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const MesmAttnArgs
   const int b = bh / p.H, h = bh % p.H;
   const int q0 = blockIdx.y * QCH;
   const int nq = (p.Lq - q0) < QCH ? (p.Lq - q0) : QCH;
-  const int mg = p.mask_group > 0 ? p.mask_group : p.B;
-  const int b2 = (b / mg) * mg + ((b % mg) * p.H + h) % mg;
+  const int b2 = mesm_quirk_row(p, b, h);
   const bool quirk = (p.mask_mode == MESM_MASK_T2V_QUIRK) && p.qpad && p.kpad;
   const bool causal = p.mask_mode == MESM_MASK_CAUSAL;
 
@@ -223,8 +222,7 @@ __device__ __forceinline__ void attn_bwd_body(const MesmAttnArgs& p, const int b
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = bh / p.H, h = bh % p.H;
   const int k0 = ktile * KT;
-  const int mg = p.mask_group > 0 ? p.mask_group : p.B;
-  const int b2 = (b / mg) * mg + ((b % mg) * p.H + h) % mg;
+  const int b2 = mesm_quirk_row(p, b, h);
   const bool quirk = (p.mask_mode == MESM_MASK_T2V_QUIRK) && p.qpad && p.kpad;
   const bool dq_atomic = ntiles > 1;
 

@@ -125,8 +125,7 @@ __device__ __forceinline__ void attn_mfma_fwd_body(const MesmAttnArgs& p, int bl
   const int q0 = qb * 32;
   const int i = q0 + li;
   const bool ivalid = i < p.Lq;
-  const int mg = p.mask_group > 0 ? p.mask_group : p.B;
-  const int b2 = (b / mg) * mg + ((b % mg) * p.H + hd) % mg;
+  const int b2 = mesm_quirk_row(p, b, hd);
   const bool quirk = (p.mask_mode == MESM_MASK_T2V_QUIRK) && p.qpad && p.kpad;
 
   float qf[16];
@@ -256,8 +255,7 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_long_kernel(const MesmAttnA
   const int q0 = qb * 32;
   const int i = q0 + li;
   const bool ivalid = i < p.Lq;
-  const int mg = p.mask_group > 0 ? p.mask_group : p.B;
-  const int b2 = (b / mg) * mg + ((b % mg) * p.H + hd) % mg;
+  const int b2 = mesm_quirk_row(p, b, hd);
   const bool quirk = (p.mask_mode == MESM_MASK_T2V_QUIRK) && p.qpad && p.kpad;
   const bool qp = quirk && ivalid && p.qpad[(int64_t)b2 * p.Lq + i] != 0;
 
@@ -368,8 +366,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const MesmAttnArgs p
   const int P = 4 / nkb;  // waves per key block (nkb <= 4)
   const int kb = wave % nkb, part = wave / nkb;
   const bool active = part < P;
-  const int mg = p.mask_group > 0 ? p.mask_group : p.B;
-  const int b2 = (b / mg) * mg + ((b % mg) * p.H + hd) % mg;
+  const int b2 = mesm_quirk_row(p, b, hd);
   const bool quirk = (p.mask_mode == MESM_MASK_T2V_QUIRK) && p.qpad && p.kpad;
   const uint32_t thresh = p.drop_p > 0.f ? mesm_drop_threshold(p.drop_p) : 0u;
   const float inv_keep = 1.0f / (1.0f - p.drop_p);

@@ -104,3 +104,15 @@ __device__ __forceinline__ float sum_within(float v) {
   if (N >= 16) v += mesm_dpp<0x140, 0xF>(0.0f, v);
   return v;
 }
+
+// Row of the key-padding / query-padding masks that batch row b, head hd sees under the T2V mask quirk (SURVEY Q1:
+// the reference repeats its (N, Lq, Lk) mask head-major but nn.MultiheadAttention indexes it batch-major):
+//   b' = (b * H + hd) mod N   inside the group of `stride` stacked rows that b belongs to.
+// stride = mask_group (0: the whole batch); N = *mask_mod when given (a device scalar: the VALID pairs of a batch padded
+// to a captured capacity, graphed.py), else the stride.  Rows at or beyond N (padding pairs) see their own masks.
+__device__ __forceinline__ int mesm_quirk_row(const MesmAttnArgs& p, int b, int hd) {
+  const int stride = p.mask_group > 0 ? p.mask_group : p.B;
+  const int mod = p.mask_mod ? *p.mask_mod : stride;
+  const int bl = b % stride;
+  return (b - bl) + (bl < mod ? (bl * p.H + hd) % mod : bl);
+}

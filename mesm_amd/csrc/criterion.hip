@@ -98,7 +98,11 @@ __global__ void set_loss_fwd_kernel(const float* __restrict__ logits, const floa
                                     const float* __restrict__ tgt_cxw, const float* __restrict__ tgt_xx,
                                     const int32_t* __restrict__ tgt_off, int N, int Q, int Tmax,
                                     float w_span, float w_giou, float w_class, float eos_coef, int P,
-                                    int32_t* __restrict__ match_q, float* __restrict__ out) {
+                                    int32_t* __restrict__ match_q, float* __restrict__ out,
+                                    const int32_t* __restrict__ n_valid) {
+  // n_valid (device scalar, NULL = N): the pairs [n_valid, N) are padding of a captured capacity (graphed.py):
+  // they take no part in the matching, the sums or the denominators
+  if (n_valid) N = *n_valid;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int nthr = P, tid = threadIdx.x;  // P pairs per pass (LDS budget); threads >= P idle
   Sap s;
@@ -187,10 +191,18 @@ __global__ __launch_bounds__(256) void set_loss_bwd_kernel(
     const float* __restrict__ logits, const float* __restrict__ spans, const float* __restrict__ tgt_cxw,
     const float* __restrict__ tgt_xx, const int32_t* __restrict__ tgt_off,
     const int32_t* __restrict__ match_q, int N, int Q, float eos_coef, const float* __restrict__ g,
-    float* __restrict__ dlogits, float* __restrict__ dspans) {
+    float* __restrict__ dlogits, float* __restrict__ dspans, const int32_t* __restrict__ n_valid) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N * Q) return;
   const int b = i / Q, q = i % Q;
+  if (n_valid) {  // padding pairs: zero gradients, and out of every denominator
+    N = *n_valid;
+    if (b >= N) {
+      dlogits[(int64_t)i * 2] = dlogits[(int64_t)i * 2 + 1] = 0.0f;
+      dspans[(int64_t)i * 2] = dspans[(int64_t)i * 2 + 1] = 0.0f;
+      return;
+    }
+  }
   const int t0 = tgt_off[b], T = tgt_off[b + 1] - t0;
   const float sumT = (float)tgt_off[N];
   int t = -1;
@@ -323,10 +335,18 @@ __global__ __launch_bounds__(256 * SSM_G) void ss_mean_fwd_kernel(
 // (SupCon-style, +1e-6 inside the log); stage C sums the N row terms (deterministic).
 __global__ __launch_bounds__(256) void ss_loss_fwd_kernel(
     const float* __restrict__ cn, const float* __restrict__ wn, const uint8_t* __restrict__ pos, int N,
-    int D, float inv_tau, float* __restrict__ sim, float* __restrict__ rowloss) {
+    int D, float inv_tau, float* __restrict__ sim, float* __restrict__ rowloss, const int32_t* __restrict__ n_valid) {
   extern __shared__ float srow[];  // N
   const int n = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ld = N;  // row stride of sim / pos: the allocated extent
+  if (n_valid) {     // padding pairs are neither rows nor columns of the contrast
+    N = *n_valid;
+    if (n >= N) {
+      if (threadIdx.x == 0) rowloss[n] = 0.0f;
+      return;
+    }
+  }
   float q[16];  // D <= 1024: this lane's slice of cn[n]
 #pragma unroll
   for (int i = 0; i < 16; ++i) { const int c = lane + 64 * i; q[i] = c < D ? cn[(int64_t)n * D + c] : 0.0f; }
@@ -335,7 +355,7 @@ __global__ __launch_bounds__(256) void ss_loss_fwd_kernel(
 #pragma unroll
     for (int i = 0; i < 16; ++i) { const int c = lane + 64 * i; if (c < D) a += q[i] * wn[(int64_t)k * D + c]; }
     a = wave_sum(a);
-    if (lane == 0) { srow[k] = a * inv_tau; sim[(int64_t)n * N + k] = a * inv_tau; }
+    if (lane == 0) { srow[k] = a * inv_tau; sim[(int64_t)n * ld + k] = a * inv_tau; }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -346,13 +366,14 @@ __global__ __launch_bounds__(256) void ss_loss_fwd_kernel(
     const float logS = logf(S + 1e-6f);
     float num = 0.0f, cnt = 0.0f;
     for (int k = 0; k < N; ++k)
-      if (pos[(int64_t)n * N + k]) { num += (srow[k] - m) - logS; cnt += 1.0f; }
+      if (pos[(int64_t)n * ld + k]) { num += (srow[k] - m) - logS; cnt += 1.0f; }
     rowloss[n] = -num / (cnt + 1e-6f);
   }
 }
 
 __global__ __launch_bounds__(64) void ss_reduce_kernel(const float* __restrict__ rowloss, int N,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out, const int32_t* __restrict__ n_valid) {
+  if (n_valid) N = *n_valid;
   float a = 0.0f;
   for (int n = threadIdx.x; n < N; n += 64) a += rowloss[n];
   a = wave_sum(a);
@@ -366,13 +387,15 @@ __global__ __launch_bounds__(256) void ss_bwd_kernel(
     const float* __restrict__ cn, const float* __restrict__ wn, const uint8_t* __restrict__ pos,
     const float* __restrict__ sim, const float* __restrict__ stats, const uint8_t* __restrict__ cmask,
     const uint8_t* __restrict__ wmask, int N, int D, int Lv, int Le, float inv_tau,
-    const float* __restrict__ g, float* __restrict__ dpv, float* __restrict__ dew) {
+    const float* __restrict__ g, float* __restrict__ dpv, float* __restrict__ dew, const int32_t* __restrict__ n_valid) {
   extern __shared__ float dsim[];  // N*N
   __shared__ float sh[8];
   const int n = blockIdx.x;
+  const int ld = N;  // row stride of sim / pos / dsim: the allocated extent
+  if (n_valid) N = *n_valid;  // padding pairs: no row, no column; their own gradients come out zero below
   const float gs = g[0] / (float)N;
   for (int r = threadIdx.x; r < N; r += 256) {
-    const float* row = sim + (int64_t)r * N;
+    const float* row = sim + (int64_t)r * ld;
     float m = -INFINITY;
     int am = 0;
     for (int k = 0; k < N; ++k)
@@ -380,21 +403,22 @@ __global__ __launch_bounds__(256) void ss_bwd_kernel(
     float S = 0.0f, cnt = 0.0f;
     for (int k = 0; k < N; ++k) {
       S += expf(row[k] - m);
-      cnt += pos[(int64_t)r * N + k] ? 1.0f : 0.0f;
+      cnt += pos[(int64_t)r * ld + k] ? 1.0f : 0.0f;
     }
     const float a = gs / (cnt + 1e-6f);
     const float iS = 1.0f / (S + 1e-6f);
     for (int k = 0; k < N; ++k) {
-      float d = -a * (pos[(int64_t)r * N + k] ? 1.0f : 0.0f) + a * cnt * expf(row[k] - m) * iS;
+      float d = -a * (pos[(int64_t)r * ld + k] ? 1.0f : 0.0f) + a * cnt * expf(row[k] - m) * iS;
       if (k == am) d += a * cnt * 1e-6f * iS;
-      dsim[r * N + k] = d * inv_tau;
+      dsim[r * ld + k] = d * inv_tau;
     }
   }
   __syncthreads();
   float dc[4] = {0, 0, 0, 0}, dw[4] = {0, 0, 0, 0}, yc[4], yw[4];
+  const int kmax = n < N ? N : 0;  // a padding pair takes part in nothing
 #pragma unroll 8
-  for (int k = 0; k < N; ++k) {
-    const float a = dsim[n * N + k], b = dsim[k * N + n];
+  for (int k = 0; k < kmax; ++k) {
+    const float a = dsim[n * ld + k], b = dsim[k * ld + n];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int c = threadIdx.x + j * 256;
@@ -451,7 +475,9 @@ __global__ __launch_bounds__(256) void ss_bwd_kernel(
 __global__ __launch_bounds__(256) void recfw_reduce_kernel(const float* __restrict__ row_loss,
                                                            const uint8_t* __restrict__ correct,
                                                            const uint8_t* __restrict__ mask, int N,
-                                                           int Lw, float* __restrict__ out) {
+                                                           int Lw, float* __restrict__ out,
+                                                           const int32_t* __restrict__ n_valid) {
+  if (n_valid) N = *n_valid;
   __shared__ float sh[3][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float loss = 0.0f, ok = 0.0f, tot = 0.0f;
@@ -479,8 +505,16 @@ __global__ __launch_bounds__(256) void recfw_reduce_kernel(const float* __restri
 // row_grad[n,w] = g * mask / (N * cnt_n): the per-row weights mesm_nll_smooth_bwd consumes
 __global__ __launch_bounds__(64) void recfw_rowgrad_kernel(const uint8_t* __restrict__ mask, int N, int Lw,
                                                           const float* __restrict__ g,
-                                                          float* __restrict__ row_grad) {
+                                                          float* __restrict__ row_grad,
+                                                          const int32_t* __restrict__ n_valid) {
   const int n = blockIdx.x, lane = threadIdx.x;
+  if (n_valid) {
+    N = *n_valid;
+    if (n >= N) {  // padding pair
+      for (int w = lane; w < Lw; w += 64) row_grad[(int64_t)n * Lw + w] = 0.0f;
+      return;
+    }
+  }
   float c = 0.0f;
   for (int w = lane; w < Lw; w += 64) c += mask[(int64_t)n * Lw + w] ? 1.0f : 0.0f;
   c = wave_sum(c);
@@ -597,10 +631,10 @@ __global__ void scale_vec_kernel(const float* __restrict__ g, const float* __res
 
 }  // namespace
 
-extern "C" int mesm_set_loss_fwd(const float* logits, const float* spans, const float* tgt_cxw,
-                                 const float* tgt_xx, const int32_t* tgt_off, int32_t N, int32_t Q,
-                                 int32_t Tmax, float w_span, float w_giou, float w_class,
-                                 float eos_coef, int32_t* match_q, float* out4, void* stream) {
+extern "C" int mesm_set_loss_fwd_nv(const float* logits, const float* spans, const float* tgt_cxw,
+                                    const float* tgt_xx, const int32_t* tgt_off, int32_t N, int32_t Q,
+                                    int32_t Tmax, float w_span, float w_giou, float w_class,
+                                    float eos_coef, int32_t* match_q, float* out4, const int32_t* n_valid, void* stream) {
   if (!logits || !spans || !tgt_cxw || !tgt_xx || !tgt_off || !match_q || !out4) return MESM_EINVAL;
   if (N <= 0 || Q <= 0 || Q > 32 || Tmax <= 0 || Tmax > 16 || Tmax > Q) return MESM_EINVAL;
   const size_t per = sap_bytes_per_thread(Tmax, Q);
@@ -610,7 +644,28 @@ extern "C" int mesm_set_loss_fwd(const float* logits, const float* spans, const 
   while (P > 1 && P / 2 >= N) P >>= 1;
   hipLaunchKernelGGL(set_loss_fwd_kernel, dim3(1), dim3(64), per * P, (hipStream_t)stream, logits, spans,
                      tgt_cxw, tgt_xx, tgt_off, N, Q, Tmax, w_span, w_giou, w_class, eos_coef, P,
-                     match_q, out4);
+                     match_q, out4, n_valid);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_set_loss_fwd(const float* logits, const float* spans, const float* tgt_cxw,
+                                 const float* tgt_xx, const int32_t* tgt_off, int32_t N, int32_t Q,
+                                 int32_t Tmax, float w_span, float w_giou, float w_class,
+                                 float eos_coef, int32_t* match_q, float* out4, void* stream) {
+  return mesm_set_loss_fwd_nv(logits, spans, tgt_cxw, tgt_xx, tgt_off, N, Q, Tmax, w_span, w_giou, w_class, eos_coef,
+                              match_q, out4, nullptr, stream);
+}
+
+extern "C" int mesm_set_loss_bwd_nv(const float* logits, const float* spans, const float* tgt_cxw,
+                                    const float* tgt_xx, const int32_t* tgt_off, const int32_t* match_q,
+                                    int32_t N, int32_t Q, float eos_coef, const float* g4, float* dlogits,
+                                    float* dspans, const int32_t* n_valid, void* stream) {
+  if (!logits || !spans || !tgt_cxw || !tgt_xx || !tgt_off || !match_q || !g4 || !dlogits || !dspans)
+    return MESM_EINVAL;
+  if (N <= 0 || Q <= 0) return MESM_EINVAL;
+  hipLaunchKernelGGL(set_loss_bwd_kernel, dim3((N * Q + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     logits, spans, tgt_cxw, tgt_xx, tgt_off, match_q, N, Q, eos_coef, g4, dlogits,
+                     dspans, n_valid);
   return mesm_launch_status();
 }
 
@@ -618,19 +673,14 @@ extern "C" int mesm_set_loss_bwd(const float* logits, const float* spans, const 
                                  const float* tgt_xx, const int32_t* tgt_off, const int32_t* match_q,
                                  int32_t N, int32_t Q, float eos_coef, const float* g4, float* dlogits,
                                  float* dspans, void* stream) {
-  if (!logits || !spans || !tgt_cxw || !tgt_xx || !tgt_off || !match_q || !g4 || !dlogits || !dspans)
-    return MESM_EINVAL;
-  if (N <= 0 || Q <= 0) return MESM_EINVAL;
-  hipLaunchKernelGGL(set_loss_bwd_kernel, dim3((N * Q + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                     logits, spans, tgt_cxw, tgt_xx, tgt_off, match_q, N, Q, eos_coef, g4, dlogits,
-                     dspans);
-  return mesm_launch_status();
+  return mesm_set_loss_bwd_nv(logits, spans, tgt_cxw, tgt_xx, tgt_off, match_q, N, Q, eos_coef, g4, dlogits, dspans,
+                              nullptr, stream);
 }
 
-extern "C" int mesm_rec_ss_fwd(const float* pv, const uint8_t* cmask, int32_t Lv, const float* ew,
-                               const uint8_t* wmask, int32_t Le, const uint8_t* pos, int32_t N,
-                               int32_t D, float tau, float* cn, float* wn, float* stats, float* sim,
-                               float* out, void* stream) {
+extern "C" int mesm_rec_ss_fwd_nv(const float* pv, const uint8_t* cmask, int32_t Lv, const float* ew,
+                                  const uint8_t* wmask, int32_t Le, const uint8_t* pos, int32_t N,
+                                  int32_t D, float tau, float* cn, float* wn, float* stats, float* sim,
+                                  float* out, const int32_t* n_valid, void* stream) {
   if (!pv || !cmask || !ew || !wmask || !pos || !cn || !wn || !stats || !sim || !out) return MESM_EINVAL;
   if (N <= 0 || D <= 0 || D > 1024 || Lv <= 0 || Le <= 0 || tau <= 0.f) return MESM_EINVAL;
   hipStream_t s = (hipStream_t)stream;
@@ -639,8 +689,26 @@ extern "C" int mesm_rec_ss_fwd(const float* pv, const uint8_t* cmask, int32_t Lv
   // stats (N, 4) has one spare use: the row losses are staged in column 0 of a second block
   float* rowloss = stats + (size_t)N * 4;
   hipLaunchKernelGGL(ss_loss_fwd_kernel, dim3(N), dim3(256), (size_t)N * 4, s, cn, wn, pos, N, D,
-                     1.0f / tau, sim, rowloss);
-  hipLaunchKernelGGL(ss_reduce_kernel, dim3(1), dim3(64), 0, s, rowloss, N, out);
+                     1.0f / tau, sim, rowloss, n_valid);
+  hipLaunchKernelGGL(ss_reduce_kernel, dim3(1), dim3(64), 0, s, rowloss, N, out, n_valid);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_rec_ss_fwd(const float* pv, const uint8_t* cmask, int32_t Lv, const float* ew,
+                               const uint8_t* wmask, int32_t Le, const uint8_t* pos, int32_t N,
+                               int32_t D, float tau, float* cn, float* wn, float* stats, float* sim,
+                               float* out, void* stream) {
+  return mesm_rec_ss_fwd_nv(pv, cmask, Lv, ew, wmask, Le, pos, N, D, tau, cn, wn, stats, sim, out, nullptr, stream);
+}
+
+extern "C" int mesm_rec_ss_bwd_nv(const float* cn, const float* wn, const uint8_t* pos, const float* sim,
+                                  const float* stats, const uint8_t* cmask, const uint8_t* wmask,
+                                  int32_t N, int32_t D, int32_t Lv, int32_t Le, float tau, const float* g,
+                                  float* dpv, float* dew, const int32_t* n_valid, void* stream) {
+  if (!cn || !wn || !pos || !sim || !stats || !cmask || !wmask || !g || !dpv || !dew) return MESM_EINVAL;
+  if (N <= 0 || N > 120 || D <= 0 || D > 1024 || tau <= 0.f) return MESM_EINVAL;
+  hipLaunchKernelGGL(ss_bwd_kernel, dim3(N), dim3(256), (size_t)N * N * 4, (hipStream_t)stream, cn, wn,
+                     pos, sim, stats, cmask, wmask, N, D, Lv, Le, 1.0f / tau, g, dpv, dew, n_valid);
   return mesm_launch_status();
 }
 
@@ -648,27 +716,33 @@ extern "C" int mesm_rec_ss_bwd(const float* cn, const float* wn, const uint8_t* 
                                const float* stats, const uint8_t* cmask, const uint8_t* wmask,
                                int32_t N, int32_t D, int32_t Lv, int32_t Le, float tau, const float* g,
                                float* dpv, float* dew, void* stream) {
-  if (!cn || !wn || !pos || !sim || !stats || !cmask || !wmask || !g || !dpv || !dew) return MESM_EINVAL;
-  if (N <= 0 || N > 120 || D <= 0 || D > 1024 || tau <= 0.f) return MESM_EINVAL;
-  hipLaunchKernelGGL(ss_bwd_kernel, dim3(N), dim3(256), (size_t)N * N * 4, (hipStream_t)stream, cn, wn,
-                     pos, sim, stats, cmask, wmask, N, D, Lv, Le, 1.0f / tau, g, dpv, dew);
+  return mesm_rec_ss_bwd_nv(cn, wn, pos, sim, stats, cmask, wmask, N, D, Lv, Le, tau, g, dpv, dew, nullptr, stream);
+}
+
+extern "C" int mesm_rec_fw_reduce_nv(const float* row_loss, const uint8_t* correct, const uint8_t* mask,
+                                     int32_t N, int32_t Lw, float* out2, const int32_t* n_valid, void* stream) {
+  if (!row_loss || !correct || !mask || !out2 || N <= 0 || Lw <= 0) return MESM_EINVAL;
+  hipLaunchKernelGGL(recfw_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, row_loss, correct,
+                     mask, N, Lw, out2, n_valid);
   return mesm_launch_status();
 }
 
 extern "C" int mesm_rec_fw_reduce(const float* row_loss, const uint8_t* correct, const uint8_t* mask,
                                   int32_t N, int32_t Lw, float* out2, void* stream) {
-  if (!row_loss || !correct || !mask || !out2 || N <= 0 || Lw <= 0) return MESM_EINVAL;
-  hipLaunchKernelGGL(recfw_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, row_loss, correct,
-                     mask, N, Lw, out2);
+  return mesm_rec_fw_reduce_nv(row_loss, correct, mask, N, Lw, out2, nullptr, stream);
+}
+
+extern "C" int mesm_rec_fw_rowgrad_nv(const uint8_t* mask, int32_t N, int32_t Lw, const float* g,
+                                      float* row_grad, const int32_t* n_valid, void* stream) {
+  if (!mask || !g || !row_grad || N <= 0 || Lw <= 0) return MESM_EINVAL;
+  hipLaunchKernelGGL(recfw_rowgrad_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, mask, N, Lw, g,
+                     row_grad, n_valid);
   return mesm_launch_status();
 }
 
 extern "C" int mesm_rec_fw_rowgrad(const uint8_t* mask, int32_t N, int32_t Lw, const float* g,
                                    float* row_grad, void* stream) {
-  if (!mask || !g || !row_grad || N <= 0 || Lw <= 0) return MESM_EINVAL;
-  hipLaunchKernelGGL(recfw_rowgrad_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, mask, N, Lw, g,
-                     row_grad);
-  return mesm_launch_status();
+  return mesm_rec_fw_rowgrad_nv(mask, N, Lw, g, row_grad, nullptr, stream);
 }
 
 extern "C" int mesm_rowdot_fwd(const float* a, const float* b, int32_t N, int32_t L, int32_t D,

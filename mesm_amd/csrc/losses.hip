@@ -185,7 +185,8 @@ __global__ __launch_bounds__(64 * NW) void saliency_fwd_kernel(
     const float* __restrict__ s_pos, const float* __restrict__ s_neg,
     const double* __restrict__ label, const uint8_t* __restrict__ vmask,
     const int64_t* __restrict__ pos_idx, const int64_t* __restrict__ neg_idx, int N, int L, int P,
-    float rank_coef, float margin, float* __restrict__ out_loss) {
+    float rank_coef, float margin, float* __restrict__ out_loss, const int32_t* __restrict__ n_valid) {
+  if (n_valid) N = *n_valid;  // pairs [n_valid, N) are padding of a captured capacity: not in the mean
   __shared__ float part[NW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float acc = 0.0f;  // lane 0 of each wave accumulates its rows
@@ -228,10 +229,17 @@ __global__ __launch_bounds__(256) void saliency_bwd_kernel(
     const double* __restrict__ label, const uint8_t* __restrict__ vmask,
     const int64_t* __restrict__ pos_idx, const int64_t* __restrict__ neg_idx, int N, int L, int P,
     float rank_coef, float margin, const float* __restrict__ gscale, float* __restrict__ ds_pos,
-    float* __restrict__ ds_neg) {
+    float* __restrict__ ds_neg, const int32_t* __restrict__ n_valid) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
+  if (n_valid) {
+    N = *n_valid;
+    if (n >= N) {  // padding pair: zero gradient rows
+      for (int l = lane; l < L; l += 64) ds_pos[(int64_t)n * L + l] = ds_neg[(int64_t)n * L + l] = 0.0f;
+      return;
+    }
+  }
   const float gs = *gscale;
   const float* sp = s_pos + (int64_t)n * L;
   const float* sn = s_neg + (int64_t)n * L;
@@ -371,29 +379,38 @@ extern "C" int mesm_nll_smooth_bwd(const float* logit, const int64_t* label, con
   return mesm_launch_status();
 }
 
-extern "C" int mesm_saliency_loss_fwd(const float* s_pos, const float* s_neg, const double* label,
-                                      const uint8_t* vmask, const int64_t* pos_idx,
-                                      const int64_t* neg_idx, int32_t N, int32_t L, int32_t P,
-                                      float rank_coef, float margin, float* out_loss,
-                                      void* stream) {
+extern "C" int mesm_saliency_loss_fwd_nv(const float* s_pos, const float* s_neg, const double* label,
+                                         const uint8_t* vmask, const int64_t* pos_idx,
+                                         const int64_t* neg_idx, int32_t N, int32_t L, int32_t P,
+                                         float rank_coef, float margin, float* out_loss, const int32_t* n_valid,
+                                         void* stream) {
   if (!s_pos || !s_neg || !label || !vmask || !out_loss || N <= 0 || L <= 0) return MESM_EINVAL;
   if (2 * L > 64 * SAL_MAXE) return MESM_EINVAL;
   if ((pos_idx == nullptr) != (neg_idx == nullptr)) return MESM_EINVAL;
   if (pos_idx && (P <= 0 || P > 64)) return MESM_EINVAL;
   if (2 * L <= 64 * 4)
     hipLaunchKernelGGL((saliency_fwd_kernel<4, 16>), dim3(1), dim3(64 * 16), 0, (hipStream_t)stream, s_pos, s_neg,
-                       label, vmask, pos_idx, neg_idx, N, L, P, rank_coef, margin, out_loss);
+                       label, vmask, pos_idx, neg_idx, N, L, P, rank_coef, margin, out_loss, n_valid);
   else
     hipLaunchKernelGGL((saliency_fwd_kernel<SAL_MAXE, 8>), dim3(1), dim3(64 * 8), 0, (hipStream_t)stream, s_pos,
-                       s_neg, label, vmask, pos_idx, neg_idx, N, L, P, rank_coef, margin, out_loss);
+                       s_neg, label, vmask, pos_idx, neg_idx, N, L, P, rank_coef, margin, out_loss, n_valid);
   return mesm_launch_status();
 }
 
-extern "C" int mesm_saliency_loss_bwd(const float* s_pos, const float* s_neg, const double* label,
+extern "C" int mesm_saliency_loss_fwd(const float* s_pos, const float* s_neg, const double* label,
                                       const uint8_t* vmask, const int64_t* pos_idx,
                                       const int64_t* neg_idx, int32_t N, int32_t L, int32_t P,
-                                      float rank_coef, float margin, const float* gscale,
-                                      float* ds_pos, float* ds_neg, void* stream) {
+                                      float rank_coef, float margin, float* out_loss,
+                                      void* stream) {
+  return mesm_saliency_loss_fwd_nv(s_pos, s_neg, label, vmask, pos_idx, neg_idx, N, L, P, rank_coef, margin, out_loss,
+                                   nullptr, stream);
+}
+
+extern "C" int mesm_saliency_loss_bwd_nv(const float* s_pos, const float* s_neg, const double* label,
+                                         const uint8_t* vmask, const int64_t* pos_idx,
+                                         const int64_t* neg_idx, int32_t N, int32_t L, int32_t P,
+                                         float rank_coef, float margin, const float* gscale,
+                                         float* ds_pos, float* ds_neg, const int32_t* n_valid, void* stream) {
   if (!s_pos || !s_neg || !label || !vmask || !gscale || !ds_pos || !ds_neg || N <= 0 || L <= 0)
     return MESM_EINVAL;
   if (2 * L > 64 * SAL_MAXE) return MESM_EINVAL;
@@ -402,12 +419,21 @@ extern "C" int mesm_saliency_loss_bwd(const float* s_pos, const float* s_neg, co
   if (2 * L <= 64 * 4)
     hipLaunchKernelGGL(saliency_bwd_kernel<4>, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                        s_pos, s_neg, label, vmask, pos_idx, neg_idx, N, L, P, rank_coef, margin,
-                       gscale, ds_pos, ds_neg);
+                       gscale, ds_pos, ds_neg, n_valid);
   else
     hipLaunchKernelGGL(saliency_bwd_kernel<SAL_MAXE>, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream,
                        s_pos, s_neg, label, vmask, pos_idx, neg_idx, N, L, P, rank_coef, margin,
-                       gscale, ds_pos, ds_neg);
+                       gscale, ds_pos, ds_neg, n_valid);
   return mesm_launch_status();
+}
+
+extern "C" int mesm_saliency_loss_bwd(const float* s_pos, const float* s_neg, const double* label,
+                                      const uint8_t* vmask, const int64_t* pos_idx,
+                                      const int64_t* neg_idx, int32_t N, int32_t L, int32_t P,
+                                      float rank_coef, float margin, const float* gscale,
+                                      float* ds_pos, float* ds_neg, void* stream) {
+  return mesm_saliency_loss_bwd_nv(s_pos, s_neg, label, vmask, pos_idx, neg_idx, N, L, P, rank_coef, margin, gscale,
+                                   ds_pos, ds_neg, nullptr, stream);
 }
 
 extern "C" int mesm_match(const float* logits, const float* spans, const float* tgt_cxw,

@@ -364,6 +364,18 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx=None, accumulate_d
     return dx2.view(x.shape), dxm.view(x.shape)
 
 
+# Device scalar (int32) with the number of VALID pairs of a batch padded to a captured capacity (graphed.py sets it
+# around the capture of a padded step): the modulus of the attention mask quirk.  None = the batch extent.
+_mask_mod = None
+
+
+def set_mask_mod(t):
+    global _mask_mod
+    if t is not None:
+        assert t.is_cuda and t.dtype == torch.int32 and t.numel() == 1
+    _mask_mod = t
+
+
 def _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop, group=0, causal=False, q2=None, k2=None, k_add=None):
     B, Lq, Eq = q.shape
     _, Lk, Ek = k.shape
@@ -393,6 +405,8 @@ def _attn_args(q, k, v, o, lse, H, kpad, qpad, scale, drop, group=0, causal=Fals
         assert qpad.dtype in (torch.uint8, torch.bool) and qpad.shape == (B, Lq) and qpad.is_contiguous()
         a.qpad = qpad.data_ptr()
         a.mask_mode = MASK_T2V_QUIRK
+        if _mask_mod is not None:
+            a.mask_mod = _mask_mod.data_ptr()
     else:
         a.mask_mode = MASK_KPAD
     if causal:
@@ -578,7 +592,7 @@ def nll_smooth_bwd(logit, label, row_lse, row_grad, eps=0.1):
     return dlogit
 
 
-def saliency_loss_fwd(s_pos, s_neg, label64, vmask, pos_idx, neg_idx, rank_coef, margin, out=None):
+def saliency_loss_fwd(s_pos, s_neg, label64, vmask, pos_idx, neg_idx, rank_coef, margin, out=None, n_valid=None):
     require_gpu(s_pos, s_neg, label64, vmask)
     N, L = s_pos.shape
     assert label64.dtype == torch.float64 and label64.is_contiguous()
@@ -586,23 +600,23 @@ def saliency_loss_fwd(s_pos, s_neg, label64, vmask, pos_idx, neg_idx, rank_coef,
     P = pos_idx.shape[1] if pos_idx is not None else 0
     if out is None:
         out = torch.empty(1, device=s_pos.device, dtype=torch.float32)
-    check(lib().mesm_saliency_loss_fwd(ptr(s_pos), ptr(s_neg), ptr(label64), ptr(vmask),
-                                       ptr(pos_idx), ptr(neg_idx), N, L, P, float(rank_coef),
-                                       float(margin), ptr(out), stream_ptr()),
+    check(lib().mesm_saliency_loss_fwd_nv(ptr(s_pos), ptr(s_neg), ptr(label64), ptr(vmask),
+                                          ptr(pos_idx), ptr(neg_idx), N, L, P, float(rank_coef),
+                                          float(margin), ptr(out), ptr(n_valid), stream_ptr()),
           "mesm_saliency_loss_fwd")
     return out
 
 
-def saliency_loss_bwd(s_pos, s_neg, label64, vmask, pos_idx, neg_idx, rank_coef, margin, gscale, out=None):
+def saliency_loss_bwd(s_pos, s_neg, label64, vmask, pos_idx, neg_idx, rank_coef, margin, gscale, out=None, n_valid=None):
     """out: (ds_pos, ds_neg) to write into (e.g. the two halves of one stacked gradient)"""
     N, L = s_pos.shape
     P = pos_idx.shape[1] if pos_idx is not None else 0
     ds_pos, ds_neg = out if out is not None else (torch.empty_like(s_pos), torch.empty_like(s_neg))
     assert ds_pos.is_contiguous() and ds_neg.is_contiguous()
-    check(lib().mesm_saliency_loss_bwd(ptr(s_pos), ptr(s_neg), ptr(label64), ptr(vmask),
-                                       ptr(pos_idx), ptr(neg_idx), N, L, P, float(rank_coef),
-                                       float(margin), ptr(gscale), ptr(ds_pos), ptr(ds_neg),
-                                       stream_ptr()), "mesm_saliency_loss_bwd")
+    check(lib().mesm_saliency_loss_bwd_nv(ptr(s_pos), ptr(s_neg), ptr(label64), ptr(vmask),
+                                          ptr(pos_idx), ptr(neg_idx), N, L, P, float(rank_coef),
+                                          float(margin), ptr(gscale), ptr(ds_pos), ptr(ds_neg), ptr(n_valid),
+                                          stream_ptr()), "mesm_saliency_loss_bwd")
     return ds_pos, ds_neg
 
 
@@ -632,32 +646,32 @@ def match(logits, spans, tgt_cxw, tgt_xx, tgt_off, Tmax, w_span, w_giou, w_class
 
 
 # ----------------------------------------------------------------------------- fused criterion
-def set_loss_fwd(logits, spans, tgt_cxw, tgt_xx, tgt_off, Tmax, w_span, w_giou, w_class, eos_coef, out4):
+def set_loss_fwd(logits, spans, tgt_cxw, tgt_xx, tgt_off, Tmax, w_span, w_giou, w_class, eos_coef, out4, n_valid=None):
     """Match + span/gIoU/label losses of one decoder layer; writes out4 (4 floats), returns match_q."""
     require_gpu(logits, spans, tgt_cxw, tgt_xx, tgt_off, out4)
     N, Q, _ = logits.shape
     assert logits.is_contiguous() and spans.is_contiguous() and tgt_off.dtype == torch.int32
     _check_match_limits(Q, Tmax)
     match_q = torch.empty(tgt_cxw.shape[0], device=logits.device, dtype=torch.int32)
-    check(lib().mesm_set_loss_fwd(ptr(logits), ptr(spans), ptr(tgt_cxw), ptr(tgt_xx), ptr(tgt_off), N, Q,
-                                  int(Tmax), float(w_span), float(w_giou), float(w_class),
-                                  float(eos_coef), ptr(match_q), ptr(out4), stream_ptr()),
+    check(lib().mesm_set_loss_fwd_nv(ptr(logits), ptr(spans), ptr(tgt_cxw), ptr(tgt_xx), ptr(tgt_off), N, Q,
+                                     int(Tmax), float(w_span), float(w_giou), float(w_class),
+                                     float(eos_coef), ptr(match_q), ptr(out4), ptr(n_valid), stream_ptr()),
           "mesm_set_loss_fwd")
     return match_q
 
 
-def set_loss_bwd(logits, spans, tgt_cxw, tgt_xx, tgt_off, match_q, eos_coef, g3, out=None):
+def set_loss_bwd(logits, spans, tgt_cxw, tgt_xx, tgt_off, match_q, eos_coef, g3, out=None, n_valid=None):
     """out: (dlogits, dspans) to write into (e.g. one layer's slice of the stacked decoder outputs' gradient)"""
     N, Q, _ = logits.shape
     dlogits, dspans = out if out is not None else (torch.empty_like(logits), torch.empty_like(spans))
     assert dlogits.is_contiguous() and dspans.is_contiguous()
-    check(lib().mesm_set_loss_bwd(ptr(logits), ptr(spans), ptr(tgt_cxw), ptr(tgt_xx), ptr(tgt_off),
-                                  ptr(match_q), N, Q, float(eos_coef), ptr(g3), ptr(dlogits),
-                                  ptr(dspans), stream_ptr()), "mesm_set_loss_bwd")
+    check(lib().mesm_set_loss_bwd_nv(ptr(logits), ptr(spans), ptr(tgt_cxw), ptr(tgt_xx), ptr(tgt_off),
+                                     ptr(match_q), N, Q, float(eos_coef), ptr(g3), ptr(dlogits),
+                                     ptr(dspans), ptr(n_valid), stream_ptr()), "mesm_set_loss_bwd")
     return dlogits, dspans
 
 
-def rec_ss_fwd(pv, cmask, ew, wmask, pos, tau, out):
+def rec_ss_fwd(pv, cmask, ew, wmask, pos, tau, out, n_valid=None):
     """-> saved (cn, wn, stats, sim); writes the loss into out (1 float)."""
     require_gpu(pv, cmask, ew, wmask, pos, out)
     N, Lv, D = pv.shape
@@ -669,33 +683,34 @@ def rec_ss_fwd(pv, cmask, ew, wmask, pos, tau, out):
     wn = torch.empty(N, D, device=dev, dtype=torch.float32)
     stats = torch.empty(2 * N, 4, device=dev, dtype=torch.float32)  # rows N.. : per-row loss staging
     sim = torch.empty(N, N, device=dev, dtype=torch.float32)
-    check(lib().mesm_rec_ss_fwd(ptr(pv), ptr(cmask), Lv, ptr(ew), ptr(wmask), Le, ptr(pos), N, D,
-                                float(tau), ptr(cn), ptr(wn), ptr(stats), ptr(sim), ptr(out),
-                                stream_ptr()), "mesm_rec_ss_fwd")
+    check(lib().mesm_rec_ss_fwd_nv(ptr(pv), ptr(cmask), Lv, ptr(ew), ptr(wmask), Le, ptr(pos), N, D,
+                                   float(tau), ptr(cn), ptr(wn), ptr(stats), ptr(sim), ptr(out), ptr(n_valid),
+                                   stream_ptr()), "mesm_rec_ss_fwd")
     return cn, wn, stats, sim
 
 
-def rec_ss_bwd(saved, pos, cmask, wmask, Lv, Le, tau, g):
+def rec_ss_bwd(saved, pos, cmask, wmask, Lv, Le, tau, g, n_valid=None):
     cn, wn, stats, sim = saved
     N, D = cn.shape
     dpv = torch.empty(N, Lv, D, device=cn.device, dtype=torch.float32)
     dew = torch.empty(N, Le, D, device=cn.device, dtype=torch.float32)
-    check(lib().mesm_rec_ss_bwd(ptr(cn), ptr(wn), ptr(pos), ptr(sim), ptr(stats), ptr(cmask), ptr(wmask),
-                                N, D, Lv, Le, float(tau), ptr(g), ptr(dpv), ptr(dew), stream_ptr()),
+    check(lib().mesm_rec_ss_bwd_nv(ptr(cn), ptr(wn), ptr(pos), ptr(sim), ptr(stats), ptr(cmask), ptr(wmask),
+                                   N, D, Lv, Le, float(tau), ptr(g), ptr(dpv), ptr(dew), ptr(n_valid), stream_ptr()),
           "mesm_rec_ss_bwd")
     return dpv, dew
 
 
-def rec_fw_reduce(row_loss, correct, mask, out2):
+def rec_fw_reduce(row_loss, correct, mask, out2, n_valid=None):
     N, Lw = mask.shape
-    check(lib().mesm_rec_fw_reduce(ptr(row_loss), ptr(correct), ptr(mask), N, Lw, ptr(out2), stream_ptr()),
-          "mesm_rec_fw_reduce")
+    check(lib().mesm_rec_fw_reduce_nv(ptr(row_loss), ptr(correct), ptr(mask), N, Lw, ptr(out2), ptr(n_valid),
+                                      stream_ptr()), "mesm_rec_fw_reduce")
 
 
-def rec_fw_rowgrad(mask, g):
+def rec_fw_rowgrad(mask, g, n_valid=None):
     N, Lw = mask.shape
     rg = torch.empty(N * Lw, device=mask.device, dtype=torch.float32)
-    check(lib().mesm_rec_fw_rowgrad(ptr(mask), N, Lw, ptr(g), ptr(rg), stream_ptr()), "mesm_rec_fw_rowgrad")
+    check(lib().mesm_rec_fw_rowgrad_nv(ptr(mask), N, Lw, ptr(g), ptr(rg), ptr(n_valid), stream_ptr()),
+          "mesm_rec_fw_rowgrad")
     return rg
 
 

@@ -38,7 +38,8 @@ def test_struct_sizes_match_the_c_layout():
     # sizeof computed from the field lists of the header (LP64): guards against a drifting mirror
     from mesm_amd import _lib
     assert ctypes.sizeof(_lib.GemmArgs) == 248
-    assert ctypes.sizeof(_lib.AttnArgs) == 248
+    assert ctypes.sizeof(_lib.AttnArgs) == 256
+    assert ctypes.sizeof(_lib.LnArgs) == 168
 
 
 def test_bad_arguments_are_rejected_without_a_gpu():

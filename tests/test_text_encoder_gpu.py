@@ -61,7 +61,9 @@ def test_clip_text_encoder_matches_reference_golden():
     # the end-of-text features through text_projection (text_encoder.py:352-354), pinned by the real reference too
     zp = np.load(os.path.join(GOLDEN, "clip_pooler_tiny.npz"))
     assert out["pooler_output"].dtype == torch.float16
-    check16(out["pooler_output"], torch.from_numpy(zp["pooler_output"].copy()), "pooler_output")
+    # one more fp16 product on top of the tower's output (which itself sits at ~1e-3 of the reference): the bound of
+    # the 12-layer case
+    check16(out["pooler_output"], torch.from_numpy(zp["pooler_output"].copy()), "pooler_output", l2_tol=2e-3)
 
 
 def test_clip_encode_text_wrapper_matches_reference_golden():
