@@ -182,3 +182,28 @@ def prepare_batch_input(batched_data, device, non_blocking=False):
         batched_data["norm_moment"] = moment / duration.unsqueeze(1)
         batched_data["norm_span"] = span_xx_to_cxw(batched_data["norm_moment"])
     return batched_data
+
+
+def pad_pairs(batch, P):
+    """The batch with its pair axis padded to P pairs: copies of pair 0 (finite everywhere, valid masks), each a video
+    group of its own, appended BEHIND the real pairs; `_n_real` = the number of real pairs.  A step captured for P pairs
+    (graphed.StepCache(pairs=...)) replays such a batch with the real count in device memory: padding pairs take no
+    part in any loss, mean, negative draw or mask wrap and get zero gradients, so the step equals the unpadded one.
+    Works on host or device tensors; per-pair lists (QVHighlights targets) are extended the same way."""
+    N = batch["video_feat"].shape[0]
+    if P < N:
+        raise ValueError("pad_pairs: %d pairs do not fit %d" % (N, P))
+    out = dict(batch)
+    out["_n_real"] = N
+    k = P - N
+    if k == 0:
+        return out
+    for key, v in batch.items():
+        if key == "num_clips":
+            out[key] = torch.cat([v, torch.ones(k, dtype=v.dtype, device=v.device)])
+        elif torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == N:
+            idx = torch.cat([torch.arange(N, device=v.device), torch.zeros(k, dtype=torch.int64, device=v.device)])
+            out[key] = v[idx]
+        elif isinstance(v, (list, tuple)) and len(v) == N:
+            out[key] = list(v) + [v[0]] * k
+    return out

@@ -147,7 +147,8 @@ class CriterionFn(Function):
             # k: this layer's index in the stacked (layers, N, Q, 2) decoder outputs (None: a tensor of its own)
             logits, spans = (t[il].contiguous(), t[isp].contiguous()) if k is None else (t[il][k], t[isp][k])
             mq = kn.set_loss_fwd(logits, spans, plan.tgt_cxw, plan.tgt_xx, plan.tgt_off, plan.Tmax,
-                                 m.cost_span, m.cost_giou, m.cost_class, c.eos_coef, lv[slot:slot + 4])
+                                 m.cost_span, m.cost_giou, m.cost_class, c.eos_coef, lv[slot:slot + 4],
+                                 n_valid=spec.n_valid)
             matches.append(mq)
             saved["set%d" % li] = (logits, spans, mq)
         if spec.sal is not None:
@@ -158,7 +159,8 @@ class CriterionFn(Function):
             else:
                 sp, sn = t[ip].contiguous(), t[ineg].contiguous()
             kn.saliency_loss_fwd(sp, sn, spec.sal_label, spec.vmask, spec.pos_idx, spec.neg_idx,
-                                 float(c.rank_coef), float(c.saliency_margin), out=lv[slot:slot + 1])
+                                 float(c.rank_coef), float(c.saliency_margin), out=lv[slot:slot + 1],
+                                 n_valid=spec.n_valid)
             saved["sal"] = (sp, sn)
         if spec.recfw is not None:
             il, slot = spec.recfw
@@ -166,13 +168,13 @@ class CriterionFn(Function):
             C = logit.shape[-1]
             row_loss, row_lse, correct = kn.nll_smooth_fwd(logit.view(-1, C), spec.words_label,
                                                            spec.words_mask.view(-1), 0.1)
-            kn.rec_fw_reduce(row_loss, correct, spec.words_mask, lv[slot:slot + 2])
+            kn.rec_fw_reduce(row_loss, correct, spec.words_mask, lv[slot:slot + 2], n_valid=spec.n_valid)
             saved["recfw"] = (logit, row_lse)
         if spec.recss is not None:
             ipv, iew, slot = spec.recss
             pv, ew = t[ipv].contiguous(), t[iew].contiguous()
             saved["recss"] = kn.rec_ss_fwd(pv, spec.clip_mask, ew, spec.ewords_mask, plan.ss_pos,
-                                           c.recss_tau, lv[slot:slot + 1])
+                                           c.recss_tau, lv[slot:slot + 1], n_valid=spec.n_valid)
             saved["recss_shape"] = (pv.shape[1], ew.shape[1])
         total = kn.weighted_sum(lv, spec.wv)
         ctx.spec, ctx.saved, ctx.n_in = spec, saved, len(t)
@@ -192,7 +194,8 @@ class CriterionFn(Function):
             logits, spans, mq = saved["set%d" % li]
             if k is None:
                 grads[il], grads[isp] = kn.set_loss_bwd(logits, spans, plan.tgt_cxw, plan.tgt_xx,
-                                                        plan.tgt_off, mq, c.eos_coef, gv[slot:slot + 3])
+                                                        plan.tgt_off, mq, c.eos_coef, gv[slot:slot + 3],
+                                                        n_valid=spec.n_valid)
                 continue
             # every layer writes its slice of ONE gradient of the stacked tensor: no select / stack backward
             # launches.  Layers of the stack the criterion does not read (aux_loss off) keep a zero slice.
@@ -202,7 +205,7 @@ class CriterionFn(Function):
                                (torch.empty_like if full else torch.zeros_like)(spec.stack_base[1]))
                 grads[il], grads[isp] = stacked[il]
             kn.set_loss_bwd(logits, spans, plan.tgt_cxw, plan.tgt_xx, plan.tgt_off, mq, c.eos_coef,
-                            gv[slot:slot + 3], out=(stacked[il][0][k], stacked[il][1][k]))
+                            gv[slot:slot + 3], out=(stacked[il][0][k], stacked[il][1][k]), n_valid=spec.n_valid)
         if spec.sal is not None:
             ip, ineg, slot = spec.sal
             sp, sn = saved["sal"]
@@ -210,24 +213,24 @@ class CriterionFn(Function):
                 ds = torch.empty(2 * sp.shape[0], sp.shape[1], device=sp.device, dtype=torch.float32)
                 kn.saliency_loss_bwd(sp, sn, spec.sal_label, spec.vmask, spec.pos_idx, spec.neg_idx,
                                      float(c.rank_coef), float(c.saliency_margin), gv[slot:slot + 1],
-                                     out=(ds[:sp.shape[0]], ds[sp.shape[0]:]))
+                                     out=(ds[:sp.shape[0]], ds[sp.shape[0]:]), n_valid=spec.n_valid)
                 grads[ip] = ds
             else:
                 grads[ip], grads[ineg] = kn.saliency_loss_bwd(
                     sp, sn, spec.sal_label, spec.vmask, spec.pos_idx, spec.neg_idx, float(c.rank_coef),
-                    float(c.saliency_margin), gv[slot:slot + 1])
+                    float(c.saliency_margin), gv[slot:slot + 1], n_valid=spec.n_valid)
         if spec.recfw is not None:
             il, slot = spec.recfw
             logit, row_lse = saved["recfw"]
             C = logit.shape[-1]
-            rg = kn.rec_fw_rowgrad(spec.words_mask, gv[slot:slot + 1])
+            rg = kn.rec_fw_rowgrad(spec.words_mask, gv[slot:slot + 1], n_valid=spec.n_valid)
             grads[il] = kn.nll_smooth_bwd(logit.view(-1, C), spec.words_label, row_lse, rg, 0.1).view(logit.shape)
         if spec.recss is not None:
             ipv, iew, slot = spec.recss
             Lv, Le = saved["recss_shape"]
             grads[ipv], grads[iew] = kn.rec_ss_bwd(saved["recss"], plan.ss_pos, spec.clip_mask,
                                                    spec.ewords_mask, Lv, Le, c.recss_tau,
-                                                   gv[slot:slot + 1])
+                                                   gv[slot:slot + 1], n_valid=spec.n_valid)
         return (None,) + tuple(grads)
 
 
@@ -276,6 +279,10 @@ class Criterion(nn.Module):
             plan = TargetPlan(targets, self.multi_clip, device, self.gamma)
         spec = _Spec()
         spec.crit, spec.plan = self, plan
+        # pairs padded to a captured capacity (batching.pad_pairs): the real count, a device scalar (int32, 1 element)
+        spec.n_valid = targets.get("_n_valid")
+        if spec.n_valid is None and targets.get("_n_real") is not None:  # eager call on a padded batch
+            spec.n_valid = torch.tensor([int(targets["_n_real"])], dtype=torch.int32, device=device)
         names, tensors = [], []
 
         def add(t):

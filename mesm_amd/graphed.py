@@ -59,7 +59,7 @@ class GraphedStep:
     BIG = 1 << 20  # batch tensors above 1 MiB (video_feat, word features) are copied on their own
 
     def __init__(self, model, criterion, batch, dataset_name, warmup=3, instrument=False, reducer=None,
-                 caps=None):
+                 caps=None, group_cap=None):
         """caps: None = exact extents of `batch` (benchmarks); "auto" = bucketed capacities so that other
         batches of the same (N, Lv, Lw, groups) replay; or a dict with any of Lc / Lss / T / Tmax."""
         from .arena import Arena
@@ -75,7 +75,11 @@ class GraphedStep:
         # model.train() itself (train.py:53)
         model.flat_params()
         self._groups = [int(g) for g in batch["num_clips"].tolist()]
-        self.caps = self._resolve_caps(caps, batch)
+        # batches padded to a pair capacity (batching.pad_pairs): the number of REAL pairs is a device scalar of the
+        # captured step; None = the step was captured for exactly its pairs and stays that way
+        self._n_real = batch.get("_n_real")
+        self.batch.pop("_n_real", None)
+        self.caps = self._resolve_caps(caps, batch, group_cap)
         # ONE device arena for: the forward's index plan, the criterion's target plan and the small batch tensors
         host = {k: v.detach().cpu() for k, v in batch.items() if torch.is_tensor(v)}
         for k in ("norm_span", "norm_moment"):
@@ -93,6 +97,8 @@ class GraphedStep:
             if k.startswith("b."):
                 self.batch[k[2:]] = t
         self.batch["_target_plan"] = self.tplan
+        if self._n_real is not None:
+            self.batch["_n_valid"] = v["p.n_valid"]
         gb = model.gradbuf()
         gb.ensure(dev)
         kn.set_seed_offset(self.counter)
@@ -141,22 +147,25 @@ class GraphedStep:
         self._ptrs = self._param_ptrs()
 
     # ------------------------------------------------------------------ capture-time capacities
-    def _resolve_caps(self, caps, batch):
+    def _resolve_caps(self, caps, batch, group_cap=None):
+        """group_cap (with caps="auto"): capacities for video groups of up to that many queries (the dataset's
+        maximum: every grouping then fits one graph per pair bucket), GT-clip runs of any length"""
         if caps is None:
             return {}
         if caps == "auto":
             caps = {}
             N, Lv = batch["video_mask"].shape
             if self.model.rec_fw:
-                caps["Lc"] = min(Lv, _round_up(int(batch["clip_mask"].sum(1).max()), 8))
+                caps["Lc"] = Lv if group_cap else min(Lv, _round_up(int(batch["clip_mask"].sum(1).max()), 8))
+            gmax = max(max(self._groups), group_cap or 0)
             if self.model.rec_ss:
-                caps["M"] = max(self._groups)  # sentence slots per pair (SS branch): other groupings with <= M fit
+                caps["M"] = gmax  # sentence slots per pair (SS branch): other groupings with <= M fit
             if self.model.rec_ss and self.dataset_name == "qvhighlights":
                 vm = batch["video_mask"].cpu()
                 lens = [int(c.sum()) for c in torch.split(vm, self._groups)]
-                full = all(g == 1 for g in self._groups) and bool(vm.all())
+                full = all(g == 1 for g in self._groups) and bool(vm.all()) and not group_cap
                 # 64 = one key tile of the attention kernels; a group cannot hold more than its pairs' clips
-                caps["Lss"] = Lv if full else min(_round_up(max(lens), 64), max(self._groups) * Lv)
+                caps["Lss"] = Lv if full else (gmax * Lv if group_cap else min(_round_up(max(lens), 64), gmax * Lv))
             if self.crit.multi_clip:
                 Q = self.model.num_queries
                 tmax = max(len(t["spans"]) for t in batch["norm_span"])
@@ -188,7 +197,7 @@ class GraphedStep:
                                     clip_mask=host["clip_mask"].numpy() if "clip_mask" in host else None,
                                     neg_index=neg_index, masked_words=masked_words,
                                     words_weight=host.get("words_weight"), Lc_cap=self.caps.get("Lc"),
-                                    Lss_cap=self.caps.get("Lss"), M_cap=self.caps.get("M"))
+                                    Lss_cap=self.caps.get("Lss"), M_cap=self.caps.get("M"), n_valid=self._n_real)
         tarr, tmeta = TargetPlan.arrays(host, self.crit.multi_clip, self.crit.gamma, T_cap=self.caps.get("T"),
                                         Tmax_cap=self.caps.get("Tmax"))
         arr = {"p." + k: v for k, v in parr.items()}
@@ -230,17 +239,22 @@ class GraphedStep:
             # exact-extent graphs (caps=None) are tied to their grouping; with capacities any grouping of the
             # same number of pairs fits as long as its largest group does (checked by the plan below)
             raise ValueError("GraphedStep.load_batch: group sizes changed %s -> %s" % (self._groups, groups))
+        n_real = batch.get("_n_real")
+        if (n_real is None) != (self._n_real is None):
+            raise ValueError("GraphedStep.load_batch: the step was captured %s a device-side pair count"
+                             % ("with" if self._n_real is not None else "without"))
         old_groups, self._groups = self._groups, groups
+        old_real, self._n_real = self._n_real, n_real
         try:
             self._load_batch(batch, redraw)
         except ValueError:
-            self._groups = old_groups
+            self._groups, self._n_real = old_groups, old_real
             raise
 
     def _load_batch(self, batch, redraw):
         for k, cur in self.batch.items():
             v = batch.get(k)
-            if k == "num_clips":
+            if k == "num_clips" or k.startswith("_"):
                 continue
             if torch.is_tensor(cur) and torch.is_tensor(v) and cur.shape != v.shape:
                 raise ValueError("GraphedStep.load_batch: %s changed shape %s -> %s"
@@ -270,6 +284,8 @@ class GraphedStep:
         self.tplan.sizes, self.tplan.sumT = tmeta["sizes"], tmeta["sumT"]
         for k, cur in self.batch.items():
             v = batch.get(k)
+            if k.startswith("_"):
+                continue
             if k == "num_clips":
                 self.batch[k] = v  # host-side bookkeeping only (the step reads the plans)
                 continue
@@ -316,7 +332,7 @@ class GraphedStep:
         """New negative-query indices and MLM word choices (host RNG, like the reference does on every forward),
         written into the static index tensors the graph reads (one arena upload)."""
         m = self.model
-        neg = m.draw_neg_index(self._groups).numpy()
+        neg = m.draw_neg_padded(self._groups, self._n_real).numpy()
         mw = None
         if hasattr(self.plan, "masked_words"):
             mw = m.draw_masked_words(self._wm_cpu, self.batch["words_weight"]).bool().numpy()
@@ -361,13 +377,25 @@ class StepCache:
     CLIP_KEYS = ("video_feat", "video_mask", "clip_mask", "saliency_label")
     WORD_KEYS = ("words_id", "words_mask", "words_weight", "unknown_mask", "words_label")
 
-    def __init__(self, model, criterion, dataset_name, reducer=None, max_graphs=16, pad=None):
+    def __init__(self, model, criterion, dataset_name, reducer=None, max_graphs=16, pad=None, pairs=None,
+                 group_caps=None):
+        """pairs: also pad the PAIR axis up to the next multiple of `pairs` (batching.pad_pairs: dummy pairs behind
+        the real ones, the real count a device scalar of the captured step) -- the reference's loaders emit a different
+        number of pairs almost every batch (an item is a video with all its queries, dataset/base.py:116-162), and
+        with pairs=8 a QVHighlights epoch of 12-group batches replays from a handful of graphs.
+        group_caps: ascending group-size buckets, e.g. (5, 9): a batch is served by a graph captured with room for
+        video groups of up to the smallest bucket that holds its largest group (9 = the QVHighlights maximum), so that
+        (pair bucket, group bucket) alone decide which graph a batch replays -- groups cost SS-MESM key slots
+        (group size x clips per pair), which is why there is more than one bucket."""
         self.model, self.crit, self.dataset_name = model, criterion, dataset_name
         self.reducer = reducer
         self.steps = {}
         self.max_graphs = max_graphs
         self.pad = pad
+        self.pairs = pairs
+        self.group_caps = tuple(sorted(group_caps)) if group_caps else None
         self.captures = 0
+        self.replays = 0
 
     @staticmethod
     def key(batch):
@@ -400,20 +428,32 @@ class StepCache:
 
     def run(self, batch, redraw=True):
         batch = self.padded(batch)
+        if self.pairs:
+            from .batching import pad_pairs
+            n = batch["video_feat"].shape[0]
+            batch = pad_pairs(batch, _round_up(n, self.pairs))
         k = self.key(batch)
+        gcap = None
+        if self.group_caps:
+            gmax = int(batch["num_clips"].max())
+            gcap = next((c for c in self.group_caps if c >= gmax), gmax)
+            k = k + (gcap,)
         for gs in self.steps.get(k, []):
             try:
                 gs.load_batch(batch, redraw=redraw)
             except ValueError:
                 continue
+            self.replays += 1
             return gs.run(redraw=False), gs
         if sum(len(v) for v in self.steps.values()) >= self.max_graphs:
             self.steps.pop(next(iter(self.steps)))
         from .synthetic import to_device
-        static = to_device({kk: (v.clone() if torch.is_tensor(v) else v) for kk, v in batch.items()},
+        static = to_device({kk: (v.clone() if torch.is_tensor(v) else v) for kk, v in batch.items() if kk != "_n_real"},
                            next(self.model.parameters()).device)
+        if "_n_real" in batch:
+            static["_n_real"] = batch["_n_real"]
         gs = GraphedStep(self.model, self.crit, static, self.dataset_name, warmup=1, reducer=self.reducer,
-                         caps="auto")
+                         caps="auto", group_cap=gcap)
         self.steps.setdefault(k, []).append(gs)
         self.captures += 1
         return gs.run(redraw=redraw), gs

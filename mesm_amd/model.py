@@ -250,8 +250,31 @@ class MESM(nn.Module):
         return masked
 
     # ------------------------------------------------------------------ host-side plan
+    @staticmethod
+    def real_groups(groups, n_valid):
+        """the video groups that hold the first n_valid pairs (the rest are padding pairs, batching.pad_pairs)"""
+        if n_valid is None:
+            return list(groups)
+        real, tot = [], 0
+        for g in groups:
+            if tot >= n_valid:
+                break
+            real.append(g)
+            tot += g
+        if tot != n_valid:
+            raise ValueError("n_valid = %d does not end at a group boundary of %s" % (n_valid, list(groups)))
+        return real
+
+    @classmethod
+    def draw_neg_padded(cls, groups, n_valid):
+        """draw_neg_index over the REAL groups; padding pairs point at pair 0 (their rows are never read by a loss)"""
+        real = cls.real_groups(groups, n_valid)
+        neg = cls.draw_neg_index(real)
+        pad = sum(groups) - sum(real)
+        return torch.cat([neg, torch.zeros(pad, dtype=neg.dtype)]) if pad else neg
+
     def plan_arrays(self, vm, wm, groups, dataset_name, is_training, clip_mask=None, neg_index=None,
-                    masked_words=None, words_weight=None, Lc_cap=None, Lss_cap=None, M_cap=None):
+                    masked_words=None, words_weight=None, Lc_cap=None, Lss_cap=None, M_cap=None, n_valid=None):
         """All data-dependent host decisions of model.py:184-207, :260, :307-325 as numpy arrays
         ({name: array}, meta) -- pure host arithmetic on the (small) masks, no device work.
 
@@ -263,8 +286,11 @@ class MESM(nn.Module):
         N, Lv = vm.shape
         arr, meta = {}, {"groups": list(groups)}
         if neg_index is None:
-            neg_index = self.draw_neg_index(groups).numpy()
+            neg_index = self.draw_neg_padded(groups, n_valid).numpy()
         arr["neg_index"] = np.asarray(neg_index, dtype=np.int64)
+        if n_valid is not None:
+            # the number of REAL pairs as a device scalar: modulus of the attention mask quirk, extent of every loss
+            arr["n_valid"] = np.asarray([n_valid], dtype=np.int32)
         if self.rec_ss:
             M = max(groups)
             if M_cap is not None:  # sentence slots per pair padded to a fixed extent (masked queries / keys)
@@ -346,7 +372,8 @@ class MESM(nn.Module):
 
     @torch.no_grad()
     def make_plan(self, video_mask, words_mask, num_clips, dataset_name, is_training, words_weight=None,
-                  clip_mask=None, neg_index=None, masked_words=None, device=None, Lc_cap=None, Lss_cap=None):
+                  clip_mask=None, neg_index=None, masked_words=None, device=None, Lc_cap=None, Lss_cap=None,
+                  n_valid=None):
         """plan_arrays on host copies of the masks, uploaded to `device` in one transfer (arena.Arena)."""
         from .arena import Arena
         device = device or video_mask.device
@@ -354,7 +381,7 @@ class MESM(nn.Module):
         arr, meta = self.plan_arrays(_np(video_mask), _np(words_mask), [int(g) for g in num_clips.tolist()],
                                      dataset_name, is_training, clip_mask=_np(clip_mask), neg_index=_np(neg_index),
                                      masked_words=_np(masked_words), words_weight=words_weight, Lc_cap=Lc_cap,
-                                     Lss_cap=Lss_cap)
+                                     Lss_cap=Lss_cap, n_valid=n_valid)
         pl = self.plan_from(Arena(arr, device).views, meta)
         return pl
 
@@ -382,7 +409,7 @@ class MESM(nn.Module):
             plan = self.make_plan(video_mask, words_mask, num_clips, kwargs["dataset_name"], is_training,
                                   words_weight=words_weight, clip_mask=kwargs.get("clip_mask"),
                                   neg_index=kwargs.get("neg_index"),
-                                  masked_words=kwargs.get("masked_words"), device=dev)
+                                  masked_words=kwargs.get("masked_words"), device=dev, n_valid=kwargs.get("_n_real"))
 
         # The step's independent chains run SIDE BY SIDE (ops.lockstep): every round, the blocks the chains are at
         # become one autograd node whose launch phases are shared -- the small problems of the SS-MESM / MLM stacks
@@ -399,6 +426,8 @@ class MESM(nn.Module):
                 x = yield from m.steps(x)
             return x
 
+        # batches padded to a captured pair capacity: the real pair count is a device scalar of the plan
+        kn.set_mask_mod(getattr(plan, "n_valid", None))
         with _scope("inproj"):
             vid_pad = (~video_mask).contiguous()
             words_pad = (~words_mask).contiguous()

@@ -319,3 +319,45 @@ def test_step_cache_replays_other_groupings_and_padded_extents(workload):
     # a grouping whose largest group exceeds the captured capacity needs its own graph
     cache.run(make([6, 2] * 4, w["Lv"], w["Lw"], 4), redraw=False)
     assert cache.captures == 2
+
+
+def _qvh_group_sizes(rng, n_groups):
+    """queries per video, roughly the QVHighlights train histogram (7,218 queries / 2,214 videos: mean 3.26, max 9)"""
+    sizes, probs = list(range(1, 10)), [0.18, 0.22, 0.20, 0.15, 0.10, 0.07, 0.04, 0.025, 0.015]
+    return [rng.choices(sizes, probs)[0] for _ in range(n_groups)]
+
+
+def test_a_loader_like_epoch_replays_from_a_handful_of_graphs():
+    """The reference's loaders emit a different number of pairs almost every batch (an item is a video with ALL its
+    queries, dataset/base.py:116-162; batch_size counts videos).  StepCache(pairs=8, group_caps=(5, 9)) pads the pair
+    axis with dummy pairs up to the next multiple of 8 (the real count is a device scalar of the captured step: modulus
+    of the attention mask quirk, extent of every loss) and buckets the largest group: 40 batches of 12 videos replay
+    from <= 6 graphs, and a replayed step equals the eager step on the UNPADDED batch."""
+    import random
+    from mesm_amd import synthetic
+    from mesm_amd.graphed import StepCache
+    args, model, crit = _build("C3b")
+    w = synthetic.WORKLOADS["C3b"]
+    cache = StepCache(model, crit, args.dataset_name, pad=(w["Lv"], w["Lw"]), pairs=8, group_caps=(5, 9))
+    rng = random.Random(11)
+    n_batches, checked = 40, 0
+    for i in range(n_batches):
+        groups = _qvh_group_sizes(rng, 12)
+        b = synthetic.make_batch(w["dataset_name"], groups, w["Lv"], w["Lw"], w["v_feat_dim"], w["t_feat_dim"],
+                                 w["vocab_size"] + 1, seed=100 + i, ragged=True)
+        tg, gs = cache.run(b, redraw=True)
+        if i % 13 == 5:  # the replayed step against the eager step on the unpadded batch, same host draws
+            tg = float(tg)
+            flat_g = model.gradbuf().flat.clone()
+            n = sum(groups)
+            bd = synthetic.to_device(b, dev())
+            plan = model.make_plan(bd["video_mask"], gs._wm_cpu[:n], bd["num_clips"], args.dataset_name, True,
+                                   words_weight=bd["words_weight"], clip_mask=bd["clip_mask"],
+                                   neg_index=gs.plan.neg_index[:n], masked_words=gs.plan.masked_words[:n], device=dev())
+            te, flat_e = _eager(model, crit, bd, args.dataset_name, plan)
+            assert abs(te - tg) < 2e-5 * max(1.0, abs(te)), (groups, te, tg)
+            assert float((flat_e - flat_g).norm()) / max(float(flat_e.norm()), 1e-6) < 2e-4, groups
+            checked += 1
+    assert checked >= 3
+    assert cache.captures <= 6, cache.captures
+    assert cache.replays >= 0.85 * n_batches, (cache.replays, cache.captures)  # 40 batches: at most 6 are captures
