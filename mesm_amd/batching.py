@@ -184,7 +184,7 @@ def prepare_batch_input(batched_data, device, non_blocking=False):
     return batched_data
 
 
-def pad_pairs(batch, P):
+def pad_pairs(batch, P, big=1 << 20):
     """The batch with its pair axis padded to P pairs: copies of pair 0 (finite everywhere, valid masks), each a video
     group of its own, appended BEHIND the real pairs; `_n_real` = the number of real pairs.  A step captured for P pairs
     (graphed.StepCache(pairs=...)) replays such a batch with the real count in device memory: padding pairs take no
@@ -201,6 +201,11 @@ def pad_pairs(batch, P):
     for key, v in batch.items():
         if key == "num_clips":
             out[key] = torch.cat([v, torch.ones(k, dtype=v.dtype, device=v.device)])
+        elif torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == N and not v.is_cuda \
+                and v.numel() * v.element_size() > big and key in ("video_feat", "words_id"):
+            # big host feature tensors keep their N rows: graphed.GraphedStep copies them into the first N rows of its
+            # static input, and whatever finite rows an earlier batch left behind serve as the padding pairs
+            continue
         elif torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == N:
             idx = torch.cat([torch.arange(N, device=v.device), torch.zeros(k, dtype=torch.int64, device=v.device)])
             out[key] = v[idx]

@@ -104,6 +104,10 @@ class GraphedStep:
         kn.set_seed_offset(self.counter)
         try:
             side = capture_stream(dev)
+            # autograd graphs of earlier (eager) steps can live on through reference cycles and keep their
+            # AccumulateGrad nodes -- pinned to the stream THEY ran on -- alive: collect them before the first warm-up
+            import gc
+            gc.collect()
             side.wait_stream(torch.cuda.current_stream())
             # A reducer learns its bucket schedule on its first step, so the first graph warms up with the
             # collectives live (every rank is there together).  Later graphs of a StepCache are captured whenever
@@ -193,6 +197,9 @@ class GraphedStep:
         criterion's target plan, "b." batch tensors below BIG bytes; plus the two metas and the word mask."""
         m = self.model
         wm = self._words_mask_host(host)
+        P = host["video_mask"].shape[0]
+        if wm.shape[0] < P:  # a big feature tensor that arrived with its real rows only (batching.pad_pairs)
+            wm = torch.cat([wm, wm[:1].expand(P - wm.shape[0], wm.shape[1])])
         parr, pmeta = m.plan_arrays(host["video_mask"].numpy(), wm.numpy(), self._groups, self.dataset_name, True,
                                     clip_mask=host["clip_mask"].numpy() if "clip_mask" in host else None,
                                     neg_index=neg_index, masked_words=masked_words,
@@ -257,6 +264,9 @@ class GraphedStep:
             if k == "num_clips" or k.startswith("_"):
                 continue
             if torch.is_tensor(cur) and torch.is_tensor(v) and cur.shape != v.shape:
+                if k in ("video_feat", "words_id") and cur.shape[1:] == v.shape[1:] and v.shape[0] <= cur.shape[0] \
+                        and self._n_real is not None:
+                    continue  # the real rows only: the rest of the static input keeps (finite) older rows
                 raise ValueError("GraphedStep.load_batch: %s changed shape %s -> %s"
                                  % (k, tuple(cur.shape), tuple(v.shape)))
         host = {k: (v.detach().cpu() if v.is_cuda and v.numel() * v.element_size() <= self.BIG else v)
@@ -293,7 +303,7 @@ class GraphedStep:
                 if not cur.is_cuda:
                     self.batch[k] = v  # host-side inputs (words_weight) are only read by redraw()
                 elif v.is_cuda:
-                    cur.copy_(v, non_blocking=True)
+                    cur[:v.shape[0]].copy_(v, non_blocking=True)
                 else:
                     self._stage_big(k, cur, v)
         self._turn ^= 1
@@ -315,15 +325,16 @@ class GraphedStep:
         if st[j] is None:
             st[j] = torch.empty_like(cur)
         main, cs = torch.cuda.current_stream(), self._copy_stream
+        n = v.shape[0]  # (fewer rows than the static input: a padded batch's real pairs)
         with torch.cuda.stream(cs):
             ev = self._d2d_done.get((k, j))
             if ev is not None:
                 cs.wait_event(ev)
-            st[j].copy_(v, non_blocking=True)
+            st[j][:n].copy_(v, non_blocking=True)
             done = torch.cuda.Event()
             done.record(cs)
         main.wait_event(done)
-        cur.copy_(st[j], non_blocking=True)
+        cur[:n].copy_(st[j][:n], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(main)
         self._d2d_done[(k, j)] = ev
@@ -399,7 +410,9 @@ class StepCache:
 
     @staticmethod
     def key(batch):
-        return (tuple(batch["video_feat"].shape), tuple(batch["words_id"].shape))
+        # (the pair extent from a mask: big feature tensors of a pair-padded batch arrive with their real rows only)
+        n = batch["video_mask"].shape[0]
+        return ((n,) + tuple(batch["video_feat"].shape[1:]), (n,) + tuple(batch["words_id"].shape[1:]))
 
     @staticmethod
     def _pad_dim1(t, L):
@@ -452,6 +465,11 @@ class StepCache:
                            next(self.model.parameters()).device)
         if "_n_real" in batch:
             static["_n_real"] = batch["_n_real"]
+            P = static["video_mask"].shape[0]
+            for kk in ("video_feat", "words_id"):  # big tensors arrive with their real rows: pad on the device
+                t = static[kk]
+                if t.shape[0] < P:
+                    static[kk] = torch.cat([t, t[:1].expand((P - t.shape[0],) + tuple(t.shape[1:]))]).contiguous()
         gs = GraphedStep(self.model, self.crit, static, self.dataset_name, warmup=1, reducer=self.reducer,
                          caps="auto", group_cap=gcap)
         self.steps.setdefault(k, []).append(gs)
