@@ -160,6 +160,12 @@ int mesm_gemm_group(const MesmGemmArgs* args, int32_t n, void* stream);
 int mesm_gemm_tape(int32_t record);
 int mesm_gemm_tape_replay(void* stream, int32_t reps, double* total_ms, int64_t* launches,
                           double* total_flops, double* total_bytes);
+/* One recorded launch timed alone (`reps` back-to-back issues under one event pair) and what it carries:
+ * shapes = up to 64 x (M, N, K, flags) int32, flags = split_k | a_layout << 8 | b_layout << 9 | grouped << 10.
+ * Diagnostic (tools/tape_profile.py); mesm_gemm_tape_size = number of recorded launches. */
+int mesm_gemm_tape_entry(void* stream, int32_t idx, int32_t reps, double* ms, int32_t* n_problems,
+                         int32_t* shapes);
+int mesm_gemm_tape_size(void);
 
 /* ------------------------------------------------------------------------- */
 /*
@@ -448,13 +454,16 @@ int mesm_saliency_loss_bwd(const float* s_pos, const float* s_neg, const double*
  * HungarianMatcher.forward, matcher.py:39-117:
  *   C[b,q,t] = w_span * L1(span_cxw[b,q], tgt_cxw[t]) - w_giou * gIoU(xx(span), tgt_xx[t])
  *              - w_class * softmax(logits[b,q])[0]
- * and the optimal assignment of the T_b <= 16 targets of pair b to the Q <= 32 queries
+ * and the optimal assignment between the T_b <= 64 targets of pair b and the Q <= 64 queries
  * (shortest-augmenting-path Hungarian in fp64 on the fp32 costs, the algorithm behind
  * scipy.optimize.linear_sum_assignment 1.9.1 pinned by the reference; identical result
- * whenever the optimum is unique).  tgt_off (N+1) int32 prefix offsets into
- * tgt_cxw / tgt_xx (sum T, 2).
+ * whenever the optimum is unique).  Any shape within those extents, as the reference's call on
+ * a (Q x T_b) block (matcher.py:108-117): with T_b < Q every target gets a query, with T_b >= Q
+ * every query gets a target and T_b - Q targets stay unmatched.  The work arrays are fp64 in LDS
+ * (60 KB per workgroup): MESM_EINVAL when one problem does not fit (never within the extents).
+ * tgt_off (N+1) int32 prefix offsets into tgt_cxw / tgt_xx (sum T, 2).
  * cost (N, Q, Tmax) optional output; match_q (sum T) int32: query matched to each
- * target, in target order.
+ * target, in target order, -1 for a target left unmatched.
  */
 int mesm_match(const float* logits, const float* spans, const float* tgt_cxw,
                const float* tgt_xx, const int32_t* tgt_off, int32_t N, int32_t Q,
@@ -468,11 +477,11 @@ int mesm_match(const float* logits, const float* spans, const float* tgt_cxw,
  * Hungarian match + span / gIoU / label losses of ONE decoder layer.  Replaces
  * HungarianMatcher.forward (matcher.py:39-117) followed by Criterion.loss_spans
  * (criterion.py:71-110) and Criterion.loss_labels (criterion.py:112-137):
- *   out4[0] = mean |src - tgt| over the matched (sumT x 2) elements
+ *   out4[0] = mean |src - tgt| over the matched (M x 2) elements, M = sum_b min(T_b, Q)
  *   out4[1] = mean (1 - gIoU(xx(src), tgt_xx)) over the matched pairs
  *   out4[2] = mean over N*Q of -log_softmax(logits)[cls] * {1, eos_coef}[cls]
  *             (cls = 0 on matched queries, 1 elsewhere; plain mean, quirk Q9)
- *   out4[3] = class_error = 100 - 100 * #(matched & argmax == 0) / sumT
+ *   out4[3] = class_error = 100 - 100 * #(matched & argmax == 0) / M
  * match_q (sumT) int32 as in mesm_match.  One workgroup, deterministic sums.
  * bwd: dlogits, dspans (N, Q, 2) fully written; g3 = device pointer to the upstream
  * gradients of out4[0..2] (three consecutive floats).

@@ -99,7 +99,7 @@ class HungarianMatcher(nn.Module):
 
     @torch.no_grad()
     def match_device(self, outputs, plan):
-        """match_q (sumT) int32 on the device: the query assigned to every target."""
+        """match_q (sumT) int32 on the device: the query assigned to every target (-1: none, T > Q only)."""
         return kn.match(outputs["pred_logits"].detach().contiguous(),
                         outputs["pred_spans"].detach().contiguous(), plan.tgt_cxw, plan.tgt_xx,
                         plan.tgt_off, plan.Tmax, self.cost_span, self.cost_giou, self.cost_class)
@@ -114,6 +114,7 @@ class HungarianMatcher(nn.Module):
         for s in plan.sizes:
             q = mq[start:start + s]
             order = torch.argsort(q)
+            order = order[q[order] >= 0]  # targets left unmatched (a pair with more targets than queries)
             res.append((q[order], order.to(torch.int64)))
             start += s
         return res

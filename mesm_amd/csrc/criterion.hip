@@ -33,9 +33,11 @@ __device__ __forceinline__ float tie(float a, float b) {  // d max(a,b)/da with 
 }
 
 // ------------------------------------------------------------------------------------------
-// Shortest-augmenting-path assignment (rows = targets, cols = queries, T <= Q) in fp64 on the
-// fp32 costs -- the algorithm of scipy.optimize.linear_sum_assignment.  Work arrays live in LDS,
-// element i of thread `tid` at [i * nthr + tid] (conflict-free).
+// Shortest-augmenting-path assignment in fp64 on the fp32 costs -- the algorithm of
+// scipy.optimize.linear_sum_assignment (matcher.py:108-117 calls it on a (Q x T) cost block of any shape).
+// Like scipy the solver walks the SHORTER side as rows: targets when T < Q (every target gets a query),
+// queries when T >= Q (every query gets a target, T - Q targets stay unmatched: match_q = -1).
+// Work arrays live in LDS, element i of thread `tid` at [i * nthr + tid] (conflict-free).
 struct Sap {
   double *cost, *u, *v, *minv;
   int *p, *way;
@@ -48,30 +50,48 @@ struct Sap {
   __device__ __forceinline__ int& P(int j) { return p[j * nthr + tid]; }
   __device__ __forceinline__ int& W(int j) { return way[j * nthr + tid]; }
   __device__ __forceinline__ uint8_t& US(int j) { return used[j * nthr + tid]; }
+  // carve the arrays for `nthr` problems of at most Tmax x Q out of a dynamic LDS block
+  __device__ void carve(unsigned char* smem, int Tmax, int Q_, int nthr_, int tid_) {
+    nthr = nthr_; tid = tid_; Q = Q_;
+    const int M1 = (Tmax > Q_ ? Tmax : Q_) + 1;
+    double* dp = reinterpret_cast<double*>(smem);
+    cost = dp; dp += (size_t)Tmax * Q_ * nthr;
+    u = dp; dp += (size_t)M1 * nthr;
+    v = dp; dp += (size_t)M1 * nthr;
+    minv = dp; dp += (size_t)M1 * nthr;
+    int* ip = reinterpret_cast<int*>(dp);
+    p = ip; ip += (size_t)M1 * nthr;
+    way = ip; ip += (size_t)M1 * nthr;
+    used = reinterpret_cast<uint8_t*>(ip);
+  }
 };
 
+// QROWS = false: rows = targets 1..T, columns = queries 1..Q (T < Q); true: rows = queries, columns = targets.
+// On return P(j) = the row assigned to column j (0 = none).
+template <bool QROWS>
 __device__ void sap_solve(Sap& s, int T, int Q) {
-  for (int i = 0; i <= T; ++i) s.U(i) = 0.0;
-  for (int j = 0; j <= Q; ++j) { s.V(j) = 0.0; s.P(j) = 0; s.W(j) = 0; }
-  for (int i = 1; i <= T; ++i) {
+  const int nR = QROWS ? Q : T, nC = QROWS ? T : Q;
+  for (int i = 0; i <= nR; ++i) s.U(i) = 0.0;
+  for (int j = 0; j <= nC; ++j) { s.V(j) = 0.0; s.P(j) = 0; s.W(j) = 0; }
+  for (int i = 1; i <= nR; ++i) {
     s.P(0) = i;
     int j0 = 0;
-    for (int j = 0; j <= Q; ++j) { s.MV(j) = 1e300; s.US(j) = 0; }
+    for (int j = 0; j <= nC; ++j) { s.MV(j) = 1e300; s.US(j) = 0; }
     do {
       s.US(j0) = 1;
       const int i0 = s.P(j0);
       double delta = 1e300;
       int j1 = 0;
       const double ui0 = s.U(i0);
-      for (int j = 1; j <= Q; ++j) {
+      for (int j = 1; j <= nC; ++j) {
         if (!s.US(j)) {
-          const double cur = s.C(i0 - 1, j - 1) - ui0 - s.V(j);
+          const double cur = (QROWS ? s.C(j - 1, i0 - 1) : s.C(i0 - 1, j - 1)) - ui0 - s.V(j);
           double mv = s.MV(j);
           if (cur < mv) { mv = cur; s.MV(j) = cur; s.W(j) = j0; }
           if (mv < delta) { delta = mv; j1 = j; }
         }
       }
-      for (int j = 0; j <= Q; ++j) {
+      for (int j = 0; j <= nC; ++j) {
         if (s.US(j)) { s.U(s.P(j)) += delta; s.V(j) -= delta; }
         else s.MV(j) -= delta;
       }
@@ -86,14 +106,77 @@ __device__ void sap_solve(Sap& s, int T, int Q) {
 }
 
 __host__ __device__ inline size_t sap_bytes_per_thread(int Tmax, int Q) {
-  // doubles: cost T*Q, u T+1, v Q+1, minv Q+1;  ints: p, way (Q+1 each);  bytes: used Q+1 (padded to 8)
-  size_t d = (size_t)Tmax * Q + (Tmax + 1) + 2 * (Q + 1);
-  return d * 8 + 2 * (size_t)(Q + 1) * 4 + (size_t)((Q + 1 + 7) / 8 * 8);
+  // doubles: cost T*Q, u / v / minv max(T,Q)+1 each;  ints: p, way;  bytes: used (padded to 8)
+  const size_t M1 = (size_t)(Tmax > Q ? Tmax : Q) + 1;
+  return ((size_t)Tmax * Q + 3 * M1) * 8 + 2 * M1 * 4 + (M1 + 7) / 8 * 8;
+}
+// pairs solved side by side by one workgroup (one thread each) within 60 KB of LDS; 0 = does not fit
+inline int sap_pairs_per_pass(int Tmax, int Q, int N) {
+  const size_t per = sap_bytes_per_thread(Tmax, Q);
+  int P = 64;
+  while (P > 1 && per * P > 60 * 1024) P >>= 1;
+  if (per * P > 60 * 1024) return 0;
+  while (P > 1 && P / 2 >= N) P >>= 1;
+  return P;
 }
 
-// One thread per pair (chunks of blockDim.x pairs); one workgroup, so the four loss sums are
-// reduced without atomics (deterministic).  out[0..3] = loss_span, loss_giou, loss_label,
-// class_error.
+// fp32 cost block of pair b exactly as matcher.py:70-105 builds it, widened to fp64 for the solver
+__device__ __forceinline__ void sap_fill_cost(Sap& s, const float* __restrict__ logits, const float* __restrict__ spans,
+                                              const float* __restrict__ tgt_cxw, const float* __restrict__ tgt_xx,
+                                              int b, int t0, int T, int Q, float w_span, float w_giou, float w_class,
+                                              float* __restrict__ cost_out, int Tmax) {
+  for (int q = 0; q < Q; ++q) {
+    const float l0 = logits[((int64_t)b * Q + q) * 2], l1 = logits[((int64_t)b * Q + q) * 2 + 1];
+    const float mx = fmaxf(l0, l1);
+    const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
+    const float prob0 = e0 / (e0 + e1);
+    const float cx = spans[((int64_t)b * Q + q) * 2], w = spans[((int64_t)b * Q + q) * 2 + 1];
+    const float x1 = cx - 0.5f * w, x2 = cx + 0.5f * w;
+    for (int t = 0; t < T; ++t) {
+      const float tc = tgt_cxw[(int64_t)(t0 + t) * 2], tw = tgt_cxw[(int64_t)(t0 + t) * 2 + 1];
+      const float g1 = tgt_xx[(int64_t)(t0 + t) * 2], g2 = tgt_xx[(int64_t)(t0 + t) * 2 + 1];
+      const float c_span = fabsf(cx - tc) + fabsf(w - tw);
+      Giou gi;
+      const float giou = giou_1d(x1, x2, g1, g2, gi);
+      const float c = w_span * c_span + w_giou * (-giou) + w_class * (-prob0);
+      s.C(t, q) = (double)c;
+      if (cost_out) cost_out[((int64_t)b * Q + q) * Tmax + t] = c;
+    }
+  }
+}
+
+// the assignment of pair b: match_q[t0 + t] = query of target t, -1 where the target stays unmatched (T > Q)
+__device__ __forceinline__ void sap_assign(Sap& s, int t0, int T, int Q, int32_t* __restrict__ match_q) {
+  if (T < Q) {
+    sap_solve<false>(s, T, Q);
+    for (int j = 1; j <= Q; ++j)
+      if (s.P(j) != 0) match_q[t0 + s.P(j) - 1] = j - 1;
+  } else {
+    sap_solve<true>(s, T, Q);
+    for (int j = 1; j <= T; ++j) match_q[t0 + j - 1] = s.P(j) - 1;
+  }
+}
+
+// matcher.py:39-117 alone (one thread per pair, blockDim.x pairs per workgroup)
+__global__ __launch_bounds__(64) void match_kernel(
+    const float* __restrict__ logits, const float* __restrict__ spans,
+    const float* __restrict__ tgt_cxw, const float* __restrict__ tgt_xx,
+    const int32_t* __restrict__ tgt_off, int N, int Q, int Tmax, float w_span, float w_giou,
+    float w_class, float* __restrict__ cost_out, int32_t* __restrict__ match_q) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  Sap s;
+  s.carve(smem, Tmax, Q, blockDim.x, threadIdx.x);
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= N) return;
+  const int t0 = tgt_off[b];
+  const int T = tgt_off[b + 1] - t0;
+  sap_fill_cost(s, logits, spans, tgt_cxw, tgt_xx, b, t0, T, Q, w_span, w_giou, w_class, cost_out, Tmax);
+  sap_assign(s, t0, T, Q, match_q);
+}
+
+// One thread per pair (chunks of P pairs); one workgroup, so the loss sums are reduced without atomics
+// (deterministic).  out[0..3] = loss_span, loss_giou, loss_label, class_error.  The span terms are means over the
+// MATCHED (query, target) pairs: sum_b min(T_b, Q) of them (criterion.py:104-107, :133).
 __global__ void set_loss_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ spans,
                                     const float* __restrict__ tgt_cxw, const float* __restrict__ tgt_xx,
                                     const int32_t* __restrict__ tgt_off, int N, int Q, int Tmax,
@@ -106,48 +189,23 @@ __global__ void set_loss_fwd_kernel(const float* __restrict__ logits, const floa
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int nthr = P, tid = threadIdx.x;  // P pairs per pass (LDS budget); threads >= P idle
   Sap s;
-  s.nthr = nthr; s.tid = tid; s.Q = Q;
-  double* dp = reinterpret_cast<double*>(smem);
-  s.cost = dp; dp += (size_t)Tmax * Q * nthr;
-  s.u = dp; dp += (size_t)(Tmax + 1) * nthr;
-  s.v = dp; dp += (size_t)(Q + 1) * nthr;
-  s.minv = dp; dp += (size_t)(Q + 1) * nthr;
-  int* ip = reinterpret_cast<int*>(dp);
-  s.p = ip; ip += (size_t)(Q + 1) * nthr;
-  s.way = ip; ip += (size_t)(Q + 1) * nthr;
-  s.used = reinterpret_cast<uint8_t*>(ip);
-  __shared__ float red[4][16];
+  s.carve(smem, Tmax, Q, nthr, tid);
+  __shared__ float red[5][16];
 
-  float a_l1 = 0.0f, a_giou = 0.0f, a_ce = 0.0f, a_ok = 0.0f;
+  float a_l1 = 0.0f, a_giou = 0.0f, a_ce = 0.0f, a_ok = 0.0f, a_cnt = 0.0f;
   for (int b0 = 0; b0 < N; b0 += nthr) {
     const int b = b0 + tid;
     if (tid < P && b < N) {
       const int t0 = tgt_off[b];
       const int T = tgt_off[b + 1] - t0;
-      for (int q = 0; q < Q; ++q) {
-        const float l0 = logits[((int64_t)b * Q + q) * 2], l1 = logits[((int64_t)b * Q + q) * 2 + 1];
-        const float mx = fmaxf(l0, l1);
-        const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
-        const float prob0 = e0 / (e0 + e1);
-        const float cx = spans[((int64_t)b * Q + q) * 2], w = spans[((int64_t)b * Q + q) * 2 + 1];
-        const float x1 = cx - 0.5f * w, x2 = cx + 0.5f * w;
-        for (int t = 0; t < T; ++t) {
-          const float tc = tgt_cxw[(int64_t)(t0 + t) * 2], tw = tgt_cxw[(int64_t)(t0 + t) * 2 + 1];
-          const float g1 = tgt_xx[(int64_t)(t0 + t) * 2], g2 = tgt_xx[(int64_t)(t0 + t) * 2 + 1];
-          const float c_span = fabsf(cx - tc) + fabsf(w - tw);
-          Giou gi;
-          const float giou = giou_1d(x1, x2, g1, g2, gi);
-          s.C(t, q) = (double)(w_span * c_span + w_giou * (-giou) + w_class * (-prob0));
-        }
-      }
-      sap_solve(s, T, Q);
-      uint32_t matched = 0;
-      for (int j = 1; j <= Q; ++j) {
-        const int pj = s.P(j);
-        if (pj != 0) {
-          const int q = j - 1, t = t0 + pj - 1;
-          match_q[t] = q;
-          matched |= 1u << q;
+      sap_fill_cost(s, logits, spans, tgt_cxw, tgt_xx, b, t0, T, Q, w_span, w_giou, w_class, nullptr, Tmax);
+      sap_assign(s, t0, T, Q, match_q);
+      uint64_t matched = 0;
+      for (int k = 0; k < T; ++k) {
+        const int t = t0 + k, q = match_q[t];  // (this thread's own stores)
+        if (q >= 0) {
+          matched |= 1ull << q;
+          a_cnt += 1.0f;
           const float cx = spans[((int64_t)b * Q + q) * 2], w = spans[((int64_t)b * Q + q) * 2 + 1];
           a_l1 += fabsf(cx - tgt_cxw[(int64_t)t * 2]) + fabsf(w - tgt_cxw[(int64_t)t * 2 + 1]);
           Giou gi;
@@ -161,28 +219,28 @@ __global__ void set_loss_fwd_kernel(const float* __restrict__ logits, const floa
         const float l0 = logits[((int64_t)b * Q + q) * 2], l1 = logits[((int64_t)b * Q + q) * 2 + 1];
         const float mx = fmaxf(l0, l1);
         const float lse = mx + logf(expf(l0 - mx) + expf(l1 - mx));
-        const bool fg = (matched >> q) & 1u;
+        const bool fg = (matched >> q) & 1ull;
         a_ce += fg ? -(l0 - lse) : -(l1 - lse) * eos_coef;
       }
     }
   }
-  float vals[4] = {a_l1, a_giou, a_ce, a_ok};
+  float vals[5] = {a_l1, a_giou, a_ce, a_ok, a_cnt};
   const int lane = tid & 63, wave = tid >> 6, nw = (int)(blockDim.x >> 6);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < 5; ++k) {
     float v = wave_sum(vals[k]);
     if (lane == 0) red[k][wave] = v;
   }
   __syncthreads();
   if (tid == 0) {
-    float r[4] = {0, 0, 0, 0};
-    for (int k = 0; k < 4; ++k)
+    float r[5] = {0, 0, 0, 0, 0};
+    for (int k = 0; k < 5; ++k)
       for (int w = 0; w < nw; ++w) r[k] += red[k][w];
-    const float sumT = (float)tgt_off[N];
-    out[0] = r[0] / (2.0f * sumT);
-    out[1] = r[1] / sumT;
+    const float nm = r[4];
+    out[0] = r[0] / (2.0f * nm);
+    out[1] = r[1] / nm;
     out[2] = r[2] / (float)(N * Q);
-    out[3] = 100.0f - r[3] * (100.0f / sumT);
+    out[3] = 100.0f - r[3] * (100.0f / nm);
   }
 }
 
@@ -193,18 +251,24 @@ __global__ __launch_bounds__(256) void set_loss_bwd_kernel(
     const int32_t* __restrict__ match_q, int N, int Q, float eos_coef, const float* __restrict__ g,
     float* __restrict__ dlogits, float* __restrict__ dspans, const int32_t* __restrict__ n_valid) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N * Q) return;
+  const int Ncap = N;
+  if (n_valid) N = *n_valid;  // padding pairs: zero gradients, and out of every denominator
+  // matched (query, target) pairs of the batch = sum_b min(T_b, Q): the denominators of the span terms
+  __shared__ float sh_cnt[4];
+  float cnt = 0.0f;
+  for (int b2 = threadIdx.x; b2 < N; b2 += blockDim.x) cnt += (float)min(tgt_off[b2 + 1] - tgt_off[b2], Q);
+  cnt = wave_sum(cnt);
+  if ((threadIdx.x & 63) == 0) sh_cnt[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  const float sumT = sh_cnt[0] + sh_cnt[1] + sh_cnt[2] + sh_cnt[3];
+  if (i >= Ncap * Q) return;
   const int b = i / Q, q = i % Q;
-  if (n_valid) {  // padding pairs: zero gradients, and out of every denominator
-    N = *n_valid;
-    if (b >= N) {
-      dlogits[(int64_t)i * 2] = dlogits[(int64_t)i * 2 + 1] = 0.0f;
-      dspans[(int64_t)i * 2] = dspans[(int64_t)i * 2 + 1] = 0.0f;
-      return;
-    }
+  if (b >= N) {
+    dlogits[(int64_t)i * 2] = dlogits[(int64_t)i * 2 + 1] = 0.0f;
+    dspans[(int64_t)i * 2] = dspans[(int64_t)i * 2 + 1] = 0.0f;
+    return;
   }
   const int t0 = tgt_off[b], T = tgt_off[b + 1] - t0;
-  const float sumT = (float)tgt_off[N];
   int t = -1;
   for (int k = 0; k < T; ++k)
     if (match_q[t0 + k] == q) t = t0 + k;
@@ -636,15 +700,27 @@ extern "C" int mesm_set_loss_fwd_nv(const float* logits, const float* spans, con
                                     int32_t Tmax, float w_span, float w_giou, float w_class,
                                     float eos_coef, int32_t* match_q, float* out4, const int32_t* n_valid, void* stream) {
   if (!logits || !spans || !tgt_cxw || !tgt_xx || !tgt_off || !match_q || !out4) return MESM_EINVAL;
-  if (N <= 0 || Q <= 0 || Q > 32 || Tmax <= 0 || Tmax > 16 || Tmax > Q) return MESM_EINVAL;
+  if (N <= 0 || Q <= 0 || Q > 64 || Tmax <= 0 || Tmax > 64) return MESM_EINVAL;
   const size_t per = sap_bytes_per_thread(Tmax, Q);
-  int P = 64;
-  while (P > 1 && per * P > 60 * 1024) P >>= 1;
-  if (per * P > 60 * 1024) return MESM_EINVAL;
-  while (P > 1 && P / 2 >= N) P >>= 1;
+  const int P = sap_pairs_per_pass(Tmax, Q, N);
+  if (P == 0) return MESM_EINVAL;
   hipLaunchKernelGGL(set_loss_fwd_kernel, dim3(1), dim3(64), per * P, (hipStream_t)stream, logits, spans,
                      tgt_cxw, tgt_xx, tgt_off, N, Q, Tmax, w_span, w_giou, w_class, eos_coef, P,
                      match_q, out4, n_valid);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_match(const float* logits, const float* spans, const float* tgt_cxw,
+                          const float* tgt_xx, const int32_t* tgt_off, int32_t N, int32_t Q,
+                          int32_t Tmax, float w_span, float w_giou, float w_class, float* cost,
+                          int32_t* match_q, void* stream) {
+  if (!logits || !spans || !tgt_cxw || !tgt_xx || !tgt_off || !match_q) return MESM_EINVAL;
+  if (N <= 0 || Q <= 0 || Q > 64 || Tmax <= 0 || Tmax > 64) return MESM_EINVAL;
+  const int P = sap_pairs_per_pass(Tmax, Q, N);
+  if (P == 0) return MESM_EINVAL;
+  hipLaunchKernelGGL(match_kernel, dim3((N + P - 1) / P), dim3(P), sap_bytes_per_thread(Tmax, Q) * P,
+                     (hipStream_t)stream, logits, spans, tgt_cxw, tgt_xx, tgt_off, N, Q, Tmax, w_span, w_giou,
+                     w_class, cost, match_q);
   return mesm_launch_status();
 }
 

@@ -2312,3 +2312,37 @@ extern "C" int mesm_gemm_tape_replay(void* stream, int32_t reps, double* total_m
   *total_bytes = bytes;
   return rc;
 }
+
+// One entry of the tape timed alone: `reps` back-to-back launches of launch `idx` under one event pair, and what
+// it carries (tools/tape_profile.py: which launches of the step lose the most time against the big-GEMM rate).
+// shapes: up to 64 x (M, N, K, split_k) int32; returns the number of problems in *n_problems.
+extern "C" int mesm_gemm_tape_entry(void* stream, int32_t idx, int32_t reps, double* ms, int32_t* n_problems,
+                                    int32_t* shapes) {
+  if (!ms || !n_problems || !shapes || reps < 1) return MESM_EINVAL;
+  if (idx < 0 || (size_t)idx >= g_tape.launches.size()) return MESM_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const TapeEntry& e = g_tape.launches[idx];
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return MESM_ELAUNCH;
+  int rc = MESM_OK;
+  hipEventRecord(e0, s);
+  for (int r = 0; r < reps && rc == MESM_OK; ++r)
+    rc = e.group ? launch_group(e.args.data(), e.vecs.data(), e.n, s) : dispatch(e.args[0], e.vecs[0], s);
+  hipEventRecord(e1, s);
+  hipStreamSynchronize(s);
+  float t = 0.0f;
+  hipEventElapsedTime(&t, e0, e1);
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  *ms = (double)t / reps;
+  *n_problems = (int32_t)e.args.size();
+  for (size_t k = 0; k < e.args.size() && k < 64; ++k) {
+    const MesmGemmArgs& a = e.args[k];
+    shapes[4 * k] = a.M; shapes[4 * k + 1] = a.N; shapes[4 * k + 2] = a.K;
+    shapes[4 * k + 3] = (a.split_k > 1 ? a.split_k : 1) | (a.a_layout << 8) | (a.b_layout << 9) | (groupable(a) ? 1 << 10 : 0);
+  }
+  return rc;
+}
+
+extern "C" int mesm_gemm_tape_size(void) { return (int)g_tape.launches.size(); }
+

@@ -280,83 +280,6 @@ __global__ __launch_bounds__(256) void saliency_bwd_kernel(
   }
 }
 
-// ---------------------------------------------------------------- matcher
-// matcher.py:60-117.  One thread per pair: fp32 cost exactly as the reference builds it,
-// then the O(T^2 Q) shortest-augmenting-path assignment in fp64 (what scipy's
-// linear_sum_assignment computes), rows = targets, columns = queries.
-constexpr int MQ = 32;  // max queries
-constexpr int MT = 16;  // max targets per pair
-
-__global__ __launch_bounds__(64) void match_kernel(
-    const float* __restrict__ logits, const float* __restrict__ spans,
-    const float* __restrict__ tgt_cxw, const float* __restrict__ tgt_xx,
-    const int32_t* __restrict__ tgt_off, int N, int Q, int Tmax, float w_span, float w_giou,
-    float w_class, float* __restrict__ cost_out, int32_t* __restrict__ match_q) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= N) return;
-  const int t0 = tgt_off[b];
-  const int T = tgt_off[b + 1] - t0;
-  double cost[MT][MQ];
-  for (int q = 0; q < Q; ++q) {
-    const float l0 = logits[((int64_t)b * Q + q) * 2], l1 = logits[((int64_t)b * Q + q) * 2 + 1];
-    const float mx = fmaxf(l0, l1);
-    const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
-    const float prob0 = e0 / (e0 + e1);
-    const float cx = spans[((int64_t)b * Q + q) * 2], w = spans[((int64_t)b * Q + q) * 2 + 1];
-    const float x1 = cx - 0.5f * w, x2 = cx + 0.5f * w;
-    for (int t = 0; t < T; ++t) {
-      const float tc = tgt_cxw[(int64_t)(t0 + t) * 2], tw = tgt_cxw[(int64_t)(t0 + t) * 2 + 1];
-      const float g1 = tgt_xx[(int64_t)(t0 + t) * 2], g2 = tgt_xx[(int64_t)(t0 + t) * 2 + 1];
-      const float c_span = fabsf(cx - tc) + fabsf(w - tw);
-      const float a1 = x2 - x1, a2 = g2 - g1;
-      const float inter = fmaxf(fminf(x2, g2) - fmaxf(x1, g1), 0.0f);
-      const float uni = a1 + a2 - inter;
-      const float iou = inter / uni;
-      const float enc = fmaxf(fmaxf(x2, g2) - fminf(x1, g1), 0.0f);
-      const float giou = iou - (enc - uni) / enc;
-      const float c = w_span * c_span + w_giou * (-giou) + w_class * (-prob0);
-      cost[t][q] = (double)c;
-      if (cost_out) cost_out[((int64_t)b * Q + q) * Tmax + t] = c;
-    }
-  }
-  // shortest augmenting paths (rows = targets 1..T, cols = queries 1..Q), T <= Q
-  double u[MT + 1], v[MQ + 1], minv[MQ + 1];
-  int p[MQ + 1], way[MQ + 1];
-  bool used[MQ + 1];
-  for (int i = 0; i <= T; ++i) u[i] = 0.0;
-  for (int j = 0; j <= Q; ++j) { v[j] = 0.0; p[j] = 0; way[j] = 0; }
-  for (int i = 1; i <= T; ++i) {
-    p[0] = i;
-    int j0 = 0;
-    for (int j = 0; j <= Q; ++j) { minv[j] = 1e300; used[j] = false; }
-    do {
-      used[j0] = true;
-      const int i0 = p[j0];
-      double delta = 1e300;
-      int j1 = 0;
-      for (int j = 1; j <= Q; ++j) {
-        if (!used[j]) {
-          const double cur = cost[i0 - 1][j - 1] - u[i0] - v[j];
-          if (cur < minv[j]) { minv[j] = cur; way[j] = j0; }
-          if (minv[j] < delta) { delta = minv[j]; j1 = j; }
-        }
-      }
-      for (int j = 0; j <= Q; ++j) {
-        if (used[j]) { u[p[j]] += delta; v[j] -= delta; }
-        else minv[j] -= delta;
-      }
-      j0 = j1;
-    } while (p[j0] != 0);
-    do {
-      const int j1 = way[j0];
-      p[j0] = p[j1];
-      j0 = j1;
-    } while (j0);
-  }
-  for (int j = 1; j <= Q; ++j)
-    if (p[j] != 0) match_q[t0 + p[j] - 1] = j - 1;
-}
-
 }  // namespace
 
 extern "C" int mesm_nll_smooth_fwd(const float* logit, const int64_t* label, const uint8_t* mask,
@@ -434,16 +357,4 @@ extern "C" int mesm_saliency_loss_bwd(const float* s_pos, const float* s_neg, co
                                       float* ds_pos, float* ds_neg, void* stream) {
   return mesm_saliency_loss_bwd_nv(s_pos, s_neg, label, vmask, pos_idx, neg_idx, N, L, P, rank_coef, margin, gscale,
                                    ds_pos, ds_neg, nullptr, stream);
-}
-
-extern "C" int mesm_match(const float* logits, const float* spans, const float* tgt_cxw,
-                          const float* tgt_xx, const int32_t* tgt_off, int32_t N, int32_t Q,
-                          int32_t Tmax, float w_span, float w_giou, float w_class, float* cost,
-                          int32_t* match_q, void* stream) {
-  if (!logits || !spans || !tgt_cxw || !tgt_xx || !tgt_off || !match_q) return MESM_EINVAL;
-  if (N <= 0 || Q <= 0 || Q > MQ || Tmax <= 0 || Tmax > MT || Tmax > Q) return MESM_EINVAL;
-  hipLaunchKernelGGL(match_kernel, dim3((N + 63) / 64), dim3(64), 0, (hipStream_t)stream, logits,
-                     spans, tgt_cxw, tgt_xx, tgt_off, N, Q, Tmax, w_span, w_giou, w_class, cost,
-                     match_q);
-  return mesm_launch_status();
 }

@@ -621,17 +621,19 @@ def saliency_loss_bwd(s_pos, s_neg, label64, vmask, pos_idx, neg_idx, rank_coef,
 
 
 def _check_match_limits(Q, Tmax):
-    """The in-kernel assignment keeps its work arrays in LDS and the matched set in a 32-bit mask: say so here
-    instead of returning an opaque status code (the reference's scipy call has no such limits)."""
-    if Q > 32 or Tmax > 16 or Tmax > Q:
+    """The in-kernel assignment keeps its fp64 work arrays in LDS (60 KB per workgroup) and the matched set in a
+    64-bit mask: say so here instead of returning an opaque status code.  Any (Q x T) shape within these extents
+    is solved like the reference's scipy call (matcher.py:108-117), T > Q included."""
+    if Q > 64 or Tmax > 64:
         raise _lib.MesmError(
-            "Hungarian matching kernel: num_queries = %d (limit 32), target windows per pair = %d (limit 16 and "
-            "<= num_queries); the shipped configs use 10 queries and <= 5 windows (qvhighlights.py:148-150)" % (Q, Tmax))
+            "Hungarian matching kernel: num_queries = %d, target windows per pair = %d (limit 64 each); the "
+            "shipped configs use 10 queries and <= 5 windows (qvhighlights.py:148-150)" % (Q, Tmax))
 
 
 def match(logits, spans, tgt_cxw, tgt_xx, tgt_off, Tmax, w_span, w_giou, w_class, want_cost=False):
     """logits (N,Q,2), spans (N,Q,2), targets (sumT,2) x2, tgt_off (N+1) int32 ->
-    match_q (sumT) int32 [, cost (N,Q,Tmax)]."""
+    match_q (sumT) int32 (-1 = target left unmatched, only where a pair has more targets than queries)
+    [, cost (N,Q,Tmax)]."""
     require_gpu(logits, spans, tgt_cxw, tgt_xx, tgt_off)
     N, Q, _ = logits.shape
     assert tgt_off.dtype == torch.int32

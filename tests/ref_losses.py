@@ -25,7 +25,9 @@ def paired_giou(a, b):
 def set_losses(logits, spans, tgt_cxw, tgt_xx, pair_of_t, match_q, eos_coef):
     """criterion.py:71-137 given the matching -> (loss_span, loss_giou, loss_label, class_error)."""
     N, Q = logits.shape[:2]
-    flat = pair_of_t * Q + match_q.to(torch.int64)
+    keep = match_q >= 0  # a pair with more targets than queries leaves targets unmatched (matcher.py:108-117)
+    flat = (pair_of_t * Q + match_q.to(torch.int64))[keep]
+    tgt_cxw, tgt_xx = tgt_cxw[keep], tgt_xx[keep]
     src = spans.reshape(-1, 2)[flat]
     loss_span = (src - tgt_cxw).abs().mean()
     loss_giou = (1 - paired_giou(span_cxw_to_xx(src), tgt_xx)).mean()

@@ -65,7 +65,9 @@ def test_limits_are_reported_in_words():
     from mesm_amd import _lib
     from mesm_amd import kernels as kn
     kn._check_match_limits(10, 5)
-    for q, t in ((40, 3), (10, 17), (4, 5)):
+    kn._check_match_limits(4, 5)  # more targets than queries is a shape like any other (matcher.py:108-117)
+    kn._check_match_limits(64, 64)
+    for q, t in ((65, 3), (10, 65)):
         with pytest.raises(_lib.MesmError, match="Hungarian matching kernel"):
             kn._check_match_limits(q, t)
     kn._check_drop_index(1 << 33, 0.0)

@@ -37,8 +37,12 @@ def _targets(N, seed, tmax=5):
     return sizes, off.to(dev()), xx, cxw, pair_of_t
 
 
-@pytest.mark.parametrize("N,Q,tmax", [(32, 10, 5), (3, 10, 1), (70, 12, 4), (16, 32, 16)])
+@pytest.mark.parametrize("N,Q,tmax", [(32, 10, 5), (3, 10, 1), (70, 12, 4), (16, 32, 16),
+                                      (9, 6, 9), (7, 7, 7), (12, 40, 20), (5, 64, 64), (4, 3, 64)])
 def test_set_loss_matches_match_kernel_and_torch(N, Q, tmax):
+    """the last rows: more targets than queries (targets left unmatched, the denominators count the matched
+    pairs), square blocks, and the largest extents the kernel takes -- the reference's scipy call has no shape
+    rule (matcher.py:108-117)"""
     from mesm_amd import kernels as kn
     sizes, off, xx, cxw, pair_of_t = _targets(N, 5 + N, tmax)
     logits = gen((N, Q, 2), 96 + N).requires_grad_()

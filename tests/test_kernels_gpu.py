@@ -472,21 +472,24 @@ def test_saliency_loss(N, L, qvh):
     assert abs(out2.item() - ref2.item()) / max(abs(ref2.item()), 1.0) < TOL
 
 
-def test_match_against_scipy():
+@pytest.mark.parametrize("N,Q,tmax", [(32, 10, 5), (9, 6, 9), (7, 7, 7), (12, 40, 20), (5, 64, 64), (4, 3, 64), (33, 33, 2)])
+def test_match_against_scipy(N, Q, tmax):
+    """any (Q x T) block like the reference's scipy call (matcher.py:108-117): T < Q, T == Q, T > Q (targets left
+    unmatched: -1), up to 64 x 64"""
     from scipy.optimize import linear_sum_assignment
     from mesm_amd import kernels as kn
-    N, Q = 32, 10
-    g = torch.Generator().manual_seed(95)
+    g = torch.Generator().manual_seed(95 + Q)
     logits = gen((N, Q, 2), 96)
     spans = torch.sigmoid(gen((N, Q, 2), 97))
-    sizes = [1 + (i % 5) for i in range(N)]
+    sizes = [1 + (i % tmax) for i in range(N)]
+    sizes[-1] = tmax
     off = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)), dtype=torch.int32)
     T = int(off[-1])
     st = torch.rand(T, generator=g) * 0.6
     ed = st + 0.05 + torch.rand(T, generator=g) * 0.3
     xx = torch.stack([st, ed], 1).to(dev())
     cxw = torch.stack([(st + ed) * 0.5, ed - st], 1).to(dev())
-    mq, cost = kn.match(logits, spans, cxw, xx, off.to(dev()), 5, 10.0, 1.0, 4.0, want_cost=True)
+    mq, cost = kn.match(logits, spans, cxw, xx, off.to(dev()), tmax, 10.0, 1.0, 4.0, want_cost=True)
     # cost against the reference formula (matcher.py:70-105) in fp32 torch
     prob = logits.flatten(0, 1).softmax(-1)
     osp = spans.flatten(0, 1)
@@ -502,10 +505,12 @@ def test_match_against_scipy():
     for b in range(N):
         cb = Cref[b, :, off[b]:off[b + 1]]
         assert (cost[b, :, :sizes[b]].cpu() - cb).abs().max().item() < 1e-5
-        qi, ti = linear_sum_assignment(cb.numpy())
-        want = torch.empty(sizes[b], dtype=torch.int32)
+        # the kernel's own fp32 costs decide the assignment (bit-exact against scipy on the same numbers)
+        qi, ti = linear_sum_assignment(cost[b, :, :sizes[b]].cpu().double().numpy())
+        want = torch.full((sizes[b],), -1, dtype=torch.int32)
         want[torch.as_tensor(ti)] = torch.as_tensor(qi, dtype=torch.int32)
         assert torch.equal(mq[off[b]:off[b + 1]], want), (b, mq[off[b]:off[b + 1]], want)
+        assert int((want >= 0).sum()) == min(sizes[b], Q)
 
 
 def _gemm_fuzz_case(rng, kn):
