@@ -14,6 +14,7 @@
 // query rows (P is recomputed from the saved log-sum-exp).  dQ rows are reduced over
 // lanes through LDS and written (single key tile) or added atomically (several tiles).
 #include "common.hpp"
+#include "attention_blk.hpp"
 #include "attention_mfma.hpp"
 #include <cstdlib>
 #include <cstddef>
@@ -450,6 +451,16 @@ __global__ __launch_bounds__(256) void attn_bwd_group_kernel(const AttnBGroup g)
   attn_bwd_body<32, 32, 4>(p, bh, local - bh * ntiles, ntiles);
 }
 
+// the 16 x 16-block matrix-core backward (attention_blk.hip) takes the short ranges; MESM_ATTN_BLK=0 (or
+// MESM_ATTN_LEGACY) keeps the lane-per-key kernels above, for A/B
+bool blk_bwd_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("MESM_ATTN_BLK");
+    return getenv("MESM_ATTN_LEGACY") == nullptr && !(e && atoi(e) == 0);
+  }();
+  return on;
+}
+
 int check_common(const MesmAttnArgs& a) {
   if (!a.q || !a.k || !a.v || !a.o) return MESM_EINVAL;
   if (a.B <= 0 || a.H <= 0 || a.Lq <= 0 || a.Lk <= 0) return MESM_EINVAL;
@@ -511,6 +522,7 @@ extern "C" int mesm_attn_bwd(const MesmAttnArgs* args, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   static const bool legacy = getenv("MESM_ATTN_LEGACY") != nullptr;
   if (!legacy && mesm_attn_mfma_bwd_ok(a)) return mesm_attn_mfma_bwd(a, s);
+  if (blk_bwd_enabled() && mesm_attn_blk_bwd_ok(a)) return mesm_attn_blk_bwd(a, s);
   dim3 grid(a.B * a.H, (a.Lk + KT - 1) / KT);
   if (grid.y > 1) ATTN_DISPATCH(attn_bwd_kernel, grid, 128, 2);  // several key tiles: 2 waves per workgroup
   else ATTN_DISPATCH(attn_bwd_kernel, grid, 256, 4);
@@ -563,8 +575,15 @@ extern "C" int mesm_attn_bwd_group(const MesmAttnArgs* list, int32_t n, void* st
   AttnBGroup g;
   g.n = 0;
   g.start[0] = 0;
+  MesmAttnArgs blk[8];
+  int nblk = 0;
   int rc = MESM_OK;
   auto flush = [&]() {
+    if (nblk > 0) {
+      rc = nblk == 1 ? mesm_attn_blk_bwd(blk[0], s) : mesm_attn_blk_bwd_group(blk, nblk, s);
+      nblk = 0;
+      if (rc != MESM_OK) return;
+    }
     if (g.n == 0) return;
     if (g.n == 1) {
       rc = mesm_attn_bwd(&g.p[0], stream);
@@ -579,7 +598,10 @@ extern "C" int mesm_attn_bwd_group(const MesmAttnArgs* list, int32_t n, void* st
     rc = check_bwd(a);
     if (rc != MESM_OK) return rc;
     const bool lane_per_key = legacy || !mesm_attn_mfma_bwd_ok(a);
-    if (lane_per_key && a.dk == 32 && a.dv == 32 && !a.q2) {
+    if (lane_per_key && blk_bwd_enabled() && mesm_attn_blk_bwd_ok(a)) {
+      blk[nblk++] = a;
+      if (nblk == 8) flush();
+    } else if (lane_per_key && a.dk == 32 && a.dv == 32 && !a.q2) {
       g.p[g.n] = a;
       g.start[g.n + 1] = g.start[g.n] + a.B * a.H * ((a.Lk + KT - 1) / KT);
       if (++g.n == ATTNB_GROUP_MAX) flush();

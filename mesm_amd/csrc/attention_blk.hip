@@ -1,0 +1,340 @@
+// Attention backward on 16 x 16 score blocks (v_mfma_f32_16x16x4_f32) for the step's short ranges: dk = dv = 32, packed
+// heads, Lq and Lk up to ~100 (transformer.py:528-533, 592-598, 640-644 backward; attention.py:329-386).
+//
+// One workgroup (4 waves) per (batch, head).  Q, dO, K, V of the head are staged ONCE into LDS (36-float rows: the
+// fragment reads below are conflict-free), with delta_i = dO_i . O_i, the saved log-sum-exp and the mask bytes beside
+// them.  The work is cut into UNITS that need no exchange between waves and no atomics:
+//
+//   J unit (one 16-key block, all query blocks):  S = Q K^T and dP = dO V^T with the KEY on the lane
+//       (C/D layout: column = lane & 15 = key, rows = 4 (lane >> 4) + r = queries), so the four accumulator registers
+//       of P_drop and dS ARE the A operands of dV += P_drop^T dO and dK += dS^T Q (sum over the block's queries);
+//       dV / dK of the key block stay in registers over the whole sweep and are stored once.
+//   I unit (one 16-query block, all key blocks):  the TRANSPOSED blocks S^T = K Q^T, dP^T = V dO^T (operands swapped:
+//       the QUERY on the lane), so dS^T's registers are the A operands of dQ += dS K.
+//
+// The score blocks are computed twice (once per orientation): 56 instead of 40 matrix instructions per block pair, in
+// exchange for no LDS transposition, no cross-wave reduction of dQ and 45 KB of LDS at 76 x 76 (three workgroups per
+// CU).  Waves draw units from an LDS counter (J units first: they are the longer ones).  The lane-per-key kernel of
+// attention.hip used half its lanes at Lk = 33 / 76 and walked the queries four at a time:
+// 75 x 33 / 76 x 76 / 33 x 75 (64 x 8 heads) 28 / 51 / 27 us there.
+#include <hip/hip_runtime.h>
+
+#include "attention_blk.hpp"
+#include "common.hpp"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int BS = 36;  // LDS row stride in floats
+#ifndef MESM_BLK_THREADS
+#define MESM_BLK_THREADS 512
+#endif
+#ifndef MESM_BLK_SSTEPS
+#define MESM_BLK_SSTEPS 8  // (probe builds: fewer reduce steps of the score products)
+#endif
+#ifndef MESM_BLK_TSTEPS
+#define MESM_BLK_TSTEPS 4
+#endif
+constexpr int BT = MESM_BLK_THREADS;  // 8 waves: a 76 x 76 head has 5 + 5 units
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+struct BlkShape {
+  int LqP, LkP;  // padded to 16
+  __host__ __device__ BlkShape(int Lq, int Lk) : LqP((Lq + 15) & ~15), LkP((Lk + 15) & ~15) {}
+  __host__ __device__ size_t floats() const { return (size_t)(2 * LqP + 2 * LkP) * BS + 3 * LqP + 2 * LkP + 4; }
+};
+
+// eight consecutive floats of an LDS row (the lane's share of a 16 x 32 operand: reduce indices 8 kq .. 8 kq + 7)
+__device__ __forceinline__ void load8(const float* p, float* f) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  const float4 b = *reinterpret_cast<const float4*>(p + 4);
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w;
+  f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+
+template <bool DROP>
+__device__ __forceinline__ void attn_blk_bwd_body(const MesmAttnArgs& p, const int bh) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const BlkShape sh(p.Lq, p.Lk);
+  float* Qs = smem;
+  float* Gs = Qs + sh.LqP * BS;   // dO
+  float* Ks = Gs + sh.LqP * BS;
+  float* Vs = Ks + sh.LkP * BS;
+  float* Lse = Vs + sh.LkP * BS;  // LqP
+  float* Dl = Lse + sh.LqP;       // LqP
+  float* Qp2 = Dl + sh.LqP;       // LqP: query padded in the quirk row
+  float* Kp = Qp2 + sh.LqP;       // LkP: key masked for this row (own padding, or beyond Lk)
+  float* Kp2 = Kp + sh.LkP;       // LkP: key padded in the quirk row
+  int* next = reinterpret_cast<int*>(Kp2 + sh.LkP);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int b = bh / p.H, h = bh % p.H;
+  const int b2 = mesm_quirk_row(p, b, h);
+  const bool quirk = (p.mask_mode == MESM_MASK_T2V_QUIRK) && p.qpad && p.kpad;
+  const int Lq = p.Lq, Lk = p.Lk;
+
+  const float* qb = p.q + (int64_t)b * p.q_bs + h * 32;
+  const float* kb = p.k + (int64_t)b * p.k_bs + h * 32;
+  const float* vb = p.v + (int64_t)b * p.v_bs + h * 32;
+  const float* ob = p.o + (int64_t)b * p.o_bs + h * 32;
+  const float* gb = p.d_o + (int64_t)b * p.o_bs + h * 32;
+
+  // ---- stage the head: 8 consecutive threads per 32-float row
+  for (int idx = tid; idx < sh.LqP * 8; idx += BT) {
+    const int r = idx >> 3, c = (idx & 7) * 4;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f), g = q, o = q;
+    if (r < Lq) {
+      q = *reinterpret_cast<const float4*>(qb + (int64_t)r * p.q_ls + c);
+      g = *reinterpret_cast<const float4*>(gb + (int64_t)r * p.o_ls + c);
+      o = *reinterpret_cast<const float4*>(ob + (int64_t)r * p.o_ls + c);
+    }
+    *reinterpret_cast<float4*>(Qs + r * BS + c) = q;
+    *reinterpret_cast<float4*>(Gs + r * BS + c) = g;
+    float part = g.x * o.x + g.y * o.y + g.z * o.z + g.w * o.w;
+    part = sum_within<8>(part);
+    if ((idx & 7) == 0) Dl[r] = part;
+  }
+  for (int idx = tid; idx < sh.LkP * 8; idx += BT) {
+    const int r = idx >> 3, c = (idx & 7) * 4;
+    float4 k = make_float4(0.f, 0.f, 0.f, 0.f), v = k;
+    if (r < Lk) {
+      k = *reinterpret_cast<const float4*>(kb + (int64_t)r * p.k_ls + c);
+      v = *reinterpret_cast<const float4*>(vb + (int64_t)r * p.v_ls + c);
+    }
+    *reinterpret_cast<float4*>(Ks + r * BS + c) = k;
+    *reinterpret_cast<float4*>(Vs + r * BS + c) = v;
+  }
+  for (int r = tid; r < sh.LqP; r += BT) {
+    // rows beyond Lq: exp(s - 1e30) = 0, so they add nothing anywhere
+    Lse[r] = r < Lq ? p.lse[(int64_t)bh * Lq + r] : 1e30f;
+    Qp2[r] = (quirk && r < Lq && p.qpad[(int64_t)b2 * Lq + r] != 0) ? 1.0f : 0.0f;
+  }
+  for (int j = tid; j < sh.LkP; j += BT) {
+    bool m = j >= Lk;
+    if (!m && p.kpad) m = p.kpad[(int64_t)b * Lk + j] != 0;
+    Kp[j] = m ? 1.0f : 0.0f;
+    Kp2[j] = (quirk && j < Lk && p.kpad[(int64_t)b2 * Lk + j] != 0) ? 1.0f : 0.0f;
+  }
+  if (tid == 0) *next = 0;
+  __syncthreads();
+
+  const uint32_t thresh = DROP ? mesm_drop_threshold(p.drop_p) : 0u;
+  const float inv_keep = 1.0f / (1.0f - p.drop_p);
+  const uint32_t drop_seed = p.drop_seed + (p.seed_offset ? *p.seed_offset : 0u);
+  const float scale = p.scale;
+  const uint32_t row0 = (uint32_t)bh * (uint32_t)Lq;  // dropout index = (row0 + i) * Lk + j
+
+  const int nI = sh.LqP >> 4, nJ = sh.LkP >> 4;
+  const int jl = lane & 15, kq = lane >> 4;
+
+#ifdef MESM_BLK_STAGGER
+  {
+    const int ph = ((tid >> 8) & 1) + 2 * ((blockIdx.x >> 8) & 1);
+    if (ph == 1) __builtin_amdgcn_s_sleep(6);
+    if (ph == 2) __builtin_amdgcn_s_sleep(12);
+    if (ph == 3) __builtin_amdgcn_s_sleep(18);
+  }
+#endif
+#ifdef MESM_BLK_PROBE_NOCOMPUTE
+  if (p.Lq > 0) return;
+#endif
+  for (;;) {
+    int u = 0;
+    if (lane == 0) u = atomicAdd(next, 1);
+    u = __builtin_amdgcn_readfirstlane(u);
+    if (u >= nI + nJ) break;
+    if (u < nJ) {
+      // ------------------------------------------------------------------ J unit: keys j0 .. j0 + 15
+      const int j0 = u << 4;
+      float kf[8], vf[8];
+      load8(Ks + (j0 + jl) * BS + 8 * kq, kf);
+      load8(Vs + (j0 + jl) * BS + 8 * kq, vf);
+      const float kpj = Kp[j0 + jl], kp2j = Kp2[j0 + jl];
+      const uint32_t j = (uint32_t)(j0 + jl);
+      f32x4 dVa[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      f32x4 dKa[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      for (int ib = 0; ib < nI; ++ib) {
+        const int i0 = ib << 4;
+        float qf[8], gf[8];
+        load8(Qs + (i0 + jl) * BS + 8 * kq, qf);
+        load8(Gs + (i0 + jl) * BS + 8 * kq, gf);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < MESM_BLK_SSTEPS; ++t) {
+          s = mfma16(qf[t], kf[t], s);     // S[i0 + 4 kq + r][j0 + jl]
+          dp = mfma16(gf[t], vf[t], dp);   // dP, same layout
+        }
+        const int ir = i0 + 4 * kq;
+        // B operands of the four products below (rows ir + r of dO and Q, columns jl and 16 + jl): issued ahead of
+        // the element-wise work so their LDS latency hides behind it
+        float gb0[4], gb1[4], qb0[4], qb1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          gb0[r] = Gs[(ir + r) * BS + jl]; gb1[r] = Gs[(ir + r) * BS + 16 + jl];
+          qb0[r] = Qs[(ir + r) * BS + jl]; qb1[r] = Qs[(ir + r) * BS + 16 + jl];
+        }
+        const float4 lse4 = *reinterpret_cast<const float4*>(Lse + ir);
+        const float4 dl4 = *reinterpret_cast<const float4*>(Dl + ir);
+        const float4 qp4 = *reinterpret_cast<const float4*>(Qp2 + ir);
+        const float lse_[4] = {lse4.x, lse4.y, lse4.z, lse4.w};
+        const float dl_[4] = {dl4.x, dl4.y, dl4.z, dl4.w};
+        const float qp_[4] = {qp4.x, qp4.y, qp4.z, qp4.w};
+        float pd[4], ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float mk = fmaf(qp_[r], kp2j, kpj);  // != 0: masked (own key padding, or the quirk row's pair)
+          const float e = __expf(s[r] * scale - lse_[r]);
+          const float pj = mk != 0.0f ? 0.0f : e;
+          float km = 1.0f;
+          if (DROP) {
+            const uint32_t idx = (row0 + (uint32_t)(ir + r)) * (uint32_t)Lk + j;
+            km = mesm_hash32(idx, drop_seed) >= thresh ? inv_keep : 0.0f;
+          }
+          pd[r] = pj * km;
+          ds[r] = pj * (dp[r] * km - dl_[r]) * scale;
+#ifdef MESM_BLK_PROBE_NOELT
+          pd[r] = s[r]; ds[r] = dp[r];
+#endif
+        }
+#pragma unroll
+        for (int r = 0; r < MESM_BLK_TSTEPS; ++r) {
+          dVa[0] = mfma16(pd[r], gb0[r], dVa[0]);
+          dKa[0] = mfma16(ds[r], qb0[r], dKa[0]);
+          dVa[1] = mfma16(pd[r], gb1[r], dVa[1]);
+          dKa[1] = mfma16(ds[r], qb1[r], dKa[1]);
+        }
+      }
+      float* dkb = p.dk_ + (int64_t)b * p.k_bs + h * 32;
+      float* dvb = p.dv_ + (int64_t)b * p.v_bs + h * 32;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int jj = j0 + 4 * kq + r;
+        if (jj < Lk) {
+          dkb[(int64_t)jj * p.k_ls + jl] = dKa[0][r];
+          dkb[(int64_t)jj * p.k_ls + 16 + jl] = dKa[1][r];
+          dvb[(int64_t)jj * p.v_ls + jl] = dVa[0][r];
+          dvb[(int64_t)jj * p.v_ls + 16 + jl] = dVa[1][r];
+        }
+      }
+    } else {
+      // ------------------------------------------------------------------ I unit: queries i0 .. i0 + 15
+      const int i0 = (u - nJ) << 4;
+      float qf[8], gf[8];
+      load8(Qs + (i0 + jl) * BS + 8 * kq, qf);
+      load8(Gs + (i0 + jl) * BS + 8 * kq, gf);
+      const float lse_i = Lse[i0 + jl], dl_i = Dl[i0 + jl];
+      const float qp_i = Qp2[i0 + jl];
+      const uint32_t rowi = (row0 + (uint32_t)(i0 + jl)) * (uint32_t)Lk;
+      f32x4 dQa[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      for (int jb = 0; jb < nJ; ++jb) {
+        const int j0 = jb << 4;
+        float kf[8], vf[8];
+        load8(Ks + (j0 + jl) * BS + 8 * kq, kf);
+        load8(Vs + (j0 + jl) * BS + 8 * kq, vf);
+        f32x4 st = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < MESM_BLK_SSTEPS; ++t) {
+          st = mfma16(kf[t], qf[t], st);    // S^T[j0 + 4 kq + r][i0 + jl]
+          dpt = mfma16(vf[t], gf[t], dpt);
+        }
+        const int jr = j0 + 4 * kq;
+        float kb0[4], kb1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { kb0[r] = Ks[(jr + r) * BS + jl]; kb1[r] = Ks[(jr + r) * BS + 16 + jl]; }
+        const float4 kp4 = *reinterpret_cast<const float4*>(Kp + jr);
+        const float4 kq4 = *reinterpret_cast<const float4*>(Kp2 + jr);
+        const float kp_[4] = {kp4.x, kp4.y, kp4.z, kp4.w};
+        const float kp2_[4] = {kq4.x, kq4.y, kq4.z, kq4.w};
+        float ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float mk = fmaf(qp_i, kp2_[r], kp_[r]);
+          const float e = __expf(st[r] * scale - lse_i);
+          const float pj = mk != 0.0f ? 0.0f : e;
+          float km = 1.0f;
+          if (DROP) km = mesm_hash32(rowi + (uint32_t)(jr + r), drop_seed) >= thresh ? inv_keep : 0.0f;
+          ds[r] = pj * (dpt[r] * km - dl_i) * scale;
+#ifdef MESM_BLK_PROBE_NOELT
+          ds[r] = st[r] + dpt[r];
+#endif
+        }
+#pragma unroll
+        for (int r = 0; r < MESM_BLK_TSTEPS; ++r) {
+          dQa[0] = mfma16(ds[r], kb0[r], dQa[0]);
+          dQa[1] = mfma16(ds[r], kb1[r], dQa[1]);
+        }
+      }
+      float* dqb = p.dq + (int64_t)b * p.q_bs + h * 32;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ii = i0 + 4 * kq + r;
+        if (ii < Lq) {
+          dqb[(int64_t)ii * p.q_ls + jl] = dQa[0][r];
+          dqb[(int64_t)ii * p.q_ls + 16 + jl] = dQa[1][r];
+        }
+      }
+    }
+  }
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(BT) void attn_blk_bwd_kernel(const MesmAttnArgs p) { attn_blk_bwd_body<DROP>(p, blockIdx.x); }
+
+constexpr int BLK_GROUP_MAX = 8;
+struct BlkGroup {
+  MesmAttnArgs p[BLK_GROUP_MAX];
+  int start[BLK_GROUP_MAX + 1];
+  int n;
+};
+
+template <bool DROP>
+__global__ __launch_bounds__(BT) void attn_blk_bwd_group_kernel(const BlkGroup g) {
+  const int bid = blockIdx.x;
+  int gi = 0;
+#pragma unroll
+  for (int k = 1; k < BLK_GROUP_MAX; ++k)
+    if (k < g.n && bid >= g.start[k]) gi = k;
+  const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+  const MesmAttnArgs p = *reinterpret_cast<const MesmAttnArgs*>(ka + offsetof(BlkGroup, p) + (size_t)gi * sizeof(MesmAttnArgs));
+  const int first = *reinterpret_cast<const int*>(ka + offsetof(BlkGroup, start) + (size_t)gi * sizeof(int));
+  if (DROP && p.drop_p > 0.f) attn_blk_bwd_body<true>(p, bid - first);
+  else attn_blk_bwd_body<false>(p, bid - first);
+}
+
+size_t lds_bytes(const MesmAttnArgs& a) { return BlkShape(a.Lq, a.Lk).floats() * sizeof(float); }
+
+}  // namespace
+
+// dk = dv = 32, packed heads, the staged head within 64 KB of LDS (Lq + Lk up to ~220), 32-bit dropout / mask indices
+bool mesm_attn_blk_bwd_ok(const MesmAttnArgs& a) {
+  return a.dk == 32 && a.dv == 32 && !a.q2 && !a.k2 && !a.k_add && a.mask_mode != MESM_MASK_CAUSAL &&
+         lds_bytes(a) <= 64 * 1024 && (int64_t)a.B * a.H * a.Lq * a.Lk < (1ll << 32);
+}
+
+int mesm_attn_blk_bwd(const MesmAttnArgs& a, hipStream_t s) {
+  if (a.drop_p > 0.f) hipLaunchKernelGGL(attn_blk_bwd_kernel<true>, dim3((unsigned)(a.B * a.H)), dim3(BT), lds_bytes(a), s, a);
+  else hipLaunchKernelGGL(attn_blk_bwd_kernel<false>, dim3((unsigned)(a.B * a.H)), dim3(BT), lds_bytes(a), s, a);
+  return mesm_launch_status();
+}
+
+int mesm_attn_blk_bwd_group(const MesmAttnArgs* list, int n, hipStream_t s) {
+  if (n <= 0 || n > BLK_GROUP_MAX) return MESM_EINVAL;
+  BlkGroup g;
+  g.n = n;
+  g.start[0] = 0;
+  size_t lds = 0;
+  bool any_drop = false;
+  for (int i = 0; i < n; ++i) {
+    any_drop = any_drop || list[i].drop_p > 0.f;
+    g.p[i] = list[i];
+    g.start[i + 1] = g.start[i] + list[i].B * list[i].H;
+    const size_t need = lds_bytes(list[i]);
+    lds = need > lds ? need : lds;
+  }
+  if (any_drop) hipLaunchKernelGGL(attn_blk_bwd_group_kernel<true>, dim3((unsigned)g.start[n]), dim3(BT), lds, s, g);
+  else hipLaunchKernelGGL(attn_blk_bwd_group_kernel<false>, dim3((unsigned)g.start[n]), dim3(BT), lds, s, g);
+  return mesm_launch_status();
+}
