@@ -461,6 +461,14 @@ bool blk_bwd_enabled() {
   return on;
 }
 
+bool blk_fwd_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("MESM_ATTN_BLK_FWD");
+    return getenv("MESM_ATTN_LEGACY") == nullptr && !(e && atoi(e) == 0);
+  }();
+  return on;
+}
+
 int check_common(const MesmAttnArgs& a) {
   if (!a.q || !a.k || !a.v || !a.o) return MESM_EINVAL;
   if (a.B <= 0 || a.H <= 0 || a.Lq <= 0 || a.Lk <= 0) return MESM_EINVAL;
@@ -502,6 +510,7 @@ extern "C" int mesm_attn_fwd(const MesmAttnArgs* args, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   // the step's hot shapes run on the matrix cores (MESM_ATTN_LEGACY=1: this file's lane-per-key kernels, for A/B)
   static const bool legacy = getenv("MESM_ATTN_LEGACY") != nullptr;
+  if (blk_fwd_enabled() && mesm_attn_blk_fwd_ok(a)) return mesm_attn_blk_fwd(a, s);
   if (!legacy && mesm_attn_mfma_ok(a)) return mesm_attn_mfma_fwd(a, s);
   dim3 grid(a.B * a.H, (a.Lq + QCH - 1) / QCH);
   ATTN_DISPATCH(attn_fwd_kernel, grid, AT_THREADS);
@@ -547,9 +556,14 @@ extern "C" int mesm_attn_fwd_group(const MesmAttnArgs* list, int32_t n, void* st
   if (!list || n <= 0 || n > 64) return MESM_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   static const bool legacy = getenv("MESM_ATTN_LEGACY") != nullptr;
-  MesmAttnArgs grp[8];
-  int ng = 0, rc = MESM_OK;
+  MesmAttnArgs grp[8], blk[8];
+  int ng = 0, nblk = 0, rc = MESM_OK;
   auto flush = [&]() {
+    if (nblk > 0) {
+      rc = nblk == 1 ? mesm_attn_blk_fwd(blk[0], s) : mesm_attn_blk_fwd_group(blk, nblk, s);
+      nblk = 0;
+      if (rc != MESM_OK) return;
+    }
     if (ng == 0) return;
     rc = ng == 1 ? mesm_attn_mfma_fwd(grp[0], s) : mesm_attn_mfma_fwd_group(grp, ng, s);
     ng = 0;
@@ -557,7 +571,10 @@ extern "C" int mesm_attn_fwd_group(const MesmAttnArgs* list, int32_t n, void* st
   for (int i = 0; i < n && rc == MESM_OK; ++i) {
     rc = check_common(list[i]);
     if (rc != MESM_OK) return rc;
-    if (!legacy && mesm_attn_mfma_groupable(list[i])) {
+    if (blk_fwd_enabled() && mesm_attn_blk_fwd_groupable(list[i])) {
+      blk[nblk++] = list[i];
+      if (nblk == 8) flush();
+    } else if (!legacy && mesm_attn_mfma_groupable(list[i])) {
       grp[ng++] = list[i];
       if (ng == 8) flush();
     } else {

@@ -304,6 +304,206 @@ __global__ __launch_bounds__(BT) void attn_blk_bwd_group_kernel(const BlkGroup g
   else attn_blk_bwd_body<false>(p, bid - first);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Forward on the same blocks.  One workgroup per (batch, head): K and V staged once; a wave owns 16 queries (the
+// QUERY on the lane: S^T = K Q^T), keeps the scores of ALL key blocks in registers (NJ x 4), so the row maximum and
+// sum are in-lane loops plus two lane exchanges (lanes 16 / 32 apart hold the other keys of the row), and the
+// normalised, dropped probabilities are the A operands of O = P V.  DK = 64: the decoder's split heads
+// ([content || position] halves from q / q2 and k (+ k_add) / k2, transformer.py:778-784).
+__device__ __forceinline__ float max_xor16(float v) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float max_xor32(float v) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+template <int DK>
+struct FwdShape {
+  static constexpr int KS = DK + 4;  // K row stride
+  int LkP;
+  __host__ __device__ explicit FwdShape(int Lk) : LkP((Lk + 15) & ~15) {}
+  __host__ __device__ size_t floats() const { return (size_t)LkP * (KS + BS) + 2 * LkP + 4; }
+};
+
+template <int DK, int NJ, bool DROP>
+__device__ __forceinline__ void attn_blk_fwd_body(const MesmAttnArgs& p, const int bh) {
+  constexpr int KS = DK + 4, DQ = DK / 4;  // DQ reduce indices per lane group
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const FwdShape<DK> sh(p.Lk);
+  float* Ks = smem;
+  float* Vs = Ks + sh.LkP * KS;
+  float* Kp = Vs + sh.LkP * BS;
+  float* Kp2 = Kp + sh.LkP;
+  int* next = reinterpret_cast<int*>(Kp2 + sh.LkP);
+
+  const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+  const int b = bh / p.H, h = bh % p.H;
+  const int b2 = mesm_quirk_row(p, b, h);
+  const bool quirk = (p.mask_mode == MESM_MASK_T2V_QUIRK) && p.qpad && p.kpad;
+  const int Lq = p.Lq, Lk = p.Lk;
+  constexpr int DKH = DK / 2;
+  const bool split = DK == 64 && p.q2 != nullptr;
+  const int hq = h * (split ? DKH : DK);
+  const float* kb = p.k + (int64_t)b * p.k_bs + hq;
+  const float* kb2 = split ? p.k2 + (int64_t)b * p.k_bs + hq - DKH : kb;
+  const float* kadd = (split && p.k_add) ? p.k_add + (int64_t)b * p.k_bs + hq : nullptr;
+  const float* vb = p.v + (int64_t)b * p.v_bs + h * 32;
+
+  for (int idx = tid; idx < sh.LkP * (DK / 4); idx += nthr) {
+    const int r = idx / (DK / 4), c = (idx % (DK / 4)) * 4;
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < Lk) {
+      x = *reinterpret_cast<const float4*>((split && c >= DKH ? kb2 : kb) + (int64_t)r * p.k_ls + c);
+      if (kadd && c < DKH) {
+        const float4 y = *reinterpret_cast<const float4*>(kadd + (int64_t)r * p.k_ls + c);
+        x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+      }
+    }
+    *reinterpret_cast<float4*>(Ks + r * KS + c) = x;
+  }
+  for (int idx = tid; idx < sh.LkP * 8; idx += nthr) {
+    const int r = idx >> 3, c = (idx & 7) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < Lk) v = *reinterpret_cast<const float4*>(vb + (int64_t)r * p.v_ls + c);
+    *reinterpret_cast<float4*>(Vs + r * BS + c) = v;
+  }
+  for (int j = tid; j < sh.LkP; j += nthr) {
+    bool m = j >= Lk;
+    if (!m && p.kpad) m = p.kpad[(int64_t)b * Lk + j] != 0;
+    Kp[j] = m ? 1.0f : 0.0f;
+    Kp2[j] = (quirk && j < Lk && p.kpad[(int64_t)b2 * Lk + j] != 0) ? 1.0f : 0.0f;
+  }
+  if (tid == 0) *next = 0;
+  __syncthreads();
+
+  const uint32_t thresh = DROP ? mesm_drop_threshold(p.drop_p) : 0u;
+  const float inv_keep = 1.0f / (1.0f - p.drop_p);
+  const uint32_t drop_seed = p.drop_seed + (p.seed_offset ? *p.seed_offset : 0u);
+  const float scale = p.scale;
+  const int nI = (Lq + 15) >> 4, nJ = sh.LkP >> 4;
+  const int jl = lane & 15, kq = lane >> 4;
+  const float* qb = p.q + (int64_t)b * p.q_bs + hq;
+  const float* qb2 = split ? p.q2 + (int64_t)b * p.q_bs + hq - DKH : qb;
+  float* ob = p.o + (int64_t)b * p.o_bs + h * 32;
+
+  for (;;) {
+    int u = 0;
+    if (lane == 0) u = atomicAdd(next, 1);
+    u = __builtin_amdgcn_readfirstlane(u);
+    if (u >= nI) break;
+    const int i0 = u << 4, i = i0 + jl;
+    // the lane's share of its query row: reduce indices DQ kq .. DQ kq + DQ - 1 (split heads: lane groups 2, 3 = q2)
+    float qf[DQ];
+    {
+      const float* src = (split && kq >= 2 ? qb2 : qb) + (int64_t)(i < Lq ? i : 0) * p.q_ls + DQ * kq;
+#pragma unroll
+      for (int t = 0; t < DQ; t += 4) {
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < Lq) x = *reinterpret_cast<const float4*>(src + t);
+        qf[t] = x.x; qf[t + 1] = x.y; qf[t + 2] = x.z; qf[t + 3] = x.w;
+      }
+    }
+    const float qp_i = (quirk && i < Lq && p.qpad[(int64_t)b2 * Lq + i] != 0) ? 1.0f : 0.0f;
+    f32x4 st[NJ];
+    float m = -INFINITY;
+#pragma unroll
+    for (int jb = 0; jb < NJ; ++jb) {
+      st[jb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (jb < nJ) {
+        const float* krow = Ks + ((jb << 4) + jl) * KS + DQ * kq;
+#pragma unroll
+        for (int t = 0; t < DQ; t += 4) {
+          const float4 kf = *reinterpret_cast<const float4*>(krow + t);
+          st[jb] = mfma16(kf.x, qf[t], st[jb]);      // S^T[j0 + 4 kq + r][i0 + jl]
+          st[jb] = mfma16(kf.y, qf[t + 1], st[jb]);
+          st[jb] = mfma16(kf.z, qf[t + 2], st[jb]);
+          st[jb] = mfma16(kf.w, qf[t + 3], st[jb]);
+        }
+        const int jr = (jb << 4) + 4 * kq;
+        const float4 kp4 = *reinterpret_cast<const float4*>(Kp + jr);
+        const float4 kq4 = *reinterpret_cast<const float4*>(Kp2 + jr);
+        const float kp_[4] = {kp4.x, kp4.y, kp4.z, kp4.w};
+        const float kp2_[4] = {kq4.x, kq4.y, kq4.z, kq4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float mk = fmaf(qp_i, kp2_[r], kp_[r]);
+          const float sv = mk != 0.0f ? -INFINITY : st[jb][r] * scale;
+          st[jb][r] = sv;
+          m = fmaxf(m, sv);
+        }
+      }
+    }
+    m = max_xor32(max_xor16(m));
+    float l = 0.0f;
+#pragma unroll
+    for (int jb = 0; jb < NJ; ++jb) {
+      if (jb < nJ) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pj = (m == -INFINITY) ? 0.0f : __expf(st[jb][r] - m);
+          st[jb][r] = pj;
+          l += pj;
+        }
+      }
+    }
+    l = add_xor32(add_xor16(l));
+    const float inv_l = 1.0f / l;
+    f32x4 oa[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const uint32_t rowi = ((uint32_t)bh * (uint32_t)Lq + (uint32_t)i) * (uint32_t)Lk;
+#pragma unroll
+    for (int jb = 0; jb < NJ; ++jb) {
+      if (jb < nJ) {
+        const int jr = (jb << 4) + 4 * kq;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float pd = st[jb][r] * inv_l;
+          if (DROP) pd = mesm_hash32(rowi + (uint32_t)(jr + r), drop_seed) >= thresh ? pd * inv_keep : 0.0f;
+          const float* vrow = Vs + (jr + r) * BS + jl;
+          oa[0] = mfma16(pd, vrow[0], oa[0]);    // O[i0 + 4 kq + r'][jl], [16 + jl]
+          oa[1] = mfma16(pd, vrow[16], oa[1]);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ii = i0 + 4 * kq + r;
+      if (ii < Lq) {
+        ob[(int64_t)ii * p.o_ls + jl] = oa[0][r];
+        ob[(int64_t)ii * p.o_ls + 16 + jl] = oa[1][r];
+      }
+    }
+    if (kq == 0 && i < Lq && p.lse) p.lse[(int64_t)bh * Lq + i] = m + __logf(l);
+  }
+}
+
+template <int DK, int NJ, bool DROP>
+__global__ __launch_bounds__(512) void attn_blk_fwd_kernel(const MesmAttnArgs p) {
+  attn_blk_fwd_body<DK, NJ, DROP>(p, blockIdx.x);
+}
+
+template <int NJ, bool DROP>
+__global__ __launch_bounds__(512) void attn_blk_fwd_group_kernel(const BlkGroup g) {
+  const int bid = blockIdx.x;
+  int gi = 0;
+#pragma unroll
+  for (int k = 1; k < BLK_GROUP_MAX; ++k)
+    if (k < g.n && bid >= g.start[k]) gi = k;
+  const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+  const MesmAttnArgs p = *reinterpret_cast<const MesmAttnArgs*>(ka + offsetof(BlkGroup, p) + (size_t)gi * sizeof(MesmAttnArgs));
+  const int first = *reinterpret_cast<const int*>(ka + offsetof(BlkGroup, start) + (size_t)gi * sizeof(int));
+  if (DROP && p.drop_p > 0.f) attn_blk_fwd_body<32, NJ, true>(p, bid - first);
+  else attn_blk_fwd_body<32, NJ, false>(p, bid - first);
+}
+
+template <int DK>
+size_t fwd_lds_bytes(const MesmAttnArgs& a) { return FwdShape<DK>(a.Lk).floats() * sizeof(float); }
+int fwd_waves(const MesmAttnArgs& a) {
+  const int nI = (a.Lq + 15) / 16;
+  return nI < 8 ? nI : 8;
+}
+
 size_t lds_bytes(const MesmAttnArgs& a) { return BlkShape(a.Lq, a.Lk).floats() * sizeof(float); }
 
 }  // namespace
@@ -338,3 +538,68 @@ int mesm_attn_blk_bwd_group(const MesmAttnArgs* list, int n, hipStream_t s) {
   else hipLaunchKernelGGL(attn_blk_bwd_group_kernel<false>, dim3((unsigned)g.start[n]), dim3(BT), lds, s, g);
   return mesm_launch_status();
 }
+
+// forward: dk = 32 packed heads or dk = 64 split heads, dv = 32, at most 128 keys (their scores stay in registers)
+bool mesm_attn_blk_fwd_ok(const MesmAttnArgs& a) {
+  if (a.dv != 32 || a.mask_mode == MESM_MASK_CAUSAL || a.Lk > 128) return false;
+  if (a.dk == 32) return !a.q2 && !a.k2 && !a.k_add;
+  // (one query block per head = one busy wave per workgroup: the lane-per-key kernel is quicker there,
+  // 10 x 75 split heads 10.3 vs 11.6 us)
+  return a.dk == 64 && a.Lq > 16 && ((a.q2 && a.k2) || (!a.q2 && !a.k2 && !a.k_add));
+}
+bool mesm_attn_blk_fwd_groupable(const MesmAttnArgs& a) { return mesm_attn_blk_fwd_ok(a) && a.dk == 32; }
+
+#define BLK_FWD_NJ(KERNEL, NJV, ...)                                                                  \
+  do {                                                                                                \
+    switch (NJV) {                                                                                    \
+      case 1: KERNEL(1, __VA_ARGS__); break;                                                          \
+      case 2: KERNEL(2, __VA_ARGS__); break;                                                          \
+      case 3: KERNEL(3, __VA_ARGS__); break;                                                          \
+      case 4: KERNEL(4, __VA_ARGS__); break;                                                          \
+      case 5: KERNEL(5, __VA_ARGS__); break;                                                          \
+      case 6: KERNEL(6, __VA_ARGS__); break;                                                          \
+      default: KERNEL(8, __VA_ARGS__); break;                                                         \
+    }                                                                                                 \
+  } while (0)
+
+int mesm_attn_blk_fwd(const MesmAttnArgs& a, hipStream_t s) {
+  const int nj = (a.Lk + 15) / 16;
+  const dim3 grid((unsigned)(a.B * a.H)), block(64 * fwd_waves(a));
+  const bool drop = a.drop_p > 0.f;
+#define LAUNCH1(NJ, DK)                                                                                        \
+  if (drop) hipLaunchKernelGGL((attn_blk_fwd_kernel<DK, NJ, true>), grid, block, fwd_lds_bytes<DK>(a), s, a); \
+  else hipLaunchKernelGGL((attn_blk_fwd_kernel<DK, NJ, false>), grid, block, fwd_lds_bytes<DK>(a), s, a)
+  if (a.dk == 32) BLK_FWD_NJ(LAUNCH1, nj, 32);
+  else BLK_FWD_NJ(LAUNCH1, nj, 64);
+#undef LAUNCH1
+  return mesm_launch_status();
+}
+
+int mesm_attn_blk_fwd_group(const MesmAttnArgs* list, int n, hipStream_t s) {
+  if (n <= 0 || n > BLK_GROUP_MAX) return MESM_EINVAL;
+  BlkGroup g;
+  g.n = n;
+  g.start[0] = 0;
+  size_t lds = 0;
+  int nj = 1, waves = 1;
+  bool drop = false;
+  for (int i = 0; i < n; ++i) {
+    g.p[i] = list[i];
+    g.start[i + 1] = g.start[i] + list[i].B * list[i].H;
+    const size_t need = fwd_lds_bytes<32>(list[i]);
+    lds = need > lds ? need : lds;
+    const int j = (list[i].Lk + 15) / 16;
+    nj = j > nj ? j : nj;
+    const int w = fwd_waves(list[i]);
+    waves = w > waves ? w : waves;
+    drop = drop || list[i].drop_p > 0.f;
+  }
+  const dim3 grid((unsigned)g.start[n]), block(64 * waves);
+#define LAUNCHG(NJ, UNUSED)                                                                       \
+  if (drop) hipLaunchKernelGGL((attn_blk_fwd_group_kernel<NJ, true>), grid, block, lds, s, g);     \
+  else hipLaunchKernelGGL((attn_blk_fwd_group_kernel<NJ, false>), grid, block, lds, s, g)
+  BLK_FWD_NJ(LAUNCHG, nj, 0);
+#undef LAUNCHG
+  return mesm_launch_status();
+}
+

@@ -8,3 +8,9 @@ bool mesm_attn_blk_bwd_ok(const MesmAttnArgs& a);
 int mesm_attn_blk_bwd(const MesmAttnArgs& a, hipStream_t s);
 // n <= 8 problems for which mesm_attn_blk_bwd_ok() holds, one launch
 int mesm_attn_blk_bwd_group(const MesmAttnArgs* list, int n, hipStream_t s);
+
+// forward on the same blocks: dk = 32 packed heads (groupable) or dk = 64 split heads, dv = 32, Lk <= 128
+bool mesm_attn_blk_fwd_ok(const MesmAttnArgs& a);
+bool mesm_attn_blk_fwd_groupable(const MesmAttnArgs& a);
+int mesm_attn_blk_fwd(const MesmAttnArgs& a, hipStream_t s);
+int mesm_attn_blk_fwd_group(const MesmAttnArgs* list, int n, hipStream_t s);
