@@ -615,7 +615,7 @@ extern "C" int mesm_attn_bwd_group(const MesmAttnArgs* list, int32_t n, void* st
     rc = check_bwd(a);
     if (rc != MESM_OK) return rc;
     const bool lane_per_key = legacy || !mesm_attn_mfma_bwd_ok(a);
-    if (lane_per_key && blk_bwd_enabled() && mesm_attn_blk_bwd_ok(a)) {
+    if (lane_per_key && blk_bwd_enabled() && mesm_attn_blk_bwd_groupable(a)) {
       blk[nblk++] = a;
       if (nblk == 8) flush();
     } else if (lane_per_key && a.dk == 32 && a.dv == 32 && !a.q2) {

@@ -29,40 +29,42 @@ constexpr int BS = 36;  // LDS row stride in floats
 #ifndef MESM_BLK_THREADS
 #define MESM_BLK_THREADS 512
 #endif
-#ifndef MESM_BLK_SSTEPS
-#define MESM_BLK_SSTEPS 8  // (probe builds: fewer reduce steps of the score products)
-#endif
-#ifndef MESM_BLK_TSTEPS
-#define MESM_BLK_TSTEPS 4
-#endif
 constexpr int BT = MESM_BLK_THREADS;  // 8 waves: a 76 x 76 head has 5 + 5 units
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+template <int DK>
 struct BlkShape {
-  int LqP, LkP;  // padded to 16
+  static constexpr int QS = DK + 4;  // Q / K row stride (dO / V rows: BS)
+  int LqP, LkP;                      // padded to 16
   __host__ __device__ BlkShape(int Lq, int Lk) : LqP((Lq + 15) & ~15), LkP((Lk + 15) & ~15) {}
-  __host__ __device__ size_t floats() const { return (size_t)(2 * LqP + 2 * LkP) * BS + 3 * LqP + 2 * LkP + 4; }
+  __host__ __device__ size_t floats() const { return (size_t)(LqP + LkP) * (QS + BS) + 3 * LqP + 2 * LkP + 4; }
 };
 
-// eight consecutive floats of an LDS row (the lane's share of a 16 x 32 operand: reduce indices 8 kq .. 8 kq + 7)
-__device__ __forceinline__ void load8(const float* p, float* f) {
-  const float4 a = *reinterpret_cast<const float4*>(p);
-  const float4 b = *reinterpret_cast<const float4*>(p + 4);
-  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w;
-  f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+// N consecutive floats of an LDS row (the lane's share of a 16 x DK operand: reduce indices N kq .. N kq + N - 1)
+template <int N>
+__device__ __forceinline__ void loadN(const float* p, float* f) {
+#pragma unroll
+  for (int t = 0; t < N; t += 4) {
+    const float4 a = *reinterpret_cast<const float4*>(p + t);
+    f[t] = a.x; f[t + 1] = a.y; f[t + 2] = a.z; f[t + 3] = a.w;
+  }
 }
 
-template <bool DROP>
+// DK = 64: the decoder's split heads ([content || position] halves of q / q2, k (+ k_add) / k2; the gradients go
+// back into dq / dq2, dk_ / dk2), or a packed 64-wide head.
+template <int DK, bool DROP>
 __device__ __forceinline__ void attn_blk_bwd_body(const MesmAttnArgs& p, const int bh) {
+  constexpr int QS = DK + 4, DQ = DK / 4, ND = DK / 16;
+  constexpr int DKH = DK / 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const BlkShape sh(p.Lq, p.Lk);
+  const BlkShape<DK> sh(p.Lq, p.Lk);
   float* Qs = smem;
-  float* Gs = Qs + sh.LqP * BS;   // dO
+  float* Gs = Qs + sh.LqP * QS;   // dO
   float* Ks = Gs + sh.LqP * BS;
-  float* Vs = Ks + sh.LkP * BS;
+  float* Vs = Ks + sh.LkP * QS;
   float* Lse = Vs + sh.LkP * BS;  // LqP
   float* Dl = Lse + sh.LqP;       // LqP
   float* Qp2 = Dl + sh.LqP;       // LqP: query padded in the quirk row
@@ -76,35 +78,52 @@ __device__ __forceinline__ void attn_blk_bwd_body(const MesmAttnArgs& p, const i
   const bool quirk = (p.mask_mode == MESM_MASK_T2V_QUIRK) && p.qpad && p.kpad;
   const int Lq = p.Lq, Lk = p.Lk;
 
-  const float* qb = p.q + (int64_t)b * p.q_bs + h * 32;
-  const float* kb = p.k + (int64_t)b * p.k_bs + h * 32;
+  const bool split = DK == 64 && p.q2 != nullptr;
+  const int hq = h * (split ? DKH : DK);
+  const float* qb = p.q + (int64_t)b * p.q_bs + hq;
+  const float* kb = p.k + (int64_t)b * p.k_bs + hq;
+  const float* qb2 = split ? p.q2 + (int64_t)b * p.q_bs + hq - DKH : qb;
+  const float* kb2 = split ? p.k2 + (int64_t)b * p.k_bs + hq - DKH : kb;
+  const float* kadd = (split && p.k_add) ? p.k_add + (int64_t)b * p.k_bs + hq : nullptr;
   const float* vb = p.v + (int64_t)b * p.v_bs + h * 32;
   const float* ob = p.o + (int64_t)b * p.o_bs + h * 32;
   const float* gb = p.d_o + (int64_t)b * p.o_bs + h * 32;
 
-  // ---- stage the head: 8 consecutive threads per 32-float row
-  for (int idx = tid; idx < sh.LqP * 8; idx += BT) {
+  // ---- stage the head
+  for (int idx = tid; idx < sh.LqP * (DK / 4); idx += BT) {
+    const int r = idx / (DK / 4), c = (idx % (DK / 4)) * 4;
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < Lq) q = *reinterpret_cast<const float4*>((split && c >= DKH ? qb2 : qb) + (int64_t)r * p.q_ls + c);
+    *reinterpret_cast<float4*>(Qs + r * QS + c) = q;
+  }
+  for (int idx = tid; idx < sh.LqP * 8; idx += BT) {  // 8 consecutive threads per 32-float row
     const int r = idx >> 3, c = (idx & 7) * 4;
-    float4 q = make_float4(0.f, 0.f, 0.f, 0.f), g = q, o = q;
+    float4 g = make_float4(0.f, 0.f, 0.f, 0.f), o = g;
     if (r < Lq) {
-      q = *reinterpret_cast<const float4*>(qb + (int64_t)r * p.q_ls + c);
       g = *reinterpret_cast<const float4*>(gb + (int64_t)r * p.o_ls + c);
       o = *reinterpret_cast<const float4*>(ob + (int64_t)r * p.o_ls + c);
     }
-    *reinterpret_cast<float4*>(Qs + r * BS + c) = q;
     *reinterpret_cast<float4*>(Gs + r * BS + c) = g;
     float part = g.x * o.x + g.y * o.y + g.z * o.z + g.w * o.w;
     part = sum_within<8>(part);
     if ((idx & 7) == 0) Dl[r] = part;
   }
+  for (int idx = tid; idx < sh.LkP * (DK / 4); idx += BT) {
+    const int r = idx / (DK / 4), c = (idx % (DK / 4)) * 4;
+    float4 k = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < Lk) {
+      k = *reinterpret_cast<const float4*>((split && c >= DKH ? kb2 : kb) + (int64_t)r * p.k_ls + c);
+      if (kadd && c < DKH) {  // content half = kcontent + kpos (decoder layer 0, transformer.py:773-776)
+        const float4 y = *reinterpret_cast<const float4*>(kadd + (int64_t)r * p.k_ls + c);
+        k.x += y.x; k.y += y.y; k.z += y.z; k.w += y.w;
+      }
+    }
+    *reinterpret_cast<float4*>(Ks + r * QS + c) = k;
+  }
   for (int idx = tid; idx < sh.LkP * 8; idx += BT) {
     const int r = idx >> 3, c = (idx & 7) * 4;
-    float4 k = make_float4(0.f, 0.f, 0.f, 0.f), v = k;
-    if (r < Lk) {
-      k = *reinterpret_cast<const float4*>(kb + (int64_t)r * p.k_ls + c);
-      v = *reinterpret_cast<const float4*>(vb + (int64_t)r * p.v_ls + c);
-    }
-    *reinterpret_cast<float4*>(Ks + r * BS + c) = k;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < Lk) v = *reinterpret_cast<const float4*>(vb + (int64_t)r * p.v_ls + c);
     *reinterpret_cast<float4*>(Vs + r * BS + c) = v;
   }
   for (int r = tid; r < sh.LqP; r += BT) {
@@ -130,17 +149,6 @@ __device__ __forceinline__ void attn_blk_bwd_body(const MesmAttnArgs& p, const i
   const int nI = sh.LqP >> 4, nJ = sh.LkP >> 4;
   const int jl = lane & 15, kq = lane >> 4;
 
-#ifdef MESM_BLK_STAGGER
-  {
-    const int ph = ((tid >> 8) & 1) + 2 * ((blockIdx.x >> 8) & 1);
-    if (ph == 1) __builtin_amdgcn_s_sleep(6);
-    if (ph == 2) __builtin_amdgcn_s_sleep(12);
-    if (ph == 3) __builtin_amdgcn_s_sleep(18);
-  }
-#endif
-#ifdef MESM_BLK_PROBE_NOCOMPUTE
-  if (p.Lq > 0) return;
-#endif
   for (;;) {
     int u = 0;
     if (lane == 0) u = atomicAdd(next, 1);
@@ -149,32 +157,39 @@ __device__ __forceinline__ void attn_blk_bwd_body(const MesmAttnArgs& p, const i
     if (u < nJ) {
       // ------------------------------------------------------------------ J unit: keys j0 .. j0 + 15
       const int j0 = u << 4;
-      float kf[8], vf[8];
-      load8(Ks + (j0 + jl) * BS + 8 * kq, kf);
-      load8(Vs + (j0 + jl) * BS + 8 * kq, vf);
+      float kf[DQ], vf[8];
+      loadN<DQ>(Ks + (j0 + jl) * QS + DQ * kq, kf);
+      loadN<8>(Vs + (j0 + jl) * BS + 8 * kq, vf);
       const float kpj = Kp[j0 + jl], kp2j = Kp2[j0 + jl];
       const uint32_t j = (uint32_t)(j0 + jl);
-      f32x4 dVa[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-      f32x4 dKa[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      f32x4 dVa[2], dKa[ND];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) dVa[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < ND; ++c) dKa[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
       for (int ib = 0; ib < nI; ++ib) {
         const int i0 = ib << 4;
-        float qf[8], gf[8];
-        load8(Qs + (i0 + jl) * BS + 8 * kq, qf);
-        load8(Gs + (i0 + jl) * BS + 8 * kq, gf);
+        float qf[DQ], gf[8];
+        loadN<DQ>(Qs + (i0 + jl) * QS + DQ * kq, qf);
+        loadN<8>(Gs + (i0 + jl) * BS + 8 * kq, gf);
         f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < MESM_BLK_SSTEPS; ++t) {
+        for (int t = 0; t < 8; ++t) {
           s = mfma16(qf[t], kf[t], s);     // S[i0 + 4 kq + r][j0 + jl]
           dp = mfma16(gf[t], vf[t], dp);   // dP, same layout
         }
+#pragma unroll
+        for (int t = 8; t < DQ; ++t) s = mfma16(qf[t], kf[t], s);
         const int ir = i0 + 4 * kq;
-        // B operands of the four products below (rows ir + r of dO and Q, columns jl and 16 + jl): issued ahead of
-        // the element-wise work so their LDS latency hides behind it
-        float gb0[4], gb1[4], qb0[4], qb1[4];
+        // B operands of the products below (rows ir + r of dO and Q, 16-column blocks): issued ahead of the
+        // element-wise work so their LDS latency hides behind it
+        float gbv[2][4], qbv[ND][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          gb0[r] = Gs[(ir + r) * BS + jl]; gb1[r] = Gs[(ir + r) * BS + 16 + jl];
-          qb0[r] = Qs[(ir + r) * BS + jl]; qb1[r] = Qs[(ir + r) * BS + 16 + jl];
+#pragma unroll
+          for (int c = 0; c < 2; ++c) gbv[c][r] = Gs[(ir + r) * BS + 16 * c + jl];
+#pragma unroll
+          for (int c = 0; c < ND; ++c) qbv[c][r] = Qs[(ir + r) * QS + 16 * c + jl];
         }
         const float4 lse4 = *reinterpret_cast<const float4*>(Lse + ir);
         const float4 dl4 = *reinterpret_cast<const float4*>(Dl + ir);
@@ -195,55 +210,59 @@ __device__ __forceinline__ void attn_blk_bwd_body(const MesmAttnArgs& p, const i
           }
           pd[r] = pj * km;
           ds[r] = pj * (dp[r] * km - dl_[r]) * scale;
-#ifdef MESM_BLK_PROBE_NOELT
-          pd[r] = s[r]; ds[r] = dp[r];
-#endif
         }
 #pragma unroll
-        for (int r = 0; r < MESM_BLK_TSTEPS; ++r) {
-          dVa[0] = mfma16(pd[r], gb0[r], dVa[0]);
-          dKa[0] = mfma16(ds[r], qb0[r], dKa[0]);
-          dVa[1] = mfma16(pd[r], gb1[r], dVa[1]);
-          dKa[1] = mfma16(ds[r], qb1[r], dKa[1]);
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+          for (int c = 0; c < 2; ++c) dVa[c] = mfma16(pd[r], gbv[c][r], dVa[c]);
+#pragma unroll
+          for (int c = 0; c < ND; ++c) dKa[c] = mfma16(ds[r], qbv[c][r], dKa[c]);
         }
       }
-      float* dkb = p.dk_ + (int64_t)b * p.k_bs + h * 32;
+      float* dkb = p.dk_ + (int64_t)b * p.k_bs + hq;
+      float* dkb2 = split ? p.dk2 + (int64_t)b * p.k_bs + hq - DKH : dkb;
       float* dvb = p.dv_ + (int64_t)b * p.v_bs + h * 32;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int jj = j0 + 4 * kq + r;
         if (jj < Lk) {
-          dkb[(int64_t)jj * p.k_ls + jl] = dKa[0][r];
-          dkb[(int64_t)jj * p.k_ls + 16 + jl] = dKa[1][r];
-          dvb[(int64_t)jj * p.v_ls + jl] = dVa[0][r];
-          dvb[(int64_t)jj * p.v_ls + 16 + jl] = dVa[1][r];
+#pragma unroll
+          for (int c = 0; c < ND; ++c) (16 * c >= DKH ? dkb2 : dkb)[(int64_t)jj * p.k_ls + 16 * c + jl] = dKa[c][r];
+#pragma unroll
+          for (int c = 0; c < 2; ++c) dvb[(int64_t)jj * p.v_ls + 16 * c + jl] = dVa[c][r];
         }
       }
     } else {
       // ------------------------------------------------------------------ I unit: queries i0 .. i0 + 15
       const int i0 = (u - nJ) << 4;
-      float qf[8], gf[8];
-      load8(Qs + (i0 + jl) * BS + 8 * kq, qf);
-      load8(Gs + (i0 + jl) * BS + 8 * kq, gf);
+      float qf[DQ], gf[8];
+      loadN<DQ>(Qs + (i0 + jl) * QS + DQ * kq, qf);
+      loadN<8>(Gs + (i0 + jl) * BS + 8 * kq, gf);
       const float lse_i = Lse[i0 + jl], dl_i = Dl[i0 + jl];
       const float qp_i = Qp2[i0 + jl];
       const uint32_t rowi = (row0 + (uint32_t)(i0 + jl)) * (uint32_t)Lk;
-      f32x4 dQa[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      f32x4 dQa[ND];
+#pragma unroll
+      for (int c = 0; c < ND; ++c) dQa[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
       for (int jb = 0; jb < nJ; ++jb) {
         const int j0 = jb << 4;
-        float kf[8], vf[8];
-        load8(Ks + (j0 + jl) * BS + 8 * kq, kf);
-        load8(Vs + (j0 + jl) * BS + 8 * kq, vf);
+        float kf[DQ], vf[8];
+        loadN<DQ>(Ks + (j0 + jl) * QS + DQ * kq, kf);
+        loadN<8>(Vs + (j0 + jl) * BS + 8 * kq, vf);
         f32x4 st = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int t = 0; t < MESM_BLK_SSTEPS; ++t) {
+        for (int t = 0; t < 8; ++t) {
           st = mfma16(kf[t], qf[t], st);    // S^T[j0 + 4 kq + r][i0 + jl]
           dpt = mfma16(vf[t], gf[t], dpt);
         }
-        const int jr = j0 + 4 * kq;
-        float kb0[4], kb1[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { kb0[r] = Ks[(jr + r) * BS + jl]; kb1[r] = Ks[(jr + r) * BS + 16 + jl]; }
+        for (int t = 8; t < DQ; ++t) st = mfma16(kf[t], qf[t], st);
+        const int jr = j0 + 4 * kq;
+        float kbv[ND][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < ND; ++c) kbv[c][r] = Ks[(jr + r) * QS + 16 * c + jl];
         const float4 kp4 = *reinterpret_cast<const float4*>(Kp + jr);
         const float4 kq4 = *reinterpret_cast<const float4*>(Kp2 + jr);
         const float kp_[4] = {kp4.x, kp4.y, kp4.z, kp4.w};
@@ -257,31 +276,28 @@ __device__ __forceinline__ void attn_blk_bwd_body(const MesmAttnArgs& p, const i
           float km = 1.0f;
           if (DROP) km = mesm_hash32(rowi + (uint32_t)(jr + r), drop_seed) >= thresh ? inv_keep : 0.0f;
           ds[r] = pj * (dpt[r] * km - dl_i) * scale;
-#ifdef MESM_BLK_PROBE_NOELT
-          ds[r] = st[r] + dpt[r];
-#endif
         }
 #pragma unroll
-        for (int r = 0; r < MESM_BLK_TSTEPS; ++r) {
-          dQa[0] = mfma16(ds[r], kb0[r], dQa[0]);
-          dQa[1] = mfma16(ds[r], kb1[r], dQa[1]);
-        }
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int c = 0; c < ND; ++c) dQa[c] = mfma16(ds[r], kbv[c][r], dQa[c]);
       }
-      float* dqb = p.dq + (int64_t)b * p.q_bs + h * 32;
+      float* dqb = p.dq + (int64_t)b * p.q_bs + hq;
+      float* dqb2 = split ? p.dq2 + (int64_t)b * p.q_bs + hq - DKH : dqb;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ii = i0 + 4 * kq + r;
         if (ii < Lq) {
-          dqb[(int64_t)ii * p.q_ls + jl] = dQa[0][r];
-          dqb[(int64_t)ii * p.q_ls + 16 + jl] = dQa[1][r];
+#pragma unroll
+          for (int c = 0; c < ND; ++c) (16 * c >= DKH ? dqb2 : dqb)[(int64_t)ii * p.q_ls + 16 * c + jl] = dQa[c][r];
         }
       }
     }
   }
 }
 
-template <bool DROP>
-__global__ __launch_bounds__(BT) void attn_blk_bwd_kernel(const MesmAttnArgs p) { attn_blk_bwd_body<DROP>(p, blockIdx.x); }
+template <int DK, bool DROP>
+__global__ __launch_bounds__(BT) void attn_blk_bwd_kernel(const MesmAttnArgs p) { attn_blk_bwd_body<DK, DROP>(p, blockIdx.x); }
 
 constexpr int BLK_GROUP_MAX = 8;
 struct BlkGroup {
@@ -300,8 +316,8 @@ __global__ __launch_bounds__(BT) void attn_blk_bwd_group_kernel(const BlkGroup g
   const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
   const MesmAttnArgs p = *reinterpret_cast<const MesmAttnArgs*>(ka + offsetof(BlkGroup, p) + (size_t)gi * sizeof(MesmAttnArgs));
   const int first = *reinterpret_cast<const int*>(ka + offsetof(BlkGroup, start) + (size_t)gi * sizeof(int));
-  if (DROP && p.drop_p > 0.f) attn_blk_bwd_body<true>(p, bid - first);
-  else attn_blk_bwd_body<false>(p, bid - first);
+  if (DROP && p.drop_p > 0.f) attn_blk_bwd_body<32, true>(p, bid - first);
+  else attn_blk_bwd_body<32, false>(p, bid - first);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -504,19 +520,32 @@ int fwd_waves(const MesmAttnArgs& a) {
   return nI < 8 ? nI : 8;
 }
 
-size_t lds_bytes(const MesmAttnArgs& a) { return BlkShape(a.Lq, a.Lk).floats() * sizeof(float); }
+size_t lds_bytes(const MesmAttnArgs& a) {
+  return (a.dk == 64 ? BlkShape<64>(a.Lq, a.Lk).floats() : BlkShape<32>(a.Lq, a.Lk).floats()) * sizeof(float);
+}
 
 }  // namespace
 
-// dk = dv = 32, packed heads, the staged head within 64 KB of LDS (Lq + Lk up to ~220), 32-bit dropout / mask indices
+// dk = dv = 32 packed heads (groupable), or dk = 64 / dv = 32 split or packed heads; the staged head within 64 KB of
+// LDS (Lq + Lk up to ~220 at dk = 32)
 bool mesm_attn_blk_bwd_ok(const MesmAttnArgs& a) {
-  return a.dk == 32 && a.dv == 32 && !a.q2 && !a.k2 && !a.k_add && a.mask_mode != MESM_MASK_CAUSAL &&
-         lds_bytes(a) <= 64 * 1024 && (int64_t)a.B * a.H * a.Lq * a.Lk < (1ll << 32);
+  if (a.dv != 32 || a.mask_mode == MESM_MASK_CAUSAL || lds_bytes(a) > 64 * 1024) return false;
+  if (a.dk == 32) return !a.q2 && !a.k2 && !a.k_add;
+  return a.dk == 64 && ((a.q2 && a.k2 && a.dq2 && a.dk2) || (!a.q2 && !a.k2 && !a.k_add));
 }
+bool mesm_attn_blk_bwd_groupable(const MesmAttnArgs& a) { return mesm_attn_blk_bwd_ok(a) && a.dk == 32; }
 
 int mesm_attn_blk_bwd(const MesmAttnArgs& a, hipStream_t s) {
-  if (a.drop_p > 0.f) hipLaunchKernelGGL(attn_blk_bwd_kernel<true>, dim3((unsigned)(a.B * a.H)), dim3(BT), lds_bytes(a), s, a);
-  else hipLaunchKernelGGL(attn_blk_bwd_kernel<false>, dim3((unsigned)(a.B * a.H)), dim3(BT), lds_bytes(a), s, a);
+  const dim3 grid((unsigned)(a.B * a.H)), block(BT);
+  const size_t lds = lds_bytes(a);
+  const bool drop = a.drop_p > 0.f;
+  if (a.dk == 32) {
+    if (drop) hipLaunchKernelGGL((attn_blk_bwd_kernel<32, true>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((attn_blk_bwd_kernel<32, false>), grid, block, lds, s, a);
+  } else {
+    if (drop) hipLaunchKernelGGL((attn_blk_bwd_kernel<64, true>), grid, block, lds, s, a);
+    else hipLaunchKernelGGL((attn_blk_bwd_kernel<64, false>), grid, block, lds, s, a);
+  }
   return mesm_launch_status();
 }
 

@@ -5,6 +5,7 @@
 #include "mesm_gfx950.h"
 
 bool mesm_attn_blk_bwd_ok(const MesmAttnArgs& a);
+bool mesm_attn_blk_bwd_groupable(const MesmAttnArgs& a);  // dk = 32 only
 int mesm_attn_blk_bwd(const MesmAttnArgs& a, hipStream_t s);
 // n <= 8 problems for which mesm_attn_blk_bwd_ok() holds, one launch
 int mesm_attn_blk_bwd_group(const MesmAttnArgs* list, int n, hipStream_t s);
