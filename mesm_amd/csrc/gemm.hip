@@ -2087,6 +2087,203 @@ int launch_lds64(const MesmGemmArgs& a, hipStream_t s) {
   return launch_lds64_l<O, R>(a, s);
 }
 
+// ------------------------------------------------------------------------------------------------
+// "big16" kernel: ONE round of large tiles on v_mfma_f32_16x16x4_f32 for the FFN-shaped products with a short reduce
+// range and a wide output (4800 x 1024 x 256: transformer.py:537, 603, 608, 647, 794 forward and their dz backward).
+// 64 x 64 tiles make 1216 workgroups there = 4.75 tiles per CU, each with its own first-load latency and epilogue
+// (section 4 of DESIGN.md: 36 us = 69 TF).  Here a workgroup (8 waves = 2 x 4, two per SIMD) owns a 160 x 128 tile:
+// 30 x 8 = 240 workgroups = one round on 256 CUs, one prologue and one epilogue per CU.  A wave's 80 x 32 share is
+// 5 x 2 accumulator blocks of 16 x 16: per reduce step of 4 it reads 7 operand values for 10 matrix instructions,
+// ten independent accumulators (no dependent issue), operands staged through registers into a double-buffered LDS
+// chunk of 32 reduce indices ([row][k], 36-float rows: the lane's 8 consecutive reduce indices are two conflict-free
+// 16-byte reads -- the k order inside a chunk is permuted the same way for A and B).
+// Plain operands only (no operand transform, no A2 / B2, no split-K, no column sums); every epilogue term.
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr int BG_THREADS = 512, BG_WMB = 5, BG_WNB = 2, BG_TM = 2 * BG_WMB * 16, BG_TN = 4 * BG_WNB * 16;
+constexpr int BG_AS = 36, BG_BSN = BG_TN + 2;
+template <int LB>
+constexpr int bg_b_floats() { return LB == MESM_LAYOUT_REDUCE_CONTIG ? BG_TN * BG_AS : 32 * BG_BSN; }
+template <int LB>
+constexpr size_t bg_lds_bytes() { return (size_t)2 * (BG_TM * BG_AS + bg_b_floats<LB>()) * sizeof(float); }
+
+constexpr int BG_NA = (BG_TM * 8 + BG_THREADS - 1) / BG_THREADS, BG_NB = (BG_TN * 8) / BG_THREADS;
+
+// staging: A chunk = 160 rows x 8 float4, B chunk = 128 rows x 8 float4 ([n][k]) or 32 rows x 32 float4 ([k][n]).
+// The loads are volatile asm: written as plain loads hipcc sinks them below the matrix instructions, next to the LDS
+// stores that use them (a load round trip per chunk in the open), and a sched_barrier sends the staging registers to
+// scratch.  The caller waits (s_waitcnt vmcnt(0)) before bg_lstore.
+__device__ __forceinline__ f32x4_t bg_ld16(const float* ptr) {
+  f32x4_t v;
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
+  return v;
+}
+
+template <int LB>
+__device__ __forceinline__ void bg_gload(const MesmGemmArgs& p, int m0, int n0, int k0, int tid, f32x4_t (&ra)[BG_NA],
+                                         f32x4_t (&rb)[BG_NB]) {
+#pragma unroll
+  for (int v = 0; v < BG_NA; ++v) {
+    int idx = tid + v * BG_THREADS;
+    idx = idx < BG_TM * 8 ? idx : BG_TM * 8 - 1;
+    const int r = idx >> 3, c = (idx & 7) * 4;
+    int gm = m0 + r;
+    gm = gm < p.M ? gm : p.M - 1;
+    ra[v] = bg_ld16(p.A + (int64_t)gm * p.lda + k0 + c);
+  }
+#pragma unroll
+  for (int v = 0; v < BG_NB; ++v) {
+    const int idx = tid + v * BG_THREADS;
+    if (LB == MESM_LAYOUT_REDUCE_CONTIG) {
+      const int r = idx >> 3, c = (idx & 7) * 4;
+      rb[v] = bg_ld16(p.B + (int64_t)(n0 + r) * p.ldb + k0 + c);
+    } else {
+      const int k = idx >> 5, c = (idx & 31) * 4;
+      rb[v] = bg_ld16(p.B + (int64_t)(k0 + k) * p.ldb + n0 + c);
+    }
+  }
+}
+
+template <int LB>
+__device__ __forceinline__ void bg_lstore(float* Ab, float* Bb, int tid, const f32x4_t (&ra)[BG_NA], const f32x4_t (&rb)[BG_NB]) {
+#pragma unroll
+  for (int v = 0; v < BG_NA; ++v) {
+    const int idx = tid + v * BG_THREADS;
+    const int r = idx >> 3, c = (idx & 7) * 4;
+    if (idx < BG_TM * 8) *reinterpret_cast<f32x4_t*>(Ab + r * BG_AS + c) = ra[v];
+  }
+#pragma unroll
+  for (int v = 0; v < BG_NB; ++v) {
+    const int idx = tid + v * BG_THREADS;
+    if (LB == MESM_LAYOUT_REDUCE_CONTIG) {
+      const int r = idx >> 3, c = (idx & 7) * 4;
+      *reinterpret_cast<f32x4_t*>(Bb + r * BG_AS + c) = rb[v];
+    } else {
+      const int k = idx >> 5, c = (idx & 31) * 4;
+      float* d = Bb + k * BG_BSN + c;  // 130-float rows: 8-byte aligned
+      *reinterpret_cast<float2*>(d) = make_float2(rb[v][0], rb[v][1]);
+      *reinterpret_cast<float2*>(d + 2) = make_float2(rb[v][2], rb[v][3]);
+    }
+  }
+}
+
+template <int LB>
+__global__ __launch_bounds__(BG_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_big16_kernel(const MesmGemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float bg_smem[];
+  constexpr int AF = BG_TM * BG_AS, BF = bg_b_floats<LB>();
+  __shared__ float sh4[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int jl = lane & 15, kq = lane >> 4;
+  const int wm = wave >> 2, wn = wave & 3;
+  int tbx, tby;
+  xcd_tile(blockIdx.x, (p.M + BG_TM - 1) / BG_TM, p.N / BG_TN, tbx, tby);
+  const int m0 = tbx * BG_TM, n0 = tby * BG_TN;
+  const float slope = p.slope ? *p.slope : 0.0f;
+  const uint32_t seed_off = p.seed_offset ? *p.seed_offset : 0u;
+  f32x4_t ra[BG_NA], rb[BG_NB];
+
+  f32x4_t acc[BG_WMB][BG_WNB];
+#pragma unroll
+  for (int i = 0; i < BG_WMB; ++i)
+#pragma unroll
+    for (int j = 0; j < BG_WNB; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int nch = p.K >> 5;
+  bg_gload<LB>(p, m0, n0, 0, tid, ra, rb);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  bg_lstore<LB>(bg_smem, bg_smem + 2 * AF, tid, ra, rb);
+  __syncthreads();
+  for (int c = 0; c < nch; ++c) {
+    const int buf = c & 1;
+    // the next chunk's global loads fly during this chunk's matrix instructions
+    if (c + 1 < nch) bg_gload<LB>(p, m0, n0, (c + 1) << 5, tid, ra, rb);
+    const float* As = bg_smem + buf * AF + (wm * BG_WMB * 16 + jl) * BG_AS + 8 * kq;
+    float af[BG_WMB][8], bf[BG_WNB][8];
+#pragma unroll
+    for (int i = 0; i < BG_WMB; ++i) {
+      const float4 x = *reinterpret_cast<const float4*>(As + i * 16 * BG_AS);
+      const float4 y = *reinterpret_cast<const float4*>(As + i * 16 * BG_AS + 4);
+      af[i][0] = x.x; af[i][1] = x.y; af[i][2] = x.z; af[i][3] = x.w;
+      af[i][4] = y.x; af[i][5] = y.y; af[i][6] = y.z; af[i][7] = y.w;
+    }
+#pragma unroll
+    for (int j = 0; j < BG_WNB; ++j) {
+      if (LB == MESM_LAYOUT_REDUCE_CONTIG) {
+        const float* Bs = bg_smem + 2 * AF + buf * BF + (wn * BG_WNB * 16 + j * 16 + jl) * BG_AS + 8 * kq;
+        const float4 x = *reinterpret_cast<const float4*>(Bs);
+        const float4 y = *reinterpret_cast<const float4*>(Bs + 4);
+        bf[j][0] = x.x; bf[j][1] = x.y; bf[j][2] = x.z; bf[j][3] = x.w;
+        bf[j][4] = y.x; bf[j][5] = y.y; bf[j][6] = y.z; bf[j][7] = y.w;
+      } else {
+        const float* Bs = bg_smem + 2 * AF + buf * BF + (8 * kq) * BG_BSN + wn * BG_WNB * 16 + j * 16 + jl;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) bf[j][t] = Bs[t * BG_BSN];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int i = 0; i < BG_WMB; ++i)
+#pragma unroll
+        for (int j = 0; j < BG_WNB; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
+    if (c + 1 < nch) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      bg_lstore<LB>(bg_smem + (buf ^ 1) * AF, bg_smem + 2 * AF + (buf ^ 1) * BF, tid, ra, rb);
+    }
+    __syncthreads();
+  }
+
+  // accumulator block (i, j), register r <-> row m0 + 80 wm + 16 i + 4 kq + r, column n0 + 32 wn + 16 j + jl
+  auto RO = [](int i) { return i; };
+  const bool full = m0 + BG_TM <= p.M;
+  float dslope_part = 0.0f;
+#pragma unroll
+  for (int i = 0; i < BG_WMB; ++i) {
+#pragma unroll
+    for (int j = 0; j < BG_WNB; ++j) {
+      float t[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) t[r] = acc[i][j][r];
+      const int rbase = m0 + wm * BG_WMB * 16 + 16 * i + 4 * kq;
+      const int col = n0 + wn * BG_WNB * 16 + j * 16 + jl;
+      if (full) dslope_part += staged_epilogue<4, true>(p, t, rbase, col, slope, seed_off, true, RO);
+      else dslope_part += staged_epilogue<4, false>(p, t, rbase, col, slope, seed_off, true, RO);
+    }
+  }
+  if (p.e_actgrad == MESM_ACT_PRELU && p.dslope) dslope_store(p, dslope_part, sh4, linear_block());
+}
+
+// what the big16 kernel takes: a plain product with the reduce index contiguous in A, K a multiple of 32, N of 128
+bool big16_ok(const MesmGemmArgs& a) {
+  return a.a_layout == MESM_LAYOUT_REDUCE_CONTIG && a.K % 32 == 0 && a.K >= 64 && a.N % BG_TN == 0 && a.M >= BG_TM &&
+         a.split_k <= 1 && !a.A2 && !a.B2 && !a.colsum && a.a_act == MESM_ACT_NONE && a.b_act == MESM_ACT_NONE &&
+         a.a_drop_p == 0.f && a.b_drop_p == 0.f && a.lda % 4 == 0 && a.ldb % 4 == 0 && aligned_to(a.A, 16) &&
+         aligned_to(a.B, 16);
+}
+
+int launch_big16(const MesmGemmArgs& a, hipStream_t s) {
+  dim3 grid(((a.M + BG_TM - 1) / BG_TM) * (a.N / BG_TN));
+  static bool raised[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return MESM_ELAUNCH;
+  if (dev < 0 || dev >= 64 || !raised[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big16_kernel<MESM_LAYOUT_REDUCE_CONTIG>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bg_lds_bytes<MESM_LAYOUT_REDUCE_CONTIG>()) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big16_kernel<MESM_LAYOUT_OUTER_CONTIG>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bg_lds_bytes<MESM_LAYOUT_OUTER_CONTIG>()) != hipSuccess)
+      return MESM_ELAUNCH;
+    if (dev >= 0 && dev < 64) raised[dev] = true;
+  }
+  if (a.b_layout == MESM_LAYOUT_REDUCE_CONTIG)
+    hipLaunchKernelGGL(gemm_big16_kernel<MESM_LAYOUT_REDUCE_CONTIG>, grid, dim3(BG_THREADS),
+                       bg_lds_bytes<MESM_LAYOUT_REDUCE_CONTIG>(), s, a);
+  else
+    hipLaunchKernelGGL(gemm_big16_kernel<MESM_LAYOUT_OUTER_CONTIG>, grid, dim3(BG_THREADS),
+                       bg_lds_bytes<MESM_LAYOUT_OUTER_CONTIG>(), s, a);
+  const int rc = mesm_launch_status();
+  return rc != MESM_OK ? rc : dslope_finish(a, grid, s);
+}
+
 // Tape of the GEMM launches of one step (argument structs as launched), for bench.py's
 // roofline measurement: recorded while a step is captured into a HIP graph (whose private
 // memory pool keeps every pointer valid), replayed back-to-back from C++ with an event pair
@@ -2128,6 +2325,17 @@ int dispatch(const MesmGemmArgs& a, int vec, hipStream_t s) {
     if (force == 0 && bf16x_mode() != 0 && wstage_ok(a) && b64 >= 128 && (a.M >= 2400 || a.K >= 2400) &&
         a.a_act == MESM_ACT_NONE && a.b_act == MESM_ACT_NONE && a.a_drop_p == 0.f && a.b_drop_p == 0.f)
       return launch_wstage64(a, s);
+    // one round of 160 x 128 tiles (round-3 experiment, off by default: MESM_GEMM_BIG16=1 or MESM_GEMM_TILE=7).  Alone
+    // it ties the 64 x 64 ring on 4800 x 1024 x 256 (35.2 vs 35.0 us; 38.0 vs 43.5 with the second output, 57 vs 62.5 at
+    // K = 512) and the step does not move (4.91-4.93 ms either way): its steady state runs at 85 % of the matrix
+    // rate, but a one-round grid has every workgroup in its epilogue at the same time -- the 20-40 MB of output are
+    // one exposed burst (~10 us) instead of trickling out under the other tiles' matrix instructions.
+    {
+      const long tb = (long)((a.M + BG_TM - 1) / BG_TM) * (a.N / BG_TN);
+      static const bool big_on = getenv("MESM_GEMM_BIG16") != nullptr;
+      if ((force == 7 || (force == 0 && big_on && a.K <= 512 && tb >= 224 && tb <= 256)) && big16_ok(a))
+        return launch_big16(a, s);
+    }
     if ((force == 3 || (force == 0 && b64 >= 512)) && wstage_ok(a)) return launch_lds64(a, s);
     // k-split 64 x 64 (half the L2 traffic per flop): wins only when its workgroups fit ONE round on the
     // 256 CUs (300 workgroups = two rounds: 4800 x 256 x 1024 59 us vs 43 us with 32 x 32 tiles) and a
