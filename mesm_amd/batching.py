@@ -207,8 +207,7 @@ def pad_pairs(batch, P, big=1 << 20):
             # static input, and whatever finite rows an earlier batch left behind serve as the padding pairs
             continue
         elif torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == N:
-            idx = torch.cat([torch.arange(N, device=v.device), torch.zeros(k, dtype=torch.int64, device=v.device)])
-            out[key] = v[idx]
+            out[key] = torch.cat([v, v[:1].expand(k, *v.shape[1:])])
         elif isinstance(v, (list, tuple)) and len(v) == N:
             out[key] = list(v) + [v[0]] * k
     return out

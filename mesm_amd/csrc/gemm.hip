@@ -2234,6 +2234,7 @@ __global__ __launch_bounds__(BG_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   }
 
   // accumulator block (i, j), register r <-> row m0 + 80 wm + 16 i + 4 kq + r, column n0 + 32 wn + 16 j + jl
+  // (one epilogue call per block: a call per column block -- 20 values per lane -- spills and is slower, 37.4 vs 34.9 us)
   auto RO = [](int i) { return i; };
   const bool full = m0 + BG_TM <= p.M;
   float dslope_part = 0.0f;
@@ -2253,6 +2254,149 @@ __global__ __launch_bounds__(BG_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   if (p.e_actgrad == MESM_ACT_PRELU && p.dslope) dslope_store(p, dslope_part, sh4, linear_block());
 }
 
+// The same 160 x 128 share per workgroup walked as TWO half-tiles of 160 x 64 (a wave: 5 x 1 blocks, chunks of 64 reduce
+// indices so a wave still issues 80 matrix instructions per barrier): the first half's epilogue -- its aux / residual
+// loads and its stores -- drains under the second half's matrix instructions, and the second half's first operand
+// chunk is already in flight when the first half ends (cross-tile prefetch).  MESM_GEMM_TILE=8.  Measured: no better
+// (4800 x 1024 x 256 bias + residual: 35.3 us against 34.9 one round, 34.2 for the 64 x 64 ring) -- the ~11-15 us a
+// workgroup spends outside its steady state are neither the exposed write burst (half the rows: 30.5 us) nor the chain of
+// epilogue calls (one call per half: same time).
+constexpr int BP_TNS = 64, BP_KC = 64, BP_AS = BP_KC + 4, BP_BSN = BP_TNS + 2;
+constexpr int BP_NA = (BG_TM * (BP_KC / 4)) / BG_THREADS, BP_NB = (BP_TNS * (BP_KC / 4)) / BG_THREADS;  // 5, 2
+template <int LB>
+constexpr int bp_b_floats() { return LB == MESM_LAYOUT_REDUCE_CONTIG ? BP_TNS * BP_AS : BP_KC * BP_BSN; }
+template <int LB>
+constexpr size_t bp_lds_bytes() { return (size_t)2 * (BG_TM * BP_AS + bp_b_floats<LB>()) * sizeof(float); }
+
+template <int LB>
+__device__ __forceinline__ void bp_gload(const MesmGemmArgs& p, int m0, int n0, int k0, int tid, f32x4_t (&ra)[BP_NA],
+                                         f32x4_t (&rb)[BP_NB]) {
+#pragma unroll
+  for (int v = 0; v < BP_NA; ++v) {
+    const int idx = tid + v * BG_THREADS;
+    const int r = idx >> 4, c = (idx & 15) * 4;
+    int gm = m0 + r;
+    gm = gm < p.M ? gm : p.M - 1;
+    ra[v] = bg_ld16(p.A + (int64_t)gm * p.lda + k0 + c);
+  }
+#pragma unroll
+  for (int v = 0; v < BP_NB; ++v) {
+    const int idx = tid + v * BG_THREADS;
+    if (LB == MESM_LAYOUT_REDUCE_CONTIG) {
+      const int r = idx >> 4, c = (idx & 15) * 4;
+      rb[v] = bg_ld16(p.B + (int64_t)(n0 + r) * p.ldb + k0 + c);
+    } else {
+      const int k = idx >> 4, c = (idx & 15) * 4;
+      rb[v] = bg_ld16(p.B + (int64_t)(k0 + k) * p.ldb + n0 + c);
+    }
+  }
+}
+
+template <int LB>
+__device__ __forceinline__ void bp_lstore(float* Ab, float* Bb, int tid, const f32x4_t (&ra)[BP_NA], const f32x4_t (&rb)[BP_NB]) {
+#pragma unroll
+  for (int v = 0; v < BP_NA; ++v) {
+    const int idx = tid + v * BG_THREADS;
+    const int r = idx >> 4, c = (idx & 15) * 4;
+    *reinterpret_cast<f32x4_t*>(Ab + r * BP_AS + c) = ra[v];
+  }
+#pragma unroll
+  for (int v = 0; v < BP_NB; ++v) {
+    const int idx = tid + v * BG_THREADS;
+    if (LB == MESM_LAYOUT_REDUCE_CONTIG) {
+      const int r = idx >> 4, c = (idx & 15) * 4;
+      *reinterpret_cast<f32x4_t*>(Bb + r * BP_AS + c) = rb[v];
+    } else {
+      const int k = idx >> 4, c = (idx & 15) * 4;
+      float* d = Bb + k * BP_BSN + c;  // 66-float rows: 8-byte aligned
+      *reinterpret_cast<float2*>(d) = make_float2(rb[v][0], rb[v][1]);
+      *reinterpret_cast<float2*>(d + 2) = make_float2(rb[v][2], rb[v][3]);
+    }
+  }
+}
+
+template <int LB>
+__global__ __launch_bounds__(BG_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_big16p_kernel(const MesmGemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) float bg_smem[];
+  constexpr int AF = BG_TM * BP_AS, BF = bp_b_floats<LB>();
+  __shared__ float sh4[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int jl = lane & 15, kq = lane >> 4;
+  const int wm = wave >> 2, wn = wave & 3;
+  int tbx, tby;
+  xcd_tile(blockIdx.x, (p.M + BG_TM - 1) / BG_TM, p.N / BG_TN, tbx, tby);
+  const int m0 = tbx * BG_TM, n0 = tby * BG_TN;
+  const float slope = p.slope ? *p.slope : 0.0f;
+  const uint32_t seed_off = p.seed_offset ? *p.seed_offset : 0u;
+  f32x4_t ra[BP_NA], rb[BP_NB];
+  f32x4_t acc[BG_WMB];
+#pragma unroll
+  for (int i = 0; i < BG_WMB; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int nch = p.K / BP_KC, nit = 2 * nch;
+  bp_gload<LB>(p, m0, n0, 0, tid, ra, rb);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  bp_lstore<LB>(bg_smem, bg_smem + 2 * AF, tid, ra, rb);
+  __syncthreads();
+  auto RO = [](int i) { return i; };
+  const bool full = m0 + BG_TM <= p.M;
+  float dslope_part = 0.0f;
+  for (int it = 0; it < nit; ++it) {
+    const int buf = it & 1;
+    const int sub = it >= nch ? 1 : 0, c = it - sub * nch;
+    if (it + 1 < nit) {
+      const int sub1 = it + 1 >= nch ? 1 : 0, c1 = it + 1 - sub1 * nch;
+      bp_gload<LB>(p, m0, n0 + sub1 * BP_TNS, c1 * BP_KC, tid, ra, rb);
+    }
+    const float* As = bg_smem + buf * AF + (wm * BG_WMB * 16 + jl) * BP_AS + 16 * kq;
+    float af[BG_WMB][16], bf[16];
+#pragma unroll
+    for (int i = 0; i < BG_WMB; ++i)
+#pragma unroll
+      for (int t = 0; t < 16; t += 4) {
+        const float4 x = *reinterpret_cast<const float4*>(As + i * 16 * BP_AS + t);
+        af[i][t] = x.x; af[i][t + 1] = x.y; af[i][t + 2] = x.z; af[i][t + 3] = x.w;
+      }
+    if (LB == MESM_LAYOUT_REDUCE_CONTIG) {
+      const float* Bs = bg_smem + 2 * AF + buf * BF + (wn * 16 + jl) * BP_AS + 16 * kq;
+#pragma unroll
+      for (int t = 0; t < 16; t += 4) {
+        const float4 x = *reinterpret_cast<const float4*>(Bs + t);
+        bf[t] = x.x; bf[t + 1] = x.y; bf[t + 2] = x.z; bf[t + 3] = x.w;
+      }
+    } else {
+      const float* Bs = bg_smem + 2 * AF + buf * BF + (16 * kq) * BP_BSN + wn * 16 + jl;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) bf[t] = Bs[t * BP_BSN];
+    }
+#pragma unroll
+    for (int t = 0; t < 16; ++t)
+#pragma unroll
+      for (int i = 0; i < BG_WMB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][t], bf[t], acc[i], 0, 0, 0);
+    if (it + 1 < nit) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      bp_lstore<LB>(bg_smem + (buf ^ 1) * AF, bg_smem + 2 * AF + (buf ^ 1) * BF, tid, ra, rb);
+    }
+    if (c == nch - 1) {
+      // this half is complete: its epilogue's loads and stores are in flight while the next half's chunks run
+      float t[4 * BG_WMB];
+#pragma unroll
+      for (int i = 0; i < BG_WMB; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[4 * i + r] = acc[i][r];
+      const int rbase = m0 + wm * BG_WMB * 16 + 4 * kq;
+      const int col = n0 + sub * BP_TNS + wn * 16 + jl;
+      auto RO20 = [](int i) { return 16 * (i >> 2) + (i & 3); };
+      if (full) dslope_part += staged_epilogue<4 * BG_WMB, true>(p, t, rbase, col, slope, seed_off, true, RO20);
+      else dslope_part += staged_epilogue<4 * BG_WMB, false>(p, t, rbase, col, slope, seed_off, true, RO20);
+#pragma unroll
+      for (int i = 0; i < BG_WMB; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+  }
+  if (p.e_actgrad == MESM_ACT_PRELU && p.dslope) dslope_store(p, dslope_part, sh4, linear_block());
+}
+
 // what the big16 kernel takes: a plain product with the reduce index contiguous in A, K a multiple of 32, N of 128
 bool big16_ok(const MesmGemmArgs& a) {
   return a.a_layout == MESM_LAYOUT_REDUCE_CONTIG && a.K % 32 == 0 && a.K >= 64 && a.N % BG_TN == 0 && a.M >= BG_TM &&
@@ -2261,7 +2405,7 @@ bool big16_ok(const MesmGemmArgs& a) {
          aligned_to(a.B, 16);
 }
 
-int launch_big16(const MesmGemmArgs& a, hipStream_t s) {
+int launch_big16(const MesmGemmArgs& a, hipStream_t s, bool halves = false) {
   dim3 grid(((a.M + BG_TM - 1) / BG_TM) * (a.N / BG_TN));
   static bool raised[64] = {};
   int dev = 0;
@@ -2273,6 +2417,25 @@ int launch_big16(const MesmGemmArgs& a, hipStream_t s) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bg_lds_bytes<MESM_LAYOUT_OUTER_CONTIG>()) != hipSuccess)
       return MESM_ELAUNCH;
     if (dev >= 0 && dev < 64) raised[dev] = true;
+  }
+  if (halves && a.K % BP_KC == 0) {
+    static bool raised2[64] = {};
+    if (dev < 0 || dev >= 64 || !raised2[dev]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big16p_kernel<MESM_LAYOUT_REDUCE_CONTIG>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp_lds_bytes<MESM_LAYOUT_REDUCE_CONTIG>()) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big16p_kernel<MESM_LAYOUT_OUTER_CONTIG>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp_lds_bytes<MESM_LAYOUT_OUTER_CONTIG>()) != hipSuccess)
+        return MESM_ELAUNCH;
+      if (dev >= 0 && dev < 64) raised2[dev] = true;
+    }
+    if (a.b_layout == MESM_LAYOUT_REDUCE_CONTIG)
+      hipLaunchKernelGGL(gemm_big16p_kernel<MESM_LAYOUT_REDUCE_CONTIG>, grid, dim3(BG_THREADS),
+                         bp_lds_bytes<MESM_LAYOUT_REDUCE_CONTIG>(), s, a);
+    else
+      hipLaunchKernelGGL(gemm_big16p_kernel<MESM_LAYOUT_OUTER_CONTIG>, grid, dim3(BG_THREADS),
+                         bp_lds_bytes<MESM_LAYOUT_OUTER_CONTIG>(), s, a);
+    const int rc2 = mesm_launch_status();
+    return rc2 != MESM_OK ? rc2 : dslope_finish(a, grid, s);
   }
   if (a.b_layout == MESM_LAYOUT_REDUCE_CONTIG)
     hipLaunchKernelGGL(gemm_big16_kernel<MESM_LAYOUT_REDUCE_CONTIG>, grid, dim3(BG_THREADS),
@@ -2333,6 +2496,7 @@ int dispatch(const MesmGemmArgs& a, int vec, hipStream_t s) {
     {
       const long tb = (long)((a.M + BG_TM - 1) / BG_TM) * (a.N / BG_TN);
       static const bool big_on = getenv("MESM_GEMM_BIG16") != nullptr;
+      if (force == 8 && big16_ok(a)) return launch_big16(a, s, true);
       if ((force == 7 || (force == 0 && big_on && a.K <= 512 && tb >= 224 && tb <= 256)) && big16_ok(a))
         return launch_big16(a, s);
     }

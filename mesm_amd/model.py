@@ -288,6 +288,11 @@ class MESM(nn.Module):
         if neg_index is None:
             neg_index = self.draw_neg_padded(groups, n_valid).numpy()
         arr["neg_index"] = np.asarray(neg_index, dtype=np.int64)
+        # the key-padding forms of the two masks (what every attention takes) ride in the plan: no inversion launches
+        arr["vpad"], arr["wpad"] = ~vm, ~wm
+        if self.rec_ss:
+            emask = np.concatenate([np.ones((N, 1), dtype=bool), wm], axis=1)  # [recon ; words] (model.py:221-224)
+            arr["emask"] = emask
         if n_valid is not None:
             # the number of REAL pairs as a device scalar: modulus of the attention mask quirk, extent of every loss
             arr["n_valid"] = np.asarray([n_valid], dtype=np.int32)
@@ -429,8 +434,8 @@ class MESM(nn.Module):
         # batches padded to a captured pair capacity: the real pair count is a device scalar of the plan
         kn.set_mask_mod(getattr(plan, "n_valid", None))
         with _scope("inproj"):
-            vid_pad = (~video_mask).contiguous()
-            words_pad = (~words_mask).contiguous()
+            vid_pad = plan.vpad if getattr(plan, "vpad", None) is not None else (~video_mask).contiguous()
+            words_pad = plan.wpad if getattr(plan, "wpad", None) is not None else (~words_mask).contiguous()
             vpos = kn.sine_pos(video_mask, d)
             chains = [proj_chain(self.input_vid_proj, video_feat), proj_chain(self.input_txt_proj, words)]
             if self.rec_ss:
@@ -515,7 +520,7 @@ class MESM(nn.Module):
                 recon = ops.gather_rows2(rec.reshape(-1, d), plan.recon_idx, plan.recon_inv, normalize=True)
                 # [recon ; words] and its padding mask (model.py:221-224), one launch
                 ewords, epad = ops.prepend(recon, pw, pad=words_pad, first_pad=False)
-                emask = ~epad
+                emask = plan.emask if getattr(plan, "emask", None) is not None else ~epad
             else:
                 ewords, emask = pw, words_mask
                 epad = words_pad

@@ -361,3 +361,50 @@ def test_a_loader_like_epoch_replays_from_a_handful_of_graphs():
     assert checked >= 3
     assert cache.captures <= 6, cache.captures
     assert cache.replays >= 0.85 * n_batches, (cache.replays, cache.captures)  # 40 batches: at most 6 are captures
+
+
+def test_a_late_gradient_under_capture_refuses_the_graph():
+    """under capture the cross-rank late-gradient check cannot run (it needs a collective result on the
+    host), so a graph captured on a batch whose contribution pattern differs from the learnt one would replay a
+    bucket all-reduce issued before that bucket was complete -- on every step.  finish() knows it locally and must
+    raise while the stream is capturing.  (Stub communicator: the collectives themselves are not the subject.)"""
+    from mesm_amd import build_criterion, build_model, synthetic
+    from mesm_amd.ddp import GradReducer
+
+    class StubComm:
+        world = 2
+        calls = 0
+
+        def allreduce(self, t, side):
+            StubComm.calls += 1
+
+        def wait(self):
+            pass
+
+    dev = torch.device("cuda:0")
+    args = synthetic.make_args("C3b", device="cuda:0")
+    torch.manual_seed(3)
+    model = build_model(args)
+    crit = build_criterion(args)
+    batch = synthetic.to_device(synthetic.workload_batch("C3b", seed=1), dev)
+    red = GradReducer(model.gradbuf(), n_buckets=4, comm=StubComm(), fold_scale=True)
+    try:
+        out = model(**batch, dataset_name=args.dataset_name, is_training=True)
+        _, total = crit(out, batch, True)
+        total.backward()  # learns the contribution counts, launches the buckets through the stub
+        torch.cuda.synchronize()
+        assert red.expected is not None and StubComm.calls >= 4
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        g = torch.cuda.CUDAGraph()
+        with pytest.raises(RuntimeError, match="while capturing, a gradient arrived after its bucket"):
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                red.next_bucket = -1   # every bucket already sent ...
+                red.stale = True       # ... and then one more gradient was written into one of them
+                red.finish()
+        # outside capture the same state goes through the agreed (collective) path instead: no local raise
+        red.next_bucket = -1
+        red.stale = False
+        red.finish()
+    finally:
+        model.gradbuf().on_ready = None

@@ -265,6 +265,12 @@ ATTN_CASES = [
     (4, 8, 512, 17, 32, 32, True, True),
     (2, 8, 300, 128, 32, 32, True, False),
     (2, 4, 257, 40, 32, 32, True, True),
+    # 16 x 16-block kernels (attention_blk.hip): 64-wide heads forward (Lq > 16) and backward, the LDS limit of the
+    # staged head (96 + 112 rows), just beyond it (lane-per-key fallback)
+    (4, 4, 40, 75, 64, 32, True, False),
+    (3, 4, 50, 60, 64, 32, True, True),
+    (2, 4, 96, 112, 32, 32, True, True),
+    (2, 4, 112, 112, 32, 32, True, False),
     (2, 4, 140, 200, 32, 32, True, True),
 ]
 
@@ -737,7 +743,8 @@ def test_gemm_fuzz_activations():
 
 
 # --------------------------------------------------------------------------- round-2 fusions
-@pytest.mark.parametrize("B,H,Lq,Lk,dh,dv", [(32, 8, 10, 75, 32, 32), (3, 4, 7, 130, 8, 8), (2, 2, 20, 33, 16, 16)])
+@pytest.mark.parametrize("B,H,Lq,Lk,dh,dv", [(32, 8, 10, 75, 32, 32), (4, 8, 40, 75, 32, 32), (3, 4, 7, 130, 8, 8),
+                                             (2, 2, 20, 33, 16, 16)])
 def test_attention_split_heads_equal_the_interleaved_copy(B, H, Lq, Lk, dh, dv):
     """q2 / k2 (MesmAttnArgs): head h sees [q_h || q2_h], [k_h || k2_h] -- the decoder's per-head
     [content || position] concatenation (transformer.py:778-784) -- forward and all five gradients equal the
