@@ -511,6 +511,8 @@ extern "C" int mesm_attn_fwd(const MesmAttnArgs* args, void* stream) {
   // the step's hot shapes run on the matrix cores (MESM_ATTN_LEGACY=1: this file's lane-per-key kernels, for A/B)
   static const bool legacy = getenv("MESM_ATTN_LEGACY") != nullptr;
   if (blk_fwd_enabled() && mesm_attn_blk_fwd_ok(a)) return mesm_attn_blk_fwd(a, s);
+  // long key ranges with enough query rows to fill the chip (the rule of the 32 x 32 two-pass kernel it replaces)
+  if (blk_fwd_enabled() && a.Lk > 128 && a.Lq >= 128 && mesm_attn_blk_fwd_long_ok(a)) return mesm_attn_blk_fwd_long(a, s);
   if (!legacy && mesm_attn_mfma_ok(a)) return mesm_attn_mfma_fwd(a, s);
   dim3 grid(a.B * a.H, (a.Lq + QCH - 1) / QCH);
   ATTN_DISPATCH(attn_fwd_kernel, grid, AT_THREADS);
@@ -532,6 +534,7 @@ extern "C" int mesm_attn_bwd(const MesmAttnArgs* args, void* stream) {
   static const bool legacy = getenv("MESM_ATTN_LEGACY") != nullptr;
   if (!legacy && mesm_attn_mfma_bwd_ok(a)) return mesm_attn_mfma_bwd(a, s);
   if (blk_bwd_enabled() && mesm_attn_blk_bwd_ok(a)) return mesm_attn_blk_bwd(a, s);
+  if (blk_bwd_enabled() && a.Lk > 128 && mesm_attn_blk_bwd_long_ok(a)) return mesm_attn_blk_bwd_long(a, s);
   dim3 grid(a.B * a.H, (a.Lk + KT - 1) / KT);
   if (grid.y > 1) ATTN_DISPATCH(attn_bwd_kernel, grid, 128, 2);  // several key tiles: 2 waves per workgroup
   else ATTN_DISPATCH(attn_bwd_kernel, grid, 256, 4);

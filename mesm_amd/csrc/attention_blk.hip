@@ -299,6 +299,237 @@ __device__ __forceinline__ void attn_blk_bwd_body(const MesmAttnArgs& p, const i
 template <int DK, bool DROP>
 __global__ __launch_bounds__(BT) void attn_blk_bwd_kernel(const MesmAttnArgs p) { attn_blk_bwd_body<DK, DROP>(p, blockIdx.x); }
 
+// ------------------------------------------------------------------------------------------------------------
+// Long ranges (TACoS' 513 x 513 encoder, transformer.py:640-644 backward): a head no longer fits in LDS, so the two
+// kinds of units become two kinds of WORKGROUPS -- J workgroups own 128 keys (a wave: 16 keys, K / V fragments and the
+// dK / dV accumulators in registers) and stream the queries through LDS in chunks of 64 (Q, dO, delta, log-sum-exp,
+// mask bytes); I workgroups own 128 queries and stream the keys.  Same block arithmetic as above, no atomics.
+constexpr int LC = 64;   // rows of the streamed side per LDS chunk (128: no change, 393 / 204 vs 395 / 209 us)
+constexpr int LW = 128;  // rows a workgroup owns (8 waves x 16)
+
+template <bool DROP>
+__global__ __launch_bounds__(BT) void attn_blk_bwd_long_kernel(const MesmAttnArgs p) {
+  __shared__ __attribute__((aligned(16))) float Xs[LC * BS];  // Q (J workgroups) / K (I workgroups) chunk
+  __shared__ __attribute__((aligned(16))) float Ys[LC * BS];  // dO / V chunk
+  __shared__ __attribute__((aligned(16))) float Aux[3][LC];   // lse, delta, quirk-row query padding / key masks
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int jl = lane & 15, kq = lane >> 4;
+  const int Lq = p.Lq, Lk = p.Lk;
+  const int nJc = (Lk + LW - 1) / LW, nIc = (Lq + LW - 1) / LW;
+  const int bh = blockIdx.x / (nJc + nIc), part = blockIdx.x % (nJc + nIc);
+  const int b = bh / p.H, h = bh % p.H;
+  const int b2 = mesm_quirk_row(p, b, h);
+  const bool quirk = (p.mask_mode == MESM_MASK_T2V_QUIRK) && p.qpad && p.kpad;
+  const float* qb = p.q + (int64_t)b * p.q_bs + h * 32;
+  const float* kb = p.k + (int64_t)b * p.k_bs + h * 32;
+  const float* vb = p.v + (int64_t)b * p.v_bs + h * 32;
+  const float* ob = p.o + (int64_t)b * p.o_bs + h * 32;
+  const float* gb = p.d_o + (int64_t)b * p.o_bs + h * 32;
+  const uint32_t thresh = DROP ? mesm_drop_threshold(p.drop_p) : 0u;
+  const float inv_keep = 1.0f / (1.0f - p.drop_p);
+  const uint32_t drop_seed = p.drop_seed + (p.seed_offset ? *p.seed_offset : 0u);
+  const float scale = p.scale;
+  const uint32_t row0 = (uint32_t)bh * (uint32_t)Lq;
+
+  auto load8g = [&](const float* base, int64_t ls, int row, int nrows, float* f) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
+    if (row < nrows) {
+      a = *reinterpret_cast<const float4*>(base + (int64_t)row * ls + 8 * kq);
+      c = *reinterpret_cast<const float4*>(base + (int64_t)row * ls + 8 * kq + 4);
+    }
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w;
+    f[4] = c.x; f[5] = c.y; f[6] = c.z; f[7] = c.w;
+  };
+
+  if (part < nJc) {
+    // ---------------------------------------------------------------- J workgroup: keys [part * 128, + 128)
+    const int j0 = part * LW + 16 * wave;
+    const bool active = j0 < Lk;
+    float kf[8], vf[8];
+    load8g(kb, p.k_ls, j0 + jl, active ? Lk : 0, kf);
+    load8g(vb, p.v_ls, j0 + jl, active ? Lk : 0, vf);
+    const int j = j0 + jl;
+    float kpj = 1.0f, kp2j = 0.0f;
+    if (j < Lk) {
+      kpj = (p.kpad && p.kpad[(int64_t)b * Lk + j] != 0) ? 1.0f : 0.0f;
+      kp2j = (quirk && p.kpad[(int64_t)b2 * Lk + j] != 0) ? 1.0f : 0.0f;
+    }
+    f32x4 dVa[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 dKa[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (int ic = 0; ic < Lq; ic += LC) {
+      __syncthreads();  // the previous chunk has been consumed
+      for (int idx = tid; idx < LC * 8; idx += BT) {
+        const int r = idx >> 3, c = (idx & 7) * 4, i = ic + r;
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f), g = q, o = q;
+        if (i < Lq) {
+          q = *reinterpret_cast<const float4*>(qb + (int64_t)i * p.q_ls + c);
+          g = *reinterpret_cast<const float4*>(gb + (int64_t)i * p.o_ls + c);
+          o = *reinterpret_cast<const float4*>(ob + (int64_t)i * p.o_ls + c);
+        }
+        *reinterpret_cast<float4*>(Xs + r * BS + c) = q;
+        *reinterpret_cast<float4*>(Ys + r * BS + c) = g;
+        float part_ = g.x * o.x + g.y * o.y + g.z * o.z + g.w * o.w;
+        part_ = sum_within<8>(part_);
+        if ((idx & 7) == 0) Aux[1][r] = part_;
+      }
+      if (tid < LC) {
+        const int i = ic + tid;
+        Aux[0][tid] = i < Lq ? p.lse[(int64_t)bh * Lq + i] : 1e30f;
+        Aux[2][tid] = (quirk && i < Lq && p.qpad[(int64_t)b2 * Lq + i] != 0) ? 1.0f : 0.0f;
+      }
+      __syncthreads();
+      if (!active) continue;
+      const int nb = (min(LC, Lq - ic) + 15) >> 4;
+      for (int ib = 0; ib < nb; ++ib) {
+        const int i0 = ib << 4;  // inside the chunk
+        float qf[8], gf[8];
+        loadN<8>(Xs + (i0 + jl) * BS + 8 * kq, qf);
+        loadN<8>(Ys + (i0 + jl) * BS + 8 * kq, gf);
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          s = mfma16(qf[t], kf[t], s);
+          dp = mfma16(gf[t], vf[t], dp);
+        }
+        const int ir = i0 + 4 * kq;
+        float gb0[4], gb1[4], qb0[4], qb1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          gb0[r] = Ys[(ir + r) * BS + jl]; gb1[r] = Ys[(ir + r) * BS + 16 + jl];
+          qb0[r] = Xs[(ir + r) * BS + jl]; qb1[r] = Xs[(ir + r) * BS + 16 + jl];
+        }
+        const float4 lse4 = *reinterpret_cast<const float4*>(&Aux[0][ir]);
+        const float4 dl4 = *reinterpret_cast<const float4*>(&Aux[1][ir]);
+        const float4 qp4 = *reinterpret_cast<const float4*>(&Aux[2][ir]);
+        const float lse_[4] = {lse4.x, lse4.y, lse4.z, lse4.w};
+        const float dl_[4] = {dl4.x, dl4.y, dl4.z, dl4.w};
+        const float qp_[4] = {qp4.x, qp4.y, qp4.z, qp4.w};
+        float pd[4], ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float mk = fmaf(qp_[r], kp2j, kpj);
+          const float e = __expf(s[r] * scale - lse_[r]);
+          const float pj = mk != 0.0f ? 0.0f : e;
+          float km = 1.0f;
+          if (DROP) {
+            const uint32_t idx = (row0 + (uint32_t)(ic + ir + r)) * (uint32_t)Lk + (uint32_t)j;
+            km = mesm_hash32(idx, drop_seed) >= thresh ? inv_keep : 0.0f;
+          }
+          pd[r] = pj * km;
+          ds[r] = pj * (dp[r] * km - dl_[r]) * scale;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dVa[0] = mfma16(pd[r], gb0[r], dVa[0]);
+          dKa[0] = mfma16(ds[r], qb0[r], dKa[0]);
+          dVa[1] = mfma16(pd[r], gb1[r], dVa[1]);
+          dKa[1] = mfma16(ds[r], qb1[r], dKa[1]);
+        }
+      }
+    }
+    if (active) {
+      float* dkb = p.dk_ + (int64_t)b * p.k_bs + h * 32;
+      float* dvb = p.dv_ + (int64_t)b * p.v_bs + h * 32;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int jj = j0 + 4 * kq + r;
+        if (jj < Lk) {
+          dkb[(int64_t)jj * p.k_ls + jl] = dKa[0][r];
+          dkb[(int64_t)jj * p.k_ls + 16 + jl] = dKa[1][r];
+          dvb[(int64_t)jj * p.v_ls + jl] = dVa[0][r];
+          dvb[(int64_t)jj * p.v_ls + 16 + jl] = dVa[1][r];
+        }
+      }
+    }
+  } else {
+    // ---------------------------------------------------------------- I workgroup: queries [ic0, ic0 + 128)
+    const int i0 = (part - nJc) * LW + 16 * wave;
+    const bool active = i0 < Lq;
+    const int i = i0 + jl;
+    float qf[8], gf[8], of[8];
+    load8g(qb, p.q_ls, i, active ? Lq : 0, qf);
+    load8g(gb, p.o_ls, i, active ? Lq : 0, gf);
+    load8g(ob, p.o_ls, i, active ? Lq : 0, of);
+    float dl_i = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) dl_i += gf[t] * of[t];
+    dl_i = add_xor32(add_xor16(dl_i));  // the row's other 24 features sit in the lanes 16 / 32 / 48 apart
+    const float lse_i = (active && i < Lq) ? p.lse[(int64_t)bh * Lq + i] : 1e30f;
+    const float qp_i = (quirk && active && i < Lq && p.qpad[(int64_t)b2 * Lq + i] != 0) ? 1.0f : 0.0f;
+    const uint32_t rowi = (row0 + (uint32_t)i) * (uint32_t)Lk;
+    f32x4 dQa[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (int jc = 0; jc < Lk; jc += LC) {
+      __syncthreads();
+      for (int idx = tid; idx < LC * 8; idx += BT) {
+        const int r = idx >> 3, c = (idx & 7) * 4, jj = jc + r;
+        float4 k = make_float4(0.f, 0.f, 0.f, 0.f), v = k;
+        if (jj < Lk) {
+          k = *reinterpret_cast<const float4*>(kb + (int64_t)jj * p.k_ls + c);
+          v = *reinterpret_cast<const float4*>(vb + (int64_t)jj * p.v_ls + c);
+        }
+        *reinterpret_cast<float4*>(Xs + r * BS + c) = k;
+        *reinterpret_cast<float4*>(Ys + r * BS + c) = v;
+      }
+      if (tid < LC) {
+        const int jj = jc + tid;
+        bool m = jj >= Lk;
+        if (!m && p.kpad) m = p.kpad[(int64_t)b * Lk + jj] != 0;
+        Aux[0][tid] = m ? 1.0f : 0.0f;
+        Aux[1][tid] = (quirk && jj < Lk && p.kpad[(int64_t)b2 * Lk + jj] != 0) ? 1.0f : 0.0f;
+      }
+      __syncthreads();
+      if (!active) continue;
+      const int nb = (min(LC, Lk - jc) + 15) >> 4;
+      for (int jb = 0; jb < nb; ++jb) {
+        const int j0 = jb << 4;
+        float kf[8], vf[8];
+        loadN<8>(Xs + (j0 + jl) * BS + 8 * kq, kf);
+        loadN<8>(Ys + (j0 + jl) * BS + 8 * kq, vf);
+        f32x4 st = {0.f, 0.f, 0.f, 0.f}, dpt = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          st = mfma16(kf[t], qf[t], st);
+          dpt = mfma16(vf[t], gf[t], dpt);
+        }
+        const int jr = j0 + 4 * kq;
+        float kb0[4], kb1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { kb0[r] = Xs[(jr + r) * BS + jl]; kb1[r] = Xs[(jr + r) * BS + 16 + jl]; }
+        const float4 kp4 = *reinterpret_cast<const float4*>(&Aux[0][jr]);
+        const float4 kq4 = *reinterpret_cast<const float4*>(&Aux[1][jr]);
+        const float kp_[4] = {kp4.x, kp4.y, kp4.z, kp4.w};
+        const float kp2_[4] = {kq4.x, kq4.y, kq4.z, kq4.w};
+        float ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float mk = fmaf(qp_i, kp2_[r], kp_[r]);
+          const float e = __expf(st[r] * scale - lse_i);
+          const float pj = mk != 0.0f ? 0.0f : e;
+          float km = 1.0f;
+          if (DROP) km = mesm_hash32(rowi + (uint32_t)(jc + jr + r), drop_seed) >= thresh ? inv_keep : 0.0f;
+          ds[r] = pj * (dpt[r] * km - dl_i) * scale;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dQa[0] = mfma16(ds[r], kb0[r], dQa[0]);
+          dQa[1] = mfma16(ds[r], kb1[r], dQa[1]);
+        }
+      }
+    }
+    if (active) {
+      float* dqb = p.dq + (int64_t)b * p.q_bs + h * 32;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ii = i0 + 4 * kq + r;
+        if (ii < Lq) {
+          dqb[(int64_t)ii * p.q_ls + jl] = dQa[0][r];
+          dqb[(int64_t)ii * p.q_ls + 16 + jl] = dQa[1][r];
+        }
+      }
+    }
+  }
+}
+
 constexpr int BLK_GROUP_MAX = 8;
 struct BlkGroup {
   MesmAttnArgs p[BLK_GROUP_MAX];
@@ -513,6 +744,127 @@ __global__ __launch_bounds__(512) void attn_blk_fwd_group_kernel(const BlkGroup 
   else attn_blk_fwd_body<32, NJ, false>(p, bid - first);
 }
 
+// Forward for long key ranges (TACoS' 513 x 513 encoder): a workgroup owns 128 queries (a wave: 16, the query on the
+// lane) and streams the keys through LDS in chunks of 64, TWICE -- pass 1 scores only (running row maximum and sum per
+// lane, merged over the four lane groups at the end), pass 2 scores again, normalised dropped probabilities straight
+// into O = P V.  24 matrix instructions per block pair, no rescaling of accumulators (their rows are not the lane's row).
+template <bool DROP>
+__global__ __launch_bounds__(BT) void attn_blk_fwd_long_kernel(const MesmAttnArgs p) {
+  __shared__ __attribute__((aligned(16))) float Ks[LC * BS];
+  __shared__ __attribute__((aligned(16))) float Vs[LC * BS];
+  __shared__ __attribute__((aligned(16))) float Aux[2][LC];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int jl = lane & 15, kq = lane >> 4;
+  const int Lq = p.Lq, Lk = p.Lk;
+  const int nIc = (Lq + LW - 1) / LW;
+  const int bh = blockIdx.x / nIc, part = blockIdx.x % nIc;
+  const int b = bh / p.H, h = bh % p.H;
+  const int b2 = mesm_quirk_row(p, b, h);
+  const bool quirk = (p.mask_mode == MESM_MASK_T2V_QUIRK) && p.qpad && p.kpad;
+  const float* qb = p.q + (int64_t)b * p.q_bs + h * 32;
+  const float* kb = p.k + (int64_t)b * p.k_bs + h * 32;
+  const float* vb = p.v + (int64_t)b * p.v_bs + h * 32;
+  const uint32_t thresh = DROP ? mesm_drop_threshold(p.drop_p) : 0u;
+  const float inv_keep = 1.0f / (1.0f - p.drop_p);
+  const uint32_t drop_seed = p.drop_seed + (p.seed_offset ? *p.seed_offset : 0u);
+  const float scale = p.scale;
+  const int i0 = part * LW + 16 * wave, i = i0 + jl;
+  const bool active = i0 < Lq;
+  float qf[8];
+  {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), c = a;
+    if (active && i < Lq) {
+      a = *reinterpret_cast<const float4*>(qb + (int64_t)i * p.q_ls + 8 * kq);
+      c = *reinterpret_cast<const float4*>(qb + (int64_t)i * p.q_ls + 8 * kq + 4);
+    }
+    qf[0] = a.x; qf[1] = a.y; qf[2] = a.z; qf[3] = a.w; qf[4] = c.x; qf[5] = c.y; qf[6] = c.z; qf[7] = c.w;
+  }
+  const float qp_i = (quirk && active && i < Lq && p.qpad[(int64_t)b2 * Lq + i] != 0) ? 1.0f : 0.0f;
+  float m_run = -INFINITY, l_run = 0.0f, inv_l = 0.0f;
+  f32x4 oa[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  const uint32_t rowi = ((uint32_t)bh * (uint32_t)Lq + (uint32_t)i) * (uint32_t)Lk;
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int jc = 0; jc < Lk; jc += LC) {
+      __syncthreads();
+      for (int idx = tid; idx < LC * 8; idx += BT) {
+        const int r = idx >> 3, c = (idx & 7) * 4, jj = jc + r;
+        float4 k = make_float4(0.f, 0.f, 0.f, 0.f), v = k;
+        if (jj < Lk) {
+          k = *reinterpret_cast<const float4*>(kb + (int64_t)jj * p.k_ls + c);
+          if (pass) v = *reinterpret_cast<const float4*>(vb + (int64_t)jj * p.v_ls + c);
+        }
+        *reinterpret_cast<float4*>(Ks + r * BS + c) = k;
+        if (pass) *reinterpret_cast<float4*>(Vs + r * BS + c) = v;
+      }
+      if (tid < LC) {
+        const int jj = jc + tid;
+        bool m = jj >= Lk;
+        if (!m && p.kpad) m = p.kpad[(int64_t)b * Lk + jj] != 0;
+        Aux[0][tid] = m ? 1.0f : 0.0f;
+        Aux[1][tid] = (quirk && jj < Lk && p.kpad[(int64_t)b2 * Lk + jj] != 0) ? 1.0f : 0.0f;
+      }
+      __syncthreads();
+      if (!active) continue;
+      const int nb = (min(LC, Lk - jc) + 15) >> 4;
+      for (int jb = 0; jb < nb; ++jb) {
+        const int j0 = jb << 4, jr = j0 + 4 * kq;
+        float kf[8];
+        loadN<8>(Ks + (j0 + jl) * BS + 8 * kq, kf);
+        f32x4 st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) st = mfma16(kf[t], qf[t], st);  // S^T[jc + j0 + 4 kq + r][i0 + jl]
+        const float4 kp4 = *reinterpret_cast<const float4*>(&Aux[0][jr]);
+        const float4 kq4 = *reinterpret_cast<const float4*>(&Aux[1][jr]);
+        const float kp_[4] = {kp4.x, kp4.y, kp4.z, kp4.w};
+        const float kp2_[4] = {kq4.x, kq4.y, kq4.z, kq4.w};
+        float sv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sv[r] = fmaf(qp_i, kp2_[r], kp_[r]) != 0.0f ? -INFINITY : st[r] * scale;
+        if (pass == 0) {
+          const float m_new = fmaxf(fmaxf(m_run, fmaxf(sv[0], sv[1])), fmaxf(sv[2], sv[3]));
+          if (m_new != -INFINITY) {
+            float acc = l_run * __expf(m_run - m_new);  // (m_run = -inf: l_run is 0, exp(-inf) = 0)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc += __expf(sv[r] - m_new);
+            l_run = acc;
+            m_run = m_new;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float pd = (m_run == -INFINITY) ? 0.0f : __expf(sv[r] - m_run) * inv_l;
+            if (DROP) pd = mesm_hash32(rowi + (uint32_t)(jc + jr + r), drop_seed) >= thresh ? pd * inv_keep : 0.0f;
+            const float* vrow = Vs + (jr + r) * BS + jl;
+            oa[0] = mfma16(pd, vrow[0], oa[0]);
+            oa[1] = mfma16(pd, vrow[16], oa[1]);
+          }
+        }
+      }
+    }
+    if (pass == 0) {
+      // merge the four lane groups' (max, sum) of the row
+      const float M = max_xor32(max_xor16(m_run));
+      const float part_l = (m_run == -INFINITY) ? 0.0f : l_run * __expf(m_run - M);
+      const float L = add_xor32(add_xor16(part_l));
+      m_run = M;
+      l_run = L;
+      inv_l = 1.0f / L;  // (a fully masked row: 0 * inf = NaN, like the reference's softmax over -inf)
+    }
+  }
+  if (active) {
+    float* ob = p.o + (int64_t)b * p.o_bs + h * 32;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ii = i0 + 4 * kq + r;
+      if (ii < Lq) {
+        ob[(int64_t)ii * p.o_ls + jl] = oa[0][r];
+        ob[(int64_t)ii * p.o_ls + 16 + jl] = oa[1][r];
+      }
+    }
+    if (kq == 0 && i < Lq && p.lse) p.lse[(int64_t)bh * Lq + i] = m_run + __logf(l_run);
+  }
+}
+
 template <int DK>
 size_t fwd_lds_bytes(const MesmAttnArgs& a) { return FwdShape<DK>(a.Lk).floats() * sizeof(float); }
 int fwd_waves(const MesmAttnArgs& a) {
@@ -629,6 +981,30 @@ int mesm_attn_blk_fwd_group(const MesmAttnArgs* list, int n, hipStream_t s) {
   else hipLaunchKernelGGL((attn_blk_fwd_group_kernel<NJ, false>), grid, block, lds, s, g)
   BLK_FWD_NJ(LAUNCHG, nj, 0);
 #undef LAUNCHG
+  return mesm_launch_status();
+}
+
+// dk = dv = 32 packed heads of any length (what mesm_attn_blk_bwd_ok() leaves because the head does not fit in LDS)
+bool mesm_attn_blk_bwd_long_ok(const MesmAttnArgs& a) {
+  return a.dk == 32 && a.dv == 32 && !a.q2 && !a.k2 && !a.k_add && a.mask_mode != MESM_MASK_CAUSAL;
+}
+
+int mesm_attn_blk_bwd_long(const MesmAttnArgs& a, hipStream_t s) {
+  const int per = (a.Lk + LW - 1) / LW + (a.Lq + LW - 1) / LW;
+  const dim3 grid((unsigned)(a.B * a.H * per)), block(BT);
+  if (a.drop_p > 0.f) hipLaunchKernelGGL(attn_blk_bwd_long_kernel<true>, grid, block, 0, s, a);
+  else hipLaunchKernelGGL(attn_blk_bwd_long_kernel<false>, grid, block, 0, s, a);
+  return mesm_launch_status();
+}
+
+bool mesm_attn_blk_fwd_long_ok(const MesmAttnArgs& a) {
+  return a.dk == 32 && a.dv == 32 && !a.q2 && !a.k2 && !a.k_add && a.mask_mode != MESM_MASK_CAUSAL;
+}
+
+int mesm_attn_blk_fwd_long(const MesmAttnArgs& a, hipStream_t s) {
+  const dim3 grid((unsigned)(a.B * a.H * ((a.Lq + LW - 1) / LW))), block(BT);
+  if (a.drop_p > 0.f) hipLaunchKernelGGL(attn_blk_fwd_long_kernel<true>, grid, block, 0, s, a);
+  else hipLaunchKernelGGL(attn_blk_fwd_long_kernel<false>, grid, block, 0, s, a);
   return mesm_launch_status();
 }
 

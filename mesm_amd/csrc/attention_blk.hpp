@@ -15,3 +15,9 @@ bool mesm_attn_blk_fwd_ok(const MesmAttnArgs& a);
 bool mesm_attn_blk_fwd_groupable(const MesmAttnArgs& a);
 int mesm_attn_blk_fwd(const MesmAttnArgs& a, hipStream_t s);
 int mesm_attn_blk_fwd_group(const MesmAttnArgs* list, int n, hipStream_t s);
+
+// long ranges (the head does not fit in LDS): J / I workgroups streaming the other side in chunks
+bool mesm_attn_blk_bwd_long_ok(const MesmAttnArgs& a);
+int mesm_attn_blk_bwd_long(const MesmAttnArgs& a, hipStream_t s);
+bool mesm_attn_blk_fwd_long_ok(const MesmAttnArgs& a);
+int mesm_attn_blk_fwd_long(const MesmAttnArgs& a, hipStream_t s);

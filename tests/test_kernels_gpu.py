@@ -272,6 +272,8 @@ ATTN_CASES = [
     (2, 4, 96, 112, 32, 32, True, True),
     (2, 4, 112, 112, 32, 32, True, False),
     (2, 4, 140, 200, 32, 32, True, True),
+    (2, 8, 513, 513, 32, 32, True, True),   # TACoS encoder: J / I workgroups streaming the other side
+    (1, 2, 300, 130, 32, 32, False, False),
 ]
 
 

@@ -6,7 +6,8 @@ from mesm_amd import kernels as kn
 dev = torch.device("cuda:0")
 SHAPES = [("T2V   Lq75 Lk33", 64, 8, 75, 33, 32, 32), ("enc   Lq76 Lk76", 64, 8, 76, 76, 32, 32),
           ("V2T   Lq33 Lk75", 64, 8, 33, 75, 32, 32), ("dec sa Lq10 Lk10", 32, 8, 10, 10, 32, 32),
-          ("dec ca Lq10 Lk75", 32, 8, 10, 75, 64, 32)]
+          ("dec ca Lq10 Lk75", 32, 8, 10, 75, 64, 32), ("tacos enc 513x513", 32, 8, 513, 513, 32, 32),
+          ("tacos t2v 512x17", 32, 8, 512, 17, 32, 32)]
 
 
 def timed(fn, n=16):
