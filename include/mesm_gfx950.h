@@ -334,6 +334,8 @@ int mesm_attn_bwd(const MesmAttnArgs* args, void* stream);
  * forward (dk = dv = 32, Lk <= 128, no split heads) / the lane-per-key backward (dk = dv = 32, no split heads)
  * take share launches of up to 8, the others run through the plain entry points.  Same contracts as
  * mesm_attn_fwd / mesm_attn_bwd per problem. */
+/* 1 if mesm_attn_bwd ADDS into dq / dq2 for this shape (they must then be zero on entry), 0 if it writes them. */
+int mesm_attn_bwd_accumulates_dq(int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t dk, int32_t dv, int32_t split);
 int mesm_attn_fwd_group(const MesmAttnArgs* list, int32_t n, void* stream);
 int mesm_attn_bwd_group(const MesmAttnArgs* list, int32_t n, void* stream);
 

@@ -99,6 +99,7 @@ PROTOTYPES = {
                                                         c_ptr, c_ptr, c_ptr]),
     "mesm_layernorm_fwd_group": (ctypes.c_int, [ctypes.POINTER(LnArgs), _i32, c_ptr]),
     "mesm_layernorm_bwd_group": (ctypes.c_int, [ctypes.POINTER(LnArgs), _i32, c_ptr]),
+    "mesm_attn_bwd_accumulates_dq": (ctypes.c_int, [_i32] * 7),
     "mesm_attn_fwd_group": (ctypes.c_int, [ctypes.POINTER(AttnArgs), _i32, c_ptr]),
     "mesm_attn_bwd_group": (ctypes.c_int, [ctypes.POINTER(AttnArgs), _i32, c_ptr]),
     "mesm_attn_fwd": (ctypes.c_int, [ctypes.POINTER(AttnArgs), c_ptr]),

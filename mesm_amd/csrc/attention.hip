@@ -519,6 +519,24 @@ extern "C" int mesm_attn_fwd(const MesmAttnArgs* args, void* stream) {
   return mesm_launch_status();
 }
 
+// Does mesm_attn_bwd ADD into dq for this shape (the lane-per-key kernel with several 64-key tiles: the caller must
+// hand in zeros), or write it (every matrix-core path, one key tile)?  Same predicates as the dispatch below, on a
+// shape-only argument block (packed layouts), so callers can skip the zero fill.
+extern "C" int mesm_attn_bwd_accumulates_dq(int32_t B, int32_t H, int32_t Lq, int32_t Lk, int32_t dk, int32_t dv,
+                                            int32_t split) {
+  MesmAttnArgs a = {};
+  static float dummy;
+  a.B = B; a.H = H; a.Lq = Lq; a.Lk = Lk; a.dk = dk; a.dv = dv;
+  a.q_ls = a.k_ls = (int64_t)H * (split ? dk / 2 : dk);
+  a.v_ls = a.o_ls = (int64_t)H * dv;
+  a.q_bs = a.q_ls * Lq; a.k_bs = a.k_ls * Lk; a.v_bs = a.v_ls * Lk; a.o_bs = a.o_ls * Lq;
+  if (split) { a.q2 = a.k2 = &dummy; a.dq2 = a.dk2 = &dummy; }
+  static const bool legacy = getenv("MESM_ATTN_LEGACY") != nullptr;
+  if (!legacy && mesm_attn_mfma_bwd_ok(a)) return 0;
+  if (blk_bwd_enabled() && (mesm_attn_blk_bwd_ok(a) || (a.Lk > 128 && mesm_attn_blk_bwd_long_ok(a)))) return 0;
+  return Lk > KT ? 1 : 0;
+}
+
 extern "C" int mesm_attn_bwd(const MesmAttnArgs* args, void* stream) {
   if (!args) return MESM_EINVAL;
   MesmAttnArgs a = *args;

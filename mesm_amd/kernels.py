@@ -441,6 +441,19 @@ def attn_fwd(q, k, v, H, kpad=None, qpad=None, scale=None, drop=(0.0, 0), group=
     return o, lse
 
 
+_dq_zero_cache = {}
+
+
+def attn_bwd_adds_dq(B, H, Lq, Lk, dk, dv, split=False):
+    """True where the attention backward that will run for this shape ADDS into dq (lane-per-key kernel, several key
+    tiles): the caller hands in zeros (from the step's zero pool); the matrix-core paths write dq."""
+    key = (int(B), int(H), int(Lq), int(Lk), int(dk), int(dv), 1 if split else 0)
+    need = _dq_zero_cache.get(key)
+    if need is None:
+        need = _dq_zero_cache[key] = bool(lib().mesm_attn_bwd_accumulates_dq(*key))
+    return need
+
+
 def attn_bwd(do, q, k, v, o, lse, H, kpad=None, qpad=None, scale=None, drop=(0.0, 0), group=0, q2=None, k2=None):
     """-> dq, dk, dv (and dq2, dk2 with split heads)."""
     require_gpu(do, q, k, v, o, lse)

@@ -775,7 +775,8 @@ class DecSelfAttnBlock:
         H, drop = ctx.cfg
         n, nq, d = tgt.shape
         q, k, v = qkv[..., :d], qkv[..., d:2 * d], qkv[..., 2 * d:]
-        dqkv = kn.zeros((n, nq, 3 * d), tgt.device) if nq > 64 else torch.empty(n, nq, 3 * d, device=tgt.device, dtype=torch.float32)
+        dqkv = (kn.zeros((n, nq, 3 * d), tgt.device) if kn.attn_bwd_adds_dq(n, H, nq, nq, d // H, d // H)
+                else torch.empty(n, nq, 3 * d, device=tgt.device, dtype=torch.float32))
         kn.attn_bwd_into(_c(do), q, k, v, o, lse, H, dqkv[..., :d], dqkv[..., d:2 * d], dqkv[..., 2 * d:], drop=drop)
         yield
         g2 = _2d(dqkv)
@@ -847,7 +848,8 @@ class DecCrossAttnBlock:
         dev = tgt.device
         kc, cv, kp = kvp[..., :d], kvp[..., d:2 * d], kvp[..., 2 * d:]
         # several 64-key tiles add into dq atomically: both query halves start from zero (one fill)
-        dq2x = kn.zeros((2, n, nq, d), dev) if lm > 64 else torch.empty(2, n, nq, d, device=dev, dtype=torch.float32)
+        dq2x = (kn.zeros((2, n, nq, d), dev) if kn.attn_bwd_adds_dq(n, H, nq, lm, 2 * d // H, d // H, split=True)
+                else torch.empty(2, n, nq, d, device=dev, dtype=torch.float32))
         dqc, dqs = dq2x[0], dq2x[1]
         dkvp = torch.empty(n, lm, 3 * d, device=dev, dtype=torch.float32)
         kn.attn_bwd_into(_c(do), qc, kc, cv, o, lse, H, dqc, dkvp[..., :d], dkvp[..., d:2 * d], kpad=mem_pad,
@@ -992,7 +994,8 @@ class MHABlock:
         dxq = dxqp = dxk = dpk = None
         if self_attn:
             # dq is added atomically only when several 64-key tiles contribute
-            dqkv = kn.zeros((N, Lq, 3 * d), dev) if Lq > 64 else torch.empty(N, Lq, 3 * d, device=dev, dtype=torch.float32)
+            dqkv = (kn.zeros((N, Lq, 3 * d), dev) if kn.attn_bwd_adds_dq(N, H, Lq, Lq, d // H, d // H)
+                    else torch.empty(N, Lq, 3 * d, device=dev, dtype=torch.float32))
             kn.attn_bwd_into(do, q, k, v, o, lse, H, dqkv[..., :d], dqkv[..., d:2 * d],
                              dqkv[..., 2 * d:], kpad=kpad, qpad=qpad, drop=attn_drop, group=group)
             yield
@@ -1013,7 +1016,8 @@ class MHABlock:
                     kn.gemm(g2, w_in, _2d(dxq), residual=dy2 if fold else None)
         else:
             Lk = k.shape[1]
-            dq = kn.zeros((N, Lq, d), dev) if Lk > 64 else torch.empty(N, Lq, d, device=dev, dtype=torch.float32)
+            dq = (kn.zeros((N, Lq, d), dev) if kn.attn_bwd_adds_dq(N, H, Lq, Lk, d // H, d // H)
+                  else torch.empty(N, Lq, d, device=dev, dtype=torch.float32))
             dkv = torch.empty(N, Lk, 2 * d, device=dev, dtype=torch.float32)
             kn.attn_bwd_into(do, q, k, v, o, lse, H, dq, dkv[..., :d], dkv[..., d:], kpad=kpad,
                              qpad=qpad, drop=attn_drop, group=group)
