@@ -34,6 +34,14 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
     step()
     torch.cuda.synchronize()
 rows = collections.Counter(); times = collections.Counter()
+# forward call site of every autograd node, by sequence number (the engine-side fan-in adds have no python frame)
+fwd_site = {}
+for e in prof.events():
+    sn = getattr(e, "sequence_nr", -1)
+    if sn is not None and sn >= 0 and e.stack and "Backward" not in e.name:
+        fr = [f for f in e.stack if "mesm_amd" in f and "ops.py" not in f]
+        if fr and sn not in fwd_site:
+            fwd_site[sn] = fr[0].split("mesm_amd/")[-1]
 for e in prof.events():
     if not e.name.startswith("aten::"):
         continue
@@ -51,6 +59,9 @@ for e in prof.events():
     while par is not None:
         if "Backward" in par.name or "AccumulateGrad" in par.name:
             node = par.name.split("autograd::engine::evaluate_function: ")[-1]
+            sn = getattr(par, "sequence_nr", -1)
+            if not frames and sn in fwd_site:
+                where = "bwd of " + fwd_site[sn]
             break
         par = par.cpu_parent
     shp = str([tuple(x) for x in (e.input_shapes or []) if x])[:60]

@@ -34,5 +34,7 @@ python3 tools/ln_bench.py > $out/ln_bench.txt 2>&1
 python3 tools/branch_cost.py > $out/branch_cost.txt 2>&1
 python3 tools/bf16x_check.py > $out/bf16x_check.txt 2>&1
 python3 tools/host_cost.py > $out/host_cost.txt 2>&1
+python3 tools/tape_profile.py > $out/tape_profile.txt 2>&1
+python3 tools/aten_origin.py > $out/aten_origin.txt 2>&1
 find $out -type f | xargs ls -la | head -40
 du -sh $out
