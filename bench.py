@@ -178,6 +178,8 @@ def main():
             from mesm_amd.ddp import RcclComm
             ok, comm, cands = 1, None, {}
             try:
+                if os.environ.get("MESM_BENCH_FAIL_OWN") == "1":  # (exercises the fallback below)
+                    raise RuntimeError("simulated failure of the own-communicator path")
                 comm = RcclComm(dev)
                 for c in (["own-inline", "own-overlapped"] if mode == "auto" else [mode]):
                     inl = c == "own-inline"
@@ -188,15 +190,23 @@ def main():
             except Exception as e:
                 log("own-communicator capture failed on this rank (%s: %s)" % (type(e).__name__, e))
                 ok = 0
+            any_ok = ok
             if world > 1:  # every rank has to agree before anything else is issued (ADVICE: no asymmetric fallback)
-                flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+                flag = torch.tensor([ok, -ok], device=dev, dtype=torch.int32)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                ok = int(flag.item())
-            if not ok:
+                ok, any_ok = int(flag[0].item()), -int(flag[1].item())
+            if not ok and not any_ok:
+                # EVERY rank failed the same way (no librccl to dlopen, capture refused, ...): nothing of the own
+                # communicator is in flight anywhere, so the plain form is safe to fall back to
+                log("own-communicator path unavailable on every rank: falling back to MESM_DDP_MODE=after")
+                cands.clear()
+                model.gradbuf().on_ready = None  # (the failed candidates' reducers hooked themselves in)
+                mode = "after"
+            elif not ok:
                 raise SystemExit("bench: the captured data-parallel step could not be built on every rank; "
                                  "restart with MESM_DDP_MODE=after")
             probe = {}
-            for c, (gs, red) in cands.items():
+            for c, (gs, red) in (cands.items() if ok else ()):
                 for _ in range(2):
                     gs.run(redraw=False)
                 torch.cuda.synchronize()
@@ -210,17 +220,19 @@ def main():
                 if world > 1:
                     dist.all_reduce(pt, op=dist.ReduceOp.MAX)
                 probe[c] = float(pt.item())
-            best = min(probe, key=probe.get)
-            gstep, reducer = cands[best]
+            best = min(probe, key=probe.get) if probe else None
+            if best is not None:
+                gstep, reducer = cands[best]
             cands.clear()
             what = {"own-inline": "one all-reduce of the flat gradient buffer recorded at the end of the step graph on the "
                                   "compute stream (one queue, wire time exposed)",
                     "own-overlapped": "six bucket all-reduces recorded inside the step graph on the communicator's own "
-                                      "stream, overlapped with backward"}[best]
-            ddp_mode = ("own RCCL communicator (mesm_ddp_*), 1/N folded into the loss gradient; %s; start-up probe, ms/step "
-                        "max over ranks: %s -> %s%s"
-                        % (what, ", ".join("%s %.3f" % kv for kv in sorted(probe.items())), best,
-                           "" if mode == "auto" else " (forced by MESM_DDP_MODE)"))
+                                      "stream, overlapped with backward"}.get(best)
+            if best is not None:
+                ddp_mode = ("own RCCL communicator (mesm_ddp_*), 1/N folded into the loss gradient; %s; start-up probe, "
+                            "ms/step max over ranks: %s -> %s%s"
+                            % (what, ", ".join("%s %.3f" % kv for kv in sorted(probe.items())), best,
+                               "" if mode == "auto" else " (forced by MESM_DDP_MODE)"))
         elif ddp_on and mode in ("captured", "inline"):
             ok = 1
             try:
@@ -499,6 +511,11 @@ def main():
                        "loader_like_epoch_not_in_metric": loader},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
+        try:  # whatever native libraries left in C stdio buffers (RCCL's version banner) goes out BEFORE the result line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(line), flush=True)
     if world > 1:
         # leave together and without tearing the communicator down: destroying a RCCL process group next to live

@@ -158,8 +158,9 @@ class T2VLayer(nn.Module):
         self.p = dropout
 
     def steps(self, txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm=False, group=0, vid_p=None,
-              out_pos=None, kv_share=None):
+              out_pos=None, kv_share=None, join_qp=False):
         """The layer as a chain of three block calls (ops.lockstep).
+        join_qp: vid_p was formed without autograd (vid + a constant): its gradient joins d vid inside the block.
         kv_share: ops.GradShare of the stack's layers for d txt (no key position term).
         vid_p: vid + pos_vid when the producer of vid has already written it (None: formed here).
         out_pos: also return output + out_pos (the next block's query) -> (out, out_p)."""
@@ -169,7 +170,7 @@ class T2VLayer(nn.Module):
         x = yield ops.mha_call(vid, vid_p, txt, pos_txt, vid, sa.in_proj_weight, sa.in_proj_bias,
                                sa.out_proj.weight, sa.out_proj.bias, self.nhead, kpad=txt_pad, qpad=vid_pad,
                                attn_drop=drop_state.next(self.p), out_drop=drop_state.next(self.p), group=group,
-                               kv_share=kv_share if pos_txt is None else None)
+                               kv_share=kv_share if pos_txt is None else None, join_qp=join_qp)
         alt = self.two_mlp and is_mlm
         n1, n2 = (self.norm1_1, self.norm2_1) if alt else (self.norm1, self.norm2)
         l1, l2 = (self.linear1_1, self.linear2_1) if alt else (self.linear1, self.linear2)
@@ -194,14 +195,14 @@ class T2VStack(nn.Module):
         self.layers = _clones(layer, n)
 
     def steps(self, txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm=False, group=0, vid_p=None,
-              out_pos=None):
+              out_pos=None, join_vid_p=False):
         n = len(self.layers)
         # every layer reads the same txt: their d txt shares are summed by the dX GEMMs' epilogues, not by autograd
         share = ops.GradShare(n) if (n > 1 and pos_txt is None and torch.is_grad_enabled() and txt.requires_grad) else None
         for i, l in enumerate(self.layers):
             op = out_pos if i == n - 1 else pos_vid
             res = yield from l.steps(txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm, group, vid_p=vid_p,
-                                     out_pos=op, kv_share=share)
+                                     out_pos=op, kv_share=share, join_qp=join_vid_p and i == 0)
             vid, vid_p = res if op is not None else (res, None)
         return (vid, vid_p) if out_pos is not None else vid
 
@@ -231,9 +232,10 @@ class T2VEncoder(nn.Module):
         return self.t2v_encoder(txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm, group, vid_p=vid_p,
                                 out_pos=out_pos)
 
-    def steps(self, txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm=False, group=0, vid_p=None, out_pos=None):
+    def steps(self, txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm=False, group=0, vid_p=None, out_pos=None,
+              join_vid_p=False):
         return self.t2v_encoder.steps(txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm, group, vid_p=vid_p,
-                                      out_pos=out_pos)
+                                      out_pos=out_pos, join_vid_p=join_vid_p)
 
 
 class EncoderLayer(nn.Module):

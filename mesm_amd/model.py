@@ -66,18 +66,6 @@ class SegSenRecon(nn.Module):
                                               LinearLayer(d, d, input_dropout, False))
 
 
-class _AddPos(torch.autograd.Function):
-    """x + pos (pos carries no gradient): d x = d out."""
-
-    @staticmethod
-    def forward(ctx, x, pos):
-        return kn.add_wrap(x.contiguous(), pos.contiguous())
-
-    @staticmethod
-    def backward(ctx, g):
-        return g, None
-
-
 class Plan:
     """Host-side decisions of one forward call, as device index tensors."""
     pass
@@ -473,7 +461,8 @@ class MESM(nn.Module):
             # for the words (neg_words_feat = expanded_words_feat[neg_index][:, 1:] = projected words of the
             # negative query; the SS token is stripped again, model.py:264-266)
             pv2, vpos2, vid_pad2, pw2, wpad2 = ops.stack_rows([pv, vpos, vid_pad, pw, words_pad], [0, 0, 0, 1, 1], ni)
-            pvp2 = kn.add_wrap(pv2, vpos2) if not pv2.requires_grad else _AddPos.apply(pv2, vpos2)
+            # pv2 + position, formed without autograd: the consumer block folds its gradient into d pv2 (join_vid_p)
+            pvp2 = kn.add_wrap(pv2.detach(), vpos2)
             stage, names = [], []
             tpos2 = None
             if self.rec_fw:
@@ -484,7 +473,8 @@ class MESM(nn.Module):
                 # every block hands its output + position embedding to the next one (second output of its last
                 # LayerNorm), so only this very first query is formed by an element-wise launch
                 if not defer_enhance:
-                    stage.append(enc.steps(pw2, pv2, tpos2, vpos2, wpad2, vid_pad2, group=N, vid_p=pvp2, out_pos=vpos2))
+                    stage.append(enc.steps(pw2, pv2, tpos2, vpos2, wpad2, vid_pad2, group=N, vid_p=pvp2, out_pos=vpos2,
+                                           join_vid_p=True))
                     names.append("E")
             if self.rec_ss:
                 # the pair's own sentence slot is replaced by the learned token (model.py:493-501)
@@ -535,7 +525,8 @@ class MESM(nn.Module):
                 ewords2, epad2, etpos2 = ops.stack_rows([ewords, epad, etpos], [1, 1, 1], ni)
                 if defer_enhance:
                     tpos2 = torch.cat([tpos, etpos2[N:, 1:]], 0)
-                    pre = enc.steps(pw2, pv2, tpos2, vpos2, wpad2, vid_pad2, group=N, vid_p=pvp2, out_pos=vpos2)
+                    pre = enc.steps(pw2, pv2, tpos2, vpos2, wpad2, vid_pad2, group=N, vid_p=pvp2, out_pos=vpos2,
+                                    join_vid_p=True)
             else:
                 ewords2, epad2 = ops.stack_rows([ewords, epad], [1, 1], ni)
                 etpos2 = None
@@ -544,7 +535,9 @@ class MESM(nn.Module):
                 e2, e2p = enhanced2, enhanced2_p
                 if pre is not None:
                     e2, e2p = yield from pre
-                enc2 = yield from self.t2v_encoder.steps(ewords2, e2, etpos2, vpos2, epad2, vid_pad2, group=N, vid_p=e2p)
+                # (without the enhance stage the t2v stack's first query is the autograd-free pv2 + position)
+                enc2 = yield from self.t2v_encoder.steps(ewords2, e2, etpos2, vpos2, epad2, vid_pad2, group=N, vid_p=e2p,
+                                                         join_vid_p=e2p is pvp2)
                 return e2, enc2
 
             def mlm_head_chain():

@@ -919,10 +919,13 @@ class MHABlock:
 
     @staticmethod
     def fwd(ctx, xq, xqp, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad, qpad, attn_drop,
-            out_drop, self_attn, group=0, sink=None, kv_share=None):
+            out_drop, self_attn, group=0, sink=None, kv_share=None, join_qp=False):
         ctx.set_materialize_grads(False)
         ctx.sink = sink
         ctx.kv_share = kv_share
+        # join_qp: xqp = xq + a constant formed WITHOUT autograd (the very first query of a stack): its gradient
+        # belongs to xq and joins the residual route in the dX GEMM's epilogue instead of an element-wise add
+        ctx.join_qp = join_qp
         xq = _c(xq)
         has_p = xqp is not None
         xqp = _c(xqp) if has_p else xq
@@ -1030,7 +1033,10 @@ class MHABlock:
             else:
                 _accum_dw(g2[:, :d], _2d(xk), gwi[d:2 * d], gbi[d:2 * d], x2=_2d(pk))
                 _accum_dw(g2[:, d:], _2d(xk), gwi[2 * d:], gbi[2 * d:])
-            if has_p:
+            if has_p and ctx.join_qp and fold and not need_qp:
+                dxq = torch.empty_like(xq)
+                kn.gemm(_2d(dq), w_in[:d], _2d(dxq), residual=dy2)
+            elif has_p:
                 if need_qp:
                     dxqp = torch.empty_like(xq)
                     kn.gemm(_2d(dq), w_in[:d], _2d(dxqp))
@@ -1062,14 +1068,14 @@ class MHABlock:
                     kn.gemm(g2[:, d:], w_in[2 * d:], _2d(dxk), residual=_2d(dk_in))
         return (dxq, dxqp, dxk, dpk, dy if has_res and ctx.needs_input_grad[4] and not fold else None,
                 None if d_wi else gwi, None if d_bi else gbi, None if d_wo else gwo,
-                None if d_bo else gbo, None, None, None, None, None, None, None, None, None)
+                None if d_bo else gbo, None, None, None, None, None, None, None, None, None, None)
 
 
 def mha_call(xq, xqp, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad=None, qpad=None,
-             attn_drop=NO_DROP, out_drop=NO_DROP, self_attn=False, group=0, kv_share=None):
+             attn_drop=NO_DROP, out_drop=NO_DROP, self_attn=False, group=0, kv_share=None, join_qp=False):
     sink = _sink_for(out_drop)
     return Call(MHABlock, (xq, xqp, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad, qpad, attn_drop,
-                           out_drop, self_attn, group, sink, kv_share), lambda y: _tag(y, sink))
+                           out_drop, self_attn, group, sink, kv_share, join_qp), lambda y: _tag(y, sink))
 
 
 def mha(xq, xqp, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad=None, qpad=None,

@@ -11,6 +11,7 @@ from mesm_amd import build_criterion, build_model, synthetic
 from oracle import mesm_oracle as O
 
 dev = torch.device("cuda:0")
+ONLY = set(int(x) for x in os.environ.get("FUZZ_ONLY", "").split(",") if x)  # re-run single cases of a sweep
 
 
 def rel(a, b):
@@ -48,6 +49,8 @@ def fuzz_case(rng, case):
         case, dataset, groups, Lv, Lw, d, heads, over["dim_feedforward"], over["num_queries"], over["rec_fw"], over["rec_ss"],
         over["aux_loss"], over["use_txt_pos"], over["n_input_proj"], over["t2v_layers"], over["enc_layers"], over["dec_layers"],
         over["num_recfw_layers"], over["num_recss_layers"], ragged, seed)
+    if ONLY and case not in ONLY:
+        return tag, "ok"  # (FUZZ_ONLY: configurations are still drawn in order)
     try:
         args = synthetic.make_args(None, **over)
         torch.manual_seed(seed)
@@ -116,7 +119,7 @@ def fuzz_case(rng, case):
         else:
             w = max((l2(grads[k], g), k) for k, g in o_grads.items())
             if not w[0] < 5e-3:
-                errs.append("grad L2 %s %.2e" % (w[1], w[0]))
+                errs.append("grad L2 %s %.2e (norms %.3e vs %.3e)" % (w[1], w[0], float(grads[w[1]].norm()), float(o_grads[w[1]].norm())))
         status = "ok" if not errs else "MISMATCH " + "; ".join(errs[:6])
     except Exception as e:  # noqa: BLE001
         status = "ERROR %s: %s" % (type(e).__name__, str(e)[:200])
