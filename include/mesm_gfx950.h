@@ -145,6 +145,11 @@ int mesm_gemm_f32(const MesmGemmArgs* args, void* stream);
  * (transformer.py:737-747, 759-784) are issued here -- a launch costs ~5 us whatever its size.
  */
 int mesm_gemm_group(const MesmGemmArgs* args, int32_t n, void* stream);
+/* The PReLU slope-gradient partials of a launch (dslope / dslope_ws) are reduced by the NEXT GEMM launch on the stream
+ * (first workgroup, before its own work) instead of a launch of their own; dslope_ws must stay valid until then.
+ * mesm_gemm_flush_side reduces whatever is still pending with plain launches: call it before dslope is read or
+ * dslope_ws is released without another GEMM launch in between. */
+int mesm_gemm_flush_side(void* stream);
 
 /*
  * Launch-duration measurement of mesm_gemm_f32 (the dominant kernel of the step) for

@@ -79,11 +79,68 @@ __global__ __launch_bounds__(256) void dslope_reduce_kernel(const float* __restr
   if (threadIdx.x == 0) dst[0] += sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// The reduction of the partials does not get a launch of its own (14 per step, ~2.3 us each in the graph): it is
+// CARRIED by the next GEMM launch on the stream -- wave 0 of that launch's first workgroup sums the partials of up to four
+// pending reductions before its own work (stream order: the producing kernel has finished).  Host-side queue; what no
+// launch has picked up is reduced by mesm_gemm_flush_side (called at the end of every backward block).
+struct SideRed {
+  const float* ws[4];
+  float* dst[4];
+  int n[4];
+  int count;
+};
+
+__device__ __forceinline__ void side_reduce(const SideRed& sr) {
+  if (sr.count == 0 || blockIdx.x != 0 || blockIdx.y != 0 || blockIdx.z != 0 || (threadIdx.x >> 6) != 0) return;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (i < sr.count) {
+      float a = 0.0f;
+      for (int k = lane; k < sr.n[i]; k += 64) a += sr.ws[i][k];
+      a = wave_sum(a);
+      if (lane == 0) sr.dst[i][0] += a;
+    }
+  }
+}
+
+struct SidePending {
+  const float* ws;
+  float* dst;
+  int n;
+};
+std::vector<SidePending> g_side;
+const bool g_side_on = getenv("MESM_DSLOPE_LAUNCH") == nullptr;  // MESM_DSLOPE_LAUNCH=1: one launch per reduction (A/B)
+
 inline int dslope_finish(const MesmGemmArgs& a, dim3 grid, hipStream_t s) {
   if (a.e_actgrad != MESM_ACT_PRELU || !a.dslope) return MESM_OK;
-  hipLaunchKernelGGL(dslope_reduce_kernel, dim3(1), dim3(256), 0, s, a.dslope_ws,
-                     (int64_t)grid.x * grid.y * grid.z, a.dslope);
+  const int64_t n = (int64_t)grid.x * grid.y * grid.z;
+  if (g_side_on && n < (1 << 30)) {
+    g_side.push_back({a.dslope_ws, a.dslope, (int)n});
+    return MESM_OK;
+  }
+  hipLaunchKernelGGL(dslope_reduce_kernel, dim3(1), dim3(256), 0, s, a.dslope_ws, n, a.dslope);
   return mesm_launch_status();
+}
+
+// up to four pending reductions for the launch that is about to be issued
+inline SideRed take_side() {
+  SideRed sr = {};
+  while (sr.count < 4 && !g_side.empty()) {
+    const SidePending e = g_side.front();
+    g_side.erase(g_side.begin());
+    sr.ws[sr.count] = e.ws; sr.dst[sr.count] = e.dst; sr.n[sr.count] = e.n;
+    ++sr.count;
+  }
+  return sr;
+}
+
+inline int flush_side(hipStream_t s) {
+  for (const SidePending& e : g_side)
+    hipLaunchKernelGGL(dslope_reduce_kernel, dim3(1), dim3(256), 0, s, e.ws, (int64_t)e.n, e.dst);
+  const bool any = !g_side.empty();
+  g_side.clear();
+  return any ? mesm_launch_status() : MESM_OK;
 }
 
 // One operand tile: ROWS (outer index) x BK (reduce index), staged through registers.
@@ -1243,7 +1300,8 @@ inline int ws_stages_for(const MesmGemmArgs& a) {
 }
 
 template <int LA, int LB, bool XF, int STAGES>
-__global__ WS_BOUNDS void gemm_wstage_kernel(const MesmGemmArgs p) {
+__global__ WS_BOUNDS void gemm_wstage_kernel(const MesmGemmArgs p, const SideRed sr) {
+  side_reduce(sr);
   __shared__ __attribute__((aligned(16))) float L[ws_lds_floats(STAGES)];
   Blk blk;
   xcd_tile(blockIdx.x, (p.M + 31) / 32, (p.N + 31) / 32, blk.x, blk.y);
@@ -1263,7 +1321,8 @@ struct GroupArgs {
 };
 
 template <int STAGES>
-__global__ WS_BOUNDS void gemm_wstage_group_kernel(const GroupArgs g) {
+__global__ WS_BOUNDS void gemm_wstage_group_kernel(const GroupArgs g, const SideRed sr) {
+  side_reduce(sr);
   __shared__ __attribute__((aligned(16))) float L[ws_lds_floats(STAGES)];
   const int bid = blockIdx.x;
   int gi = 0;
@@ -1303,10 +1362,11 @@ int launch_wstage_l(const MesmGemmArgs& a, hipStream_t s) {
   dim3 grid(((a.M + 31) / 32) * ((a.N + 31) / 32), 1, a.split_k > 1 ? a.split_k : 1);  // 1-D: xcd_tile() maps it
   const bool xf = a.a_act != MESM_ACT_NONE || a.b_act != MESM_ACT_NONE || a.a_drop_p > 0.f || a.b_drop_p > 0.f;
   const bool one = ws_stages_for(a) == 1;
-  if (xf && one) hipLaunchKernelGGL((gemm_wstage_kernel<LA, LB, true, 1>), grid, dim3(WS_THREADS), 0, s, a);
-  else if (xf) hipLaunchKernelGGL((gemm_wstage_kernel<LA, LB, true, 2>), grid, dim3(WS_THREADS), 0, s, a);
-  else if (one) hipLaunchKernelGGL((gemm_wstage_kernel<LA, LB, false, 1>), grid, dim3(WS_THREADS), 0, s, a);
-  else hipLaunchKernelGGL((gemm_wstage_kernel<LA, LB, false, 2>), grid, dim3(WS_THREADS), 0, s, a);
+  const SideRed sr = take_side();
+  if (xf && one) hipLaunchKernelGGL((gemm_wstage_kernel<LA, LB, true, 1>), grid, dim3(WS_THREADS), 0, s, a, sr);
+  else if (xf) hipLaunchKernelGGL((gemm_wstage_kernel<LA, LB, true, 2>), grid, dim3(WS_THREADS), 0, s, a, sr);
+  else if (one) hipLaunchKernelGGL((gemm_wstage_kernel<LA, LB, false, 1>), grid, dim3(WS_THREADS), 0, s, a, sr);
+  else hipLaunchKernelGGL((gemm_wstage_kernel<LA, LB, false, 2>), grid, dim3(WS_THREADS), 0, s, a, sr);
   const int rc = mesm_launch_status();
   return rc != MESM_OK ? rc : dslope_finish(a, grid, s);
 }
@@ -1567,7 +1627,8 @@ __device__ __forceinline__ void wstage64_body(const MesmGemmArgs& p, const Blk b
 }
 
 template <int LA, int LB, bool XF, int BF = 0>
-__global__ __launch_bounds__(NTHREADS) void gemm_wstage64_kernel(const MesmGemmArgs p) {
+__global__ __launch_bounds__(NTHREADS) void gemm_wstage64_kernel(const MesmGemmArgs p, const SideRed sr) {
+  side_reduce(sr);
   __shared__ __attribute__((aligned(16))) float L[4 * 4 * WS_SLAB];  // 4 waves x 4 slabs = 64 KB
   Blk blk;
   xcd_tile(blockIdx.x, (p.M + 63) / 64, (p.N + 63) / 64, blk.x, blk.y);
@@ -1587,10 +1648,11 @@ int launch_wstage64_l(const MesmGemmArgs& a, hipStream_t s) {
   dim3 grid(((a.M + 63) / 64) * ((a.N + 63) / 64), 1, a.split_k > 1 ? a.split_k : 1);  // 1-D: xcd_tile() maps it
   const bool xf = a.a_act != MESM_ACT_NONE || a.b_act != MESM_ACT_NONE || a.a_drop_p > 0.f || a.b_drop_p > 0.f;
   const int bf = xf ? 0 : bf16x_mode();
-  if (bf == 6) hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, false, 6>), grid, dim3(NTHREADS), 0, s, a);
-  else if (bf == 3) hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, false, 3>), grid, dim3(NTHREADS), 0, s, a);
-  else if (xf) hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, true>), grid, dim3(NTHREADS), 0, s, a);
-  else hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, false>), grid, dim3(NTHREADS), 0, s, a);
+  const SideRed sr = take_side();
+  if (bf == 6) hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, false, 6>), grid, dim3(NTHREADS), 0, s, a, sr);
+  else if (bf == 3) hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, false, 3>), grid, dim3(NTHREADS), 0, s, a, sr);
+  else if (xf) hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, true>), grid, dim3(NTHREADS), 0, s, a, sr);
+  else hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, false>), grid, dim3(NTHREADS), 0, s, a, sr);
   const int rc = mesm_launch_status();
   return rc != MESM_OK ? rc : dslope_finish(a, grid, s);
 }
@@ -1884,7 +1946,8 @@ __device__ __forceinline__ void l64_issue(const float* __restrict__ base, int64_
 // occupancy target; -DMESM_L64_NO_LOAD / _NO_MFMA / _NO_STORE are kill switches that remove one phase
 // (wrong results, timing only) -- the decomposition quoted in DESIGN.md section 8 comes from them.
 template <int LA, int LB, bool XF>
-__global__ L64_BOUNDS void gemm_lds64_kernel(const MesmGemmArgs p) {
+__global__ L64_BOUNDS void gemm_lds64_kernel(const MesmGemmArgs p, const SideRed sr) {
+  side_reduce(sr);
   __shared__ __attribute__((aligned(16))) float L[L64_STAGES * L64_STAGE_FLOATS];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -2073,8 +2136,9 @@ template <int LA, int LB>
 int launch_lds64_l(const MesmGemmArgs& a, hipStream_t s) {
   dim3 grid(((a.M + 63) / 64) * ((a.N + 63) / 64), 1, a.split_k > 1 ? a.split_k : 1);  // 1-D: xcd_tile() maps it
   const bool xf = a.a_act != MESM_ACT_NONE || a.b_act != MESM_ACT_NONE || a.a_drop_p > 0.f || a.b_drop_p > 0.f;
-  if (xf) hipLaunchKernelGGL((gemm_lds64_kernel<LA, LB, true>), grid, dim3(NTHREADS), 0, s, a);
-  else hipLaunchKernelGGL((gemm_lds64_kernel<LA, LB, false>), grid, dim3(NTHREADS), 0, s, a);
+  const SideRed sr = take_side();
+  if (xf) hipLaunchKernelGGL((gemm_lds64_kernel<LA, LB, true>), grid, dim3(NTHREADS), 0, s, a, sr);
+  else hipLaunchKernelGGL((gemm_lds64_kernel<LA, LB, false>), grid, dim3(NTHREADS), 0, s, a, sr);
   const int rc = mesm_launch_status();
   return rc != MESM_OK ? rc : dslope_finish(a, grid, s);
 }
@@ -2595,8 +2659,9 @@ int launch_group(const MesmGemmArgs* list, const int* vecs, int n, hipStream_t s
     } else {
       bool one = true;  // single-stage staging only if every problem of the group wants it
       for (int k = 0; k < g.n; ++k) one = one && ws_stages_for(g.p[k]) == 1;
-      if (one) hipLaunchKernelGGL(gemm_wstage_group_kernel<1>, dim3(g.start[g.n]), dim3(WS_THREADS), 0, s, g);
-      else hipLaunchKernelGGL(gemm_wstage_group_kernel<2>, dim3(g.start[g.n]), dim3(WS_THREADS), 0, s, g);
+      const SideRed sr = take_side();
+      if (one) hipLaunchKernelGGL(gemm_wstage_group_kernel<1>, dim3(g.start[g.n]), dim3(WS_THREADS), 0, s, g, sr);
+      else hipLaunchKernelGGL(gemm_wstage_group_kernel<2>, dim3(g.start[g.n]), dim3(WS_THREADS), 0, s, g, sr);
       rc = mesm_launch_status();
       for (int k = 0; k < g.n && rc == MESM_OK; ++k) {
         const MesmGemmArgs& a = g.p[k];
@@ -2642,6 +2707,8 @@ extern "C" int mesm_gemm_group(const MesmGemmArgs* args, int32_t n, void* stream
   return launch_group(list, vecs, n, (hipStream_t)stream);
 }
 
+extern "C" int mesm_gemm_flush_side(void* stream) { return flush_side((hipStream_t)stream); }
+
 extern "C" int mesm_gemm_tape(int32_t record) {
   if (record) g_tape.launches.clear();
   g_tape.recording = record != 0;
@@ -2665,6 +2732,7 @@ extern "C" int mesm_gemm_tape_replay(void* stream, int32_t reps, double* total_m
       const TapeEntry& e = g_tape.launches[i];
       rc = e.group ? launch_group(e.args.data(), e.vecs.data(), e.n, s) : dispatch(e.args[0], e.vecs[0], s);
     }
+    if (rc == MESM_OK) rc = flush_side(s);
     hipEventRecord(e1, s);
     hipStreamSynchronize(s);
     float t = 0.0f;
@@ -2700,6 +2768,7 @@ extern "C" int mesm_gemm_tape_entry(void* stream, int32_t idx, int32_t reps, dou
   hipEventRecord(e0, s);
   for (int r = 0; r < reps && rc == MESM_OK; ++r)
     rc = e.group ? launch_group(e.args.data(), e.vecs.data(), e.n, s) : dispatch(e.args[0], e.vecs[0], s);
+  if (rc == MESM_OK) rc = flush_side(s);
   hipEventRecord(e1, s);
   hipStreamSynchronize(s);
   float t = 0.0f;

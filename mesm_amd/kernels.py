@@ -180,6 +180,9 @@ def gemm(A, B, C, *, trans_a=False, trans_b=False, A2=None, B2=None, bias=None, 
                                ws if dslope is not None else None, pre_out))
         return C
     check(lib().mesm_gemm_f32(ctypes.byref(g), stream_ptr()), "mesm_gemm_f32")
+    if dslope is not None:
+        _side_keep.append(ws)
+        gemm_flush_side()  # a direct call: nothing is known about a following launch
     return C
 
 
@@ -214,10 +217,29 @@ class _Phase:
                 arr = (struct * len(chunk))(*chunk)
                 check(getattr(L, group_fn)(arr, len(chunk), st), group_fn)
             self.q[kind] = []
+        # the workspaces of slope-gradient partials are read by a LATER launch (the reduction rides in the next GEMM
+        # launch of the stream, gemm.hip side_reduce): keep them until gemm_flush_side() at the end of the block
+        _side_keep.extend(self.keep)
         self.keep = []
 
 
 _phase = None
+_side_keep = []
+_side_defer = 0
+
+
+def defer_side(d):
+    """ops._drive brackets a block's phases with +1 / -1: inside, a phase end leaves pending slope-gradient reductions
+    to the next phase's GEMM launches; a phase used on its own (gemm_group in user code) completes them on exit."""
+    global _side_defer
+    _side_defer += d
+
+
+def gemm_flush_side():
+    """Slope-gradient reductions that no GEMM launch has picked up yet get their own launch; called at the end of every
+    backward block (ops._drive) and after a direct gemm(..., dslope=...) call."""
+    check(lib().mesm_gemm_flush_side(stream_ptr()), "mesm_gemm_flush_side")
+    _side_keep.clear()
 
 
 class phase:
@@ -242,6 +264,8 @@ class phase:
         ph, _phase = _phase, None
         if et is None:
             ph.flush()
+            if _side_defer == 0:
+                gemm_flush_side()
         return False
 
 

@@ -158,6 +158,14 @@ def _drive(thunks):
     gens = [None] * n
     outer = kn._phase is not None  # the caller's own phase (gemm_group) collects: only single-phase blocks fit in it
     live = []
+    kn.defer_side(+1)  # slope-gradient reductions ride in the block's later GEMM launches: flushed once, below
+    try:
+        return _drive_phases(thunks, results, gens, outer, live)
+    finally:
+        kn.defer_side(-1)
+
+
+def _drive_phases(thunks, results, gens, outer, live):
     with kn.phase():
         for i, t in enumerate(thunks):
             r = t()
@@ -182,6 +190,7 @@ def _drive(thunks):
                     results[i] = e.value
         live = nxt
     if not outer:
+        kn.gemm_flush_side()  # (slope-gradient reductions no later GEMM launch of the block has carried)
         flush_ready()
     return results
 

@@ -238,13 +238,16 @@ def test_allreduce_captured_inside_the_step_graph(mode):
     import sys
     import socket
     here = os.path.dirname(os.path.abspath(__file__))
-    # Up to three attempts: with collectives captured in a graph, torch's process-group WATCHDOG thread now and
+    # Up to five attempts (this is the LEGACY path, kept for comparison: the shipped one is the own communicator below,
+    # which needs none): with collectives captured in a graph, torch's process-group WATCHDOG thread now and
     # then queries an event that was recorded in the capturing stream (hipErrorCapturedEvent) and terminates the
     # child -- ~3 % of starts on this stack even with capture_error_mode="thread_local" and the flight recorder
     # off (46 + 30 runs counted).  That race lives in the runtime, not in the reducer under test; it is the
     # reason why bench.py's default for N > 1 keeps the collectives OUT of the graph.
+    # Counted again at the end of round 3: 4 of 20 starts (the capture of the lockstep step issues its launches over a
+    # longer window than the round-2 step did).
     lines, r = [], None
-    for _ in range(3):
+    for _ in range(5):
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
@@ -252,7 +255,9 @@ def test_allreduce_captured_inside_the_step_graph(mode):
         r = subprocess.run([sys.executable, os.path.join(here, "ddp_capture_worker.py"), mode], env=env,
                            capture_output=True, text=True, timeout=600)
         lines = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
-        if lines or "CapturedEvent" not in r.stderr and "stream is capturing" not in r.stderr:
+        # (the same race seen from the capturing thread: the watchdog's query invalidates the capture and the next
+        # launch of the step reports hipErrorStreamCaptureInvalidated = status -1901)
+        if lines or not any(t in r.stderr for t in ("CapturedEvent", "stream is capturing", "status -1901")):
             break
     assert lines, (r.returncode, r.stdout[-3000:], r.stderr[-3000:])
     res = json.loads(lines[-1][7:])
