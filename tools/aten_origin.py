@@ -39,9 +39,10 @@ fwd_site = {}
 for e in prof.events():
     sn = getattr(e, "sequence_nr", -1)
     if sn is not None and sn >= 0 and e.stack and "Backward" not in e.name:
-        fr = [f for f in e.stack if "mesm_amd" in f and "ops.py" not in f]
+        fr = [f for f in e.stack if "mesm_amd" in f and "ops.py" not in f and "kernels.py" not in f]
         if fr and sn not in fwd_site:
-            fwd_site[sn] = fr[0].split("mesm_amd/")[-1]
+            # innermost model / layers frame(s): the stack lists the innermost frame first
+            fwd_site[sn] = " < ".join(f.split("mesm_amd/")[-1].split(":")[0] for f in fr[:2])
 for e in prof.events():
     if not e.name.startswith("aten::"):
         continue
