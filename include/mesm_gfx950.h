@@ -150,6 +150,8 @@ int mesm_gemm_group(const MesmGemmArgs* args, int32_t n, void* stream);
  * mesm_gemm_flush_side reduces whatever is still pending with plain launches: call it before dslope is read or
  * dslope_ws is released without another GEMM launch in between. */
 int mesm_gemm_flush_side(void* stream);
+/* Forget the pending reductions without running them (error paths: their workspaces may already be released). */
+int mesm_gemm_drop_side(void);
 
 /*
  * Launch-duration measurement of mesm_gemm_f32 (the dominant kernel of the step) for

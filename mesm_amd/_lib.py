@@ -85,6 +85,7 @@ PROTOTYPES = {
     "mesm_gemm_f32": (ctypes.c_int, [ctypes.POINTER(GemmArgs), c_ptr]),
     "mesm_gemm_group": (ctypes.c_int, [ctypes.POINTER(GemmArgs), _i32, c_ptr]),
     "mesm_gemm_flush_side": (ctypes.c_int, [c_ptr]),
+    "mesm_gemm_drop_side": (ctypes.c_int, []),
     "mesm_gemm_tape": (ctypes.c_int, [_i32]),
     "mesm_gemm_tape_entry": (ctypes.c_int, [c_ptr, _i32, _i32, ctypes.POINTER(ctypes.c_double),
                                             ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),

@@ -2708,6 +2708,11 @@ extern "C" int mesm_gemm_group(const MesmGemmArgs* args, int32_t n, void* stream
 }
 
 extern "C" int mesm_gemm_flush_side(void* stream) { return flush_side((hipStream_t)stream); }
+// forget what is pending without reducing it (error paths: the workspaces may be gone)
+extern "C" int mesm_gemm_drop_side(void) {
+  g_side.clear();
+  return MESM_OK;
+}
 
 extern "C" int mesm_gemm_tape(int32_t record) {
   if (record) g_tape.launches.clear();

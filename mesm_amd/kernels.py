@@ -242,6 +242,12 @@ def gemm_flush_side():
     _side_keep.clear()
 
 
+def gemm_drop_side():
+    """error path: pending reductions are forgotten, not run (their workspaces are released with the failed block)"""
+    lib().mesm_gemm_drop_side()
+    _side_keep.clear()
+
+
 class phase:
     """Context manager: ONE LAUNCH PHASE.  The gemm / layernorm / attention calls made inside are INDEPENDENT of
     each other (none reads what another writes; atomic accumulation into the same gradient view is fine); they

@@ -161,6 +161,9 @@ def _drive(thunks):
     kn.defer_side(+1)  # slope-gradient reductions ride in the block's later GEMM launches: flushed once, below
     try:
         return _drive_phases(thunks, results, gens, outer, live)
+    except BaseException:
+        kn.gemm_drop_side()
+        raise
     finally:
         kn.defer_side(-1)
 
