@@ -897,3 +897,35 @@ def test_attention_group_matches_individual_launches():
             # forward: the same kernel body; backward: 4-wave workgroups for every key-tile count (2 alone) and
             # float atomics into dq when there are several key tiles
             assert rel_err(y[ok], x[ok]) < (1e-6 if k < 2 else 2e-5), (cfg, k)
+
+
+def test_slope_gradient_partials_ride_in_the_next_gemm_launch():
+    """gemm.hip side_reduce: the PReLU slope-gradient partials of a dz GEMM are reduced by the NEXT GEMM launch on the
+    stream (wave 0 of its first workgroup), not by a launch of their own -- pending after the producing phase, complete
+    after the carrier, for every kernel that can carry (k-split 32 x 32 / 64 x 64, 64 x 64 ring, grouped); what nobody
+    carried is completed by gemm_flush_side."""
+    from mesm_amd import kernels as kn
+    slope = torch.tensor([0.25], device=dev())
+    for (M, N, K), carrier in (((320, 256, 256), (64, 64, 64)), ((4800, 1024, 256), (4096, 256, 1024)),
+                               ((1024, 1024, 256), (4800, 256, 256)), ((320, 256, 256), None)):
+        dY, W, Z = gen((M, K), 1), gen((K, N), 2, 0.1), gen((M, N), 3)
+        ds = torch.zeros(1, device=dev())
+        ref = float(((dY.double() @ W.double()) * Z.double().clamp(max=0)).sum())
+        kn.defer_side(+1)
+        try:
+            with kn.phase():
+                kn.gemm(dY, W, torch.empty(M, N, device=dev()), aux=Z, e_actgrad=kn.ACT_PRELU, slope=slope, dslope=ds)
+            torch.cuda.synchronize()
+            assert ds.item() == 0.0  # produced, not yet reduced
+            if carrier is not None:
+                m, n, k = carrier
+                with kn.phase():
+                    kn.gemm(gen((m, k), 4), gen((k, n), 5), torch.empty(m, n, device=dev()))
+                    kn.gemm(gen((64, 32), 6), gen((32, 64), 7), torch.empty(64, 64, device=dev()))
+            else:
+                kn.gemm_flush_side()
+            torch.cuda.synchronize()
+            assert abs(ds.item() - ref) < 2e-4 * max(abs(ref), 1.0), (M, N, K, carrier, ds.item(), ref)
+        finally:
+            kn.defer_side(-1)
+            kn.gemm_flush_side()
