@@ -2671,9 +2671,24 @@ int launch_group(const MesmGemmArgs* list, const int* vecs, int n, hipStream_t s
     }
     g.n = 0;
   };
+  // A kernel costs ~9 us of ramp whatever it computes (profiles/r3c/tile_compare.txt), more than a specialised tile
+  // saves on a mid-size product (the tall 96 x 32 tile on 2400 x 256 x 512: 13.4 -> 12.7 us alone): in a call that has a
+  // grouped launch anyway, the products below MID_GF that the 32 x 32 kernel can take join it instead of getting a
+  // kernel of their own.  MESM_GEMM_GROUP_MID=0: the standalone rule only (A/B).
+  static const bool group_mid = []() { const char* e = getenv("MESM_GEMM_GROUP_MID"); return !(e && atoi(e) == 0); }();
+  constexpr double MID_GF = 1.5e9;
+  int n_plain = 0;
+  for (int i = 0; i < n; ++i) n_plain += groupable(list[i]) ? 1 : 0;
+  auto joins = [&](const MesmGemmArgs& a) {
+    if (groupable(a)) return true;
+    if (!group_mid || n_plain == 0 || bf16x_mode() != 0) return false;
+    const char* env = getenv("MESM_GEMM_TILE");
+    if (env && atoi(env) != 0) return false;
+    return wstage_ok(a) && 2.0 * a.M * a.N * a.K < MID_GF;
+  };
   for (int i = 0; i < n && rc == MESM_OK; ++i) {
     const MesmGemmArgs& a = list[i];
-    if (groupable(a)) {
+    if (joins(a)) {
       const int wgs = ((a.M + 31) / 32) * ((a.N + 31) / 32) * (a.split_k > 1 ? a.split_k : 1);
       g.p[g.n] = a;
       g.start[g.n + 1] = g.start[g.n] + wgs;

@@ -33,8 +33,14 @@ print("%d launches, %.1f us back to back one at a time, %.1f GFLOP -> %.1f TF; a
       (n, tot_us, tot_fl / 1e9, tot_fl / tot_us / 1e6, rate, tot_fl / rate / 1e6))
 def desc(p):
     M, N, K, f = p
-    return "%dx%dx%d%s%s%s" % (M, N, K, "T" if f & 256 else "N", "T" if f & 512 else "N", ("/s%d" % (f & 255)) if (f & 255) > 1 else "")
+    # '*': not taken by the grouped 32 x 32 launch of its call -- a kernel of its own
+    return "%dx%dx%d%s%s%s%s" % (M, N, K, "T" if f & 256 else "N", "T" if f & 512 else "N", ("/s%d" % (f & 255)) if (f & 255) > 1 else "",
+                               "" if f & 1024 else "*")
 rows.sort(key=lambda r: -(r[1] - r[2] / rate / 1e6))
 for i, us, fl, probs in rows:
     lost = us - fl / rate / 1e6
     print("#%3d %7.2f us %7.3f GF %5.1f TF lost %6.2f us  %s" % (i, us, fl / 1e9, fl / us / 1e6, lost, " ".join(desc(p) for p in probs)))
+alone = [(2.0 * M * N * K / 1e9, desc((M, N, K, f))) for _, _, _, probs in rows for (M, N, K, f) in probs if not f & 1024]
+alone.sort()
+print("problems launched as kernels of their own: %d; below 1.5 GF: %s" % (len(alone), " ".join("%s(%.2f)" % (d, g) for g, d in alone if g < 1.5)))
+
