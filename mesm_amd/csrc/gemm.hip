@@ -1313,7 +1313,10 @@ __global__ WS_BOUNDS void gemm_wstage_kernel(const MesmGemmArgs p, const SideRed
 // dispatch + ~3 us of exposed latency chain whatever its size, and the backward of every block as well
 // as the decoder are made of independent 5 us GEMMs).  The workgroups of all problems are laid out
 // back to back on blockIdx.x; layouts / transforms are selected per problem at run time (wave-uniform).
-constexpr int GROUP_MAX = 8;
+#ifndef MESM_GROUP_MAX
+#define MESM_GROUP_MAX 8  // (12: the larger kernel-argument segment costs every grouped launch more than the 4 merged launches save, 4.923 vs 4.896 ms)
+#endif
+constexpr int GROUP_MAX = MESM_GROUP_MAX;
 struct GroupArgs {
   MesmGemmArgs p[GROUP_MAX];
   int start[GROUP_MAX + 1];  // first workgroup of every problem
