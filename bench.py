@@ -6,8 +6,9 @@
         --master-port P bench.py --gpus N --steps K --warmup W
 
 A step = model(**batch) -> criterion(outputs, batch) -> zero_grad -> total.backward()
-[-> gradient all-reduce of the flat buffer for N > 1: one blocking all-reduce on the compute stream after the
-this library's own RCCL communicator recorded inside the step graph, form chosen by a start-up probe; see MESM_DDP_MODE], in
+[-> gradient all-reduce of the flat buffer for N > 1: on this library's own RCCL communicator, recorded inside the
+step graph, form (one all-reduce in line / six buckets overlapped with backward) chosen by a start-up probe; see
+MESM_DDP_MODE], in
 TRAIN mode (all dropouts active), on the QVHighlights C+SF workload "C3a" of SURVEY.md 8d (32 pairs per
 GPU, Lv=75, Lw=32, Dv=2818, Dt=512, C=5003, fp32).  Inputs are resident in HBM before the timed
 region; the host-side draws of the reference (negative query index, MLM word choice) are re-drawn
@@ -24,9 +25,15 @@ Prints ONE JSON line on rank 0 (contract in the task statement) including
                  launch from the rocprofv3 PMC passes committed under profiles/ (null when that profile
                  was taken with another launch count, i.e. is stale); `families` = in-situ ms per kernel
                  family (GEMM / attention / LayerNorm / losses / element-wise / assembly) by ablation;
+                 `attention_hbm_frac` / `layernorm_hbm_frac` = SURVEY 8d's byte split / family ms / 8 TB/s;
+                 `experimental` = the split-bf16 GEMM modes (MESM_GEMM_BF16X=6|3: ms/step, GEMM TF, the parity
+                 suite's verdict) -- never the headline, whose dtype stays exact f32;
+  config       — besides the workload: `ddp`, and (not part of the metric) the eager step, the optimizer tail, the
+                 PCIe-inclusive rate, and `loader_like_epoch_not_in_metric`: a stream of loader-shaped batches
+                 from host memory through StepCache (pair axis padded, real count on the device);
   cpu_baseline — the CPU oracle (a port of the reference step, oracle/mesm_oracle.py) timed on
-                 this box's host cores on the same workload (rank 0, N = 1 only): 2 warm-up steps,
-                 median of 5.
+                 this box's host cores on the same workload, train mode (rank 0, N = 1 only): 2 warm-up
+                 steps, median of 5.
 """
 import argparse
 import json
