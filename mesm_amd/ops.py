@@ -221,17 +221,38 @@ class _Sub:
         self.nondiff.extend(ts)
 
 
+# tools/fanin.py: {(data_ptr, shape) of a block INPUT: [blocks that returned a gradient for it]} -- which tensors get
+# their gradient from several nodes (the engine then adds them with element-wise launches).  None = off.
+FANIN_DEBUG = None
+
+
+def _dbg_inputs(args):
+    return [(a.data_ptr(), tuple(a.shape)) if torch.is_tensor(a) and a.is_floating_point() and a.requires_grad else None
+            for a in args]
+
+
+def _dbg_record(keys, grads, name):
+    for k, g in zip(keys, grads):
+        if k is not None and g is not None:
+            FANIN_DEBUG.setdefault(k, []).append(name)
+
+
 def make_fn(block):
     """A block as a stand-alone autograd.Function."""
 
     class Fn(Function):
         @staticmethod
         def forward(ctx, *args):
+            if FANIN_DEBUG is not None:
+                ctx._dbg = _dbg_inputs(args)
             return _drive([lambda: block.fwd(ctx, *args)])[0]
 
         @staticmethod
         def backward(ctx, *gs):
-            return _drive([lambda: block.bwd(ctx, *gs)])[0]
+            out = _drive([lambda: block.bwd(ctx, *gs)])[0]
+            if FANIN_DEBUG is not None:
+                _dbg_record(ctx._dbg, out, block.__name__)
+            return out
 
     Fn.__name__ = Fn.__qualname__ = block.__name__.replace("Block", "Fn")
     return Fn
@@ -244,6 +265,8 @@ class ParFn(Function):
     @staticmethod
     def forward(ctx, spec, *flat):
         ctx.set_materialize_grads(False)
+        if FANIN_DEBUG is not None:
+            ctx._dbg = _dbg_inputs(flat)
         subs, runs, pos = [], [], 0
         for block, n in spec:
             sub = _Sub(ctx.needs_input_grad[1 + pos:1 + pos + n])
@@ -289,6 +312,8 @@ class ParFn(Function):
         out = [None]
         for r, (block, n) in zip(res, ctx.spec):
             assert len(r) == n, (block.__name__, len(r), n)
+            if FANIN_DEBUG is not None:
+                _dbg_record(ctx._dbg[len(out) - 1:len(out) - 1 + n], r, "par:" + block.__name__)
             out.extend(r)
         return tuple(out)
 
@@ -1218,6 +1243,9 @@ def gather_rows(x2d, idx):
 
 
 # ----------------------------------------------------------------------------- assembly blocks (csrc/glue.hip)
+_STACK_GRAD_ALL = os.environ.get("MESM_STACK_GRAD_ALL") == "1"  # A/B: the round-2 behaviour (every float output differentiable)
+
+
 class StackRowsFn(Function):
     """outs[t] = [x_t ; x_t[idx]] or [x_t ; x_t]: the negative pass stacked behind the positive one
     (model.py:260-299), every tensor of the stage in one launch; backward = one gather-sum per float tensor."""
@@ -1227,9 +1255,12 @@ class StackRowsFn(Function):
         ctx.set_materialize_grads(False)
         outs = kn.stack_rows(list(xs), gather, idx)
         ctx.idx, ctx.gather, ctx.N = idx, gather, xs[0].shape[0]
-        for o, x in zip(outs, xs):
-            if not x.is_floating_point():
-                ctx.mark_non_differentiable(o)
+        # a stacked copy of a tensor that carries no gradient (position embeddings, masks) carries none either: left
+        # differentiable, its consumers return gradients for it that the engine sums with element-wise launches
+        # (three x 15 MB for the stacked video positions) before this function's backward drops them.  ONE call:
+        # mark_non_differentiable replaces what an earlier call marked.
+        ctx.mark_non_differentiable(*[o for i, (o, x) in enumerate(zip(outs, xs))
+                                      if not x.is_floating_point() or not (ctx.needs_input_grad[2 + i] or _STACK_GRAD_ALL)])
         return tuple(outs)
 
     @staticmethod
