@@ -307,7 +307,7 @@ class DecoderLayer(nn.Module):
              "sa_p": ("sa_qpos_proj", "sa_kpos_proj"),
              "ca_kv": ("ca_kcontent_proj", "ca_v_proj")}
 
-    def steps(self, tgt, memory, mem_pad, pos, query_pos, qsine, is_first, pack):
+    def steps(self, tgt, memory, mem_pad, pos, query_pos, qsine, is_first, pack, mem_share=None):
         """The layer as a chain (ops.lockstep).  pack(key) -> (weight, bias) views of a parameter pack of THIS layer
         (MESM.pack).  The query-side position projections of the cross attention do not depend on the self-attention
         block: they fork beside it."""
@@ -325,7 +325,8 @@ class DecoderLayer(nn.Module):
         wkv, bkv = pack("ca_kv")
         a = yield ops.dec_cross_attn_call(tgt, qs, qpp, memory, pos, mem_pad, self.ca_qcontent_proj.weight,
                                           self.ca_qcontent_proj.bias, wkv, bkv, self.ca_kpos_proj.weight,
-                                          self.ca_kpos_proj.bias, is_first, h, drop=drop_state.next(self.p))
+                                          self.ca_kpos_proj.bias, is_first, h, drop=drop_state.next(self.p),
+                                          mem_share=mem_share)
         co = self.cross_attn.out_proj
         x = yield L(a, co.weight, co.bias, residual=tgt, out_drop=drop_state.next(self.p))
         tgt = yield ops.layer_norm_call(x, self.norm2.weight, self.norm2.bias)
@@ -377,11 +378,13 @@ class Decoder(nn.Module):
         qsine = ops.query_sine(ref, d)
         (query_pos, anchor), _ = yield from mlp_heads_steps([(self.ref_point_head, qsine), (self.ref_anchor_head, out)])
         scale = None
+        # every layer reads the same memory: their d memory shares are summed by the dX GEMMs' epilogues
+        mem_share = ops.GradShare(nl) if (nl > 1 and torch.is_grad_enabled() and memory.requires_grad) else None
         for li, layer in enumerate(self.layers):
             # qsine * query_scale(out) * (sigmoid(ref_anchor_head(out)) / ref_width): one kernel
             qsine = ops.qsine_scale(qsine, scale, anchor, ref)
             out = yield from layer.steps(out, memory, mem_pad, pos, query_pos, qsine, li == 0,
-                                         lambda key, li=li: pack("dec%d.%s" % (li, key)))
+                                         lambda key, li=li: pack("dec%d.%s" % (li, key)), mem_share=mem_share)
             heads = [(self.bbox_embed, out)]
             if li + 1 < nl:
                 heads += [(self.ref_anchor_head, out), (self.query_scale, out)]

@@ -855,8 +855,9 @@ class DecCrossAttnBlock:
     N_OUT = 1
 
     @staticmethod
-    def fwd(ctx, tgt, qs, qpp, memory, pos, mem_pad, wqc, bqc, wkv, bkv, wkp, bkp, first, H, drop):
+    def fwd(ctx, tgt, qs, qpp, memory, pos, mem_pad, wqc, bqc, wkv, bkv, wkp, bkp, first, H, drop, mem_share=None):
         ctx.set_materialize_grads(False)
+        ctx.mem_share = mem_share  # GradShare of the decoder's layers for d memory (every layer reads the same memory)
         tgt, qs, memory, pos = _c(tgt), _c(qs), _c(memory), _c(pos)
         n, nq, d = tgt.shape
         lm = memory.shape[1]
@@ -909,15 +910,26 @@ class DecCrossAttnBlock:
             dtgt = torch.empty_like(tgt)
             kn.gemm(_2d(dqc), wqc, _2d(dtgt))
         if ctx.needs_input_grad[3]:
-            dmem = torch.empty_like(memory)
-            kn.gemm(g3[:, :2 * d], wkv, _2d(dmem))
+            share = ctx.mem_share
+            if share is not None:
+                if share.seen == 0:
+                    share.buf = torch.empty_like(memory)
+                kn.gemm(g3[:, :2 * d], wkv, _2d(share.buf), accumulate=0 if share.seen == 0 else 1)
+                share.seen += 1
+                if share.seen == share.n:  # every layer has added its share
+                    dmem, share.buf, share.seen = share.buf, None, 0
+            else:
+                dmem = torch.empty_like(memory)
+                kn.gemm(g3[:, :2 * d], wkv, _2d(dmem))
         return (dtgt, dqs if ctx.needs_input_grad[1] else None,
                 dqc if (first and has_qpp and ctx.needs_input_grad[2]) else None, dmem,
-                None, None, None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None, None, None)
 
 
-def dec_cross_attn_call(tgt, qs, qpp, memory, pos, mem_pad, wqc, bqc, wkv, bkv, wkp, bkp, first, H, drop=NO_DROP):
-    return Call(DecCrossAttnBlock, (tgt, qs, qpp, memory, pos, mem_pad, wqc, bqc, wkv, bkv, wkp, bkp, first, H, drop))
+def dec_cross_attn_call(tgt, qs, qpp, memory, pos, mem_pad, wqc, bqc, wkv, bkv, wkp, bkp, first, H, drop=NO_DROP,
+                        mem_share=None):
+    return Call(DecCrossAttnBlock, (tgt, qs, qpp, memory, pos, mem_pad, wqc, bqc, wkv, bkv, wkp, bkp, first, H, drop,
+                                    mem_share))
 
 
 def dec_cross_attn(tgt, qs, qpp, memory, pos, mem_pad, wqc, bqc, wkv, bkv, wkp, bkp, first, H, drop=NO_DROP):
