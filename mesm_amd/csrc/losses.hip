@@ -16,7 +16,10 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh) {
 }
 
 // ---------------------------------------------------------------- label-smoothed NLL
-// one workgroup per row (criterion.py:291-306)
+// one workgroup per row (criterion.py:291-306).  NPT > 0: the row (C <= 256 NPT classes) is read ONCE, NPT independent
+// loads per thread in flight together, and both passes run on registers (the two-pass form below walked the row twice
+// with one load in flight per thread: 19.5 -> 9.3 us at 1024 x 5003); NPT = 0: any C, two passes over the L2-resident row.
+template <int NPT>
 __global__ __launch_bounds__(256) void nll_fwd_kernel(
     const float* __restrict__ logit, const int64_t* __restrict__ label,
     const uint8_t* __restrict__ mask, float* __restrict__ row_loss,
@@ -30,10 +33,27 @@ __global__ __launch_bounds__(256) void nll_fwd_kernel(
   // pass 1: max + first argmax + plain sum
   float m = -INFINITY, s = 0.0f;
   int am = 0x7fffffff;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    float v = x[c];
-    s += v;
-    if (v > m) { m = v; am = c; }
+  float v[NPT > 0 ? NPT : 1];
+  if (NPT > 0) {
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+      const int c = threadIdx.x + k * 256;
+      v[k] = c < C ? x[c] : -INFINITY;
+    }
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+      const int c = threadIdx.x + k * 256;
+      if (c < C) {
+        s += v[k];
+        if (v[k] > m) { m = v[k]; am = c; }
+      }
+    }
+  } else {
+    for (int c = threadIdx.x; c < C; c += 256) {
+      float t = x[c];
+      s += t;
+      if (t > m) { m = t; am = c; }
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -50,9 +70,14 @@ __global__ __launch_bounds__(256) void nll_fwd_kernel(
     if (shm[w] > M || (shm[w] == M && shi[w] < AM)) { M = shm[w]; AM = shi[w]; }
   __syncthreads();
   const float total = block_sum_256(s, sh);
-  // pass 2: sum exp (row is L2-resident)
+  // pass 2: sum exp
   float e = 0.0f;
-  for (int c = threadIdx.x; c < C; c += 256) e += __expf(x[c] - M);
+  if (NPT > 0) {
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) e += __expf(v[k] - M);  // (exp(-inf) = 0 beyond C)
+  } else {
+    for (int c = threadIdx.x; c < C; c += 256) e += __expf(x[c] - M);
+  }
   const float E = block_sum_256(e, sh);
   if (threadIdx.x == 0) {
     const float lse = M + __logf(E);
@@ -286,8 +311,11 @@ extern "C" int mesm_nll_smooth_fwd(const float* logit, const int64_t* label, con
                                    float* row_loss, float* row_lse, uint8_t* correct, int64_t R,
                                    int32_t C, float eps, void* stream) {
   if (!logit || !label || !row_loss || !row_lse || R <= 0 || C <= 0) return MESM_EINVAL;
-  hipLaunchKernelGGL(nll_fwd_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, logit,
-                     label, mask, row_loss, row_lse, correct, C, eps);
+  const dim3 grid((unsigned)R), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (C <= 256 * 8) hipLaunchKernelGGL(nll_fwd_kernel<8>, grid, block, 0, st, logit, label, mask, row_loss, row_lse, correct, C, eps);
+  else if (C <= 256 * 20) hipLaunchKernelGGL(nll_fwd_kernel<20>, grid, block, 0, st, logit, label, mask, row_loss, row_lse, correct, C, eps);
+  else hipLaunchKernelGGL(nll_fwd_kernel<0>, grid, block, 0, st, logit, label, mask, row_loss, row_lse, correct, C, eps);
   return mesm_launch_status();
 }
 
