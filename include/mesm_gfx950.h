@@ -499,6 +499,12 @@ int mesm_set_loss_fwd(const float* logits, const float* spans, const float* tgt_
                       const float* tgt_xx, const int32_t* tgt_off, int32_t N, int32_t Q,
                       int32_t Tmax, float w_span, float w_giou, float w_class, float eos_coef,
                       int32_t* match_q, float* out4, void* stream);
+/* The same for n_layers <= 8 decoder layers (main + auxiliary outputs, criterion.py:338-357) in ONE launch, a workgroup per
+ * layer: arrays of n_layers device pointers (host arrays); targets, weights and n_valid (may be NULL) shared. */
+int mesm_set_loss_fwd_layers(const float* const* logits, const float* const* spans, int32_t n_layers,
+                             const float* tgt_cxw, const float* tgt_xx, const int32_t* tgt_off, int32_t N, int32_t Q,
+                             int32_t Tmax, float w_span, float w_giou, float w_class, float eos_coef,
+                             int32_t* const* match_q, float* const* out4, const int32_t* n_valid, void* stream);
 int mesm_set_loss_bwd(const float* logits, const float* spans, const float* tgt_cxw,
                       const float* tgt_xx, const int32_t* tgt_off, const int32_t* match_q,
                       int32_t N, int32_t Q, float eos_coef, const float* g3, float* dlogits,

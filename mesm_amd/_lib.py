@@ -126,6 +126,8 @@ PROTOTYPES = {
     "mesm_clip_grad": (ctypes.c_int, [c_ptr, _i64, c_ptr, _i32, _f32, c_ptr, c_ptr]),
     "mesm_adamw_step": (ctypes.c_int, [c_ptr] * 5 + [_i64, c_ptr, _i32, _f32, c_ptr, _f32, _f32, _f32, _f32,
                                        c_ptr, c_ptr, c_ptr]),
+    "mesm_set_loss_fwd_layers": (ctypes.c_int, [c_ptr, c_ptr, _i32, c_ptr, c_ptr, c_ptr, _i32, _i32, _i32, _f32, _f32, _f32,
+                                                _f32, c_ptr, c_ptr, c_ptr, c_ptr]),
     "mesm_set_loss_fwd": (ctypes.c_int, [c_ptr] * 5 + [_i32, _i32, _i32, _f32, _f32, _f32, _f32, c_ptr, c_ptr, c_ptr]),
     "mesm_set_loss_bwd": (ctypes.c_int, [c_ptr] * 6 + [_i32, _i32, _f32, c_ptr, c_ptr, c_ptr, c_ptr]),
     "mesm_rec_ss_fwd": (ctypes.c_int, [c_ptr, c_ptr, _i32, c_ptr, c_ptr, _i32, c_ptr, _i32, _i32, _f32] + [c_ptr] * 6),

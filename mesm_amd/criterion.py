@@ -144,12 +144,19 @@ class CriterionFn(Function):
         lv = torch.empty(len(spec.names), device=dev, dtype=torch.float32)
         saved = {}
         matches = []
+        lay = []
         for li, (il, isp, slot, k) in enumerate(spec.set_layers):
             # k: this layer's index in the stacked (layers, N, Q, 2) decoder outputs (None: a tensor of its own)
             logits, spans = (t[il].contiguous(), t[isp].contiguous()) if k is None else (t[il][k], t[isp][k])
-            mq = kn.set_loss_fwd(logits, spans, plan.tgt_cxw, plan.tgt_xx, plan.tgt_off, plan.Tmax,
-                                 m.cost_span, m.cost_giou, m.cost_class, c.eos_coef, lv[slot:slot + 4],
-                                 n_valid=spec.n_valid)
+            lay.append((logits, spans, lv[slot:slot + 4]))
+        if 1 < len(lay) <= 8:
+            # the layers' matchings are independent one-workgroup latency chains: one launch, a workgroup per layer
+            mqs = kn.set_loss_fwd_layers(lay, plan.tgt_cxw, plan.tgt_xx, plan.tgt_off, plan.Tmax, m.cost_span, m.cost_giou,
+                                         m.cost_class, c.eos_coef, n_valid=spec.n_valid)
+        else:
+            mqs = [kn.set_loss_fwd(lg, sp, plan.tgt_cxw, plan.tgt_xx, plan.tgt_off, plan.Tmax, m.cost_span, m.cost_giou,
+                                   m.cost_class, c.eos_coef, o4, n_valid=spec.n_valid) for lg, sp, o4 in lay]
+        for li, ((logits, spans, _), mq) in enumerate(zip(lay, mqs)):
             matches.append(mq)
             saved["set%d" % li] = (logits, spans, mq)
         if spec.sal is not None:

@@ -177,12 +177,12 @@ __global__ __launch_bounds__(64) void match_kernel(
 // One thread per pair (chunks of P pairs); one workgroup, so the loss sums are reduced without atomics
 // (deterministic).  out[0..3] = loss_span, loss_giou, loss_label, class_error.  The span terms are means over the
 // MATCHED (query, target) pairs: sum_b min(T_b, Q) of them (criterion.py:104-107, :133).
-__global__ void set_loss_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ spans,
-                                    const float* __restrict__ tgt_cxw, const float* __restrict__ tgt_xx,
-                                    const int32_t* __restrict__ tgt_off, int N, int Q, int Tmax,
-                                    float w_span, float w_giou, float w_class, float eos_coef, int P,
-                                    int32_t* __restrict__ match_q, float* __restrict__ out,
-                                    const int32_t* __restrict__ n_valid) {
+__device__ __forceinline__ void set_loss_fwd_body(const float* __restrict__ logits, const float* __restrict__ spans,
+                                                  const float* __restrict__ tgt_cxw, const float* __restrict__ tgt_xx,
+                                                  const int32_t* __restrict__ tgt_off, int N, int Q, int Tmax,
+                                                  float w_span, float w_giou, float w_class, float eos_coef, int P,
+                                                  int32_t* __restrict__ match_q, float* __restrict__ out,
+                                                  const int32_t* __restrict__ n_valid) {
   // n_valid (device scalar, NULL = N): the pairs [n_valid, N) are padding of a captured capacity (graphed.py):
   // they take no part in the matching, the sums or the denominators
   if (n_valid) N = *n_valid;
@@ -242,6 +242,38 @@ __global__ void set_loss_fwd_kernel(const float* __restrict__ logits, const floa
     out[2] = r[2] / (float)(N * Q);
     out[3] = 100.0f - r[3] * (100.0f / nm);
   }
+}
+
+__global__ void set_loss_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ spans,
+                                    const float* __restrict__ tgt_cxw, const float* __restrict__ tgt_xx,
+                                    const int32_t* __restrict__ tgt_off, int N, int Q, int Tmax,
+                                    float w_span, float w_giou, float w_class, float eos_coef, int P,
+                                    int32_t* __restrict__ match_q, float* __restrict__ out,
+                                    const int32_t* __restrict__ n_valid) {
+  set_loss_fwd_body(logits, spans, tgt_cxw, tgt_xx, tgt_off, N, Q, Tmax, w_span, w_giou, w_class, eos_coef, P, match_q, out,
+                    n_valid);
+}
+
+// The decoder layers' set losses (main + auxiliary, criterion.py:338-357) are independent one-workgroup latency chains
+// (~28 us each: the assignment is sequential fp64 arithmetic): one launch, a workgroup per layer.
+constexpr int SET_LAYERS_MAX = 8;
+struct SetLossLayers {
+  const float* logits[SET_LAYERS_MAX];
+  const float* spans[SET_LAYERS_MAX];
+  int32_t* match_q[SET_LAYERS_MAX];
+  float* out[SET_LAYERS_MAX];
+};
+__global__ void set_loss_fwd_layers_kernel(const SetLossLayers L, const float* __restrict__ tgt_cxw,
+                                           const float* __restrict__ tgt_xx, const int32_t* __restrict__ tgt_off, int N,
+                                           int Q, int Tmax, float w_span, float w_giou, float w_class, float eos_coef, int P,
+                                           const int32_t* __restrict__ n_valid) {
+  const float *lg = L.logits[0], *sp = L.spans[0];
+  int32_t* mq = L.match_q[0];
+  float* out = L.out[0];
+#pragma unroll
+  for (int k = 1; k < SET_LAYERS_MAX; ++k)
+    if ((int)blockIdx.x == k) { lg = L.logits[k]; sp = L.spans[k]; mq = L.match_q[k]; out = L.out[k]; }
+  set_loss_fwd_body(lg, sp, tgt_cxw, tgt_xx, tgt_off, N, Q, Tmax, w_span, w_giou, w_class, eos_coef, P, mq, out, n_valid);
 }
 
 // one thread per (pair, query): g = upstream gradient of [loss_span, loss_giou, loss_label, *]
@@ -721,6 +753,26 @@ extern "C" int mesm_match(const float* logits, const float* spans, const float* 
   hipLaunchKernelGGL(match_kernel, dim3((N + P - 1) / P), dim3(P), sap_bytes_per_thread(Tmax, Q) * P,
                      (hipStream_t)stream, logits, spans, tgt_cxw, tgt_xx, tgt_off, N, Q, Tmax, w_span, w_giou,
                      w_class, cost, match_q);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_set_loss_fwd_layers(const float* const* logits, const float* const* spans, int32_t n_layers,
+                                        const float* tgt_cxw, const float* tgt_xx, const int32_t* tgt_off, int32_t N,
+                                        int32_t Q, int32_t Tmax, float w_span, float w_giou, float w_class, float eos_coef,
+                                        int32_t* const* match_q, float* const* out4, const int32_t* n_valid, void* stream) {
+  if (!logits || !spans || !tgt_cxw || !tgt_xx || !tgt_off || !match_q || !out4) return MESM_EINVAL;
+  if (n_layers <= 0 || n_layers > SET_LAYERS_MAX) return MESM_EINVAL;
+  if (N <= 0 || Q <= 0 || Q > 64 || Tmax <= 0 || Tmax > 64) return MESM_EINVAL;
+  SetLossLayers L = {};
+  for (int k = 0; k < n_layers; ++k) {
+    if (!logits[k] || !spans[k] || !match_q[k] || !out4[k]) return MESM_EINVAL;
+    L.logits[k] = logits[k]; L.spans[k] = spans[k]; L.match_q[k] = match_q[k]; L.out[k] = out4[k];
+  }
+  const size_t per = sap_bytes_per_thread(Tmax, Q);
+  const int P = sap_pairs_per_pass(Tmax, Q, N);
+  if (P == 0) return MESM_EINVAL;
+  hipLaunchKernelGGL(set_loss_fwd_layers_kernel, dim3(n_layers), dim3(64), per * P, (hipStream_t)stream, L, tgt_cxw, tgt_xx,
+                     tgt_off, N, Q, Tmax, w_span, w_giou, w_class, eos_coef, P, n_valid);
   return mesm_launch_status();
 }
 

@@ -705,6 +705,25 @@ def set_loss_fwd(logits, spans, tgt_cxw, tgt_xx, tgt_off, Tmax, w_span, w_giou, 
     return match_q
 
 
+def set_loss_fwd_layers(layers, tgt_cxw, tgt_xx, tgt_off, Tmax, w_span, w_giou, w_class, eos_coef, n_valid=None):
+    """layers: [(logits, spans, out4), ...] of the decoder layers (main + auxiliary): one launch, a workgroup per
+    layer; -> [match_q, ...]."""
+    n = len(layers)
+    N, Q, _ = layers[0][0].shape
+    _check_match_limits(Q, Tmax)
+    mqs = [torch.empty(tgt_cxw.shape[0], device=layers[0][0].device, dtype=torch.int32) for _ in range(n)]
+    for lg, sp, o4 in layers:
+        require_gpu(lg, sp, o4)
+        assert lg.is_contiguous() and sp.is_contiguous() and lg.shape == (N, Q, 2)
+    P = ctypes.c_void_p * n
+    check(lib().mesm_set_loss_fwd_layers(P(*[t[0].data_ptr() for t in layers]), P(*[t[1].data_ptr() for t in layers]), n,
+                                         ptr(tgt_cxw), ptr(tgt_xx), ptr(tgt_off), N, Q, int(Tmax), float(w_span),
+                                         float(w_giou), float(w_class), float(eos_coef),
+                                         P(*[m.data_ptr() for m in mqs]), P(*[t[2].data_ptr() for t in layers]),
+                                         ptr(n_valid), stream_ptr()), "mesm_set_loss_fwd_layers")
+    return mqs
+
+
 def set_loss_bwd(logits, spans, tgt_cxw, tgt_xx, tgt_off, match_q, eos_coef, g3, out=None, n_valid=None):
     """out: (dlogits, dspans) to write into (e.g. one layer's slice of the stacked decoder outputs' gradient)"""
     N, Q, _ = logits.shape
