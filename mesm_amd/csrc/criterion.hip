@@ -484,14 +484,31 @@ __global__ __launch_bounds__(256) void ss_bwd_kernel(
     const float* __restrict__ sim, const float* __restrict__ stats, const uint8_t* __restrict__ cmask,
     const uint8_t* __restrict__ wmask, int N, int D, int Lv, int Le, float inv_tau,
     const float* __restrict__ g, float* __restrict__ dpv, float* __restrict__ dew, const int32_t* __restrict__ n_valid) {
-  extern __shared__ float dsim[];  // N*N
+  // dynamic LDS: dsim (ld rows of ld + 1 floats: lane = row accesses stay conflict-free), staged with sim and turned into
+  // d sim in place | the positive mask (bytes) | the pair's clip / word masks.  Everything a thread then loops over comes
+  // from LDS: the loops below used to be chains of dependent global loads (one row of sim per thread, one mask byte per
+  // output row): 38 us for 2.4 MB of output.
+  extern __shared__ float dsim[];
   __shared__ float sh[8];
   const int n = blockIdx.x;
-  const int ld = N;  // row stride of sim / pos / dsim: the allocated extent
+  const int ld = N;  // row stride of sim / pos: the allocated extent
+  const int lp = ld + 1;
+  float* cmL = dsim + ld * lp;  // Lv
+  float* wmL = cmL + Lv;        // Le
+  uint8_t* posL = reinterpret_cast<uint8_t*>(wmL + Le);  // ld * ld
+  for (int idx = threadIdx.x; idx < ld * ld; idx += 256) {
+    const int r = idx / ld, k = idx - r * ld;
+    dsim[r * lp + k] = sim[idx];
+    posL[idx] = pos[idx];
+  }
+  for (int l = threadIdx.x; l < Lv; l += 256) cmL[l] = cmask[(int64_t)n * Lv + l] ? 1.0f : 0.0f;
+  for (int l = threadIdx.x; l < Le; l += 256) wmL[l] = wmask[(int64_t)n * Le + l] ? 1.0f : 0.0f;
+  __syncthreads();
   if (n_valid) N = *n_valid;  // padding pairs: no row, no column; their own gradients come out zero below
   const float gs = g[0] / (float)N;
   for (int r = threadIdx.x; r < N; r += 256) {
-    const float* row = sim + (int64_t)r * ld;
+    float* row = dsim + r * lp;
+    const uint8_t* prow = posL + r * ld;
     float m = -INFINITY;
     int am = 0;
     for (int k = 0; k < N; ++k)
@@ -499,14 +516,14 @@ __global__ __launch_bounds__(256) void ss_bwd_kernel(
     float S = 0.0f, cnt = 0.0f;
     for (int k = 0; k < N; ++k) {
       S += expf(row[k] - m);
-      cnt += pos[(int64_t)r * ld + k] ? 1.0f : 0.0f;
+      cnt += prow[k] ? 1.0f : 0.0f;
     }
     const float a = gs / (cnt + 1e-6f);
     const float iS = 1.0f / (S + 1e-6f);
     for (int k = 0; k < N; ++k) {
-      float d = -a * (pos[(int64_t)r * ld + k] ? 1.0f : 0.0f) + a * cnt * expf(row[k] - m) * iS;
+      float d = -a * (prow[k] ? 1.0f : 0.0f) + a * cnt * expf(row[k] - m) * iS;
       if (k == am) d += a * cnt * 1e-6f * iS;
-      dsim[r * ld + k] = d * inv_tau;
+      row[k] = d * inv_tau;
     }
   }
   __syncthreads();
@@ -514,7 +531,7 @@ __global__ __launch_bounds__(256) void ss_bwd_kernel(
   const int kmax = n < N ? N : 0;  // a padding pair takes part in nothing
 #pragma unroll 8
   for (int k = 0; k < kmax; ++k) {
-    const float a = dsim[n * ld + k], b = dsim[k * ld + n];
+    const float a = dsim[n * lp + k], b = dsim[k * lp + n];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int c = threadIdx.x + j * 256;
@@ -546,7 +563,7 @@ __global__ __launch_bounds__(256) void ss_bwd_kernel(
     dw[j] = (wok ? (dw[j] - yw[j] * pw) : dw[j]) / (wnorm * wcnt);
   }
   for (int l = 0; l < Lv; ++l) {
-    const float m = cmask[(int64_t)n * Lv + l] ? 1.0f : 0.0f;
+    const float m = cmL[l];
     float* r = dpv + ((int64_t)n * Lv + l) * D;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -555,7 +572,7 @@ __global__ __launch_bounds__(256) void ss_bwd_kernel(
     }
   }
   for (int l = 0; l < Le; ++l) {
-    const float m = wmask[(int64_t)n * Le + l] ? 1.0f : 0.0f;
+    const float m = wmL[l];
     float* r = dew + ((int64_t)n * Le + l) * D;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -834,8 +851,9 @@ extern "C" int mesm_rec_ss_bwd_nv(const float* cn, const float* wn, const uint8_
                                   int32_t N, int32_t D, int32_t Lv, int32_t Le, float tau, const float* g,
                                   float* dpv, float* dew, const int32_t* n_valid, void* stream) {
   if (!cn || !wn || !pos || !sim || !stats || !cmask || !wmask || !g || !dpv || !dew) return MESM_EINVAL;
-  if (N <= 0 || N > 120 || D <= 0 || D > 1024 || tau <= 0.f) return MESM_EINVAL;
-  hipLaunchKernelGGL(ss_bwd_kernel, dim3(N), dim3(256), (size_t)N * N * 4, (hipStream_t)stream, cn, wn,
+  const size_t lds = ((size_t)N * (N + 1) + Lv + Le) * 4 + (size_t)N * N;
+  if (N <= 0 || lds > 64 * 1024 || D <= 0 || D > 1024 || tau <= 0.f) return MESM_EINVAL;  // (N <= ~100 pairs)
+  hipLaunchKernelGGL(ss_bwd_kernel, dim3(N), dim3(256), lds, (hipStream_t)stream, cn, wn,
                      pos, sim, stats, cmask, wmask, N, D, Lv, Le, 1.0f / tau, g, dpv, dew, n_valid);
   return mesm_launch_status();
 }
