@@ -367,9 +367,20 @@ __global__ __launch_bounds__(256 * SSM_G) void ss_mean_fwd_kernel(
   const int t = threadIdx.x & 255, g = threadIdx.x >> 8;
   // valid clips / words of the pair, counted by the whole workgroup (a per-thread loop over the mask bytes was a
   // chain of Lv + Le dependent loads in front of everything else)
+  // (the mask bytes also go to LDS: read inside the row loops they made every iteration wait for a global load)
+  __shared__ uint8_t cmS[1024], wmS[256];
+  const bool inl = Lv <= 1024 && Le <= 256;
   float ccnt = 0.0f, wcnt = 0.0f;
-  for (int l = threadIdx.x; l < Lv; l += 256 * SSM_G) ccnt += cmask[(int64_t)n * Lv + l] ? 1.0f : 0.0f;
-  for (int l = threadIdx.x; l < Le; l += 256 * SSM_G) wcnt += wmask[(int64_t)n * Le + l] ? 1.0f : 0.0f;
+  for (int l = threadIdx.x; l < Lv; l += 256 * SSM_G) {
+    const uint8_t b = cmask[(int64_t)n * Lv + l];
+    if (inl) cmS[l] = b;
+    ccnt += b ? 1.0f : 0.0f;
+  }
+  for (int l = threadIdx.x; l < Le; l += 256 * SSM_G) {
+    const uint8_t b = wmask[(int64_t)n * Le + l];
+    if (inl) wmS[l] = b;
+    wcnt += b ? 1.0f : 0.0f;
+  }
   ccnt = block_sum(ccnt, sh);
   wcnt = block_sum(wcnt, sh);
   // D <= 4 * 256 handled per thread in registers; the row loops are unrolled so that several rows' loads are in
@@ -377,7 +388,7 @@ __global__ __launch_bounds__(256 * SSM_G) void ss_mean_fwd_kernel(
   float cs[4] = {0, 0, 0, 0}, ws[4] = {0, 0, 0, 0};
 #pragma unroll 5
   for (int l = g; l < Lv; l += SSM_G) {
-    const float m = cmask[(int64_t)n * Lv + l] ? 1.0f : 0.0f;
+    const float m = (inl ? cmS[l] : cmask[(int64_t)n * Lv + l]) ? 1.0f : 0.0f;
     const float* r = pv + ((int64_t)n * Lv + l) * D;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -387,7 +398,7 @@ __global__ __launch_bounds__(256 * SSM_G) void ss_mean_fwd_kernel(
   }
 #pragma unroll 5
   for (int l = g; l < Le; l += SSM_G) {
-    const float m = wmask[(int64_t)n * Le + l] ? 1.0f : 0.0f;
+    const float m = (inl ? wmS[l] : wmask[(int64_t)n * Le + l]) ? 1.0f : 0.0f;
     const float* r = ew + ((int64_t)n * Le + l) * D;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {

@@ -192,11 +192,18 @@ __global__ __launch_bounds__(256) void token_mix_bwd_kernel(const float* __restr
                                                             int64_t rows, int D) {
   const int64_t r0 = (int64_t)blockIdx.x * TM_ROWS;
   const int64_t r1 = (r0 + TM_ROWS) < rows ? (r0 + TM_ROWS) : rows;
+  // the rows' mask bytes first, into LDS: read inside the loop they made every iteration wait for a global load
+  __shared__ uint8_t mk1[TM_ROWS], mk2[TM_ROWS];
+  if (threadIdx.x < TM_ROWS && r0 + threadIdx.x < r1) {
+    mk1[threadIdx.x] = m1[r0 + threadIdx.x];
+    mk2[threadIdx.x] = m2 ? m2[r0 + threadIdx.x] : 0;
+  }
+  __syncthreads();
   for (int c = threadIdx.x; c < D; c += 256) {
     float s1 = 0.0f, s2 = 0.0f;
     for (int64_t r = r0; r < r1; ++r) {
       const float g = dy[r * D + c];
-      const bool b2 = m2 && m2[r], b1 = m1[r] != 0;
+      const bool b2 = mk2[r - r0] != 0, b1 = mk1[r - r0] != 0;
       if (dx) dx[r * D + c] = (b1 || b2) ? 0.0f : g;
       if (b2) s2 += g;
       else if (b1) s1 += g;
