@@ -457,24 +457,36 @@ __global__ __launch_bounds__(256) void ss_loss_fwd_kernel(
   float q[16];  // D <= 1024: this lane's slice of cn[n]
 #pragma unroll
   for (int i = 0; i < 16; ++i) { const int c = lane + 64 * i; q[i] = c < D ? cn[(int64_t)n * D + c] : 0.0f; }
-  for (int k = wave; k < N; k += 4) {
-    float a = 0.0f;
+  // two columns per turn of a wave: both columns' loads are in flight before the first reduction starts
+  for (int k = wave; k < N; k += 8) {
+    const int k2 = k + 4 < N ? k + 4 : k;
+    float a = 0.0f, b = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { const int c = lane + 64 * i; if (c < D) a += q[i] * wn[(int64_t)k * D + c]; }
+    for (int i = 0; i < 16; ++i) {
+      const int c = lane + 64 * i;
+      if (c < D) { a += q[i] * wn[(int64_t)k * D + c]; b += q[i] * wn[(int64_t)k2 * D + c]; }
+    }
     a = wave_sum(a);
-    if (lane == 0) { srow[k] = a * inv_tau; sim[(int64_t)n * ld + k] = a * inv_tau; }
+    b = wave_sum(b);
+    if (lane == 0) {
+      srow[k] = a * inv_tau; sim[(int64_t)n * ld + k] = a * inv_tau;
+      if (k + 4 < N) { srow[k2] = b * inv_tau; sim[(int64_t)n * ld + k2] = b * inv_tau; }
+    }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (wave == 0) {  // the row's log-sum-exp and positive terms across the lanes of one wave
     float m = -INFINITY;
-    for (int k = 0; k < N; ++k) m = fmaxf(m, srow[k]);
-    float S = 0.0f;
-    for (int k = 0; k < N; ++k) S += expf(srow[k] - m);
+    for (int k = lane; k < N; k += 64) m = fmaxf(m, srow[k]);
+    m = wave_max(m);
+    float S = 0.0f, num = 0.0f, cnt = 0.0f;
+    for (int k = lane; k < N; k += 64) S += expf(srow[k] - m);
+    S = wave_sum(S);
     const float logS = logf(S + 1e-6f);
-    float num = 0.0f, cnt = 0.0f;
-    for (int k = 0; k < N; ++k)
+    for (int k = lane; k < N; k += 64)
       if (pos[(int64_t)n * ld + k]) { num += (srow[k] - m) - logS; cnt += 1.0f; }
-    rowloss[n] = -num / (cnt + 1e-6f);
+    num = wave_sum(num);
+    cnt = wave_sum(cnt);
+    if (lane == 0) rowloss[n] = -num / (cnt + 1e-6f);
   }
 }
 
@@ -708,12 +720,24 @@ __global__ __launch_bounds__(TP_THREADS) void text_prep_kernel(const float* __re
   for (int w = wave; w < Lw; w += TP_THREADS / 64) {
     const float* r = x + ((int64_t)n * Lw + w) * D;
     float* o = words + ((int64_t)n * Lw + w) * D;
-    float s2 = 0.0f;
-    for (int c = lane; c < D; c += 64) { const float v = r[c]; s2 += v * v; }
-    s2 = wave_sum(s2);
-    const float inv = normalize ? 1.0f / fmaxf(sqrtf(s2), 1e-5f) : 1.0f;
-    float s = 0.0f;
-    for (int c = lane; c < D; c += 64) { const float v = r[c] * inv; o[c] = v; s += v; }
+    float s2 = 0.0f, s = 0.0f;
+    if (D <= 512) {  // the row in registers, its 8 loads in flight together (same summation order as the loops below)
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = lane + 64 * u < D ? r[lane + 64 * u] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s2 += v[u] * v[u];
+      s2 = wave_sum(s2);
+      const float inv = normalize ? 1.0f / fmaxf(sqrtf(s2), 1e-5f) : 1.0f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (lane + 64 * u < D) { const float t = v[u] * inv; o[lane + 64 * u] = t; s += t; }
+    } else {
+      for (int c = lane; c < D; c += 64) { const float v = r[c]; s2 += v * v; }
+      s2 = wave_sum(s2);
+      const float inv = normalize ? 1.0f / fmaxf(sqrtf(s2), 1e-5f) : 1.0f;
+      for (int c = lane; c < D; c += 64) { const float v = r[c] * inv; o[c] = v; s += v; }
+    }
     s = wave_sum(s);
     if (lane == 0) {
       flags[w] = s != 0.0f ? 1.0f : 0.0f;
@@ -728,7 +752,16 @@ __global__ __launch_bounds__(TP_THREADS) void text_prep_kernel(const float* __re
   // the reference sums ALL words (pads are zero vectors) and divides by the number of valid ones
   for (int c = threadIdx.x; c < D; c += TP_THREADS) {
     float a = 0.0f;
-    for (int w = 0; w < Lw; ++w) a += words[((int64_t)n * Lw + w) * D + c];
+    const float* wc = words + (int64_t)n * Lw * D + c;
+    int w = 0;
+    for (; w + 8 <= Lw; w += 8) {  // 8 loads in flight, added in word order
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = wc[(int64_t)(w + u) * D];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += t[u];
+    }
+    for (; w < Lw; ++w) a += wc[(int64_t)w * D];
     a /= cnt;
     accv[c] = a;
     part += a * a;

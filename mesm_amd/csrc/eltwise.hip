@@ -13,6 +13,12 @@ __global__ __launch_bounds__(256) void sine_pos_kernel(const uint8_t* __restrict
   const int b = blockIdx.x;
   const int l0 = blockIdx.y * SP_ROWS;
   const uint8_t* m = mask + (int64_t)b * L;
+  __shared__ uint8_t ms[1024];  // the mask row, staged once: the counting loop below is a chain of byte loads otherwise
+  if (L <= 1024) {
+    for (int t = threadIdx.x; t < L; t += blockDim.x) ms[t] = m[t];
+    __syncthreads();
+    m = ms;
+  }
   // inclusive prefix count of valid clips (exact in fp32, like cumsum(dtype=float32))
   if (threadIdx.x <= SP_ROWS) {
     const int upto = threadIdx.x == SP_ROWS ? L - 1 : l0 + threadIdx.x;

@@ -376,25 +376,54 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_bwd_group_kernel(const LnGroup
 }
 
 // Parameter gradients only (dx == NULL: the input needs no gradient, e.g. the LayerNorm over the raw
-// 2818-d video features): a column-parallel reduction, thread = column, blockIdx.y = row chunk.
+// 2818-d video features): a column-parallel reduction.  A workgroup owns 64 columns x one row chunk; its 4 waves
+// take every 4th row of the chunk, 4 rows in flight each (the row loop is a chain of dependent global loads
+// otherwise), meet in LDS, and wave 0 issues the one atomic per column and workgroup.
 __global__ __launch_bounds__(256) void ln_bwd_params_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
     const float* __restrict__ rstd, float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows,
     int D, int rows_per_block, LnDrop dr) {
-  const int col = blockIdx.x * 256 + threadIdx.x;
-  if (col >= D) return;
+  __shared__ float red[2][3][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  const bool live = col < D;
+  const int c = live ? col : D - 1;
   const uint32_t dseed = dr.seed + (dr.seed_offset ? *dr.seed_offset : 0u);
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
   float dg = 0.0f, db = 0.0f;
-  for (int64_t r = r0; r < r1; ++r) {
-    float d = dy[r * D + col];
-    if (dr.thresh) d = mesm_dropout_apply(d, (uint32_t)(r * D + col), dseed, dr.thresh, dr.inv_keep);
-    dg += d * (x[r * D + col] - mean[r]) * rstd[r];
-    db += d;
+  for (int64_t r = r0 + w; r < r1; r += 16) {
+    float d[4], xv[4], mu[4], rs[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t rr = r + 4 * u < r1 ? r + 4 * u : r1 - 1;
+      d[u] = dy[rr * D + c];
+      xv[u] = x[rr * D + c];
+      mu[u] = mean[rr];
+      rs[u] = rstd[rr];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t rr = r + 4 * u;
+      if (rr < r1) {
+        float dv = d[u];
+        if (dr.thresh) dv = mesm_dropout_apply(dv, (uint32_t)(rr * D + c), dseed, dr.thresh, dr.inv_keep);
+        dg += dv * (xv[u] - mu[u]) * rs[u];
+        db += dv;
+      }
+    }
   }
-  atomicAdd(dgamma + col, dg);
-  atomicAdd(dbeta + col, db);
+  if (w) {
+    red[0][w - 1][lane] = dg;
+    red[1][w - 1][lane] = db;
+  }
+  __syncthreads();
+  if (w == 0 && live) {
+    dg += red[0][0][lane] + red[0][1][lane] + red[0][2][lane];
+    db += red[1][0][lane] + red[1][1][lane] + red[1][2][lane];
+    atomicAdd(dgamma + col, dg);
+    atomicAdd(dbeta + col, db);
+  }
 }
 
 inline int pick_vec(int D, const void* a, const void* b, const void* c, const void* d) {
@@ -513,9 +542,9 @@ extern "C" int mesm_layernorm_bwd3(const float* dy, const float* x, const float*
   const LnDrop dr = make_drop(drop_p, drop_seed, seed_offset);
   if (!dx) {
     if (accumulate_dx || dyb || addend) return MESM_EINVAL;
-    const int cb = (D + 255) / 256;
-    int rb = (int)((1024 + cb - 1) / cb);  // about 1024 workgroups
-    if (rb > rows) rb = (int)rows;
+    const int cb = (D + 63) / 64;
+    int rb = (int)((1024 + cb - 1) / cb);  // about 1024 workgroups, of 32 rows or more
+    if ((int64_t)rb * 32 > rows) rb = (int)((rows + 31) / 32);
     const int rpb = (int)((rows + rb - 1) / rb);
     rb = (int)((rows + rpb - 1) / rpb);
     hipLaunchKernelGGL(ln_bwd_params_kernel, dim3(cb, rb), dim3(256), 0, s, dy, x, mean, rstd, dgamma,
