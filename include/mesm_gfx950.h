@@ -593,6 +593,11 @@ int mesm_scale_vec(const float* g, const float* weights, int32_t n, float* out, 
  *                      keeps the norm).  Backward through the host-built inverse map inv (source row -> j or -1):
  *                      every source row is written once (zeros where not gathered): model.py:312-325, :485-486.
  * mesm_add_wrap        out[i] = a[i] + b[i mod nb]  (n, nb element counts, % 4 == 0)
+ * mesm_skinny_linear_bwd  backward of y = x W^T + b with J <= 4 output features (last layers of the MLP heads
+ *                      span_embed / bbox_embed / ref_anchor_head and class_embed: model.py:118-119, 402-410,
+ *                      transformer.py:349-352) in one launch: dx (M, K) = dz (M, J) W (J, K), zeroed where x <= 0 when
+ *                      relu_mask (x is the previous layer's ReLU output); dw (J, K) += dz^T x and db (J) += colsum(dz),
+ *                      both atomic into the gradient views.  dx / db may be NULL.
  */
 int mesm_stack_rows(const void* const* src, void* const* dst, const int64_t* row_bytes, const int32_t* gather,
                     int32_t n, const int64_t* idx, int32_t N, void* stream);
@@ -616,6 +621,8 @@ int mesm_gather_rows_bwd(const float* dy, const float* y, const float* rnorm, co
                          const uint8_t* valid, float* dx, int64_t src_rows, int32_t D, int32_t normalize,
                          void* stream);
 int mesm_add_wrap(const float* a, const float* b, float* out, int64_t n, int64_t nb, void* stream);
+int mesm_skinny_linear_bwd(const float* dz, const float* x, const float* w, float* dx, float* dw, float* db,
+                           int64_t M, int32_t K, int32_t J, int32_t relu_mask, void* stream);
 
 /* ------------------------------------------------------------------------- */
 /*

@@ -365,5 +365,5 @@ extern "C" int mesm_act_dropout(const float* x, float* y, int64_t n, int32_t act
   return mesm_launch_status();
 }
 
-extern "C" int mesm_abi_version(void) { return 6; }  // 6: MesmAttnArgs.mask_mod, MesmLnArgs + group entries, *_nv, mesm_ddp_*, match_q = -1
+extern "C" int mesm_abi_version(void) { return 7; }  // 7: mesm_skinny_linear_bwd; 6: MesmAttnArgs.mask_mod, MesmLnArgs + group entries, *_nv, mesm_ddp_*, match_q = -1
 extern "C" const char* mesm_arch(void) { return "gfx950"; }

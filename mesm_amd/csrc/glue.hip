@@ -267,6 +267,59 @@ __global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const float* __res
   for (int c = lane; c < D; c += 64) dx[i * D + c] = (dy[j * D + c] - y[j * D + c] * dot) / n;
 }
 
+// ---- backward of a Linear with at most 4 output features (the last layers of the box / class / anchor heads,
+// transformer.py:395-398, model.py:118-119): dX = dz W (masked by x > 0 when x is a ReLU's output), dW += dz^T x,
+// db += colsum(dz) in ONE launch.  As GEMMs these are a 1-2 wide product and a 1-2 deep one, each a launch of its own
+// that nothing else could share (extent < 4 on the vectorised axis).  Workgroup = 32 rows x 256 columns, thread =
+// column: dz of the 32 rows sits in LDS, W's J rows in registers, 8 rows of x in flight per turn.
+constexpr int SK_ROWS = 32;
+__global__ __launch_bounds__(256) void skinny_linear_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ x,
+                                                                const float* __restrict__ w, float* __restrict__ dx,
+                                                                float* __restrict__ dw, float* __restrict__ db,
+                                                                int64_t M, int K, int J, int relu_mask) {
+  __shared__ float dzs[SK_ROWS][4];
+  const int64_t r0 = (int64_t)blockIdx.x * SK_ROWS;
+  const int nr = M - r0 < SK_ROWS ? (int)(M - r0) : SK_ROWS;
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (threadIdx.x < SK_ROWS * 4) {
+    const int r = threadIdx.x >> 2, j = threadIdx.x & 3;
+    dzs[r][j] = (r < nr && j < J) ? dz[(r0 + r) * J + j] : 0.0f;
+  }
+  __syncthreads();
+  if (c < K) {
+    float wv[4], acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { wv[j] = j < J ? w[(int64_t)j * K + c] : 0.0f; acc[j] = 0.0f; }
+    for (int rb = 0; rb < nr; rb += 8) {
+      float xv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) xv[u] = rb + u < nr ? x[(r0 + rb + u) * K + c] : 0.0f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (rb + u < nr) {
+          float o = 0.0f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float d = dzs[rb + u][j];
+            acc[j] += d * xv[u];
+            o += d * wv[j];
+          }
+          if (dx) dx[(r0 + rb + u) * K + c] = (relu_mask && !(xv[u] > 0.0f)) ? 0.0f : o;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < J) atomicAdd(dw + (int64_t)j * K + c, acc[j]);
+  }
+  if (db && blockIdx.y == 0 && threadIdx.x < J) {
+    float t = 0.0f;
+    for (int r = 0; r < nr; ++r) t += dzs[r][threadIdx.x];
+    atomicAdd(db + threadIdx.x, t);
+  }
+}
+
+
 // out[i, :] = a[i, :] + b[i % rows_b, :]  (one float4 per thread): the first query of the enhance encoder,
 // projected video + sine position embedding for both stacked passes (model.py:175-180, 281-286)
 __global__ __launch_bounds__(256) void add_wrap_kernel(const float* __restrict__ a, const float* __restrict__ b,
@@ -370,6 +423,17 @@ extern "C" int mesm_gather_rows_bwd(const float* dy, const float* y, const float
   if (!dy || !inv || !dx || src_rows <= 0 || D <= 0 || (normalize && (!y || !rnorm))) return MESM_EINVAL;
   hipLaunchKernelGGL(gather_rows_bwd_kernel, dim3((unsigned)((src_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dy,
                      y, rnorm, inv, valid, dx, src_rows, D, normalize);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_skinny_linear_bwd(const float* dz, const float* x, const float* w, float* dx, float* dw, float* db,
+                                      int64_t M, int32_t K, int32_t J, int32_t relu_mask, void* stream) {
+  if (!dz || !x || !w || !dw || M < 0 || K <= 0 || J < 1 || J > 4) return MESM_EINVAL;
+  if (M == 0) return MESM_OK;
+  const int64_t rb = (M + SK_ROWS - 1) / SK_ROWS;
+  if (rb > 0x7fffffff) return MESM_EINVAL;
+  hipLaunchKernelGGL(skinny_linear_bwd_kernel, dim3((unsigned)rb, (unsigned)((K + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, dz, x, w, dx, dw, db, M, K, J, relu_mask);
   return mesm_launch_status();
 }
 

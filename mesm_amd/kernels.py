@@ -944,6 +944,23 @@ def add_wrap(a, b):
     return out
 
 
+SKINNY_OUT = 4  # Linear layers with at most this many output features take skinny_linear_bwd
+
+
+def skinny_linear_bwd(dz, x, w, dw, db=None, need_dx=True, relu_mask=False):
+    """Backward of y = x W^T + b, W (J <= 4, K), in one launch: -> dx (or None); dw += dz^T x, db += colsum(dz)."""
+    require_gpu(dz, x, w, dw)
+    M, J = dz.shape
+    K = x.shape[1]
+    assert x.shape[0] == M and tuple(w.shape) == (J, K) and tuple(dw.shape) == (J, K) and 1 <= J <= SKINNY_OUT
+    assert dz.is_contiguous() and x.is_contiguous() and w.is_contiguous() and dw.is_contiguous()
+    assert db is None or (db.is_contiguous() and db.numel() == J)
+    dx = torch.empty_like(x) if need_dx else None
+    check(lib().mesm_skinny_linear_bwd(ptr(dz), ptr(x), ptr(w), ptr(dx), ptr(dw), ptr(db), M, K, J,
+                                       1 if relu_mask else 0, stream_ptr()), "mesm_skinny_linear_bwd")
+    return dx
+
+
 # ----------------------------------------------------------------------------- frozen text encoders
 def clip_embed(ids, tok, pos):
     """ids (N, L) int64, tok (V, D) f32, pos (L, D) f32 -> (N, L, D) fp16."""

@@ -465,10 +465,25 @@ class LinearBlock:
         gw, wdirect = grad_target(w)
         gb, bdirect = grad_target(b) if b is not None else (None, True)
         dx = None
+        need_dx = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        wv = _rows(w, rows)
+        if SKINNY_BWD and wv.shape[0] <= kn.SKINNY_OUT and x2 is None and ctx.in_drop[0] == 0.0 and dz.is_contiguous():
+            # a 1-4 feature head: dX, dW and db from one launch instead of two degenerate GEMMs
+            ir = ctx.in_relu
+            dx = kn.skinny_linear_bwd(dz, _2d(x), wv, _rows(gw, rows), _rows(gb, rows) if gb is not None else None,
+                                      need_dx=need_dx, relu_mask=ir is not None and need_dx)
+            if dx is not None:
+                dx = dx.view(x.shape)
+                if ir is not None:
+                    ir.t = dx
+            return (dx if ctx.needs_input_grad[0] else None, None,
+                    dy if ctx.has_res and ctx.needs_input_grad[2] else None,
+                    None if wdirect else gw, None if (b is None or bdirect) else gb,
+                    None, None, None, None, None, None, None)
         # dW and dX are independent: one launch when both are small
         _accum_dw(dz, _2d(x), _rows(gw, rows), _rows(gb, rows) if gb is not None else None,
                   x2=_2d(x2) if x2 is not None else None, b_drop=ctx.in_drop)
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+        if need_dx:
             dx = torch.empty_like(x)
             ir = ctx.in_relu if (x2 is None and ctx.in_drop[0] == 0.0) else None
             if ir is not None:  # x = relu(z) of the previous Linear: write d z (see ReluSink)
@@ -482,6 +497,9 @@ class LinearBlock:
                 None if wdirect else gw, None if (b is None or bdirect) else gb,
                 None, None, None, None, None, None, None)
 
+
+# A/B switch: MESM_SKINNY_BWD=0 sends the 1-4 feature heads' backward through the GEMM entry again
+SKINNY_BWD = os.environ.get("MESM_SKINNY_BWD", "1") != "0"
 
 # Test switch (tests/test_model_gpu.py, kink control run): drop every ReLU of the Linear blocks so that the
 # full-width gradient comparison with the oracle has no activation kinks to flip.  Never set in production.

@@ -213,6 +213,52 @@ def test_layernorm(rows, D):
     assert rel_err(db2, bd.grad) < TOL
 
 
+@pytest.mark.parametrize("M,K,J", [(320, 256, 2), (640, 256, 2), (320, 256, 1), (37, 300, 3), (1, 7, 4), (2400, 512, 1)])
+@pytest.mark.parametrize("relu_mask", [False, True])
+def test_skinny_linear_backward_in_one_launch(M, K, J, relu_mask):
+    """dX, dW, db of a 1-4 feature Linear (the heads' last layers) from mesm_skinny_linear_bwd against fp64;
+    dW / db accumulate into what the views already hold."""
+    from mesm_amd import kernels as kn
+    x = gen((M, K), 60)
+    if relu_mask:
+        x = torch.relu(x)
+    w = gen((J, K), 61, 0.2)
+    dz = gen((M, J), 62)
+    dw0, db0 = gen((J, K), 63), gen((J,), 64)
+    dw, db = dw0.clone(), db0.clone()
+    dx = kn.skinny_linear_bwd(dz, x, w, dw, db, relu_mask=relu_mask)
+    ref_dx = dz.double() @ w.double()
+    if relu_mask:
+        ref_dx = ref_dx * (x > 0)
+    assert rel_err(dx, ref_dx) < TOL
+    assert rel_err(dw, dw0.double() + dz.double().t() @ x.double()) < TOL
+    assert rel_err(db, db0.double() + dz.double().sum(0)) < TOL
+    # parameter gradients only
+    dw2 = torch.zeros_like(dw0)
+    assert kn.skinny_linear_bwd(dz, x, w, dw2, None, need_dx=False) is None
+    assert rel_err(dw2, dz.double().t() @ x.double()) < TOL
+
+
+def test_linear_block_backward_is_the_same_through_either_route():
+    """ops.linear with 2 output features behind a ReLU layer: the one-launch backward against the two-GEMM route."""
+    from mesm_amd import ops
+    outs = {}
+    for skinny in (True, False):
+        ops.SKINNY_BWD = skinny
+        try:
+            x = gen((32, 10, 256), 70).requires_grad_(True)
+            w1, b1 = gen((256, 256), 71, 0.06).requires_grad_(True), gen((256,), 72, 0.1).requires_grad_(True)
+            w2, b2 = gen((2, 256), 73, 0.06).requires_grad_(True), gen((2,), 74, 0.1).requires_grad_(True)
+            h = ops.linear(x, w1, b1, relu=True)
+            y = ops.linear(h, w2, b2)
+            y.backward(gen((32, 10, 2), 75))
+            outs[skinny] = [t.grad.clone() for t in (x, w1, b1, w2, b2)]
+        finally:
+            ops.SKINNY_BWD = True
+    for a, b in zip(outs[True], outs[False]):
+        assert rel_err(a, b) < 1e-5
+
+
 # --------------------------------------------------------------------------- attention
 def attn_reference(q, k, v, H, kpad, qpad, scale, quirk_B=None):
     """fp64 restatement of nn.MultiheadAttention's core incl. the reference's
