@@ -383,54 +383,57 @@ __global__ __launch_bounds__(256 * SSM_G) void ss_mean_fwd_kernel(
   }
   ccnt = block_sum(ccnt, sh);
   wcnt = block_sum(wcnt, sh);
-  // D <= 4 * 256 handled per thread in registers; the row loops are unrolled so that several rows' loads are in
+  // a row takes `tpr` threads (a float4 each when D % 4 == 0), so the workgroup walks G = 1024 / tpr rows side by
+  // side: 16 at D = 256, i.e. 5 rounds for 75 clips, and the rounds of a thread are unrolled so that their loads are in
   // flight together (one workgroup per pair: nothing else hides their latency)
+  const int vw = (D & 3) ? 1 : 4;
+  const int tpr = (((D + vw - 1) / vw + 63) / 64) * 64;
+  const int G = (256 * SSM_G) / tpr;
+  const int rg = threadIdx.x / tpr, col = (threadIdx.x % tpr) * vw;
   float cs[4] = {0, 0, 0, 0}, ws[4] = {0, 0, 0, 0};
+  if (rg < G && col < D) {
 #pragma unroll 5
-  for (int l = g; l < Lv; l += SSM_G) {
-    const float m = (inl ? cmS[l] : cmask[(int64_t)n * Lv + l]) ? 1.0f : 0.0f;
-    const float* r = pv + ((int64_t)n * Lv + l) * D;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int c = t + k * 256;
-      if (c < D) cs[k] += m * r[c];
+    for (int l = rg; l < Lv; l += G) {
+      const float m = (inl ? cmS[l] : cmask[(int64_t)n * Lv + l]) ? 1.0f : 0.0f;
+      const float* r = pv + ((int64_t)n * Lv + l) * D + col;
+      if (vw == 4) {
+        const float4 v = *reinterpret_cast<const float4*>(r);
+        cs[0] += m * v.x; cs[1] += m * v.y; cs[2] += m * v.z; cs[3] += m * v.w;
+      } else {
+        cs[0] += m * r[0];
+      }
     }
-  }
 #pragma unroll 5
-  for (int l = g; l < Le; l += SSM_G) {
-    const float m = (inl ? wmS[l] : wmask[(int64_t)n * Le + l]) ? 1.0f : 0.0f;
-    const float* r = ew + ((int64_t)n * Le + l) * D;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int c = t + k * 256;
-      if (c < D) ws[k] += m * r[c];
+    for (int l = rg; l < Le; l += G) {
+      const float m = (inl ? wmS[l] : wmask[(int64_t)n * Le + l]) ? 1.0f : 0.0f;
+      const float* r = ew + ((int64_t)n * Le + l) * D + col;
+      if (vw == 4) {
+        const float4 v = *reinterpret_cast<const float4*>(r);
+        ws[0] += m * v.x; ws[1] += m * v.y; ws[2] += m * v.z; ws[3] += m * v.w;
+      } else {
+        ws[0] += m * r[0];
+      }
     }
-  }
+    float* p0 = &part[0][0][0] + rg * D + col;  // [G][D] <= 4096 floats each
+    float* p1 = &part[1][0][0] + rg * D + col;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { part[0][g][t + k * 256] = cs[k]; part[1][g][t + k * 256] = ws[k]; }
+    for (int e = 0; e < 4; ++e)
+      if (e < vw) { p0[e] = cs[e]; p1[e] = ws[e]; }
+  }
   __syncthreads();
-  float c2 = 0.0f, w2 = 0.0f;
-  if (g == 0) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float a = 0.0f, b = 0.0f;
-#pragma unroll
-      for (int gg = 0; gg < SSM_G; ++gg) { a += part[0][gg][t + k * 256]; b += part[1][gg][t + k * 256]; }
-      cs[k] = a / ccnt; ws[k] = b / wcnt;
-      c2 += cs[k] * cs[k]; w2 += ws[k] * ws[k];
-    }
+  float c2 = 0.0f, w2 = 0.0f, cm = 0.0f, wm = 0.0f;
+  const int c = threadIdx.x;  // thread = column for the rest (D <= 1024)
+  if (c < D) {
+    float a = 0.0f, b2 = 0.0f;
+    for (int gg = 0; gg < G; ++gg) { a += (&part[0][0][0])[gg * D + c]; b2 += (&part[1][0][0])[gg * D + c]; }
+    cm = a / ccnt; wm = b2 / wcnt;
+    c2 = cm * cm; w2 = wm * wm;
   }
   const float cnorm = fmaxf(sqrtf(block_sum(c2, sh)), 1e-12f);
   const float wnorm = fmaxf(sqrtf(block_sum(w2, sh)), 1e-12f);
-  if (g == 0) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int c = t + k * 256;
-      if (c < D) {
-        cn[(int64_t)n * D + c] = cs[k] / cnorm;
-        wn[(int64_t)n * D + c] = ws[k] / wnorm;
-      }
-    }
+  if (c < D) {
+    cn[(int64_t)n * D + c] = cm / cnorm;
+    wn[(int64_t)n * D + c] = wm / wnorm;
   }
   if (threadIdx.x == 0) {
     stats[n * 4 + 0] = ccnt; stats[n * 4 + 1] = wcnt;

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void split_bwd_kernel(const float* __restrict_
 // SegSenRecon's masked sentence slot (model.py:493-501).  m2 / tok2 optional.  Backward: dx = dy where neither
 // mask is set, else 0; dtok1 += sum of dy over (m1 & ~m2) rows, dtok2 += sum over m2 rows (atomics, one
 // partial per workgroup of 32 rows).
-constexpr int TM_ROWS = 32;
+constexpr int TM_ROWS = 8;
 __global__ __launch_bounds__(256) void token_mix_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ m1,
                                                             const float* __restrict__ tok1, const uint8_t* __restrict__ m2,
                                                             const float* __restrict__ tok2, float* __restrict__ y,
@@ -201,12 +201,18 @@ __global__ __launch_bounds__(256) void token_mix_bwd_kernel(const float* __restr
   __syncthreads();
   for (int c = threadIdx.x; c < D; c += 256) {
     float s1 = 0.0f, s2 = 0.0f;
-    for (int64_t r = r0; r < r1; ++r) {
-      const float g = dy[r * D + c];
-      const bool b2 = mk2[r - r0] != 0, b1 = mk1[r - r0] != 0;
-      if (dx) dx[r * D + c] = (b1 || b2) ? 0.0f : g;
-      if (b2) s2 += g;
-      else if (b1) s1 += g;
+    float gv[TM_ROWS];  // the workgroup's rows of this column, all in flight together
+#pragma unroll
+    for (int u = 0; u < TM_ROWS; ++u) gv[u] = r0 + u < r1 ? dy[(r0 + u) * D + c] : 0.0f;
+#pragma unroll
+    for (int u = 0; u < TM_ROWS; ++u) {
+      if (r0 + u < r1) {
+        const float g = gv[u];
+        const bool b2 = mk2[u] != 0, b1 = mk1[u] != 0;
+        if (dx) dx[(r0 + u) * D + c] = (b1 || b2) ? 0.0f : g;
+        if (b2) s2 += g;
+        else if (b1) s1 += g;
+      }
     }
     if (dtok1 && s1 != 0.0f) atomicAdd(dtok1 + c, s1);
     if (dtok2 && s2 != 0.0f) atomicAdd(dtok2 + c, s2);
