@@ -522,40 +522,83 @@ __global__ __launch_bounds__(256) void ss_bwd_kernel(
   float* cmL = dsim + ld * lp;  // Lv
   float* wmL = cmL + Lv;        // Le
   uint8_t* posL = reinterpret_cast<uint8_t*>(wmL + Le);  // ld * ld
-  for (int idx = threadIdx.x; idx < ld * ld; idx += 256) {
-    const int r = idx / ld, k = idx - r * ld;
-    dsim[r * lp + k] = sim[idx];
-    posL[idx] = pos[idx];
+  // everything this workgroup reads from memory besides wn / cn of the other pairs is requested up front, four
+  // elements of sim / pos per thread at a time: taken one by one inside the loops these were a dozen round trips
+  const float g0 = g[0];
+  const int nv = n_valid ? *n_valid : N;
+  const float ccnt = stats[n * 4 + 0], wcnt = stats[n * 4 + 1];
+  const float cnorm = stats[n * 4 + 2], wnorm = stats[n * 4 + 3];
+  float yc[4], yw[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = threadIdx.x + j * 256;
+    yc[j] = c < D ? cn[(int64_t)n * D + c] : 0.0f;
+    yw[j] = c < D ? wn[(int64_t)n * D + c] : 0.0f;
+  }
+  for (int base = 0; base < ld * ld; base += 1024) {
+    float sv[4];
+    uint8_t pb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = base + threadIdx.x + 256 * u;
+      sv[u] = idx < ld * ld ? sim[idx] : 0.0f;
+      pb[u] = idx < ld * ld ? pos[idx] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = base + threadIdx.x + 256 * u;
+      if (idx < ld * ld) {
+        const int r = idx / ld, k = idx - r * ld;
+        dsim[r * lp + k] = sv[u];
+        posL[idx] = pb[u];
+      }
+    }
   }
   for (int l = threadIdx.x; l < Lv; l += 256) cmL[l] = cmask[(int64_t)n * Lv + l] ? 1.0f : 0.0f;
   for (int l = threadIdx.x; l < Le; l += 256) wmL[l] = wmask[(int64_t)n * Le + l] ? 1.0f : 0.0f;
   __syncthreads();
-  if (n_valid) N = *n_valid;  // padding pairs: no row, no column; their own gradients come out zero below
-  const float gs = g[0] / (float)N;
-  for (int r = threadIdx.x; r < N; r += 256) {
-    float* row = dsim + r * lp;
-    const uint8_t* prow = posL + r * ld;
+  N = nv;  // padding pairs: no row, no column; their own gradients come out zero below
+  const float gs = g0 / (float)N;
+  // d sim row by row: 8 lanes share a row (a thread per row left one 32-iteration chain of LDS reads and expf per
+  // loop to a single wave)
+  const int seg = threadIdx.x & 7;
+  for (int rbase = 0; rbase < N; rbase += 32) {
+    const int r = rbase + (threadIdx.x >> 3);
+    const bool live = r < N;
+    float* row = dsim + (live ? r : 0) * lp;
+    const uint8_t* prow = posL + (live ? r : 0) * ld;
     float m = -INFINITY;
-    int am = 0;
-    for (int k = 0; k < N; ++k)
-      if (row[k] > m) { m = row[k]; am = k; }
-    float S = 0.0f, cnt = 0.0f;
-    for (int k = 0; k < N; ++k) {
-      S += expf(row[k] - m);
-      cnt += prow[k] ? 1.0f : 0.0f;
+    int am = 0x7fffffff;
+    if (live)
+      for (int k = seg; k < N; k += 8)
+        if (row[k] > m) { m = row[k]; am = k; }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {  // the first index of the maximum, as a serial scan finds it
+      const float m2 = __shfl_xor(m, o);
+      const int a2 = __shfl_xor(am, o);
+      if (m2 > m || (m2 == m && a2 < am)) { m = m2; am = a2; }
     }
+    float S = 0.0f, cnt = 0.0f;
+    if (live)
+      for (int k = seg; k < N; k += 8) {
+        S += expf(row[k] - m);
+        cnt += prow[k] ? 1.0f : 0.0f;
+      }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { S += __shfl_xor(S, o); cnt += __shfl_xor(cnt, o); }
     const float a = gs / (cnt + 1e-6f);
     const float iS = 1.0f / (S + 1e-6f);
-    for (int k = 0; k < N; ++k) {
-      float d = -a * (prow[k] ? 1.0f : 0.0f) + a * cnt * expf(row[k] - m) * iS;
-      if (k == am) d += a * cnt * 1e-6f * iS;
-      row[k] = d * inv_tau;
-    }
+    if (live)
+      for (int k = seg; k < N; k += 8) {
+        float d = -a * (prow[k] ? 1.0f : 0.0f) + a * cnt * expf(row[k] - m) * iS;
+        if (k == am) d += a * cnt * 1e-6f * iS;
+        row[k] = d * inv_tau;
+      }
   }
   __syncthreads();
-  float dc[4] = {0, 0, 0, 0}, dw[4] = {0, 0, 0, 0}, yc[4], yw[4];
+  float dc[4] = {0, 0, 0, 0}, dw[4] = {0, 0, 0, 0};
   const int kmax = n < N ? N : 0;  // a padding pair takes part in nothing
-#pragma unroll 8
+#pragma unroll 16
   for (int k = 0; k < kmax; ++k) {
     const float a = dsim[n * lp + k], b = dsim[k * lp + n];
 #pragma unroll
@@ -570,16 +613,11 @@ __global__ __launch_bounds__(256) void ss_bwd_kernel(
   float pc = 0.0f, pw = 0.0f;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int c = threadIdx.x + j * 256;
-    yc[j] = c < D ? cn[(int64_t)n * D + c] : 0.0f;
-    yw[j] = c < D ? wn[(int64_t)n * D + c] : 0.0f;
     pc += yc[j] * dc[j];
     pw += yw[j] * dw[j];
   }
   pc = block_sum(pc, sh);
   pw = block_sum(pw, sh);
-  const float ccnt = stats[n * 4 + 0], wcnt = stats[n * 4 + 1];
-  const float cnorm = stats[n * 4 + 2], wnorm = stats[n * 4 + 3];
   // y = x / max(|x|, eps): dx = (dy - y (y.dy)) / |x|  (|x| > eps; F.normalize's clamp branch has
   // zero gradient through the norm, dx = dy / eps)
   const bool cok = cnorm > 1e-12f, wok = wnorm > 1e-12f;
@@ -587,6 +625,30 @@ __global__ __launch_bounds__(256) void ss_bwd_kernel(
   for (int j = 0; j < 4; ++j) {
     dc[j] = (cok ? (dc[j] - yc[j] * pc) : dc[j]) / (cnorm * ccnt);
     dw[j] = (wok ? (dw[j] - yw[j] * pw) : dw[j]) / (wnorm * wcnt);
+  }
+  if ((D & 3) == 0) {
+    // rows out as float4 lanes, 4 rows per turn of the workgroup (a thread per column walked all Lv + Le rows alone)
+    __shared__ __attribute__((aligned(16))) float dcw[2][1024];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = threadIdx.x + j * 256;
+      if (c < D) { dcw[0][c] = dc[j]; dcw[1][c] = dw[j]; }
+    }
+    __syncthreads();
+    const int rg = threadIdx.x >> 6;
+    for (int c = (threadIdx.x & 63) * 4; c < D; c += 256) {
+      const float4 a = *reinterpret_cast<const float4*>(&dcw[0][c]);
+      const float4 b = *reinterpret_cast<const float4*>(&dcw[1][c]);
+      for (int l = rg; l < Lv; l += 4) {
+        const float m = cmL[l];
+        *reinterpret_cast<float4*>(dpv + ((int64_t)n * Lv + l) * D + c) = make_float4(m * a.x, m * a.y, m * a.z, m * a.w);
+      }
+      for (int l = rg; l < Le; l += 4) {
+        const float m = wmL[l];
+        *reinterpret_cast<float4*>(dew + ((int64_t)n * Le + l) * D + c) = make_float4(m * b.x, m * b.y, m * b.z, m * b.w);
+      }
+    }
+    return;
   }
   for (int l = 0; l < Lv; ++l) {
     const float m = cmL[l];

@@ -276,9 +276,9 @@ __global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const float* __res
 // ---- backward of a Linear with at most 4 output features (the last layers of the box / class / anchor heads,
 // transformer.py:395-398, model.py:118-119): dX = dz W (masked by x > 0 when x is a ReLU's output), dW += dz^T x,
 // db += colsum(dz) in ONE launch.  As GEMMs these are a 1-2 wide product and a 1-2 deep one, each a launch of its own
-// that nothing else could share (extent < 4 on the vectorised axis).  Workgroup = 32 rows x 256 columns, thread =
-// column: dz of the 32 rows sits in LDS, W's J rows in registers, 8 rows of x in flight per turn.
-constexpr int SK_ROWS = 32;
+// that nothing else could share (extent < 4 on the vectorised axis).  Workgroup = 8 rows x 256 columns, thread =
+// column: dz of the rows sits in LDS, W's J rows in registers, the 8 rows of x in flight together.
+constexpr int SK_ROWS = 8;
 __global__ __launch_bounds__(256) void skinny_linear_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ x,
                                                                 const float* __restrict__ w, float* __restrict__ dx,
                                                                 float* __restrict__ dw, float* __restrict__ db,
