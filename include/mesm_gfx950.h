@@ -398,6 +398,10 @@ int mesm_ref_update_fwd(const float* delta, const float* ref, float* out, int64_
                         void* stream);
 int mesm_ref_update_bwd(const float* out, const float* ref, const float* dout, float* ddelta,
                         float* dref, int64_t n, float eps, void* stream);
+/* The decoder's first reference points (transformer.py:197, 361): out (N, QC) = sigmoid(p (QC)) for every pair;
+ * backward dp[j] += out[0, j] (1 - out[0, j]) sum_n dout[n, j] into the parameter's gradient view (one workgroup). */
+int mesm_ref_init_fwd(const float* p, float* out, int32_t N, int32_t QC, void* stream);
+int mesm_ref_init_bwd(const float* out, const float* dout, float* dp, int32_t N, int32_t QC, void* stream);
 int mesm_qsine_scale_fwd(const float* qsine, const float* scale, const float* anchor,
                          const float* ref, float* out, int64_t R, int32_t D, void* stream);
 int mesm_qsine_scale_bwd(const float* qsine, const float* scale, const float* anchor,

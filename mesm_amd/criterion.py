@@ -138,6 +138,7 @@ class CriterionFn(Function):
 
     @staticmethod
     def forward(ctx, spec, *t):
+        ctx.set_materialize_grads(False)  # (the engine would zero-fill a gradient for the loss vector: one launch)
         c, plan = spec.crit, spec.plan
         m = c.matcher
         dev = t[0].device

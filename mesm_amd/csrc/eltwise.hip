@@ -158,6 +158,35 @@ __global__ __launch_bounds__(256) void ref_update_bwd_kernel(const float* __rest
   if (dref) dref[i] = dpre * d;
 }
 
+// ---- the decoder's first reference points: ref[n, q, :] = sigmoid(p[q, :]) for every pair n
+// (transformer.py:197, 361: query_embed.weight repeated over the batch, then .sigmoid()).  As torch ops this was
+// sigmoid + expand-copy forward and sum + sigmoid_backward + accumulate backward: five launches for 20 numbers.
+__global__ __launch_bounds__(256) void ref_init_fwd_kernel(const float* __restrict__ p, float* __restrict__ out,
+                                                          int64_t total, int QC) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  out[i] = 1.0f / (1.0f + expf(-p[i % QC]));
+}
+
+// dp[j] += s (1 - s) sum_n dout[n, j]   (one workgroup; dp is the parameter's gradient view)
+__global__ __launch_bounds__(256) void ref_init_bwd_kernel(const float* __restrict__ out, const float* __restrict__ dout,
+                                                          float* __restrict__ dp, int N, int QC) {
+  for (int j = threadIdx.x; j < QC; j += 256) {
+    float acc = 0.0f;
+    int n = 0;
+    for (; n + 8 <= N; n += 8) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = dout[(int64_t)(n + u) * QC + j];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += t[u];
+    }
+    for (; n < N; ++n) acc += dout[(int64_t)n * QC + j];
+    const float sg = out[j];
+    dp[j] += acc * sg * (1.0f - sg);
+  }
+}
+
 // out[r, :] = qsine[r, :] * (scale ? scale[r, :] : 1) * sigmoid(anchor[r]) / ref[r, 1]   (one wave per row)
 __global__ __launch_bounds__(256) void qsine_scale_fwd_kernel(const float* __restrict__ qsine,
                                                              const float* __restrict__ scale,
@@ -334,6 +363,20 @@ extern "C" int mesm_ref_update_bwd(const float* out, const float* ref, const flo
   return mesm_launch_status();
 }
 
+extern "C" int mesm_ref_init_fwd(const float* p, float* out, int32_t N, int32_t QC, void* stream) {
+  if (!p || !out || N <= 0 || QC <= 0) return MESM_EINVAL;
+  const int64_t total = (int64_t)N * QC;
+  hipLaunchKernelGGL(ref_init_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, out,
+                     total, QC);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_ref_init_bwd(const float* out, const float* dout, float* dp, int32_t N, int32_t QC, void* stream) {
+  if (!out || !dout || !dp || N <= 0 || QC <= 0) return MESM_EINVAL;
+  hipLaunchKernelGGL(ref_init_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, out, dout, dp, N, QC);
+  return mesm_launch_status();
+}
+
 extern "C" int mesm_qsine_scale_fwd(const float* qsine, const float* scale, const float* anchor,
                                     const float* ref, float* out, int64_t R, int32_t D, void* stream) {
   if (!qsine || !anchor || !ref || !out || R <= 0 || D <= 0) return MESM_EINVAL;
@@ -365,5 +408,5 @@ extern "C" int mesm_act_dropout(const float* x, float* y, int64_t n, int32_t act
   return mesm_launch_status();
 }
 
-extern "C" int mesm_abi_version(void) { return 7; }  // 7: mesm_skinny_linear_bwd; 6: MesmAttnArgs.mask_mod, MesmLnArgs + group entries, *_nv, mesm_ddp_*, match_q = -1
+extern "C" int mesm_abi_version(void) { return 8; }  // 8: mesm_ref_init_*; 7: mesm_skinny_linear_bwd; 6: MesmAttnArgs.mask_mod, MesmLnArgs + group entries, *_nv, mesm_ddp_*, match_q = -1
 extern "C" const char* mesm_arch(void) { return "gfx950"; }

@@ -368,8 +368,8 @@ class Decoder(nn.Module):
         n = memory.shape[0]
         nq = refpoints_unsigmoid.shape[0]
         d = self.d_model
-        # (made contiguous once: the three kernels that read it each copied the expanded view)
-        ref = torch.sigmoid(refpoints_unsigmoid)[None].expand(n, nq, 2).contiguous()
+        # sigmoid(refpoints)[None].expand(n, nq, 2), materialised by one kernel (backward: one more)
+        ref = ops.ref_init(refpoints_unsigmoid, n)
         refs = [ref]
         out = kn.zeros((n, nq, d), memory.device) if torch.is_grad_enabled() else torch.zeros(n, nq, d, device=memory.device)
         inter = []

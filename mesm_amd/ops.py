@@ -1180,6 +1180,7 @@ class NLLSmoothFn(Function):
 
     @staticmethod
     def forward(ctx, logit, label, mask, eps):
+        ctx.set_materialize_grads(False)  # (no zero fill for the gradient of `correct`)
         logit = _c(logit)
         C = logit.shape[-1]
         l2 = logit.view(-1, C)
@@ -1457,6 +1458,33 @@ def gather_rows2(x2d, idx, inv, valid=None, normalize=False):
 
 
 # ----------------------------------------------------------------------------- decoder reference points
+class RefInitFn(Function):
+    """ref (n, nq, 2) = sigmoid(refpoints_unsigmoid (nq, 2)) for every pair (transformer.py:197, 361), one launch each
+    way; the parameter's gradient goes straight into its view."""
+
+    @staticmethod
+    def forward(ctx, p, n):
+        pc = _c(p)
+        out = torch.empty((n,) + tuple(p.shape), device=p.device, dtype=torch.float32)
+        kn.check(kn.lib().mesm_ref_init_fwd(kn.ptr(pc), kn.ptr(out), n, pc.numel(), kn.stream_ptr()), "mesm_ref_init_fwd")
+        ctx.save_for_backward(out)
+        ctx.p = p
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (out,) = ctx.saved_tensors
+        g, direct = grad_target(ctx.p)
+        kn.check(kn.lib().mesm_ref_init_bwd(kn.ptr(out), kn.ptr(_c(dout)), kn.ptr(g), out.shape[0], ctx.p.numel(),
+                                            kn.stream_ptr()), "mesm_ref_init_bwd")
+        flush_ready()
+        return (None if direct else g), None
+
+
+def ref_init(p, n):
+    return RefInitFn.apply(p, n)
+
+
 class RefUpdateFn(Function):
     """sigmoid(delta + inverse_sigmoid(ref)) (transformer.py:36-40, 392-394; model.py:250)."""
 

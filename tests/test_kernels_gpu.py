@@ -259,6 +259,19 @@ def test_linear_block_backward_is_the_same_through_either_route():
         assert rel_err(a, b) < 1e-5
 
 
+def test_reference_point_init_matches_sigmoid_expand_and_its_autograd():
+    from mesm_amd import ops
+    p = gen((10, 2), 80).requires_grad_(True)
+    ref = ops.ref_init(p, 32)
+    pd = p.detach().double().requires_grad_(True)
+    want = torch.sigmoid(pd)[None].expand(32, 10, 2)
+    assert ref.shape == (32, 10, 2) and rel_err(ref, want) < 1e-6
+    g = gen((32, 10, 2), 81)
+    ref.backward(g)
+    want.backward(g.double())
+    assert rel_err(p.grad, pd.grad) < 1e-5
+
+
 # --------------------------------------------------------------------------- attention
 def attn_reference(q, k, v, H, kpad, qpad, scale, quirk_B=None):
     """fp64 restatement of nn.MultiheadAttention's core incl. the reference's
