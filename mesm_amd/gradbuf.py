@@ -95,9 +95,7 @@ class GradBuffer:
         p.grad = None  # let _open() see the pre-backward state of this parameter
         if self.pending:
             self._open()
-        else:
-            v.zero_()
-        v.copy_(g)
+        v.copy_(g)  # (overwrites the whole view: no zero fill in front of it)
         p.grad = v
         if self.on_ready is not None:
             self.on_ready(p)
