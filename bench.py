@@ -47,6 +47,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+SETTLE_STEPS = 60  # untimed steps in front of the caller's warm-up (see main)
 PEAK_HBM_TBS = 8.0            # MI355X_MICROARCH.md: HBM3E spec peak
 # algorithmic work of one step (kernel-boundary traffic / FLOPs); closed form for C3a-type batches,
 # the analytic model's totals for the other workloads
@@ -281,6 +282,10 @@ def main():
         torch.cuda.synchronize()
 
     log("model built (%d params), starting warm-up" % sum(p.numel() for p in model.parameters()))
+    # clocks and allocator settle before the W warm-up steps the caller asked for (reported as config.settle_steps;
+    # untimed like them -- a fresh box's first second of replays runs a few percent slow)
+    for _ in range(SETTLE_STEPS if not opt.eager else 0):
+        step()
     for i in range(opt.warmup):
         step()
         if i == 0:
@@ -512,6 +517,7 @@ def main():
                                       wl["v_feat_dim"], wl["t_feat_dim"], wl["vocab_size"] + 1),
                        "global_pairs": n_pairs * world, "parallelism": "dp%d" % world,
                        "launch": "eager" if opt.eager else "hip-graph", "ddp": ddp_mode,
+                       "settle_steps": 0 if opt.eager else SETTLE_STEPS,
                        "eager_ms_per_step_not_in_metric": eager_ms,
                        "optimizer_tail_ms_not_in_metric": opt_tail_ms,
                        "pcie_inclusive_not_in_metric": pcie,
