@@ -14,10 +14,13 @@ _TORCH = {np.dtype(np.int64): torch.int64, np.dtype(np.int32): torch.int32, np.d
 
 
 class Arena:
-    def __init__(self, arrays, device):
-        """arrays: {name: np.ndarray}; shapes and dtypes are fixed from here on."""
+    def __init__(self, arrays, device, first=()):
+        """arrays: {name: np.ndarray}; shapes and dtypes are fixed from here on.  first: names laid out at the front,
+        next to each other (what `upload(only=...)` refreshes on its own: one short copy)."""
         self.specs, off = [], 0
-        for name, a in arrays.items():
+        order = [n for n in first if n in arrays] + [n for n in arrays if n not in first]
+        for name in order:
+            a = arrays[name]
             a = np.ascontiguousarray(a)
             self.specs.append((name, a.shape, a.dtype, off, a.nbytes))
             off += (a.nbytes + 15) // 16 * 16
@@ -43,8 +46,15 @@ class Arena:
         """raise ValueError if `arrays` cannot be uploaded into this arena (nothing is modified)"""
         self._check(arrays)
 
-    def upload(self, arrays):
+    def upload(self, arrays, only=None):
+        """only: names whose values changed since the last full upload (everything else is already on the device):
+        the byte range that covers them is packed and copied instead of the whole arena."""
         self._check(arrays)
+        lo, hi = 0, self.nbytes
+        if only is not None:
+            hit = [(o, o + (nb + 15) // 16 * 16) for name, _, _, o, nb in self.specs if name in only]
+            if hit:
+                lo, hi = min(h[0] for h in hit), min(max(h[1] for h in hit), self.nbytes)
         if self.device.type != "cuda":
             host = self.dev.numpy()
             for name, _, _, o, nb in self.specs:
@@ -57,9 +67,12 @@ class Arena:
             ev.synchronize()  # the copy that used this mirror two uploads ago
         host = buf.numpy()
         for name, _, _, o, nb in self.specs:
-            if nb:
+            if nb and lo <= o < hi:
                 host[o:o + nb] = np.ascontiguousarray(arrays[name]).reshape(-1).view(np.uint8)
-        self.dev.copy_(buf, non_blocking=True)
+        if lo == 0 and hi == self.nbytes:
+            self.dev.copy_(buf, non_blocking=True)
+        else:
+            self.dev[lo:hi].copy_(buf[lo:hi], non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         self._pins[self._turn][1] = ev

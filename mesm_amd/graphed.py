@@ -57,6 +57,7 @@ def capture_stream(dev):
 
 class GraphedStep:
     BIG = 1 << 20  # batch tensors above 1 MiB (video_feat, word features) are copied on their own
+    DRAWN = ("p.neg_index", "p.masked_words")  # what redraw() changes: the host RNG draws of a step
 
     def __init__(self, model, criterion, batch, dataset_name, warmup=3, instrument=False, reducer=None,
                  caps=None, group_cap=None):
@@ -88,7 +89,7 @@ class GraphedStep:
         arr, self._pmeta, self._tmeta, self._wm_cpu = self._host_arrays(host, None, None)
         self._arr = arr  # host mirror of the arena
         self._draws = (arr["p.neg_index"], arr.get("p.masked_words"))
-        self.arena = Arena(arr, dev)
+        self.arena = Arena(arr, dev, first=self.DRAWN)  # the per-step draws sit together at the front
         v = self.arena.views
         self.plan = model.plan_from({k[2:]: t for k, t in v.items() if k.startswith("p.")}, self._pmeta)
         self.tplan = TargetPlan.__new__(TargetPlan)
@@ -351,7 +352,7 @@ class GraphedStep:
         self._arr["p.neg_index"] = neg
         if mw is not None:
             self._arr["p.masked_words"] = mw
-        self.arena.upload(self._arr)
+        self.arena.upload(self._arr, only=self.DRAWN)  # ~1 KB instead of the whole 57 KB arena
 
     def set_draws(self, neg_index, masked_words=None):
         """replay with given host draws (tests / reproducing a recorded step)"""
