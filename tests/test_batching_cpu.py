@@ -65,3 +65,24 @@ def test_prepare_batch_input_packs_one_transfer():
     assert all(e["spans"].is_cuda for e in prep["norm_span"])
     assert torch.equal(torch.cat([e["moments"] for e in prep["norm_moment"]]).cpu(),
                        torch.cat([e["moments"] for e in host["norm_moment"]]))
+
+
+def test_arena_layout_puts_the_drawn_arrays_first_and_cpu_upload_refreshes_everything():
+    """arena.Arena (the one-transfer home of a step's small tensors): `first` names lead the layout side by side;
+    on a CPU device an upload (full or `only=...`) rewrites the views in place."""
+    import numpy as np
+    from mesm_amd.arena import Arena
+    arr = {"a": np.arange(5, dtype=np.int64), "neg": np.arange(3, dtype=np.int64), "b": np.ones((2, 3), np.float32),
+           "mw": np.zeros((2, 4), np.bool_)}
+    ar = Arena(arr, "cpu", first=("neg", "mw"))
+    names = [s[0] for s in ar.specs]
+    assert names[:2] == ["neg", "mw"] and sorted(names) == sorted(arr)
+    offs = {s[0]: s[3] for s in ar.specs}
+    assert offs["neg"] == 0 and offs["mw"] == 32  # 24 bytes rounded up to the 16-byte grid
+    assert torch.equal(ar.views["a"], torch.arange(5)) and ar.views["b"].shape == (2, 3)
+    arr2 = dict(arr, neg=np.array([7, 8, 9], dtype=np.int64), mw=np.ones((2, 4), np.bool_))
+    ar.upload(arr2, only=("neg", "mw"))
+    assert ar.views["neg"].tolist() == [7, 8, 9] and bool(ar.views["mw"].all())
+    assert torch.equal(ar.views["a"], torch.arange(5))
+    with pytest.raises(ValueError):
+        ar.upload(dict(arr, neg=np.arange(4, dtype=np.int64)))

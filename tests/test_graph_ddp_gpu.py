@@ -413,3 +413,44 @@ def test_a_late_gradient_under_capture_refuses_the_graph():
         red.finish()
     finally:
         model.gradbuf().on_ready = None
+
+
+def test_arena_partial_upload_rewrites_only_the_named_range_and_redraw_uses_it():
+    """Arena.upload(only=...): the bytes of the named arrays (laid out first) change on the device, nothing else is
+    touched even when the host copy of another array differs; a replayed step with redraw=True then equals the
+    eager step run with the same draws (the graph reads the refreshed range)."""
+    import numpy as np
+    from mesm_amd.arena import Arena
+    arr = {"a": np.arange(5000, dtype=np.int64), "neg": np.arange(32, dtype=np.int64),
+           "mw": np.zeros((32, 32), np.bool_), "z": np.full(7, 3.5, np.float32)}
+    ar = Arena(arr, "cuda:0", first=("neg", "mw"))
+    arr2 = dict(arr, neg=np.arange(32, dtype=np.int64)[::-1].copy(), mw=np.ones((32, 32), np.bool_),
+                a=np.zeros(5000, dtype=np.int64))  # `a` differs on the host but is NOT named
+    ar.upload(arr2, only=("neg", "mw"))
+    torch.cuda.synchronize()
+    assert ar.views["neg"].tolist() == list(range(31, -1, -1)) and bool(ar.views["mw"].all())
+    assert torch.equal(ar.views["a"].cpu(), torch.arange(5000)) and ar.views["z"].tolist() == [3.5] * 7
+    for i in range(3):  # both pinned mirrors and back again
+        arr3 = dict(arr, neg=np.full(32, i, dtype=np.int64))
+        ar.upload(arr3, only=("neg",))
+        torch.cuda.synchronize()
+        assert ar.views["neg"].tolist() == [i] * 32 and torch.equal(ar.views["a"].cpu(), torch.arange(5000))
+    ar.upload(arr2)
+    torch.cuda.synchronize()
+    assert int(ar.views["a"].abs().sum()) == 0
+
+    from mesm_amd import synthetic
+    from mesm_amd.graphed import GraphedStep
+    args, model, crit = _build("C3a")
+    batch = synthetic.to_device(synthetic.workload_batch("C3a", seed=3), dev())
+    g = GraphedStep(model, crit, batch, args.dataset_name, warmup=1)
+    assert [s[0] for s in g.arena.specs][0] == "p.neg_index"
+    seen = []
+    for _ in range(3):
+        t1 = float(g.run(redraw=True))  # the draws go up as a short range
+        neg, mw = g._draws
+        g.set_draws(torch.from_numpy(neg), torch.from_numpy(mw) if mw is not None else None)  # same draws, whole arena
+        t2 = float(g.run(redraw=False))
+        assert abs(t1 - t2) <= 1e-6 * abs(t2), (t1, t2)
+        seen.append(t1)
+    assert len(set(seen)) > 1  # other negatives / masked words: another loss
