@@ -449,8 +449,10 @@ def main():
     if families is not None:
         # SURVEY 8d byte split of C3a (kernel-boundary traffic per step): attention cores 0.45 GB, LayerNorm 0.65 GB;
         # achieved fraction of the 8 TB/s HBM roofline of those two HBM-bound families, from their in-situ time
-        roofline["attention_hbm_frac"] = 0.45e9 / (families["attention_ms"] * 1e-3) / (PEAK_HBM_TBS * 1e12)
-        roofline["layernorm_hbm_frac"] = 0.65e9 / (families["layernorm_ms"] * 1e-3) / (PEAK_HBM_TBS * 1e12)
+        def _hbm_frac(nbytes, ms):  # None rather than an exception: informational sections never take the line down
+            return nbytes / (ms * 1e-3) / (PEAK_HBM_TBS * 1e12) if isinstance(ms, (int, float)) and ms > 0 else None
+        roofline["attention_hbm_frac"] = _hbm_frac(0.45e9, families.get("attention_ms"))
+        roofline["layernorm_hbm_frac"] = _hbm_frac(0.65e9, families.get("layernorm_ms"))
 
     # EXPERIMENTAL, never the headline (value / dtype above are exact f32): the same step with the large GEMMs' products
     # on v_mfma_f32_32x32x16_bf16 over operands split into bf16 terms (gemm.hip: SplitFrag; MESM_GEMM_BF16X = 6 | 3),

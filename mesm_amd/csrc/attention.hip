@@ -639,6 +639,11 @@ extern "C" int mesm_attn_bwd_group(const MesmAttnArgs* list, int32_t n, void* st
     if (lane_per_key && blk_bwd_enabled() && mesm_attn_blk_bwd_groupable(a)) {
       blk[nblk++] = a;
       if (nblk == 8) flush();
+    } else if (lane_per_key && blk_bwd_enabled() &&
+               (mesm_attn_blk_bwd_ok(a) || (a.Lk > 128 && mesm_attn_blk_bwd_long_ok(a)))) {
+      // a block kernel takes it when issued alone and WRITES dq (mesm_attn_bwd_accumulates_dq says 0 for it, so the
+      // caller hands in uninitialised memory): it must never reach the lane-per-key group, which ADDS into dq
+      rc = mesm_attn_bwd(&a, stream);
     } else if (lane_per_key && a.dk == 32 && a.dv == 32 && !a.q2) {
       g.p[g.n] = a;
       g.start[g.n + 1] = g.start[g.n] + a.B * a.H * ((a.Lk + KT - 1) / KT);

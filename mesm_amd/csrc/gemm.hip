@@ -108,6 +108,7 @@ struct SidePending {
   const float* ws;
   float* dst;
   int n;
+  hipStream_t stream;  // the stream the producing launch went to: only a launch on the SAME stream may carry it
 };
 std::vector<SidePending> g_side;
 const bool g_side_on = getenv("MESM_DSLOPE_LAUNCH") == nullptr;  // MESM_DSLOPE_LAUNCH=1: one launch per reduction (A/B)
@@ -116,28 +117,31 @@ inline int dslope_finish(const MesmGemmArgs& a, dim3 grid, hipStream_t s) {
   if (a.e_actgrad != MESM_ACT_PRELU || !a.dslope) return MESM_OK;
   const int64_t n = (int64_t)grid.x * grid.y * grid.z;
   if (g_side_on && n < (1 << 30)) {
-    g_side.push_back({a.dslope_ws, a.dslope, (int)n});
+    g_side.push_back({a.dslope_ws, a.dslope, (int)n, s});
     return MESM_OK;
   }
   hipLaunchKernelGGL(dslope_reduce_kernel, dim3(1), dim3(256), 0, s, a.dslope_ws, n, a.dslope);
   return mesm_launch_status();
 }
 
-// up to four pending reductions for the launch that is about to be issued
-inline SideRed take_side() {
+// up to four pending reductions for the launch that is about to be issued on stream s (stream order is what makes
+// the partials visible to it: entries produced on another stream stay queued for mesm_gemm_flush_side)
+inline SideRed take_side(hipStream_t s) {
   SideRed sr = {};
-  while (sr.count < 4 && !g_side.empty()) {
-    const SidePending e = g_side.front();
-    g_side.erase(g_side.begin());
+  for (size_t i = 0; i < g_side.size() && sr.count < 4;) {
+    if (g_side[i].stream != s) { ++i; continue; }
+    const SidePending e = g_side[i];
+    g_side.erase(g_side.begin() + i);
     sr.ws[sr.count] = e.ws; sr.dst[sr.count] = e.dst; sr.n[sr.count] = e.n;
     ++sr.count;
   }
   return sr;
 }
 
-inline int flush_side(hipStream_t s) {
+// every pending reduction with a launch of its own, each on the stream that produced its partials
+inline int flush_side(hipStream_t) {
   for (const SidePending& e : g_side)
-    hipLaunchKernelGGL(dslope_reduce_kernel, dim3(1), dim3(256), 0, s, e.ws, (int64_t)e.n, e.dst);
+    hipLaunchKernelGGL(dslope_reduce_kernel, dim3(1), dim3(256), 0, e.stream, e.ws, (int64_t)e.n, e.dst);
   const bool any = !g_side.empty();
   g_side.clear();
   return any ? mesm_launch_status() : MESM_OK;
@@ -1365,7 +1369,7 @@ int launch_wstage_l(const MesmGemmArgs& a, hipStream_t s) {
   dim3 grid(((a.M + 31) / 32) * ((a.N + 31) / 32), 1, a.split_k > 1 ? a.split_k : 1);  // 1-D: xcd_tile() maps it
   const bool xf = a.a_act != MESM_ACT_NONE || a.b_act != MESM_ACT_NONE || a.a_drop_p > 0.f || a.b_drop_p > 0.f;
   const bool one = ws_stages_for(a) == 1;
-  const SideRed sr = take_side();
+  const SideRed sr = take_side(s);
   if (xf && one) hipLaunchKernelGGL((gemm_wstage_kernel<LA, LB, true, 1>), grid, dim3(WS_THREADS), 0, s, a, sr);
   else if (xf) hipLaunchKernelGGL((gemm_wstage_kernel<LA, LB, true, 2>), grid, dim3(WS_THREADS), 0, s, a, sr);
   else if (one) hipLaunchKernelGGL((gemm_wstage_kernel<LA, LB, false, 1>), grid, dim3(WS_THREADS), 0, s, a, sr);
@@ -1651,7 +1655,7 @@ int launch_wstage64_l(const MesmGemmArgs& a, hipStream_t s) {
   dim3 grid(((a.M + 63) / 64) * ((a.N + 63) / 64), 1, a.split_k > 1 ? a.split_k : 1);  // 1-D: xcd_tile() maps it
   const bool xf = a.a_act != MESM_ACT_NONE || a.b_act != MESM_ACT_NONE || a.a_drop_p > 0.f || a.b_drop_p > 0.f;
   const int bf = xf ? 0 : bf16x_mode();
-  const SideRed sr = take_side();
+  const SideRed sr = take_side(s);
   if (bf == 6) hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, false, 6>), grid, dim3(NTHREADS), 0, s, a, sr);
   else if (bf == 3) hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, false, 3>), grid, dim3(NTHREADS), 0, s, a, sr);
   else if (xf) hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, true>), grid, dim3(NTHREADS), 0, s, a, sr);
@@ -2139,7 +2143,7 @@ template <int LA, int LB>
 int launch_lds64_l(const MesmGemmArgs& a, hipStream_t s) {
   dim3 grid(((a.M + 63) / 64) * ((a.N + 63) / 64), 1, a.split_k > 1 ? a.split_k : 1);  // 1-D: xcd_tile() maps it
   const bool xf = a.a_act != MESM_ACT_NONE || a.b_act != MESM_ACT_NONE || a.a_drop_p > 0.f || a.b_drop_p > 0.f;
-  const SideRed sr = take_side();
+  const SideRed sr = take_side(s);
   if (xf) hipLaunchKernelGGL((gemm_lds64_kernel<LA, LB, true>), grid, dim3(NTHREADS), 0, s, a, sr);
   else hipLaunchKernelGGL((gemm_lds64_kernel<LA, LB, false>), grid, dim3(NTHREADS), 0, s, a, sr);
   const int rc = mesm_launch_status();
@@ -2662,7 +2666,7 @@ int launch_group(const MesmGemmArgs* list, const int* vecs, int n, hipStream_t s
     } else {
       bool one = true;  // single-stage staging only if every problem of the group wants it
       for (int k = 0; k < g.n; ++k) one = one && ws_stages_for(g.p[k]) == 1;
-      const SideRed sr = take_side();
+      const SideRed sr = take_side(s);
       if (one) hipLaunchKernelGGL(gemm_wstage_group_kernel<1>, dim3(g.start[g.n]), dim3(WS_THREADS), 0, s, g, sr);
       else hipLaunchKernelGGL(gemm_wstage_group_kernel<2>, dim3(g.start[g.n]), dim3(WS_THREADS), 0, s, g, sr);
       rc = mesm_launch_status();

@@ -268,10 +268,16 @@ class phase:
         if self.outer is not None:  # nested: the outermost phase launches
             return False
         ph, _phase = _phase, None
-        if et is None:
+        if et is not None:
+            gemm_drop_side()  # the workspaces of pending slope-gradient reductions die with the failed block
+            return False
+        try:
             ph.flush()
             if _side_defer == 0:
                 gemm_flush_side()
+        except BaseException:
+            gemm_drop_side()
+            raise
         return False
 
 

@@ -133,15 +133,10 @@ class CLIPTextEncoder(nn.Module):
         # text_encoder.py:352-354: the features of the end-of-text token (the largest id) through text_projection,
         # fp16 like the rest of the tower (MESM itself only reads last_hidden_state)
         eos = x[torch.arange(N, device=x.device), text.argmax(dim=-1)]
-        pt = self._proj_t
-        if pt is None or pt.data_ptr() != self._proj_src or pt.device != x.device:
-            pt = self._proj_t = self.text_projection.detach().t().contiguous()
-            self._proj_src = pt.data_ptr()
-        pooled = kn.gemm_f16(eos.contiguous(), pt)
+        # the transposed operand is rebuilt per call: a (W x E) one-off, and a cache keyed on the source tensor would have
+        # to see load_state_dict / convert_weights / .half() / in-place updates of text_projection
+        pooled = kn.gemm_f16(eos.contiguous(), self.text_projection.detach().to(torch.float16).t().contiguous())
         return dict(last_hidden_state=x, pooler_output=pooled)
-
-    _proj_t = None
-    _proj_src = None
 
 
 def convert_weights(model):

@@ -36,7 +36,9 @@ from scipy.optimize import linear_sum_assignment
 
 
 def _lin(x, sd, prefix):
-    return x @ sd[prefix + ".weight"].t() + sd[prefix + ".bias"]
+    w = sd[prefix + ".weight"]
+    # (x follows the parameters' dtype: the fp64 adjudication run of train_step64 feeds fp32 sine tables)
+    return x.to(w.dtype) @ w.t() + sd[prefix + ".bias"]
 
 
 def _ln(x, sd, prefix, eps=1e-5):
@@ -631,6 +633,26 @@ def criterion_forward(out, targets, cfg, is_training=True):
     wd = weight_dict(cfg)
     total = sum(losses[k] * wd[k] for k in losses if k in wd)
     return losses, total, all_idx
+
+
+def train_step64(sd, cfg, batch, neg_index, masked_words):
+    """train_step with every floating tensor in fp64: the referee when the fp32 oracle and the device disagree on a
+    gradient -- an activation whose pre-activation is within fp32 rounding of zero has no defined fp32 side (the sign of
+    z, hence the PReLU / ReLU derivative, depends on the summation order of the GEMM that produced it)."""
+    def up(x):
+        if torch.is_tensor(x):
+            return x.double() if x.is_floating_point() else x
+        if isinstance(x, dict):
+            return {k: up(v) for k, v in x.items()}
+        if isinstance(x, (list, tuple)):
+            return type(x)(up(v) for v in x)
+        return x
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float64)
+    try:
+        return train_step(up(sd), cfg, up(batch), neg_index, masked_words)
+    finally:
+        torch.set_default_dtype(old)
 
 
 def train_step(sd, cfg, batch, neg_index, masked_words):

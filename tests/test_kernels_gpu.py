@@ -357,6 +357,32 @@ def test_attention_fwd_bwd(B, H, Lq, Lk, dk, dv, use_kpad, quirk):
     assert rel_err(dv_, vd.grad) < TOL
 
 
+def test_two_long_attention_backwards_in_one_phase():
+    """with Lk > 128 and a head too large to stage, mesm_attn_bwd alone takes the dq-WRITING long block kernel
+    (attn_bwd_adds_dq == False, so callers hand in uninitialised dq); two such problems in ONE launch phase used to fall
+    into the lane-per-key GROUP kernel, which ADDS into dq.  dq starts as NaN here: any add shows."""
+    from mesm_amd import kernels as kn
+    B, H, Lq, Lk, dk = 2, 4, 150, 256, 32
+    probs = []
+    for i in range(2):
+        q, k, v = gen((B, Lq, H * dk), 70 + i), gen((B, Lk, H * dk), 72 + i), gen((B, Lk, H * dk), 74 + i)
+        o, lse = kn.attn_fwd(q, k, v, H)
+        do = gen((B, Lq, H * dk), 76 + i)
+        adds = kn.attn_bwd_adds_dq(B, H, Lq, Lk, dk, dk)
+        dq = torch.zeros_like(q) if adds else torch.full_like(q, float("nan"))
+        probs.append((q, k, v, o, lse, do, dq, torch.empty_like(k), torch.empty_like(v)))
+    with kn.phase():
+        for q, k, v, o, lse, do, dq, dk_, dv_ in probs:
+            kn.attn_bwd_into(do, q, k, v, o, lse, H, dq, dk_, dv_)
+    for q, k, v, o, lse, do, dq, dk_, dv_ in probs:
+        qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+        ref, _ = attn_reference(qd, kd, vd, H, None, None, dk ** -0.5)
+        ref.backward(do.double())
+        assert rel_err(dq, qd.grad) < TOL
+        assert rel_err(dk_, kd.grad) < TOL
+        assert rel_err(dv_, vd.grad) < TOL
+
+
 def test_attention_dropout_is_consistent_between_fwd_and_bwd():
     from mesm_amd import kernels as kn
     B, H, Lq, Lk, dk = 4, 8, 30, 90, 32

@@ -24,8 +24,8 @@ def l2(a, b):
     return float((a - b).norm()) / max(float(b.norm()), 1e-3 * b.numel() ** 0.5)
 
 
-def fuzz_case(rng, case):
-    """one random configuration -> (description, 'ok' | 'MISMATCH ...' | 'ERROR ...')"""
+def draw(rng, case):
+    """draw one random configuration -> (description, spec); consumes the same rng stream whether or not the case is run"""
     dataset = rng.choice(["qvhighlights", "charades", "tacos"])
     ngroups = rng.randint(2, 5)
     groups = [rng.randint(1, 3) for _ in range(ngroups)]
@@ -49,31 +49,62 @@ def fuzz_case(rng, case):
         case, dataset, groups, Lv, Lw, d, heads, over["dim_feedforward"], over["num_queries"], over["rec_fw"], over["rec_ss"],
         over["aux_loss"], over["use_txt_pos"], over["n_input_proj"], over["t2v_layers"], over["enc_layers"], over["dec_layers"],
         over["num_recfw_layers"], over["num_recss_layers"], ragged, seed)
+    return tag, dict(dataset=dataset, groups=groups, Lv=Lv, Lw=Lw, over=over, ragged=ragged, seed=seed)
+
+
+def build(spec):
+    """model, criterion, batch and the two host draws of a drawn configuration (everything seeded by spec['seed'])"""
+    over, seed, dataset = spec["over"], spec["seed"], spec["dataset"]
+    args = synthetic.make_args(None, **over)
+    torch.manual_seed(seed)
+    model = build_model(args)
+    with torch.no_grad():
+        for n_, p in model.named_parameters():
+            if n_.endswith("_token") or "masked_sent_token" in n_:
+                p.normal_(0, 0.5)
+            if n_.endswith("activation.weight"):
+                p.uniform_(0.1, 0.4)
+    crit = build_criterion(args)
+    batch = synthetic.make_batch(dataset, spec["groups"], spec["Lv"], spec["Lw"], over["v_feat_dim"], over["t_feat_dim"],
+                                 over["vocab_size"] + 1, seed=seed, ragged=spec["ragged"])
+    neg, masked = synthetic.host_draws(batch, seed=seed)
+    if not over["rec_fw"]:
+        masked = None
+    model.eval()
+    return args, model, crit, batch, neg, masked
+
+
+def hip_step(model, crit, batch, dataset, neg, masked):
+    """one forward + criterion + backward of the HIP path -> (outputs, losses, total, {name: grad})"""
+    b = synthetic.to_device(batch, dev)
+    out = model(**b, dataset_name=dataset, is_training=True, neg_index=neg, masked_words=masked)
+    losses, total = crit(out, b, True)
+    model.zero_grad()
+    total.backward()
+    torch.cuda.synchronize()
+    grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    return out, losses, total, grads
+
+
+def dump_case(case, spec, sd, batch, neg, masked, grads, o_grads, where=None):
+    """everything needed to replay a mismatching case off-line: configuration, state dict, inputs, both gradient sets"""
+    where = where or os.path.join(ROOT, "gpurun_out", "fuzz_dump_case%d.pt" % case)
+    os.makedirs(os.path.dirname(where), exist_ok=True)
+    torch.save(dict(case=case, spec=spec, state_dict=sd, batch=batch, neg=neg, masked=masked,
+                    hip_grads={k: v.detach().cpu() for k, v in grads.items()},
+                    oracle_grads={k: v.detach().cpu() for k, v in o_grads.items()}), where)
+    return where
+
+
+def fuzz_case(rng, case):
+    """one random configuration -> (description, 'ok' | 'MISMATCH ...' | 'ERROR ...')"""
+    tag, spec = draw(rng, case)
     if ONLY and case not in ONLY:
         return tag, "ok"  # (FUZZ_ONLY: configurations are still drawn in order)
+    dataset, over, groups, Lv, Lw, ragged, seed = (spec[k] for k in ("dataset", "over", "groups", "Lv", "Lw", "ragged", "seed"))
     try:
-        args = synthetic.make_args(None, **over)
-        torch.manual_seed(seed)
-        model = build_model(args)
-        with torch.no_grad():
-            for n_, p in model.named_parameters():
-                if n_.endswith("_token") or "masked_sent_token" in n_:
-                    p.normal_(0, 0.5)
-                if n_.endswith("activation.weight"):
-                    p.uniform_(0.1, 0.4)
-        crit = build_criterion(args)
-        batch = synthetic.make_batch(dataset, groups, Lv, Lw, over["v_feat_dim"], over["t_feat_dim"], over["vocab_size"] + 1,
-                                     seed=seed, ragged=ragged)
-        neg, masked = synthetic.host_draws(batch, seed=seed)
-        if not over["rec_fw"]:
-            masked = None
-        model.eval()
-        b = synthetic.to_device(batch, dev)
-        out = model(**b, dataset_name=dataset, is_training=True, neg_index=neg, masked_words=masked)
-        losses, total = crit(out, b, True)
-        model.zero_grad()
-        total.backward()
-        torch.cuda.synchronize()
+        args, model, crit, batch, neg, masked = build(spec)
+        out, losses, total, grads = hip_step(model, crit, batch, dataset, neg, masked)
         sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
         o_out, o_losses, o_total, o_grads, o_idx = O.train_step(sd, dict(vars(args)), batch, neg, masked)
         errs = []
@@ -113,14 +144,25 @@ def fuzz_case(rng, case):
                 errs.append("matcher differs, cost gap %.3e" % gap)
             else:
                 print("   (case %d: assignments differ at a cost tie, gap %.2e)" % (case, gap))
-        grads = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
         if set(grads) != set(o_grads):
             errs.append("grad key set differs: %s" % sorted(set(grads) ^ set(o_grads))[:4])
         else:
             w = max((l2(grads[k], g), k) for k, g in o_grads.items())
             if not w[0] < 5e-3:
+                # referee: the oracle in fp64.  A pre-activation within fp32 rounding of zero has no defined fp32 sign
+                # (profiles/r4a/fuzz_case14.md: z = -6.0e-07 in fp64, the fp32 oracle's sign depended on what its BLAS did
+                # with the buffers the preceding cases left behind); the device has to agree with the exact run.
+                g64 = O.train_step64(sd, dict(vars(args)), batch, neg, masked)[3]
+                w64 = max((l2(grads[k], g.float()), k) for k, g in g64.items())
+                if w64[0] < 5e-3:
+                    print("   (case %d: fp32 oracle off by %.2e on %s, device within %.2e of the fp64 oracle: activation kink)"
+                          % (case, w[0], w[1], w64[0]))
+                    w = w64
+            if not w[0] < 5e-3:
                 errs.append("grad L2 %s %.2e (norms %.3e vs %.3e)" % (w[1], w[0], float(grads[w[1]].norm()), float(o_grads[w[1]].norm())))
         status = "ok" if not errs else "MISMATCH " + "; ".join(errs[:6])
+        if errs and os.environ.get("FUZZ_DUMP", "1") != "0":
+            print("   (case %d dumped to %s)" % (case, dump_case(case, spec, sd, batch, neg, masked, grads, o_grads)))
     except Exception as e:  # noqa: BLE001
         status = "ERROR %s: %s" % (type(e).__name__, str(e)[:200])
     return tag, status
