@@ -29,7 +29,7 @@ def sources():
 
 def _deps():
     deps = [os.path.join(INCLUDE, "mesm_gfx950.h")]
-    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inl"))]
     return deps
 
 

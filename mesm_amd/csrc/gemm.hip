@@ -15,58 +15,13 @@
 #include <vector>
 
 #include <cstddef>
-#include "common.hpp"
+#include "gemm_common.hpp"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int NTHREADS = 256;
-constexpr int BK_MAX = 64;  // split-K chunks and the tail granularity are multiples of this
-
-struct XForm {
-  int act;
-  float slope;
-  uint32_t thresh;  // 0 => no dropout
-  uint32_t seed;
-  float inv_keep;
-  int64_t lld;  // logical row length for the dropout index
-};
-
-// PReLU slope gradient: every workgroup stores ONE partial sum (plain store) into the workspace
-// slot of its linear block id and a 1-workgroup kernel adds them into the parameter gradient.
-// (One float atomic per wave on the single dslope address cost +45 us per GEMM: same-address
-// atomics serialise at the memory side.)
-__device__ __forceinline__ int64_t linear_block() {
-  return ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-}
-
-// XCD-aware tile order.  Workgroups are dealt round-robin to the 8 XCDs (private 4 MB L2 each) by
-// their linear id.  With the natural (x = M-tile fastest) order the N-tiles of one M-tile land on 8
-// different XCDs whenever gridDim.x % 8 != 0, so every A tile was fetched into up to 8 L2s (PMC: 4 x the
-// algorithmic HBM-side traffic on the GEMMs).  Remap: XCD c owns a CONTIGUOUS range of logical tiles,
-// and logical tiles run N-fastest, so all column tiles of a row tile share one L2.
-__device__ __forceinline__ void xcd_tile(int lid, int mt, int nt, int& bx, int& by) {
-  const int total = mt * nt;
-  const int xcd = lid & 7, idx = lid >> 3;
-  const int q = total >> 3, r = total & 7;
-  const int t = xcd * q + (xcd < r ? xcd : r) + idx;  // bijection on [0, total)
-  bx = t / nt;
-  by = t - bx * nt;
-}
-
-__device__ __forceinline__ void dslope_store(const MesmGemmArgs& p, float part, float* sh4, int64_t slot) {
-  part = wave_sum(part);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  __syncthreads();
-  if (lane == 0) sh4[wave] = part;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float t = 0.0f;
-    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh4[w];
-    p.dslope_ws[slot] = t;
-  }
-}
+int mesm_gemm_force_tile();  // MESM_GEMM_TILE / MESM_GEMM_BF16X, read once at load (definitions next to dispatch)
+int mesm_gemm_bf16x();
 
 __global__ __launch_bounds__(256) void dslope_reduce_kernel(const float* __restrict__ ws, int64_t n,
                                                             float* __restrict__ dst) {
@@ -113,15 +68,18 @@ struct SidePending {
 std::vector<SidePending> g_side;
 const bool g_side_on = getenv("MESM_DSLOPE_LAUNCH") == nullptr;  // MESM_DSLOPE_LAUNCH=1: one launch per reduction (A/B)
 
-inline int dslope_finish(const MesmGemmArgs& a, dim3 grid, hipStream_t s) {
+inline int dslope_finish_n(const MesmGemmArgs& a, int64_t n, hipStream_t s) {
   if (a.e_actgrad != MESM_ACT_PRELU || !a.dslope) return MESM_OK;
-  const int64_t n = (int64_t)grid.x * grid.y * grid.z;
   if (g_side_on && n < (1 << 30)) {
     g_side.push_back({a.dslope_ws, a.dslope, (int)n, s});
     return MESM_OK;
   }
   hipLaunchKernelGGL(dslope_reduce_kernel, dim3(1), dim3(256), 0, s, a.dslope_ws, n, a.dslope);
   return mesm_launch_status();
+}
+
+inline int dslope_finish(const MesmGemmArgs& a, dim3 grid, hipStream_t s) {
+  return dslope_finish_n(a, (int64_t)grid.x * grid.y * grid.z, s);
 }
 
 // up to four pending reductions for the launch that is about to be issued on stream s (stream order is what makes
@@ -578,8 +536,7 @@ int launch_tile(const MesmGemmArgs& a, hipStream_t s) {
   const long z = a.split_k > 1 ? a.split_k : 1;
   auto blocks = [&](int t) { return (long)((a.M + t - 1) / t) * ((a.N + t - 1) / t) * z; };
   // tuning knob (tools/gemm_bench4.py): MESM_GEMM_TILE=32|64|128 pins the configuration
-  const char* force_env = getenv("MESM_GEMM_TILE");
-  const int force_tile = force_env ? atoi(force_env) : 0;
+  const int force_tile = mesm_gemm_force_tile();
   if (force_tile == 128 && add == 0) return launch_layout<128, 128, VEC, 0>(a, s);
   if (force_tile == 64) {
     if (add == 0) return launch_layout<64, 64, VEC, 0>(a, s);
@@ -602,223 +559,6 @@ int launch_tile(const MesmGemmArgs& a, hipStream_t s) {
   if (add == 0) return launch_layout<32, 32, VEC, 0>(a, s);
   if (add == 1) return launch_layout<32, 32, VEC, 1>(a, s);
   return launch_layout<32, 32, VEC, 2>(a, s);
-}
-
-inline bool aligned_to(const void* p, size_t b) { return p == nullptr || ((uintptr_t)p % b) == 0; }
-
-// Reduce indices [gemm_kmain, K) are NOT staged by the LDS-DMA kernels (wstage / wstage64 / lds64):
-//  * a reduce-contiguous operand is staged in 16-byte chunks along k: the main loop ends at K & ~3;
-//  * an outer-contiguous operand whose outer extent is not a multiple of 4 has one chunk per reduce row
-//    that runs 1-3 floats into the NEXT reduce row (harmless: those outer positions are never stored);
-//    for the last reduce row that would be past the end of the matrix, so the main loop stops before it.
-// The remaining 1-4 indices are added to the accumulators by scalar loads (tail_accumulate).
-__device__ __forceinline__ int gemm_kmain(const MesmGemmArgs& p) {
-  const bool a_red = p.a_layout == MESM_LAYOUT_REDUCE_CONTIG, b_red = p.b_layout == MESM_LAYOUT_REDUCE_CONTIG;
-  int km = p.K;
-  if (a_red || b_red) km &= ~3;
-  if ((!a_red && (p.M & 3)) || (!b_red && (p.N & 3))) {
-    const int lim = (p.K - 1) & ~3;
-    km = km < lim ? km : lim;
-  }
-  return km;
-}
-
-// operand element (outer index o, reduce index k) with the operand transform of the main loop
-template <int LAYOUT, bool XF>
-__device__ __forceinline__ float tail_elem(const float* __restrict__ base, int64_t ld, int o, int k, const XForm& xf) {
-  float x = LAYOUT == MESM_LAYOUT_REDUCE_CONTIG ? base[(int64_t)o * ld + k] : base[(int64_t)k * ld + o];
-  if (XF) {
-    x = mesm_act(x, xf.act, xf.slope);
-    if (xf.thresh)
-      x = mesm_dropout_apply(x, (uint32_t)(LAYOUT == MESM_LAYOUT_REDUCE_CONTIG ? (int64_t)o * xf.lld + k : (int64_t)k * xf.lld + o),
-                             xf.seed, xf.thresh, xf.inv_keep);
-  }
-  return x;
-}
-
-// t[i] += sum over k in [km, K) of A(rbase + RO(i), k) * B(col, k)   (rows / columns clamped into the matrix)
-template <int NV, int LA, int LB, bool XF, typename RowOff>
-__device__ __forceinline__ void tail_accumulate(const MesmGemmArgs& p, float (&t)[NV], int rbase, int col, int km,
-                                                const XForm& xa, const XForm& xb, RowOff RO) {
-  const int colc = col < p.N ? col : p.N - 1;
-  for (int k = km; k < p.K; ++k) {
-    const float y = tail_elem<LB, XF>(p.B, p.ldb, colc, k, xb);
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      int row = rbase + RO(i);
-      row = row < p.M ? row : p.M - 1;
-      t[i] += tail_elem<LA, XF>(p.A, p.lda, row, k, xa) * y;
-    }
-  }
-}
-
-// Epilogue of NV accumulator values per lane: value i belongs to row rbase + RO(i) (RO = row offset
-// table of the MFMA 32x32 accumulator layout) and column col.  Written in STAGES over the whole
-// register array -- scale+bias, activation, dropout, activation-gradient, residual / read-modify-write,
-// store -- so that every run-time flag of MesmGemmArgs is tested once per wave, not once per element, and
-// the side loads of a stage are all in flight together; row addresses are one per-lane 64-bit base plus
-// wave-uniform multiples of the leading dimension.  (In-kernel stamps, tools/l64_trace.py: the
-// per-element form took ~8,000 cycles per 32x32 tile, as long as 3.5 k-tiles of MFMA work.)
-// FULL: the wave's 32 x 32 tile lies inside C, no bounds handling at all.
-template <int NV, bool FULL, typename RowOff>
-__device__ __forceinline__ float staged_epilogue(const MesmGemmArgs& p, float (&t)[NV], int rbase, int col,
-                                                 float slope, uint32_t seed_off, bool first_split, RowOff RO) {
-  const bool colok = FULL || col < p.N;
-  const int colc = colok ? col : p.N - 1;
-  bool ok[NV];
-#pragma unroll
-  for (int i = 0; i < NV; ++i) ok[i] = FULL || (colok && rbase + RO(i) < p.M);
-  // element offset of value i in a row-major side matrix with leading dimension ld, clamped into the matrix
-  auto off = [&](int i, int64_t lane_base, int64_t ld) -> int64_t {
-    const int64_t o = lane_base + (int64_t)RO(i) * ld;
-    if (FULL) return o;
-    const int64_t last = (int64_t)(p.M - 1) * ld + colc;
-    return o < last ? o : last;
-  };
-
-  const float bias_v = (p.bias != nullptr && first_split) ? p.bias[colc] : 0.0f;
-  const float sc = p.out_scale;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) t[i] = t[i] * sc + bias_v;
-  if (p.pre_out != nullptr) {  // second output: the pre-activation (what the backward's e_actgrad reads as aux)
-    float* pp = p.pre_out + ((int64_t)rbase * p.ldpre + col);
-#pragma unroll
-    for (int i = 0; i < NV; ++i)
-      if (ok[i]) pp[(int64_t)RO(i) * p.ldpre] = t[i];
-  }
-  if (p.e_act != MESM_ACT_NONE) {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) t[i] = mesm_act(t[i], p.e_act, slope);
-  }
-  if (p.e_drop_p > 0.f) {
-    const uint32_t thresh = mesm_drop_threshold(p.e_drop_p);
-    const float inv_keep = 1.0f / (1.0f - p.e_drop_p);
-    const uint32_t seed = p.e_drop_seed + seed_off;
-    // dense index of C, modulo 2^32 (e_drop_row0: this launch computes rows [row0, row0 + M) of a taller C)
-    const uint32_t idx0 = (uint32_t)(rbase + p.e_drop_row0) * (uint32_t)p.N + (uint32_t)col;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) t[i] = mesm_dropout_apply(t[i], idx0 + (uint32_t)RO(i) * (uint32_t)p.N, seed, thresh, inv_keep);
-  }
-  float dslope_part = 0.0f;
-  if (p.e_actgrad != MESM_ACT_NONE) {
-    const int64_t lb = (int64_t)rbase * p.ldaux + colc;
-    float z[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) z[i] = p.aux[off(i, lb, p.ldaux)];
-    if (p.e_actgrad == MESM_ACT_RELU) {
-#pragma unroll
-      for (int i = 0; i < NV; ++i) t[i] = z[i] > 0.0f ? t[i] : 0.0f;
-    } else {
-#pragma unroll
-      for (int i = 0; i < NV; ++i)
-        if (z[i] <= 0.0f) {
-          if (ok[i]) dslope_part += t[i] * z[i];
-          t[i] *= slope;
-        }
-    }
-  }
-  const bool use_res = p.residual != nullptr && first_split;
-  const bool rmw = p.accumulate == 1;
-  if (use_res || rmw) {
-    float add[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) add[i] = 0.0f;
-    if (use_res) {
-      const int64_t lb = (int64_t)rbase * p.ldr + colc;
-#pragma unroll
-      for (int i = 0; i < NV; ++i) add[i] = p.residual[off(i, lb, p.ldr)];
-    }
-    if (rmw) {
-      const int64_t lb = (int64_t)rbase * p.ldc + colc;
-#pragma unroll
-      for (int i = 0; i < NV; ++i) add[i] += p.C[off(i, lb, p.ldc)];
-    }
-#pragma unroll
-    for (int i = 0; i < NV; ++i) t[i] += add[i];
-  }
-  float* cp = p.C + ((int64_t)rbase * p.ldc + col);
-  if (p.accumulate == 2) {
-#pragma unroll
-    for (int i = 0; i < NV; ++i)
-      if (ok[i]) atomicAdd(cp + (int64_t)RO(i) * p.ldc, t[i]);
-  } else {
-#pragma unroll
-    for (int i = 0; i < NV; ++i)
-      if (ok[i]) cp[(int64_t)RO(i) * p.ldc] = t[i];
-  }
-  return dslope_part;
-}
-
-// Epilogue shared by the k-split kernels: the four waves hold partial sums of the same 32x32 tile;
-// they meet in LDS (Red: 4 x 16 x 64 floats) and wave w takes accumulator registers [4w, 4w+4)
-// (rows 4h + rr + 8w) through the staged epilogue.
-template <int LA, int LB, bool XF, int NW = 4>
-__device__ __forceinline__ void ksplit_epilogue(const MesmGemmArgs& p, const f32x16& acc, float* Red, int m0,
-                                                int n0, float slope, uint32_t seed_off, int bz, int64_t slot,
-                                                int km, const XForm& xa, const XForm& xb) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int li = lane & 31, h = lane >> 5;
-  constexpr int NV = 16 / NW;  // accumulator registers per wave after the cross-wave sum
-  float vals[NV];
-  if (NW > 1) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) Red[(wave * 16 + r) * 64 + lane] = acc[r];
-    __syncthreads();
-    const int r0 = wave * NV;
-#pragma unroll
-    for (int rr = 0; rr < NV; ++rr) {
-      float t = 0.0f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) t += Red[(w * 16 + r0 + rr) * 64 + lane];
-      vals[rr] = t;
-    }
-  } else {
-#pragma unroll
-    for (int rr = 0; rr < NV; ++rr) vals[rr] = acc[rr];
-  }
-  const bool first_split = (p.split_k <= 1) || (bz == 0);
-  // register r <-> row 4h + (r & 3) + 8 (r >> 2); this wave owns registers [wave * NV, wave * NV + NV)
-  const int r0 = wave * NV;
-  const int rbase = m0 + 4 * h + (r0 & 3) + 8 * (r0 >> 2);
-  auto RO = [](int i) { return NV <= 4 ? i : (i & 3) + 8 * (i >> 2); };
-  if (first_split && km < p.K) tail_accumulate<NV, LA, LB, XF>(p, vals, rbase, n0 + li, km, xa, xb, RO);
-  float dslope_part;
-  if (m0 + 32 <= p.M && n0 + 32 <= p.N)
-    dslope_part = staged_epilogue<NV, true>(p, vals, rbase, n0 + li, slope, seed_off, first_split, RO);
-  else
-    dslope_part = staged_epilogue<NV, false>(p, vals, rbase, n0 + li, slope, seed_off, first_split, RO);
-  if (p.e_actgrad == MESM_ACT_PRELU && p.dslope) dslope_store(p, dslope_part, Red, slot);
-}
-
-// Epilogue of ONE wave-owned 32 x 32 tile held in 16 accumulator registers (register r <-> row
-// 4h + (r & 3) + 8 (r >> 2), column lane & 31).
-template <int LA, int LB, bool XF>
-__device__ __forceinline__ void tile16_epilogue(const MesmGemmArgs& p, const f32x16& acc, int row0, int col0,
-                                                float slope, uint32_t seed_off, int bz, float* sh4,
-                                                int64_t slot, int km, const XForm& xa, const XForm& xb) {
-  const int lane = threadIdx.x & 63;
-  const int li = lane & 31, h = lane >> 5;
-  const bool first_split = (p.split_k <= 1) || (bz == 0);
-  float t[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) t[i] = acc[i];
-  auto RO = [](int i) { return (i & 3) + 8 * (i >> 2); };
-  if (first_split && km < p.K) tail_accumulate<16, LA, LB, XF>(p, t, row0 + 4 * h, col0 + li, km, xa, xb, RO);
-  float dslope_part;
-  if (row0 + 32 <= p.M && col0 + 32 <= p.N)
-    dslope_part = staged_epilogue<16, true>(p, t, row0 + 4 * h, col0 + li, slope, seed_off, first_split, RO);
-  else
-    dslope_part = staged_epilogue<16, false>(p, t, row0 + 4 * h, col0 + li, slope, seed_off, first_split, RO);
-  if (p.e_actgrad == MESM_ACT_PRELU && p.dslope) dslope_store(p, dslope_part, sh4, slot);
-}
-
-// column-sum share of the tail reduce indices for output row gm (added by the lanes that own the atomics)
-template <int LA, bool XF>
-__device__ __forceinline__ float tail_colsum(const MesmGemmArgs& p, int gm, int km, const XForm& xa) {
-  float c = 0.0f;
-  if (gm < p.M)
-    for (int k = km; k < p.K; ++k) c += tail_elem<LA, XF>(p.A, p.lda, gm, k, xa);
-  return c;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1157,11 +897,6 @@ __device__ __forceinline__ void ws_read(const float* slab, int li, int h, float 
     }
   }
 }
-
-struct Blk {
-  int x, y, z;    // tile coordinates of this workgroup inside ITS problem
-  int64_t slot;   // linear id inside its problem (dslope workspace slot)
-};
 
 // WS_STAGES: wave-private k-tiles resident in LDS per operand pair.  2 = double buffer (64 KB per workgroup,
 // 2 workgroups per CU), 1 = load / read / refill in place (32 KB, 5 per CU).  Measured (tools/gemm_sweep.py):
@@ -1644,11 +1379,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_wstage64_kernel(const MesmGemmA
 }
 
 // MESM_GEMM_BF16X = 6 | 3: the experimental split-bf16 products (see SplitFrag); 0 / unset = exact f32
-inline int bf16x_mode() {
-  const char* e = getenv("MESM_GEMM_BF16X");
-  const int m = e ? atoi(e) : 0;
-  return (m == 3 || m == 6) ? m : 0;
-}
+inline int bf16x_mode() { return mesm_gemm_bf16x(); }
 
 template <int LA, int LB>
 int launch_wstage64_l(const MesmGemmArgs& a, hipStream_t s) {
@@ -2158,366 +1889,6 @@ int launch_lds64(const MesmGemmArgs& a, hipStream_t s) {
   return launch_lds64_l<O, R>(a, s);
 }
 
-// ------------------------------------------------------------------------------------------------
-// "big16" kernel: ONE round of large tiles on v_mfma_f32_16x16x4_f32 for the FFN-shaped products with a short reduce
-// range and a wide output (4800 x 1024 x 256: transformer.py:537, 603, 608, 647, 794 forward and their dz backward).
-// 64 x 64 tiles make 1216 workgroups there = 4.75 tiles per CU, each with its own first-load latency and epilogue
-// (section 4 of DESIGN.md: 36 us = 69 TF).  Here a workgroup (8 waves = 2 x 4, two per SIMD) owns a 160 x 128 tile:
-// 30 x 8 = 240 workgroups = one round on 256 CUs, one prologue and one epilogue per CU.  A wave's 80 x 32 share is
-// 5 x 2 accumulator blocks of 16 x 16: per reduce step of 4 it reads 7 operand values for 10 matrix instructions,
-// ten independent accumulators (no dependent issue), operands staged through registers into a double-buffered LDS
-// chunk of 32 reduce indices ([row][k], 36-float rows: the lane's 8 consecutive reduce indices are two conflict-free
-// 16-byte reads -- the k order inside a chunk is permuted the same way for A and B).
-// Plain operands only (no operand transform, no A2 / B2, no split-K, no column sums); every epilogue term.
-typedef float f32x4_t __attribute__((ext_vector_type(4)));
-constexpr int BG_THREADS = 512, BG_WMB = 5, BG_WNB = 2, BG_TM = 2 * BG_WMB * 16, BG_TN = 4 * BG_WNB * 16;
-constexpr int BG_AS = 36, BG_BSN = BG_TN + 2;
-template <int LB>
-constexpr int bg_b_floats() { return LB == MESM_LAYOUT_REDUCE_CONTIG ? BG_TN * BG_AS : 32 * BG_BSN; }
-template <int LB>
-constexpr size_t bg_lds_bytes() { return (size_t)2 * (BG_TM * BG_AS + bg_b_floats<LB>()) * sizeof(float); }
-
-constexpr int BG_NA = (BG_TM * 8 + BG_THREADS - 1) / BG_THREADS, BG_NB = (BG_TN * 8) / BG_THREADS;
-
-// staging: A chunk = 160 rows x 8 float4, B chunk = 128 rows x 8 float4 ([n][k]) or 32 rows x 32 float4 ([k][n]).
-// The loads are volatile asm: written as plain loads hipcc sinks them below the matrix instructions, next to the LDS
-// stores that use them (a load round trip per chunk in the open), and a sched_barrier sends the staging registers to
-// scratch.  The caller waits (s_waitcnt vmcnt(0)) before bg_lstore.
-__device__ __forceinline__ f32x4_t bg_ld16(const float* ptr) {
-  f32x4_t v;
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(ptr) : "memory");
-  return v;
-}
-
-template <int LB>
-__device__ __forceinline__ void bg_gload(const MesmGemmArgs& p, int m0, int n0, int k0, int tid, f32x4_t (&ra)[BG_NA],
-                                         f32x4_t (&rb)[BG_NB]) {
-#pragma unroll
-  for (int v = 0; v < BG_NA; ++v) {
-    int idx = tid + v * BG_THREADS;
-    idx = idx < BG_TM * 8 ? idx : BG_TM * 8 - 1;
-    const int r = idx >> 3, c = (idx & 7) * 4;
-    int gm = m0 + r;
-    gm = gm < p.M ? gm : p.M - 1;
-    ra[v] = bg_ld16(p.A + (int64_t)gm * p.lda + k0 + c);
-  }
-#pragma unroll
-  for (int v = 0; v < BG_NB; ++v) {
-    const int idx = tid + v * BG_THREADS;
-    if (LB == MESM_LAYOUT_REDUCE_CONTIG) {
-      const int r = idx >> 3, c = (idx & 7) * 4;
-      rb[v] = bg_ld16(p.B + (int64_t)(n0 + r) * p.ldb + k0 + c);
-    } else {
-      const int k = idx >> 5, c = (idx & 31) * 4;
-      rb[v] = bg_ld16(p.B + (int64_t)(k0 + k) * p.ldb + n0 + c);
-    }
-  }
-}
-
-template <int LB>
-__device__ __forceinline__ void bg_lstore(float* Ab, float* Bb, int tid, const f32x4_t (&ra)[BG_NA], const f32x4_t (&rb)[BG_NB]) {
-#pragma unroll
-  for (int v = 0; v < BG_NA; ++v) {
-    const int idx = tid + v * BG_THREADS;
-    const int r = idx >> 3, c = (idx & 7) * 4;
-    if (idx < BG_TM * 8) *reinterpret_cast<f32x4_t*>(Ab + r * BG_AS + c) = ra[v];
-  }
-#pragma unroll
-  for (int v = 0; v < BG_NB; ++v) {
-    const int idx = tid + v * BG_THREADS;
-    if (LB == MESM_LAYOUT_REDUCE_CONTIG) {
-      const int r = idx >> 3, c = (idx & 7) * 4;
-      *reinterpret_cast<f32x4_t*>(Bb + r * BG_AS + c) = rb[v];
-    } else {
-      const int k = idx >> 5, c = (idx & 31) * 4;
-      float* d = Bb + k * BG_BSN + c;  // 130-float rows: 8-byte aligned
-      *reinterpret_cast<float2*>(d) = make_float2(rb[v][0], rb[v][1]);
-      *reinterpret_cast<float2*>(d + 2) = make_float2(rb[v][2], rb[v][3]);
-    }
-  }
-}
-
-template <int LB>
-__global__ __launch_bounds__(BG_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_big16_kernel(const MesmGemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) float bg_smem[];
-  constexpr int AF = BG_TM * BG_AS, BF = bg_b_floats<LB>();
-  __shared__ float sh4[8];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int jl = lane & 15, kq = lane >> 4;
-  const int wm = wave >> 2, wn = wave & 3;
-  int tbx, tby;
-  xcd_tile(blockIdx.x, (p.M + BG_TM - 1) / BG_TM, p.N / BG_TN, tbx, tby);
-  const int m0 = tbx * BG_TM, n0 = tby * BG_TN;
-  const float slope = p.slope ? *p.slope : 0.0f;
-  const uint32_t seed_off = p.seed_offset ? *p.seed_offset : 0u;
-  f32x4_t ra[BG_NA], rb[BG_NB];
-
-  f32x4_t acc[BG_WMB][BG_WNB];
-#pragma unroll
-  for (int i = 0; i < BG_WMB; ++i)
-#pragma unroll
-    for (int j = 0; j < BG_WNB; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-  const int nch = p.K >> 5;
-  bg_gload<LB>(p, m0, n0, 0, tid, ra, rb);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  bg_lstore<LB>(bg_smem, bg_smem + 2 * AF, tid, ra, rb);
-  __syncthreads();
-  for (int c = 0; c < nch; ++c) {
-    const int buf = c & 1;
-    // the next chunk's global loads fly during this chunk's matrix instructions
-    if (c + 1 < nch) bg_gload<LB>(p, m0, n0, (c + 1) << 5, tid, ra, rb);
-    const float* As = bg_smem + buf * AF + (wm * BG_WMB * 16 + jl) * BG_AS + 8 * kq;
-    float af[BG_WMB][8], bf[BG_WNB][8];
-#pragma unroll
-    for (int i = 0; i < BG_WMB; ++i) {
-      const float4 x = *reinterpret_cast<const float4*>(As + i * 16 * BG_AS);
-      const float4 y = *reinterpret_cast<const float4*>(As + i * 16 * BG_AS + 4);
-      af[i][0] = x.x; af[i][1] = x.y; af[i][2] = x.z; af[i][3] = x.w;
-      af[i][4] = y.x; af[i][5] = y.y; af[i][6] = y.z; af[i][7] = y.w;
-    }
-#pragma unroll
-    for (int j = 0; j < BG_WNB; ++j) {
-      if (LB == MESM_LAYOUT_REDUCE_CONTIG) {
-        const float* Bs = bg_smem + 2 * AF + buf * BF + (wn * BG_WNB * 16 + j * 16 + jl) * BG_AS + 8 * kq;
-        const float4 x = *reinterpret_cast<const float4*>(Bs);
-        const float4 y = *reinterpret_cast<const float4*>(Bs + 4);
-        bf[j][0] = x.x; bf[j][1] = x.y; bf[j][2] = x.z; bf[j][3] = x.w;
-        bf[j][4] = y.x; bf[j][5] = y.y; bf[j][6] = y.z; bf[j][7] = y.w;
-      } else {
-        const float* Bs = bg_smem + 2 * AF + buf * BF + (8 * kq) * BG_BSN + wn * BG_WNB * 16 + j * 16 + jl;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) bf[j][t] = Bs[t * BG_BSN];
-      }
-    }
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-      for (int i = 0; i < BG_WMB; ++i)
-#pragma unroll
-        for (int j = 0; j < BG_WNB; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][t], bf[j][t], acc[i][j], 0, 0, 0);
-    if (c + 1 < nch) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      bg_lstore<LB>(bg_smem + (buf ^ 1) * AF, bg_smem + 2 * AF + (buf ^ 1) * BF, tid, ra, rb);
-    }
-    __syncthreads();
-  }
-
-  // accumulator block (i, j), register r <-> row m0 + 80 wm + 16 i + 4 kq + r, column n0 + 32 wn + 16 j + jl
-  // (one epilogue call per block: a call per column block -- 20 values per lane -- spills and is slower, 37.4 vs 34.9 us)
-  auto RO = [](int i) { return i; };
-  const bool full = m0 + BG_TM <= p.M;
-  float dslope_part = 0.0f;
-#pragma unroll
-  for (int i = 0; i < BG_WMB; ++i) {
-#pragma unroll
-    for (int j = 0; j < BG_WNB; ++j) {
-      float t[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) t[r] = acc[i][j][r];
-      const int rbase = m0 + wm * BG_WMB * 16 + 16 * i + 4 * kq;
-      const int col = n0 + wn * BG_WNB * 16 + j * 16 + jl;
-      if (full) dslope_part += staged_epilogue<4, true>(p, t, rbase, col, slope, seed_off, true, RO);
-      else dslope_part += staged_epilogue<4, false>(p, t, rbase, col, slope, seed_off, true, RO);
-    }
-  }
-  if (p.e_actgrad == MESM_ACT_PRELU && p.dslope) dslope_store(p, dslope_part, sh4, linear_block());
-}
-
-// The same 160 x 128 share per workgroup walked as TWO half-tiles of 160 x 64 (a wave: 5 x 1 blocks, chunks of 64 reduce
-// indices so a wave still issues 80 matrix instructions per barrier): the first half's epilogue -- its aux / residual
-// loads and its stores -- drains under the second half's matrix instructions, and the second half's first operand
-// chunk is already in flight when the first half ends (cross-tile prefetch).  MESM_GEMM_TILE=8.  Measured: no better
-// (4800 x 1024 x 256 bias + residual: 35.3 us against 34.9 one round, 34.2 for the 64 x 64 ring) -- the ~11-15 us a
-// workgroup spends outside its steady state are neither the exposed write burst (half the rows: 30.5 us) nor the chain of
-// epilogue calls (one call per half: same time).
-constexpr int BP_TNS = 64, BP_KC = 64, BP_AS = BP_KC + 4, BP_BSN = BP_TNS + 2;
-constexpr int BP_NA = (BG_TM * (BP_KC / 4)) / BG_THREADS, BP_NB = (BP_TNS * (BP_KC / 4)) / BG_THREADS;  // 5, 2
-template <int LB>
-constexpr int bp_b_floats() { return LB == MESM_LAYOUT_REDUCE_CONTIG ? BP_TNS * BP_AS : BP_KC * BP_BSN; }
-template <int LB>
-constexpr size_t bp_lds_bytes() { return (size_t)2 * (BG_TM * BP_AS + bp_b_floats<LB>()) * sizeof(float); }
-
-template <int LB>
-__device__ __forceinline__ void bp_gload(const MesmGemmArgs& p, int m0, int n0, int k0, int tid, f32x4_t (&ra)[BP_NA],
-                                         f32x4_t (&rb)[BP_NB]) {
-#pragma unroll
-  for (int v = 0; v < BP_NA; ++v) {
-    const int idx = tid + v * BG_THREADS;
-    const int r = idx >> 4, c = (idx & 15) * 4;
-    int gm = m0 + r;
-    gm = gm < p.M ? gm : p.M - 1;
-    ra[v] = bg_ld16(p.A + (int64_t)gm * p.lda + k0 + c);
-  }
-#pragma unroll
-  for (int v = 0; v < BP_NB; ++v) {
-    const int idx = tid + v * BG_THREADS;
-    if (LB == MESM_LAYOUT_REDUCE_CONTIG) {
-      const int r = idx >> 4, c = (idx & 15) * 4;
-      rb[v] = bg_ld16(p.B + (int64_t)(n0 + r) * p.ldb + k0 + c);
-    } else {
-      const int k = idx >> 4, c = (idx & 15) * 4;
-      rb[v] = bg_ld16(p.B + (int64_t)(k0 + k) * p.ldb + n0 + c);
-    }
-  }
-}
-
-template <int LB>
-__device__ __forceinline__ void bp_lstore(float* Ab, float* Bb, int tid, const f32x4_t (&ra)[BP_NA], const f32x4_t (&rb)[BP_NB]) {
-#pragma unroll
-  for (int v = 0; v < BP_NA; ++v) {
-    const int idx = tid + v * BG_THREADS;
-    const int r = idx >> 4, c = (idx & 15) * 4;
-    *reinterpret_cast<f32x4_t*>(Ab + r * BP_AS + c) = ra[v];
-  }
-#pragma unroll
-  for (int v = 0; v < BP_NB; ++v) {
-    const int idx = tid + v * BG_THREADS;
-    if (LB == MESM_LAYOUT_REDUCE_CONTIG) {
-      const int r = idx >> 4, c = (idx & 15) * 4;
-      *reinterpret_cast<f32x4_t*>(Bb + r * BP_AS + c) = rb[v];
-    } else {
-      const int k = idx >> 4, c = (idx & 15) * 4;
-      float* d = Bb + k * BP_BSN + c;  // 66-float rows: 8-byte aligned
-      *reinterpret_cast<float2*>(d) = make_float2(rb[v][0], rb[v][1]);
-      *reinterpret_cast<float2*>(d + 2) = make_float2(rb[v][2], rb[v][3]);
-    }
-  }
-}
-
-template <int LB>
-__global__ __launch_bounds__(BG_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void gemm_big16p_kernel(const MesmGemmArgs p) {
-  extern __shared__ __attribute__((aligned(16))) float bg_smem[];
-  constexpr int AF = BG_TM * BP_AS, BF = bp_b_floats<LB>();
-  __shared__ float sh4[8];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int jl = lane & 15, kq = lane >> 4;
-  const int wm = wave >> 2, wn = wave & 3;
-  int tbx, tby;
-  xcd_tile(blockIdx.x, (p.M + BG_TM - 1) / BG_TM, p.N / BG_TN, tbx, tby);
-  const int m0 = tbx * BG_TM, n0 = tby * BG_TN;
-  const float slope = p.slope ? *p.slope : 0.0f;
-  const uint32_t seed_off = p.seed_offset ? *p.seed_offset : 0u;
-  f32x4_t ra[BP_NA], rb[BP_NB];
-  f32x4_t acc[BG_WMB];
-#pragma unroll
-  for (int i = 0; i < BG_WMB; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-  const int nch = p.K / BP_KC, nit = 2 * nch;
-  bp_gload<LB>(p, m0, n0, 0, tid, ra, rb);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  bp_lstore<LB>(bg_smem, bg_smem + 2 * AF, tid, ra, rb);
-  __syncthreads();
-  auto RO = [](int i) { return i; };
-  const bool full = m0 + BG_TM <= p.M;
-  float dslope_part = 0.0f;
-  for (int it = 0; it < nit; ++it) {
-    const int buf = it & 1;
-    const int sub = it >= nch ? 1 : 0, c = it - sub * nch;
-    if (it + 1 < nit) {
-      const int sub1 = it + 1 >= nch ? 1 : 0, c1 = it + 1 - sub1 * nch;
-      bp_gload<LB>(p, m0, n0 + sub1 * BP_TNS, c1 * BP_KC, tid, ra, rb);
-    }
-    const float* As = bg_smem + buf * AF + (wm * BG_WMB * 16 + jl) * BP_AS + 16 * kq;
-    float af[BG_WMB][16], bf[16];
-#pragma unroll
-    for (int i = 0; i < BG_WMB; ++i)
-#pragma unroll
-      for (int t = 0; t < 16; t += 4) {
-        const float4 x = *reinterpret_cast<const float4*>(As + i * 16 * BP_AS + t);
-        af[i][t] = x.x; af[i][t + 1] = x.y; af[i][t + 2] = x.z; af[i][t + 3] = x.w;
-      }
-    if (LB == MESM_LAYOUT_REDUCE_CONTIG) {
-      const float* Bs = bg_smem + 2 * AF + buf * BF + (wn * 16 + jl) * BP_AS + 16 * kq;
-#pragma unroll
-      for (int t = 0; t < 16; t += 4) {
-        const float4 x = *reinterpret_cast<const float4*>(Bs + t);
-        bf[t] = x.x; bf[t + 1] = x.y; bf[t + 2] = x.z; bf[t + 3] = x.w;
-      }
-    } else {
-      const float* Bs = bg_smem + 2 * AF + buf * BF + (16 * kq) * BP_BSN + wn * 16 + jl;
-#pragma unroll
-      for (int t = 0; t < 16; ++t) bf[t] = Bs[t * BP_BSN];
-    }
-#pragma unroll
-    for (int t = 0; t < 16; ++t)
-#pragma unroll
-      for (int i = 0; i < BG_WMB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][t], bf[t], acc[i], 0, 0, 0);
-    if (it + 1 < nit) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      bp_lstore<LB>(bg_smem + (buf ^ 1) * AF, bg_smem + 2 * AF + (buf ^ 1) * BF, tid, ra, rb);
-    }
-    if (c == nch - 1) {
-      // this half is complete: its epilogue's loads and stores are in flight while the next half's chunks run
-      float t[4 * BG_WMB];
-#pragma unroll
-      for (int i = 0; i < BG_WMB; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) t[4 * i + r] = acc[i][r];
-      const int rbase = m0 + wm * BG_WMB * 16 + 4 * kq;
-      const int col = n0 + sub * BP_TNS + wn * 16 + jl;
-      auto RO20 = [](int i) { return 16 * (i >> 2) + (i & 3); };
-      if (full) dslope_part += staged_epilogue<4 * BG_WMB, true>(p, t, rbase, col, slope, seed_off, true, RO20);
-      else dslope_part += staged_epilogue<4 * BG_WMB, false>(p, t, rbase, col, slope, seed_off, true, RO20);
-#pragma unroll
-      for (int i = 0; i < BG_WMB; ++i) acc[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    }
-    __syncthreads();
-  }
-  if (p.e_actgrad == MESM_ACT_PRELU && p.dslope) dslope_store(p, dslope_part, sh4, linear_block());
-}
-
-// what the big16 kernel takes: a plain product with the reduce index contiguous in A, K a multiple of 32, N of 128
-bool big16_ok(const MesmGemmArgs& a) {
-  return a.a_layout == MESM_LAYOUT_REDUCE_CONTIG && a.K % 32 == 0 && a.K >= 64 && a.N % BG_TN == 0 && a.M >= BG_TM &&
-         a.split_k <= 1 && !a.A2 && !a.B2 && !a.colsum && a.a_act == MESM_ACT_NONE && a.b_act == MESM_ACT_NONE &&
-         a.a_drop_p == 0.f && a.b_drop_p == 0.f && a.lda % 4 == 0 && a.ldb % 4 == 0 && aligned_to(a.A, 16) &&
-         aligned_to(a.B, 16);
-}
-
-int launch_big16(const MesmGemmArgs& a, hipStream_t s, bool halves = false) {
-  dim3 grid(((a.M + BG_TM - 1) / BG_TM) * (a.N / BG_TN));
-  static bool raised[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return MESM_ELAUNCH;
-  if (dev < 0 || dev >= 64 || !raised[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big16_kernel<MESM_LAYOUT_REDUCE_CONTIG>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bg_lds_bytes<MESM_LAYOUT_REDUCE_CONTIG>()) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big16_kernel<MESM_LAYOUT_OUTER_CONTIG>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)bg_lds_bytes<MESM_LAYOUT_OUTER_CONTIG>()) != hipSuccess)
-      return MESM_ELAUNCH;
-    if (dev >= 0 && dev < 64) raised[dev] = true;
-  }
-  if (halves && a.K % BP_KC == 0) {
-    static bool raised2[64] = {};
-    if (dev < 0 || dev >= 64 || !raised2[dev]) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big16p_kernel<MESM_LAYOUT_REDUCE_CONTIG>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp_lds_bytes<MESM_LAYOUT_REDUCE_CONTIG>()) != hipSuccess ||
-          hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big16p_kernel<MESM_LAYOUT_OUTER_CONTIG>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bp_lds_bytes<MESM_LAYOUT_OUTER_CONTIG>()) != hipSuccess)
-        return MESM_ELAUNCH;
-      if (dev >= 0 && dev < 64) raised2[dev] = true;
-    }
-    if (a.b_layout == MESM_LAYOUT_REDUCE_CONTIG)
-      hipLaunchKernelGGL(gemm_big16p_kernel<MESM_LAYOUT_REDUCE_CONTIG>, grid, dim3(BG_THREADS),
-                         bp_lds_bytes<MESM_LAYOUT_REDUCE_CONTIG>(), s, a);
-    else
-      hipLaunchKernelGGL(gemm_big16p_kernel<MESM_LAYOUT_OUTER_CONTIG>, grid, dim3(BG_THREADS),
-                         bp_lds_bytes<MESM_LAYOUT_OUTER_CONTIG>(), s, a);
-    const int rc2 = mesm_launch_status();
-    return rc2 != MESM_OK ? rc2 : dslope_finish(a, grid, s);
-  }
-  if (a.b_layout == MESM_LAYOUT_REDUCE_CONTIG)
-    hipLaunchKernelGGL(gemm_big16_kernel<MESM_LAYOUT_REDUCE_CONTIG>, grid, dim3(BG_THREADS),
-                       bg_lds_bytes<MESM_LAYOUT_REDUCE_CONTIG>(), s, a);
-  else
-    hipLaunchKernelGGL(gemm_big16_kernel<MESM_LAYOUT_OUTER_CONTIG>, grid, dim3(BG_THREADS),
-                       bg_lds_bytes<MESM_LAYOUT_OUTER_CONTIG>(), s, a);
-  const int rc = mesm_launch_status();
-  return rc != MESM_OK ? rc : dslope_finish(a, grid, s);
-}
-
 // Tape of the GEMM launches of one step (argument structs as launched), for bench.py's
 // roofline measurement: recorded while a step is captured into a HIP graph (whose private
 // memory pool keeps every pointer valid), replayed back-to-back from C++ with an event pair
@@ -2534,13 +1905,19 @@ struct Tape {
 };
 Tape g_tape;
 
+// tuning switches, read ONCE when the library is loaded (they used to be getenv calls per dispatch)
+int g_force_tile = []() { const char* e = getenv("MESM_GEMM_TILE"); return e ? atoi(e) : 0; }();
+int g_bf16x = []() { const char* e = getenv("MESM_GEMM_BF16X"); const int m = e ? atoi(e) : 0; return (m == 3 || m == 6) ? m : 0; }();
+
+int mesm_gemm_force_tile() { return g_force_tile; }
+int mesm_gemm_bf16x() { return g_bf16x; }
+
 int dispatch(const MesmGemmArgs& a, int vec, hipStream_t s) {
   {
     // small problems (fewer than ~2 workgroups of 64x64 per CU): register-fragment kernel
-    const char* env = getenv("MESM_GEMM_TILE");
     const long z = a.split_k > 1 ? a.split_k : 1;
     const long b64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * z;
-    const int force = env ? atoi(env) : 0;  // 1 = frag kernel, 32 | 64 | 128 = staged tile, 0 = auto
+    const int force = g_force_tile;  // 1 = frag kernel, 32 | 64 | 128 = staged tile, 0 = auto
     // 1 = frag, 2 = wstage (k-split 32x32, wave-private LDS-DMA), 3 = lds64 (64x64, LDS-DMA ring),
     // 4 = wstage64 (k-split 64x64),
     // 32 | 64 | 128 = register-staged tile, 0 = auto
@@ -2559,18 +1936,6 @@ int dispatch(const MesmGemmArgs& a, int vec, hipStream_t s) {
     if (force == 0 && bf16x_mode() != 0 && wstage_ok(a) && b64 >= 128 && (a.M >= 2400 || a.K >= 2400) &&
         a.a_act == MESM_ACT_NONE && a.b_act == MESM_ACT_NONE && a.a_drop_p == 0.f && a.b_drop_p == 0.f)
       return launch_wstage64(a, s);
-    // one round of 160 x 128 tiles (round-3 experiment, off by default: MESM_GEMM_BIG16=1 or MESM_GEMM_TILE=7).  Alone
-    // it ties the 64 x 64 ring on 4800 x 1024 x 256 (35.2 vs 35.0 us; 38.0 vs 43.5 with the second output, 57 vs 62.5 at
-    // K = 512) and the step does not move (4.91-4.93 ms either way): its steady state runs at 85 % of the matrix
-    // rate, but a one-round grid has every workgroup in its epilogue at the same time -- the 20-40 MB of output are
-    // one exposed burst (~10 us) instead of trickling out under the other tiles' matrix instructions.
-    {
-      const long tb = (long)((a.M + BG_TM - 1) / BG_TM) * (a.N / BG_TN);
-      static const bool big_on = getenv("MESM_GEMM_BIG16") != nullptr;
-      if (force == 8 && big16_ok(a)) return launch_big16(a, s, true);
-      if ((force == 7 || (force == 0 && big_on && a.K <= 512 && tb >= 224 && tb <= 256)) && big16_ok(a))
-        return launch_big16(a, s);
-    }
     if ((force == 3 || (force == 0 && b64 >= 512)) && wstage_ok(a)) return launch_lds64(a, s);
     // k-split 64 x 64 (half the L2 traffic per flop): wins only when its workgroups fit ONE round on the
     // 256 CUs (300 workgroups = two rounds: 4800 x 256 x 1024 59 us vs 43 us with 32 x 32 tiles) and a
@@ -2627,8 +1992,7 @@ int prepare(MesmGemmArgs& a, int& vec) {
 
 // does the auto dispatch send this problem to the wstage kernel (the one that can be grouped)?
 bool groupable(const MesmGemmArgs& a) {
-  const char* env = getenv("MESM_GEMM_TILE");
-  const int force = env ? atoi(env) : 0;
+  const int force = g_force_tile;
   if (force != 0 && force != 2) return false;
   if (force == 0 && bf16x_mode() != 0 && (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * (a.split_k > 1 ? a.split_k : 1) >= 128 &&
       (a.M >= 2400 || a.K >= 2400))
@@ -2689,8 +2053,7 @@ int launch_group(const MesmGemmArgs* list, const int* vecs, int n, hipStream_t s
   auto joins = [&](const MesmGemmArgs& a) {
     if (groupable(a)) return true;
     if (!group_mid || n_plain == 0 || bf16x_mode() != 0) return false;
-    const char* env = getenv("MESM_GEMM_TILE");
-    if (env && atoi(env) != 0) return false;
+    if (g_force_tile != 0) return false;
     return wstage_ok(a) && 2.0 * a.M * a.N * a.K < MID_GF;
   };
   for (int i = 0; i < n && rc == MESM_OK; ++i) {
@@ -2727,6 +2090,15 @@ extern "C" int mesm_gemm_group(const MesmGemmArgs* args, int32_t n, void* stream
     g_tape.launches.push_back(e);
   }
   return launch_group(list, vecs, n, (hipStream_t)stream);
+}
+
+int mesm_gemm_dslope_finish(const MesmGemmArgs& a, int64_t nblocks, hipStream_t s) { return dslope_finish_n(a, nblocks, s); }
+
+// tuning tools flip the two dispatch switches between calls of one process (< 0: keep)
+extern "C" int mesm_gemm_set_switches(int32_t force_tile, int32_t bf16x) {
+  if (force_tile >= 0) g_force_tile = force_tile;
+  if (bf16x >= 0) g_bf16x = (bf16x == 3 || bf16x == 6) ? bf16x : 0;
+  return MESM_OK;
 }
 
 extern "C" int mesm_gemm_flush_side(void* stream) { return flush_side((hipStream_t)stream); }

@@ -1014,3 +1014,43 @@ def test_slope_gradient_partials_ride_in_the_next_gemm_launch():
         finally:
             kn.defer_side(-1)
             kn.gemm_flush_side()
+
+
+# --------------------------------------------------------------------------- split-bf16 plane GEMM (opt-in path)
+PX_CASES = [  # M, N, K, trans_a, trans_b, split_k
+    (200, 130, 77, False, True, 1), (200, 130, 77, False, False, 1), (77, 130, 200, True, False, 2),
+    (4800, 256, 256, False, True, 1), (1024, 256, 4800, True, False, 4), (300, 2818, 64, False, False, 1),
+    (96, 64, 1024, False, True, 1), (33, 65, 31, False, True, 1),
+]
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb,split", PX_CASES)
+@pytest.mark.parametrize("mode", [1, 2, 8])
+def test_plane_gemm_matches_fp64(M, N, K, ta, tb, split, mode):
+    """mesm_gemm_px (three bf16 planes per operand, six products on the bf16 matrix pipe, f32 accumulate) against fp64, at
+    the exact-f32 kernel's own error level; every layout pair, both tiles, the three loop forms (MESM_PX_RING), split-K with
+    column sums, and the full epilogue."""
+    from mesm_amd import kernels as kn
+    from mesm_amd._lib import lib
+    A = gen((K, M) if ta else (M, K), 300)
+    B = gen((N, K) if tb else (K, N), 301) * 0.1
+    pa, pb = kn.split_planes(A), kn.split_planes(B)
+    assert torch.equal(pa.float(), A) and torch.equal(pb.float(), B)  # hi + mid + lo is the operand, exactly
+    ref = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double())
+    for tile in (64, 96):
+        lib().mesm_gemm_px_set_tile(tile)
+        lib().mesm_gemm_px_set_ring(mode)
+        C = torch.zeros(M, N, device=dev())
+        if split > 1:
+            cs = torch.zeros(M, device=dev())
+            kn.gemm(A, B, C, trans_a=ta, trans_b=tb, split_k=split, accumulate=2, colsum=cs, a_planes=pa, b_planes=pb)
+            want_cs = (A.double().t() if ta else A.double()).sum(1)
+            assert rel_err(cs, want_cs) < 1e-5
+            assert rel_err(C, ref) < 2e-6
+        else:
+            bias, res = gen((N,), 302), gen((M, N), 303)
+            kn.gemm(A, B, C, trans_a=ta, trans_b=tb, bias=bias, residual=res, e_act=kn.ACT_RELU, a_planes=pa, b_planes=pb)
+            want = torch.relu(ref + bias.double()) + res.double()
+            assert rel_err(C, want) < 2e-6
+    lib().mesm_gemm_px_set_tile(0)
+    lib().mesm_gemm_px_set_ring(0)

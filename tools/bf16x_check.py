@@ -11,8 +11,8 @@ SHAPES = [(4800, 1024, 256, False, True), (4800, 256, 1024, False, True), (4800,
 
 
 def run(M, N, K, ta, tb, mode):
-    if mode: os.environ["MESM_GEMM_BF16X"] = str(mode)
-    else: os.environ.pop("MESM_GEMM_BF16X", None)
+    if mode: kn.gemm_switches(bf16x=int(str(mode)))
+    else: kn.gemm_switches(bf16x=0)
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn((K, M) if ta else (M, K), generator=g).to(dev)
     B = (torch.randn((N, K) if tb else (K, N), generator=g) * 0.06).to(dev)
@@ -46,4 +46,4 @@ for M, N, K, ta, tb in SHAPES:
         print("M=%5d N=%5d K=%5d %s%s  %-8s max rel err %.2e  rms rel err %.2e  %7.2f us  %6.1f TF" % (
             M, N, K, "T" if ta else "N", "T" if tb else "N", {0: "f32", 6: "bf16x6", 3: "bf16x3"}[mode], err, rms, us,
             2.0 * M * N * K / us / 1e6), flush=True)
-os.environ.pop("MESM_GEMM_BF16X", None)
+kn.gemm_switches(bf16x=0)

@@ -40,7 +40,7 @@ for name, M, N, K, ta, tb, split in SHAPES:
              torch.zeros(M, N, device=dev)) for _ in range(NSET)]
     res = []
     for tile in ("0", "2", "4", "3", "32"):
-        os.environ["MESM_GEMM_TILE"] = tile
+        kn.gemm_switches(tile=int(tile))
         def body():
             for i in range(NL):
                 A, B, C = sets[i % NSET]
@@ -63,6 +63,6 @@ for name, M, N, K, ta, tb, split in SHAPES:
             g.replay()
         torch.cuda.synchronize()
         res.append((time.perf_counter() - t0) / REPS / NL * 1e6)
-    os.environ["MESM_GEMM_TILE"] = "0"
+    kn.gemm_switches(tile=int("0"))
     print("%s M=%5d N=%5d K=%5d s%-2d auto %7.2f | wstage %7.2f | wstage64 %7.2f | lds64 %7.2f | t32 %7.2f us  (best %5.1f TF)" % (
         name, M, N, K, split, res[0], res[1], res[2], res[3], res[4], 2.0 * M * N * K / min(res) / 1e6), flush=True)

@@ -8,7 +8,7 @@ dev = torch.device("cuda:0")
 
 
 def run(M, N, K, ta, tb, split, tile, acc=0, NSET=8, NL=32):
-    os.environ["MESM_GEMM_TILE"] = str(tile)
+    kn.gemm_switches(tile=int(str(tile)))
     sets = [(torch.randn((K, M) if ta else (M, K), device=dev), torch.randn((N, K) if tb else (K, N), device=dev),
              torch.zeros(M, N, device=dev)) for _ in range(NSET)]
 

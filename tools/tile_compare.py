@@ -6,14 +6,14 @@ dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
 rnd = lambda *s: (torch.randn(*s, generator=g)).to(dev)
 def run(force, fn, reps=50):
-    if force: os.environ["MESM_GEMM_TILE"] = str(force)
-    else: os.environ.pop("MESM_GEMM_TILE", None)
+    if force: kn.gemm_switches(tile=int(str(force)))
+    else: kn.gemm_switches(tile=0)
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
     e0.record()
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
-    os.environ.pop("MESM_GEMM_TILE", None)
+    kn.gemm_switches(tile=0)
     return e0.elapsed_time(e1) / reps * 1e3
 for (M, N, K, tb) in ((4800, 256, 256, True), (4800, 256, 256, False), (2400, 512, 256, True), (4864, 512, 256, True), (2400, 256, 256, True),
                       (2048, 512, 256, True), (4800, 512, 256, True), (1024, 1024, 256, True), (1024, 256, 1024, True), (2400, 256, 512, False)):
