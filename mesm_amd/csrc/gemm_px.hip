@@ -516,6 +516,191 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : (RING == 1 ? 3 : 1)) void ge
   if (p.e_actgrad == MESM_ACT_PRELU && p.dslope) dslope_store(p, dslope_part, L, blk.slot);
 }
 
+// ---- shared-stage kernel ("pxs") --------------------------------------------------------------------------------------
+// The exact-f32 ring kernel's structure (gemm.hip: gemm_lds64_kernel) on plane operands: 64 x 64 tile, 2 x 2 waves of one
+// 32 x 32 accumulator block each, stages of 32 reduce indices (two 16-deep substeps x three planes x two operands = 24 KB)
+// staged ONCE per workgroup by LDS-DMA into a ring of NS slots -- each wave issues 6 of the stage's 24 instructions, a
+// quarter of what a k-split wave issues for the same matrix work (the per-wave LDS-DMA issue cost, ~90 cycles per 1 KB
+// instruction, is what bounded the k-split kernels) -- one raw s_barrier per stage, 48-72 KB of LDS and ~100 registers: two
+// or three workgroups per CU, so one workgroup's prologue, barrier waits, epilogue and store drain run under its neighbours'
+// matrix instructions.
+constexpr int PXS_OPER = 12288, PXS_STAGE = 2 * PXS_OPER;  // bytes: [A | B] x [hi | mid | lo] x [substep 0 | 1] x 2 KB
+
+template <int LAYOUT>
+struct PxsSrc {
+  unsigned voff[2];     // per-lane byte offsets of the two 1 KB halves of a 2 KB plane-substep image
+  int64_t sub_step;     // bytes between the two substeps of a stage
+  int64_t stage_step;   // bytes between stages
+  __device__ __forceinline__ void init(const MesmPlanes& P, int o0, int lane) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (LAYOUT == R_) {
+        const int row = 32 * q + (lane >> 1), pos = lane & 1;
+        const int c = pos ^ ((row >> 3) & 1);
+        int ro = o0 + row;
+        ro = ro < P.rows ? ro : P.rows - 1;
+        voff[q] = (unsigned)(ro * 16 + 8 * c) * 2u;
+      } else {
+        const int krow = 8 * q + (lane >> 3), pos = lane & 7;
+        const int ch = pos ^ (((krow >> 1) & 1) << 2);
+        int cb = (o0 >> 4) + (ch >> 1);
+        const int ncb = P.cols >> 4;
+        cb = cb < ncb ? cb : ncb - 1;
+        voff[q] = (unsigned)(cb * (int)P.ld + krow * 16 + (ch & 1) * 8) * 2u;
+      }
+    }
+    sub_step = LAYOUT == R_ ? 2 * P.ld : 512;
+    stage_step = 2 * sub_step;
+  }
+};
+
+// one fragment: plane image of one substep at `img` (2 KB), outer block t, per-lane offset a0 (PxFrag::lane_off)
+template <int LAYOUT>
+__device__ __forceinline__ u32x4 pxs_frag(const char* img, int t, int a0) {
+  if (LAYOUT == R_) return *reinterpret_cast<const u32x4*>(img + t * 1024 + a0);
+  const char* a = img + (t ? (a0 ^ 64) : a0);
+  const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a));
+  const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + 512));
+  const u32x2 l2 = __builtin_bit_cast(u32x2, lo4), h2 = __builtin_bit_cast(u32x2, hi4);
+  return u32x4{l2[0], l2[1], h2[0], h2[1]};
+}
+
+template <int LA, int LB, bool CS, int NS>
+__global__ __launch_bounds__(NTHREADS, NS == 2 ? 3 : 2) void gemm_pxs_kernel(const MesmGemmArgs p, const MesmPlanes PA, const MesmPlanes PB) {
+  extern __shared__ __attribute__((aligned(16))) char px_lds[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, h = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  Blk blk;
+  xcd_tile(blockIdx.x, (p.M + 63) / 64, (p.N + 63) / 64, blk.x, blk.y);
+  blk.z = blockIdx.z;
+  blk.slot = linear_block();
+  const int m0 = blk.x * 64, n0 = blk.y * 64;
+
+  const int KP = LA == R_ ? PA.cols : PA.rows;  // padded reduce extent: a multiple of 32, zeros beyond K
+  int kbeg = 0, kend = KP;
+  if (p.split_k > 1) {
+    int chunk = (KP + p.split_k - 1) / p.split_k;
+    chunk = (chunk + 31) & ~31;
+    kbeg = blk.z * chunk;
+    kend = kbeg + chunk < KP ? kbeg + chunk : KP;
+    if (kbeg >= KP) {
+      if (blk.z > 0) return;
+      kbeg = kend = KP;
+    }
+  }
+  const int nst = (kend - kbeg) >> 5;
+
+  const float slope = p.slope ? *p.slope : 0.0f;
+  const uint32_t seed_off = p.seed_offset ? *p.seed_offset : 0u;
+
+  // waves 0 / 1 stage operand A, waves 2 / 3 operand B; the operand's 12 instructions per stage (plane x substep x half)
+  // are split 6 / 6 between its two waves
+  const bool mine_a = wave < 2;
+  const int part = wave & 1;
+  PxsSrc<LA> sa;
+  PxsSrc<LB> sb;
+  sa.init(PA, m0, lane);
+  sb.init(PB, n0, lane);
+  const char* base[3];
+  {
+    const MesmPlanes& P = mine_a ? PA : PB;
+    const bool red = mine_a ? (LA == R_) : (LB == R_);
+    const int64_t first = red ? (int64_t)(kbeg >> 4) * P.ld : (int64_t)kbeg * 16;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) base[pl] = reinterpret_cast<const char*>(P.p[pl] + first);
+  }
+  const unsigned v0 = mine_a ? sa.voff[0] : sb.voff[0], v1 = mine_a ? sa.voff[1] : sb.voff[1];
+  const int64_t sub_step = mine_a ? sa.sub_step : sb.sub_step, stage_step = mine_a ? sa.stage_step : sb.stage_step;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)px_lds;
+  // the stages are walked from a workgroup-dependent start (see the k-split kernel: L2 channel hot spots otherwise)
+  const int rot = nst > 0 ? (int)((unsigned)(blk.x * 5 + blk.y * 3 + blk.z) % (unsigned)nst) : 0;
+  auto stage_of = [&](int i) { const int s_ = i + rot; return s_ < nst ? s_ : s_ - nst; };
+  int i_slot = 0;
+  auto issue = [&](int i) {
+    const int64_t adv = (int64_t)stage_of(i) * stage_step;
+    const unsigned slot = lds0 + (unsigned)i_slot * PXS_STAGE + (mine_a ? 0u : (unsigned)PXS_OPER);
+    i_slot = i_slot + 1 == NS ? 0 : i_slot + 1;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int idx = part * 6 + j;          // 0 .. 11: plane = idx / 4, substep = (idx / 2) & 1, half = idx & 1
+      const int pl = idx >> 2, sub = (idx >> 1) & 1, q = idx & 1;
+      const uint64_t bv = (uint64_t)((pl == 0 ? base[0] : (pl == 1 ? base[1] : base[2])) + adv + (sub ? sub_step : 0));
+      // (wave-uniform by construction; the asm wants it in SGPRs)
+      const uint64_t bs = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(bv >> 32)) << 32) |
+                          (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bv);
+      px_glds(reinterpret_cast<const void*>(bs), q ? v1 : v0,
+              __builtin_amdgcn_readfirstlane(slot + (unsigned)(pl * 4096 + sub * 2048 + q * 1024)));
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  float csum = 0.0f;
+  const bool do_colsum = CS && (p.colsum != nullptr) && (blk.y == 0) && (wn == 0);
+  const int a0a = PxFrag<LA, 2>::lane_off(lane), a0b = PxFrag<LB, 2>::lane_off(lane);
+
+  constexpr int AHEAD = NS - 1;
+#pragma unroll
+  for (int i = 0; i < AHEAD; ++i)
+    if (i < nst) issue(i);
+  int c_slot = 0;
+  for (int st = 0; st < nst; ++st) {
+    // this wave's 6 instructions of stage st have landed; the min(AHEAD - 1, nst - 1 - st) stages issued after it may fly
+    const int later = nst - 1 - st < AHEAD - 1 ? nst - 1 - st : AHEAD - 1;
+    if (later == 0) px_wait_vm<0>();
+    else if (later == 1) px_wait_vm<6>();
+    else px_wait_vm<12>();
+    // ... and so have the other waves'; the barrier also orders every wave's fragment reads of stage st - 1 ahead of the
+    // refill of its slot issued below
+    __builtin_amdgcn_s_barrier();
+    if (st + AHEAD < nst) issue(st + AHEAD);
+    const char* sl = px_lds + c_slot * PXS_STAGE;
+    c_slot = c_slot + 1 == NS ? 0 : c_slot + 1;
+    u32x4 fa[2][3], fb[2][3];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        fa[sub][pl] = pxs_frag<LA>(sl + pl * 4096 + sub * 2048, wm, a0a);
+        fb[sub][pl] = pxs_frag<LB>(sl + PXS_OPER + pl * 4096 + sub * 2048, wn, a0b);
+      }
+#define PX_BF(x) __builtin_bit_cast(bf16x8, x)
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {  // smallest terms first
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PX_BF(fa[sub][2]), PX_BF(fb[sub][0]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PX_BF(fa[sub][0]), PX_BF(fb[sub][2]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PX_BF(fa[sub][1]), PX_BF(fb[sub][1]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PX_BF(fa[sub][1]), PX_BF(fb[sub][0]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PX_BF(fa[sub][0]), PX_BF(fb[sub][1]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(PX_BF(fa[sub][0]), PX_BF(fb[sub][0]), acc, 0, 0, 0);
+    }
+#undef PX_BF
+    if (do_colsum) {
+#pragma unroll
+      for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int pl = 2; pl >= 0; --pl)
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            const unsigned u = fa[sub][pl][w];
+            csum += __uint_as_float(u << 16) + __uint_as_float(u & 0xFFFF0000u);
+          }
+    }
+  }
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  if (do_colsum) {
+    const float c = add_xor32(csum);
+    const int gm = m0 + 32 * wm + li;
+    if (h == 0 && gm < p.M && c != 0.0f) atomicAdd(p.colsum + gm, c);
+  }
+  __syncthreads();  // every wave is done with the ring: dslope_store uses its head
+  tile16_epilogue<R_, R_, false>(p, acc, m0 + 32 * wm, n0 + 32 * wn, slope, seed_off, blk.z, reinterpret_cast<float*>(px_lds),
+                                 blk.slot, p.K, XForm{}, XForm{});
+}
+
 // ---- operand split ---------------------------------------------------------------------------------------------------
 // x (rows x cols f32, leading dimension ld) -> hi / mid / lo planes [rows_pad][ldp], zeros in the padding.
 // One thread = 8 consecutive columns of one row: 32 bytes in, 3 x 16 bytes out.
@@ -639,8 +824,32 @@ int px_launch_cs(const MesmGemmArgs& a, const MesmPlanes& PA, const MesmPlanes& 
   return px_launch_ring<LA, LB, TM, CS, 2, 4>(a, PA, PB, s);
 }
 
+template <int LA, int LB, bool CS, int NS>
+int pxs_launch_ns(const MesmGemmArgs& a, const MesmPlanes& PA, const MesmPlanes& PB, hipStream_t s) {
+  constexpr int LDS = NS * PXS_STAGE;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pxs_kernel<LA, LB, CS, NS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            LDS) != hipSuccess)
+      return MESM_ELAUNCH;
+    attr_done = true;
+  }
+  const int z = a.split_k > 1 ? a.split_k : 1;
+  dim3 grid(((a.M + 63) / 64) * ((a.N + 63) / 64), 1, z);
+  hipLaunchKernelGGL((gemm_pxs_kernel<LA, LB, CS, NS>), grid, dim3(NTHREADS), LDS, s, a, PA, PB);
+  const int rc = mesm_launch_status();
+  return rc != MESM_OK ? rc : mesm_gemm_dslope_finish(a, (int64_t)grid.x * z, s);
+}
+
+template <int LA, int LB>
+int pxs_launch(const MesmGemmArgs& a, const MesmPlanes& PA, const MesmPlanes& PB, int ns, hipStream_t s) {
+  if (a.colsum) return ns == 2 ? pxs_launch_ns<LA, LB, true, 2>(a, PA, PB, s) : pxs_launch_ns<LA, LB, true, 3>(a, PA, PB, s);
+  return ns == 2 ? pxs_launch_ns<LA, LB, false, 2>(a, PA, PB, s) : pxs_launch_ns<LA, LB, false, 3>(a, PA, PB, s);
+}
+
 template <int LA, int LB, int TM>
 int px_launch(const MesmGemmArgs& a, const MesmPlanes& PA, const MesmPlanes& PB, hipStream_t s) {
+  if (g_px_ring == 32 || g_px_ring == 33 || g_px_ring == 0) return pxs_launch<LA, LB>(a, PA, PB, g_px_ring == 32 ? 2 : 3, s);
   return a.colsum ? px_launch_cs<LA, LB, TM, true>(a, PA, PB, s) : px_launch_cs<LA, LB, TM, false>(a, PA, PB, s);
 }
 

@@ -1025,10 +1025,10 @@ PX_CASES = [  # M, N, K, trans_a, trans_b, split_k
 
 
 @pytest.mark.parametrize("M,N,K,ta,tb,split", PX_CASES)
-@pytest.mark.parametrize("mode", [1, 2, 8])
+@pytest.mark.parametrize("mode", [1, 2, 8, 32, 33])
 def test_plane_gemm_matches_fp64(M, N, K, ta, tb, split, mode):
     """mesm_gemm_px (three bf16 planes per operand, six products on the bf16 matrix pipe, f32 accumulate) against fp64, at
-    the exact-f32 kernel's own error level; every layout pair, both tiles, the three loop forms (MESM_PX_RING), split-K with
+    the exact-f32 kernel's own error level; every layout pair, both tiles, the k-split loop forms (1, 2, 8) and the shared-stage kernel with a ring of 2 / 3 stages (32, 33), split-K with
     column sums, and the full epilogue."""
     from mesm_amd import kernels as kn
     from mesm_amd._lib import lib
