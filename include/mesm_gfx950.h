@@ -779,6 +779,8 @@ int mesm_ddp_init(const uint8_t* id128, int32_t rank, int32_t world, void** hand
 int mesm_ddp_allreduce(void* handle, float* buf, int64_t count, void* stream, int32_t side);
 int mesm_ddp_wait(void* handle, void* stream);
 int mesm_ddp_destroy(void* handle);
+/* ranks the communicator spans as RCCL reports it (ncclCommCount) */
+int mesm_ddp_count(void* handle, int32_t* ranks);
 const char* mesm_ddp_last_error(void);
 
 #ifdef __cplusplus

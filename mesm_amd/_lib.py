@@ -183,6 +183,7 @@ PROTOTYPES = {
     "mesm_ddp_allreduce": (ctypes.c_int, [c_ptr, c_ptr, _i64, c_ptr, _i32]),
     "mesm_ddp_wait": (ctypes.c_int, [c_ptr, c_ptr]),
     "mesm_ddp_destroy": (ctypes.c_int, [c_ptr]),
+    "mesm_ddp_count": (ctypes.c_int, [c_ptr, ctypes.POINTER(ctypes.c_int32)]),
     "mesm_ddp_last_error": (ctypes.c_char_p, []),
     "mesm_weighted_sum": (ctypes.c_int, [c_ptr, c_ptr, _i32, c_ptr, c_ptr]),
     "mesm_scale_vec": (ctypes.c_int, [c_ptr, c_ptr, _i32, c_ptr, c_ptr]),

@@ -21,6 +21,7 @@ typedef int (*fn_init_rank)(RcclComm*, int, RcclId, int);
 typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, RcclComm, hipStream_t);
 typedef int (*fn_destroy)(RcclComm);
 typedef const char* (*fn_errstr)(int);
+typedef int (*fn_count)(RcclComm, int*);
 constexpr int RCCL_FLOAT32 = 7, RCCL_SUM = 0;  // ncclFloat32, ncclSum (rccl.h)
 
 struct Api {
@@ -30,6 +31,7 @@ struct Api {
   fn_allreduce allreduce = nullptr;
   fn_destroy destroy = nullptr;
   fn_errstr errstr = nullptr;
+  fn_count count = nullptr;
 };
 Api g_api;
 char g_err[256] = "";
@@ -52,6 +54,7 @@ bool load_api() {
   a.allreduce = (fn_allreduce)dlsym(h, "ncclAllReduce");
   a.destroy = (fn_destroy)dlsym(h, "ncclCommDestroy");
   a.errstr = (fn_errstr)dlsym(h, "ncclGetErrorString");
+  a.count = (fn_count)dlsym(h, "ncclCommCount");
   if (!a.get_id || !a.init_rank || !a.allreduce || !a.destroy) {
     snprintf(g_err, sizeof g_err, "librccl.so.1 lacks a required symbol");
     return false;
@@ -134,6 +137,19 @@ extern "C" int mesm_ddp_wait(void* handle, void* stream) {
     return MESM_ELAUNCH;
   }
   d->side_used = false;
+  return MESM_OK;
+}
+
+// Ranks the communicator actually spans, as RCCL itself reports it (ncclCommCount): what a first multi-GPU run prints
+// to show that the library's own communicator, not a 1-rank stand-in, carried the gradients.
+extern "C" int mesm_ddp_count(void* handle, int32_t* ranks) {
+  Ddp* d = (Ddp*)handle;
+  if (!d || !ranks) return MESM_EINVAL;
+  if (!g_api.count) { *ranks = d->world; return MESM_OK; }
+  int n = 0;
+  const int rc = g_api.count(d->comm, &n);
+  if (rc != 0) { set_err("ncclCommCount", rc); return MESM_ELAUNCH; }
+  *ranks = n;
   return MESM_OK;
 }
 

@@ -101,6 +101,34 @@ class RcclComm:
     def wait(self):
         self._check(self._lib.lib().mesm_ddp_wait(self.handle, self._lib.stream_ptr()), "mesm_ddp_wait")
 
+    def count(self):
+        """ranks the communicator spans, as RCCL reports it (ncclCommCount)"""
+        n = self._ct.c_int32(0)
+        self._check(self._lib.lib().mesm_ddp_count(self.handle, self._ct.byref(n)), "mesm_ddp_count")
+        return int(n.value)
+
+
+def flat_checksum(flat):
+    """(sum, sum of squares, sum of |x| weighted by position) of a flat buffer in fp64, as a 3-element tensor on its
+    device: cheap, and sensitive to a permuted or partially reduced buffer"""
+    x = flat.detach().double()
+    w = torch.arange(1, x.numel() + 1, device=x.device, dtype=torch.float64) / x.numel()
+    return torch.stack([x.sum(), (x * x).sum(), (x.abs() * w).sum()])
+
+
+def ranks_agree(flat, process_group=None, rtol=0.0):
+    """True iff every rank holds the same flat buffer (after a gradient all-reduce they must: same sum, same order of
+    the RCCL ring on every rank): the checksums' MAX and MIN over ranks coincide.  -> (ok, relative spread).  Used by
+    bench.py after its first data-parallel step and by the gloo tests."""
+    c = flat_checksum(flat)
+    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+        return True, 0.0
+    hi, lo = c.clone(), c.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=process_group)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=process_group)
+    spread = float(((hi - lo).abs() / hi.abs().clamp_min(1e-30)).max())
+    return spread <= rtol, spread
+
 
 class GradReducer:
     def __init__(self, gradbuf, process_group=None, n_buckets=6, hook=True, force=False, inline=False, comm=None,

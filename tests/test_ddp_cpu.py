@@ -216,3 +216,40 @@ def test_buckets_cover_the_flat_buffer():
     assert red.buckets[0][0] == 0 and red.buckets[-1][1] == gb.numel
     for (l0, h0, _), (l1, _, _) in zip(red.buckets[:-1], red.buckets[1:]):
         assert h0 == l1
+
+
+def _agree_worker(rank, world, port, out):
+    _init(rank, world, port)
+    from mesm_amd.ddp import flat_checksum, ranks_agree
+    torch.manual_seed(3)
+    flat = torch.randn(1000)
+    same = ranks_agree(flat)                       # identical buffers on both ranks
+    flat2 = flat.clone()
+    if rank == 1:
+        flat2[517] += 1e-3                         # one element differs on one rank
+    diff = ranks_agree(flat2)
+    perm = flat.clone()
+    if rank == 1:
+        perm = perm.flip(0)                        # same multiset, other order: the position-weighted term sees it
+    out.put((rank, same, diff, ranks_agree(perm), flat_checksum(flat).tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_rank_agreement_check():
+    """the check bench.py runs after its first data-parallel step (every rank must hold the same reduced gradient
+    buffer): agrees on equal buffers, trips on a single differing element and on a permuted buffer"""
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_agree_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [out.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same, diff, perm, cs in res:
+        assert same == (True, 0.0)
+        assert diff[0] is False and diff[1] > 0
+        assert perm[0] is False

@@ -11,6 +11,7 @@
 """
 import argparse
 import os
+import sys
 
 import pytest
 import torch
@@ -454,3 +455,34 @@ def test_arena_partial_upload_rewrites_only_the_named_range_and_redraw_uses_it()
         assert abs(t1 - t2) <= 1e-6 * abs(t2), (t1, t2)
         seen.append(t1)
     assert len(set(seen)) > 1  # other negatives / masked words: another loss
+
+
+def test_bench_data_parallel_flow_is_self_diagnosing_on_one_rank():
+    """bench.py's N > 1 flow on ONE GPU (MESM_BENCH_FORCE_DDP=1: 1-rank groups, every collective really issued): the
+    headline is measured with `after` first; then the library's own communicator is built and counted (ncclCommCount),
+    its two captured forms are verified against `after` on the same batch and timed next to it, and the JSON line carries
+    all of it (config.ddp_diag) -- what the first real multi-GPU run will print."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MESM_BENCH_FORCE_DDP="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("MESM_DDP_MODE", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-steps", "0",
+                        "--no-extras", "--no-roofline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    d = line["config"]["ddp_diag"]
+    assert d["rccl_ranks"] == 1 and d["grad_checksum_spread_over_ranks"] == 0.0
+    assert set(d["probe_ms"]) == {"after", "own-inline", "own-overlapped"}
+    assert d["own_comm_selftest_exact"] is True
+    for form, v in d["own_forms_ranks_agree"].items():
+        assert v["ranks_agree"] and v["finite"], (form, v)
+    assert d["headline_form"] in ("after", "own-inline", "own-overlapped")
+    assert line["warmup"] == 1 and line["steps"] == 3 and line["value"] > 0
+    # and the failure path: the own communicator cannot be built -> the `after` headline stands, the error is reported
+    env["MESM_BENCH_FAIL_OWN"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-steps", "0",
+                        "--no-extras", "--no-roofline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])["config"]["ddp_diag"]
+    assert "simulated failure" in d["own_communicator_error"] and d["headline_form"] == "after"

@@ -11,16 +11,21 @@ import csv, json, sys
 csv.field_size_limit(1 << 30)
 
 
+ALL = {}
+
+
 def gemm_sum(path, counter):
-    tot, n, steps = 0.0, 0, 0
+    tot, n, steps, every = 0.0, 0, 0, 0.0
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
+        every += float(r["Counter_Value"])
         if "gemm_" in r["Kernel_Name"]:
             tot += float(r["Counter_Value"])
             n += 1
         elif "saliency_fwd_kernel" in r["Kernel_Name"]:
             steps += 1
+    ALL[counter] = every
     return tot, n, steps
 
 
@@ -36,6 +41,8 @@ out = {
     "fetch_kib_raw_per_launch": f / max(nf, 1), "write_kib_per_launch": w / max(nw, 1),
     "correction": "FETCH_SIZE x2 (gfx950: 128-B requests tallied at 64 B), WRITE_SIZE x1, KiB -> bytes",
     "hbm_bytes_per_launch": (2.0 * f / max(nf, 1) + w / max(nw, 1)) * 1024.0,
+    # every kernel of the step (same correction): the whole-step HBM-side traffic next to SURVEY 8d's algorithmic bytes
+    "step_hbm_bytes_all_kernels": (2.0 * ALL["FETCH_SIZE"] + ALL["WRITE_SIZE"]) * 1024.0 / steps,
 }
 if len(sys.argv) > 5:
     try:
