@@ -64,8 +64,10 @@ class GraphedStep:
         """caps: None = exact extents of `batch` (benchmarks); "auto" = bucketed capacities so that other
         batches of the same (N, Lv, Lw, groups) replay; or a dict with any of Lc / Lss / T / Tmax."""
         from .arena import Arena
+        from .hostplan import HostSpec
         self.model, self.crit = model, criterion
         self.dataset_name = dataset_name
+        self.spec = HostSpec.from_model(model, criterion, dataset_name)
         dev = batch["video_feat"].device
         self.dev = dev
         self.batch = dict(batch)  # static inputs: big tensors as given, everything small re-homed in the arena
@@ -151,70 +153,14 @@ class GraphedStep:
                 kn.gemm_tape(False)
         self._ptrs = self._param_ptrs()
 
-    # ------------------------------------------------------------------ capture-time capacities
+    # ------------------------------------------------------------------ host half (shared with the loader workers)
     def _resolve_caps(self, caps, batch, group_cap=None):
-        """group_cap (with caps="auto"): capacities for video groups of up to that many queries (the dataset's
-        maximum: every grouping then fits one graph per pair bucket), GT-clip runs of any length"""
-        if caps is None:
-            return {}
-        if caps == "auto":
-            caps = {}
-            N, Lv = batch["video_mask"].shape
-            if self.model.rec_fw:
-                caps["Lc"] = Lv if group_cap else min(Lv, _round_up(int(batch["clip_mask"].sum(1).max()), 8))
-            gmax = max(max(self._groups), group_cap or 0)
-            if self.model.rec_ss:
-                caps["M"] = gmax  # sentence slots per pair (SS branch): other groupings with <= M fit
-            if self.model.rec_ss and self.dataset_name == "qvhighlights":
-                vm = batch["video_mask"].cpu()
-                lens = [int(c.sum()) for c in torch.split(vm, self._groups)]
-                full = all(g == 1 for g in self._groups) and bool(vm.all()) and not group_cap
-                # 64 = one key tile of the attention kernels; a group cannot hold more than its pairs' clips
-                caps["Lss"] = Lv if full else (gmax * Lv if group_cap else min(_round_up(max(lens), 64), gmax * Lv))
-            if self.crit.multi_clip:
-                Q = self.model.num_queries
-                tmax = max(len(t["spans"]) for t in batch["norm_span"])
-                caps["Tmax"] = max(tmax, min(5, Q))  # QVHighlights keeps <= 5 windows (qvhighlights.py:148-150)
-                caps["T"] = N * caps["Tmax"]
-        return dict(caps)
-
-    def _words_mask_host(self, host):
-        """validity of every word on the host: the collate mask for token ids (cut like model.py:114-116), the
-        non-zero rows of pre-extracted features (post_process_text, model.py:145-152)"""
-        w = host["words_id"]
-        if w.dim() != 3:
-            return host["words_mask"][:, :self.model.max_words_l]
-        # numpy on purpose: a multi-threaded torch CPU reduction stalls ~17 ms next to a busy HIP queue on this
-        # platform (measured, tools/load_batch_probe.py); these are 2 MB
-        import numpy as np
-        a = w.numpy()
-        if self.model.normalize_txt:
-            n = np.maximum(np.sqrt((a * a).sum(-1, keepdims=True)), 1e-5)
-            a = a / n
-        return torch.from_numpy(a.sum(-1) != 0)
+        return self.spec.resolve_caps(caps, batch, self._groups, group_cap)
 
     def _host_arrays(self, host, neg_index, masked_words):
-        """{name: numpy array} of everything small the captured step reads: "p." the forward's plan, "t." the
-        criterion's target plan, "b." batch tensors below BIG bytes; plus the two metas and the word mask."""
-        m = self.model
-        wm = self._words_mask_host(host)
-        P = host["video_mask"].shape[0]
-        if wm.shape[0] < P:  # a big feature tensor that arrived with its real rows only (batching.pad_pairs)
-            wm = torch.cat([wm, wm[:1].expand(P - wm.shape[0], wm.shape[1])])
-        parr, pmeta = m.plan_arrays(host["video_mask"].numpy(), wm.numpy(), self._groups, self.dataset_name, True,
-                                    clip_mask=host["clip_mask"].numpy() if "clip_mask" in host else None,
-                                    neg_index=neg_index, masked_words=masked_words,
-                                    words_weight=host.get("words_weight"), Lc_cap=self.caps.get("Lc"),
-                                    Lss_cap=self.caps.get("Lss"), M_cap=self.caps.get("M"), n_valid=self._n_real)
-        tarr, tmeta = TargetPlan.arrays(host, self.crit.multi_clip, self.crit.gamma, T_cap=self.caps.get("T"),
-                                        Tmax_cap=self.caps.get("Tmax"))
-        arr = {"p." + k: v for k, v in parr.items()}
-        arr.update({"t." + k: v for k, v in tarr.items()})
-        for k, v in host.items():
-            # (num_clips has one entry per GROUP and is only read on the host: the step reads the plans)
-            if torch.is_tensor(v) and k not in ("words_weight", "num_clips") and v.numel() * v.element_size() <= self.BIG:
-                arr["b." + k] = v.numpy()
-        return arr, pmeta, tmeta, wm
+        """hostplan.HostSpec.host_arrays with this step's groups / capacities: {name: numpy array} of everything small
+        the captured step reads, the two metas and the word mask"""
+        return self.spec.host_arrays(host, self._groups, self.caps, self._n_real, neg_index, masked_words, self.BIG)
 
     def _param_ptrs(self):
         gb = self.model.gradbuf()
@@ -309,6 +255,51 @@ class GraphedStep:
                     self._stage_big(k, cur, v)
         self._turn ^= 1
         self._wm_cpu = wm
+
+    def load_prepared(self, prep):
+        """load_batch for a batch whose host half was done elsewhere (loader.HostPipeline.prepare in a worker process):
+        `prep` carries the arena arrays (placeholder draws), the metas, the word mask and the big feature tensors
+        (pinned when they came through a DataLoader with pin_memory).  Here: compatibility checks, the two host-RNG
+        draws of the reference's forward (in THIS process: its RNG stream), one arena upload, the feature copies.
+        Raises ValueError (nothing modified) when the batch does not fit this graph."""
+        if prep["spec"] != self.spec:
+            raise ValueError("GraphedStep.load_prepared: prepared for another model configuration")
+        groups = prep["groups"]
+        if groups != self._groups and (self.caps.get("M") is None or sum(groups) != sum(self._groups)):
+            raise ValueError("GraphedStep.load_prepared: group sizes changed %s -> %s" % (self._groups, groups))
+        if (prep["n_real"] is None) != (self._n_real is None):
+            raise ValueError("GraphedStep.load_prepared: pair-count mode differs from the captured step")
+        if {k: prep["caps"].get(k) for k in self.caps} != self.caps:
+            raise ValueError("GraphedStep.load_prepared: prepared with other capacities %r (graph: %r)" % (prep["caps"], self.caps))
+        pmeta, tmeta = prep["pmeta"], prep["tmeta"]
+        for k in ("vid_identity", "has_vid_src"):
+            if pmeta.get(k) != self._pmeta.get(k):
+                raise ValueError("GraphedStep.load_prepared: plan.%s changed (%r -> %r): needs its own graph"
+                                 % (k, self._pmeta.get(k), pmeta.get(k)))
+        arr = {k: (v.numpy() if torch.is_tensor(v) else v) for k, v in prep["arr"].items()}
+        self.arena.check(arr)
+        big = prep["big"]
+        for k, v in big.items():
+            cur = self.batch[k]
+            if cur.shape[1:] != v.shape[1:] or v.shape[0] > cur.shape[0]:
+                raise ValueError("GraphedStep.load_prepared: %s changed shape %s -> %s" % (k, tuple(cur.shape), tuple(v.shape)))
+        # nothing above modified anything; from here on: draws, copies
+        self._groups, self._n_real = groups, prep["n_real"]
+        self._wm_cpu = prep["wm"]
+        self.batch["words_weight"] = prep["words_weight"]
+        self.batch["num_clips"] = prep["num_clips"]
+        neg = self.model.draw_neg_padded(self._groups, self._n_real).numpy()
+        arr["p.neg_index"] = neg
+        mw = None
+        if "p.masked_words" in arr:
+            mw = self.model.draw_masked_words(self._wm_cpu, prep["words_weight"]).bool().numpy()
+            arr["p.masked_words"] = mw
+        self._arr, self._draws = arr, (neg, mw)
+        self.arena.upload(arr)
+        self.tplan.sizes, self.tplan.sumT = tmeta["sizes"], tmeta["sumT"]
+        for k, v in big.items():
+            self._stage_big(k, self.batch[k], v)
+        self._turn ^= 1
 
     _copy_stream = None
     _turn = 0
@@ -476,3 +467,26 @@ class StepCache:
         self.steps.setdefault(k, []).append(gs)
         self.captures += 1
         return gs.run(redraw=redraw), gs
+
+    def pipeline(self, keep_raw=True):
+        """the host half of `run` as a picklable object for loader workers (loader.HostPipeline).  keep_raw=False once
+        every bucket of the stream has its graph: the raw batch (needed only to capture) then does not travel."""
+        from .hostplan import HostSpec
+        from .loader import HostPipeline
+        return HostPipeline(HostSpec.from_model(self.model, self.crit, self.dataset_name), pad=self.pad, pairs=self.pairs,
+                            group_caps=self.group_caps, keep_raw=keep_raw)
+
+    def run_prepared(self, prep):
+        """`run` for a batch prepared by a loader worker (loader.HostPipeline.prepare): the graph of its bucket key takes
+        the arrays as they are (the two host draws are made here); a bucket without a graph yet goes through `run` on
+        the raw batch the worker kept alongside (prep["raw"]), which captures it."""
+        for gs in self.steps.get(prep["key"], []):
+            try:
+                gs.load_prepared(prep)
+            except ValueError:
+                continue
+            self.replays += 1
+            return gs.run(redraw=False), gs
+        if prep.get("raw") is None:
+            raise ValueError("StepCache.run_prepared: no graph for bucket %r and the prepared batch carries no raw batch" % (prep["key"],))
+        return self.run(prep["raw"], redraw=True)

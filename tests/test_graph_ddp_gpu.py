@@ -369,6 +369,53 @@ def test_a_loader_like_epoch_replays_from_a_handful_of_graphs():
     assert cache.replays >= 0.85 * n_batches, (cache.replays, cache.captures)  # 40 batches: at most 6 are captures
 
 
+def test_batches_prepared_by_loader_workers_replay_like_in_process_batches():
+    """SURVEY 8f row 2 / round-3 review item 6: the host half of a batch (clip / word / pair padding, the forward's
+    index plan, the criterion's targets) done by loader.HostPipeline -- in forked DataLoader workers -- and handed to
+    StepCache.run_prepared, against StepCache.run doing the same work in the training process: same graphs, same losses
+    and gradients for the same host draws (the draws stay in this process either way: same RNG stream)."""
+    import random
+    import numpy as np
+    from mesm_amd import synthetic
+    from mesm_amd.graphed import StepCache
+    from mesm_amd.loader import prepared_loader
+    args, model, crit = _build("C3b")
+    model.eval()  # dropout off: a replay is a function of the batch and the host draws alone
+    w = synthetic.WORKLOADS["C3b"]
+    cache = StepCache(model, crit, args.dataset_name, pad=(w["Lv"], w["Lw"]), pairs=8, group_caps=(5, 9))
+    rng = random.Random(23)
+    batches = []
+    for i in range(10):
+        groups = _qvh_group_sizes(rng, 8)
+        batches.append(synthetic.make_batch(w["dataset_name"], groups, w["Lv"], w["Lw"], w["v_feat_dim"], w["t_feat_dim"],
+                                            w["vocab_size"] + 1, seed=300 + i, ragged=True))
+    ref = []
+    for i, b in enumerate(batches):  # in-process path (captures the graphs of every bucket on the way)
+        torch.manual_seed(50 + i); np.random.seed(50 + i)
+        cache.run(b, redraw=True)          # first visit may capture: draw again on the replay path below
+        torch.manual_seed(50 + i); np.random.seed(50 + i)
+        t, gs = cache.run(b, redraw=True)
+        ref.append((float(t), model.gradbuf().flat.clone(), gs))
+    caps0 = cache.captures
+    pipe = cache.pipeline()
+    for workers in (0, 2):
+        loader = prepared_loader(batches, pipe, num_workers=workers, pin_memory=True)
+        for i, prep in enumerate(loader):
+            torch.manual_seed(50 + i); np.random.seed(50 + i)
+            t, gs = cache.run_prepared(prep)
+            tr, gr, gsr = ref[i]
+            assert gs is gsr, "prepared batch %d replayed another graph" % i
+            assert abs(float(t) - tr) < 1e-6 * max(1.0, abs(tr)), (i, float(t), tr)
+            rel = float((model.gradbuf().flat - gr).norm()) / max(float(gr.norm()), 1e-6)
+            assert rel < 1e-5, (i, rel)  # (split-K float atomics: the only run-to-run freedom)
+        del loader
+    assert cache.captures == caps0, "a prepared batch caused a capture"
+    # a prepared batch of a bucket without a graph falls back to the in-process path through its raw batch
+    fresh = StepCache(model, crit, args.dataset_name, pad=(w["Lv"], w["Lw"]), pairs=8, group_caps=(5, 9))
+    t, _ = fresh.run_prepared(fresh.pipeline().prepare(batches[0]))
+    assert fresh.captures == 1 and torch.isfinite(t)
+
+
 def test_a_late_gradient_under_capture_refuses_the_graph():
     """under capture the cross-rank late-gradient check cannot run (it needs a collective result on the
     host), so a graph captured on a batch whose contribution pattern differs from the learnt one would replay a
