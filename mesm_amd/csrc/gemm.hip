@@ -1362,7 +1362,7 @@ __device__ __forceinline__ void wstage64_body(const MesmGemmArgs& p, const Blk b
   }
   __syncthreads();  // dslope_store reuses the head of L
   tile16_epilogue<LA, LB, XF>(p, sum, m0 + 32 * (wave >> 1), n0 + 32 * (wave & 1), slope, seed_off, blk.z, L, blk.slot,
-                              KM, xa, xb);
+                              KM, xa, xb, WIDE_ON);
   L64_STAMP(29);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   L64_STAMP(30);
@@ -1848,8 +1848,9 @@ __global__ L64_BOUNDS void gemm_lds64_kernel(const MesmGemmArgs p, const SideRed
     if (h == 0 && gm < p.M && csum != 0.0f) atomicAdd(p.colsum + gm, csum);
   }
 
+  __syncthreads();  // every wave is done with the ring: the epilogue's store transposition uses it as scratch
   tile16_epilogue<LA, LB, XF>(p, acc, m0 + 32 * wm, n0 + 32 * wn, slope, seed_off, blockIdx.z, L, linear_block(), KM, xa,
-                              xb);
+                              xb, WIDE_ON);
   L64_STAMP(29);  // stores issued
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   L64_STAMP(30);  // stores acknowledged

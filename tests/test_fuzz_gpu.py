@@ -33,3 +33,18 @@ def test_sequence_of_sweep_777_including_the_case_whose_fp32_oracle_flips():
     import fuzz_replay
     assert fuzz_replay.replay(14, 777, "plain") == 0
     assert fuzz_replay.replay(14, 777, "poison") == 0
+
+
+def test_case_with_a_device_side_activation_kink_is_refereed():
+    """Case 227 of `fuzz_parity.py 300 4242` (round 4): the device gradient differs from BOTH oracles by 2.3e-2 on a PReLU
+    slope (1e-3 on everything upstream of the encoder).  Cause (profiles/r4b/fuzz_case227.md): encoder layer 0's FFN
+    pre-activation [42, 164] is -1.5e-08 in fp64 and +1.2e-07 on the device -- the mirror image of sweep 777's case 14.
+    The third referee (the fp64 oracle made to take the device's branch where |z64| <= 1e-5) has to accept it, and only
+    it: the case itself must come out `ok`."""
+    from fuzz_parity import draw, fuzz_case
+    import fuzz_parity
+    rng = random.Random(4242)
+    for case in range(227):
+        draw(rng, case)
+    tag, status = fuzz_case(rng, 227)
+    assert status == "ok", tag + " -> " + status
