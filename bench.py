@@ -575,7 +575,13 @@ def main():
                             "replayed %d x" % opt.steps,
                 "avg_launch_us": avg_ms * 1e3, "flops_per_launch": flops_per_launch,
                 "gemm_ms_per_step": prof["ms"] / opt.steps,
-                "algorithmic_bytes_per_launch": prof.get("bytes", 0) / max(prof["launches"], 1)})
+                "algorithmic_bytes_per_launch": prof.get("bytes", 0) / max(prof["launches"], 1),
+                # the same with every side matrix the fused epilogues touch (residual, second output, aux, RMW read)
+                "algorithmic_bytes_per_launch_with_side_operands": prof.get("bytes_with_sides", 0) / max(prof["launches"], 1)})
+            if traffic:
+                roofline["traffic_over_algorithmic"] = {
+                    "operands_only": traffic / max(roofline["algorithmic_bytes_per_launch"], 1.0),
+                    "with_side_operands": traffic / max(roofline["algorithmic_bytes_per_launch_with_side_operands"], 1.0)}
 
     # informational: the same steps with every batch arriving from HOST memory (PCIe-inclusive rate; never
     # `value`): the host batch goes through GraphedStep.load_batch (static inputs + rebuilt index plans)

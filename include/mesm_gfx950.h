@@ -213,6 +213,9 @@ int mesm_gemm_px(const MesmGemmArgs* args, const MesmPlanes* a, const MesmPlanes
 int mesm_gemm_tape(int32_t record);
 int mesm_gemm_tape_replay(void* stream, int32_t reps, double* total_ms, int64_t* launches,
                           double* total_flops, double* total_bytes);
+/* algorithmic bytes of one pass over the recorded tape: A + B + C only, and with every side matrix of the fused
+ * epilogues / prologues (second operands, residual, activation-gradient aux, accumulate's read of C, second output) */
+int mesm_gemm_tape_bytes(double* operands, double* with_sides);
 /* One recorded launch timed alone (`reps` back-to-back issues under one event pair) and what it carries:
  * shapes = up to 64 x (M, N, K, flags) int32, flags = split_k | a_layout << 8 | b_layout << 9 | grouped << 10.
  * Diagnostic (tools/tape_profile.py); mesm_gemm_tape_size = number of recorded launches. */

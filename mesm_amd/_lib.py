@@ -103,6 +103,7 @@ PROTOTYPES = {
     "mesm_gemm_tape_entry": (ctypes.c_int, [c_ptr, _i32, _i32, ctypes.POINTER(ctypes.c_double),
                                             ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "mesm_gemm_tape_size": (ctypes.c_int, []),
+    "mesm_gemm_tape_bytes": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "mesm_gemm_tape_replay": (ctypes.c_int, [c_ptr, _i32, ctypes.POINTER(ctypes.c_double),
                                              ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_double),
                                              ctypes.POINTER(ctypes.c_double)]),

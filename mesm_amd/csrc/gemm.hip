@@ -1043,8 +1043,8 @@ __global__ WS_BOUNDS void gemm_wstage_kernel(const MesmGemmArgs p, const SideRed
   side_reduce(sr);
   __shared__ __attribute__((aligned(16))) float L[ws_lds_floats(STAGES)];
   Blk blk;
-  xcd_tile(blockIdx.x, (p.M + 31) / 32, (p.N + 31) / 32, blk.x, blk.y);
-  blk.z = blockIdx.z; blk.slot = linear_block();
+  blk.slot = linear_block();
+  xcd_tile_z((int)blk.slot, (p.M + 31) / 32, (p.N + 31) / 32, p.split_k, blk.x, blk.y, blk.z);
   wstage_body<LA, LB, XF, STAGES>(p, blk, L);
 }
 
@@ -1080,8 +1080,7 @@ __global__ WS_BOUNDS void gemm_wstage_group_kernel(const GroupArgs g, const Side
   const int local = bid - first;
   const int mt = (p.M + 31) / 32, nt = (p.N + 31) / 32;
   Blk blk;
-  blk.z = local / (mt * nt);
-  xcd_tile(local - blk.z * (mt * nt), mt, nt, blk.x, blk.y);
+  xcd_tile_z(local, mt, nt, p.split_k, blk.x, blk.y, blk.z);  // (local & 7 names an XCD up to a rotation by the problem's first workgroup)
   blk.slot = local;
   constexpr int R = MESM_LAYOUT_REDUCE_CONTIG, O = MESM_LAYOUT_OUTER_CONTIG;
   const bool xf = p.a_act != MESM_ACT_NONE || p.b_act != MESM_ACT_NONE || p.a_drop_p > 0.f || p.b_drop_p > 0.f;
@@ -1362,7 +1361,7 @@ __device__ __forceinline__ void wstage64_body(const MesmGemmArgs& p, const Blk b
   }
   __syncthreads();  // dslope_store reuses the head of L
   tile16_epilogue<LA, LB, XF>(p, sum, m0 + 32 * (wave >> 1), n0 + 32 * (wave & 1), slope, seed_off, blk.z, L, blk.slot,
-                              KM, xa, xb, WIDE_ON);
+                              KM, xa, xb);
   L64_STAMP(29);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   L64_STAMP(30);
@@ -1373,8 +1372,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_wstage64_kernel(const MesmGemmA
   side_reduce(sr);
   __shared__ __attribute__((aligned(16))) float L[4 * 4 * WS_SLAB];  // 4 waves x 4 slabs = 64 KB
   Blk blk;
-  xcd_tile(blockIdx.x, (p.M + 63) / 64, (p.N + 63) / 64, blk.x, blk.y);
-  blk.z = blockIdx.z; blk.slot = linear_block();
+  blk.slot = linear_block();
+  xcd_tile_z((int)blk.slot, (p.M + 63) / 64, (p.N + 63) / 64, p.split_k, blk.x, blk.y, blk.z);
   wstage64_body<LA, LB, XF, BF>(p, blk, L);
 }
 
@@ -1556,8 +1555,8 @@ template <int LA, int LB, bool XF, int RB>
 __global__ __launch_bounds__(NTHREADS) void gemm_wtall_kernel(const MesmGemmArgs p) {
   __shared__ __attribute__((aligned(16))) float L[4 * (RB + 1) * WS_SLAB];  // RB = 5: 96 KB, RB = 3: 64 KB
   Blk blk;
-  xcd_tile(blockIdx.x, (p.M + 32 * RB - 1) / (32 * RB), (p.N + 31) / 32, blk.x, blk.y);
-  blk.z = blockIdx.z; blk.slot = linear_block();
+  blk.slot = linear_block();
+  xcd_tile_z((int)blk.slot, (p.M + 32 * RB - 1) / (32 * RB), (p.N + 31) / 32, p.split_k, blk.x, blk.y, blk.z);
   wtall_body<LA, LB, XF, RB>(p, blk, L);
 }
 
@@ -1692,8 +1691,8 @@ __global__ L64_BOUNDS void gemm_lds64_kernel(const MesmGemmArgs p, const SideRed
   const int li = lane & 31, h = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   L64_STAMP(0);
-  int tbx, tby;
-  xcd_tile(blockIdx.x, (p.M + 63) / 64, (p.N + 63) / 64, tbx, tby);
+  int tbx, tby, tbz;
+  xcd_tile_z((int)linear_block(), (p.M + 63) / 64, (p.N + 63) / 64, p.split_k, tbx, tby, tbz);
   const int m0 = tbx * 64, n0 = tby * 64;
 
   const int KM = gemm_kmain(p);  // reduce indices [KM, K) are added in the epilogue of the first k-slice
@@ -1701,10 +1700,10 @@ __global__ L64_BOUNDS void gemm_lds64_kernel(const MesmGemmArgs p, const SideRed
   if (p.split_k > 1) {
     int chunk = (p.K + p.split_k - 1) / p.split_k;
     chunk = ((chunk + BK_MAX - 1) / BK_MAX) * BK_MAX;
-    kbeg = blockIdx.z * chunk;
+    kbeg = tbz * chunk;
     kend = kbeg + chunk < KM ? kbeg + chunk : KM;
     if (kbeg >= KM) {
-      if (blockIdx.z > 0) return;
+      if (tbz > 0) return;
       kbeg = kend = KM;
     }
   }
@@ -1844,13 +1843,11 @@ __global__ L64_BOUNDS void gemm_lds64_kernel(const MesmGemmArgs p, const SideRed
   if (do_colsum) {
     csum = add_xor32(csum);
     const int gm = m0 + 32 * wm + li;
-    if (blockIdx.z == 0 && KM < p.K) csum += tail_colsum<LA, XF>(p, gm, KM, xa);
+    if (tbz == 0 && KM < p.K) csum += tail_colsum<LA, XF>(p, gm, KM, xa);
     if (h == 0 && gm < p.M && csum != 0.0f) atomicAdd(p.colsum + gm, csum);
   }
 
-  __syncthreads();  // every wave is done with the ring: the epilogue's store transposition uses it as scratch
-  tile16_epilogue<LA, LB, XF>(p, acc, m0 + 32 * wm, n0 + 32 * wn, slope, seed_off, blockIdx.z, L, linear_block(), KM, xa,
-                              xb, WIDE_ON);
+  tile16_epilogue<LA, LB, XF>(p, acc, m0 + 32 * wm, n0 + 32 * wn, slope, seed_off, tbz, L, linear_block(), KM, xa, xb);
   L64_STAMP(29);  // stores issued
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   L64_STAMP(30);  // stores acknowledged
@@ -2151,6 +2148,26 @@ extern "C" int mesm_gemm_tape_replay(void* stream, int32_t reps, double* total_m
   *total_flops = flops;
   *total_bytes = bytes;
   return rc;
+}
+
+// Algorithmic bytes of ONE pass over the tape, two ways: `operands` = A + B read once, C written once (the figure
+// mesm_gemm_tape_replay reports); `with_sides` = that plus every side matrix the fused epilogue / prologue must touch
+// once: second operands (A2, B2), the residual, the activation-gradient aux, a read of C when the launch accumulates,
+// the second output.  Bias / colsum / slope vectors and split-K partial sums are not counted.
+extern "C" int mesm_gemm_tape_bytes(double* operands, double* with_sides) {
+  if (!operands || !with_sides) return MESM_EINVAL;
+  double o = 0.0, w = 0.0;
+  for (const TapeEntry& e : g_tape.launches)
+    for (const MesmGemmArgs& a : e.args) {
+      const double mk = (double)a.M * a.K, kn = (double)a.K * a.N, mn = (double)a.M * a.N;
+      o += 4.0 * (mk + kn + mn);
+      w += 4.0 * (mk * (a.A2 ? 2 : 1) + kn * (a.B2 ? 2 : 1) +
+                  mn * (1 + (a.accumulate ? 1 : 0) + (a.residual ? 1 : 0) +
+                        ((a.aux && a.e_actgrad != MESM_ACT_NONE) ? 1 : 0) + (a.pre_out ? 1 : 0)));
+    }
+  *operands = o;
+  *with_sides = w;
+  return MESM_OK;
 }
 
 // One entry of the tape timed alone: `reps` back-to-back launches of launch `idx` under one event pair, and what

@@ -42,6 +42,39 @@ __device__ __forceinline__ void xcd_tile(int lid, int mt, int nt, int& bx, int& 
   by = t - bx * nt;
 }
 
+// Split-K launches (grid = tiles x 1 x S, or a grouped launch's run of tiles x S workgroups): `lid` = tile + tiles * slice
+// as launched.  With xcd_tile() alone every XCD walks ALL k-slices of its tile range, so the operand that is shared
+// between its row tiles is fetched into all 8 L2s (PMC, round 3: a 1024 x 256 x 4800 weight gradient at S = 4 pulled
+// 72 MB for 25 MB of operands).  Here an XCD works on ONE slice: S in {2, 4, 8}: 8 / S XCDs share a slice and split its
+// tiles in contiguous ranges; S a multiple of 8: XCD c takes the slices = c (mod 8).  `MESM_XCD_Z` = 0 keeps the old map
+// (A/B builds).  The map needs the tile count to divide evenly; otherwise the old one applies.
+#ifndef MESM_XCD_Z
+#define MESM_XCD_Z 1
+#endif
+__device__ __forceinline__ void xcd_tile_z(int lid, int mt, int nt, int S, int& bx, int& by, int& z) {
+  const int T = mt * nt;
+  if (MESM_XCD_Z && S > 1) {
+    const int xcd = lid & 7, idx = lid >> 3;
+    if (S <= 8 && (8 % S) == 0 && T % (8 / S) == 0) {
+      const int G = 8 / S;
+      z = xcd / G;
+      const int t = (xcd - z * G) * (T / G) + idx;
+      bx = t / nt;
+      by = t - bx * nt;
+      return;
+    }
+    if ((S & 7) == 0) {
+      const int zi = idx / T, t = idx - zi * T;
+      z = zi * 8 + xcd;
+      bx = t / nt;
+      by = t - bx * nt;
+      return;
+    }
+  }
+  z = S > 1 ? lid / T : 0;
+  xcd_tile(lid - z * T, mt, nt, bx, by);
+}
+
 __device__ __forceinline__ void dslope_store(const MesmGemmArgs& p, float part, float* sh4, int64_t slot) {
   part = wave_sum(part);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -111,38 +144,9 @@ __device__ __forceinline__ void tail_accumulate(const MesmGemmArgs& p, float (&t
 // wave-uniform multiples of the leading dimension.  (In-kernel stamps, tools/l64_trace.py: the
 // per-element form took ~8,000 cycles per 32x32 tile, as long as 3.5 k-tiles of MFMA work.)
 // FULL: the wave's 32 x 32 tile lies inside C, no bounds handling at all.
-// A wave's 32 x 32 block of final values (NV = 16: column lane & 31, rows RO(i) + 4 (lane >> 5)) -> memory as 16-byte
-// stores: transposed through 4.6 KB of wave-private LDS so that a store instruction writes 8 rows x 128 contiguous bytes
-// (as 4-byte stores an instruction writes 2 rows x 128 bytes and a 19.6 MB output drains at ~1.4 TB/s: 3.5-10 us of the
-// 1024- / 2818- / 5003-wide products were their store phase, tools/f32_store_probe.py).  dst = &M[tile row 0][tile col 0].
-// The LDS operations of one wave execute in order: the read-back needs no barrier.
-#ifndef MESM_WIDE_STORE
-#define MESM_WIDE_STORE 1  // A/B: tools/build_variant.sh narrow -DMESM_WIDE_STORE=0
-#endif
-constexpr bool WIDE_ON = MESM_WIDE_STORE != 0;
-constexpr int WIDE_STRIDE = 36;               // floats per scratch row (16-byte aligned rows)
-constexpr int WIDE_FLOATS = 32 * WIDE_STRIDE;  // per wave
-template <typename RowOff>
-__device__ __forceinline__ void wide_store32(float* S, float* dst, int64_t ld, const float (&t)[16], RowOff RO) {
-  const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) S[(RO(i) + 4 * h) * WIDE_STRIDE + li] = t[i];
-  const int r = lane >> 3, c4 = (lane & 7) * 4;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = r + 8 * j;
-    const float4 v = *reinterpret_cast<const float4*>(S + row * WIDE_STRIDE + c4);
-    *reinterpret_cast<float4*>(dst + (int64_t)row * ld + c4) = v;
-  }
-}
-
-// S (optional): WIDE_FLOATS floats of wave-private LDS; with it, a FULL 32 x 32 block (NV = 16) leaves through
-// wide_store32 (C when it is plainly stored, and the pre-activation second output)
 template <int NV, bool FULL, typename RowOff>
 __device__ __forceinline__ float staged_epilogue(const MesmGemmArgs& p, float (&t)[NV], int rbase, int col,
-                                                 float slope, uint32_t seed_off, bool first_split, RowOff RO,
-                                                 float* S = nullptr) {
-  const bool wide_ok = FULL && NV == 16 && S != nullptr;
+                                                 float slope, uint32_t seed_off, bool first_split, RowOff RO) {
   const bool colok = FULL || col < p.N;
   const int colc = colok ? col : p.N - 1;
   bool ok[NV];
@@ -166,18 +170,9 @@ __device__ __forceinline__ float staged_epilogue(const MesmGemmArgs& p, float (&
   for (int i = 0; i < NV; ++i) t[i] = t[i] * sc + bias_v;
   if (p.pre_out != nullptr) {  // second output: the pre-activation (what the backward's e_actgrad reads as aux)
     float* pp = p.pre_out + ((int64_t)rbase * p.ldpre + col);
-    if constexpr (NV == 16) {
-      if (wide_ok && (p.ldpre & 3) == 0 && (((uintptr_t)p.pre_out) & 15) == 0) {
-        const int lane = threadIdx.x & 63;
-        wide_store32(S, pp - (int64_t)(4 * (lane >> 5)) * p.ldpre - (lane & 31), p.ldpre, t, RO);
-        pp = nullptr;
-      }
-    }
-    if (pp != nullptr) {
 #pragma unroll
-      for (int i = 0; i < NV; ++i)
-        if (ok[i]) pp[(int64_t)RO(i) * p.ldpre] = t[i];
-    }
+    for (int i = 0; i < NV; ++i)
+      if (ok[i]) pp[(int64_t)RO(i) * p.ldpre] = t[i];
   }
   if (p.e_act != MESM_ACT_NONE) {
 #pragma unroll
@@ -239,13 +234,6 @@ __device__ __forceinline__ float staged_epilogue(const MesmGemmArgs& p, float (&
     for (int i = 0; i < NV; ++i)
       if (ok[i]) atomicAdd(cp + (int64_t)RO(i) * p.ldc, t[i]);
   } else {
-    if constexpr (NV == 16) {
-      if (wide_ok && (p.ldc & 3) == 0 && (((uintptr_t)p.C) & 15) == 0) {
-        const int lane = threadIdx.x & 63;
-        wide_store32(S, cp - (int64_t)(4 * (lane >> 5)) * p.ldc - (lane & 31), p.ldc, t, RO);
-        return dslope_part;
-      }
-    }
 #pragma unroll
     for (int i = 0; i < NV; ++i)
       if (ok[i]) cp[(int64_t)RO(i) * p.ldc] = t[i];
@@ -296,12 +284,10 @@ __device__ __forceinline__ void ksplit_epilogue(const MesmGemmArgs& p, const f32
 
 // Epilogue of ONE wave-owned 32 x 32 tile held in 16 accumulator registers (register r <-> row
 // 4h + (r & 3) + 8 (r >> 2), column lane & 31).
-// wide: sh4 points at >= 64 + 4 * WIDE_FLOATS floats of LDS no wave reads any more (the caller's barrier): the block's
-// outputs leave as 16-byte stores (wide_store32)
 template <int LA, int LB, bool XF>
 __device__ __forceinline__ void tile16_epilogue(const MesmGemmArgs& p, const f32x16& acc, int row0, int col0,
                                                 float slope, uint32_t seed_off, int bz, float* sh4,
-                                                int64_t slot, int km, const XForm& xa, const XForm& xb, bool wide = false) {
+                                                int64_t slot, int km, const XForm& xa, const XForm& xb) {
   const int lane = threadIdx.x & 63;
   const int li = lane & 31, h = lane >> 5;
   const bool first_split = (p.split_k <= 1) || (bz == 0);
@@ -312,8 +298,7 @@ __device__ __forceinline__ void tile16_epilogue(const MesmGemmArgs& p, const f32
   if (first_split && km < p.K) tail_accumulate<16, LA, LB, XF>(p, t, row0 + 4 * h, col0 + li, km, xa, xb, RO);
   float dslope_part;
   if (row0 + 32 <= p.M && col0 + 32 <= p.N)
-    dslope_part = staged_epilogue<16, true>(p, t, row0 + 4 * h, col0 + li, slope, seed_off, first_split, RO,
-                                            wide ? sh4 + 64 + (threadIdx.x >> 6) * WIDE_FLOATS : nullptr);
+    dslope_part = staged_epilogue<16, true>(p, t, row0 + 4 * h, col0 + li, slope, seed_off, first_split, RO);
   else
     dslope_part = staged_epilogue<16, false>(p, t, row0 + 4 * h, col0 + li, slope, seed_off, first_split, RO);
   if (p.e_actgrad == MESM_ACT_PRELU && p.dslope) dslope_store(p, dslope_part, sh4, slot);

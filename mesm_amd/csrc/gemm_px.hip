@@ -698,7 +698,7 @@ __global__ __launch_bounds__(NTHREADS, NS == 2 ? 3 : 2) void gemm_pxs_kernel(con
   }
   __syncthreads();  // every wave is done with the ring: dslope_store uses its head
   tile16_epilogue<R_, R_, false>(p, acc, m0 + 32 * wm, n0 + 32 * wn, slope, seed_off, blk.z, reinterpret_cast<float*>(px_lds),
-                                 blk.slot, p.K, XForm{}, XForm{}, WIDE_ON);
+                                 blk.slot, p.K, XForm{}, XForm{});
 }
 
 // ---- operand split ---------------------------------------------------------------------------------------------------

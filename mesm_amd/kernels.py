@@ -1097,4 +1097,7 @@ def gemm_tape_replay(reps=1):
     ms, n, fl, by = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double(), ctypes.c_double()
     check(lib().mesm_gemm_tape_replay(stream_ptr(), int(reps), ctypes.byref(ms), ctypes.byref(n),
                                       ctypes.byref(fl), ctypes.byref(by)), "mesm_gemm_tape_replay")
-    return {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}
+    o, w = ctypes.c_double(), ctypes.c_double()
+    check(lib().mesm_gemm_tape_bytes(ctypes.byref(o), ctypes.byref(w)), "mesm_gemm_tape_bytes")
+    return {"ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value,
+            "bytes_with_sides": w.value * int(reps)}
