@@ -19,15 +19,16 @@ Prints ONE JSON line on rank 0 (contract in the task statement) including
   roofline     — SURVEY 8d's step-level figures: `step_hbm_frac` = algorithmic bytes of the step
                  (0.272 GB + N_pairs x 109.0 MB) / t_step / 8 TB/s and `step_mfma_frac` = N_pairs x 6.22
                  GFLOP / t_step / 157.3 TF; and, as achieved / peak / frac, the dominant kernel family
-                 (mesm_gemm_f32: exact-f32 MFMA GEMMs): algorithmic FLOPs per launch / mean launch
+                 (mesm_gemm_f32: f32 GEMMs whose large products run as six bf16 MFMA products over exactly split
+                 operands, f32 accumulate -- MESM_GEMM_BF16X=0 for f32 MFMA throughout): algorithmic FLOPs per launch / mean launch
                  duration, HIP events on the launch stream around back-to-back replays of the GEMM
                  launches of one captured step, right after the timed region; `traffic` = HBM bytes per
                  launch from the rocprofv3 PMC passes committed under profiles/ (null when that profile
                  was taken with another launch count, i.e. is stale); `families` = in-situ ms per kernel
                  family (GEMM / attention / LayerNorm / losses / element-wise / assembly) by ablation;
                  `attention_hbm_frac` / `layernorm_hbm_frac` = SURVEY 8d's byte split / family ms / 8 TB/s;
-                 `experimental` = the split-bf16 GEMM modes (MESM_GEMM_BF16X=6|3: ms/step, GEMM TF, the parity
-                 suite's verdict) -- never the headline, whose dtype stays exact f32;
+                 `exact_f32` / `exact_f32_ms` = the same step with every product on the f32 MFMA instruction;
+                 `experimental` = the two-term split (MESM_GEMM_BF16X=3), never the headline;
   config       — besides the workload: `ddp`, and (not part of the metric) the eager step, the optimizer tail, the
                  PCIe-inclusive rate, and `loader_like_epoch_not_in_metric`: a stream of loader-shaped batches
                  from host memory through StepCache (pair axis padded, real count on the device);
@@ -47,6 +48,18 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_mfma_f32_32x32x16_bf16)
+
+
+def gemm_mode():
+    """the GEMM arithmetic of this process (mesm_amd/csrc/gemm.hip: MESM_GEMM_BF16X, read once at load)"""
+    e = os.environ.get("MESM_GEMM_BF16X")
+    return int(e) if e in ("0", "3", "6") else 6
+
+
+def dtype_name():
+    return {6: "f32 (3-term split-bf16 products, f32 accumulate)", 0: "f32",
+            3: "f32 (EXPERIMENTAL 2-term split-bf16 products: 16-bit mantissa)"}[gemm_mode()]
 SETTLE_STEPS = 60  # untimed steps in front of the SECOND, informational timing (config.settled: not the headline)
 PEAK_HBM_TBS = 8.0            # MI355X_MICROARCH.md: HBM3E spec peak
 # SURVEY.md 8d: algorithmic work of one step (kernel-boundary traffic / FLOPs); closed form for C3a-type batches,
@@ -143,7 +156,7 @@ def ddp_diagnostics(opt, world, rank, dev, model, crit, batch, args, g_after, r_
         _WATCHDOG["line"] = {
             "metric": "clip-query pairs/sec (fwd+bwd)", "value": n_pairs * world / t_after, "unit": "pairs/s",
             "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": t_after * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_name(), "data": "synthetic",
             "config": {"workload": opt.workload, "global_pairs": n_pairs * world, "parallelism": "dp%d" % world,
                        "launch": "hip-graph",
                        "ddp": "torch process group: one blocking all-reduce of the flat buffer after the graph replay "
@@ -567,8 +580,10 @@ def main():
                 roofline["step_traffic"] = tj["step_hbm_bytes_all_kernels"]
                 roofline["step_traffic_source"] = "profiles/gemm_traffic.json (%s), FETCH_SIZE x 2 + WRITE_SIZE over every kernel" % tj.get("profile", "?")
             roofline.update({
-                "kernel": "mesm_gemm_f32 family (gemm_wstage / gemm_lds64 / gemm_frag / gemm_f32 kernels, "
-                          "v_mfma_f32_32x32x2_f32)",
+                "kernel": "mesm_gemm_f32 family (gemm_wstage64_group / gemm_wstage64: v_mfma_f32_32x32x16_bf16 x 6 over "
+                          "split operands; gemm_wstage / gemm_lds64 / gemm_frag: v_mfma_f32_32x32x2_f32)"
+                          if gemm_mode() == 6 else
+                          "mesm_gemm_f32 family (gemm_wstage / gemm_lds64 / gemm_frag / gemm_f32 kernels, v_mfma_f32_32x32x2_f32)",
                 "achieved": achieved, "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                 "traffic_source": tsrc, "launches_per_step": lps,
                 "measured": "HIP event pair around the back-to-back GEMM launches of one captured step, "
@@ -718,29 +733,40 @@ def main():
         roofline["attention_hbm_frac"] = _hbm_frac(0.45e9, families.get("attention_ms"))
         roofline["layernorm_hbm_frac"] = _hbm_frac(0.65e9, families.get("layernorm_ms"))
 
-    # EXPERIMENTAL, never the headline (value / dtype above are exact f32): the same step with the large GEMMs' products
-    # on v_mfma_f32_32x32x16_bf16 over operands split into bf16 terms (gemm.hip: SplitFrag; MESM_GEMM_BF16X = 6 | 3),
-    # each mode in a child process; `parity` = the GPU parity suite under that mode at unchanged tolerances
+    # The same step in the other GEMM arithmetics, each in a child process (the switch is read once at load):
+    # `exact_f32` = every product on v_mfma_f32_32x32x2_f32 (MESM_GEMM_BF16X=0; `exact_f32_ms` beside the headline so a
+    # reader sees both); `experimental.bf16x3` = the two-term split (16-bit mantissa: narrower than the reference, fails
+    # parity tests, never the headline).  `parity` = the GPU parity suite under that mode at unchanged tolerances
     # (tools/experimental_parity.py, committed under profiles/)
     if extras and not opt.eager and world == 1 and opt.workload == "C3a" and "MESM_GEMM_BF16X" not in os.environ:
-        exp = {}
         ppath = os.path.join(ROOT, "profiles", "experimental_parity.json")
         parity = json.load(open(ppath)) if os.path.exists(ppath) else {}
-        for mode in ("6", "3"):
+
+        def other_mode(mode):
             try:
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", str(opt.steps), "--warmup",
                                     str(opt.warmup), "--cpu-steps", "0", "--no-extras"],
                                    env=dict(os.environ, MESM_GEMM_BF16X=mode), capture_output=True, text=True, timeout=300)
                 lj = json.loads(r.stdout.strip().splitlines()[-1])
-                exp["bf16x" + mode] = {"ms_per_step": lj["ms_per_step"], "gemm_tflops": lj["roofline"]["achieved"],
-                                       "gemm_ms_per_step": lj["roofline"].get("gemm_ms_per_step"),
-                                       "parity": parity.get("bf16x" + mode, "not recorded")}
+                return {"ms_per_step": lj["ms_per_step"], "gemm_tflops": lj["roofline"]["achieved"],
+                        "gemm_ms_per_step": lj["roofline"].get("gemm_ms_per_step"),
+                        "parity": parity.get({"0": "exact_f32", "3": "bf16x3"}[mode], "not recorded")}
             except Exception as e:
-                exp["bf16x" + mode] = {"error": "%s: %s" % (type(e).__name__, e)}
-        exp["note"] = ("experimental: GEMMs with >= 2400 output rows or reduce indices through split-bf16 MFMA products "
-                       "(6 = hi*hi+hi*mid+mid*hi+mid*mid+hi*lo+lo*hi, 3 = the first three), operands split in registers; "
-                       "headline value / dtype stay exact f32")
-        roofline["experimental"] = exp
+                return {"error": "%s: %s" % (type(e).__name__, e)}
+        ex = other_mode("0")
+        roofline["exact_f32"] = ex
+        roofline["exact_f32_ms"] = ex.get("ms_per_step")
+        roofline["experimental"] = {"bf16x3": other_mode("3"),
+                                    "note": "two-term split (hi*hi + hi*mid + mid*hi): 16-bit mantissa, NOT the headline"}
+    if roofline.get("achieved") and gemm_mode() == 6:
+        # what the matrix pipes see: six bf16 products per algorithmic f32 product on the launches that take the split
+        # path (an upper bound: it prices EVERY GEMM flop of the step at six products, the small 32 x 32-tile launches
+        # still run v_mfma_f32_32x32x2_f32)
+        roofline["bf16_mfma_issue"] = {"achieved_upper": 6.0 * roofline["achieved"], "peak": PEAK_BF16_MFMA_TFLOPS,
+                                       "unit": "TFLOP/s", "frac_upper": 6.0 * roofline["achieved"] / PEAK_BF16_MFMA_TFLOPS}
+        roofline["arithmetic"] = ("operands split exactly into hi + mid + lo bf16 (x = hi + mid + lo), products lo*hi, hi*lo, "
+                                  "mid*mid, mid*hi, hi*mid, hi*hi on v_mfma_f32_32x32x16_bf16, f32 accumulate; `achieved` / "
+                                  "`frac` stay ALGORITHMIC f32 flops against the f32 MFMA peak (157.3 TF)")
 
     cpu_baseline = None
     if rank == 0 and world == 1 and opt.cpu_steps > 0:
@@ -774,7 +800,7 @@ def main():
             "metric": "clip-query pairs/sec (fwd+bwd)", "value": n_pairs * world / t_step,
             "unit": "pairs/s", "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup,
             "ms_per_step": t_step * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": dtype_name(), "data": "synthetic",
             "config": {"workload": "%s: %s, %d pairs/GPU (%d groups), Lv=%d, Lw=%d, "
                                    "Dv=%d, Dt=%d, C=%d, 10 moment queries, train mode (dropout on)"
                                    % (opt.workload, {"qvhighlights": "QVHighlights C+SF", "charades": "Charades-STA",

@@ -1135,7 +1135,7 @@ bool wstage_ok(const MesmGemmArgs& a) {
   return ok(a.a_layout, a.M) && ok(a.b_layout, a.N);
 }
 
-// EXPERIMENTAL split-precision path (never the default, never the benchmark's headline): the products of a stage
+// Split-precision products (BF = 6: the default for the large products since round 4; BF = 3 experimental): a stage
 // on v_mfma_f32_32x32x16_bf16 (16x the f32 MFMA rate) with every f32 operand value split exactly into bf16 terms
 // x = hi + mid + lo (8 mantissa bits each; hi and mid by truncation, so x - hi and x - hi - mid are exact f32
 // subtractions) and the significant cross products accumulated in f32:
@@ -1150,6 +1150,16 @@ template <int BF>
 struct SplitFrag {
   u32x4 hi[2], mid[2], lo[2];  // [bf16 k-step of 16][4 dwords = 8 bf16]
   // v[s][j] = operand[outer][kb + 8 s + 4 h + j]: k-step t takes s = 2t, 2t + 1 (the same slot map on both operands)
+  __device__ __forceinline__ void fake(const float (&v)[4][4]) {  // probe builds: no split arithmetic
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        hi[t][i] = __float_as_uint(v[2 * t + (i >> 1)][2 * (i & 1)]);
+        mid[t][i] = __float_as_uint(v[2 * t + (i >> 1)][2 * (i & 1) + 1]);
+        lo[t][i] = hi[t][i];
+      }
+  }
   __device__ __forceinline__ void make(const float (&v)[4][4]) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -1261,10 +1271,12 @@ __device__ __forceinline__ void wstage64_body(const MesmGemmArgs& p, const Blk b
     ws_read<LB>(mine + 2 * WS_SLAB, li, h, b[0]);
     ws_read<LB>(mine + 3 * WS_SLAB, li, h, b[1]);
     const int kb = k0 + 32 * st;
+#ifndef MESM_W64_NO_LOAD  // (probe builds MESM_W64_NO_*: wrong results, where does a stage's time go -- tools/w64_probe.py)
     if (st + 1 < nst) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments are in registers: refill the slabs
       issue(st + 1);
     }
+#endif
     if (kb + 32 > k1) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -1302,13 +1314,28 @@ __device__ __forceinline__ void wstage64_body(const MesmGemmArgs& p, const Blk b
       SplitFrag<BF> sa[2], sb[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
+#ifdef MESM_W64_NO_SPLIT
+        sa[t].fake(a[t]);
+        sb[t].fake(b[t]);
+#else
         sa[t].make(a[t]);
         sb[t].make(b[t]);
+#endif
       }
+#ifdef MESM_W64_NO_MMA
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            acc[t][q][i] += __uint_as_float((sa[t].hi[q][i] ^ sa[t].mid[q][i] ^ sa[t].lo[q][i] ^ sb[t].hi[q][i] ^ sb[t].mid[q][i] ^ sb[t].lo[q][i]) & 0x3fffffffu);
+#else
 #pragma unroll
       for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
         for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = split_mma<BF>(sa[ti], sb[tj], acc[ti][tj]);
+#endif
     } else {
 #pragma unroll
       for (int s_ = 0; s_ < 4; ++s_)
@@ -1368,7 +1395,7 @@ __device__ __forceinline__ void wstage64_body(const MesmGemmArgs& p, const Blk b
 }
 
 template <int LA, int LB, bool XF, int BF = 0>
-__global__ __launch_bounds__(NTHREADS) void gemm_wstage64_kernel(const MesmGemmArgs p, const SideRed sr) {
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_wstage64_kernel(const MesmGemmArgs p, const SideRed sr) {
   side_reduce(sr);
   __shared__ __attribute__((aligned(16))) float L[4 * 4 * WS_SLAB];  // 4 waves x 4 slabs = 64 KB
   Blk blk;
@@ -1377,14 +1404,50 @@ __global__ __launch_bounds__(NTHREADS) void gemm_wstage64_kernel(const MesmGemmA
   wstage64_body<LA, LB, XF, BF>(p, blk, L);
 }
 
+// Grouped launch of 64 x 64 k-split tiles (same GroupArgs as the 32 x 32 one): the problems of one call that are large
+// enough for this tile share ONE launch whatever their shapes, layouts and fusions -- a kernel costs ~9 us of ramp
+// whatever it computes, and in split-bf16 mode a 64 x 64-per-wave tile is the only one that amortises the split.
+template <int BF>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_wstage64_group_kernel(const GroupArgs g, const SideRed sr) {
+  side_reduce(sr);
+  __shared__ __attribute__((aligned(16))) float L[4 * 4 * WS_SLAB];
+  const int bid = blockIdx.x;
+  int gi = 0;
+#pragma unroll
+  for (int k = 1; k < GROUP_MAX; ++k)
+    if (k < g.n && bid >= g.start[k]) gi = k;
+  const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();  // (see gemm_wstage_group_kernel)
+  const MesmGemmArgs p = *reinterpret_cast<const MesmGemmArgs*>(ka + offsetof(GroupArgs, p) + (size_t)gi * sizeof(MesmGemmArgs));
+  const int first = *reinterpret_cast<const int*>(ka + offsetof(GroupArgs, start) + (size_t)gi * sizeof(int));
+  const int local = bid - first;
+  Blk blk;
+  xcd_tile_z(local, (p.M + 63) / 64, (p.N + 63) / 64, p.split_k, blk.x, blk.y, blk.z);
+  blk.slot = local;
+  constexpr int R = MESM_LAYOUT_REDUCE_CONTIG, O = MESM_LAYOUT_OUTER_CONTIG;
+  const bool xf = p.a_act != MESM_ACT_NONE || p.b_act != MESM_ACT_NONE || p.a_drop_p > 0.f || p.b_drop_p > 0.f;
+  const int sel = (p.a_layout == O ? 2 : 0) + (p.b_layout == O ? 1 : 0);
+  if (!xf) {
+    if (sel == 0) wstage64_body<R, R, false, BF>(p, blk, L);
+    else if (sel == 1) wstage64_body<R, O, false, BF>(p, blk, L);
+    else if (sel == 2) wstage64_body<O, R, false, BF>(p, blk, L);
+    else wstage64_body<O, O, false, BF>(p, blk, L);
+  } else if (BF == 0) {  // (operand transforms in split mode stay out of the group: register budget)
+    if (sel == 0) wstage64_body<R, R, true, 0>(p, blk, L);
+    else if (sel == 1) wstage64_body<R, O, true, 0>(p, blk, L);
+    else if (sel == 2) wstage64_body<O, R, true, 0>(p, blk, L);
+    else wstage64_body<O, O, true, 0>(p, blk, L);
+  }
+}
+
 // MESM_GEMM_BF16X = 6 | 3: the experimental split-bf16 products (see SplitFrag); 0 / unset = exact f32
 inline int bf16x_mode() { return mesm_gemm_bf16x(); }
+int mesm_gemm_group64();
 
 template <int LA, int LB>
 int launch_wstage64_l(const MesmGemmArgs& a, hipStream_t s) {
   dim3 grid(((a.M + 63) / 64) * ((a.N + 63) / 64), 1, a.split_k > 1 ? a.split_k : 1);  // 1-D: xcd_tile() maps it
   const bool xf = a.a_act != MESM_ACT_NONE || a.b_act != MESM_ACT_NONE || a.a_drop_p > 0.f || a.b_drop_p > 0.f;
-  const int bf = xf ? 0 : bf16x_mode();
+  const int bf = xf ? 0 : bf16x_mode();  // (operand transforms + split: 260-288 VGPRs, one workgroup per CU or spills)
   const SideRed sr = take_side(s);
   if (bf == 6) hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, false, 6>), grid, dim3(NTHREADS), 0, s, a, sr);
   else if (bf == 3) hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, false, 3>), grid, dim3(NTHREADS), 0, s, a, sr);
@@ -1905,10 +1968,18 @@ Tape g_tape;
 
 // tuning switches, read ONCE when the library is loaded (they used to be getenv calls per dispatch)
 int g_force_tile = []() { const char* e = getenv("MESM_GEMM_TILE"); return e ? atoi(e) : 0; }();
-int g_bf16x = []() { const char* e = getenv("MESM_GEMM_BF16X"); const int m = e ? atoi(e) : 0; return (m == 3 || m == 6) ? m : 0; }();
+// MESM_GEMM_BF16X: 6 (default) = the large products on v_mfma_f32_32x32x16_bf16 over operands split exactly into three
+// bf16 terms, six cross products, f32 accumulate (error at or below the f32 MFMA kernels' own, tools/bf16x_check.py);
+// 0 = every product on v_mfma_f32_32x32x2_f32; 3 = EXPERIMENTAL two-term split (16-bit mantissa: fails parity tests)
+int g_bf16x = []() { const char* e = getenv("MESM_GEMM_BF16X"); const int m = e ? atoi(e) : 6; return (m == 3 || m == 6) ? m : 0; }();
 
 int mesm_gemm_force_tile() { return g_force_tile; }
 int mesm_gemm_bf16x() { return g_bf16x; }
+// MESM_GEMM_GROUP64: 1 = the problems of a grouped call that the 64 x 64 k-split kernel takes share ONE
+// gemm_wstage64_group_kernel launch, and the call's other products ride along (default in split-bf16 mode: 4.40 -> 4.01
+// ms/step; in exact-f32 mode it loses, 4.609 -> 4.642, and stays off); 0 = launched one by one
+int g_group64 = []() { const char* e = getenv("MESM_GEMM_GROUP64"); return e ? atoi(e) : -1; }();
+int mesm_gemm_group64() { return g_group64 >= 0 ? g_group64 : (g_bf16x != 0 ? 1 : 0); }
 
 int dispatch(const MesmGemmArgs& a, int vec, hipStream_t s) {
   {
@@ -2054,9 +2125,59 @@ int launch_group(const MesmGemmArgs* list, const int* vecs, int n, hipStream_t s
     if (g_force_tile != 0) return false;
     return wstage_ok(a) && 2.0 * a.M * a.N * a.K < MID_GF;
   };
+  // 64 x 64 class: what the single dispatch would hand to the k-split 64 x 64 kernel
+  GroupArgs g64;
+  g64.n = 0;
+  g64.start[0] = 0;
+  auto flush64 = [&]() {
+    if (g64.n == 0) return;
+    if (g64.n == 1) {
+      rc = launch_wstage64(g64.p[0], s);
+    } else {
+      const SideRed sr = take_side(s);
+      const int bf = bf16x_mode();
+      if (bf == 6) hipLaunchKernelGGL(gemm_wstage64_group_kernel<6>, dim3(g64.start[g64.n]), dim3(NTHREADS), 0, s, g64, sr);
+      else hipLaunchKernelGGL(gemm_wstage64_group_kernel<0>, dim3(g64.start[g64.n]), dim3(NTHREADS), 0, s, g64, sr);
+      rc = mesm_launch_status();
+      for (int k = 0; k < g64.n && rc == MESM_OK; ++k) {
+        const MesmGemmArgs& a = g64.p[k];
+        rc = dslope_finish_n(a, (int64_t)((a.M + 63) / 64) * ((a.N + 63) / 64) * (a.split_k > 1 ? a.split_k : 1), s);
+      }
+    }
+    g64.n = 0;
+  };
+  auto joins64 = [&](const MesmGemmArgs& a) {
+    if (mesm_gemm_group64() == 0 || g_force_tile != 0 || !wstage_ok(a)) return false;
+    const long z = a.split_k > 1 ? a.split_k : 1;
+    const long b64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * z;
+    const long kper = ((a.K + z - 1) / z + 3) / 4;
+    const long t96 = (long)((a.M + 95) / 96) * ((a.N + 31) / 32);
+    static const int min_dim = []() { const char* e = getenv("MESM_G64_MINDIM"); return e ? atoi(e) : 1024; }();
+    static const int min_b64 = []() { const char* e = getenv("MESM_G64_MINB64"); return e ? atoi(e) : 128; }();
+    static const int tall = []() { const char* e = getenv("MESM_G64_TALL"); return e ? atoi(e) : 1; }();
+    if (!tall && z == 1 && a.K >= 512 && t96 >= 160 && t96 <= 256 && wtall_ok(a)) return false;  // the tall tile's shapes
+    const bool xf = a.a_act != MESM_ACT_NONE || a.b_act != MESM_ACT_NONE || a.a_drop_p > 0.f || a.b_drop_p > 0.f;
+    if (bf16x_mode() != 0) return !xf && b64 >= min_b64 && (a.M >= min_dim || a.K >= min_dim);
+    return b64 >= 128 && b64 <= 256 && kper >= 128;
+  };
+  // a call that has a 64 x 64 launch anyway: products of >= join_mf MFLOP that the 32 x 32 group would take ride along
+  static const double join_mf = []() { const char* e = getenv("MESM_G64_JOIN_MF"); return e ? atof(e) : 0.0; }();
+  int n64 = 0;
+  for (int i = 0; i < n; ++i) n64 += joins64(list[i]) ? 1 : 0;
+  auto rides64 = [&](const MesmGemmArgs& a) {
+    if (n64 == 0 || join_mf < 0.0 || mesm_gemm_group64() == 0 || !joins(a)) return false;
+    const bool xf = a.a_act != MESM_ACT_NONE || a.b_act != MESM_ACT_NONE || a.a_drop_p > 0.f || a.b_drop_p > 0.f;
+    if (xf && bf16x_mode() != 0) return false;
+    return 2.0 * a.M * a.N * a.K >= join_mf * 1e6;
+  };
   for (int i = 0; i < n && rc == MESM_OK; ++i) {
     const MesmGemmArgs& a = list[i];
-    if (joins(a)) {
+    if (joins64(a) || rides64(a)) {
+      const int wgs = ((a.M + 63) / 64) * ((a.N + 63) / 64) * (a.split_k > 1 ? a.split_k : 1);
+      g64.p[g64.n] = a;
+      g64.start[g64.n + 1] = g64.start[g64.n] + wgs;
+      if (++g64.n == GROUP_MAX) flush64();
+    } else if (joins(a)) {
       const int wgs = ((a.M + 31) / 32) * ((a.N + 31) / 32) * (a.split_k > 1 ? a.split_k : 1);
       g.p[g.n] = a;
       g.start[g.n + 1] = g.start[g.n] + wgs;
@@ -2066,6 +2187,7 @@ int launch_group(const MesmGemmArgs* list, const int* vecs, int n, hipStream_t s
     }
   }
   if (rc == MESM_OK) flush();
+  if (rc == MESM_OK) flush64();
   return rc;
 }
 }  // namespace

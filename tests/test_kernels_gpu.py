@@ -710,9 +710,18 @@ def test_gemm_group_matches_individual_launches():
         torch.cuda.synchronize()
         for a, b in zip(outs1, outs2):
             assert rel_err(b, a) < 1e-5
-        for sa, sb in zip(side1, side2):
-            for x, y in zip(sa, sb):
-                if x is not None:
+        for (A, B, kw), sa, sb in zip(calls, side1, side2):
+            for name, x, y in zip(("colsum", "dslope"), sa, sb):
+                if x is None:
+                    continue
+                if name == "dslope":
+                    # a cancelling sum over M x N terms: the two routes may differ in arithmetic (a product that rides
+                    # in the 64 x 64 split-bf16 launch against the f32 MFMA kernel it gets alone), so the bound is
+                    # relative to the sum of the terms' magnitudes, not to the sum
+                    prod = (A.t() if kw["trans_a"] else A).double() @ (B.t() if kw["trans_b"] else B).double()
+                    scale = (prod * kw["aux"].double())[kw["aux"] < 0].abs().sum().item()
+                    assert abs(float(y) - float(x)) < 2e-6 * scale, (float(x), float(y), scale)
+                else:
                     assert rel_err(y, x) < 1e-4
 
 
