@@ -674,6 +674,12 @@ int mesm_gather_rows_bwd(const float* dy, const float* y, const float* rnorm, co
                          const uint8_t* valid, float* dx, int64_t src_rows, int32_t D, int32_t normalize,
                          void* stream);
 int mesm_add_wrap(const float* a, const float* b, float* out, int64_t n, int64_t nb, void* stream);
+/* First node of a captured training step (no counterpart in the reference: its forward draws on the host and indexes
+ * with host tensors, model.py:260, 361-384): copies slot (*pull_ctr % slots) of a ring of `slots` x slot_bytes in PINNED
+ * HOST memory (device-readable) to dst, then *pull_ctr += 1 and, when given, *seed_ctr += 1 (the dropout seed offset of
+ * the step).  slot_bytes % 16 == 0; one workgroup. */
+int mesm_step_begin(const void* host_ring, int32_t slot_bytes, int32_t slots, void* dst, int32_t* pull_ctr,
+                    int32_t* seed_ctr, void* stream);
 int mesm_skinny_linear_bwd(const float* dz, const float* x, const float* w, float* dx, float* dw, float* db,
                            int64_t M, int32_t K, int32_t J, int32_t relu_mask, void* stream);
 

@@ -42,6 +42,19 @@ class Arena:
             if tuple(a.shape) != tuple(shape) or np.dtype(a.dtype) != np.dtype(dt):
                 raise ValueError("Arena.upload: %s does not fit (%s %s -> %s %s)" % (name, shape, dt, a.shape, a.dtype))
 
+    def span(self, names):
+        """byte range [lo, hi) of the arena that covers the named tensors (16-byte granules)"""
+        hit = [(o, o + (nb + 15) // 16 * 16) for name, _, _, o, nb in self.specs if name in names]
+        if not hit:
+            return 0, 0
+        return min(h[0] for h in hit), min(max(h[1] for h in hit), self.nbytes)
+
+    def pack(self, arrays, lo, hi, out):
+        """the bytes [lo, hi) of the arena image of `arrays` into the uint8 numpy array `out` (length hi - lo)"""
+        for name, _, _, o, nb in self.specs:
+            if nb and lo <= o < hi:
+                out[o - lo:o - lo + nb] = np.ascontiguousarray(arrays[name]).reshape(-1).view(np.uint8)
+
     def check(self, arrays):
         """raise ValueError if `arrays` cannot be uploaded into this arena (nothing is modified)"""
         self._check(arrays)

@@ -2188,6 +2188,18 @@ int launch_group(const MesmGemmArgs* list, const int* vecs, int n, hipStream_t s
   }
   if (rc == MESM_OK) flush();
   if (rc == MESM_OK) flush64();
+  static const bool plan_log = getenv("MESM_GEMM_PLAN_LOG") != nullptr;  // tools/gemm_plan.py: what a call turned into
+  if (plan_log) {
+    fprintf(stderr, "[gemm plan] call of %d:", n);
+    for (int i = 0; i < n; ++i) {
+      const MesmGemmArgs& a = list[i];
+      const bool xf = a.a_act != MESM_ACT_NONE || a.b_act != MESM_ACT_NONE || a.a_drop_p > 0.f || a.b_drop_p > 0.f;
+      const char* where = (joins64(a) || rides64(a)) ? "g64" : (joins(a) ? "g32" : "alone");
+      fprintf(stderr, " %dx%dx%d%s%s/s%d%s%s->%s", a.M, a.N, a.K, a.a_layout == MESM_LAYOUT_OUTER_CONTIG ? "T" : "N",
+              a.b_layout == MESM_LAYOUT_REDUCE_CONTIG ? "T" : "N", a.split_k, xf ? "(xf)" : "", (a.A2 || a.B2) ? "(2nd)" : "", where);
+    }
+    fprintf(stderr, "\n");
+  }
   return rc;
 }
 }  // namespace

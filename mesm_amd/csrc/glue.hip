@@ -336,7 +336,35 @@ __global__ __launch_bounds__(256) void add_wrap_kernel(const float* __restrict__
   }
 }
 
+// First node of a captured step: the step's host draws come from a ring of `slots` buffers in PINNED HOST memory
+// (read over the host link by this kernel: ~1 KB) instead of a host-to-device copy between two graph replays (a copy
+// on the stream between two graph launches cost ~50 us of idle queue per step, tools/host_cost.py), and the dropout
+// seed offset of the step is advanced (it used to be an element-wise launch of its own).  The slot is chosen by a
+// DEVICE counter that this kernel advances: the host publishes replay n's draws into slot n % slots before it
+// launches replay n and never runs more than slots - 1 replays ahead (graphed.GraphedStep).
+__global__ __launch_bounds__(256) void step_begin_kernel(const uint4* __restrict__ ring, int32_t slot_vec, int32_t slots,
+                                                         uint4* __restrict__ dst, int32_t* __restrict__ pull_ctr,
+                                                         int32_t* __restrict__ seed_ctr) {
+  const int c = *pull_ctr;
+  const uint4* src = ring + (size_t)(c % slots) * slot_vec;
+  for (int i = threadIdx.x; i < slot_vec; i += 256) dst[i] = src[i];
+  __syncthreads();  // every thread has read the counter
+  if (threadIdx.x == 0) {
+    *pull_ctr = c + 1;
+    if (seed_ctr) *seed_ctr += 1;
+  }
+}
+
 }  // namespace
+
+extern "C" int mesm_step_begin(const void* host_ring, int32_t slot_bytes, int32_t slots, void* dst, int32_t* pull_ctr,
+                               int32_t* seed_ctr, void* stream) {
+  if (!host_ring || !dst || !pull_ctr || slots <= 0 || slot_bytes <= 0 || (slot_bytes & 15)) return MESM_EINVAL;
+  if ((((uintptr_t)host_ring) | ((uintptr_t)dst)) & 15) return MESM_EALIGN;
+  hipLaunchKernelGGL(step_begin_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const uint4*)host_ring, slot_bytes / 16,
+                     slots, (uint4*)dst, pull_ctr, seed_ctr);
+  return mesm_launch_status();
+}
 
 extern "C" int mesm_stack_rows(const void* const* src, void* const* dst, const int64_t* row_bytes, const int32_t* gather,
                                int32_t n, const int64_t* idx, int32_t N, void* stream) {

@@ -55,6 +55,58 @@ def capture_stream(dev):
     return st
 
 
+class _DrawRing:
+    """The per-step host draws reach the device through a ring of pinned host buffers that the FIRST NODE of the
+    captured step reads itself (kernels.step_begin), instead of a host-to-device copy between two replays: replay n
+    reads slot n % SLOTS -- the device counts its own replays -- so the host publishes the draws of replay n into that
+    slot right before launching it and waits, when it gets SLOTS - 1 replays ahead, for the replay that last used the
+    slot."""
+    SLOTS = 4
+
+    def __init__(self, arena, names, device):
+        self.arena = arena
+        self.lo, self.hi = arena.span(names)
+        self.nbytes = self.hi - self.lo
+        self.ring = torch.zeros(self.SLOTS * self.nbytes, dtype=torch.uint8).pin_memory()
+        self.host = self.ring.numpy()
+        self.ctr = torch.zeros(1, dtype=torch.int32, device=device)
+        self.dst = arena.dev[self.lo:self.hi]
+        self.n = 0
+        self.events = [None] * self.SLOTS
+
+    def capture_node(self, seed_ctr):
+        kn.step_begin(self.ring, self.nbytes, self.SLOTS, self.dst, self.ctr, seed_ctr)
+
+    def publish(self, arrays):
+        s = self.n % self.SLOTS
+        if self.events[s] is not None:
+            self.events[s].synchronize()  # the replay SLOTS launches ago has read this slot
+        self.arena.pack(arrays, self.lo, self.hi, self.host[s * self.nbytes:(s + 1) * self.nbytes])
+        return s
+
+    def launched(self, s):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.events[s] = ev
+        self.n += 1
+
+
+class _PulledGraph:
+    """graph.replay() that first publishes the owner's current draws for the replay's first node"""
+
+    def __init__(self, graph, owner):
+        self._g, self._o = graph, owner
+
+    def replay(self):
+        o = self._o
+        s = o._pull.publish(o._arr)
+        self._g.replay()
+        o._pull.launched(s)
+
+    def __getattr__(self, k):
+        return getattr(self._g, k)
+
+
 class GraphedStep:
     BIG = 1 << 20  # batch tensors above 1 MiB (video_feat, word features) are copied on their own
     DRAWN = ("p.neg_index", "p.masked_words")  # what redraw() changes: the host RNG draws of a step
@@ -92,6 +144,12 @@ class GraphedStep:
         self._arr = arr  # host mirror of the arena
         self._draws = (arr["p.neg_index"], arr.get("p.masked_words"))
         self.arena = Arena(arr, dev, first=self.DRAWN)  # the per-step draws sit together at the front
+        # MESM_STEP_PULL=1: the draws are pulled from a pinned ring by the graph's first node instead of travelling as a
+        # host-to-device copy between replays.  Measured equal (bench 3.964 vs 3.966 ms/step, profiles/r4c/
+        # step_pull_ab.txt: the copy between two replays was never the 50 us tools/host_cost.py's 30-step loop
+        # suggested), so the plain copy stays the default.
+        self._pull = (_DrawRing(self.arena, self.DRAWN, dev)
+                      if dev.type == "cuda" and os.environ.get("MESM_STEP_PULL", "0") == "1" else None)
         v = self.arena.views
         self.plan = model.plan_from({k[2:]: t for k, t in v.items() if k.startswith("p.")}, self._pmeta)
         self.tplan = TargetPlan.__new__(TargetPlan)
@@ -143,10 +201,15 @@ class GraphedStep:
             # hand-over to that stream as a side branch of the graph -- a second hardware queue at replay, which
             # costs every kernel boundary of the main chain (5.2 -> 5.5 ms per step)
             with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
-                self.counter.add_(1)
+                if self._pull is not None:
+                    self._pull.capture_node(self.counter)  # draws from the pinned ring + seed offset += 1: one node
+                else:
+                    self.counter.add_(1)
                 self.total, self.losses = self._step_body()
             if dot:
                 self.graph.debug_dump(dot)
+            if self._pull is not None:
+                self.graph = _PulledGraph(self.graph, self)
         finally:
             kn.set_seed_offset(None)
             if instrument:
@@ -343,7 +406,9 @@ class GraphedStep:
         self._arr["p.neg_index"] = neg
         if mw is not None:
             self._arr["p.masked_words"] = mw
-        self.arena.upload(self._arr, only=self.DRAWN)  # ~1 KB instead of the whole 57 KB arena
+        if self._pull is None:
+            self.arena.upload(self._arr, only=self.DRAWN)  # ~1 KB instead of the whole 57 KB arena
+        # (with the ring: the next replay publishes self._arr's draws itself)
 
     def set_draws(self, neg_index, masked_words=None):
         """replay with given host draws (tests / reproducing a recorded step)"""

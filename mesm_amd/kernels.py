@@ -996,6 +996,14 @@ def gather_rows_bwd(dy, y, rnorm, inv, valid, src_rows, normalize):
     return dx
 
 
+def step_begin(ring, slot_bytes, slots, dst, pull_ctr, seed_ctr=None):
+    """first node of a captured step: dst <- ring[*pull_ctr % slots] (ring: PINNED host uint8 tensor), counters += 1"""
+    require_gpu(dst, pull_ctr)
+    assert ring.is_pinned() and ring.numel() >= slot_bytes * slots and dst.numel() * dst.element_size() >= slot_bytes
+    check(lib().mesm_step_begin(ring.data_ptr(), int(slot_bytes), int(slots), ptr(dst), ptr(pull_ctr),
+                                ptr(seed_ctr) if seed_ctr is not None else None, stream_ptr()), "mesm_step_begin")
+
+
 def add_wrap(a, b):
     """a + b with b repeated along dim 0 (a.numel() a multiple of b.numel())."""
     require_gpu(a, b)

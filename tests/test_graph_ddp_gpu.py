@@ -533,3 +533,41 @@ def test_bench_data_parallel_flow_is_self_diagnosing_on_one_rank():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(r.stdout.strip().splitlines()[-1])["config"]["ddp_diag"]
     assert "simulated failure" in d["own_communicator_error"] and d["headline_form"] == "after"
+
+
+@pytest.mark.gpu
+def test_draws_pulled_by_the_first_graph_node_replay_like_copied_draws():
+    """MESM_STEP_PULL=1 (graphed._DrawRing, kernels.step_begin): the step's host draws reach the device through a ring of
+    pinned host buffers read by the graph's first node.  Same draws -> same losses and gradients as the copied form,
+    over more replays than the ring has slots, with and without new draws in between."""
+    import subprocess
+    code = r'''
+import os, sys, torch
+sys.path.insert(0, %r)
+from mesm_amd import build_criterion, build_model, synthetic
+from mesm_amd.graphed import GraphedStep
+dev = torch.device("cuda:0")
+res = {}
+for mode in ("0", "1"):
+    os.environ["MESM_STEP_PULL"] = mode
+    args = synthetic.make_args("C2", device=str(dev))
+    torch.manual_seed(7)
+    model = build_model(args); crit = build_criterion(args); model.eval()
+    batch = synthetic.to_device(synthetic.workload_batch("C2", seed=3), dev)
+    g = GraphedStep(model, crit, batch, args.dataset_name, warmup=1)
+    assert (g._pull is not None) == (mode == "1")
+    import random, numpy as np
+    out = []
+    for i in range(11):
+        random.seed(100 + i); np.random.seed(100 + i); torch.manual_seed(100 + i)
+        t = g.run(redraw=(i %% 3 != 2))
+        torch.cuda.synchronize()
+        out.append((float(t), float(model.gradbuf().flat.double().norm())))
+    res[mode] = out
+for a, b in zip(res["0"], res["1"]):
+    assert abs(a[0] - b[0]) <= 1e-6 * abs(a[0]) and abs(a[1] - b[1]) <= 1e-6 * abs(a[1]), (a, b)
+assert len({round(x[0], 6) for x in res["1"]}) > 3, "the draws never changed"
+print("PULL-OK")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert "PULL-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
