@@ -1376,15 +1376,20 @@ __device__ __forceinline__ void wstage64_body(const MesmGemmArgs& p, const Blk b
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) L[((wave * 4 + ti * 2 + tj) * 16 + r) * 64 + lane] = acc[ti][tj][r];
+      for (int r4 = 0; r4 < 4; ++r4)  // 16-byte LDS accesses: 16 writes + 16 reads per wave instead of 64 + 64
+        reinterpret_cast<float4*>(L)[((wave * 4 + ti * 2 + tj) * 4 + r4) * 64 + lane] =
+            make_float4(acc[ti][tj][4 * r4], acc[ti][tj][4 * r4 + 1], acc[ti][tj][4 * r4 + 2], acc[ti][tj][4 * r4 + 3]);
   __syncthreads();
   f32x16 sum;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    float t = 0.0f;
+  for (int r4 = 0; r4 < 4; ++r4) {
+    float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
-    for (int w = 0; w < 4; ++w) t += L[((w * 4 + wave) * 16 + r) * 64 + lane];
-    sum[r] = t;
+    for (int w = 0; w < 4; ++w) {
+      const float4 u = reinterpret_cast<const float4*>(L)[((w * 4 + wave) * 4 + r4) * 64 + lane];
+      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+    }
+    sum[4 * r4] = t.x; sum[4 * r4 + 1] = t.y; sum[4 * r4 + 2] = t.z; sum[4 * r4 + 3] = t.w;
   }
   __syncthreads();  // dslope_store reuses the head of L
   tile16_epilogue<LA, LB, XF>(p, sum, m0 + 32 * (wave >> 1), n0 + 32 * (wave & 1), slope, seed_off, blk.z, L, blk.slot,
