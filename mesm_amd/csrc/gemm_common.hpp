@@ -59,8 +59,13 @@ __device__ __forceinline__ void xcd_tile_z(int lid, int mt, int nt, int S, int& 
       const int G = 8 / S;
       z = xcd / G;
       const int t = (xcd - z * G) * (T / G) + idx;
-      bx = t / nt;
-      by = t - bx * nt;
+      if (nt > mt) {  // the XCDs of a slice split the LONGER tile axis: each then reads all of the smaller operand only
+        by = t / mt;
+        bx = t - by * mt;
+      } else {
+        bx = t / nt;
+        by = t - bx * nt;
+      }
       return;
     }
     if ((S & 7) == 0) {
