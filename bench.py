@@ -12,7 +12,7 @@ MESM_DDP_MODE], in
 TRAIN mode (all dropouts active), on the QVHighlights C+SF workload "C3a" of SURVEY.md 8d (32 pairs per
 GPU, Lv=75, Lw=32, Dv=2818, Dt=512, C=5003, fp32).  Inputs are resident in HBM before the timed
 region; the host-side draws of the reference (negative query index, MLM word choice) are re-drawn
-every step.  For N > 1 rank r takes the video groups r::N of a global batch of 32 N groups
+every step (drawn for step i + 1 while step i runs on the device).  For N > 1 rank r takes the video groups r::N of a global batch of 32 N groups
 (mesm_amd.ddp.shard_groups): weak scaling, 32 pairs per GPU.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) including
@@ -424,9 +424,15 @@ def main():
         log("step captured in a HIP graph")
 
         def step():
-            total = gstep.run(redraw=True)
+            # the host half of a step is software-pipelined like a loader's prefetch: replay with the draws prepared
+            # during the PREVIOUS step (the very first ones at construction), then draw the next step's while this one
+            # runs on the device.  Still one fresh set of host draws per step, K draws inside the K timed steps -- but
+            # the device does not idle for the ~1 ms of host RNG work in front of the first timed replay (at K = 20 that
+            # idle millisecond was 50 us per step of the round-3 headline).
+            total = gstep.run(redraw=False)
             if post:
                 reducer.finish()
+            gstep.redraw()
             return total
 
     def fence():
