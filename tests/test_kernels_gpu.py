@@ -1063,3 +1063,41 @@ def test_plane_gemm_matches_fp64(M, N, K, ta, tb, split, mode):
             assert rel_err(C, want) < 2e-6
     lib().mesm_gemm_px_set_tile(0)
     lib().mesm_gemm_px_set_ring(0)
+
+
+@pytest.mark.gpu
+def test_grouped_64x64_split_launch_against_fp64():
+    """The round-4 production form of a GEMM call: one gemm_wstage64_group_kernel launch (split-bf16 products) carrying a
+    large product AND the small ones that ride along -- every layout pair, partial tiles in both extents, reduce ranges
+    with a tail, split-K with column sums, bias / residual epilogues -- against fp64."""
+    from mesm_amd import kernels as kn
+    for ta in (False, True):
+        for tb in (False, True):
+            probs = []
+            for (M, N, K, extra) in [(2433, 258, 262, "bias"), (1056, 256, 1030, "res"), (33, 256, 256, None), (1, 256, 70, "bias"),
+                                     (320, 512, 64, None)]:
+                A = gen((K, M) if ta else (M, K), M + 3 * K)
+                B = gen((N, K) if tb else (K, N), N + 7 * K, 0.1)
+                kw = dict(trans_a=ta, trans_b=tb)
+                ref = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double())
+                if extra == "bias":
+                    kw["bias"] = gen((N,), 5)
+                    ref = ref + kw["bias"].double()
+                elif extra == "res":
+                    kw["residual"] = gen((M, N), 6)
+                    ref = ref + kw["residual"].double()
+                probs.append((A, B, kw, ref, torch.zeros(M, N, device=dev())))
+            if ta:  # a split-K weight-gradient form with its column sums rides along too
+                A = gen((4800, 256), 11); B = gen((4800, 192), 12, 0.1)
+                cs = torch.zeros(256, device=dev())
+                probs.append((A, B, dict(trans_a=True, trans_b=False, split_k=4, accumulate=2, colsum=cs),
+                              A.double().t() @ B.double(), torch.zeros(256, 192, device=dev())))
+            with kn.gemm_group():
+                for A, B, kw, ref, C in probs:
+                    kn.gemm(A, B, C, **kw)
+            torch.cuda.synchronize()
+            for A, B, kw, ref, C in probs:
+                err = ((C.double() - ref).abs().max() / ref.abs().max()).item()
+                assert err < 2e-6, (ta, tb, tuple(C.shape), A.shape, err)
+                if "colsum" in kw:
+                    assert rel_err(kw["colsum"], A.sum(0)) < 1e-5
