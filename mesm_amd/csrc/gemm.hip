@@ -1205,6 +1205,10 @@ __device__ __forceinline__ f32x16 split_mma(const SplitFrag<BF>& a, const SplitF
 // stage's loads: a single LDS buffer per wave suffices, because all fragments of a stage are in
 // registers before its refill is issued.  Used when the problem has enough 64 x 64 tiles to occupy
 // the chip (the 2400- and 4800-row d x d GEMMs, the split-K weight gradients).
+#ifdef MESM_W64_FINISH_PROBE
+__device__ unsigned w64_probe_ctr[1024];
+__device__ float w64_probe_out[8192 * 256];
+#endif
 template <int LA, int LB, bool XF, int BF = 0>
 __device__ __forceinline__ void wstage64_body(const MesmGemmArgs& p, const Blk blk, float* L) {
   const int tid = threadIdx.x;
@@ -1397,6 +1401,37 @@ __device__ __forceinline__ void wstage64_body(const MesmGemmArgs& p, const Blk b
   L64_STAMP(29);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   L64_STAMP(30);
+#ifdef MESM_W64_FINISH_PROBE
+  // PROBE (timing only; tools/w64_probe.py): what would a "last arriver normalises the row block" LayerNorm cost inside
+  // this kernel?  Every workgroup releases its tile (device-scope fence), counts itself on its row block, and the last
+  // of the N / 64 tiles acquires and runs a two-pass LayerNorm over the block's 64 x 256 values into a scratch buffer.
+  if (p.N == 256 && p.split_k <= 1) {
+    __threadfence();
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(L);
+    if (threadIdx.x == 0) {
+      const unsigned prev = atomicAdd(&w64_probe_ctr[blk.x & 1023], 1u);
+      const int last = prev == 3u;
+      if (last) w64_probe_ctr[blk.x & 1023] = 0u;
+      *flag = last;
+    }
+    __syncthreads();
+    if (*flag) {
+      __threadfence();
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wave * 16 + r;
+        if (row < p.M) {
+          const float4 v = *reinterpret_cast<const float4*>(p.C + (int64_t)row * p.ldc + lane * 4);
+          const float mu = wave_sum(v.x + v.y + v.z + v.w) * (1.0f / 256.0f);
+          const float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
+          const float rs = rsqrtf(wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.0f / 256.0f) + 1e-5f);
+          *reinterpret_cast<float4*>(w64_probe_out + ((int64_t)(row & 8191) * 256 + lane * 4)) =
+              make_float4(dx * rs, dy * rs, dz * rs, dw * rs);
+        }
+      }
+    }
+  }
+#endif
 }
 
 template <int LA, int LB, bool XF, int BF = 0>
