@@ -1406,22 +1406,42 @@ __device__ __forceinline__ void wstage64_body(const MesmGemmArgs& p, const Blk b
   // this kernel?  Every workgroup releases its tile (device-scope fence), counts itself on its row block, and the last
   // of the N / 64 tiles acquires and runs a two-pass LayerNorm over the block's 64 x 256 values into a scratch buffer.
   if (p.N == 256 && p.split_k <= 1) {
+#if MESM_W64_FINISH_PROBE == 2
+    // variant 2: no device-scope fences -- valid only if the four tiles of a row block run on ONE XCD (its L2 is then
+    // the coherence point): stores acknowledged (vmcnt(0) above), an L2 atomic, the last arriver's loads bypass L1 (sc0)
+    __syncthreads();
+#else
     __threadfence();
     __syncthreads();
+#endif
     int* flag = reinterpret_cast<int*>(L);
     if (threadIdx.x == 0) {
+#if MESM_W64_FINISH_PROBE == 2
+      const unsigned prev = __hip_atomic_fetch_add(&w64_probe_ctr[blk.x & 1023], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
       const unsigned prev = atomicAdd(&w64_probe_ctr[blk.x & 1023], 1u);
+#endif
       const int last = prev == 3u;
       if (last) w64_probe_ctr[blk.x & 1023] = 0u;
       *flag = last;
     }
     __syncthreads();
     if (*flag) {
+#if MESM_W64_FINISH_PROBE != 2
       __threadfence();
+#endif
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wave * 16 + r;
         if (row < p.M) {
+#if MESM_W64_FINISH_PROBE == 2
+          float4 v;
+          {
+            const float* src = p.C + (int64_t)row * p.ldc + lane * 4;
+            asm volatile("global_load_dwordx4 %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(src) : "memory");
+          }
+#else
           const float4 v = *reinterpret_cast<const float4*>(p.C + (int64_t)row * p.ldc + lane * 4);
+#endif
           const float mu = wave_sum(v.x + v.y + v.z + v.w) * (1.0f / 256.0f);
           const float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
           const float rs = rsqrtf(wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.0f / 256.0f) + 1e-5f);
