@@ -1499,6 +1499,130 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_wstage64_group_kernel(const 
   }
 }
 
+#ifdef MESM_W64_ANTI
+// PROBE (tools/w64_probe.py, -DMESM_W64_ANTI): the split kernel as an 8-wave workgroup (k-split 8, one per CU, 128 KB of
+// slabs) whose waves 0-3 and 4-7 are held in ANTI-phase by two barriers per stage: one group issues its loads, waits
+// for them and reads its fragments while the other splits and multiplies.  Tests the reading of the other probes
+// (DESIGN.md section 8.1): co-resident waves of the production kernel run in lockstep, so their load phases and their
+// matrix phases add up.  No column sums, no operand transforms, split mode only.
+template <int LA, int LB>
+__global__ __launch_bounds__(512) void gemm_w64anti_kernel(const MesmGemmArgs p, const SideRed sr) {
+  side_reduce(sr);
+  extern __shared__ __attribute__((aligned(16))) float L[];  // 8 waves x 4 slabs
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, h = lane >> 5;
+  Blk blk;
+  blk.slot = linear_block();
+  xcd_tile_z((int)blk.slot, (p.M + 63) / 64, (p.N + 63) / 64, p.split_k, blk.x, blk.y, blk.z);
+  const int m0 = blk.x * 64, n0 = blk.y * 64;
+  const int KM = gemm_kmain(p);
+  int kbeg = 0, kend = KM;
+  if (p.split_k > 1) {
+    int chunk = (p.K + p.split_k - 1) / p.split_k;
+    chunk = ((chunk + BK_MAX - 1) / BK_MAX) * BK_MAX;
+    kbeg = blk.z * chunk;
+    kend = kbeg + chunk < KM ? kbeg + chunk : KM;
+    if (kbeg >= KM) {
+      if (blk.z > 0) return;
+      kbeg = kend = KM;
+    }
+  }
+  const int kw = (((kend - kbeg + 7) >> 3) + 31) & ~31;
+  const int k0 = kbeg + wave * kw;
+  const int k1 = k0 + kw < kend ? k0 + kw : kend;
+  const int nst = k1 > k0 ? (k1 - k0 + 31) >> 5 : 0;
+  const int nst_max = kw >> 5;  // the same for every wave: they all walk the barriers
+  const float slope = p.slope ? *p.slope : 0.0f;
+  const uint32_t seed_off = p.seed_offset ? *p.seed_offset : 0u;
+  XForm xa{}, xb{};
+  float* mine = L + wave * (4 * WS_SLAB);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  const int grp = wave >> 2;
+  if (grp == 1) __syncthreads();
+  for (int st = 0; st < nst_max; ++st) {
+    const bool have = st < nst;
+    const int kb = k0 + 32 * st;
+    float a[2][4][4], b[2][4][4];
+    // LOAD phase
+    if (have) {
+      ws_issue<LA>(p.A, p.lda, m0, p.M, kb, k1, mine, lane);
+      ws_issue<LA>(p.A, p.lda, m0 + 32, p.M, kb, k1, mine + WS_SLAB, lane);
+      ws_issue<LB>(p.B, p.ldb, n0, p.N, kb, k1, mine + 2 * WS_SLAB, lane);
+      ws_issue<LB>(p.B, p.ldb, n0 + 32, p.N, kb, k1, mine + 3 * WS_SLAB, lane);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (have) {
+      ws_read<LA>(mine, li, h, a[0]);
+      ws_read<LA>(mine + WS_SLAB, li, h, a[1]);
+      ws_read<LB>(mine + 2 * WS_SLAB, li, h, b[0]);
+      ws_read<LB>(mine + 3 * WS_SLAB, li, h, b[1]);
+      if (kb + 32 > k1) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int s_ = 0; s_ < 4; ++s_)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const bool ok = kb + 8 * s_ + 4 * h + j < k1;
+              a[t][s_][j] = ok ? a[t][s_][j] : 0.0f;
+              b[t][s_][j] = ok ? b[t][s_][j] : 0.0f;
+            }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    // COMPUTE phase
+    if (have) {
+      SplitFrag<6> sa[2], sb[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        sa[t].make(a[t]);
+        sb[t].make(b[t]);
+      }
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = split_mma<6>(sa[ti], sb[tj], acc[ti][tj]);
+    }
+    __syncthreads();
+  }
+  if (grp == 0) __syncthreads();
+  __syncthreads();
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4)
+        reinterpret_cast<float4*>(L)[((wave * 4 + ti * 2 + tj) * 4 + r4) * 64 + lane] =
+            make_float4(acc[ti][tj][4 * r4], acc[ti][tj][4 * r4 + 1], acc[ti][tj][4 * r4 + 2], acc[ti][tj][4 * r4 + 3]);
+  __syncthreads();
+  if (wave < 4) {
+    f32x16 sum;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        const float4 u = reinterpret_cast<const float4*>(L)[((w * 4 + wave) * 4 + r4) * 64 + lane];
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      }
+      sum[4 * r4] = t.x; sum[4 * r4 + 1] = t.y; sum[4 * r4 + 2] = t.z; sum[4 * r4 + 3] = t.w;
+    }
+    // (dslope_store's use of the head of L is not supported by this probe: no PReLU slope gradients)
+    tile16_epilogue<LA, LB, false>(p, sum, m0 + 32 * (wave >> 1), n0 + 32 * (wave & 1), slope, seed_off, blk.z, L + 8 * 4 * WS_SLAB,
+                                   blk.slot, KM, xa, xb);
+  }
+}
+#endif
+
 // MESM_GEMM_BF16X = 6 | 3: the experimental split-bf16 products (see SplitFrag); 0 / unset = exact f32
 inline int bf16x_mode() { return mesm_gemm_bf16x(); }
 int mesm_gemm_group64();
@@ -1509,6 +1633,18 @@ int launch_wstage64_l(const MesmGemmArgs& a, hipStream_t s) {
   const bool xf = a.a_act != MESM_ACT_NONE || a.b_act != MESM_ACT_NONE || a.a_drop_p > 0.f || a.b_drop_p > 0.f;
   const int bf = xf ? 0 : bf16x_mode();  // (operand transforms + split: 260-288 VGPRs, one workgroup per CU or spills)
   const SideRed sr = take_side(s);
+#ifdef MESM_W64_ANTI
+  if (bf == 6 && a.colsum == nullptr && !(a.e_actgrad == MESM_ACT_PRELU && a.dslope)) {
+    static bool attr = false;
+    const size_t lds = (size_t)(8 * 4 * WS_SLAB + 64) * sizeof(float);
+    if (!attr) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w64anti_kernel<LA, LB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr = true;
+    }
+    hipLaunchKernelGGL((gemm_w64anti_kernel<LA, LB>), grid, dim3(512), lds, s, a, sr);
+    return mesm_launch_status();
+  }
+#endif
   if (bf == 6) hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, false, 6>), grid, dim3(NTHREADS), 0, s, a, sr);
   else if (bf == 3) hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, false, 3>), grid, dim3(NTHREADS), 0, s, a, sr);
   else if (xf) hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, true>), grid, dim3(NTHREADS), 0, s, a, sr);
