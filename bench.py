@@ -60,6 +60,14 @@ def gemm_mode():
 def dtype_name():
     return {6: "f32 (3-term split-bf16 products, f32 accumulate)", 0: "f32",
             3: "f32 (EXPERIMENTAL 2-term split-bf16 products: 16-bit mantissa)"}[gemm_mode()]
+
+
+def draws_mode():
+    from mesm_amd import draws
+    return ("%s (mesm_amd/draws.py; host_ms_per_step = host time of one step of the timed loop: graph launch + the "
+            "next step's negative / masked-word draws + their upload, overlapped with the device step)" % draws.MODE)
+
+
 SETTLE_STEPS = 60  # untimed steps in front of the SECOND, informational timing (config.settled: not the headline)
 PEAK_HBM_TBS = 8.0            # MI355X_MICROARCH.md: HBM3E spec peak
 # algorithmic work of one step (kernel-boundary traffic / FLOPs); closed form for C3a-type batches,
@@ -429,11 +437,15 @@ def main():
             # runs on the device.  Still one fresh set of host draws per step, K draws inside the K timed steps -- but
             # the device does not idle for the ~1 ms of host RNG work in front of the first timed replay (at K = 20 that
             # idle millisecond was 50 us per step of the round-3 headline).
+            h0 = time.perf_counter()
             total = gstep.run(redraw=False)
             if post:
                 reducer.finish()
             gstep.redraw()
+            HOST["s"] += time.perf_counter() - h0
             return total
+
+    HOST = {"s": 0.0}  # host time inside step(): graph launch call + the next step's draws + their upload
 
     def fence():
         torch.cuda.synchronize()
@@ -450,9 +462,11 @@ def main():
             log("first step done")
     fence()
     log("warm-up done")
+    HOST["s"] = 0.0
     t0 = time.perf_counter()
     for _ in range(opt.steps):
         last = step()
+    host_ms = None if opt.eager else HOST["s"] / opt.steps * 1e3
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -805,7 +819,7 @@ def main():
         line = {
             "metric": "clip-query pairs/sec (fwd+bwd)", "value": n_pairs * world / t_step,
             "unit": "pairs/s", "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup,
-            "ms_per_step": t_step * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": t_step * 1e3, "host_ms_per_step": host_ms, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dtype_name(), "data": "synthetic",
             "config": {"workload": "%s: %s, %d pairs/GPU (%d groups), Lv=%d, Lw=%d, "
                                    "Dv=%d, Dt=%d, C=%d, 10 moment queries, train mode (dropout on)"
@@ -815,6 +829,7 @@ def main():
                                       wl["v_feat_dim"], wl["t_feat_dim"], wl["vocab_size"] + 1),
                        "global_pairs": n_pairs * world, "parallelism": "dp%d" % world,
                        "launch": "eager" if opt.eager else "hip-graph", "ddp": ddp_mode, "ddp_diag": ddp_diag,
+                       "host_draws": draws_mode(),
                        "settled_not_in_metric": settled,
                        "eager_ms_per_step_not_in_metric": eager_ms,
                        "optimizer_tail_ms_not_in_metric": opt_tail_ms,

@@ -31,6 +31,7 @@ import os
 
 import torch
 
+from . import draws
 from . import kernels as kn
 from .criterion import TargetPlan
 
@@ -351,11 +352,11 @@ class GraphedStep:
         self._wm_cpu = prep["wm"]
         self.batch["words_weight"] = prep["words_weight"]
         self.batch["num_clips"] = prep["num_clips"]
-        neg = self.model.draw_neg_padded(self._groups, self._n_real).numpy()
+        neg = draws.neg_index(self._groups, self._n_real)
         arr["p.neg_index"] = neg
         mw = None
         if "p.masked_words" in arr:
-            mw = self.model.draw_masked_words(self._wm_cpu, prep["words_weight"]).bool().numpy()
+            mw = draws.masked_words(self._wm_cpu, prep["words_weight"])
             arr["p.masked_words"] = mw
         self._arr, self._draws = arr, (neg, mw)
         self.arena.upload(arr)
@@ -398,10 +399,10 @@ class GraphedStep:
         """New negative-query indices and MLM word choices (host RNG, like the reference does on every forward),
         written into the static index tensors the graph reads (one arena upload)."""
         m = self.model
-        neg = m.draw_neg_padded(self._groups, self._n_real).numpy()
+        neg = draws.neg_index(self._groups, self._n_real)
         mw = None
         if hasattr(self.plan, "masked_words"):
-            mw = m.draw_masked_words(self._wm_cpu, self.batch["words_weight"]).bool().numpy()
+            mw = draws.masked_words(self._wm_cpu, self.batch["words_weight"])
         self._draws = (neg, mw)
         self._arr["p.neg_index"] = neg
         if mw is not None:

@@ -46,16 +46,6 @@ class HostSpec:
         from .model import MESM
         return MESM.plan_arrays(self, *a, **kw)
 
-    @staticmethod
-    def draw_neg_padded(groups, n_valid):
-        from .model import MESM
-        return MESM.draw_neg_padded(groups, n_valid)
-
-    @staticmethod
-    def draw_masked_words(words_mask_cpu, words_weight):
-        from .model import MESM
-        return MESM.draw_masked_words(words_mask_cpu, words_weight)
-
     # ---- word validity on the host
     def words_mask(self, host):
         """the collate mask for token ids (cut like model.py:114-116), the non-zero rows of pre-extracted features

@@ -18,6 +18,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import draws
 from . import kernels as kn
 from . import ops
 from .gradbuf import GradBuffer
@@ -205,61 +206,25 @@ class MESM(nn.Module):
         emb = self.text_encoder(words_id)
         return kn.text_pool(emb, words_mask, emb.shape[1], self.normalize_txt)
 
-    # ------------------------------------------------------------------ host RNG draws
+    # ------------------------------------------------------------------ host RNG draws (draws.py)
     @staticmethod
     def draw_neg_index(groups):
-        """sample_outclass_neg (utils/data_utils.py:113-124): for every pair one query index drawn
-        uniformly from the OTHER video groups, one torch.randperm per pair (host generator)."""
-        if len(groups) < 2:
-            raise IndexError("index 0 is out of bounds: negatives need >= 2 video groups in a batch")
-        N = sum(groups)
-        neg, start = [], 0
-        for g in groups:
-            cand = torch.cat([torch.arange(0, start), torch.arange(start + g, N)])
-            for _ in range(g):
-                neg.append(cand[torch.randperm(cand.shape[0])][0])
-            start += g
-        return torch.stack(neg)
+        """sample_outclass_neg (utils/data_utils.py:113-124), the reference's RNG stream (draws.neg_index_reference)."""
+        return draws.neg_index_reference(groups)
 
     @staticmethod
     def draw_masked_words(words_mask_cpu, words_weight):
-        """_mask_words (model.py:361-384): max(l//3, 1) positions per pair, without replacement,
-        p ~ words_weight, numpy global RNG on the host; pairs with <= 1 word are skipped."""
-        masked = torch.zeros_like(words_mask_cpu)
-        weight = F.normalize(words_weight.float().cpu(), dim=1, p=1) if words_weight is not None else None
-        for i, l in enumerate(words_mask_cpu.count_nonzero(dim=1)):
-            l = int(l)
-            if l <= 1:
-                continue
-            k = max(l // 3, 1)
-            p = weight[i, :l].numpy() if weight is not None else None
-            choices = np.random.choice(np.arange(0, l), k, replace=False, p=p)
-            masked[i, choices] = 1
-        return masked
+        """_mask_words (model.py:361-384), the reference's RNG stream (draws.masked_words_reference)."""
+        return draws.masked_words_reference(words_mask_cpu, words_weight)
 
     # ------------------------------------------------------------------ host-side plan
-    @staticmethod
-    def real_groups(groups, n_valid):
-        """the video groups that hold the first n_valid pairs (the rest are padding pairs, batching.pad_pairs)"""
-        if n_valid is None:
-            return list(groups)
-        real, tot = [], 0
-        for g in groups:
-            if tot >= n_valid:
-                break
-            real.append(g)
-            tot += g
-        if tot != n_valid:
-            raise ValueError("n_valid = %d does not end at a group boundary of %s" % (n_valid, list(groups)))
-        return real
+    real_groups = staticmethod(draws.real_groups)
 
-    @classmethod
-    def draw_neg_padded(cls, groups, n_valid):
-        """draw_neg_index over the REAL groups; padding pairs point at pair 0 (their rows are never read by a loss)"""
-        real = cls.real_groups(groups, n_valid)
-        neg = cls.draw_neg_index(real)
-        pad = sum(groups) - sum(real)
-        return torch.cat([neg, torch.zeros(pad, dtype=neg.dtype)]) if pad else neg
+    @staticmethod
+    def draw_neg_padded(groups, n_valid):
+        """the step's negative draw (draws.MODE: vectorized by default, MESM_DRAWS=reference for the reference's
+        stream) over the REAL groups; padding pairs point at pair 0 (their rows are never read by a loss)"""
+        return torch.from_numpy(draws.neg_index(groups, n_valid))
 
     def plan_arrays(self, vm, wm, groups, dataset_name, is_training, clip_mask=None, neg_index=None,
                     masked_words=None, words_weight=None, Lc_cap=None, Lss_cap=None, M_cap=None, n_valid=None):
@@ -274,7 +239,7 @@ class MESM(nn.Module):
         N, Lv = vm.shape
         arr, meta = {}, {"groups": list(groups)}
         if neg_index is None:
-            neg_index = self.draw_neg_padded(groups, n_valid).numpy()
+            neg_index = draws.neg_index(groups, n_valid)
         arr["neg_index"] = np.asarray(neg_index, dtype=np.int64)
         # the key-padding forms of the two masks (what every attention takes) ride in the plan: no inversion launches
         arr["vpad"], arr["wpad"] = ~vm, ~wm
@@ -348,7 +313,7 @@ class MESM(nn.Module):
             cinv[src[cmask]] = np.arange(N * Lc).reshape(N, Lc)[cmask]
             arr["clip_src"], arr["clip_inv"], arr["clip_mask"], arr["clip_pad"] = src, cinv, cmask, ~cmask
             if masked_words is None:
-                masked_words = self.draw_masked_words(torch.from_numpy(wm), words_weight).numpy()
+                masked_words = draws.masked_words(wm, words_weight)
             arr["masked_words"] = np.asarray(masked_words, dtype=bool)
         return arr, meta
 
