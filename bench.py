@@ -52,9 +52,10 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (v_m
 
 
 def gemm_mode():
-    """the GEMM arithmetic of this process (mesm_amd/csrc/gemm.hip: MESM_GEMM_BF16X, read once at load)"""
-    e = os.environ.get("MESM_GEMM_BF16X")
-    return int(e) if e in ("0", "3", "6") else 6
+    """the GEMM arithmetic of this process, as the loaded library reports it (MESM_GEMM_BF16X is read once at load and
+    tools may change it through mesm_gemm_set_switches: the environment is not the authority)"""
+    from mesm_amd._lib import lib
+    return int(lib().mesm_gemm_get_bf16x())
 
 
 def dtype_name():
@@ -64,8 +65,9 @@ def dtype_name():
 
 def draws_mode():
     from mesm_amd import draws
-    return ("%s (mesm_amd/draws.py; host_ms_per_step = host time of one step of the timed loop: graph launch + the "
-            "next step's negative / masked-word draws + their upload, overlapped with the device step)" % draws.MODE)
+    return ("%s (mesm_amd/draws.py; host_ms_per_step = host work of one step: graph launch call + the next step's "
+            "negative / masked-word draws + their upload, measured with the device idle at the start of the step so that no "
+            "back-pressure wait is counted; in the timed loop it overlaps the device step)" % draws.MODE)
 
 
 SETTLE_STEPS = 60  # untimed steps in front of the SECOND, informational timing (config.settled: not the headline)
@@ -437,15 +439,11 @@ def main():
             # runs on the device.  Still one fresh set of host draws per step, K draws inside the K timed steps -- but
             # the device does not idle for the ~1 ms of host RNG work in front of the first timed replay (at K = 20 that
             # idle millisecond was 50 us per step of the round-3 headline).
-            h0 = time.perf_counter()
             total = gstep.run(redraw=False)
             if post:
                 reducer.finish()
             gstep.redraw()
-            HOST["s"] += time.perf_counter() - h0
             return total
-
-    HOST = {"s": 0.0}  # host time inside step(): graph launch call + the next step's draws + their upload
 
     def fence():
         torch.cuda.synchronize()
@@ -462,11 +460,9 @@ def main():
             log("first step done")
     fence()
     log("warm-up done")
-    HOST["s"] = 0.0
     t0 = time.perf_counter()
     for _ in range(opt.steps):
         last = step()
-    host_ms = None if opt.eager else HOST["s"] / opt.steps * 1e3
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -550,6 +546,21 @@ def main():
                            "HIP-event median (max over ranks); neither is `value`"}
         log("settled: %.3f ms/step, event median %.3f" % (settled["ms_per_step_after_settling"],
                                                           settled["hip_event_median_ms_per_step"]))
+
+    # HOST work of one step (informational): the same step() with the device idle at its start, so that nothing in it
+    # waits for an earlier replay (in the timed loop the arena upload's back-pressure -- at most two steps ahead of
+    # the device -- makes step() LAST as long as the device step; that wait is not host work)
+    host_ms = None
+    if not opt.eager:
+        hs = 0.0
+        for _ in range(opt.steps):
+            torch.cuda.synchronize()
+            h0 = time.perf_counter()
+            step()
+            hs += time.perf_counter() - h0
+        torch.cuda.synchronize()
+        host_ms = hs / opt.steps * 1e3
+        log("host work per step %.3f ms" % host_ms)
 
     extras = rank == 0 and not opt.no_extras
     # the fallback path of ragged / unseen batch shapes before their graph exists: every launch from Python

@@ -153,51 +153,18 @@ int mesm_gemm_flush_side(void* stream);
 /* Tuning tools only: the dispatch switches MESM_GEMM_TILE / MESM_GEMM_BF16X are read from the environment ONCE, when the
  * library is loaded; this entry changes them between calls of one process (a negative value keeps the current one). */
 int mesm_gemm_set_switches(int32_t force_tile, int32_t bf16x);
+/* The GEMM arithmetic in force: 6 = f32 products as six bf16 matrix products over exactly split operands (the default),
+ * 3 = experimental two-term split, 0 = every product on the f32 matrix instruction (what bench.py reports as `dtype`). */
+int mesm_gemm_get_bf16x(void);
+/* Persistent form of the grouped split-bf16 launch (csrc/gemm_pk.hip: a fixed grid of two workgroups per CU walks the
+ * flattened (problem, tile, 128-deep reduce stage) list of a mesm_gemm_group call in equal shares; tiles cut between two
+ * workgroups are completed through a workspace).  mesm_gemm_pk_status: 0 = every launch so far completed its hand-offs
+ * (synchronises the device; tests).  mesm_gemm_pk_set (tuning tools): on = 0 | 1 (< 0: keep; MESM_GEMM_PK at load),
+ * grid = workgroups of the persistent grid (0: keep; clamped to what the device keeps resident). */
+int mesm_gemm_pk_status(void);
+int mesm_gemm_pk_set(int32_t on, int32_t grid);
 /* Forget the pending reductions without running them (error paths: their workspaces may already be released). */
 int mesm_gemm_drop_side(void);
-
-/* ------------------------------------------------------------------------- */
-/*
- * Split-bf16 "plane" GEMMs (csrc/gemm_px.hip) for the step's large nn.Linear products
- * (/root/reference/model/transformer.py:537, 603-608, 647, 794 and model.py:427-434, forward and both backward GEMMs):
- * every f32 operand value is held as three bf16 planes x = hi + mid + lo (8 significant bits each, exact), written once
- * by the operand's producer, and the six significant cross products are accumulated in f32 on
- * v_mfma_f32_32x32x16_bf16 -- the f32 product's own 2^-24 accuracy at 3/8 of the exact-f32 matrix-instruction time.
- *
- * MesmPlanes: three bf16 arrays (hi, mid, lo) in COLUMN-BLOCK-major order [cols / 16][rows][16]: element (r, c) of the
- * logical tensor at ((c / 16) * ld_rows + r) * 16 + c % 16, i.e. `ld` = elements between column blocks (>= rows * 16).
- * rows and cols are the PADDED extents (multiples of 32, padding = zeros), every pointer 16-byte aligned, plane < 2^31
- * elements.  A 16-deep reduce stage of the kernels then reads whole 128-byte lines whichever index is reduced: one plane
- * set serves a tensor both as a reduce-contiguous operand (reduce index = column) and as an outer-contiguous one (reduce
- * index = row: the weight-gradient GEMMs), see MesmGemmArgs.a_layout / b_layout.
- */
-typedef struct MesmPlanes {
-  uint16_t* p[3]; /* hi, mid, lo */
-  int64_t ld;
-  int32_t rows, cols;
-} MesmPlanes;
-
-/* x (rows x cols f32, leading dimension ld) -> planes (out->rows >= rows, out->cols >= cols; the padding is zeroed). */
-int mesm_split_planes(const float* x, int64_t ld, int32_t rows, int32_t cols, const MesmPlanes* out, void* stream);
-/* Many tensors in ONE launch (all weight matrices, once per step).  The descriptor table is built on the host with
- * mesm_split_desc_fill (entry size mesm_split_desc_size() bytes; returns the workgroups the entry takes, -1 on a bad
- * argument; `start` = sum of the previous entries' workgroups), copied to the device by the caller, and launched with
- * mesm_split_planes_table(table_dev, n, total_workgroups). */
-int64_t mesm_split_desc_size(void);
-int32_t mesm_split_desc_fill(void* table_host, int32_t idx, const float* x, int64_t ld, int32_t rows, int32_t cols,
-                             const MesmPlanes* out, int32_t start);
-int mesm_split_planes_table(const void* table_dev, int32_t n, int32_t total_workgroups, void* stream);
-/* C = epi(op(A) op(B)) exactly as mesm_gemm_f32 describes it (same MesmGemmArgs: shapes, layouts, every epilogue
- * field, split_k, colsum), with the operand VALUES taken from the plane sets a / b instead of args->A / args->B
- * (which are ignored).  Not available (MESM_EINVAL, and mesm_gemm_px_supported() == 0): operand transforms
- * (a_act / b_act / a_drop / b_drop), addends (A2 / B2), and the layout pair (outer-contiguous A, reduce-contiguous B).
- * Plane extents: outer extents >= M / N rounded up to 32, the two reduce extents equal and = K rounded up to 32. */
-int mesm_gemm_px_supported(const MesmGemmArgs* args);
-/* Tuning tools only: pin the plane kernel's tile (64 = 64 x 64, 96 = 96 x 64 where the A operand allows it, 0 = automatic). */
-int mesm_gemm_px_set_tile(int32_t tile);
-/* ... and its loop form (0 = automatic; 1 | 2 = one | two stage buffers per wave with 4 waves; 8 = 8 waves, one buffer). */
-int mesm_gemm_px_set_ring(int32_t mode);
-int mesm_gemm_px(const MesmGemmArgs* args, const MesmPlanes* a, const MesmPlanes* b, void* stream);
 
 /*
  * Launch-duration measurement of mesm_gemm_f32 (the dominant kernel of the step) for

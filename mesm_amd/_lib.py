@@ -77,10 +77,6 @@ class LnArgs(ctypes.Structure):
     ]
 
 
-class Planes(ctypes.Structure):
-    _fields_ = [("p", c_ptr * 3), ("ld", ctypes.c_int64), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32)]
-
-
 # name -> (restype, argtypes); mirrors include/mesm_gfx950.h one to one.
 _i32, _i64, _f32, _u32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_uint32
 PROTOTYPES = {
@@ -89,15 +85,10 @@ PROTOTYPES = {
     "mesm_gemm_f32": (ctypes.c_int, [ctypes.POINTER(GemmArgs), c_ptr]),
     "mesm_gemm_group": (ctypes.c_int, [ctypes.POINTER(GemmArgs), _i32, c_ptr]),
     "mesm_gemm_flush_side": (ctypes.c_int, [c_ptr]),
+    "mesm_gemm_get_bf16x": (ctypes.c_int, []),
+    "mesm_gemm_pk_status": (ctypes.c_int, []),
+    "mesm_gemm_pk_set": (ctypes.c_int, [_i32, _i32]),
     "mesm_gemm_set_switches": (ctypes.c_int, [_i32, _i32]),
-    "mesm_split_planes": (ctypes.c_int, [c_ptr, _i64, _i32, _i32, ctypes.POINTER(Planes), c_ptr]),
-    "mesm_split_desc_size": (ctypes.c_int64, []),
-    "mesm_split_desc_fill": (ctypes.c_int32, [c_ptr, _i32, c_ptr, _i64, _i32, _i32, ctypes.POINTER(Planes), _i32]),
-    "mesm_split_planes_table": (ctypes.c_int, [c_ptr, _i32, _i32, c_ptr]),
-    "mesm_gemm_px_supported": (ctypes.c_int, [ctypes.POINTER(GemmArgs)]),
-    "mesm_gemm_px_set_tile": (ctypes.c_int, [_i32]),
-    "mesm_gemm_px_set_ring": (ctypes.c_int, [_i32]),
-    "mesm_gemm_px": (ctypes.c_int, [ctypes.POINTER(GemmArgs), ctypes.POINTER(Planes), ctypes.POINTER(Planes), c_ptr]),
     "mesm_gemm_drop_side": (ctypes.c_int, []),
     "mesm_gemm_tape": (ctypes.c_int, [_i32]),
     "mesm_gemm_tape_entry": (ctypes.c_int, [c_ptr, _i32, _i32, ctypes.POINTER(ctypes.c_double),

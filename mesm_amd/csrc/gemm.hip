@@ -15,7 +15,7 @@
 #include <vector>
 
 #include <cstddef>
-#include "gemm_common.hpp"
+#include "gemm_ws.hpp"
 
 
 namespace {
@@ -32,31 +32,6 @@ __global__ __launch_bounds__(256) void dslope_reduce_kernel(const float* __restr
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
   __syncthreads();
   if (threadIdx.x == 0) dst[0] += sh[0] + sh[1] + sh[2] + sh[3];
-}
-
-// The reduction of the partials does not get a launch of its own (14 per step, ~2.3 us each in the graph): it is
-// CARRIED by the next GEMM launch on the stream -- wave 0 of that launch's first workgroup sums the partials of up to four
-// pending reductions before its own work (stream order: the producing kernel has finished).  Host-side queue; what no
-// launch has picked up is reduced by mesm_gemm_flush_side (called at the end of every backward block).
-struct SideRed {
-  const float* ws[4];
-  float* dst[4];
-  int n[4];
-  int count;
-};
-
-__device__ __forceinline__ void side_reduce(const SideRed& sr) {
-  if (sr.count == 0 || blockIdx.x != 0 || blockIdx.y != 0 || blockIdx.z != 0 || (threadIdx.x >> 6) != 0) return;
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if (i < sr.count) {
-      float a = 0.0f;
-      for (int k = lane; k < sr.n[i]; k += 64) a += sr.ws[i][k];
-      a = wave_sum(a);
-      if (lane == 0) sr.dst[i][0] += a;
-    }
-  }
 }
 
 struct SidePending {
@@ -836,7 +811,6 @@ __device__ __forceinline__ void l64_stamp(int slot) {
 #define L64_STAMP(i)
 #endif
 
-constexpr int WS_SLAB = 32 * 32;  // floats
 #ifndef MESM_WS_NW
 #define MESM_WS_NW 4
 #endif
@@ -853,50 +827,6 @@ constexpr int WS_THREADS = 64 * WS_NW;
 #else
 #define WS_BOUNDS __launch_bounds__(WS_THREADS)
 #endif
-
-template <int LAYOUT>
-__device__ __forceinline__ void ws_issue(const float* __restrict__ base, int64_t ld, int o0, int extent,
-                                         int kb, int k1, float* slab, int lane) {
-  const int sr = lane >> 3, pos = lane & 7;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const float* g;
-    if (LAYOUT == MESM_LAYOUT_REDUCE_CONTIG) {
-      const int r = 8 * q + sr;
-      int row = o0 + r;
-      row = row < extent ? row : extent - 1;
-      const int c = pos ^ ((r >> 1) & 7);
-      int k = kb + 4 * c;
-      k = k < k1 ? k : k1 - 4;  // tail: clamped garbage, zeroed at fragment read
-      g = base + (int64_t)row * ld + k;
-    } else {
-      int k = kb + 8 * q + (((sr & 1) << 2) | (sr >> 1));
-      k = k < k1 ? k : k1 - 1;
-      int o = o0 + 4 * pos;
-      const int e4 = (extent + 3) & ~3;  // a chunk may straddle the extent (into the next reduce row: gemm_kmain)
-      o = o + 4 <= e4 ? o : e4 - 4;
-      g = base + (int64_t)k * ld + o;
-    }
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)(slab + q * 256), 16, 0, 0);
-  }
-}
-
-// fragment of one stage: v[s][j] = operand[outer = lane & 31][k = kb + 8s + 4h + j]
-template <int LAYOUT>
-__device__ __forceinline__ void ws_read(const float* slab, int li, int h, float (&v)[4][4]) {
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    if (LAYOUT == MESM_LAYOUT_REDUCE_CONTIG) {
-      const int pos = (2 * s + h) ^ ((li >> 1) & 7);
-      const float4 x = *reinterpret_cast<const float4*>(slab + li * 32 + pos * 4);
-      v[s][0] = x.x; v[s][1] = x.y; v[s][2] = x.z; v[s][3] = x.w;
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[s][j] = slab[(8 * s + 2 * j + h) * 32 + li];
-    }
-  }
-}
 
 // WS_STAGES: wave-private k-tiles resident in LDS per operand pair.  2 = double buffer (64 KB per workgroup,
 // 2 workgroups per CU), 1 = load / read / refill in place (32 KB, 5 per CU).  Measured (tools/gemm_sweep.py):
@@ -1052,16 +982,6 @@ __global__ WS_BOUNDS void gemm_wstage_kernel(const MesmGemmArgs p, const SideRed
 // dispatch + ~3 us of exposed latency chain whatever its size, and the backward of every block as well
 // as the decoder are made of independent 5 us GEMMs).  The workgroups of all problems are laid out
 // back to back on blockIdx.x; layouts / transforms are selected per problem at run time (wave-uniform).
-#ifndef MESM_GROUP_MAX
-#define MESM_GROUP_MAX 8  // (12: the larger kernel-argument segment costs every grouped launch more than the 4 merged launches save, 4.923 vs 4.896 ms)
-#endif
-constexpr int GROUP_MAX = MESM_GROUP_MAX;
-struct GroupArgs {
-  MesmGemmArgs p[GROUP_MAX];
-  int start[GROUP_MAX + 1];  // first workgroup of every problem
-  int n;
-};
-
 template <int STAGES>
 __global__ WS_BOUNDS void gemm_wstage_group_kernel(const GroupArgs g, const SideRed sr) {
   side_reduce(sr);
@@ -1135,68 +1055,6 @@ bool wstage_ok(const MesmGemmArgs& a) {
   return ok(a.a_layout, a.M) && ok(a.b_layout, a.N);
 }
 
-// Split-precision products (BF = 6: the default for the large products since round 4; BF = 3 experimental): a stage
-// on v_mfma_f32_32x32x16_bf16 (16x the f32 MFMA rate) with every f32 operand value split exactly into bf16 terms
-// x = hi + mid + lo (8 mantissa bits each; hi and mid by truncation, so x - hi and x - hi - mid are exact f32
-// subtractions) and the significant cross products accumulated in f32:
-//   BF = 6: hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi   (error ~2^-24 of |a||b|, the f32 product's own)
-//   BF = 3: hi*hi + hi*mid + mid*hi                              (error ~2^-16)
-// Selected at run time by MESM_GEMM_BF16X=6|3 (bench.py reports both under roofline.experimental with the parity
-// suite's verdict at unchanged tolerances); the split is done on the fragment registers (~6 VALU per value).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-template <int BF>
-struct SplitFrag {
-  u32x4 hi[2], mid[2], lo[2];  // [bf16 k-step of 16][4 dwords = 8 bf16]
-  // v[s][j] = operand[outer][kb + 8 s + 4 h + j]: k-step t takes s = 2t, 2t + 1 (the same slot map on both operands)
-  __device__ __forceinline__ void fake(const float (&v)[4][4]) {  // probe builds: no split arithmetic
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        hi[t][i] = __float_as_uint(v[2 * t + (i >> 1)][2 * (i & 1)]);
-        mid[t][i] = __float_as_uint(v[2 * t + (i >> 1)][2 * (i & 1) + 1]);
-        lo[t][i] = hi[t][i];
-      }
-  }
-  __device__ __forceinline__ void make(const float (&v)[4][4]) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float x0 = v[2 * t + (i >> 1)][2 * (i & 1)], x1 = v[2 * t + (i >> 1)][2 * (i & 1) + 1];
-        const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
-        hi[t][i] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
-        const float r0 = x0 - __uint_as_float(u0 & 0xFFFF0000u), r1 = x1 - __uint_as_float(u1 & 0xFFFF0000u);
-        const unsigned m0 = __float_as_uint(r0), m1 = __float_as_uint(r1);
-        mid[t][i] = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
-        if (BF == 6) {
-          const float q0 = r0 - __uint_as_float(m0 & 0xFFFF0000u), q1 = r1 - __uint_as_float(m1 & 0xFFFF0000u);
-          lo[t][i] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
-        }
-      }
-  }
-};
-
-template <int BF>
-__device__ __forceinline__ f32x16 split_mma(const SplitFrag<BF>& a, const SplitFrag<BF>& b, f32x16 acc) {
-#define MESM_BF(x) __builtin_bit_cast(bf16x8, x)
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    if (BF == 6) {  // smallest terms first
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MESM_BF(a.lo[t]), MESM_BF(b.hi[t]), acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MESM_BF(a.hi[t]), MESM_BF(b.lo[t]), acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MESM_BF(a.mid[t]), MESM_BF(b.mid[t]), acc, 0, 0, 0);
-    }
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MESM_BF(a.mid[t]), MESM_BF(b.hi[t]), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MESM_BF(a.hi[t]), MESM_BF(b.mid[t]), acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MESM_BF(a.hi[t]), MESM_BF(b.hi[t]), acc, 0, 0, 0);
-  }
-#undef MESM_BF
-  return acc;
-}
-
 // ------------------------------------------------------------------------------------------------
 // "wstage64": the k-split idea on a 64 x 64 tile.  Each of the four waves computes the WHOLE tile
 // (2 x 2 accumulators) over its quarter of the reduce range, staged wave-privately by LDS-DMA like
@@ -1205,10 +1063,6 @@ __device__ __forceinline__ f32x16 split_mma(const SplitFrag<BF>& a, const SplitF
 // stage's loads: a single LDS buffer per wave suffices, because all fragments of a stage are in
 // registers before its refill is issued.  Used when the problem has enough 64 x 64 tiles to occupy
 // the chip (the 2400- and 4800-row d x d GEMMs, the split-K weight gradients).
-#ifdef MESM_W64_FINISH_PROBE
-__device__ unsigned w64_probe_ctr[1024];
-__device__ float w64_probe_out[8192 * 256];
-#endif
 template <int LA, int LB, bool XF, int BF = 0>
 __device__ __forceinline__ void wstage64_body(const MesmGemmArgs& p, const Blk blk, float* L) {
   const int tid = threadIdx.x;
@@ -1275,12 +1129,10 @@ __device__ __forceinline__ void wstage64_body(const MesmGemmArgs& p, const Blk b
     ws_read<LB>(mine + 2 * WS_SLAB, li, h, b[0]);
     ws_read<LB>(mine + 3 * WS_SLAB, li, h, b[1]);
     const int kb = k0 + 32 * st;
-#ifndef MESM_W64_NO_LOAD  // (probe builds MESM_W64_NO_*: wrong results, where does a stage's time go -- tools/w64_probe.py)
     if (st + 1 < nst) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments are in registers: refill the slabs
       issue(st + 1);
     }
-#endif
     if (kb + 32 > k1) {
 #pragma unroll
       for (int t = 0; t < 2; ++t)
@@ -1318,28 +1170,13 @@ __device__ __forceinline__ void wstage64_body(const MesmGemmArgs& p, const Blk b
       SplitFrag<BF> sa[2], sb[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-#ifdef MESM_W64_NO_SPLIT
-        sa[t].fake(a[t]);
-        sb[t].fake(b[t]);
-#else
         sa[t].make(a[t]);
         sb[t].make(b[t]);
-#endif
       }
-#ifdef MESM_W64_NO_MMA
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            acc[t][q][i] += __uint_as_float((sa[t].hi[q][i] ^ sa[t].mid[q][i] ^ sa[t].lo[q][i] ^ sb[t].hi[q][i] ^ sb[t].mid[q][i] ^ sb[t].lo[q][i]) & 0x3fffffffu);
-#else
 #pragma unroll
       for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
         for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = split_mma<BF>(sa[ti], sb[tj], acc[ti][tj]);
-#endif
     } else {
 #pragma unroll
       for (int s_ = 0; s_ < 4; ++s_)
@@ -1401,57 +1238,6 @@ __device__ __forceinline__ void wstage64_body(const MesmGemmArgs& p, const Blk b
   L64_STAMP(29);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   L64_STAMP(30);
-#ifdef MESM_W64_FINISH_PROBE
-  // PROBE (timing only; tools/w64_probe.py): what would a "last arriver normalises the row block" LayerNorm cost inside
-  // this kernel?  Every workgroup releases its tile (device-scope fence), counts itself on its row block, and the last
-  // of the N / 64 tiles acquires and runs a two-pass LayerNorm over the block's 64 x 256 values into a scratch buffer.
-  if (p.N == 256 && p.split_k <= 1) {
-#if MESM_W64_FINISH_PROBE == 2
-    // variant 2: no device-scope fences -- valid only if the four tiles of a row block run on ONE XCD (its L2 is then
-    // the coherence point): stores acknowledged (vmcnt(0) above), an L2 atomic, the last arriver's loads bypass L1 (sc0)
-    __syncthreads();
-#else
-    __threadfence();
-    __syncthreads();
-#endif
-    int* flag = reinterpret_cast<int*>(L);
-    if (threadIdx.x == 0) {
-#if MESM_W64_FINISH_PROBE == 2
-      const unsigned prev = __hip_atomic_fetch_add(&w64_probe_ctr[blk.x & 1023], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
-      const unsigned prev = atomicAdd(&w64_probe_ctr[blk.x & 1023], 1u);
-#endif
-      const int last = prev == 3u;
-      if (last) w64_probe_ctr[blk.x & 1023] = 0u;
-      *flag = last;
-    }
-    __syncthreads();
-    if (*flag) {
-#if MESM_W64_FINISH_PROBE != 2
-      __threadfence();
-#endif
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wave * 16 + r;
-        if (row < p.M) {
-#if MESM_W64_FINISH_PROBE == 2
-          float4 v;
-          {
-            const float* src = p.C + (int64_t)row * p.ldc + lane * 4;
-            asm volatile("global_load_dwordx4 %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(src) : "memory");
-          }
-#else
-          const float4 v = *reinterpret_cast<const float4*>(p.C + (int64_t)row * p.ldc + lane * 4);
-#endif
-          const float mu = wave_sum(v.x + v.y + v.z + v.w) * (1.0f / 256.0f);
-          const float dx = v.x - mu, dy = v.y - mu, dz = v.z - mu, dw = v.w - mu;
-          const float rs = rsqrtf(wave_sum(dx * dx + dy * dy + dz * dz + dw * dw) * (1.0f / 256.0f) + 1e-5f);
-          *reinterpret_cast<float4*>(w64_probe_out + ((int64_t)(row & 8191) * 256 + lane * 4)) =
-              make_float4(dx * rs, dy * rs, dz * rs, dw * rs);
-        }
-      }
-    }
-  }
-#endif
 }
 
 template <int LA, int LB, bool XF, int BF = 0>
@@ -1499,133 +1285,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_wstage64_group_kernel(const 
   }
 }
 
-#ifdef MESM_W64_ANTI
-// PROBE (tools/w64_probe.py, -DMESM_W64_ANTI): the split kernel as an 8-wave workgroup (k-split 8, one per CU, 128 KB of
-// slabs) whose waves 0-3 and 4-7 are held in ANTI-phase by two barriers per stage: one group issues its loads, waits
-// for them and reads its fragments while the other splits and multiplies.  Tests the reading of the other probes
-// (DESIGN.md section 8.1): co-resident waves of the production kernel run in lockstep, so their load phases and their
-// matrix phases add up.  No column sums, no operand transforms, split mode only.
-template <int LA, int LB>
-__global__ __launch_bounds__(512) void gemm_w64anti_kernel(const MesmGemmArgs p, const SideRed sr) {
-  side_reduce(sr);
-  extern __shared__ __attribute__((aligned(16))) float L[];  // 8 waves x 4 slabs
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 31, h = lane >> 5;
-  Blk blk;
-  blk.slot = linear_block();
-  xcd_tile_z((int)blk.slot, (p.M + 63) / 64, (p.N + 63) / 64, p.split_k, blk.x, blk.y, blk.z);
-  const int m0 = blk.x * 64, n0 = blk.y * 64;
-  const int KM = gemm_kmain(p);
-  int kbeg = 0, kend = KM;
-  if (p.split_k > 1) {
-    int chunk = (p.K + p.split_k - 1) / p.split_k;
-    chunk = ((chunk + BK_MAX - 1) / BK_MAX) * BK_MAX;
-    kbeg = blk.z * chunk;
-    kend = kbeg + chunk < KM ? kbeg + chunk : KM;
-    if (kbeg >= KM) {
-      if (blk.z > 0) return;
-      kbeg = kend = KM;
-    }
-  }
-  const int kw = (((kend - kbeg + 7) >> 3) + 31) & ~31;
-  const int k0 = kbeg + wave * kw;
-  const int k1 = k0 + kw < kend ? k0 + kw : kend;
-  const int nst = k1 > k0 ? (k1 - k0 + 31) >> 5 : 0;
-  const int nst_max = kw >> 5;  // the same for every wave: they all walk the barriers
-  const float slope = p.slope ? *p.slope : 0.0f;
-  const uint32_t seed_off = p.seed_offset ? *p.seed_offset : 0u;
-  XForm xa{}, xb{};
-  float* mine = L + wave * (4 * WS_SLAB);
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-  const int grp = wave >> 2;
-  if (grp == 1) __syncthreads();
-  for (int st = 0; st < nst_max; ++st) {
-    const bool have = st < nst;
-    const int kb = k0 + 32 * st;
-    float a[2][4][4], b[2][4][4];
-    // LOAD phase
-    if (have) {
-      ws_issue<LA>(p.A, p.lda, m0, p.M, kb, k1, mine, lane);
-      ws_issue<LA>(p.A, p.lda, m0 + 32, p.M, kb, k1, mine + WS_SLAB, lane);
-      ws_issue<LB>(p.B, p.ldb, n0, p.N, kb, k1, mine + 2 * WS_SLAB, lane);
-      ws_issue<LB>(p.B, p.ldb, n0 + 32, p.N, kb, k1, mine + 3 * WS_SLAB, lane);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (have) {
-      ws_read<LA>(mine, li, h, a[0]);
-      ws_read<LA>(mine + WS_SLAB, li, h, a[1]);
-      ws_read<LB>(mine + 2 * WS_SLAB, li, h, b[0]);
-      ws_read<LB>(mine + 3 * WS_SLAB, li, h, b[1]);
-      if (kb + 32 > k1) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int s_ = 0; s_ < 4; ++s_)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const bool ok = kb + 8 * s_ + 4 * h + j < k1;
-              a[t][s_][j] = ok ? a[t][s_][j] : 0.0f;
-              b[t][s_][j] = ok ? b[t][s_][j] : 0.0f;
-            }
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __syncthreads();
-    // COMPUTE phase
-    if (have) {
-      SplitFrag<6> sa[2], sb[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        sa[t].make(a[t]);
-        sb[t].make(b[t]);
-      }
-#pragma unroll
-      for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = split_mma<6>(sa[ti], sb[tj], acc[ti][tj]);
-    }
-    __syncthreads();
-  }
-  if (grp == 0) __syncthreads();
-  __syncthreads();
-#pragma unroll
-  for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-    for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4)
-        reinterpret_cast<float4*>(L)[((wave * 4 + ti * 2 + tj) * 4 + r4) * 64 + lane] =
-            make_float4(acc[ti][tj][4 * r4], acc[ti][tj][4 * r4 + 1], acc[ti][tj][4 * r4 + 2], acc[ti][tj][4 * r4 + 3]);
-  __syncthreads();
-  if (wave < 4) {
-    f32x16 sum;
-#pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-      float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-#pragma unroll
-      for (int w = 0; w < 8; ++w) {
-        const float4 u = reinterpret_cast<const float4*>(L)[((w * 4 + wave) * 4 + r4) * 64 + lane];
-        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
-      }
-      sum[4 * r4] = t.x; sum[4 * r4 + 1] = t.y; sum[4 * r4 + 2] = t.z; sum[4 * r4 + 3] = t.w;
-    }
-    // (dslope_store's use of the head of L is not supported by this probe: no PReLU slope gradients)
-    tile16_epilogue<LA, LB, false>(p, sum, m0 + 32 * (wave >> 1), n0 + 32 * (wave & 1), slope, seed_off, blk.z, L + 8 * 4 * WS_SLAB,
-                                   blk.slot, KM, xa, xb);
-  }
-}
-#endif
 
-// MESM_GEMM_BF16X = 6 | 3: the experimental split-bf16 products (see SplitFrag); 0 / unset = exact f32
+// MESM_GEMM_BF16X: unset / 6 = split-bf16 products, three exact terms (see SplitFrag); 3 = experimental two-term form;
+// anything else = exact f32
 inline int bf16x_mode() { return mesm_gemm_bf16x(); }
 int mesm_gemm_group64();
+}  // namespace
+// gemm_pk.hip
+int mesm_gemm_pk_launch(const MesmGemmArgs* list, int n, const void* side_red, hipStream_t s, int64_t* dslope_slots);
+namespace {
 
 template <int LA, int LB>
 int launch_wstage64_l(const MesmGemmArgs& a, hipStream_t s) {
@@ -1633,18 +1301,6 @@ int launch_wstage64_l(const MesmGemmArgs& a, hipStream_t s) {
   const bool xf = a.a_act != MESM_ACT_NONE || a.b_act != MESM_ACT_NONE || a.a_drop_p > 0.f || a.b_drop_p > 0.f;
   const int bf = xf ? 0 : bf16x_mode();  // (operand transforms + split: 260-288 VGPRs, one workgroup per CU or spills)
   const SideRed sr = take_side(s);
-#ifdef MESM_W64_ANTI
-  if (bf == 6 && a.colsum == nullptr && !(a.e_actgrad == MESM_ACT_PRELU && a.dslope)) {
-    static bool attr = false;
-    const size_t lds = (size_t)(8 * 4 * WS_SLAB + 64) * sizeof(float);
-    if (!attr) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w64anti_kernel<LA, LB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr = true;
-    }
-    hipLaunchKernelGGL((gemm_w64anti_kernel<LA, LB>), grid, dim3(512), lds, s, a, sr);
-    return mesm_launch_status();
-  }
-#endif
   if (bf == 6) hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, false, 6>), grid, dim3(NTHREADS), 0, s, a, sr);
   else if (bf == 3) hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, false, 3>), grid, dim3(NTHREADS), 0, s, a, sr);
   else if (xf) hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, true>), grid, dim3(NTHREADS), 0, s, a, sr);
@@ -2172,10 +1828,11 @@ int g_bf16x = []() { const char* e = getenv("MESM_GEMM_BF16X"); const int m = e 
 int mesm_gemm_force_tile() { return g_force_tile; }
 int mesm_gemm_bf16x() { return g_bf16x; }
 // MESM_GEMM_GROUP64: 1 = the problems of a grouped call that the 64 x 64 k-split kernel takes share ONE
-// gemm_wstage64_group_kernel launch, and the call's other products ride along (default in split-bf16 mode: 4.40 -> 4.01
-// ms/step; in exact-f32 mode it loses, 4.609 -> 4.642, and stays off); 0 = launched one by one
+// launch, and the call's other products ride along (default in the three-term split-bf16 mode: 4.40 -> 4.01
+// ms/step; in exact-f32 mode it loses, 4.609 -> 4.642, and stays off; off in the experimental two-term mode as well, whose
+// grouped kernel is not instantiated: every product of that mode then runs the two-term split); 0 = launched one by one
 int g_group64 = []() { const char* e = getenv("MESM_GEMM_GROUP64"); return e ? atoi(e) : -1; }();
-int mesm_gemm_group64() { return g_group64 >= 0 ? g_group64 : (g_bf16x != 0 ? 1 : 0); }
+int mesm_gemm_group64() { return g_group64 >= 0 ? g_group64 : (g_bf16x == 6 ? 1 : 0); }
 
 int dispatch(const MesmGemmArgs& a, int vec, hipStream_t s) {
   {
@@ -2327,11 +1984,25 @@ int launch_group(const MesmGemmArgs* list, const int* vecs, int n, hipStream_t s
   g64.start[0] = 0;
   auto flush64 = [&]() {
     if (g64.n == 0) return;
+    const int bf = bf16x_mode();
+    if (bf == 6) {
+      // the persistent form (gemm_pk.hip): a fixed grid walks the flattened (problem, tile, 128-deep stage) list in
+      // equal shares; 1 = not available (first call under capture, switched off): the per-tile launch below
+      const SideRed sr = take_side(s);
+      int64_t slots[GROUP_MAX];
+      const int prc = mesm_gemm_pk_launch(g64.p, g64.n, &sr, s, slots);
+      if (prc != 1) {
+        rc = prc;
+        for (int k = 0; k < g64.n && rc == MESM_OK; ++k) rc = dslope_finish_n(g64.p[k], slots[k], s);
+        g64.n = 0;
+        return;
+      }
+      for (int i = 0; i < sr.count; ++i) g_side.push_back({sr.ws[i], sr.dst[i], sr.n[i], s});  // (hand them back)
+    }
     if (g64.n == 1) {
       rc = launch_wstage64(g64.p[0], s);
     } else {
       const SideRed sr = take_side(s);
-      const int bf = bf16x_mode();
       if (bf == 6) hipLaunchKernelGGL(gemm_wstage64_group_kernel<6>, dim3(g64.start[g64.n]), dim3(NTHREADS), 0, s, g64, sr);
       else hipLaunchKernelGGL(gemm_wstage64_group_kernel<0>, dim3(g64.start[g64.n]), dim3(NTHREADS), 0, s, g64, sr);
       rc = mesm_launch_status();
@@ -2423,6 +2094,8 @@ extern "C" int mesm_gemm_group(const MesmGemmArgs* args, int32_t n, void* stream
 int mesm_gemm_dslope_finish(const MesmGemmArgs& a, int64_t nblocks, hipStream_t s) { return dslope_finish_n(a, nblocks, s); }
 
 // tuning tools flip the two dispatch switches between calls of one process (< 0: keep)
+extern "C" int mesm_gemm_get_bf16x(void) { return g_bf16x; }
+
 extern "C" int mesm_gemm_set_switches(int32_t force_tile, int32_t bf16x) {
   if (force_tile >= 0) g_force_tile = force_tile;
   if (bf16x >= 0) g_bf16x = (bf16x == 3 || bf16x == 6) ? bf16x : 0;

@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 from ._lib import (ACT_NONE, ACT_PRELU, ACT_RELU, LAYOUT_OUTER_CONTIG,
-                   LAYOUT_REDUCE_CONTIG, MASK_CAUSAL, MASK_KPAD, MASK_T2V_QUIRK, AttnArgs, GemmArgs, LnArgs, Planes,
+                   LAYOUT_REDUCE_CONTIG, MASK_CAUSAL, MASK_KPAD, MASK_T2V_QUIRK, AttnArgs, GemmArgs, LnArgs,
                    check, lib, ptr, require_gpu, stream_ptr)
 
 __all__ = [
@@ -91,56 +91,27 @@ def gemm_switches(tile=None, bf16x=None):
           "mesm_gemm_set_switches")
 
 
-class PlaneSet:
-    """The three bf16 planes (hi, mid, lo: x = hi + mid + lo exactly) of a 2-D fp32 tensor, zero-padded to multiples of 32
-    in both extents, in the column-block-major order of MesmPlanes (include/mesm_gfx950.h): the operand form of the
-    split-bf16 GEMMs (mesm_gemm_px).  `buf` is one int16 tensor (3, cols_pad / 16, rows_pad, 16); `shape` the logical
-    (rows, cols)."""
-    __slots__ = ("buf", "shape", "c")
-
-    def __init__(self, rows, cols, device, buf=None):
-        rp, cp = (int(rows) + 31) // 32 * 32, (int(cols) + 31) // 32 * 32
-        self.buf = torch.empty((3, cp // 16, rp, 16), device=device, dtype=torch.int16) if buf is None else buf
-        assert self.buf.shape == (3, cp // 16, rp, 16) and self.buf.is_contiguous()
-        self.shape = (int(rows), int(cols))
-        c = Planes()
-        base, step = self.buf.data_ptr(), rp * cp * 2
-        c.p[0], c.p[1], c.p[2] = base, base + step, base + 2 * step
-        c.ld, c.rows, c.cols = rp * 16, rp, cp
-        self.c = c
-
-    def float(self):
-        """hi + mid + lo as fp32 in the logical orientation (tests)"""
-        b = self.buf.view(torch.bfloat16).float()          # (3, cb, rows_pad, 16)
-        x = (b[2] + b[1] + b[0]).permute(1, 0, 2).reshape(b.shape[2], -1)
-        return x[:self.shape[0], :self.shape[1]]
+def gemm_pk(on=None, grid=None):
+    """tuning tools / tests: the persistent form of the grouped split-bf16 launch on / off, its grid (csrc/gemm_pk.hip)"""
+    check(lib().mesm_gemm_pk_set(-1 if on is None else int(bool(on)), 0 if grid is None else int(grid)), "mesm_gemm_pk_set")
 
 
-def split_planes(x, out=None):
-    """PlaneSet of a 2-D fp32 tensor with unit column stride (one launch: 4 bytes read, 6 written per element)."""
-    require_gpu(x)
-    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32
-    ps = out if out is not None else PlaneSet(x.shape[0], x.shape[1], x.device)
-    assert ps.shape == tuple(x.shape)
-    check(lib().mesm_split_planes(x.data_ptr(), x.stride(0), x.shape[0], x.shape[1], ctypes.byref(ps.c), stream_ptr()),
-          "mesm_split_planes")
-    return ps
+def gemm_pk_status():
+    """0 = every persistent launch so far completed its cross-workgroup hand-offs (synchronises the device)"""
+    return int(lib().mesm_gemm_pk_status())
 
 
 def gemm(A, B, C, *, trans_a=False, trans_b=False, A2=None, B2=None, bias=None, residual=None,
          aux=None, slope=None, dslope=None, colsum=None, a_act=ACT_NONE, b_act=ACT_NONE,
          a_drop=(0.0, 0), b_drop=(0.0, 0), e_act=ACT_NONE, e_actgrad=ACT_NONE,
-         e_drop=(0.0, 0), out_scale=1.0, accumulate=0, split_k=1, pre_out=None, row0=0,
-         a_planes=None, b_planes=None):
+         e_drop=(0.0, 0), out_scale=1.0, accumulate=0, split_k=1, pre_out=None, row0=0):
     """C[M,N] (+)= epi( op(A) @ op(B) ).
 
     A is (M,K) (or (K,M) with trans_a), B is (K,N) (or (N,K) with trans_b); both are
     2-D views whose last stride is 1.  C is (M,N) with unit column stride.
-    a_planes / b_planes (PlaneSet of A / B as stored): the split-bf16 plane kernel takes the product (mesm_gemm_px).
     """
     require_gpu(A, B, C)
-    px = a_planes is not None and b_planes is not None
-    if (_SPLIT_ROWS and not px and row0 == 0 and not trans_a and C.shape[1] == 256 and A.shape[1] >= 1024
+    if (_SPLIT_ROWS and row0 == 0 and not trans_a and C.shape[1] == 256 and A.shape[1] >= 1024
             and 4096 < C.shape[0] <= 5120 and split_k == 1 and colsum is None and dslope is None and A2 is None
             and float(a_drop[0]) == 0.0 and a_act == ACT_NONE):
         # 4800 / 4864-row outputs of width 256: 300 tiles of 64 x 64 on 256 CUs are two rounds with the second 17 %
@@ -219,16 +190,6 @@ def gemm(A, B, C, *, trans_a=False, trans_b=False, A2=None, B2=None, bias=None, 
         g.pre_out, g.ldpre = pre_out.data_ptr(), pre_out.stride(0)
     g.e_drop_row0 = int(row0)
     g.seed_offset = _seed_off_ptr()
-    if px:
-        # plane operands: issued at once (these are the step's large products: nothing to gain from a grouped launch)
-        assert a_planes.shape == tuple(A.shape) and b_planes.shape == tuple(B.shape)
-        check(lib().mesm_gemm_px(ctypes.byref(g), ctypes.byref(a_planes.c), ctypes.byref(b_planes.c), stream_ptr()),
-              "mesm_gemm_px")
-        if dslope is not None:
-            _side_keep.append(ws)
-            if _phase is None and _side_defer == 0:
-                gemm_flush_side()
-        return C
     if _phase is not None:
         # inside a launch phase: queued; the tensors stay referenced until the phase is launched
         _phase.add("gemm", g, (A, B, C, A2, B2, bias, residual, aux, slope, dslope, colsum,

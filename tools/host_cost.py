@@ -24,6 +24,14 @@ for _ in range(N):
     tr += b - a; tp += c - b
 torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) / N * 1e3
+# the same with the device idle at the start of every step: redraw() then never waits for the arena mirror it wrote
+# two uploads ago (back-pressure of the loop above: that wait is as long as the device step and is not host work)
+ir = ip = 0.0
+for _ in range(N):
+    torch.cuda.synchronize()
+    a = time.perf_counter(); g.redraw(); b = time.perf_counter(); g.graph.replay(); c = time.perf_counter()
+    ir += b - a; ip += c - b
+torch.cuda.synchronize()
 # GPU time alone: replays back to back without the host work in between
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(N): g.graph.replay()
@@ -33,5 +41,6 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record()
 for _ in range(N): g.graph.replay()
 e1.record(); torch.cuda.synchronize()
+print("host work with the device idle at the start of each step: redraw %.3f ms + replay call %.3f ms" % (ir / N * 1e3, ip / N * 1e3))
 print("wall %.3f ms/step with redraw; host: redraw %.3f ms + replay call %.3f ms; replay-only wall %.3f ms; event-timed %.3f ms"
       % (wall, tr / N * 1e3, tp / N * 1e3, gpu, e0.elapsed_time(e1) / N))
