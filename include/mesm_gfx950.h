@@ -156,13 +156,6 @@ int mesm_gemm_set_switches(int32_t force_tile, int32_t bf16x);
 /* The GEMM arithmetic in force: 6 = f32 products as six bf16 matrix products over exactly split operands (the default),
  * 3 = experimental two-term split, 0 = every product on the f32 matrix instruction (what bench.py reports as `dtype`). */
 int mesm_gemm_get_bf16x(void);
-/* Persistent form of the grouped split-bf16 launch (csrc/gemm_pk.hip: a fixed grid of two workgroups per CU walks the
- * flattened (problem, tile, 128-deep reduce stage) list of a mesm_gemm_group call in equal shares; tiles cut between two
- * workgroups are completed through a workspace).  mesm_gemm_pk_status: 0 = every launch so far completed its hand-offs
- * (synchronises the device; tests).  mesm_gemm_pk_set (tuning tools): on = 0 | 1 (< 0: keep; MESM_GEMM_PK at load),
- * grid = workgroups of the persistent grid (0: keep; clamped to what the device keeps resident). */
-int mesm_gemm_pk_status(void);
-int mesm_gemm_pk_set(int32_t on, int32_t grid);
 /* Forget the pending reductions without running them (error paths: their workspaces may already be released). */
 int mesm_gemm_drop_side(void);
 

@@ -86,8 +86,6 @@ PROTOTYPES = {
     "mesm_gemm_group": (ctypes.c_int, [ctypes.POINTER(GemmArgs), _i32, c_ptr]),
     "mesm_gemm_flush_side": (ctypes.c_int, [c_ptr]),
     "mesm_gemm_get_bf16x": (ctypes.c_int, []),
-    "mesm_gemm_pk_status": (ctypes.c_int, []),
-    "mesm_gemm_pk_set": (ctypes.c_int, [_i32, _i32]),
     "mesm_gemm_set_switches": (ctypes.c_int, [_i32, _i32]),
     "mesm_gemm_drop_side": (ctypes.c_int, []),
     "mesm_gemm_tape": (ctypes.c_int, [_i32]),

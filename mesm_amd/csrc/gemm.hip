@@ -1290,10 +1290,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_wstage64_group_kernel(const 
 // anything else = exact f32
 inline int bf16x_mode() { return mesm_gemm_bf16x(); }
 int mesm_gemm_group64();
-}  // namespace
-// gemm_pk.hip
-int mesm_gemm_pk_launch(const MesmGemmArgs* list, int n, const void* side_red, hipStream_t s, int64_t* dslope_slots);
-namespace {
 
 template <int LA, int LB>
 int launch_wstage64_l(const MesmGemmArgs& a, hipStream_t s) {
@@ -1984,25 +1980,11 @@ int launch_group(const MesmGemmArgs* list, const int* vecs, int n, hipStream_t s
   g64.start[0] = 0;
   auto flush64 = [&]() {
     if (g64.n == 0) return;
-    const int bf = bf16x_mode();
-    if (bf == 6) {
-      // the persistent form (gemm_pk.hip): a fixed grid walks the flattened (problem, tile, 128-deep stage) list in
-      // equal shares; 1 = not available (first call under capture, switched off): the per-tile launch below
-      const SideRed sr = take_side(s);
-      int64_t slots[GROUP_MAX];
-      const int prc = mesm_gemm_pk_launch(g64.p, g64.n, &sr, s, slots);
-      if (prc != 1) {
-        rc = prc;
-        for (int k = 0; k < g64.n && rc == MESM_OK; ++k) rc = dslope_finish_n(g64.p[k], slots[k], s);
-        g64.n = 0;
-        return;
-      }
-      for (int i = 0; i < sr.count; ++i) g_side.push_back({sr.ws[i], sr.dst[i], sr.n[i], s});  // (hand them back)
-    }
     if (g64.n == 1) {
       rc = launch_wstage64(g64.p[0], s);
     } else {
       const SideRed sr = take_side(s);
+      const int bf = bf16x_mode();
       if (bf == 6) hipLaunchKernelGGL(gemm_wstage64_group_kernel<6>, dim3(g64.start[g64.n]), dim3(NTHREADS), 0, s, g64, sr);
       else hipLaunchKernelGGL(gemm_wstage64_group_kernel<0>, dim3(g64.start[g64.n]), dim3(NTHREADS), 0, s, g64, sr);
       rc = mesm_launch_status();

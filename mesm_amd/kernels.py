@@ -91,16 +91,6 @@ def gemm_switches(tile=None, bf16x=None):
           "mesm_gemm_set_switches")
 
 
-def gemm_pk(on=None, grid=None):
-    """tuning tools / tests: the persistent form of the grouped split-bf16 launch on / off, its grid (csrc/gemm_pk.hip)"""
-    check(lib().mesm_gemm_pk_set(-1 if on is None else int(bool(on)), 0 if grid is None else int(grid)), "mesm_gemm_pk_set")
-
-
-def gemm_pk_status():
-    """0 = every persistent launch so far completed its cross-workgroup hand-offs (synchronises the device)"""
-    return int(lib().mesm_gemm_pk_status())
-
-
 def gemm(A, B, C, *, trans_a=False, trans_b=False, A2=None, B2=None, bias=None, residual=None,
          aux=None, slope=None, dslope=None, colsum=None, a_act=ACT_NONE, b_act=ACT_NONE,
          a_drop=(0.0, 0), b_drop=(0.0, 0), e_act=ACT_NONE, e_actgrad=ACT_NONE,

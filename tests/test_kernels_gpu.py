@@ -1026,22 +1026,11 @@ def test_slope_gradient_partials_ride_in_the_next_gemm_launch():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("pk", [1, 0])
-def test_grouped_64x64_split_launch_against_fp64(pk):
-    """The production form of a GEMM call: ONE split-bf16 launch carrying a large product AND the small ones that ride
-    along -- every layout pair, partial tiles in both extents, reduce ranges with a tail, split-K with column sums,
-    bias / residual epilogues -- against fp64; as the persistent kernel of round 5 (pk = 1: gemm_pk_kernel, tiles cut
-    between workgroups) and as one workgroup per tile (pk = 0: gemm_wstage64_group_kernel)."""
+def test_grouped_64x64_split_launch_against_fp64():
+    """The production form of a GEMM call: one gemm_wstage64_group_kernel launch (split-bf16 products) carrying a
+    large product AND the small ones that ride along -- every layout pair, partial tiles in both extents, reduce ranges
+    with a tail, split-K with column sums, bias / residual epilogues -- against fp64."""
     from mesm_amd import kernels as kn
-    kn.gemm_pk(on=pk)
-    try:
-        _grouped_64x64_cases(kn)
-        assert kn.gemm_pk_status() == 0
-    finally:
-        kn.gemm_pk(on=1)
-
-
-def _grouped_64x64_cases(kn):
     for ta in (False, True):
         for tb in (False, True):
             probs = []
@@ -1073,133 +1062,3 @@ def _grouped_64x64_cases(kn):
                 if "colsum" in kw:
                     assert rel_err(kw["colsum"], A.sum(0)) < 1e-5
 
-
-# --------------------------------------------------------------------------- persistent grouped launch (round 5)
-def _pk_problem(rng, ta, tb, kind, M, N, K):
-    """one problem of a grouped call with epilogue `kind`, its fp64 reference and a checker"""
-    from mesm_amd import kernels as kn
-    sa, sb = int(rng.integers(1 << 20)), int(rng.integers(1 << 20))
-    A = gen((K, M) if ta else (M, K), sa)
-    B = gen((N, K) if tb else (K, N), sb, 0.1)
-    ref = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double())
-    kw = dict(trans_a=ta, trans_b=tb)
-    C = torch.zeros(M, N, device=dev())
-    extra = None
-    if kind == "bias_relu":
-        kw.update(bias=gen((N,), sa + 1), e_act=kn.ACT_RELU)
-        ref = torch.relu(ref + kw["bias"].double())
-    elif kind == "res":
-        kw.update(residual=gen((M, N), sa + 2), bias=gen((N,), sa + 3))
-        ref = ref + kw["residual"].double() + kw["bias"].double()
-    elif kind == "rmw":
-        C = gen((M, N), sa + 4)
-        ref = ref + C.double()
-        kw.update(accumulate=1)
-    elif kind == "atomic":
-        C = gen((M, N), sa + 5)
-        ref = ref + C.double()
-        kw.update(accumulate=2, bias=gen((N,), sa + 6))
-        ref = ref + kw["bias"].double()
-    elif kind == "splitk":
-        cs = torch.zeros(M, device=dev())
-        kw.update(split_k=int(rng.integers(2, 6)), accumulate=2, colsum=cs)
-        extra = ("colsum", cs, (A.double().t() if ta else A.double()).sum(1))
-    elif kind == "pre_prelu":
-        slope = torch.tensor([0.25], device=dev())
-        pre = torch.zeros(M, N, device=dev())
-        kw.update(bias=gen((N,), sa + 7), e_act=kn.ACT_PRELU, slope=slope, pre_out=pre)
-        z = ref + kw["bias"].double()
-        extra = ("pre", pre, z)
-        ref = torch.where(z > 0, z, 0.25 * z)
-    elif kind == "actgrad":
-        aux = gen((M, N), sa + 8)
-        slope = torch.tensor([0.25], device=dev())
-        ds = torch.zeros(1, device=dev())
-        kw.update(aux=aux, e_actgrad=kn.ACT_PRELU, slope=slope, dslope=ds)
-        extra = ("dslope", ds, (ref * aux.double() * (aux <= 0)).sum().reshape(1))
-        ref = torch.where(aux > 0, ref, 0.25 * ref)
-    return A, B, C, kw, ref, extra
-
-
-PK_KINDS = ["plain", "bias_relu", "res", "rmw", "atomic", "splitk", "pre_prelu", "actgrad"]
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(6))
-def test_persistent_grouped_launch_fuzz(seed):
-    """gemm_pk_kernel on random calls: 2-6 problems of random shapes / layouts / epilogues, at least one of them large
-    enough to open the 64 x 64 launch, under grids that cut tiles in different places (512 / 256 / 104 workgroups) --
-    every output, second output, column sum and slope gradient against fp64; the hand-off status word stays 0."""
-    import numpy as np
-    from mesm_amd import kernels as kn
-    rng = np.random.default_rng(100 + seed)
-    try:
-        for grid in (512, 256, 104):
-            kn.gemm_pk(on=1, grid=grid)
-            probs = []
-            ta, tb = bool(rng.integers(2)), bool(rng.integers(2))
-            big = [(4800, 256, 1024), (2400, 256, 2818), (4800, 1024, 256), (1024, 256, 4864), (4096, 256, 1030)][int(rng.integers(5))]
-            probs.append(_pk_problem(rng, ta, tb, PK_KINDS[int(rng.integers(len(PK_KINDS)))], *big))
-            for _ in range(int(rng.integers(1, 6))):
-                M, N, K = int(rng.integers(1, 700)), int(rng.choice([1, 2, 64, 200, 256, 258, 512])), int(rng.integers(4, 1500))
-                if rng.integers(3) == 0:
-                    K = int(rng.choice([64, 256, 512, 1024]))
-                kind = PK_KINDS[int(rng.integers(len(PK_KINDS)))]
-                probs.append(_pk_problem(rng, bool(rng.integers(2)), bool(rng.integers(2)), kind, M, N, K))
-            kn.defer_side(+1)
-            try:
-                with kn.gemm_group():
-                    for A, B, C, kw, ref, extra in probs:
-                        kn.gemm(A, B, C, **kw)
-            finally:
-                kn.defer_side(-1)
-                kn.gemm_flush_side()
-            torch.cuda.synchronize()
-            for A, B, C, kw, ref, extra in probs:
-                scale = max(float(ref.abs().max()), 1e-3)
-                err = float((C.double() - ref).abs().max()) / scale
-                assert err < 3e-6, (seed, grid, tuple(C.shape), A.shape, sorted(kw), err)
-                if extra is not None:
-                    name, got, want = extra
-                    e2 = float((got.double() - want).abs().max()) / max(float(want.abs().max()), 1e-3)
-                    assert e2 < (2e-5 if name != "pre" else 3e-6), (seed, grid, name, e2)
-            assert kn.gemm_pk_status() == 0
-    finally:
-        kn.gemm_pk(on=1, grid=512)
-
-
-@pytest.mark.gpu
-def test_persistent_launch_partials_are_never_stale():
-    """The cross-workgroup hand-off of gemm_pk_kernel under uneven load: 300 back-to-back launches of the SAME call
-    (4800 x 256 x 1024 + riders: most tiles are cut between two workgroups) whose operands ALTERNATE between two
-    data sets -- a partial tile read from the previous launch (a stale line in some L2 / L1, a flag seen early) is off by
-    O(1), the tolerance is 3e-6 -- with a second stream keeping part of the chip busy every other launch."""
-    from mesm_amd import kernels as kn
-    kn.gemm_pk(on=1, grid=512)
-    sets = []
-    for k in range(2):
-        A = gen((4800, 1024), 700 + k); B = gen((256, 1024), 710 + k, 0.1)
-        A2 = gen((300, 512), 720 + k); B2 = gen((256, 512), 730 + k, 0.1)
-        res = gen((4800, 256), 740 + k)
-        sets.append((A, B, A2, B2, res, A.double() @ B.double().t() + res.double(), A2.double() @ B2.double().t()))
-    C, C2 = torch.zeros(4800, 256, device=dev()), torch.zeros(300, 256, device=dev())
-    side = torch.cuda.Stream()
-    junk = torch.zeros(64 << 20, device=dev())
-    bad = []
-    for it in range(300):
-        A, B, A2, B2, res, ref, ref2 = sets[it & 1]
-        if it % 2 == 1:
-            with torch.cuda.stream(side):
-                junk.add_(1.0)
-        with kn.gemm_group():
-            kn.gemm(A, B, C, trans_b=True, residual=res)
-            kn.gemm(A2, B2, C2, trans_b=True)
-        if it % 25 == 24 or it < 4:
-            torch.cuda.synchronize()
-            e = float((C.double() - ref).abs().max() / ref.abs().max())
-            e2 = float((C2.double() - ref2).abs().max() / ref2.abs().max())
-            if e > 3e-6 or e2 > 3e-6:
-                bad.append((it, e, e2))
-    torch.cuda.synchronize()
-    assert not bad, bad
-    assert kn.gemm_pk_status() == 0

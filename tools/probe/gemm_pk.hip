@@ -55,6 +55,8 @@ struct PkArgs {
   MesmGemmArgs p[GROUP_MAX];
   int ustart[GROUP_MAX + 1];  // first unit of every problem
   int S[GROUP_MAX];           // units per (tile, k-slice)
+  int cut[GROUP_MAX];         // 0 = tiles stay whole, 1 = may be cut (hand-off through the workspace), 2 = atomics
+  int c0;                     // fixed cost of a tile in units (see pk_unit_begin): a run of S stages weighs S + c0
   int n;
   int W;                      // = ustart[n]
   float* ws;                  // PK_GRID_MAX slots of PK_SLOT floats
@@ -65,15 +67,48 @@ struct PkArgs {
 struct Piece {
   int gi;    // problem
   int unit;  // (k-slice, tile) index inside the problem
-  int s0;    // first stage of the piece inside its unit run
+  int s0;    // first stage of the piece inside its run
   int len;   // stages
   int S;     // stages of the whole (tile, slice)
-  int u;     // global index of the piece's first unit
+  int u;     // global index of the piece's first (weighted) unit
+  int vlen;  // weighted units the piece covers (u + vlen = the next piece)
+  int V;     // weighted units of the whole run = S + c0
+  bool whole;
 };
 
-__device__ __forceinline__ int pk_unit_begin(int pos, int W, int G) { return (int)(((int64_t)pos * W) / G); }
+// First unit of the workgroup at position pos: pos W / G, SNAPPED so that a hand-off is only ever paid where it pays.
+// Cutting a tile between two workgroups costs both of them a cross-wave reduction and -- unless the problem accumulates
+// with atomics -- a 16 KB round trip through memory on the critical path of the finisher (measured: ~6 us): worth it for
+// a tile with a long reduce range (>= PK_CUT_MIN stages) cut into pieces of >= PK_PIECE_MIN stages, not for the
+// K = 256 tiles (2 stages), which stay whole: their boundary goes to the nearer end of the tile.
+// Shares are equal in WEIGHTED units: a tile costs its workgroup a fixed ~c0 stages' worth of time whatever its reduce
+// range (first loads, cross-wave reduction, epilogue: per-tile launches of the step fit t = 7.9 us + 2.8 us x stages at
+// two workgroups per CU), so a run of S stages weighs S + c0 -- without it the workgroups that got the short-K
+// tiles of a mixed call (dX 4864 x 1024 x 256 beside its split-K dW) ran twice as long as the others.
+constexpr int PK_CUT_MIN = 8, PK_PIECE_MIN = 2;
+__device__ __forceinline__ int pk_unit_begin(const char* ka, int n, int pos, int W, int G) {
+  const int raw = (int)(((int64_t)pos * W) / G);
+  if (raw <= 0 || raw >= W) return raw < 0 ? 0 : (raw > W ? W : raw);
+  int gi = 0;
+#pragma unroll
+  for (int k = 1; k < GROUP_MAX; ++k) {
+    const int st = *reinterpret_cast<const int*>(ka + offsetof(PkArgs, ustart) + k * sizeof(int));
+    if (k < n && raw >= st) gi = k;
+  }
+  const int first = *reinterpret_cast<const int*>(ka + offsetof(PkArgs, ustart) + (size_t)gi * sizeof(int));
+  const int S = *reinterpret_cast<const int*>(ka + offsetof(PkArgs, S) + (size_t)gi * sizeof(int));
+  const int cut = *reinterpret_cast<const int*>(ka + offsetof(PkArgs, cut) + (size_t)gi * sizeof(int));
+  const int c0 = *reinterpret_cast<const int*>(ka + offsetof(PkArgs, c0));
+  const int V = S + c0;
+  const int o = (raw - first) % V, rs = raw - o;
+  if (cut == 0) return 2 * o >= V ? rs + V : rs;          // whole tiles only
+  if (o < c0 + PK_PIECE_MIN) return rs;                   // (the fixed cost goes with the piece that holds stage 0)
+  if (V - o < PK_PIECE_MIN) return rs + V;
+  return raw;
+}
 
-// the piece that starts at global unit u (u < u1 <= W)
+// the piece that starts at global (weighted) unit u (u < u1 <= W): a run of S stages occupies V = S + c0 units, the
+// first c0 of them standing for the tile's fixed cost (they belong to the piece that holds stage 0)
 __device__ __forceinline__ Piece pk_decode(const char* ka, int n, int u, int u1) {
   Piece pc;
   int gi = 0;
@@ -84,13 +119,20 @@ __device__ __forceinline__ Piece pk_decode(const char* ka, int n, int u, int u1)
   }
   const int first = *reinterpret_cast<const int*>(ka + offsetof(PkArgs, ustart) + (size_t)gi * sizeof(int));
   const int S = *reinterpret_cast<const int*>(ka + offsetof(PkArgs, S) + (size_t)gi * sizeof(int));
+  const int c0 = *reinterpret_cast<const int*>(ka + offsetof(PkArgs, c0));
+  const int V = S + c0;
   const int local = u - first;
   pc.gi = gi;
   pc.S = S;
-  pc.unit = local / S;
-  pc.s0 = local - pc.unit * S;
-  const int room = S - pc.s0, want = u1 - u;
-  pc.len = room < want ? room : want;
+  pc.V = V;
+  pc.unit = local / V;
+  const int o0 = local - pc.unit * V;
+  const int room = V - o0, want = u1 - u;
+  pc.vlen = room < want ? room : want;
+  pc.s0 = o0 > c0 ? o0 - c0 : 0;
+  const int s1 = o0 + pc.vlen > c0 ? o0 + pc.vlen - c0 : 0;
+  pc.len = s1 - pc.s0;
+  pc.whole = o0 == 0 && pc.vlen == V;
   pc.u = u;
   return pc;
 }
@@ -167,14 +209,23 @@ __device__ __forceinline__ void pk_store16(float* dst, f32x4 v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(v) : "memory");
 #endif
 }
-__device__ __forceinline__ f32x4 pk_load16_issue(const float* src) {
-  f32x4 v;
+// the four 1 KB rows a wave owns of a partial tile: issued together and WAITED FOR inside one asm statement (outputs of
+// an asm load are not ready when the statement ends; the compiler may move them before a separate s_waitcnt)
+__device__ __forceinline__ void pk_load_partial(const float* src, f32x4 (&v)[4]) {
 #if MESM_PK_FENCE
-  v = *reinterpret_cast<const f32x4*>(src);
+#pragma unroll
+  for (int r4 = 0; r4 < 4; ++r4) v[r4] = *reinterpret_cast<const f32x4*>(src + r4 * 256);
 #else
-  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(src) : "memory");
+  asm volatile(
+      "global_load_dwordx4 %0, %4, off sc0 sc1\n\t"
+      "global_load_dwordx4 %1, %4, off offset:1024 sc0 sc1\n\t"
+      "global_load_dwordx4 %2, %4, off offset:2048 sc0 sc1\n\t"
+      "global_load_dwordx4 %3, %4, off offset:3072 sc0 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+      : "v"(src)
+      : "memory");
 #endif
-  return v;
 }
 
 // One piece, start to finish.  Its stage 0 is already in flight in the slabs.  `next` (has_next) is the workgroup's
@@ -293,11 +344,11 @@ __device__ __forceinline__ void pk_piece(const char* ka, const Piece& pc, int n,
     sum[4 * r4] = t.x; sum[4 * r4 + 1] = t.y; sum[4 * r4 + 2] = t.z; sum[4 * r4 + 3] = t.w;
   }
   __syncthreads();  // the slabs are free again
-  if (pc.u + pc.len < u1) pk_issue_first(ka, pk_decode(ka, n, pc.u + pc.len, u1), mine, wave, lane);
+  if (pc.u + pc.vlen < u1) pk_issue_first(ka, pk_decode(ka, n, pc.u + pc.vlen, u1), mine, wave, lane);
 
   const float slope = pe.slope ? *pe.slope : 0.0f;
   const uint32_t seed_off = pe.seed_offset ? *pe.seed_offset : 0u;
-  const bool whole = pc.s0 == 0 && pc.len == pc.S;
+  const bool whole = pc.whole;
   if (pe.accumulate == 2 || whole) {
     // atomics: every piece adds its share (the first-split terms ride with the piece that holds reduce index 0)
     MesmGemmArgs q = pe;
@@ -324,8 +375,14 @@ __device__ __forceinline__ void pk_piece(const char* ka, const Piece& pc, int n,
     return;
   }
   // finisher: the tile's other pieces belong to the workgroups at the following positions
-  const int uend = pc.u + pc.S;  // first unit behind this (tile, slice)
-  for (int q = pos + 1; q < G && pk_unit_begin(q, W, G) < uend; ++q) {
+  const int uend = pc.u + pc.V;  // first unit behind this (tile, slice): a finisher starts at its run's first unit
+  const int n_ = *reinterpret_cast<const int*>(kb_ + offsetof(PkArgs, n));
+  int qb = pk_unit_begin(kb_, n_, pos + 1, W, G);
+  for (int q = pos + 1; q < G && qb < uend; ++q) {
+    const int qe = pk_unit_begin(kb_, n_, q + 1, W, G);
+    const bool empty = qe == qb;  // (a position whose share was snapped away owes nothing)
+    qb = qe;
+    if (empty) continue;
     unsigned* flag = flags + (size_t)q * PK_FLAG_STRIDE;
     if (tid == 0) {
       unsigned spins = 0;
@@ -344,9 +401,7 @@ __device__ __forceinline__ void pk_piece(const char* ka, const Piece& pc, int n,
     __syncthreads();
     const float* slot = ws + (size_t)q * PK_SLOT;
     f32x4 v[4];
-#pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) v[r4] = pk_load16_issue(slot + ((wave * 4 + r4) * 64 + lane) * 4);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    pk_load_partial(slot + (wave * 4 * 64 + lane) * 4, v);
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4) {
       sum[4 * r4] += v[r4].x; sum[4 * r4 + 1] += v[r4].y; sum[4 * r4 + 2] += v[r4].z; sum[4 * r4 + 3] += v[r4].w;
@@ -367,8 +422,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pk_kernel(const PkArgs g, co
   const int pos = (bid & 7) * (G >> 3) + (bid >> 3);  // an XCD's workgroups own one contiguous range (G % 8 == 0)
   const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
   const int W = g.W, n = g.n;
-  const int u1 = pk_unit_begin(pos + 1, W, G);
-  int u = pk_unit_begin(pos, W, G);
+  const int u1 = pk_unit_begin(ka, n, pos + 1, W, G);
+  int u = pk_unit_begin(ka, n, pos, W, G);
   if (u >= u1) return;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   pk_issue_first(ka, pk_decode(ka, n, u, u1), L + wave * (4 * WS_SLAB), wave, lane);
@@ -383,7 +438,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_pk_kernel(const PkArgs g, co
     else if (sel == 1) pk_piece<R, O, BF>(ka, cur, n, u1, L, sh4, pos);
     else if (sel == 2) pk_piece<O, R, BF>(ka, cur, n, u1, L, sh4, pos);
     else pk_piece<O, O, BF>(ka, cur, n, u1, L, sh4, pos);
-    u += cur.len;
+    u += cur.vlen;
   }
 }
 
@@ -401,6 +456,12 @@ PkState g_pk[16];
 int g_pk_on = []() { const char* e = getenv("MESM_GEMM_PK"); return e ? atoi(e) : 1; }();
 // MESM_GEMM_PK_GRID: workgroups of the persistent grid (default: 2 per CU)
 int g_pk_grid = []() { const char* e = getenv("MESM_GEMM_PK_GRID"); return e ? atoi(e) : 0; }();
+
+// MESM_GEMM_PK_CUT: tiles of problems with at least this many 128-deep stages may be cut between workgroups (default 8)
+int g_pk_cut_min = []() { const char* e = getenv("MESM_GEMM_PK_CUT"); return e ? atoi(e) : PK_CUT_MIN; }();
+
+// MESM_GEMM_PK_C0: fixed cost of a tile in stages (the weight of a run of S stages is S + c0)
+int g_pk_c0 = []() { const char* e = getenv("MESM_GEMM_PK_C0"); return e ? atoi(e) : 3; }();
 
 PkState* pk_state(hipStream_t s) {
   int dev = 0;
@@ -481,20 +542,25 @@ int mesm_gemm_pk_launch(const MesmGemmArgs* list, int n, const void* side_red, h
     g.p[i] = list[i];
     int64_t units = 0, slots = 0;
     pk_units(list[i], g.S[i], units, slots);
+    units = units / g.S[i] * (g.S[i] + g_pk_c0);
     if (g.ustart[i] + units > (int64_t)1 << 30) return 1;
     g.ustart[i + 1] = g.ustart[i] + (int)units;
+    g.cut[i] = list[i].accumulate == 2 ? 2 : (g.S[i] >= g_pk_cut_min ? 1 : 0);
     if (dslope_slots) dslope_slots[i] = slots;
   }
   for (int i = n; i < GROUP_MAX; ++i) {
     g.ustart[i + 1] = g.ustart[n];
     g.S[i] = 1;
+    g.cut[i] = 0;
   }
   g.W = g.ustart[n];
+  g.c0 = g_pk_c0;
   g.ws = st->ws;
   g.flags = st->flags;
   g.status = st->status;
   int grid = st->grid;
-  if (g.W < grid) grid = ((g.W + 7) & ~7) < 8 ? 8 : ((g.W + 7) & ~7);
+  const int runs_w = g.W / (1 + g_pk_c0);
+  if (runs_w < grid) grid = (runs_w & ~7) < 8 ? 8 : (runs_w & ~7);  // (no more workgroups than one-stage tiles)
   SideRed sr;
   memcpy(&sr, side_red, sizeof(sr));
   hipLaunchKernelGGL(gemm_pk_kernel<6>, dim3(grid), dim3(NTHREADS), 0, s, g, sr);
@@ -512,8 +578,10 @@ extern "C" int mesm_gemm_pk_status(void) {
 }
 
 // tuning tools: switch the persistent form on / off, set its grid (0 = keep) between calls of one process
-extern "C" int mesm_gemm_pk_set(int32_t on, int32_t grid) {
+extern "C" int mesm_gemm_pk_set(int32_t on, int32_t grid, int32_t cut_min, int32_t c0) {
   if (on >= 0) g_pk_on = on;
+  if (cut_min > 0) g_pk_cut_min = cut_min;
+  if (c0 >= 0) g_pk_c0 = c0;
   if (grid > 0) {
     g_pk_grid = grid;
     for (auto& st : g_pk)
