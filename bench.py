@@ -146,7 +146,9 @@ def _watchdog_fire():
         print(json.dumps(_WATCHDOG["line"]), flush=True)
     sys.stdout.flush()
     sys.stderr.flush()
-    os._exit(0)
+    # the `after` headline above is a complete, measured line -- but a stalled collective is NOT a clean run: leave with a
+    # non-zero status so that the launcher sees it; never restart or re-exec from here (the GPU is initialised)
+    os._exit(3)
 
 
 def ddp_diagnostics(opt, world, rank, dev, model, crit, batch, args, g_after, r_after, diag, fence, n_pairs, t_after,
@@ -172,7 +174,7 @@ def ddp_diagnostics(opt, world, rank, dev, model, crit, batch, args, g_after, r_
                        "ddp": "torch process group: one blocking all-reduce of the flat buffer after the graph replay "
                               "(own-communicator diagnostics timed out after %.0f s)" % limit,
                        "ddp_diag": dict(diag, timed_out=True)},
-            "roofline": None, "cpu_baseline": None}
+            "roofline": _WATCHDOG.get("roofline"), "cpu_baseline": _WATCHDOG.get("cpu_baseline")}
     _WATCHDOG["armed"] = True
     timer = threading.Timer(limit, _watchdog_fire)
     timer.daemon = True
@@ -259,7 +261,10 @@ def ddp_diagnostics(opt, world, rank, dev, model, crit, batch, args, g_after, r_
     timer.cancel()
     if best is None:
         _WATCHDOG["armed"] = False
-    else:  # the re-timing of the chosen form in main() stays under a fresh watchdog
+    else:  # the re-timing of the chosen form in main() stays under a fresh watchdog (its line says which form stalled)
+        if rank == 0 and _WATCHDOG["line"] is not None:
+            _WATCHDOG["line"]["config"]["ddp_diag"] = dict(diag, timed_out=True, timed_out_while="re-timing " + best)
+            _WATCHDOG["line"]["config"]["ddp_diag"].pop("_after_objs", None)
         t2 = threading.Timer(limit, _watchdog_fire)
         t2.daemon = True
         t2.start()
@@ -473,6 +478,12 @@ def main():
     t_step = dt / opt.steps
     log("timed region: %.3f ms/step" % (t_step * 1e3))
 
+    # the step-level roofline figures exist as soon as the headline does: a watchdog line (diagnostics that stall) carries them
+    _sb, _sf = step_work(opt.workload, n_pairs)
+    _WATCHDOG["roofline"] = {"bound": "mfma", "achieved": None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": None,
+                             "traffic": None, "step_hbm_frac": _sb / t_step / (PEAK_HBM_TBS * 1e12),
+                             "step_mfma_frac": _sf / t_step / (PEAK_F32_MFMA_TFLOPS * 1e12), "step_bytes": _sb, "step_flops": _sf,
+                             "note": "dominant-kernel figures and the CPU baseline are single-GPU measurements (N = 1 run)"}
     ddp_diag = None
     if not opt.eager and ddp_on:
         from mesm_amd.ddp import ranks_agree
@@ -795,6 +806,11 @@ def main():
         # still run v_mfma_f32_32x32x2_f32)
         roofline["bf16_mfma_issue"] = {"achieved_upper": 6.0 * roofline["achieved"], "peak": PEAK_BF16_MFMA_TFLOPS,
                                        "unit": "TFLOP/s", "frac_upper": 6.0 * roofline["achieved"] / PEAK_BF16_MFMA_TFLOPS}
+        # the two honest ceilings side by side: `frac` = algorithmic f32 flops / the f32 matrix peak (what an
+        # exact-f32 kernel could reach: continuity with earlier rounds); `frac_issue` = the same flops / the ceiling of a
+        # kernel that issues six bf16 products per f32 flop, 2.5 PF / 6
+        roofline["issue_peak"] = PEAK_BF16_MFMA_TFLOPS / 6.0
+        roofline["frac_issue"] = roofline["achieved"] / (PEAK_BF16_MFMA_TFLOPS / 6.0)
         roofline["arithmetic"] = ("operands split exactly into hi + mid + lo bf16 (x = hi + mid + lo), products lo*hi, hi*lo, "
                                   "mid*mid, mid*hi, hi*mid, hi*hi on v_mfma_f32_32x32x16_bf16, f32 accumulate; `achieved` / "
                                   "`frac` stay ALGORITHMIC f32 flops against the f32 MFMA peak (157.3 TF)")

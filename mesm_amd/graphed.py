@@ -345,7 +345,9 @@ class GraphedStep:
         big = prep["big"]
         for k, v in big.items():
             cur = self.batch[k]
-            if cur.shape[1:] != v.shape[1:] or v.shape[0] > cur.shape[0]:
+            # fewer rows than the static input only where the step reads the real pair count from the device (like
+            # load_batch: without it the stale rows of the previous batch would take part in the step)
+            if cur.shape[1:] != v.shape[1:] or v.shape[0] > cur.shape[0] or (v.shape[0] < cur.shape[0] and self._n_real is None):
                 raise ValueError("GraphedStep.load_prepared: %s changed shape %s -> %s" % (k, tuple(cur.shape), tuple(v.shape)))
         # nothing above modified anything; from here on: draws, copies
         self._groups, self._n_real = groups, prep["n_real"]

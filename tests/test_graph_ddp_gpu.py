@@ -416,6 +416,32 @@ def test_batches_prepared_by_loader_workers_replay_like_in_process_batches():
     assert fresh.captures == 1 and torch.isfinite(t)
 
 
+def test_a_short_prepared_batch_is_refused_without_a_device_side_pair_count():
+    """a graph captured WITHOUT a device-side pair count (pairs=None) must not accept a prepared batch whose
+    feature tensors have fewer rows than its static inputs -- the stale rows of the previous batch would take part in
+    the step -- exactly like load_batch refuses it."""
+    from mesm_amd import synthetic
+    from mesm_amd.graphed import StepCache
+    args, model, crit = _build("C2")
+    model.eval()
+    w = synthetic.WORKLOADS["C2"]
+    cache = StepCache(model, crit, args.dataset_name, pad=(w["Lv"], w["Lw"]))   # pairs=None
+    batch = synthetic.workload_batch("C2", seed=1)
+    t, gs = cache.run(batch, redraw=True)
+    assert gs._n_real is None
+    prep = cache.pipeline().prepare(batch)
+    t2, gs2 = cache.run_prepared(prep)
+    assert gs2 is gs and torch.isfinite(t2)
+    short = dict(prep)
+    short["big"] = {k: v[:-1].contiguous() for k, v in prep["big"].items()}
+    assert short["big"], "the workload's feature tensors are expected to travel as big tensors"
+    before = {k: gs.batch[k].clone() for k in short["big"]}
+    with pytest.raises(ValueError, match="changed shape"):
+        gs.load_prepared(short)
+    for k, v in before.items():
+        assert torch.equal(gs.batch[k], v), "a refused batch must not modify the static inputs"
+
+
 def test_a_late_gradient_under_capture_refuses_the_graph():
     """under capture the cross-rank late-gradient check cannot run (it needs a collective result on the
     host), so a graph captured on a batch whose contribution pattern differs from the learnt one would replay a
