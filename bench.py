@@ -577,14 +577,22 @@ def main():
     # the fallback path of ragged / unseen batch shapes before their graph exists: every launch from Python
     eager_ms = None
     if extras and not opt.eager and world == 1:
-        for _ in range(2):
-            eager_step()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(5):
-            eager_step()
-        torch.cuda.synchronize()
-        eager_ms = (time.perf_counter() - t1) / 5 * 1e3
+        # on the stream the graphs were captured on, like the warm-up steps of a capture and StepCache's first visit of a
+        # shape bucket: autograd pins every AccumulateGrad node to the stream of its first use, and eager steps on ANOTHER
+        # stream pay a cross-stream synchronisation per parameter (what rounds 3-4 reported here: 21 / 27 ms)
+        from mesm_amd.graphed import capture_stream
+        side = capture_stream(dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                eager_step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                eager_step()
+            torch.cuda.synchronize()
+            eager_ms = (time.perf_counter() - t1) / 5 * 1e3
+        torch.cuda.current_stream().wait_stream(side)
 
     roofline = {"bound": "mfma", "achieved": None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": None,
                 "traffic": None}
@@ -690,7 +698,8 @@ def main():
             tw, wk = None, min(4, max(2, host_cores() // 4))
             try:
                 from mesm_amd.loader import prepared_loader
-                ld = prepared_loader([hb for _, hb in stream_b], cache.pipeline(keep_raw=False), num_workers=wk, pin_memory=False)
+                ld = prepared_loader([hb for _, hb in stream_b], cache.pipeline(keep_raw=False), num_workers=wk, pin_memory=False,
+                                     ring=True)  # feature tensors through a shared page-locked ring, not the loader's queues
                 for prep in ld:  # first pass: workers start, pinned buffers and staging get allocated
                     cache.run_prepared(prep)
                 torch.cuda.synchronize()
@@ -729,8 +738,8 @@ def main():
                               "work in the training process; ms_per_step_replay_only_same_graphs: the same graphs replayed "
                               "without any host work (these batches average 41 pairs padded to 48 / 64 with groups of up "
                               "to 9 queries: a heavier step than the 32-pair headline); with_loader_workers: the host half "
-                              "in forked DataLoader workers (every feature tensor then crosses process boundaries through "
-                              "shared memory and the pin thread, as it does in the reference's own loader)"}
+                              "in forked DataLoader workers, feature tensors through a shared page-locked ring of host "
+                              "slots (mesm_amd/loader.py PinnedRing): only descriptors cross the process boundary"}
             del cache
         except Exception as e:
             log("loader-like section skipped: %s: %s" % (type(e).__name__, e))

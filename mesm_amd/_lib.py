@@ -205,7 +205,20 @@ def check(rc, what):
         raise MesmError("%s failed with status %d" % (what, rc))
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_dev_index = None
+
+
+def set_device_index(idx):
+    """the device the step runs on (MESM._begin): lets stream_ptr() skip torch.cuda.current_stream()'s device lookup and
+    Stream object (1.9 ms per eager step over its ~1,900 launches)"""
+    global _dev_index
+    _dev_index = None if idx is None else int(idx)
+
+
 def stream_ptr():
+    if _raw_stream is not None and _dev_index is not None:
+        return ctypes.c_void_p(_raw_stream(_dev_index))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -391,6 +391,8 @@ class GraphedStep:
             st[j][:n].copy_(v, non_blocking=True)
             done = torch.cuda.Event()
             done.record(cs)
+            from .loader import H2D_EVENTS
+            H2D_EVENTS.append(done)  # (a ring slot of loader.PinnedRing is rewritten only after the copy that read it)
         main.wait_event(done)
         cur[:n].copy_(st[j][:n], non_blocking=True)
         ev = torch.cuda.Event()

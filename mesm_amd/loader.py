@@ -12,7 +12,13 @@ process against a 4.67 ms replay.
         total, step = cache.run_prepared(prep)
 
 Workers are FORKED (no exec: the GPU box refuses an exec from a process that has initialised the GPU) and never touch
-the device; big feature tensors come back through shared memory and are pinned by the DataLoader's pin thread."""
+the device.  The big feature tensors do NOT travel through the DataLoader's queues (round 4 measured that path at 15.6 ms
+per step against 8.7 in-process: two copies and a pickle of 35 MB per batch): `prepared_loader(..., ring=True)` gives the
+workers a ring of SHARED, PAGE-LOCKED host slots (allocated before the fork, registered with the HIP runtime once) --
+a worker writes the padded features of batch i into slot i % slots and returns only a descriptor; the training process
+copies from the slot to the device asynchronously (`GraphedStep._stage_big`), the small arrays come as before."""
+import collections
+
 import numpy as np
 import torch
 
@@ -95,24 +101,115 @@ class HostPipeline:
     __call__ = prepare
 
 
+class PinnedRing:
+    """`slots` host buffers of `slot_bytes` each in ONE shared-memory allocation that forked workers inherit, page-locked
+    (cudaHostRegister: a device copy from it is asynchronous) when a GPU is present.  put(slot, {name: tensor}) copies the
+    tensors into the slot back to back and returns picklable descriptors; get(descriptors) gives zero-copy views."""
+    _DT = {"float32": torch.float32, "int64": torch.int64, "int32": torch.int32, "float16": torch.float16,
+           "uint8": torch.uint8, "bool": torch.bool, "float64": torch.float64}
+
+    def __init__(self, slot_bytes, slots, pin=True):
+        self.slot_bytes = (int(slot_bytes) + 4095) // 4096 * 4096
+        self.slots = int(slots)
+        self.buf = torch.empty(self.slot_bytes * self.slots, dtype=torch.uint8).share_memory_()
+        self.pinned = False
+        if pin and torch.cuda.is_available():
+            try:
+                rc = torch.cuda.cudart().cudaHostRegister(self.buf.data_ptr(), self.buf.numel(), 0)
+                self.pinned = int(rc) == 0
+            except Exception:  # a runtime without host registration: the ring still works, copies are synchronous
+                self.pinned = False
+
+    def put(self, slot, tensors):
+        off, desc = 0, {}
+        base = int(slot) % self.slots * self.slot_bytes
+        for k, t in tensors.items():
+            t = t.contiguous()
+            nb = t.numel() * t.element_size()
+            if off + nb > self.slot_bytes:
+                raise ValueError("PinnedRing: %s (%d bytes at offset %d) does not fit a slot of %d bytes"
+                                 % (k, nb, off, self.slot_bytes))
+            dst = self.buf[base + off:base + off + nb].view(t.dtype).view(t.shape)
+            dst.copy_(t)
+            desc[k] = ("ring", int(slot) % self.slots, off, tuple(t.shape), str(t.dtype).replace("torch.", ""))
+            off += (nb + 255) // 256 * 256
+        return desc
+
+    def get(self, desc):
+        out = {}
+        for k, d in desc.items():
+            if not (isinstance(d, tuple) and len(d) == 5 and d[0] == "ring"):
+                out[k] = d
+                continue
+            _, slot, off, shape, dt = d
+            dtype = self._DT[dt]
+            nb = int(np.prod(shape)) * torch.empty(0, dtype=dtype).element_size()
+            base = slot * self.slot_bytes + off
+            out[k] = self.buf[base:base + nb].view(dtype).view(shape)
+        return out
+
+
 class _PreparedDataset(torch.utils.data.Dataset):
     """dataset of COLLATED raw batches (what the reference's collate returns) -> prepared batches"""
 
-    def __init__(self, batches, pipeline):
-        self.batches, self.pipeline = batches, pipeline
+    def __init__(self, batches, pipeline, ring=None):
+        self.batches, self.pipeline, self.ring = batches, pipeline, ring
 
     def __len__(self):
         return len(self.batches)
 
     def __getitem__(self, i):
-        return self.pipeline.prepare(self.batches[i])
+        prep = self.pipeline.prepare(self.batches[i])
+        if self.ring is not None and prep["big"]:
+            prep["big"] = self.ring.put(i, prep["big"])   # only a descriptor travels back
+        return prep
+
+
+# events of the host -> device copies GraphedStep._stage_big issued most recently (appended there): a ring slot may be
+# rewritten only after the copy that read it has finished
+H2D_EVENTS = collections.deque(maxlen=16)
+
+
+class PreparedLoader:
+    """iterable over prepared batches; with a ring, `big` comes back as views of the ring's slots"""
+
+    def __init__(self, loader, ring, keep=2):
+        self.loader, self.ring, self.keep = loader, ring, keep
+
+    def __len__(self):
+        return len(self.loader)
+
+    def _fence(self, all_=False):
+        # the DataLoader hands index m + prefetch x workers to a worker when batch m is fetched here; the slot it will
+        # fill was read by a copy issued >= 2 batches ago (ring size, prepared_loader): wait for everything but the
+        # copies of the batch fetched last (normally finished long ago: an event query)
+        evs = list(H2D_EVENTS)
+        for ev in (evs if all_ else evs[:-self.keep]):
+            ev.synchronize()
+
+    def __iter__(self):
+        if self.ring is None:
+            yield from self.loader
+            return
+        self._fence(all_=True)  # (a new pass starts at slot 0 again)
+        it = iter(self.loader)
+        while True:
+            self._fence()
+            try:
+                prep = next(it)
+            except StopIteration:
+                return
+            if isinstance(prep.get("big"), dict):
+                prep["big"] = self.ring.get(prep["big"])
+            yield prep
 
 
 def _identity(x):
     return x
 
 
-def prepared_loader(batches, pipeline, num_workers=4, pin_memory=False, prefetch_factor=2, persistent=True):
+def prepared_loader(batches, pipeline, num_workers=4, pin_memory=False, prefetch_factor=2, persistent=True, ring=False,
+                    slot_bytes=None):
     """DataLoader over a sequence (or map-style dataset) of collated raw host batches whose workers run
     `pipeline.prepare` (forked workers).  pin_memory: have the loader's pin thread copy every tensor into pinned memory
     -- measured on the bench box (tools/loader_path_probe.py) this costs more than it saves for 35 MB feature tensors
@@ -122,6 +219,15 @@ def prepared_loader(batches, pipeline, num_workers=4, pin_memory=False, prefetch
     kw = {}
     if num_workers > 0:
         kw = dict(multiprocessing_context="fork", prefetch_factor=prefetch_factor, persistent_workers=persistent)
+    rg = None
+    if ring and num_workers > 0:
+        # ring=True: the big feature tensors through a shared page-locked ring (module docstring).  slot_bytes: what the
+        # largest prepared batch needs (default: probed on the first batch, + 25 %); slots = batches in flight + 3
+        if slot_bytes is None:
+            big = pipeline.prepare(batches[0])["big"]
+            slot_bytes = int(1.25 * sum((t.numel() * t.element_size() + 255) // 256 * 256 for t in big.values())) + 4096
+        rg = PinnedRing(slot_bytes, prefetch_factor * num_workers + 3)
     # (collate_fn = identity: the default conversion of un-batched samples would turn the key tuples into lists)
-    return torch.utils.data.DataLoader(_PreparedDataset(batches, pipeline), batch_size=None, shuffle=False,
-                                       num_workers=num_workers, pin_memory=pin_memory, collate_fn=_identity, **kw)
+    dl = torch.utils.data.DataLoader(_PreparedDataset(batches, pipeline, rg), batch_size=None, shuffle=False,
+                                     num_workers=num_workers, pin_memory=pin_memory, collate_fn=_identity, **kw)
+    return PreparedLoader(dl, rg) if rg is not None else dl

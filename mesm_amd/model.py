@@ -132,6 +132,7 @@ class MESM(nn.Module):
         self._gradbuf = None
         self._flat_params = None
         self._step = 0
+        self._flat_checked = -1
 
     # ------------------------------------------------------------------ infrastructure
     def gradbuf(self):
@@ -147,7 +148,10 @@ class MESM(nn.Module):
 
     def pack(self, key):
         """(weight, bias) views of a parameter pack in the flat parameter buffer (see gradbuf.Pack)."""
-        gb, fp = self.gradbuf(), self.flat_params()
+        gb = self.gradbuf()
+        # (the 273-parameter address check of flat_params() once per step, not once per pack: 6 packs per forward)
+        fp = self._flat_params if (self._flat_checked == self._step and self._flat_params is not None) else self.flat_params()
+        self._flat_checked = self._step
         return gb.packs[key + ".weight"].weight(fp), gb.packs[key + ".bias"].weight(fp)
 
     def flat_params(self):
@@ -177,6 +181,7 @@ class MESM(nn.Module):
             raise kn._lib.MesmError(
                 "mesm_amd.MESM runs on an MI355X only (got %s); the CPU oracle in oracle/ is a "
                 "test checker, not a fallback" % device)
+        kn._lib.set_device_index(device.index if device.index is not None else torch.cuda.current_device())
         gb = self.gradbuf()
         gb.ensure(device)
         if torch.is_grad_enabled():

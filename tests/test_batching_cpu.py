@@ -86,3 +86,32 @@ def test_arena_layout_puts_the_drawn_arrays_first_and_cpu_upload_refreshes_every
     assert torch.equal(ar.views["a"], torch.arange(5))
     with pytest.raises(ValueError):
         ar.upload(dict(arr, neg=np.arange(4, dtype=np.int64)))
+
+
+def test_loader_workers_hand_feature_tensors_over_through_the_shared_ring():
+    """loader.PinnedRing (shared host slots; page-locked when a GPU is there): batches prepared by forked DataLoader
+    workers come back with their big tensors as views of the ring, equal to what prepare() gives in-process -- over two
+    passes of more batches than the ring has slots (every slot is reused)."""
+    import torch
+    from mesm_amd import synthetic
+    from mesm_amd.hostplan import HostSpec
+    from mesm_amd.loader import HostPipeline, prepared_loader
+    args = synthetic.make_args("C2")
+    w = synthetic.WORKLOADS["C2"]
+    spec = HostSpec.from_args(args)
+    pipe = HostPipeline(spec, pad=(w["Lv"], w["Lw"]), pairs=8, group_caps=(5, 9), keep_raw=False)
+    pipe.BIG = 1 << 12   # (small synthetic features still count as "big" here)
+    batches = [synthetic.make_batch(w["dataset_name"], [2, 1, 3][: 1 + i % 3], w["Lv"], w["Lw"], 64, 32, w["vocab_size"] + 1,
+                                    seed=40 + i, ragged=True) for i in range(9)]
+    want = [pipe.prepare(b) for b in batches]
+    loader = prepared_loader(batches, pipe, num_workers=2, prefetch_factor=1, ring=True)
+    assert loader.ring.slots == 5
+    for _ in range(2):
+        got = 0
+        for prep, ref in zip(loader, want):
+            assert set(prep["big"]) == set(ref["big"]) and prep["big"]
+            for k, v in ref["big"].items():
+                assert prep["big"][k].shape == v.shape and torch.equal(prep["big"][k], v), k
+            assert prep["key"] == ref["key"] and prep["groups"] == ref["groups"]
+            got += 1
+        assert got == len(batches)

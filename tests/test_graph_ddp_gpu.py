@@ -398,8 +398,13 @@ def test_batches_prepared_by_loader_workers_replay_like_in_process_batches():
         ref.append((float(t), model.gradbuf().flat.clone(), gs))
     caps0 = cache.captures
     pipe = cache.pipeline()
-    for workers in (0, 2):
-        loader = prepared_loader(batches, pipe, num_workers=workers, pin_memory=True)
+    for workers, ring in ((0, False), (2, False), (2, True)):
+        # ring: the feature tensors through loader.PinnedRing (shared page-locked slots), two passes so that slots are reused
+        loader = prepared_loader(batches, pipe, num_workers=workers, pin_memory=not ring, ring=ring)
+        if ring:
+            assert loader.ring.pinned, "the ring could not be page-locked"
+            for prep in loader:
+                pass
         for i, prep in enumerate(loader):
             torch.manual_seed(50 + i); np.random.seed(50 + i)
             t, gs = cache.run_prepared(prep)
