@@ -93,10 +93,26 @@ class HostPipeline:
         arr, pmeta, tmeta, wm = self.spec.host_arrays(host, groups, caps, n_real, neg0, mw0, self.BIG)
         big = {k: batch[k].contiguous() for k in ("video_feat", "words_id")
                if batch[k].numel() * batch[k].element_size() > self.BIG}
+        # the ~35 small arrays travel as NUMPY arrays: pickled by value into the loader's pipe (57 KB in all), where torch
+        # tensors would each go through a shared-memory file descriptor (~3 ms per batch on the receiving side)
         return {"key": key, "spec": self.spec, "groups": groups, "n_real": n_real, "caps": caps,
-                "arr": {k: torch.from_numpy(np.array(v, copy=True, order="C")) for k, v in arr.items()},
+                "arr": {k: np.array(v, copy=True, order="C") for k, v in arr.items()},
                 "pmeta": pmeta, "tmeta": tmeta, "wm": wm, "big": big, "num_clips": batch["num_clips"],
                 "words_weight": batch.get("words_weight"), "raw": raw if self.keep_raw else None}
+
+    def big_bytes(self, raw):
+        """ring-slot bytes the big tensors of `raw` need once prepared (shapes only, nothing is copied)"""
+        n = raw["video_feat"].shape[0]
+        if self.pairs:
+            n = _round_up(n, self.pairs)
+        tot = 0
+        for k, L in (("video_feat", self.pad[0] if self.pad else None), ("words_id", self.pad[1] if self.pad else None)):
+            t = raw[k]
+            ext = max(t.shape[1], L) if (L is not None and t.dim() >= 2) else (t.shape[1] if t.dim() >= 2 else 1)
+            nb = n * ext * int(np.prod(t.shape[2:])) * t.element_size()
+            if nb > self.BIG:
+                tot += (nb + 255) // 256 * 256
+        return tot
 
     __call__ = prepare
 
@@ -162,6 +178,9 @@ class _PreparedDataset(torch.utils.data.Dataset):
         prep = self.pipeline.prepare(self.batches[i])
         if self.ring is not None and prep["big"]:
             prep["big"] = self.ring.put(i, prep["big"])   # only a descriptor travels back
+            for k in ("wm", "num_clips", "words_weight"):  # small tensors by value as well (re-wrapped on arrival)
+                if torch.is_tensor(prep.get(k)):
+                    prep[k] = ("np", prep[k].numpy())
         return prep
 
 
@@ -201,6 +220,10 @@ class PreparedLoader:
                 return
             if isinstance(prep.get("big"), dict):
                 prep["big"] = self.ring.get(prep["big"])
+            for k in ("wm", "num_clips", "words_weight"):
+                v = prep.get(k)
+                if isinstance(v, tuple) and len(v) == 2 and v[0] == "np":
+                    prep[k] = torch.from_numpy(v[1])
             yield prep
 
 
@@ -224,8 +247,10 @@ def prepared_loader(batches, pipeline, num_workers=4, pin_memory=False, prefetch
         # ring=True: the big feature tensors through a shared page-locked ring (module docstring).  slot_bytes: what the
         # largest prepared batch needs (default: probed on the first batch, + 25 %); slots = batches in flight + 3
         if slot_bytes is None:
-            big = pipeline.prepare(batches[0])["big"]
-            slot_bytes = int(1.25 * sum((t.numel() * t.element_size() + 255) // 256 * 256 for t in big.values())) + 4096
+            if not isinstance(batches, (list, tuple)):
+                raise ValueError("prepared_loader(ring=True): pass slot_bytes (the largest batch's big tensors, "
+                                 "HostPipeline.big_bytes) for a dataset that is not a list of collated batches")
+            slot_bytes = max(pipeline.big_bytes(b) for b in batches) + 4096
         rg = PinnedRing(slot_bytes, prefetch_factor * num_workers + 3)
     # (collate_fn = identity: the default conversion of un-batched samples would turn the key tuples into lists)
     dl = torch.utils.data.DataLoader(_PreparedDataset(batches, pipeline, rg), batch_size=None, shuffle=False,

@@ -146,6 +146,15 @@ class MESM(nn.Module):
             self._gradbuf = GradBuffer([(n, p) for n, p in self.named_parameters() if p.requires_grad], packs)
         return self._gradbuf
 
+    def zero_grad(self, set_to_none=True):
+        """nn.Module.zero_grad for the trainable parameters the flat gradient buffer knows (the frozen text encoder never
+        gets gradients): the module-tree walk of the stock method costs 0.8 ms per eager step over 273 parameters"""
+        gb = self._gradbuf
+        if not set_to_none or gb is None:
+            return super().zero_grad(set_to_none=set_to_none)
+        for p in gb.params:
+            p.grad = None
+
     def pack(self, key):
         """(weight, bias) views of a parameter pack in the flat parameter buffer (see gradbuf.Pack)."""
         gb = self.gradbuf()
