@@ -634,6 +634,9 @@ int mesm_gather_rows_bwd(const float* dy, const float* y, const float* rnorm, co
                          const uint8_t* valid, float* dx, int64_t src_rows, int32_t D, int32_t normalize,
                          void* stream);
 int mesm_add_wrap(const float* a, const float* b, float* out, int64_t n, int64_t nb, void* stream);
+/* out[i] = srcs[0][i] + ... + srcs[k - 1][i], 1 <= k <= 8, n % 4 == 0, 16-byte aligned: the gradient of a tensor with
+ * several consumers in one launch (mesm_amd.ops.fork) instead of the autograd engine's k - 1 pairwise adds. */
+int mesm_add_n(const float* const* srcs, int32_t k, float* out, int64_t n, void* stream);
 /* First node of a captured training step (no counterpart in the reference: its forward draws on the host and indexes
  * with host tensors, model.py:260, 361-384): copies slot (*pull_ctr % slots) of a ring of `slots` x slot_bytes in PINNED
  * HOST memory (device-readable) to dst, then *pull_ctr += 1 and, when given, *seed_ctr += 1 (the dropout seed offset of

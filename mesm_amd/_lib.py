@@ -153,6 +153,7 @@ PROTOTYPES = {
     "mesm_gather_rows_fwd": (ctypes.c_int, [c_ptr] * 5 + [_i64, _i32, _i32, c_ptr]),
     "mesm_gather_rows_bwd": (ctypes.c_int, [c_ptr] * 6 + [_i64, _i32, _i32, c_ptr]),
     "mesm_add_wrap": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, _i64, _i64, c_ptr]),
+    "mesm_add_n": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), _i32, c_ptr, _i64, c_ptr]),
     "mesm_step_begin": (ctypes.c_int, [c_ptr, _i32, _i32, c_ptr, c_ptr, c_ptr, c_ptr]),
     "mesm_skinny_linear_bwd": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, _i64, _i32, _i32, _i32, c_ptr]),
     "mesm_clip_embed": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, _i64, _i32, _i32, _i32, c_ptr]),

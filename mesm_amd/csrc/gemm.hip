@@ -1851,7 +1851,9 @@ int dispatch(const MesmGemmArgs& a, int vec, hipStream_t s) {
     // experimental split-bf16 mode: the 64 x 64-per-wave kernel is the one that carries it (the split costs VALU per
     // fragment value, amortised over four products there) -- every problem of >= 2400 output rows or reduce indices
     // with enough tiles goes there, whatever its round count
-    if (force == 0 && bf16x_mode() != 0 && wstage_ok(a) && b64 >= 128 && (a.M >= 2400 || a.K >= 2400) &&
+    // (... or >= 512 tiles whatever the extents: the 1024 x 5003 x 256 vocabulary head used to fall through to the
+    // exact-f32 64 x 64 ring, 37 us; the split kernel takes its 1,264 tiles in 28)
+    if (force == 0 && bf16x_mode() != 0 && wstage_ok(a) && b64 >= 128 && (a.M >= 2400 || a.K >= 2400 || b64 >= 512) &&
         a.a_act == MESM_ACT_NONE && a.b_act == MESM_ACT_NONE && a.a_drop_p == 0.f && a.b_drop_p == 0.f)
       return launch_wstage64(a, s);
     if ((force == 3 || (force == 0 && b64 >= 512)) && wstage_ok(a)) return launch_lds64(a, s);
@@ -1912,9 +1914,11 @@ int prepare(MesmGemmArgs& a, int& vec) {
 bool groupable(const MesmGemmArgs& a) {
   const int force = g_force_tile;
   if (force != 0 && force != 2) return false;
-  if (force == 0 && bf16x_mode() != 0 && (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * (a.split_k > 1 ? a.split_k : 1) >= 128 &&
-      (a.M >= 2400 || a.K >= 2400))
-    return false;  // experimental mode: goes to the split-bf16 kernel on its own
+  {
+    const long b64g = (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * (a.split_k > 1 ? a.split_k : 1);
+    if (force == 0 && bf16x_mode() != 0 && b64g >= 128 && (a.M >= 2400 || a.K >= 2400 || b64g >= 512))
+      return false;  // split mode: goes to the split-bf16 kernel on its own
+  }
   const long z = a.split_k > 1 ? a.split_k : 1;
   const long b64 = (long)((a.M + 63) / 64) * ((a.N + 63) / 64) * z;
   const long kper = ((a.K + z - 1) / z + 3) / 4;

@@ -336,6 +336,25 @@ __global__ __launch_bounds__(256) void add_wrap_kernel(const float* __restrict__
   }
 }
 
+// out = src[0] + ... + src[k - 1], k <= 8 (one float4 per thread): the gradient of a tensor with several consumers in ONE
+// launch instead of the autograd engine's k - 1 pairwise adds (a decoder layer's output feeds the box head, the next
+// layer's anchor / scale heads, the final norm and the next layer twice: transformer.py:370-394)
+struct AddNSrc {
+  const float* p[8];
+};
+__global__ __launch_bounds__(256) void add_n_kernel(const AddNSrc s, int k, float* __restrict__ out, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 t = reinterpret_cast<const float4*>(s.p[0])[i];
+#pragma unroll
+    for (int j = 1; j < 8; ++j)
+      if (j < k) {
+        const float4 u = reinterpret_cast<const float4*>(s.p[j])[i];
+        t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      }
+    reinterpret_cast<float4*>(out)[i] = t;
+  }
+}
+
 // First node of a captured step: the step's host draws come from a ring of `slots` buffers in PINNED HOST memory
 // (read over the host link by this kernel: ~1 KB) instead of a host-to-device copy between two graph replays (a copy
 // on the stream between two graph launches cost ~50 us of idle queue per step, tools/host_cost.py), and the dropout
@@ -468,6 +487,22 @@ extern "C" int mesm_skinny_linear_bwd(const float* dz, const float* x, const flo
   if (rb > 0x7fffffff) return MESM_EINVAL;
   hipLaunchKernelGGL(skinny_linear_bwd_kernel, dim3((unsigned)rb, (unsigned)((K + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, dz, x, w, dx, dw, db, M, K, J, relu_mask);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_add_n(const float* const* srcs, int32_t k, float* out, int64_t n, void* stream) {
+  if (!srcs || !out || k < 1 || k > 8 || n <= 0 || (n & 3)) return MESM_EINVAL;
+  AddNSrc s = {};
+  uintptr_t al = (uintptr_t)out;
+  for (int j = 0; j < k; ++j) {
+    if (!srcs[j]) return MESM_EINVAL;
+    s.p[j] = srcs[j];
+    al |= (uintptr_t)srcs[j];
+  }
+  if (al & 15) return MESM_EALIGN;
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(add_n_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, s, (int)k, out, n / 4);
   return mesm_launch_status();
 }
 

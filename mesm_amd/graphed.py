@@ -125,6 +125,7 @@ class GraphedStep:
         self.dev = dev
         self.batch = dict(batch)  # static inputs: big tensors as given, everything small re-homed in the arena
         self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._seed = {}
         self.reducer = reducer
         # the step is captured in the model's CURRENT mode (train(): dropout on, fresh masks every replay;
         # eval(): dropout off, e.g. to reproduce a recorded step) -- like the reference's loop, which calls
@@ -238,10 +239,11 @@ class GraphedStep:
         # a hooked reducer launches its bucket collectives from inside and joins at the end; with fold_scale the
         # 1 / world of the gradient MEAN rides the loss gradient (one scalar) instead of a pass over the flat buffer
         sc = self.reducer.backward_scale() if self.reducer is not None else 1.0
-        if sc != 1.0:
-            total.backward(torch.full_like(total, sc))
-        else:
-            total.backward()
+        # the seed of the backward pass from a tensor made once (autograd's own ones_like is a fill launch per step)
+        seed = self._seed.get(sc)
+        if seed is None or seed.shape != total.shape:
+            seed = self._seed[sc] = torch.full_like(total, sc)
+        total.backward(seed)
         return total.detach(), {k: v.detach() for k, v in losses.items()}
 
     # ------------------------------------------------------------------ new batch, same graph

@@ -955,6 +955,16 @@ def step_begin(ring, slot_bytes, slots, dst, pull_ctr, seed_ctr=None):
                                 ptr(seed_ctr) if seed_ctr is not None else None, stream_ptr()), "mesm_step_begin")
 
 
+def add_n(ts):
+    """sum of 1-8 contiguous fp32 tensors of one shape, one launch"""
+    require_gpu(*ts)
+    assert 1 <= len(ts) <= 8 and all(t.is_contiguous() and t.shape == ts[0].shape and t.dtype == torch.float32 for t in ts)
+    out = torch.empty_like(ts[0])
+    arr = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
+    check(lib().mesm_add_n(arr, len(ts), ptr(out), out.numel(), stream_ptr()), "mesm_add_n")
+    return out
+
+
 def add_wrap(a, b):
     """a + b with b repeated along dim 0 (a.numel() a multiple of b.numel())."""
     require_gpu(a, b)

@@ -307,7 +307,7 @@ class DecoderLayer(nn.Module):
              "sa_p": ("sa_qpos_proj", "sa_kpos_proj"),
              "ca_kv": ("ca_kcontent_proj", "ca_v_proj")}
 
-    def steps(self, tgt, memory, mem_pad, pos, query_pos, qsine, is_first, pack, mem_share=None):
+    def steps(self, tgt, memory, mem_pad, pos, query_pos, qsine, is_first, pack, mem_share=None, tgt_res=None):
         """The layer as a chain (ops.lockstep).  pack(key) -> (weight, bias) views of a parameter pack of THIS layer
         (MESM.pack).  The query-side position projections of the cross attention do not depend on the self-attention
         block: they fork beside it."""
@@ -320,7 +320,8 @@ class DecoderLayer(nn.Module):
             L(qsine, self.ca_qpos_sine_proj.weight, self.ca_qpos_sine_proj.bias),
             L(query_pos, self.ca_qpos_proj.weight, self.ca_qpos_proj.bias) if is_first else None]
         so = self.self_attn.out_proj
-        x = yield L(a, so.weight, so.bias, residual=tgt, out_drop=drop_state.next(self.p))
+        # (tgt_res: a second alias of tgt for the residual route, ops.fork: its gradient joins the others' in one launch)
+        x = yield L(a, so.weight, so.bias, residual=tgt if tgt_res is None else tgt_res, out_drop=drop_state.next(self.p))
         tgt = yield ops.layer_norm_call(x, self.norm1.weight, self.norm1.bias)
         wkv, bkv = pack("ca_kv")
         a = yield ops.dec_cross_attn_call(tgt, qs, qpp, memory, pos, mem_pad, self.ca_qcontent_proj.weight,
@@ -380,15 +381,21 @@ class Decoder(nn.Module):
         scale = None
         # every layer reads the same memory: their d memory shares are summed by the dX GEMMs' epilogues
         mem_share = ops.GradShare(nl) if (nl > 1 and torch.is_grad_enabled() and memory.requires_grad) else None
+        out_res = None
         for li, layer in enumerate(self.layers):
             # qsine * query_scale(out) * (sigmoid(ref_anchor_head(out)) / ref_width): one kernel
             qsine = ops.qsine_scale(qsine, scale, anchor, ref)
             out = yield from layer.steps(out, memory, mem_pad, pos, query_pos, qsine, li == 0,
-                                         lambda key, li=li: pack("dec%d.%s" % (li, key)), mem_share=mem_share)
-            heads = [(self.bbox_embed, out)]
+                                         lambda key, li=li: pack("dec%d.%s" % (li, key)), mem_share=mem_share,
+                                         tgt_res=out_res)
+            # a layer's output has up to six consumers (box head, final norm, the next layer's anchor / scale heads, the
+            # next layer's self-attention and its residual): their gradients meet in one launch (ops.fork)
+            o_box, o_norm, o_anchor, o_scale, o_next, out_res = ops.fork(out, 6) if li + 1 < nl else (out,) * 6
+            heads = [(self.bbox_embed, o_box)]
             if li + 1 < nl:
-                heads += [(self.ref_anchor_head, out), (self.query_scale, out)]
-            res, ex = yield from mlp_heads_steps(heads, extra=[ops.layer_norm_call(out, self.norm.weight, self.norm.bias)])
+                heads += [(self.ref_anchor_head, o_anchor), (self.query_scale, o_scale)]
+            res, ex = yield from mlp_heads_steps(heads, extra=[ops.layer_norm_call(o_norm, self.norm.weight, self.norm.bias)])
+            out = o_next
             inter.append(ex[0])
             # sigmoid(bbox_embed(out) + inverse_sigmoid(ref)): one kernel
             new_ref = ops.ref_update(res[0], ref)

@@ -421,6 +421,37 @@ def run(call):
     return call.post(o) if call.post is not None else o
 
 
+# ----------------------------------------------------------------------------- fork (n-ary gradient fan-in)
+class ForkFn(Function):
+    """x -> n aliases of x for n consumers; the backward sums the gradients that arrive in ONE launch (kn.add_n) where
+    the autograd engine would add them pairwise, n - 1 element-wise launches (19 fan-in adds per step, four in
+    a row on the decoder's query tensor)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        live = [_c(g) for g in gs if g is not None]
+        if not live:
+            return None, None
+        if len(live) == 1:
+            return live[0], None
+        while len(live) > 8:
+            live = [kn.add_n(live[:8])] + live[8:]
+        return (kn.add_n(live) if live[0].numel() % 4 == 0 and all(t.data_ptr() % 16 == 0 for t in live)
+                else torch.stack(live).sum(0)), None
+
+
+def fork(x, n):
+    """n aliases of x whose gradients are summed by one launch; x itself when nothing is to be gained"""
+    if n < 3 or not (torch.is_grad_enabled() and x.requires_grad):
+        return (x,) * n
+    return ForkFn.apply(x, n)
+
+
 # ----------------------------------------------------------------------------- Linear
 class LinearBlock:
     """y = dropout_out( relu?( dropout_in(x [+ x2]) @ W[rows]^T + b[rows] ) ) [+ residual].
