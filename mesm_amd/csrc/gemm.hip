@@ -1291,6 +1291,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_wstage64_group_kernel(const 
 inline int bf16x_mode() { return mesm_gemm_bf16x(); }
 int mesm_gemm_group64();
 
+
 template <int LA, int LB>
 int launch_wstage64_l(const MesmGemmArgs& a, hipStream_t s) {
   dim3 grid(((a.M + 63) / 64) * ((a.N + 63) / 64), 1, a.split_k > 1 ? a.split_k : 1);  // 1-D: xcd_tile() maps it
