@@ -33,10 +33,11 @@ for w in C2 C3b C5; do python3 bench.py --workload $w --steps 10 --warmup 3 --cp
 python3 tools/ln_bench.py > $out/ln_bench.txt 2>&1
 python3 tools/branch_cost.py > $out/branch_cost.txt 2>&1
 python3 tools/bf16x_check.py > $out/bf16x_check.txt 2>&1
-python3 tools/w64_probe.py > $out/w64_probe.txt 2>&1
 python3 tools/gemm_plan.py 2> $out/gemm_plan.txt > /dev/null
 python3 tools/host_cost.py > $out/host_cost.txt 2>&1
 python3 tools/tape_profile.py > $out/tape_profile.txt 2>&1
 python3 tools/aten_origin.py > $out/aten_origin.txt 2>&1
+python3 tools/eager_profile.py > $out/eager_profile.txt 2>&1
+[ -d ab_r4 ] && tools/ab3.sh "ab_r4 ." 3 > $out/ab_vs_r4.txt 2>&1
 find $out -type f | xargs ls -la | head -40
 du -sh $out

@@ -2,7 +2,7 @@
 wire time?  (a) no reducer; (b) bucket all-reduces captured inside the step graph on the collective stream;
 (c) one all-reduce of the flat gradient buffer after the replay."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
 import torch

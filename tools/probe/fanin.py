@@ -1,7 +1,7 @@
 """Which tensors of the step have several consumers in the autograd graph (= gradient fan-in adds by the engine):
 producer node, output index, shape, consumers."""
 import collections, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from mesm_amd import build_criterion, build_model, synthetic

@@ -2,7 +2,7 @@
 nodes between fork and join?  Main chain: NM small GEMMs; side branch: NS GEMMs forked after main node f and
 joined after main node j."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from mesm_amd import kernels as kn
 

@@ -1,7 +1,7 @@
 """Localise a backward discrepancy of one fuzz case: the same configuration with one loss weight at a time (the others 0),
 worst gradient distances from the fp64 oracle.  usage: fuzz_localize.py <case> <seed>"""
 import os, random, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 import fuzz_parity as F

@@ -1,7 +1,7 @@
 """Bisect a failing fuzz case by configuration: the case with one setting changed at a time, worst gradient distance
 from the fp64 oracle.  usage: fuzz_vary.py <case> <seed>"""
 import os, random, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 import fuzz_parity as F

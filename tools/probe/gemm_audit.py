@@ -1,7 +1,7 @@
 """Audit every GEMM of one fuzz-case step against an fp64 torch evaluation of the same call (operands kept alive until
 the step is over): finds the launch whose result is off.  usage: gemm_audit.py <case> <seed> [only_loss_coef]"""
 import os, random, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 import fuzz_parity as F

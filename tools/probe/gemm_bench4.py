@@ -2,7 +2,7 @@
 rotating operand sets (so operands are not L2-hot from the previous launch), replayed 20 x.
 Columns: auto dispatch | frag kernel | staged 32 / 64 / 128 tiles.   us per launch."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from mesm_amd import kernels as kn
 dev = torch.device("cuda:0")

@@ -1,7 +1,7 @@
 """Sweep one GEMM shape over forced kernels and split-k factors (captured chain of 32 launches over 8
 rotating operand sets, like gemm_bench4).  usage: gemm_sweep.py M N K ta tb "splits" "tiles" [acc]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from mesm_amd import kernels as kn
 dev = torch.device("cuda:0")

@@ -1,7 +1,7 @@
 """which single-block autograd nodes of a step receive MATERIALISED zero gradients (autograd fills one tensor per output
 that nothing reached: an element-wise launch each) -- python tools/grad_target_debug.py"""
 import os, sys, collections
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from mesm_amd import build_criterion, build_model, synthetic, ops
 dev = torch.device("cuda:0")

@@ -1,5 +1,5 @@
 import sys, os, random
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); 
 import torch
 from mesm_amd import kernels as kn
 dev = torch.device("cuda:0")

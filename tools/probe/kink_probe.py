@@ -2,7 +2,7 @@
 (the second output of the FFN's first GEMM) against the fp64 oracle's: elements whose SIGN differs.
 usage: kink_probe.py <case> <seed>"""
 import os, random, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 import fuzz_parity as F

@@ -2,7 +2,7 @@
 run with MESM_LIB_PATH=mesm_amd/variants/libmesm_trace.so; MESM_GEMM_TILE=3 (default) stamps the lds64 kernel,
 MESM_GEMM_TILE=2 the wstage kernel, whose stamp slots have the same meaning).  usage: l64_trace.py M N K ta tb [split]"""
 import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ.setdefault("MESM_GEMM_TILE", "3")
 import numpy as np
 import torch

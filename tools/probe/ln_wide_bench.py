@@ -1,7 +1,7 @@
 """The input LayerNorm of the feature projections (2400 x 2818 QVHighlights, 8192 x 4098 TACoS): forward with / without
 the fused dropout, parameter-gradient backward; us per launch and effective TB/s."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from mesm_amd import kernels as kn
 dev = torch.device("cuda:0")

@@ -1,7 +1,7 @@
 """Where the loader-worker path's time goes (bench.py's loader-like stream): per-batch times of worker prepare, the pin
 thread, load_prepared, replay; variants: workers 0 / 2 / 4, pin on / off."""
 import os, random, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from mesm_amd import build_criterion, build_model, synthetic

@@ -1,6 +1,6 @@
 """Host-side profile of the loader-like stream of bench.py (StepCache over batches from host memory)."""
 import cProfile, pstats, random, sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from mesm_amd import build_criterion, build_model, synthetic

@@ -2,7 +2,7 @@
 v_mfma_f32_32x32x16_bf16 (production) vs v_mfma_f32_16x16x32_bf16 (MESM_GEMM_MF16 / mesm_gemm_set_mf16): error against
 fp64 on every layout pair (with tails, split-K + column sums, epilogues) and time per launch on the step's large shapes."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from mesm_amd import kernels as kn

@@ -3,7 +3,7 @@ call of the step's tape timed ALONE (mesm_gemm_tape_entry, its own grouping and 
 (one workgroup per tile: gemm_wstage64_group_kernel) and on, at the given grids.
 usage: pk_ab.py [workload] [grid:cut_min[:c0] ...]   (default: 512:8 512:2)"""
 import ctypes, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from mesm_amd import build_criterion, build_model, synthetic, kernels as kn

@@ -1,6 +1,6 @@
 """which problem of tests/test_kernels_gpu.py::test_gemm_group_matches_individual_launches differs under the persistent launch"""
 import os, sys, random
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from mesm_amd import kernels as kn

@@ -1,7 +1,7 @@
 """Probe: do parallel branches of a captured HIP graph run concurrently on gfx950 / ROCm 7.2, and
 what does a fork/join pair cost?  Workload: 64 launches of the 2400x256x256 forward GEMM."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from mesm_amd import kernels as kn
 

@@ -1,7 +1,7 @@
 """Probe: per-node cost of a 500-GEMM linear graph alone, next to a second busy queue, and with a fork inside,
 under whatever HIP runtime knobs the environment sets (see tools/queue_probe.sh)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from mesm_amd import kernels as kn
 

@@ -1,6 +1,6 @@
 """cProfile of GraphedStep.redraw() (the host work of a replayed step) with the GPU idle and busy."""
 import cProfile, os, pstats, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 from mesm_amd import build_criterion, build_model, synthetic

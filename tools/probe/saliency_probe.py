@@ -1,6 +1,6 @@
 """saliency loss kernels against the oracle's autograd on the inputs of a dumped fuzz case (scores random or given)"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 from mesm_amd import kernels as kn, synthetic

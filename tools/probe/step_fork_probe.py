@@ -2,7 +2,7 @@
 with a side stream forked at its start and joined at its end; the side branch runs n small independent GEMMs
 (320 x 256 x 256, ~4.5 us each when serial).  n = -1: no fork at all.  usage: step_fork_probe.py "-1,0,1,50,150" """
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from mesm_amd import build_criterion, build_model, synthetic, kernels as kn
 from mesm_amd.graphed import GraphedStep

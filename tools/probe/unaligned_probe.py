@@ -2,7 +2,7 @@
 forced kernel.  (The experiment that removed the alignment rule from wstage_ok: 78 -> 51 us at Dv = 2818.)
 usage: unaligned_probe.py [M N ld K]   (operands are [:, :K] views of ld-wide matrices)"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from mesm_amd import kernels as kn
 dev = torch.device("cuda:0")

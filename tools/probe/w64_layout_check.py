@@ -1,6 +1,6 @@
 """forced k-split 64 x 64 kernel on every layout pair against fp64 (debugging aid for its load addressing)"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from mesm_amd import kernels as kn
 dev = torch.device("cuda:0")

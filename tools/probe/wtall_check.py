@@ -1,7 +1,7 @@
 """Forced-kernel check of the tall-tile GEMM (MESM_GEMM_TILE=5 / 6) against the default dispatch on the same
 arguments, then timings of the step's tall shapes.  usage: wtall_check.py [check] [time]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from mesm_amd import kernels as kn
 dev = torch.device("cuda:0")
