@@ -532,14 +532,13 @@ class LinearBlock:
 # A/B switch: MESM_SKINNY_BWD=0 sends the 1-4 feature heads' backward through the GEMM entry again
 SKINNY_BWD = os.environ.get("MESM_SKINNY_BWD", "1") != "0"
 
-# Test switch (tests/test_model_gpu.py, kink control run): drop every ReLU of the Linear blocks so that the
-# full-width gradient comparison with the oracle has no activation kinks to flip.  Never set in production.
-TEST_NO_RELU = False
+# set only by mesm_amd.testing.no_relu() (a context manager for the kink control run of tests/test_model_gpu.py)
+_NO_RELU = False
 
 
 def linear_call(x, w, b, *, x2=None, residual=None, rows=None, relu=False, in_drop=NO_DROP,
                 out_drop=NO_DROP):
-    if TEST_NO_RELU:
+    if _NO_RELU:
         relu = False
     sink = _sink_for(out_drop)
     rsink = ReluSink() if (relu and out_drop[0] == 0.0 and residual is None) else None

@@ -56,7 +56,7 @@ def _l2norm(x, eps):
     return x / x.norm(dim=-1, keepdim=True).clamp_min(eps)
 
 
-# Test switch mirrored by mesm_amd.ops.TEST_NO_RELU: the kink control run of tests/test_model_gpu.py.
+# Test switch mirrored by mesm_amd.testing.no_relu(): the kink control run of tests/test_model_gpu.py.
 NO_RELU = False
 
 

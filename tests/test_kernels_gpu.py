@@ -1062,3 +1062,57 @@ def test_grouped_64x64_split_launch_against_fp64():
                 if "colsum" in kw:
                     assert rel_err(kw["colsum"], A.sum(0)) < 1e-5
 
+
+
+@pytest.mark.gpu
+def test_split_bf16_products_keep_non_finite_operands_non_finite():
+    """the three-term split computes x - hi(x), so an operand of +/-inf turns into NaN inside the split (inf - inf)
+    where the f32 matrix instruction and torch give +/-inf; a NaN operand stays NaN.  What is promised (and documented in
+    DESIGN.md section 4): the result is NON-FINITE exactly where the f32 product is non-finite, finite and accurate
+    everywhere else -- a diverged activation cannot come out of a GEMM looking healthy."""
+    from mesm_amd import kernels as kn
+    M, N, K = 4800, 256, 256   # takes the split-bf16 64 x 64 kernel
+    A = gen((M, K), 901)
+    B = gen((N, K), 902, 0.1)
+    A[7, 13] = float("inf")
+    A[100, 200] = float("-inf")
+    A[4000, 0] = float("nan")
+    B[5, 77] = float("inf")
+    C = torch.zeros(M, N, device=dev())
+    kn.gemm(A, B, C, trans_b=True)
+    torch.cuda.synchronize()
+    ref = A.double() @ B.double().t()
+    bad_ref = ~torch.isfinite(ref)
+    bad = ~torch.isfinite(C)
+    assert torch.equal(bad, bad_ref), (int(bad.sum()), int(bad_ref.sum()))
+    assert int(bad.sum()) >= 3 * N + M - 3   # rows 7, 100, 4000 and column 5
+    ok = ~bad_ref
+    assert float((C.double() - ref)[ok].abs().max()) / float(ref[ok].abs().max()) < 2e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [1, 2, 5, 8])
+def test_add_n_sums_up_to_eight_tensors_in_one_launch(k):
+    from mesm_amd import kernels as kn
+    ts = [gen((32, 10, 256), 950 + i) for i in range(k)]
+    out = kn.add_n(ts)
+    want = torch.stack(ts).double().sum(0)
+    assert rel_err(out, want) < 1e-6
+
+
+@pytest.mark.gpu
+def test_fork_sums_the_consumers_gradients_like_autograd_does():
+    """ops.fork: n aliases of a tensor whose gradients meet in ONE launch (mesm_add_n) -- same values as the autograd
+    engine's pairwise adds, None gradients (an alias nobody used) skipped, fewer than three consumers left to autograd."""
+    from mesm_amd import ops
+    x = gen((32, 10, 256), 960).requires_grad_(True)
+    ws = [gen((32, 10, 256), 961 + i) for i in range(5)]
+    a = ops.fork(x, 6)
+    assert len(a) == 6 and all(t.data_ptr() == x.data_ptr() for t in a)
+    loss = sum((a[i] * ws[i]).sum() for i in range(5))   # the sixth alias stays unused
+    loss.backward()
+    x2 = x.detach().clone().requires_grad_(True)
+    sum((x2 * ws[i]).sum() for i in range(5)).backward()
+    assert rel_err(x.grad, x2.grad) < 1e-6
+    y = gen((4, 8), 970).requires_grad_(True)
+    assert all(t is y for t in ops.fork(y, 2))            # nothing to gain: no node

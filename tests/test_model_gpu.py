@@ -279,10 +279,10 @@ def test_full_size_workload_against_cpu_oracle(workload):
 
 def test_full_width_gradients_are_tight_without_activation_kinks():
     """Control run for the loose full-width gradient bound above: the same C3a step with
-    every PReLU slope = 1 and every ReLU bypassed (test switches mesm_amd.ops.TEST_NO_RELU / oracle NO_RELU)
+    every PReLU slope = 1 and every ReLU bypassed (mesm_amd.testing.no_relu() / the oracle's NO_RELU)
     has no activation kink to flip, and then EVERY parameter gradient must sit within 5e-4 (max norm) of the
     oracle's.  If this held only with the loose bound there would be a defect in a backward kernel."""
-    from mesm_amd import build_criterion, build_model, ops, synthetic
+    from mesm_amd import build_criterion, build_model, synthetic, testing
     from oracle import mesm_oracle as O
     args = synthetic.make_args("C3a", device="cuda:0")
     torch.manual_seed(1234)
@@ -294,13 +294,14 @@ def test_full_width_gradients_are_tight_without_activation_kinks():
     crit = build_criterion(args)
     batch = synthetic.workload_batch("C3a", seed=0)
     neg, masked = synthetic.host_draws(batch, seed=0)
-    ops.TEST_NO_RELU = O.NO_RELU = True
+    O.NO_RELU = True
     try:
-        out, losses, total = run_step(model, crit, batch, vars(args), neg, masked)
+        with testing.no_relu():
+            out, losses, total = run_step(model, crit, batch, vars(args), neg, masked)
         sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
         o_out, o_losses, o_total, o_grads, o_idx = O.train_step(sd, dict(vars(args)), batch, neg, masked)
     finally:
-        ops.TEST_NO_RELU = O.NO_RELU = False
+        O.NO_RELU = False
     assert abs(float(total) - float(o_total)) < TOL * max(1.0, abs(float(o_total)))
     worst = max((rel(p.grad, o_grads[n]), n) for n, p in model.named_parameters() if n in o_grads)
     assert worst[0] < 5e-4, worst
