@@ -311,6 +311,8 @@ def main():
     batch = synthetic.to_device(batch_cpu, dev)
     n_pairs = batch_cpu["video_feat"].shape[0]
     torch.manual_seed(99 + rank)  # per-rank host-RNG streams (negatives, MLM words), SURVEY 8e
+    import numpy as _np
+    _np.random.seed(99 + rank)    # (the vectorized draws read numpy's global stream, mesm_amd/draws.py)
 
     def eager_step():
         out = model(**batch, dataset_name=args.dataset_name, is_training=True)
