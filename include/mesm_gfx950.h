@@ -580,6 +580,63 @@ int mesm_weighted_sum(const float* vals, const float* weights, int32_t n, float*
                       void* stream);
 int mesm_scale_vec(const float* g, const float* weights, int32_t n, float* out, void* stream);
 
+/*
+ * The whole criterion backward (criterion.py:319-367, the autograd of every loss of the step) as ONE launch: the
+ * gradient kernels of the set losses (one per decoder layer), the saliency loss, the masked-LM NLL and rec_ss are
+ * independent 256-thread kernels and run as workgroup ranges of one grid.  g_total = d total (1 float), weights = the loss
+ * vector's weights (the `*_slot` fields index it: a role multiplies g_total by its own weight, mesm_scale_vec is folded in);
+ * the NLL's per-row weights (mesm_rec_fw_rowgrad) are computed in place from words_mask.  A block with its `*_on` flag 0 (or
+ * n_set = 0) is skipped.  Field meanings as in mesm_set_loss_bwd_nv / mesm_saliency_loss_bwd_nv / mesm_nll_smooth_bwd /
+ * mesm_rec_ss_bwd_nv.
+ */
+typedef struct MesmCritBwd {
+  const float* g_total;
+  const float* weights;
+  const int32_t* n_valid; /* device scalar: real pairs of a padded batch, or NULL */
+  int32_t N, Q;           /* pairs, moment queries */
+  int32_t n_set;          /* set-loss layers (<= 8) */
+  float eos_coef;
+  const float* tgt_cxw;
+  const float* tgt_xx;
+  const int32_t* tgt_off;
+  const float* set_logits[8];
+  const float* set_spans[8];
+  const int32_t* set_match[8];
+  float* set_dlogits[8];
+  float* set_dspans[8];
+  int32_t set_slot[8];
+  int32_t sal_on, sal_L, sal_P, sal_slot;
+  float rank_coef, margin;
+  const float* s_pos;
+  const float* s_neg;
+  const double* sal_label;
+  const uint8_t* vmask;
+  const int64_t* pos_idx;
+  const int64_t* neg_idx;
+  float* ds_pos;
+  float* ds_neg;
+  int32_t fw_on, fw_Lw, fw_C, fw_slot;
+  float fw_eps;
+  int32_t reserved0;
+  const float* logit;
+  const int64_t* label;
+  const float* row_lse;
+  const uint8_t* words_mask;
+  float* dlogit;
+  int32_t ss_on, ss_D, ss_Lv, ss_Le, ss_slot;
+  float ss_tau;
+  const float* cn;
+  const float* wn;
+  const uint8_t* ss_pos;
+  const float* sim;
+  const float* stats;
+  const uint8_t* cmask;
+  const uint8_t* wmask;
+  float* dpv;
+  float* dew;
+} MesmCritBwd;
+int mesm_criterion_bwd(const MesmCritBwd* args, void* stream);
+
 /* ------------------------------------------------------------------------- */
 /*
  * Assembly kernels of MESM.forward (csrc/glue.hip): the concatenations, repeats, selections and masked

@@ -77,6 +77,27 @@ class LnArgs(ctypes.Structure):
     ]
 
 
+class CritBwdArgs(ctypes.Structure):
+    _fields_ = [
+        ("g_total", c_ptr), ("weights", c_ptr), ("n_valid", c_ptr),
+        ("N", ctypes.c_int32), ("Q", ctypes.c_int32), ("n_set", ctypes.c_int32), ("eos_coef", ctypes.c_float),
+        ("tgt_cxw", c_ptr), ("tgt_xx", c_ptr), ("tgt_off", c_ptr),
+        ("set_logits", c_ptr * 8), ("set_spans", c_ptr * 8), ("set_match", c_ptr * 8),
+        ("set_dlogits", c_ptr * 8), ("set_dspans", c_ptr * 8), ("set_slot", ctypes.c_int32 * 8),
+        ("sal_on", ctypes.c_int32), ("sal_L", ctypes.c_int32), ("sal_P", ctypes.c_int32), ("sal_slot", ctypes.c_int32),
+        ("rank_coef", ctypes.c_float), ("margin", ctypes.c_float),
+        ("s_pos", c_ptr), ("s_neg", c_ptr), ("sal_label", c_ptr), ("vmask", c_ptr), ("pos_idx", c_ptr), ("neg_idx", c_ptr),
+        ("ds_pos", c_ptr), ("ds_neg", c_ptr),
+        ("fw_on", ctypes.c_int32), ("fw_Lw", ctypes.c_int32), ("fw_C", ctypes.c_int32), ("fw_slot", ctypes.c_int32),
+        ("fw_eps", ctypes.c_float), ("reserved0", ctypes.c_int32),
+        ("logit", c_ptr), ("label", c_ptr), ("row_lse", c_ptr), ("words_mask", c_ptr), ("dlogit", c_ptr),
+        ("ss_on", ctypes.c_int32), ("ss_D", ctypes.c_int32), ("ss_Lv", ctypes.c_int32), ("ss_Le", ctypes.c_int32),
+        ("ss_slot", ctypes.c_int32), ("ss_tau", ctypes.c_float),
+        ("cn", c_ptr), ("wn", c_ptr), ("ss_pos", c_ptr), ("sim", c_ptr), ("stats", c_ptr), ("cmask", c_ptr), ("wmask", c_ptr),
+        ("dpv", c_ptr), ("dew", c_ptr),
+    ]
+
+
 # name -> (restype, argtypes); mirrors include/mesm_gfx950.h one to one.
 _i32, _i64, _f32, _u32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_uint32
 PROTOTYPES = {
@@ -179,6 +200,7 @@ PROTOTYPES = {
     "mesm_ddp_last_error": (ctypes.c_char_p, []),
     "mesm_weighted_sum": (ctypes.c_int, [c_ptr, c_ptr, _i32, c_ptr, c_ptr]),
     "mesm_scale_vec": (ctypes.c_int, [c_ptr, c_ptr, _i32, c_ptr, c_ptr]),
+    "mesm_criterion_bwd": (ctypes.c_int, [ctypes.POINTER(CritBwdArgs), c_ptr]),
 }
 
 _lib = None

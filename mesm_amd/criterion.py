@@ -133,8 +133,8 @@ class _Spec:
 
 class CriterionFn(Function):
     """(total, loss_vector) = criterion(model outputs).  Forward: one launch per loss block writing
-    straight into its slots of the loss vector + one weighted sum.  Backward: one launch that
-    turns d total into per-slot scales, then one launch per block."""
+    straight into its slots of the loss vector + one weighted sum.  Backward: ONE launch, the blocks'
+    gradient kernels as workgroup ranges of one grid (mesm_criterion_bwd)."""
 
     @staticmethod
     def forward(ctx, spec, *t):
@@ -197,14 +197,16 @@ class CriterionFn(Function):
         c, plan = spec.crit, spec.plan
         grads = [None] * ctx.n_in
         g = g_total.reshape(1).to(torch.float32).contiguous()
-        gv = kn.scale_vec(g, spec.wv)
+        N = None
         stacked = {}
+        blocks = {}
+        lay = []
         for li, (il, isp, slot, k) in enumerate(spec.set_layers):
             logits, spans, mq = saved["set%d" % li]
+            N, Q = logits.shape[0], logits.shape[1]
             if k is None:
-                grads[il], grads[isp] = kn.set_loss_bwd(logits, spans, plan.tgt_cxw, plan.tgt_xx,
-                                                        plan.tgt_off, mq, c.eos_coef, gv[slot:slot + 3],
-                                                        n_valid=spec.n_valid)
+                grads[il], grads[isp] = torch.empty_like(logits), torch.empty_like(spans)
+                lay.append((logits, spans, mq, grads[il], grads[isp], slot))
                 continue
             # every layer writes its slice of ONE gradient of the stacked tensor: no select / stack backward
             # launches.  Layers of the stack the criterion does not read (aux_loss off) keep a zero slice.
@@ -213,33 +215,46 @@ class CriterionFn(Function):
                 stacked[il] = ((torch.empty_like if full else torch.zeros_like)(spec.stack_base[0]),
                                (torch.empty_like if full else torch.zeros_like)(spec.stack_base[1]))
                 grads[il], grads[isp] = stacked[il]
-            kn.set_loss_bwd(logits, spans, plan.tgt_cxw, plan.tgt_xx, plan.tgt_off, mq, c.eos_coef,
-                            gv[slot:slot + 3], out=(stacked[il][0][k], stacked[il][1][k]), n_valid=spec.n_valid)
+            lay.append((logits, spans, mq, stacked[il][0][k], stacked[il][1][k], slot))
+        for i0 in range(0, len(lay), 8):  # (one launch holds 8 layers)
+            part = dict(Q=Q, eos_coef=c.eos_coef, tgt_cxw=plan.tgt_cxw, tgt_xx=plan.tgt_xx, tgt_off=plan.tgt_off,
+                        layers=lay[i0:i0 + 8])
+            if i0 + 8 < len(lay):
+                kn.criterion_bwd(g, spec.wv, N, n_valid=spec.n_valid, set_losses=part)
+            else:
+                blocks["set_losses"] = part
         if spec.sal is not None:
             ip, ineg, slot = spec.sal
             sp, sn = saved["sal"]
+            N = sp.shape[0]
             if ineg is None:
-                ds = torch.empty(2 * sp.shape[0], sp.shape[1], device=sp.device, dtype=torch.float32)
-                kn.saliency_loss_bwd(sp, sn, spec.sal_label, spec.vmask, spec.pos_idx, spec.neg_idx,
-                                     float(c.rank_coef), float(c.saliency_margin), gv[slot:slot + 1],
-                                     out=(ds[:sp.shape[0]], ds[sp.shape[0]:]), n_valid=spec.n_valid)
+                ds = torch.empty(2 * N, sp.shape[1], device=sp.device, dtype=torch.float32)
                 grads[ip] = ds
+                dsp, dsn = ds[:N], ds[N:]
             else:
-                grads[ip], grads[ineg] = kn.saliency_loss_bwd(
-                    sp, sn, spec.sal_label, spec.vmask, spec.pos_idx, spec.neg_idx, float(c.rank_coef),
-                    float(c.saliency_margin), gv[slot:slot + 1], n_valid=spec.n_valid)
+                dsp, dsn = torch.empty_like(sp), torch.empty_like(sn)
+                grads[ip], grads[ineg] = dsp, dsn
+            blocks["sal"] = dict(s_pos=sp, s_neg=sn, label=spec.sal_label, vmask=spec.vmask, pos_idx=spec.pos_idx,
+                                 neg_idx=spec.neg_idx, rank_coef=c.rank_coef, margin=c.saliency_margin, ds_pos=dsp,
+                                 ds_neg=dsn, slot=slot)
         if spec.recfw is not None:
             il, slot = spec.recfw
             logit, row_lse = saved["recfw"]
-            C = logit.shape[-1]
-            rg = kn.rec_fw_rowgrad(spec.words_mask, gv[slot:slot + 1], n_valid=spec.n_valid)
-            grads[il] = kn.nll_smooth_bwd(logit.view(-1, C), spec.words_label, row_lse, rg, 0.1).view(logit.shape)
+            N = logit.shape[0]
+            grads[il] = torch.empty_like(logit)
+            blocks["recfw"] = dict(logit=logit, label=spec.words_label, row_lse=row_lse, mask=spec.words_mask, eps=0.1,
+                                   dlogit=grads[il], slot=slot)
         if spec.recss is not None:
             ipv, iew, slot = spec.recss
             Lv, Le = saved["recss_shape"]
-            grads[ipv], grads[iew] = kn.rec_ss_bwd(saved["recss"], plan.ss_pos, spec.clip_mask,
-                                                   spec.ewords_mask, Lv, Le, c.recss_tau,
-                                                   gv[slot:slot + 1], n_valid=spec.n_valid)
+            cn = saved["recss"][0]
+            N, D = cn.shape
+            grads[ipv] = torch.empty(N, Lv, D, device=cn.device, dtype=torch.float32)
+            grads[iew] = torch.empty(N, Le, D, device=cn.device, dtype=torch.float32)
+            blocks["recss"] = dict(saved=saved["recss"], pos=plan.ss_pos, cmask=spec.clip_mask, wmask=spec.ewords_mask,
+                                   Lv=Lv, Le=Le, tau=c.recss_tau, dpv=grads[ipv], dew=grads[iew], slot=slot)
+        if blocks:
+            kn.criterion_bwd(g, spec.wv, N, n_valid=spec.n_valid, **blocks)
         return (None,) + tuple(grads)
 
 

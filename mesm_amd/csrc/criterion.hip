@@ -11,6 +11,7 @@
 //   text prep  : post_process_text (model.py:145-152)
 //   wsum       : total = sum_k w_k * loss_k (criterion.py:361-365)
 #include "common.hpp"
+#include "loss_bodies.hpp"
 
 namespace {
 
@@ -276,13 +277,13 @@ __global__ void set_loss_fwd_layers_kernel(const SetLossLayers L, const float* _
   set_loss_fwd_body(lg, sp, tgt_cxw, tgt_xx, tgt_off, N, Q, Tmax, w_span, w_giou, w_class, eos_coef, P, mq, out, n_valid);
 }
 
-// one thread per (pair, query): g = upstream gradient of [loss_span, loss_giou, loss_label, *]
-__global__ __launch_bounds__(256) void set_loss_bwd_kernel(
+// one thread per (pair, query): g_span / g_giou / g_label = upstream gradients of loss_span, loss_giou, loss_label
+__device__ __forceinline__ void set_loss_bwd_body(
     const float* __restrict__ logits, const float* __restrict__ spans, const float* __restrict__ tgt_cxw,
     const float* __restrict__ tgt_xx, const int32_t* __restrict__ tgt_off,
-    const int32_t* __restrict__ match_q, int N, int Q, float eos_coef, const float* __restrict__ g,
-    float* __restrict__ dlogits, float* __restrict__ dspans, const int32_t* __restrict__ n_valid) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int32_t* __restrict__ match_q, int N, int Q, float eos_coef, float g_span, float g_giou, float g_label,
+    float* __restrict__ dlogits, float* __restrict__ dspans, const int32_t* __restrict__ n_valid, int bid) {
+  const int i = bid * blockDim.x + threadIdx.x;
   const int Ncap = N;
   if (n_valid) N = *n_valid;  // padding pairs: zero gradients, and out of every denominator
   // matched (query, target) pairs of the batch = sum_b min(T_b, Q): the denominators of the span terms
@@ -308,7 +309,7 @@ __global__ __launch_bounds__(256) void set_loss_bwd_kernel(
   const float mx = fmaxf(l0, l1);
   const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
   const float p0 = e0 / (e0 + e1), p1 = e1 / (e0 + e1);
-  const float gl = g[2] / (float)(N * Q) * (t >= 0 ? 1.0f : eos_coef);
+  const float gl = g_label / (float)(N * Q) * (t >= 0 ? 1.0f : eos_coef);
   // d(-logp[cls])/dl_c = p_c - [c == cls]
   dlogits[(int64_t)i * 2] = gl * (p0 - (t >= 0 ? 1.0f : 0.0f));
   dlogits[(int64_t)i * 2 + 1] = gl * (p1 - (t >= 0 ? 0.0f : 1.0f));
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(256) void set_loss_bwd_kernel(
   if (t >= 0) {
     const float cx = spans[(int64_t)i * 2], w = spans[(int64_t)i * 2 + 1];
     const float tc = tgt_cxw[(int64_t)t * 2], tw = tgt_cxw[(int64_t)t * 2 + 1];
-    const float ks = g[0] / (2.0f * sumT);
+    const float ks = g_span / (2.0f * sumT);
     const float a = cx - tc, c = w - tw;
     dcx += ks * (a > 0.0f ? 1.0f : (a < 0.0f ? -1.0f : 0.0f));
     dw += ks * (c > 0.0f ? 1.0f : (c < 0.0f ? -1.0f : 0.0f));
@@ -334,12 +335,21 @@ __global__ __launch_bounds__(256) void set_loss_bwd_kernel(
     const float iu2 = 1.0f / (s.uni * s.uni), ie2 = 1.0f / (s.enc * s.enc);
     const float dL2 = -(dI2 * s.uni - s.inter * dU2) * iu2 - (dU2 * s.enc - s.uni * dE2) * ie2;
     const float dL1 = -(dI1 * s.uni - s.inter * dU1) * iu2 - (dU1 * s.enc - s.uni * dE1) * ie2;
-    const float kg = g[1] / sumT;
+    const float kg = g_giou / sumT;
     dcx += kg * (dL1 + dL2);
     dw += kg * 0.5f * (dL2 - dL1);
   }
   dspans[(int64_t)i * 2] = dcx;
   dspans[(int64_t)i * 2 + 1] = dw;
+}
+
+__global__ __launch_bounds__(256) void set_loss_bwd_kernel(
+    const float* __restrict__ logits, const float* __restrict__ spans, const float* __restrict__ tgt_cxw,
+    const float* __restrict__ tgt_xx, const int32_t* __restrict__ tgt_off,
+    const int32_t* __restrict__ match_q, int N, int Q, float eos_coef, const float* __restrict__ g,
+    float* __restrict__ dlogits, float* __restrict__ dspans, const int32_t* __restrict__ n_valid) {
+  set_loss_bwd_body(logits, spans, tgt_cxw, tgt_xx, tgt_off, match_q, N, Q, eos_coef, g[0], g[1], g[2], dlogits, dspans, n_valid,
+                    blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -505,18 +515,18 @@ __global__ __launch_bounds__(64) void ss_reduce_kernel(const float* __restrict__
 // Backward, one workgroup per pair n: rebuild dsim (N x N) in LDS from the saved sim, then
 // d cn[n] = dsim[n,:] wn / tau, d wn[n] = dsim[:,n]^T cn / tau, through the L2 normalisation and the
 // masked means into d projed_video_feat[n] (Lv, D) and d expanded_words_feat[n] (Le, D).
-__global__ __launch_bounds__(256) void ss_bwd_kernel(
+__device__ __forceinline__ void ss_bwd_body(
     const float* __restrict__ cn, const float* __restrict__ wn, const uint8_t* __restrict__ pos,
     const float* __restrict__ sim, const float* __restrict__ stats, const uint8_t* __restrict__ cmask,
     const uint8_t* __restrict__ wmask, int N, int D, int Lv, int Le, float inv_tau,
-    const float* __restrict__ g, float* __restrict__ dpv, float* __restrict__ dew, const int32_t* __restrict__ n_valid) {
+    float g0, float* __restrict__ dpv, float* __restrict__ dew, const int32_t* __restrict__ n_valid, int bid) {
   // dynamic LDS: dsim (ld rows of ld + 1 floats: lane = row accesses stay conflict-free), staged with sim and turned into
   // d sim in place | the positive mask (bytes) | the pair's clip / word masks.  Everything a thread then loops over comes
   // from LDS: the loops below used to be chains of dependent global loads (one row of sim per thread, one mask byte per
   // output row): 38 us for 2.4 MB of output.
   extern __shared__ float dsim[];
   __shared__ float sh[8];
-  const int n = blockIdx.x;
+  const int n = bid;
   const int ld = N;  // row stride of sim / pos: the allocated extent
   const int lp = ld + 1;
   float* cmL = dsim + ld * lp;  // Lv
@@ -524,7 +534,6 @@ __global__ __launch_bounds__(256) void ss_bwd_kernel(
   uint8_t* posL = reinterpret_cast<uint8_t*>(wmL + Le);  // ld * ld
   // everything this workgroup reads from memory besides wn / cn of the other pairs is requested up front, four
   // elements of sim / pos per thread at a time: taken one by one inside the loops these were a dozen round trips
-  const float g0 = g[0];
   const int nv = n_valid ? *n_valid : N;
   const float ccnt = stats[n * 4 + 0], wcnt = stats[n * 4 + 1];
   const float cnorm = stats[n * 4 + 2], wnorm = stats[n * 4 + 3];
@@ -667,6 +676,60 @@ __global__ __launch_bounds__(256) void ss_bwd_kernel(
       const int c = threadIdx.x + j * 256;
       if (c < D) r[c] = m * dw[j];
     }
+  }
+}
+
+__global__ __launch_bounds__(256) void ss_bwd_kernel(
+    const float* __restrict__ cn, const float* __restrict__ wn, const uint8_t* __restrict__ pos,
+    const float* __restrict__ sim, const float* __restrict__ stats, const uint8_t* __restrict__ cmask,
+    const uint8_t* __restrict__ wmask, int N, int D, int Lv, int Le, float inv_tau,
+    const float* __restrict__ g, float* __restrict__ dpv, float* __restrict__ dew, const int32_t* __restrict__ n_valid) {
+  ss_bwd_body(cn, wn, pos, sim, stats, cmask, wmask, N, D, Lv, Le, inv_tau, g[0], dpv, dew, n_valid, blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------
+// The whole criterion backward as ONE launch (round 5): its kernels are independent of each other -- each reads d total,
+// its loss weight and what the forward saved, and writes its own gradient tensors -- and every one of them is a 256-thread
+// kernel, so their workgroups share a grid: [set-loss layers | saliency | masked-LM NLL | rec_ss], a role per range of
+// block indices.  What used to be separate launches in front of them is folded in: the scale vector d total x weight
+// (each role multiplies its own) and the per-row weights of the NLL (mask / (N x words of the pair), a 32-byte count per
+// workgroup).  7 launches -> 1; the launch lasts as long as its longest role (rec_ss, ~17 us).
+template <int NE>
+__global__ __launch_bounds__(256) void crit_bwd_kernel(const MesmCritBwd a, const int4 r0, const int4 r1) {
+  extern __shared__ float dyn_[];  // (ss_bwd_body's dsim: the same dynamic segment)
+  const int bid = blockIdx.x;
+  const float gt = a.g_total[0];
+  // role starts: r0 = (set layers end, saliency end, nll end, ss end); r1.x = workgroups per set layer, r1.y = nll column groups
+  if (bid < r0.x) {
+    const int l = bid / r1.x, b = bid - l * r1.x;
+    const float* w = a.weights + a.set_slot[l];
+    set_loss_bwd_body(a.set_logits[l], a.set_spans[l], a.tgt_cxw, a.tgt_xx, a.tgt_off, a.set_match[l], a.N, a.Q, a.eos_coef,
+                      gt * w[0], gt * w[1], gt * w[2], a.set_dlogits[l], a.set_dspans[l], a.n_valid, b);
+  } else if (bid < r0.y) {
+    saliency_bwd_body<NE>(a.s_pos, a.s_neg, a.sal_label, a.vmask, a.pos_idx, a.neg_idx, a.N, a.sal_L, a.sal_P, a.rank_coef,
+                          a.margin, gt * a.weights[a.sal_slot], a.ds_pos, a.ds_neg, a.n_valid, bid - r0.x);
+  } else if (bid < r0.z) {
+    const int b = bid - r0.y;
+    const int64_t r = b / r1.y;
+    const int by = b - (int)r * r1.y;
+    // row weight g x mask / (N x valid words of the row's pair) (criterion.py:293-299; recfw_rowgrad_kernel)
+    __shared__ float sh_cnt;
+    const int n = (int)(r / a.fw_Lw);
+    int Nv = a.N;
+    if (a.n_valid) Nv = *a.n_valid;
+    if (threadIdx.x < 64) {
+      float c = 0.0f;
+      for (int w = threadIdx.x; w < a.fw_Lw; w += 64) c += a.words_mask[(int64_t)n * a.fw_Lw + w] ? 1.0f : 0.0f;
+      c = wave_sum(c);
+      if (threadIdx.x == 0) sh_cnt = c;
+    }
+    __syncthreads();
+    float g = 0.0f;
+    if (n < Nv && a.words_mask[r]) g = gt * a.weights[a.fw_slot] / ((float)Nv * sh_cnt);
+    nll_bwd_body(a.logit, a.label, a.row_lse, g, a.dlogit, a.fw_C, a.fw_eps, r, by, r1.y);
+  } else {
+    ss_bwd_body(a.cn, a.wn, a.ss_pos, a.sim, a.stats, a.cmask, a.wmask, a.N, a.ss_D, a.ss_Lv, a.ss_Le, 1.0f / a.ss_tau,
+                gt * a.weights[a.ss_slot], a.dpv, a.dew, a.n_valid, bid - r0.z);
   }
 }
 
@@ -972,6 +1035,55 @@ extern "C" int mesm_rec_ss_bwd(const float* cn, const float* wn, const uint8_t* 
                                int32_t N, int32_t D, int32_t Lv, int32_t Le, float tau, const float* g,
                                float* dpv, float* dew, void* stream) {
   return mesm_rec_ss_bwd_nv(cn, wn, pos, sim, stats, cmask, wmask, N, D, Lv, Le, tau, g, dpv, dew, nullptr, stream);
+}
+
+extern "C" int mesm_criterion_bwd(const MesmCritBwd* args, void* stream) {
+  if (!args) return MESM_EINVAL;
+  const MesmCritBwd& a = *args;
+  if (!a.g_total || !a.weights || a.N <= 0) return MESM_EINVAL;
+  if (a.n_set < 0 || a.n_set > 8) return MESM_EINVAL;
+  int per_layer = 0;
+  if (a.n_set > 0) {
+    if (a.Q <= 0 || !a.tgt_cxw || !a.tgt_xx || !a.tgt_off) return MESM_EINVAL;
+    for (int l = 0; l < a.n_set; ++l)
+      if (!a.set_logits[l] || !a.set_spans[l] || !a.set_match[l] || !a.set_dlogits[l] || !a.set_dspans[l]) return MESM_EINVAL;
+    per_layer = (a.N * a.Q + 255) / 256;
+  }
+  int4 r0, r1;
+  r0.x = a.n_set * per_layer;
+  r1.x = per_layer > 0 ? per_layer : 1;
+  int sal_blocks = 0;
+  if (a.sal_on) {
+    if (!a.s_pos || !a.s_neg || !a.sal_label || !a.vmask || !a.ds_pos || !a.ds_neg || a.sal_L <= 0 || 2 * a.sal_L > 64 * SAL_MAXE ||
+        (a.sal_P > 0 && (!a.pos_idx || !a.neg_idx)))
+      return MESM_EINVAL;
+    sal_blocks = (a.N + 3) / 4;
+  }
+  r0.y = r0.x + sal_blocks;
+  int gy = 1;
+  int64_t nll_blocks = 0;
+  if (a.fw_on) {
+    if (!a.logit || !a.label || !a.row_lse || !a.words_mask || !a.dlogit || a.fw_Lw <= 0 || a.fw_C <= 0) return MESM_EINVAL;
+    gy = (a.fw_C + 1023) / 1024;
+    nll_blocks = (int64_t)a.N * a.fw_Lw * gy;
+    if (nll_blocks > (1 << 30)) return MESM_EINVAL;
+  }
+  r1.y = gy;
+  r0.z = r0.y + (int)nll_blocks;
+  size_t lds = 0;
+  if (a.ss_on) {
+    if (!a.cn || !a.wn || !a.ss_pos || !a.sim || !a.stats || !a.cmask || !a.wmask || !a.dpv || !a.dew) return MESM_EINVAL;
+    lds = ((size_t)a.N * (a.N + 1) + a.ss_Lv + a.ss_Le) * 4 + (size_t)a.N * a.N;
+    if (lds > 64 * 1024 || a.ss_D <= 0 || a.ss_D > 1024 || a.ss_tau <= 0.f) return MESM_EINVAL;
+  }
+  r0.w = r0.z + (a.ss_on ? a.N : 0);
+  r1.z = r1.w = 0;
+  if (r0.w <= 0) return MESM_OK;
+  if (a.sal_on && 2 * a.sal_L > 256)
+    hipLaunchKernelGGL(crit_bwd_kernel<SAL_MAXE>, dim3(r0.w), dim3(256), lds, (hipStream_t)stream, a, r0, r1);
+  else
+    hipLaunchKernelGGL(crit_bwd_kernel<4>, dim3(r0.w), dim3(256), lds, (hipStream_t)stream, a, r0, r1);
+  return mesm_launch_status();
 }
 
 extern "C" int mesm_rec_fw_reduce_nv(const float* row_loss, const uint8_t* correct, const uint8_t* mask,

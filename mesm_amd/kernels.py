@@ -838,6 +838,47 @@ def scale_vec(g, weights):
     return out
 
 
+def criterion_bwd(g_total, weights, N, n_valid=None, set_losses=None, sal=None, recfw=None, recss=None):
+    """The criterion's whole backward as one launch (mesm_criterion_bwd): each block multiplies d total by its own weight.
+    set_losses: dict(Q, eos_coef, tgt_cxw, tgt_xx, tgt_off, layers=[(logits, spans, match_q, dlogits, dspans, slot)]);
+    sal: dict(s_pos, s_neg, label, vmask, pos_idx, neg_idx, rank_coef, margin, ds_pos, ds_neg, slot);
+    recfw: dict(logit (N, Lw, C), label, row_lse, mask (N, Lw), eps, dlogit, slot);
+    recss: dict(saved=(cn, wn, stats, sim), pos, cmask, wmask, Lv, Le, tau, dpv, dew, slot)."""
+    require_gpu(g_total, weights)
+    a = _lib.CritBwdArgs()
+    a.g_total, a.weights, a.n_valid, a.N = ptr(g_total), ptr(weights), ptr(n_valid), N
+    keep = []
+    if set_losses:
+        lay = set_losses["layers"]
+        assert 0 < len(lay) <= 8
+        a.Q, a.n_set, a.eos_coef = set_losses["Q"], len(lay), float(set_losses["eos_coef"])
+        a.tgt_cxw, a.tgt_xx, a.tgt_off = ptr(set_losses["tgt_cxw"]), ptr(set_losses["tgt_xx"]), ptr(set_losses["tgt_off"])
+        for l, (lg, sp, mq, dl, dsp, slot) in enumerate(lay):
+            assert lg.is_contiguous() and sp.is_contiguous() and dl.is_contiguous() and dsp.is_contiguous()
+            a.set_logits[l], a.set_spans[l], a.set_match[l] = ptr(lg), ptr(sp), ptr(mq)
+            a.set_dlogits[l], a.set_dspans[l], a.set_slot[l] = ptr(dl), ptr(dsp), slot
+    if sal:
+        N_, L = sal["s_pos"].shape
+        assert sal["ds_pos"].is_contiguous() and sal["ds_neg"].is_contiguous()
+        a.sal_on, a.sal_L, a.sal_slot = 1, L, sal["slot"]
+        a.sal_P = sal["pos_idx"].shape[1] if sal["pos_idx"] is not None else 0
+        a.rank_coef, a.margin = float(sal["rank_coef"]), float(sal["margin"])
+        a.s_pos, a.s_neg, a.sal_label, a.vmask = ptr(sal["s_pos"]), ptr(sal["s_neg"]), ptr(sal["label"]), ptr(sal["vmask"])
+        a.pos_idx, a.neg_idx, a.ds_pos, a.ds_neg = ptr(sal["pos_idx"]), ptr(sal["neg_idx"]), ptr(sal["ds_pos"]), ptr(sal["ds_neg"])
+    if recfw:
+        _, Lw, C = recfw["logit"].shape
+        a.fw_on, a.fw_Lw, a.fw_C, a.fw_slot, a.fw_eps = 1, Lw, C, recfw["slot"], float(recfw["eps"])
+        a.logit, a.label, a.row_lse = ptr(recfw["logit"]), ptr(recfw["label"]), ptr(recfw["row_lse"])
+        a.words_mask, a.dlogit = ptr(recfw["mask"]), ptr(recfw["dlogit"])
+    if recss:
+        cn, wn, stats, sim = recss["saved"]
+        a.ss_on, a.ss_D, a.ss_Lv, a.ss_Le, a.ss_slot = 1, cn.shape[1], recss["Lv"], recss["Le"], recss["slot"]
+        a.ss_tau = float(recss["tau"])
+        a.cn, a.wn, a.ss_pos, a.sim, a.stats = ptr(cn), ptr(wn), ptr(recss["pos"]), ptr(sim), ptr(stats)
+        a.cmask, a.wmask, a.dpv, a.dew = ptr(recss["cmask"]), ptr(recss["wmask"]), ptr(recss["dpv"]), ptr(recss["dew"])
+    check(lib().mesm_criterion_bwd(ctypes.byref(a), stream_ptr()), "mesm_criterion_bwd")
+
+
 # ----------------------------------------------------------------------------- assembly kernels (csrc/glue.hip)
 def _u8(t):
     return t if t.dtype == torch.uint8 else t.view(torch.uint8)

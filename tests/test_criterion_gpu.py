@@ -144,3 +144,72 @@ def test_weighted_sum_and_scale_vec():
     assert close(t.reshape(1), (v[keep].double() * w[keep].double()).sum().reshape(1))
     g = torch.tensor([2.5], device=dev())
     assert close(kn.scale_vec(g, w), 2.5 * w)
+
+
+@pytest.mark.parametrize("nv,blocks", [(None, "set sal fw ss"), (21, "set sal fw ss"), (None, "sal"), (None, "set ss"),
+                                       (5, "fw"), (None, "salwide fw")])
+def test_one_launch_backward_equals_the_blocks_own_launches(nv, blocks):
+    """mesm_criterion_bwd (every block's gradient kernel as a workgroup range of one grid, d total x weight and the NLL's
+    row weights folded in) against the separate launches it replaces: same device functions, bit-exact."""
+    from mesm_amd import kernels as kn
+    N, Q, tmax, Lw, C, Lv, Le, D = 32, 10, 5, 32, 1503, 75, 33, 64
+    L = 400 if "salwide" in blocks else 75  # (2L > 256: the 20-element saliency rows)
+    n_valid = None if nv is None else torch.tensor([nv], dtype=torch.int32, device=dev())
+    wv = gen((12,), 40).abs() + 0.1
+    g = torch.tensor([0.37], device=dev())
+    gv = kn.scale_vec(g, wv)
+    want, kw = {}, {}
+    if "set" in blocks:
+        sizes, off, xx, cxw, _ = _targets(N, 41, tmax)
+        lay = []
+        for l in range(3):
+            logits, spans = gen((N, Q, 2), 50 + l), torch.sigmoid(gen((N, Q, 2), 60 + l))
+            mq = kn.set_loss_fwd(logits, spans, cxw, xx, off, tmax, 10.0, 1.0, 4.0, 0.1, torch.zeros(4, device=dev()),
+                                 n_valid=n_valid)
+            want["set%d" % l] = kn.set_loss_bwd(logits, spans, cxw, xx, off, mq, 0.1, gv[4 * l:4 * l + 3], n_valid=n_valid)
+            lay.append((logits, spans, mq, torch.empty_like(logits), torch.empty_like(spans), 4 * l))
+        kw["set_losses"] = dict(Q=Q, eos_coef=0.1, tgt_cxw=cxw, tgt_xx=xx, tgt_off=off, layers=lay)
+    if "sal" in blocks:
+        gg = torch.Generator().manual_seed(42)
+        sp, sn = gen((N, L), 43), gen((N, L), 44)
+        label = torch.randint(0, 5, (N, L), generator=gg).double().to(dev())
+        vmask = (torch.rand(N, L, generator=gg) < 0.8).to(dev())
+        pos_idx = torch.randint(0, L, (N, 2), generator=gg).to(dev())
+        neg_idx = torch.randint(0, L, (N, 2), generator=gg).to(dev())
+        want["sal"] = kn.saliency_loss_bwd(sp, sn, label, vmask, pos_idx, neg_idx, 12.0, 0.2, gv[10:11], n_valid=n_valid)
+        kw["sal"] = dict(s_pos=sp, s_neg=sn, label=label, vmask=vmask, pos_idx=pos_idx, neg_idx=neg_idx, rank_coef=12.0,
+                         margin=0.2, ds_pos=torch.empty_like(sp), ds_neg=torch.empty_like(sn), slot=10)
+    if "fw" in blocks:
+        logit = gen((N, Lw, C), 45)
+        label = torch.randint(0, C, (N, Lw), generator=torch.Generator().manual_seed(46)).to(dev()).view(-1)
+        lens = torch.tensor([1 + (5 * i) % Lw for i in range(N)])
+        mask = (torch.arange(Lw)[None] < lens[:, None]).to(dev())
+        _, row_lse, _ = kn.nll_smooth_fwd(logit.view(-1, C), label, mask.view(-1), 0.1)
+        rg = kn.rec_fw_rowgrad(mask, gv[9:10], n_valid=n_valid)
+        want["fw"] = kn.nll_smooth_bwd(logit.view(-1, C), label, row_lse, rg, 0.1).view(N, Lw, C)
+        kw["recfw"] = dict(logit=logit, label=label, row_lse=row_lse, mask=mask, eps=0.1, dlogit=torch.empty_like(logit),
+                           slot=9)
+    if "ss" in blocks:
+        gg = torch.Generator().manual_seed(47)
+        pv, ew = gen((N, Lv, D), 48), gen((N, Le, D), 49)
+        cmask = torch.rand(N, Lv, generator=gg) < 0.3
+        cmask[:, 0] = True
+        wmask = torch.rand(N, Le, generator=gg) < 0.7
+        wmask[:, 0] = True
+        pos = (torch.rand(N, N, generator=gg) < 0.2) | torch.eye(N, dtype=torch.bool)
+        cmask, wmask, pos8 = cmask.to(dev()), wmask.to(dev()), pos.to(torch.uint8).to(dev())
+        saved = kn.rec_ss_fwd(pv, cmask, ew, wmask, pos8, 0.5, torch.zeros(1, device=dev()), n_valid=n_valid)
+        want["ss"] = kn.rec_ss_bwd(saved, pos8, cmask, wmask, Lv, Le, 0.5, gv[11:12], n_valid=n_valid)
+        kw["recss"] = dict(saved=saved, pos=pos8, cmask=cmask, wmask=wmask, Lv=Lv, Le=Le, tau=0.5,
+                           dpv=torch.empty(N, Lv, D, device=dev()), dew=torch.empty(N, Le, D, device=dev()), slot=11)
+    kn.criterion_bwd(g, wv, N, n_valid=n_valid, **kw)
+    torch.cuda.synchronize()
+    if "set" in blocks:
+        for l, lay_l in enumerate(kw["set_losses"]["layers"]):
+            assert torch.equal(lay_l[3], want["set%d" % l][0]) and torch.equal(lay_l[4], want["set%d" % l][1])
+    if "sal" in blocks:
+        assert torch.equal(kw["sal"]["ds_pos"], want["sal"][0]) and torch.equal(kw["sal"]["ds_neg"], want["sal"][1])
+    if "fw" in blocks:
+        assert torch.equal(kw["recfw"]["dlogit"], want["fw"])
+    if "ss" in blocks:
+        assert torch.equal(kw["recss"]["dpv"], want["ss"][0]) and torch.equal(kw["recss"]["dew"], want["ss"][1])
