@@ -581,6 +581,63 @@ int mesm_weighted_sum(const float* vals, const float* weights, int32_t n, float*
 int mesm_scale_vec(const float* g, const float* weights, int32_t n, float* out, void* stream);
 
 /*
+ * The criterion forward (criterion.py:319-367: every loss of the step and their weighted total) in three launches:
+ * A = the first stage of every block as workgroup ranges of one grid (set losses with their matching, one workgroup per
+ * decoder layer | saliency | rec_ss masked means | masked-LM NLL rows), B = rec_ss' similarity rows, C = one workgroup
+ * that finishes rec_fw and rec_ss and writes total = sum_k weights[k] * lv[k].  lv = the loss vector (n_slots floats;
+ * the `*_slot` fields say where a block's values go: set losses 4 slots [span, giou, label, class_error], rec_fw 2
+ * [loss, accuracy], the others 1).  Outputs kept for the backward: set_match, row_lse (row_loss / correct: staging),
+ * cn / wn / stats (2N x 4) / sim.  Field meanings as in mesm_set_loss_fwd_layers / mesm_saliency_loss_fwd_nv /
+ * mesm_nll_smooth_fwd + mesm_rec_fw_reduce_nv / mesm_rec_ss_fwd_nv / mesm_weighted_sum; results bit-identical to those.
+ */
+typedef struct MesmCritFwd {
+  const float* weights;
+  float* lv;
+  float* total;
+  const int32_t* n_valid; /* device scalar: real pairs of a padded batch, or NULL */
+  int32_t N, n_slots;
+  int32_t n_set, Q, Tmax; /* set-loss layers (<= 8), moment queries, most targets of a pair */
+  float w_span, w_giou, w_class, eos_coef;
+  int32_t reserved0;
+  const float* tgt_cxw;
+  const float* tgt_xx;
+  const int32_t* tgt_off;
+  const float* set_logits[8];
+  const float* set_spans[8];
+  int32_t* set_match[8];
+  int32_t set_slot[8];
+  int32_t sal_on, sal_L, sal_P, sal_slot;
+  float rank_coef, margin;
+  const float* s_pos;
+  const float* s_neg;
+  const double* sal_label;
+  const uint8_t* vmask;
+  const int64_t* pos_idx;
+  const int64_t* neg_idx;
+  int32_t fw_on, fw_Lw, fw_C, fw_slot;
+  float fw_eps;
+  int32_t reserved1;
+  const float* logit;
+  const int64_t* label;
+  const uint8_t* words_mask;
+  float* row_loss;
+  float* row_lse;
+  uint8_t* correct;
+  int32_t ss_on, ss_D, ss_Lv, ss_Le, ss_slot;
+  float ss_tau;
+  const float* pv;
+  const uint8_t* cmask;
+  const float* ew;
+  const uint8_t* wmask;
+  const uint8_t* ss_pos;
+  float* cn;
+  float* wn;
+  float* stats;
+  float* sim;
+} MesmCritFwd;
+int mesm_criterion_fwd(const MesmCritFwd* args, void* stream);
+
+/*
  * The whole criterion backward (criterion.py:319-367, the autograd of every loss of the step) as ONE launch: the
  * gradient kernels of the set losses (one per decoder layer), the saliency loss, the masked-LM NLL and rec_ss are
  * independent 256-thread kernels and run as workgroup ranges of one grid.  g_total = d total (1 float), weights = the loss

@@ -77,6 +77,28 @@ class LnArgs(ctypes.Structure):
     ]
 
 
+class CritFwdArgs(ctypes.Structure):
+    _fields_ = [
+        ("weights", c_ptr), ("lv", c_ptr), ("total", c_ptr), ("n_valid", c_ptr),
+        ("N", ctypes.c_int32), ("n_slots", ctypes.c_int32),
+        ("n_set", ctypes.c_int32), ("Q", ctypes.c_int32), ("Tmax", ctypes.c_int32),
+        ("w_span", ctypes.c_float), ("w_giou", ctypes.c_float), ("w_class", ctypes.c_float), ("eos_coef", ctypes.c_float),
+        ("reserved0", ctypes.c_int32),
+        ("tgt_cxw", c_ptr), ("tgt_xx", c_ptr), ("tgt_off", c_ptr),
+        ("set_logits", c_ptr * 8), ("set_spans", c_ptr * 8), ("set_match", c_ptr * 8), ("set_slot", ctypes.c_int32 * 8),
+        ("sal_on", ctypes.c_int32), ("sal_L", ctypes.c_int32), ("sal_P", ctypes.c_int32), ("sal_slot", ctypes.c_int32),
+        ("rank_coef", ctypes.c_float), ("margin", ctypes.c_float),
+        ("s_pos", c_ptr), ("s_neg", c_ptr), ("sal_label", c_ptr), ("vmask", c_ptr), ("pos_idx", c_ptr), ("neg_idx", c_ptr),
+        ("fw_on", ctypes.c_int32), ("fw_Lw", ctypes.c_int32), ("fw_C", ctypes.c_int32), ("fw_slot", ctypes.c_int32),
+        ("fw_eps", ctypes.c_float), ("reserved1", ctypes.c_int32),
+        ("logit", c_ptr), ("label", c_ptr), ("words_mask", c_ptr), ("row_loss", c_ptr), ("row_lse", c_ptr), ("correct", c_ptr),
+        ("ss_on", ctypes.c_int32), ("ss_D", ctypes.c_int32), ("ss_Lv", ctypes.c_int32), ("ss_Le", ctypes.c_int32),
+        ("ss_slot", ctypes.c_int32), ("ss_tau", ctypes.c_float),
+        ("pv", c_ptr), ("cmask", c_ptr), ("ew", c_ptr), ("wmask", c_ptr), ("ss_pos", c_ptr),
+        ("cn", c_ptr), ("wn", c_ptr), ("stats", c_ptr), ("sim", c_ptr),
+    ]
+
+
 class CritBwdArgs(ctypes.Structure):
     _fields_ = [
         ("g_total", c_ptr), ("weights", c_ptr), ("n_valid", c_ptr),
@@ -200,6 +222,7 @@ PROTOTYPES = {
     "mesm_ddp_last_error": (ctypes.c_char_p, []),
     "mesm_weighted_sum": (ctypes.c_int, [c_ptr, c_ptr, _i32, c_ptr, c_ptr]),
     "mesm_scale_vec": (ctypes.c_int, [c_ptr, c_ptr, _i32, c_ptr, c_ptr]),
+    "mesm_criterion_fwd": (ctypes.c_int, [ctypes.POINTER(CritFwdArgs), c_ptr]),
     "mesm_criterion_bwd": (ctypes.c_int, [ctypes.POINTER(CritBwdArgs), c_ptr]),
 }
 

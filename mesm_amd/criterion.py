@@ -132,8 +132,9 @@ class _Spec:
 
 
 class CriterionFn(Function):
-    """(total, loss_vector) = criterion(model outputs).  Forward: one launch per loss block writing
-    straight into its slots of the loss vector + one weighted sum.  Backward: ONE launch, the blocks'
+    """(total, loss_vector) = criterion(model outputs).  Forward: three launches (mesm_criterion_fwd: every block's first
+    stage as workgroup ranges of one grid, rec_ss' similarity rows, one finishing workgroup with the weighted sum), the
+    blocks' values written straight into their slots of the loss vector.  Backward: ONE launch, the blocks'
     gradient kernels as workgroup ranges of one grid (mesm_criterion_bwd)."""
 
     @staticmethod
@@ -144,22 +145,25 @@ class CriterionFn(Function):
         dev = t[0].device
         lv = torch.empty(len(spec.names), device=dev, dtype=torch.float32)
         saved = {}
-        matches = []
+        blocks = {}
+        N = None
         lay = []
         for li, (il, isp, slot, k) in enumerate(spec.set_layers):
             # k: this layer's index in the stacked (layers, N, Q, 2) decoder outputs (None: a tensor of its own)
             logits, spans = (t[il].contiguous(), t[isp].contiguous()) if k is None else (t[il][k], t[isp][k])
-            lay.append((logits, spans, lv[slot:slot + 4]))
-        if 1 < len(lay) <= 8:
-            # the layers' matchings are independent one-workgroup latency chains: one launch, a workgroup per layer
-            mqs = kn.set_loss_fwd_layers(lay, plan.tgt_cxw, plan.tgt_xx, plan.tgt_off, plan.Tmax, m.cost_span, m.cost_giou,
-                                         m.cost_class, c.eos_coef, n_valid=spec.n_valid)
-        else:
-            mqs = [kn.set_loss_fwd(lg, sp, plan.tgt_cxw, plan.tgt_xx, plan.tgt_off, plan.Tmax, m.cost_span, m.cost_giou,
-                                   m.cost_class, c.eos_coef, o4, n_valid=spec.n_valid) for lg, sp, o4 in lay]
-        for li, ((logits, spans, _), mq) in enumerate(zip(lay, mqs)):
-            matches.append(mq)
-            saved["set%d" % li] = (logits, spans, mq)
+            lay.append((logits, spans, slot))
+            N = logits.shape[0]
+        mqs = []
+        for i0 in range(0, len(lay), 8):  # (one launch holds 8 layers)
+            part = dict(Q=lay[0][0].shape[1], Tmax=plan.Tmax, w_span=m.cost_span, w_giou=m.cost_giou, w_class=m.cost_class,
+                        eos_coef=c.eos_coef, tgt_cxw=plan.tgt_cxw, tgt_xx=plan.tgt_xx, tgt_off=plan.tgt_off,
+                        layers=lay[i0:i0 + 8])
+            if i0 + 8 < len(lay):
+                mqs += kn.set_loss_fwd_layers([(lg, sp, lv[slot:slot + 4]) for lg, sp, slot in part["layers"]], plan.tgt_cxw,
+                                              plan.tgt_xx, plan.tgt_off, plan.Tmax, m.cost_span, m.cost_giou, m.cost_class,
+                                              c.eos_coef, n_valid=spec.n_valid)
+            else:
+                blocks["set_losses"] = part
         if spec.sal is not None:
             ip, ineg, slot = spec.sal
             if ineg is None:  # both passes stacked in one (2N, L) tensor
@@ -167,27 +171,33 @@ class CriterionFn(Function):
                 sp, sn = t[ip][:half], t[ip][half:]
             else:
                 sp, sn = t[ip].contiguous(), t[ineg].contiguous()
-            kn.saliency_loss_fwd(sp, sn, spec.sal_label, spec.vmask, spec.pos_idx, spec.neg_idx,
-                                 float(c.rank_coef), float(c.saliency_margin), out=lv[slot:slot + 1],
-                                 n_valid=spec.n_valid)
+            N = sp.shape[0]
+            blocks["sal"] = dict(s_pos=sp, s_neg=sn, label=spec.sal_label, vmask=spec.vmask, pos_idx=spec.pos_idx,
+                                 neg_idx=spec.neg_idx, rank_coef=c.rank_coef, margin=c.saliency_margin, slot=slot)
             saved["sal"] = (sp, sn)
         if spec.recfw is not None:
             il, slot = spec.recfw
             logit = t[il].contiguous()
-            C = logit.shape[-1]
-            row_loss, row_lse, correct = kn.nll_smooth_fwd(logit.view(-1, C), spec.words_label,
-                                                           spec.words_mask.view(-1), 0.1)
-            kn.rec_fw_reduce(row_loss, correct, spec.words_mask, lv[slot:slot + 2], n_valid=spec.n_valid)
-            saved["recfw"] = (logit, row_lse)
+            N = logit.shape[0]
+            blocks["recfw"] = dict(logit=logit, label=spec.words_label, mask=spec.words_mask, eps=0.1, slot=slot)
         if spec.recss is not None:
             ipv, iew, slot = spec.recss
             pv, ew = t[ipv].contiguous(), t[iew].contiguous()
-            saved["recss"] = kn.rec_ss_fwd(pv, spec.clip_mask, ew, spec.ewords_mask, plan.ss_pos,
-                                           c.recss_tau, lv[slot:slot + 1], n_valid=spec.n_valid)
+            N = pv.shape[0]
+            blocks["recss"] = dict(pv=pv, cmask=spec.clip_mask, ew=ew, wmask=spec.ewords_mask, pos=plan.ss_pos,
+                                   tau=c.recss_tau, slot=slot)
             saved["recss_shape"] = (pv.shape[1], ew.shape[1])
-        total = kn.weighted_sum(lv, spec.wv)
+        # every block's first stage in one grid, rec_ss' similarity rows, one finishing workgroup with the weighted sum
+        total, out = kn.criterion_fwd(lv, spec.wv, N, n_valid=spec.n_valid, **blocks)
+        mqs += out.get("match", [])
+        for li, ((logits, spans, _), mq) in enumerate(zip(lay, mqs)):
+            saved["set%d" % li] = (logits, spans, mq)
+        if spec.recfw is not None:
+            saved["recfw"] = (blocks["recfw"]["logit"], out["row_lse"])
+        if spec.recss is not None:
+            saved["recss"] = out["recss"]
         ctx.spec, ctx.saved, ctx.n_in = spec, saved, len(t)
-        spec.matches = matches
+        spec.matches = mqs
         ctx.mark_non_differentiable(lv)
         return total, lv
 

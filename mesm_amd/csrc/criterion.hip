@@ -367,13 +367,12 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 }
 
 constexpr int SSM_G = 4;  // row groups per workgroup (independent load chains)
-__global__ __launch_bounds__(256 * SSM_G) void ss_mean_fwd_kernel(
+__device__ __forceinline__ void ss_mean_fwd_body(
     const float* __restrict__ pv, const uint8_t* __restrict__ cmask, int Lv,
     const float* __restrict__ ew, const uint8_t* __restrict__ wmask, int Le, int D,
-    float* __restrict__ cn, float* __restrict__ wn, float* __restrict__ stats) {
+    float* __restrict__ cn, float* __restrict__ wn, float* __restrict__ stats, int n) {
   __shared__ float sh[16];
   __shared__ float part[2][SSM_G][1024];
-  const int n = blockIdx.x;
   const int t = threadIdx.x & 255, g = threadIdx.x >> 8;
   // valid clips / words of the pair, counted by the whole workgroup (a per-thread loop over the mask bytes was a
   // chain of Lv + Le dependent loads in front of everything else)
@@ -449,6 +448,13 @@ __global__ __launch_bounds__(256 * SSM_G) void ss_mean_fwd_kernel(
     stats[n * 4 + 0] = ccnt; stats[n * 4 + 1] = wcnt;
     stats[n * 4 + 2] = cnorm; stats[n * 4 + 3] = wnorm;
   }
+}
+
+__global__ __launch_bounds__(256 * SSM_G) void ss_mean_fwd_kernel(
+    const float* __restrict__ pv, const uint8_t* __restrict__ cmask, int Lv,
+    const float* __restrict__ ew, const uint8_t* __restrict__ wmask, int Le, int D,
+    float* __restrict__ cn, float* __restrict__ wn, float* __restrict__ stats) {
+  ss_mean_fwd_body(pv, cmask, Lv, ew, wmask, Le, D, cn, wn, stats, blockIdx.x);
 }
 
 // Stage B, one workgroup per row n: sim[n,:] = cn[n] wn^T / tau (saved) and the row's loss term
@@ -736,11 +742,11 @@ __global__ __launch_bounds__(256) void crit_bwd_kernel(const MesmCritBwd a, cons
 // ------------------------------------------------------------------------------------------
 // rec_fw reductions (criterion.py:293-304): out[0] = mean_n( sum_w row_loss / cnt_n ),
 // out[1] = sum(correct * mask) / sum(mask).  One workgroup; one wave per pair.
-__global__ __launch_bounds__(256) void recfw_reduce_kernel(const float* __restrict__ row_loss,
-                                                           const uint8_t* __restrict__ correct,
-                                                           const uint8_t* __restrict__ mask, int N,
-                                                           int Lw, float* __restrict__ out,
-                                                           const int32_t* __restrict__ n_valid) {
+__device__ __forceinline__ void recfw_reduce_body(const float* __restrict__ row_loss,
+                                                  const uint8_t* __restrict__ correct,
+                                                  const uint8_t* __restrict__ mask, int N,
+                                                  int Lw, float* __restrict__ out,
+                                                  const int32_t* __restrict__ n_valid) {
   if (n_valid) N = *n_valid;
   __shared__ float sh[3][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -763,6 +769,64 @@ __global__ __launch_bounds__(256) void recfw_reduce_kernel(const float* __restri
     for (int w = 0; w < 4; ++w) { a += sh[0][w]; b += sh[1][w]; c += sh[2][w]; }
     out[0] = a / (float)N;
     out[1] = b / c;
+  }
+}
+
+__global__ __launch_bounds__(256) void recfw_reduce_kernel(const float* __restrict__ row_loss,
+                                                           const uint8_t* __restrict__ correct,
+                                                           const uint8_t* __restrict__ mask, int N,
+                                                           int Lw, float* __restrict__ out,
+                                                           const int32_t* __restrict__ n_valid) {
+  recfw_reduce_body(row_loss, correct, mask, N, Lw, out, n_valid);
+}
+
+// ------------------------------------------------------------------------------------------
+// The criterion forward in three launches instead of eight (round 5).  Its blocks are independent until the weighted sum,
+// and the longest of them -- the set losses' assignment, a one-wave latency chain of ~30 us per decoder layer -- used to
+// run with the rest of the chip idle.  Launch A holds every block's first stage as workgroup ranges of one grid of
+// 1,024-thread workgroups: [set-loss layers | saliency | rec_ss masked means | NLL rows, a row per 256-thread quarter];
+// launch B is rec_ss' similarity rows (they need every pair's mean: a grid-wide dependency, hence a launch); launch C, one
+// workgroup, finishes rec_fw (row losses -> loss, accuracy), rec_ss (row terms -> loss) and the weighted total.  Same
+// device functions as the separate launches: the results are bit-identical.
+template <int NPT>
+__global__ __launch_bounds__(1024) void crit_fwd_kernel(const MesmCritFwd a, const int4 r0, const int P) {
+  const int bid = blockIdx.x;
+  if (bid < r0.x) {
+    set_loss_fwd_body(a.set_logits[bid], a.set_spans[bid], a.tgt_cxw, a.tgt_xx, a.tgt_off, a.N, a.Q, a.Tmax, a.w_span, a.w_giou,
+                      a.w_class, a.eos_coef, P, a.set_match[bid], a.lv + a.set_slot[bid], a.n_valid);
+  } else if (bid < r0.y) {
+    saliency_fwd_body<4, 16>(a.s_pos, a.s_neg, a.sal_label, a.vmask, a.pos_idx, a.neg_idx, a.N, a.sal_L, a.sal_P, a.rank_coef,
+                             a.margin, a.lv + a.sal_slot, a.n_valid);
+  } else if (bid < r0.z) {
+    ss_mean_fwd_body(a.pv, a.cmask, a.ss_Lv, a.ew, a.wmask, a.ss_Le, a.ss_D, a.cn, a.wn, a.stats, bid - r0.y);
+  } else {
+    __shared__ NllShared nsh[4];
+    const int q = threadIdx.x >> 8;
+    const int64_t R = (int64_t)a.N * a.fw_Lw;
+    int64_t r = (int64_t)(bid - r0.z) * 4 + q;
+    const bool live = r < R;
+    if (!live) r = R - 1;
+    nll_fwd_body<NPT>(a.logit, a.label, a.words_mask, a.row_loss, a.row_lse, a.correct, a.fw_C, a.fw_eps, r, live,
+                      threadIdx.x & 255, nsh[q]);
+  }
+}
+
+__global__ __launch_bounds__(256) void crit_tail_kernel(const MesmCritFwd a) {
+  if (a.fw_on) recfw_reduce_body(a.row_loss, a.correct, a.words_mask, a.N, a.fw_Lw, a.lv + a.fw_slot, a.n_valid);
+  if (threadIdx.x < 64 && a.ss_on) {  // (ss_reduce_kernel)
+    int N = a.N;
+    if (a.n_valid) N = *a.n_valid;
+    const float* rowloss = a.stats + (size_t)a.N * 4;
+    float t = 0.0f;
+    for (int n = threadIdx.x; n < N; n += 64) t += rowloss[n];
+    t = wave_sum(t);
+    if (threadIdx.x == 0) a.lv[a.ss_slot] = t / (float)N;
+  }
+  if (threadIdx.x == 0) {  // (wsum_kernel; this thread wrote the two values above itself)
+    float t = 0.0f;
+    for (int k = 0; k < a.n_slots; ++k)
+      if (a.weights[k] != 0.0f) t += a.weights[k] * a.lv[k];
+    a.total[0] = t;
   }
 }
 
@@ -1035,6 +1099,67 @@ extern "C" int mesm_rec_ss_bwd(const float* cn, const float* wn, const uint8_t* 
                                int32_t N, int32_t D, int32_t Lv, int32_t Le, float tau, const float* g,
                                float* dpv, float* dew, void* stream) {
   return mesm_rec_ss_bwd_nv(cn, wn, pos, sim, stats, cmask, wmask, N, D, Lv, Le, tau, g, dpv, dew, nullptr, stream);
+}
+
+extern "C" int mesm_criterion_fwd(const MesmCritFwd* args, void* stream) {
+  if (!args) return MESM_EINVAL;
+  const MesmCritFwd& a = *args;
+  hipStream_t s = (hipStream_t)stream;
+  if (!a.lv || !a.weights || !a.total || a.N <= 0 || a.n_slots <= 0 || a.n_slots > 256) return MESM_EINVAL;
+  if (a.n_set < 0 || a.n_set > SET_LAYERS_MAX) return MESM_EINVAL;
+  int P = 0;
+  size_t lds = 0;
+  if (a.n_set > 0) {
+    if (!a.tgt_cxw || !a.tgt_xx || !a.tgt_off || a.Q <= 0 || a.Q > 64 || a.Tmax <= 0 || a.Tmax > 64) return MESM_EINVAL;
+    for (int l = 0; l < a.n_set; ++l)
+      if (!a.set_logits[l] || !a.set_spans[l] || !a.set_match[l] || a.set_slot[l] < 0 || a.set_slot[l] + 4 > a.n_slots)
+        return MESM_EINVAL;
+    P = sap_pairs_per_pass(a.Tmax, a.Q, a.N);
+    if (P == 0) return MESM_EINVAL;
+    lds = sap_bytes_per_thread(a.Tmax, a.Q) * P;
+  }
+  bool sal_inside = false;
+  if (a.sal_on) {
+    if (!a.s_pos || !a.s_neg || !a.sal_label || !a.vmask || a.sal_L <= 0 || a.sal_slot < 0 || a.sal_slot >= a.n_slots ||
+        (a.sal_P > 0 && (!a.pos_idx || !a.neg_idx)))
+      return MESM_EINVAL;
+    sal_inside = 2 * a.sal_L <= 256;  // (the 20-element rows need more registers than a 1,024-thread workgroup has)
+    if (!sal_inside) {
+      const int rc = mesm_saliency_loss_fwd_nv(a.s_pos, a.s_neg, a.sal_label, a.vmask, a.pos_idx, a.neg_idx, a.N, a.sal_L, a.sal_P,
+                                               a.rank_coef, a.margin, a.lv + a.sal_slot, a.n_valid, stream);
+      if (rc != MESM_OK) return rc;
+    }
+  }
+  if (a.fw_on) {
+    if (!a.logit || !a.label || !a.words_mask || !a.row_loss || !a.row_lse || !a.correct || a.fw_Lw <= 0 || a.fw_C <= 0 ||
+        a.fw_slot < 0 || a.fw_slot + 2 > a.n_slots)
+      return MESM_EINVAL;
+  }
+  if (a.ss_on) {
+    if (!a.pv || !a.cmask || !a.ew || !a.wmask || !a.ss_pos || !a.cn || !a.wn || !a.stats || !a.sim) return MESM_EINVAL;
+    if (a.ss_D <= 0 || a.ss_D > 1024 || a.ss_Lv <= 0 || a.ss_Le <= 0 || a.ss_tau <= 0.f || a.ss_slot < 0 || a.ss_slot >= a.n_slots)
+      return MESM_EINVAL;
+  }
+  int4 r0;
+  r0.x = a.n_set;
+  r0.y = r0.x + (sal_inside ? 1 : 0);
+  r0.z = r0.y + (a.ss_on ? a.N : 0);
+  const int64_t nll_blocks = a.fw_on ? ((int64_t)a.N * a.fw_Lw + 3) / 4 : 0;
+  if (nll_blocks > (1 << 30)) return MESM_EINVAL;
+  r0.w = r0.z + (int)nll_blocks;
+  if (r0.w > 0) {
+    if (!a.fw_on || a.fw_C <= 2048)
+      hipLaunchKernelGGL(crit_fwd_kernel<8>, dim3(r0.w), dim3(1024), lds, s, a, r0, P);
+    else if (a.fw_C <= 5120)
+      hipLaunchKernelGGL(crit_fwd_kernel<20>, dim3(r0.w), dim3(1024), lds, s, a, r0, P);
+    else
+      hipLaunchKernelGGL(crit_fwd_kernel<0>, dim3(r0.w), dim3(1024), lds, s, a, r0, P);
+  }
+  if (a.ss_on)
+    hipLaunchKernelGGL(ss_loss_fwd_kernel, dim3(a.N), dim3(256), (size_t)a.N * 4, s, a.cn, a.wn, a.ss_pos, a.N, a.ss_D,
+                       1.0f / a.ss_tau, a.sim, a.stats + (size_t)a.N * 4, a.n_valid);
+  hipLaunchKernelGGL(crit_tail_kernel, dim3(1), dim3(256), 0, s, a);
+  return mesm_launch_status();
 }
 
 extern "C" int mesm_criterion_bwd(const MesmCritBwd* args, void* stream) {

@@ -1,5 +1,5 @@
 // Device bodies of loss kernels that run both as launches of their own (losses.hip) and as workgroups of the merged
-// criterion backward launch (criterion.hip, mesm_criterion_bwd).
+// criterion launches (criterion.hip: mesm_criterion_fwd, mesm_criterion_bwd).
 #pragma once
 #include "common.hpp"
 
@@ -170,5 +170,140 @@ __device__ __forceinline__ void saliency_bwd_body(
   }
 }
 
+// ---------------------------------------------------------------- label-smoothed NLL, forward
+// One 256-thread group per row (criterion.py:291-306): a workgroup of its own (nll_fwd_kernel) or a quarter of a
+// 1,024-thread workgroup of the merged criterion forward; `t` = the thread's index in its group, `sh` = the group's LDS.
+// NPT > 0: the row (C <= 256 NPT classes) is read ONCE, NPT independent loads per thread in flight together, and both
+// passes run on registers (the two-pass form walked the row twice with one load in flight per thread: 19.5 -> 9.3 us at
+// 1024 x 5003); NPT = 0: any C, two passes over the L2-resident row.  live = false: a group past the last row (it takes
+// part in the barriers and writes nothing).
+struct NllShared {
+  float sh[4];
+  float shm[4];
+  int shi[4];
+};
+
+__device__ __forceinline__ float nll_group_sum(float v, float* sh, int t) {
+  v = wave_sum(v);
+  if ((t & 63) == 0) sh[t >> 6] = v;
+  __syncthreads();
+  const float r = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  return r;
+}
+
+template <int NPT>
+__device__ __forceinline__ void nll_fwd_body(const float* __restrict__ logit, const int64_t* __restrict__ label,
+                                             const uint8_t* __restrict__ mask, float* __restrict__ row_loss,
+                                             float* __restrict__ row_lse, uint8_t* __restrict__ correct, int C, float eps,
+                                             int64_t r, bool live, int t, NllShared& S) {
+  const float* x = logit + r * C;
+  const int wave = t >> 6;
+  // pass 1: max + first argmax + plain sum
+  float m = -INFINITY, s = 0.0f;
+  int am = 0x7fffffff;
+  float v[NPT > 0 ? NPT : 1];
+  if (NPT > 0) {
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+      const int c = t + k * 256;
+      v[k] = c < C ? x[c] : -INFINITY;
+    }
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) {
+      const int c = t + k * 256;
+      if (c < C) {
+        s += v[k];
+        if (v[k] > m) { m = v[k]; am = c; }
+      }
+    }
+  } else {
+    for (int c = t; c < C; c += 256) {
+      float u = x[c];
+      s += u;
+      if (u > m) { m = u; am = c; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float m2 = __shfl_xor(m, o, 64);
+    int a2 = __shfl_xor(am, o, 64);
+    if (m2 > m || (m2 == m && a2 < am)) { m = m2; am = a2; }
+  }
+  if ((t & 63) == 0) { S.shm[wave] = m; S.shi[wave] = am; }
+  __syncthreads();
+  float M = S.shm[0];
+  int AM = S.shi[0];
+#pragma unroll
+  for (int w = 1; w < 4; ++w)
+    if (S.shm[w] > M || (S.shm[w] == M && S.shi[w] < AM)) { M = S.shm[w]; AM = S.shi[w]; }
+  __syncthreads();
+  const float total = nll_group_sum(s, S.sh, t);
+  // pass 2: sum exp
+  float e = 0.0f;
+  if (NPT > 0) {
+#pragma unroll
+    for (int k = 0; k < NPT; ++k) e += __expf(v[k] - M);  // (exp(-inf) = 0 beyond C)
+  } else {
+    for (int c = t; c < C; c += 256) e += __expf(x[c] - M);
+  }
+  const float E = nll_group_sum(e, S.sh, t);
+  if (t == 0 && live) {
+    const float lse = M + __logf(E);
+    const int64_t lab = label[r];
+    const float nll = -(x[lab] - lse);
+    const float smooth = -(total - (float)C * lse);
+    float loss = (1.0f - eps) * nll + eps / (float)C * smooth;
+    if (mask && mask[r] == 0) loss = 0.0f;
+    row_loss[r] = loss;
+    row_lse[r] = lse;
+    if (correct) correct[r] = (AM == (int)lab) ? 1 : 0;
+  }
+}
+
+// ---------------------------------------------------------------- saliency losses, forward
+// one workgroup (deterministic sum) of NW waves, a wave per pair
+template <int NE, int NW>
+__device__ __forceinline__ void saliency_fwd_body(
+    const float* __restrict__ s_pos, const float* __restrict__ s_neg,
+    const double* __restrict__ label, const uint8_t* __restrict__ vmask,
+    const int64_t* __restrict__ pos_idx, const int64_t* __restrict__ neg_idx, int N, int L, int P,
+    float rank_coef, float margin, float* __restrict__ out_loss, const int32_t* __restrict__ n_valid) {
+  if (n_valid) N = *n_valid;  // pairs [n_valid, N) are padding of a captured capacity: not in the mean
+  __shared__ float part[NW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float acc = 0.0f;  // lane 0 of each wave accumulates its rows
+  for (int n = wave; n < N; n += NW) {
+    const float* sp = s_pos + (int64_t)n * L;
+    const float* sn = s_neg + (int64_t)n * L;
+    const uint8_t* vm = vmask + (int64_t)n * L;
+    SalRow<NE> R;
+    sal_row_stats(sp, sn, label + (int64_t)n * L, vm, L, lane, R);
+    // neg-pair term: sum_l -log(1 - sigmoid(s_neg)) * vmask
+    float np = 0.0f;
+    for (int l = lane; l < L; l += 64) {
+      float sg = 1.0f / (1.0f + __expf(-sn[l]));
+      np += -__logf(1.0f - sg) * (vm[l] ? 1.0f : 0.0f);
+    }
+    np = wave_sum(np);
+    float trip = 0.0f;
+    if (pos_idx && lane < P) {
+      float ps = sp[pos_idx[(int64_t)n * P + lane]];
+      float ns = sp[neg_idx[(int64_t)n * P + lane]];
+      float t = margin + ns - ps;
+      trip = t > 0.0f ? t : 0.0f;
+    }
+    trip = wave_sum(trip);
+    acc += R.rank / ((float)N * rank_coef) + np / (float)N;
+    if (pos_idx) acc += trip / (float)(N * P) * 2.0f;
+  }
+  if (lane == 0) part[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.0f;
+    for (int w = 0; w < NW; ++w) t += part[w];
+    *out_loss = t;
+  }
+}
 
 }  // namespace

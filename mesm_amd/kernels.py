@@ -838,6 +838,72 @@ def scale_vec(g, weights):
     return out
 
 
+def criterion_fwd(lv, weights, N, n_valid=None, set_losses=None, sal=None, recfw=None, recss=None):
+    """The criterion's forward in three launches (mesm_criterion_fwd): every block's first stage in one grid, rec_ss'
+    similarity rows, one finishing workgroup.  Writes the blocks' values into their slots of `lv`; -> (total, saved) with
+    saved = dict(match=[...], row_lse=..., recss=(cn, wn, stats, sim)) for the backward.
+    set_losses: dict(Q, Tmax, w_span, w_giou, w_class, eos_coef, tgt_cxw, tgt_xx, tgt_off, layers=[(logits, spans, slot)]);
+    sal: dict(s_pos, s_neg, label, vmask, pos_idx, neg_idx, rank_coef, margin, slot);
+    recfw: dict(logit (N, Lw, C), label, mask (N, Lw), eps, slot);  recss: dict(pv, cmask, ew, wmask, pos, tau, slot)."""
+    require_gpu(lv, weights)
+    dev = lv.device
+    a = _lib.CritFwdArgs()
+    total = torch.empty((), device=dev, dtype=torch.float32)
+    a.weights, a.lv, a.total, a.n_valid, a.N, a.n_slots = ptr(weights), ptr(lv), ptr(total), ptr(n_valid), N, lv.numel()
+    saved = {}
+    if set_losses:
+        lay = set_losses["layers"]
+        assert 0 < len(lay) <= 8
+        _check_match_limits(set_losses["Q"], set_losses["Tmax"])
+        a.Q, a.Tmax, a.n_set = set_losses["Q"], set_losses["Tmax"], len(lay)
+        a.w_span, a.w_giou, a.w_class = float(set_losses["w_span"]), float(set_losses["w_giou"]), float(set_losses["w_class"])
+        a.eos_coef = float(set_losses["eos_coef"])
+        a.tgt_cxw, a.tgt_xx, a.tgt_off = ptr(set_losses["tgt_cxw"]), ptr(set_losses["tgt_xx"]), ptr(set_losses["tgt_off"])
+        sumT = set_losses["tgt_cxw"].shape[0]
+        mqs = torch.empty(len(lay), max(sumT, 1), dtype=torch.int32, device=dev)
+        saved["match"] = [mqs[l, :sumT] for l in range(len(lay))]
+        for l, (lg, sp, slot) in enumerate(lay):
+            assert lg.is_contiguous() and sp.is_contiguous()
+            a.set_logits[l], a.set_spans[l], a.set_match[l], a.set_slot[l] = ptr(lg), ptr(sp), ptr(mqs[l]), slot
+    if sal:
+        _, L = sal["s_pos"].shape
+        assert sal["label"].dtype == torch.float64 and sal["label"].is_contiguous()
+        assert sal["s_pos"].is_contiguous() and sal["s_neg"].is_contiguous() and sal["vmask"].is_contiguous()
+        a.sal_on, a.sal_L, a.sal_slot = 1, L, sal["slot"]
+        a.sal_P = sal["pos_idx"].shape[1] if sal["pos_idx"] is not None else 0
+        a.rank_coef, a.margin = float(sal["rank_coef"]), float(sal["margin"])
+        a.s_pos, a.s_neg, a.sal_label, a.vmask = ptr(sal["s_pos"]), ptr(sal["s_neg"]), ptr(sal["label"]), ptr(sal["vmask"])
+        a.pos_idx, a.neg_idx = ptr(sal["pos_idx"]), ptr(sal["neg_idx"])
+    if recfw:
+        N_, Lw, C = recfw["logit"].shape
+        assert recfw["logit"].is_contiguous()
+        R = N_ * Lw
+        row_loss = torch.empty(R, device=dev, dtype=torch.float32)
+        row_lse = torch.empty(R, device=dev, dtype=torch.float32)
+        correct = torch.empty(R, device=dev, dtype=torch.uint8)
+        a.fw_on, a.fw_Lw, a.fw_C, a.fw_slot, a.fw_eps = 1, Lw, C, recfw["slot"], float(recfw["eps"])
+        a.logit, a.label, a.words_mask = ptr(recfw["logit"]), ptr(recfw["label"]), ptr(recfw["mask"])
+        a.row_loss, a.row_lse, a.correct = ptr(row_loss), ptr(row_lse), ptr(correct)
+        saved["row_lse"] = row_lse
+        saved["_staging"] = (row_loss, correct)
+    if recss:
+        pv, ew = recss["pv"], recss["ew"]
+        N_, Lv, D = pv.shape
+        Le = ew.shape[1]
+        assert pv.is_contiguous() and ew.is_contiguous() and recss["cmask"].is_contiguous() and recss["wmask"].is_contiguous()
+        assert recss["pos"].shape == (N_, N_) and recss["pos"].is_contiguous()
+        cn = torch.empty(N_, D, device=dev, dtype=torch.float32)
+        wn = torch.empty(N_, D, device=dev, dtype=torch.float32)
+        stats = torch.empty(2 * N_, 4, device=dev, dtype=torch.float32)  # rows N.. : per-row loss staging
+        sim = torch.empty(N_, N_, device=dev, dtype=torch.float32)
+        a.ss_on, a.ss_D, a.ss_Lv, a.ss_Le, a.ss_slot, a.ss_tau = 1, D, Lv, Le, recss["slot"], float(recss["tau"])
+        a.pv, a.cmask, a.ew, a.wmask, a.ss_pos = ptr(pv), ptr(recss["cmask"]), ptr(ew), ptr(recss["wmask"]), ptr(recss["pos"])
+        a.cn, a.wn, a.stats, a.sim = ptr(cn), ptr(wn), ptr(stats), ptr(sim)
+        saved["recss"] = (cn, wn, stats, sim)
+    check(lib().mesm_criterion_fwd(ctypes.byref(a), stream_ptr()), "mesm_criterion_fwd")
+    return total, saved
+
+
 def criterion_bwd(g_total, weights, N, n_valid=None, set_losses=None, sal=None, recfw=None, recss=None):
     """The criterion's whole backward as one launch (mesm_criterion_bwd): each block multiplies d total by its own weight.
     set_losses: dict(Q, eos_coef, tgt_cxw, tgt_xx, tgt_off, layers=[(logits, spans, match_q, dlogits, dspans, slot)]);

@@ -213,3 +213,76 @@ def test_one_launch_backward_equals_the_blocks_own_launches(nv, blocks):
         assert torch.equal(kw["recfw"]["dlogit"], want["fw"])
     if "ss" in blocks:
         assert torch.equal(kw["recss"]["dpv"], want["ss"][0]) and torch.equal(kw["recss"]["dew"], want["ss"][1])
+
+
+@pytest.mark.parametrize("nv,blocks,C", [(None, "set sal fw ss", 1503), (21, "set sal fw ss", 5003), (None, "sal", 0),
+                                         (None, "set ss", 0), (5, "fw", 6001), (None, "salwide fw", 1022)])
+def test_three_launch_forward_equals_the_blocks_own_launches(nv, blocks, C):
+    """mesm_criterion_fwd (first stages of every block in one grid of 1,024-thread workgroups, rec_ss' similarity rows,
+    one finishing workgroup) against the separate launches it replaces: loss vector, total and everything the backward
+    reads, bit-exact.  C covers the three row forms of the NLL (<= 2048, <= 5120, any); "salwide" the saliency rows that
+    stay a launch of their own."""
+    from mesm_amd import kernels as kn
+    N, Q, tmax, Lw, Lv, Le, D = 32, 10, 5, 30, 75, 33, 64
+    L = 400 if "salwide" in blocks else 75
+    n_valid = None if nv is None else torch.tensor([nv], dtype=torch.int32, device=dev())
+    wv = gen((16,), 40).abs() + 0.1
+    wv[3] = 0.0  # (class_error: a logged value, not part of the total)
+    lv_a = torch.full((16,), 7.0, device=dev())
+    lv_b = lv_a.clone()
+    kw, want = {}, {}
+    if "set" in blocks:
+        sizes, off, xx, cxw, _ = _targets(N, 41, tmax)
+        lay = [(gen((N, Q, 2), 50 + l), torch.sigmoid(gen((N, Q, 2), 60 + l)), 4 * l) for l in range(3)]
+        want["match"] = kn.set_loss_fwd_layers([(lg, sp, lv_a[s:s + 4]) for lg, sp, s in lay], cxw, xx, off, tmax, 10.0, 1.0,
+                                               4.0, 0.1, n_valid=n_valid)
+        kw["set_losses"] = dict(Q=Q, Tmax=tmax, w_span=10.0, w_giou=1.0, w_class=4.0, eos_coef=0.1, tgt_cxw=cxw, tgt_xx=xx,
+                                tgt_off=off, layers=lay)
+    if "sal" in blocks:
+        gg = torch.Generator().manual_seed(42)
+        sp, sn = gen((N, L), 43), gen((N, L), 44)
+        label = torch.randint(0, 5, (N, L), generator=gg).double().to(dev())
+        vmask = (torch.rand(N, L, generator=gg) < 0.8).to(dev())
+        pos_idx = torch.randint(0, L, (N, 2), generator=gg).to(dev())
+        neg_idx = torch.randint(0, L, (N, 2), generator=gg).to(dev())
+        kn.saliency_loss_fwd(sp, sn, label, vmask, pos_idx, neg_idx, 12.0, 0.2, out=lv_a[12:13], n_valid=n_valid)
+        kw["sal"] = dict(s_pos=sp, s_neg=sn, label=label, vmask=vmask, pos_idx=pos_idx, neg_idx=neg_idx, rank_coef=12.0,
+                         margin=0.2, slot=12)
+    if "fw" in blocks:
+        logit = gen((N, Lw, C), 45)
+        label = torch.randint(0, C, (N, Lw), generator=torch.Generator().manual_seed(46)).to(dev()).view(-1)
+        lens = torch.tensor([1 + (5 * i) % Lw for i in range(N)])
+        mask = (torch.arange(Lw)[None] < lens[:, None]).to(dev())
+        row_loss, row_lse, correct = kn.nll_smooth_fwd(logit.view(-1, C), label, mask.view(-1), 0.1)
+        kn.rec_fw_reduce(row_loss, correct, mask, lv_a[13:15], n_valid=n_valid)
+        want["row_lse"] = row_lse
+        kw["recfw"] = dict(logit=logit, label=label, mask=mask, eps=0.1, slot=13)
+    if "ss" in blocks:
+        gg = torch.Generator().manual_seed(47)
+        pv, ew = gen((N, Lv, D), 48), gen((N, Le, D), 49)
+        cmask = torch.rand(N, Lv, generator=gg) < 0.3
+        cmask[:, 0] = True
+        wmask = torch.rand(N, Le, generator=gg) < 0.7
+        wmask[:, 0] = True
+        pos = (torch.rand(N, N, generator=gg) < 0.2) | torch.eye(N, dtype=torch.bool)
+        cmask, wmask, pos8 = cmask.to(dev()), wmask.to(dev()), pos.to(torch.uint8).to(dev())
+        want["recss"] = kn.rec_ss_fwd(pv, cmask, ew, wmask, pos8, 0.5, lv_a[15:16], n_valid=n_valid)
+        kw["recss"] = dict(pv=pv, cmask=cmask, ew=ew, wmask=wmask, pos=pos8, tau=0.5, slot=15)
+    total_a = kn.weighted_sum(lv_a, wv)
+    total_b, out = kn.criterion_fwd(lv_b, wv, N, n_valid=n_valid, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(lv_a, lv_b), (lv_a, lv_b)
+    assert torch.equal(total_a, total_b) and total_b.shape == total_a.shape
+    rows = N if nv is None else nv
+    if "set" in blocks:
+        T = int(off[rows])  # (the padding pairs' targets are not matched)
+        for a, b in zip(want["match"], out["match"]):
+            assert torch.equal(a[:T], b[:T])
+    if "fw" in blocks:
+        assert torch.equal(want["row_lse"], out["row_lse"])
+    if "ss" in blocks:
+        cn, wn, stats, sim = want["recss"]
+        assert torch.equal(cn, out["recss"][0]) and torch.equal(wn, out["recss"][1])
+        assert torch.equal(stats[:N], out["recss"][2][:N])
+        assert torch.equal(stats.view(-1)[4 * N:4 * N + rows], out["recss"][2].view(-1)[4 * N:4 * N + rows])  # (row terms)
+        assert torch.equal(sim[:rows, :rows], out["recss"][3][:rows, :rows])
