@@ -121,6 +121,16 @@ inline int sap_pairs_per_pass(int Tmax, int Q, int N) {
   return P;
 }
 
+// the wave-per-pair form (set losses): waves of a 1,024-thread workgroup that work side by side, a (Tmax x Q) block of
+// doubles in LDS each, within 60 KB
+constexpr int SAPW_THREADS = 1024;
+inline int sapw_waves_per_pass(int Tmax, int Q, int N) {
+  const size_t per = (size_t)Tmax * Q * 8;
+  int P = SAPW_THREADS / 64;
+  while (P > 1 && (per * P > 60 * 1024 || P / 2 >= N)) P >>= 1;
+  return per * P > 60 * 1024 ? 0 : P;
+}
+
 // fp32 cost block of pair b exactly as matcher.py:70-105 builds it, widened to fp64 for the solver
 __device__ __forceinline__ void sap_fill_cost(Sap& s, const float* __restrict__ logits, const float* __restrict__ spans,
                                               const float* __restrict__ tgt_cxw, const float* __restrict__ tgt_xx,
@@ -175,8 +185,87 @@ __global__ __launch_bounds__(64) void match_kernel(
   sap_assign(s, t0, T, Q, match_q);
 }
 
-// One thread per pair (chunks of P pairs); one workgroup, so the loss sums are reduced without atomics
-// (deterministic).  out[0..3] = loss_span, loss_giou, loss_label, class_error.  The span terms are means over the
+// ------------------------------------------------------------------------------------------
+// The same assignment with one WAVE per pair (round 5): lane = column.  The thread-per-pair form above is a chain of
+// dependent LDS round trips and fp64 operations -- 33 us for 32 pairs of 10 queries x <= 5 targets, with 31 of a wave's
+// lanes waiting on the longest pair -- and sat on the critical path of the criterion forward.  Here a column's state
+// (v, minv, way, used, its row p and THAT ROW's potential u) lives in its lane's registers; a step of the search is one
+// LDS read of the cost column, the elementwise fp64 updates of the sequential algorithm (the same operations on the same
+// operands: the potentials are bit-identical), a DPP minimum and a ballot for the first column that attains it (the
+// sequential scan's strict `<` keeps the lowest index too).  u travels with its row when the augmenting path reassigns it.
+__device__ __forceinline__ double dpp_min_f64_row(double v) {  // every lane: the minimum over its row of 16 lanes
+#define MESM_DMIN_STEP(CTRL)                                                                                   \
+  {                                                                                                            \
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, 0xF, 0xF, false);   \
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, 0xF, 0xF, false);   \
+    const double o = __hiloint2double(hi, lo);                                                                 \
+    v = o < v ? o : v;                                                                                         \
+  }
+  MESM_DMIN_STEP(0xB1)   // quad_perm [1,0,3,2]
+  MESM_DMIN_STEP(0x4E)   // quad_perm [2,3,0,1]
+  MESM_DMIN_STEP(0x141)  // row_half_mirror
+  MESM_DMIN_STEP(0x140)  // row_mirror
+#undef MESM_DMIN_STEP
+  return v;
+}
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+// cost: the pair's (T x Q) block in LDS as doubles, [t * Q + q].  QROWS as in sap_solve.  Returns this lane's column's row
+// (1-based, 0 = none): lane = query (QROWS false) or target (QROWS true).
+template <bool QROWS>
+__device__ __forceinline__ int sapw_solve(const double* __restrict__ cost, int T, int Q, int lane) {
+  const int nR = QROWS ? Q : T, nC = QROWS ? T : Q;
+  const bool col = lane < nC;
+  double v = 0.0, ucol = 0.0;
+  int p = 0;
+  for (int i = 1; i <= nR; ++i) {
+    double u_i = 0.0;  // the potential of row i, which sits in the virtual column 0 during the search
+    double minv = 1e300;
+    int way = 0, j0 = 0;
+    bool used = false;
+    for (int guard = 0; guard <= nC + 1; ++guard) {  // (a column joins the tree per turn: nC turns at most; NaN costs end here)
+      if (lane == j0 - 1) used = true;
+      const int i0 = j0 ? __builtin_amdgcn_readlane(p, j0 - 1) : i;
+      const double ui0 = j0 ? readlane_f64(ucol, j0 - 1) : u_i;
+      double key = 1e300;
+      if (col && !used) {
+        const double c = QROWS ? cost[lane * Q + (i0 - 1)] : cost[(i0 - 1) * Q + lane];
+        const double cur = c - ui0 - v;
+        if (cur < minv) { minv = cur; way = j0; }
+        key = minv;
+      }
+      double m = dpp_min_f64_row(key);
+      if (nC > 16) {
+        const double m1 = readlane_f64(m, 16), m2 = readlane_f64(m, 32), m3 = readlane_f64(m, 48);
+        m = readlane_f64(m, 0);
+        m = m1 < m ? m1 : m; m = m2 < m ? m2 : m; m = m3 < m ? m3 : m;
+      } else {
+        m = readlane_f64(m, 0);
+      }
+      const double delta = m;
+      int j1 = 0;
+      if (delta < 1e300) j1 = __ffsll((unsigned long long)__ballot(key == delta));  // first column at the minimum, 1-based
+      if (used) { ucol += delta; v -= delta; }
+      else if (col) minv -= delta;
+      u_i += delta;
+      j0 = j1;
+      if (j0 == 0 || __builtin_amdgcn_readlane(p, j0 - 1) == 0) break;
+    }
+    for (int guard = 0; j0 && guard <= nC + 1; ++guard) {  // flip the path: column j0 takes the row of the column before it
+      const int j1 = __builtin_amdgcn_readlane(way, j0 - 1);
+      const int pj1 = j1 ? __builtin_amdgcn_readlane(p, j1 - 1) : i;
+      const double uj1 = j1 ? readlane_f64(ucol, j1 - 1) : u_i;
+      if (lane == j0 - 1) { p = pj1; ucol = uj1; }
+      j0 = j1;
+    }
+  }
+  return col ? p : 0;
+}
+
+// One wave per pair, `P` pairs per pass (the cost blocks' LDS budget); one workgroup, so the loss sums are reduced without
+// atomics (deterministic).  out[0..3] = loss_span, loss_giou, loss_label, class_error.  The span terms are means over the
 // MATCHED (query, target) pairs: sum_b min(T_b, Q) of them (criterion.py:104-107, :133).
 __device__ __forceinline__ void set_loss_fwd_body(const float* __restrict__ logits, const float* __restrict__ spans,
                                                   const float* __restrict__ tgt_cxw, const float* __restrict__ tgt_xx,
@@ -188,45 +277,62 @@ __device__ __forceinline__ void set_loss_fwd_body(const float* __restrict__ logi
   // they take no part in the matching, the sums or the denominators
   if (n_valid) N = *n_valid;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int nthr = P, tid = threadIdx.x;  // P pairs per pass (LDS budget); threads >= P idle
-  Sap s;
-  s.carve(smem, Tmax, Q, nthr, tid);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (int)(blockDim.x >> 6);
+  double* cost = reinterpret_cast<double*>(smem) + (size_t)wave * Tmax * Q;
   __shared__ float red[5][16];
 
   float a_l1 = 0.0f, a_giou = 0.0f, a_ce = 0.0f, a_ok = 0.0f, a_cnt = 0.0f;
-  for (int b0 = 0; b0 < N; b0 += nthr) {
-    const int b = b0 + tid;
-    if (tid < P && b < N) {
+  if (wave < P) {
+    for (int b = wave; b < N; b += P) {
       const int t0 = tgt_off[b];
       const int T = tgt_off[b + 1] - t0;
-      sap_fill_cost(s, logits, spans, tgt_cxw, tgt_xx, b, t0, T, Q, w_span, w_giou, w_class, nullptr, Tmax);
-      sap_assign(s, t0, T, Q, match_q);
-      uint64_t matched = 0;
-      for (int k = 0; k < T; ++k) {
-        const int t = t0 + k, q = match_q[t];  // (this thread's own stores)
-        if (q >= 0) {
-          matched |= 1ull << q;
-          a_cnt += 1.0f;
-          const float cx = spans[((int64_t)b * Q + q) * 2], w = spans[((int64_t)b * Q + q) * 2 + 1];
-          a_l1 += fabsf(cx - tgt_cxw[(int64_t)t * 2]) + fabsf(w - tgt_cxw[(int64_t)t * 2 + 1]);
-          Giou gi;
-          a_giou += 1.0f - giou_1d(cx - 0.5f * w, cx + 0.5f * w, tgt_xx[(int64_t)t * 2],
-                                   tgt_xx[(int64_t)t * 2 + 1], gi);
-          const float l0 = logits[((int64_t)b * Q + q) * 2], l1 = logits[((int64_t)b * Q + q) * 2 + 1];
-          a_ok += (l0 >= l1) ? 1.0f : 0.0f;  // argmax == foreground (first max wins)
-        }
+      const float* lg = logits + (int64_t)b * Q * 2;
+      const float* sp = spans + (int64_t)b * Q * 2;
+      // fp32 cost block exactly as matcher.py:70-105 builds it, widened to fp64 for the solver (sap_fill_cost)
+      for (int e = lane; e < T * Q; e += 64) {
+        const int t = e / Q, q = e - t * Q;
+        const float l0 = lg[q * 2], l1 = lg[q * 2 + 1];
+        const float mx = fmaxf(l0, l1);
+        const float e0 = expf(l0 - mx), e1 = expf(l1 - mx);
+        const float prob0 = e0 / (e0 + e1);
+        const float cx = sp[q * 2], w = sp[q * 2 + 1];
+        const float tc = tgt_cxw[(int64_t)(t0 + t) * 2], tw = tgt_cxw[(int64_t)(t0 + t) * 2 + 1];
+        const float g1 = tgt_xx[(int64_t)(t0 + t) * 2], g2 = tgt_xx[(int64_t)(t0 + t) * 2 + 1];
+        const float c_span = fabsf(cx - tc) + fabsf(w - tw);
+        Giou gi;
+        const float giou = giou_1d(cx - 0.5f * w, cx + 0.5f * w, g1, g2, gi);
+        cost[e] = (double)(w_span * c_span + w_giou * (-giou) + w_class * (-prob0));
       }
-      for (int q = 0; q < Q; ++q) {
-        const float l0 = logits[((int64_t)b * Q + q) * 2], l1 = logits[((int64_t)b * Q + q) * 2 + 1];
+      // (a wave's LDS writes are visible to its own later reads: no barrier between the waves' independent problems)
+      int q = -1, t = -1;  // this lane's matched (query, target), if it has one
+      bool fg = false;     // lane = query: is it matched
+      if (T < Q) {
+        const int r = sapw_solve<false>(cost, T, Q, lane);  // lane = query, r = its target (1-based)
+        if (r) { q = lane; t = t0 + r - 1; match_q[t] = lane; }
+        fg = r != 0;
+      } else {
+        const int r = sapw_solve<true>(cost, T, Q, lane);  // lane = target, r = its query (0: the target stays unmatched)
+        if (lane < T) match_q[t0 + lane] = r - 1;
+        if (r) { q = r - 1; t = t0 + lane; }
+        fg = true;  // every query is a row of the assignment: all matched
+      }
+      if (q >= 0) {
+        a_cnt += 1.0f;
+        const float cx = sp[q * 2], w = sp[q * 2 + 1];
+        a_l1 += fabsf(cx - tgt_cxw[(int64_t)t * 2]) + fabsf(w - tgt_cxw[(int64_t)t * 2 + 1]);
+        Giou gi;
+        a_giou += 1.0f - giou_1d(cx - 0.5f * w, cx + 0.5f * w, tgt_xx[(int64_t)t * 2], tgt_xx[(int64_t)t * 2 + 1], gi);
+        a_ok += (lg[q * 2] >= lg[q * 2 + 1]) ? 1.0f : 0.0f;  // argmax == foreground (first max wins)
+      }
+      if (lane < Q) {
+        const float l0 = lg[lane * 2], l1 = lg[lane * 2 + 1];
         const float mx = fmaxf(l0, l1);
         const float lse = mx + logf(expf(l0 - mx) + expf(l1 - mx));
-        const bool fg = (matched >> q) & 1ull;
         a_ce += fg ? -(l0 - lse) : -(l1 - lse) * eos_coef;
       }
     }
   }
   float vals[5] = {a_l1, a_giou, a_ce, a_ok, a_cnt};
-  const int lane = tid & 63, wave = tid >> 6, nw = (int)(blockDim.x >> 6);
 #pragma unroll
   for (int k = 0; k < 5; ++k) {
     float v = wave_sum(vals[k]);
@@ -245,7 +351,7 @@ __device__ __forceinline__ void set_loss_fwd_body(const float* __restrict__ logi
   }
 }
 
-__global__ void set_loss_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ spans,
+__global__ __launch_bounds__(SAPW_THREADS) void set_loss_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ spans,
                                     const float* __restrict__ tgt_cxw, const float* __restrict__ tgt_xx,
                                     const int32_t* __restrict__ tgt_off, int N, int Q, int Tmax,
                                     float w_span, float w_giou, float w_class, float eos_coef, int P,
@@ -256,7 +362,7 @@ __global__ void set_loss_fwd_kernel(const float* __restrict__ logits, const floa
 }
 
 // The decoder layers' set losses (main + auxiliary, criterion.py:338-357) are independent one-workgroup latency chains
-// (~28 us each: the assignment is sequential fp64 arithmetic): one launch, a workgroup per layer.
+// (a wave per pair, the pairs' loss terms summed inside the workgroup): one launch, a workgroup per layer.
 constexpr int SET_LAYERS_MAX = 8;
 struct SetLossLayers {
   const float* logits[SET_LAYERS_MAX];
@@ -264,7 +370,7 @@ struct SetLossLayers {
   int32_t* match_q[SET_LAYERS_MAX];
   float* out[SET_LAYERS_MAX];
 };
-__global__ void set_loss_fwd_layers_kernel(const SetLossLayers L, const float* __restrict__ tgt_cxw,
+__global__ __launch_bounds__(SAPW_THREADS) void set_loss_fwd_layers_kernel(const SetLossLayers L, const float* __restrict__ tgt_cxw,
                                            const float* __restrict__ tgt_xx, const int32_t* __restrict__ tgt_off, int N,
                                            int Q, int Tmax, float w_span, float w_giou, float w_class, float eos_coef, int P,
                                            const int32_t* __restrict__ n_valid) {
@@ -703,9 +809,12 @@ __global__ __launch_bounds__(256) void ss_bwd_kernel(
 template <int NE>
 __global__ __launch_bounds__(256) void crit_bwd_kernel(const MesmCritBwd a, const int4 r0, const int4 r1) {
   extern __shared__ float dyn_[];  // (ss_bwd_body's dsim: the same dynamic segment)
-  const int bid = blockIdx.x;
+  // the rec_ss workgroups are the long ones (one per pair, ~19 us): they take the first block indices so that they start
+  // first, the thousands of short NLL row groups fill in behind them
+  const int nss = r0.w - r0.z;
+  const int bid = (int)blockIdx.x < nss ? r0.z + (int)blockIdx.x : (int)blockIdx.x - nss;
   const float gt = a.g_total[0];
-  // role starts: r0 = (set layers end, saliency end, nll end, ss end); r1.x = workgroups per set layer, r1.y = nll column groups
+  // role ranges: r0 = (set layers end, saliency end, nll end, ss end); r1.x = workgroups per set layer, r1.y = nll column groups
   if (bid < r0.x) {
     const int l = bid / r1.x, b = bid - l * r1.x;
     const float* w = a.weights + a.set_slot[l];
@@ -986,10 +1095,10 @@ extern "C" int mesm_set_loss_fwd_nv(const float* logits, const float* spans, con
                                     float eos_coef, int32_t* match_q, float* out4, const int32_t* n_valid, void* stream) {
   if (!logits || !spans || !tgt_cxw || !tgt_xx || !tgt_off || !match_q || !out4) return MESM_EINVAL;
   if (N <= 0 || Q <= 0 || Q > 64 || Tmax <= 0 || Tmax > 64) return MESM_EINVAL;
-  const size_t per = sap_bytes_per_thread(Tmax, Q);
-  const int P = sap_pairs_per_pass(Tmax, Q, N);
+  const size_t per = (size_t)Tmax * Q * 8;
+  const int P = sapw_waves_per_pass(Tmax, Q, N);
   if (P == 0) return MESM_EINVAL;
-  hipLaunchKernelGGL(set_loss_fwd_kernel, dim3(1), dim3(64), per * P, (hipStream_t)stream, logits, spans,
+  hipLaunchKernelGGL(set_loss_fwd_kernel, dim3(1), dim3(SAPW_THREADS), per * P, (hipStream_t)stream, logits, spans,
                      tgt_cxw, tgt_xx, tgt_off, N, Q, Tmax, w_span, w_giou, w_class, eos_coef, P,
                      match_q, out4, n_valid);
   return mesm_launch_status();
@@ -1021,10 +1130,10 @@ extern "C" int mesm_set_loss_fwd_layers(const float* const* logits, const float*
     if (!logits[k] || !spans[k] || !match_q[k] || !out4[k]) return MESM_EINVAL;
     L.logits[k] = logits[k]; L.spans[k] = spans[k]; L.match_q[k] = match_q[k]; L.out[k] = out4[k];
   }
-  const size_t per = sap_bytes_per_thread(Tmax, Q);
-  const int P = sap_pairs_per_pass(Tmax, Q, N);
+  const size_t per = (size_t)Tmax * Q * 8;
+  const int P = sapw_waves_per_pass(Tmax, Q, N);
   if (P == 0) return MESM_EINVAL;
-  hipLaunchKernelGGL(set_loss_fwd_layers_kernel, dim3(n_layers), dim3(64), per * P, (hipStream_t)stream, L, tgt_cxw, tgt_xx,
+  hipLaunchKernelGGL(set_loss_fwd_layers_kernel, dim3(n_layers), dim3(SAPW_THREADS), per * P, (hipStream_t)stream, L, tgt_cxw, tgt_xx,
                      tgt_off, N, Q, Tmax, w_span, w_giou, w_class, eos_coef, P, n_valid);
   return mesm_launch_status();
 }
@@ -1114,9 +1223,9 @@ extern "C" int mesm_criterion_fwd(const MesmCritFwd* args, void* stream) {
     for (int l = 0; l < a.n_set; ++l)
       if (!a.set_logits[l] || !a.set_spans[l] || !a.set_match[l] || a.set_slot[l] < 0 || a.set_slot[l] + 4 > a.n_slots)
         return MESM_EINVAL;
-    P = sap_pairs_per_pass(a.Tmax, a.Q, a.N);
+    P = sapw_waves_per_pass(a.Tmax, a.Q, a.N);
     if (P == 0) return MESM_EINVAL;
-    lds = sap_bytes_per_thread(a.Tmax, a.Q) * P;
+    lds = (size_t)a.Tmax * a.Q * 8 * P;
   }
   bool sal_inside = false;
   if (a.sal_on) {
