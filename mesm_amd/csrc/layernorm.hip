@@ -291,6 +291,7 @@ __device__ __forceinline__ void ln_bwd_body(
         for (int e = 0; e < VEC; ++e) { xh[c][e] = 0.0f; dv[c][e] = 0.0f; }
       }
     }
+    if (dx == nullptr) continue;  // parameter gradients only (a grouped launch's input LayerNorm over raw features)
     const float c1 = wave_sum(s1) * invD;
     const float c2 = wave_sum(s2) * invD;
     float* dxr = dx + row * D;
@@ -582,17 +583,20 @@ extern "C" int mesm_layernorm_bwd(const float* dy, const float* x, const float* 
 
 // ------------------------------------------------------------------------------------------------
 // Grouped launches: independent LayerNorms of one launch phase (the lockstep chains of ops.py) share ONE kernel.
-// Problems of the common class (D <= 256, D % 4 == 0, 16-byte aligned: one float4 chunk per lane) go into groups of up
-// to LN_GROUP_MAX; anything else runs through the plain entry points.
+// Problems of the two common classes (D <= 256 or D <= 512, D % 4 == 0, 16-byte aligned: one / two float4 chunks per
+// lane) go into groups of up to LN_GROUP_MAX per class; anything else runs through the plain entry points.
 namespace {
 
-bool ln_group_class(const MesmLnArgs& a, bool bwd) {
-  if (a.D > 256 || a.D % 4 != 0 || a.rows <= 0) return false;
+// 0: runs alone; 1: D <= 256 (one float4 chunk per lane); 2: D <= 512 (two chunks: the 512-d text features' input
+// LayerNorms -- words, sentences, the two learned tokens -- used to be four launches forward and four backward)
+int ln_group_class(const MesmLnArgs& a, bool bwd) {
+  if (a.D > 512 || a.D % 4 != 0 || a.rows <= 0) return 0;
   const void* ps[] = {a.x, a.gamma, a.beta, a.y, a.add, a.y2, a.dy, a.dx, a.dx2, a.dyb, a.addend};
   for (const void* q : ps)
-    if (q != nullptr && ((uintptr_t)q % 16) != 0) return false;
-  if (bwd && a.dx == nullptr) return false;  // parameter gradients only: the column-parallel kernel
-  return true;
+    if (q != nullptr && ((uintptr_t)q % 16) != 0) return 0;
+  // parameter gradients only: the column-parallel kernel, unless the problem is small enough to ride in a group
+  if (bwd && a.dx == nullptr && (a.rows > 2048 || a.accumulate_dx || a.dx2 || a.addend || a.relu_in)) return 0;
+  return a.D <= 256 ? 1 : 2;
 }
 
 LnProb ln_prob(const MesmLnArgs& a) {
@@ -613,71 +617,82 @@ LnProb ln_prob(const MesmLnArgs& a) {
 extern "C" int mesm_layernorm_fwd_group(const MesmLnArgs* list, int32_t n, void* stream) {
   if (!list || n <= 0 || n > 64) return MESM_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  LnGroup g;
-  g.n = 0;
-  g.start[0] = 0;
+  LnGroup g[2];  // one per class
+  g[0].n = g[1].n = 0;
+  g[0].start[0] = g[1].start[0] = 0;
   int rc = MESM_OK;
-  auto flush = [&]() {
-    if (g.n == 0) return;
-    hipLaunchKernelGGL((ln_fwd_group_kernel<4, 1>), dim3((unsigned)g.start[g.n]), dim3(LN_THREADS), 0, s, g);
+  auto flush = [&](int c) {
+    if (g[c].n == 0) return;
+    if (c == 0)
+      hipLaunchKernelGGL((ln_fwd_group_kernel<4, 1>), dim3((unsigned)g[c].start[g[c].n]), dim3(LN_THREADS), 0, s, g[c]);
+    else
+      hipLaunchKernelGGL((ln_fwd_group_kernel<4, 2>), dim3((unsigned)g[c].start[g[c].n]), dim3(LN_THREADS), 0, s, g[c]);
     rc = mesm_launch_status();
-    g.n = 0;
+    g[c].n = 0;
   };
-  int ngroupable = 0;
-  for (int i = 0; i < n; ++i) ngroupable += ln_group_class(list[i], false) ? 1 : 0;
+  int ngroupable[3] = {0, 0, 0};
+  for (int i = 0; i < n; ++i) ngroupable[ln_group_class(list[i], false)]++;
   for (int i = 0; i < n && rc == MESM_OK; ++i) {
     const MesmLnArgs& a = list[i];
     if ((a.add == nullptr) != (a.y2 == nullptr) || a.drop_p < 0.f || a.drop_p >= 1.f) return MESM_EINVAL;
-    if (ngroupable >= 2 && ln_group_class(a, false)) {
+    const int cls = ln_group_class(a, false);
+    if (cls && ngroupable[cls] >= 2) {
       if (!a.x || !a.gamma || !a.beta || !a.y || !a.mean || !a.rstd) return MESM_EINVAL;
       int64_t blocks = (a.rows + LN_WAVES - 1) / LN_WAVES;
       if (blocks > 4096) blocks = 4096;
-      g.p[g.n] = ln_prob(a);
-      g.start[g.n + 1] = g.start[g.n] + (int)blocks;
-      if (++g.n == LN_GROUP_MAX) flush();
+      LnGroup& gg = g[cls - 1];
+      gg.p[gg.n] = ln_prob(a);
+      gg.start[gg.n + 1] = gg.start[gg.n] + (int)blocks;
+      if (++gg.n == LN_GROUP_MAX) flush(cls - 1);
     } else {
       rc = mesm_layernorm_fwd2(a.x, a.gamma, a.beta, a.y, a.mean, a.rstd, a.rows, a.D, a.eps, a.drop_p, a.drop_seed,
                                a.seed_offset, a.add, a.y2, stream);
     }
   }
-  if (rc == MESM_OK) flush();
+  for (int c = 0; c < 2 && rc == MESM_OK; ++c) flush(c);
   return rc;
 }
 
 extern "C" int mesm_layernorm_bwd_group(const MesmLnArgs* list, int32_t n, void* stream) {
   if (!list || n <= 0 || n > 64) return MESM_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  LnGroup g;
-  g.n = 0;
-  g.start[0] = 0;
+  LnGroup g[2];
+  g[0].n = g[1].n = 0;
+  g[0].start[0] = g[1].start[0] = 0;
   int rc = MESM_OK;
-  auto flush = [&]() {
-    if (g.n == 0) return;
-    hipLaunchKernelGGL((ln_bwd_group_kernel<4, 1>), dim3((unsigned)g.start[g.n]), dim3(LNB_THREADS),
-                       (size_t)LNB_WAVES * 256 * sizeof(float), s, g);
+  auto flush = [&](int c) {
+    if (g[c].n == 0) return;
+    if (c == 0)
+      hipLaunchKernelGGL((ln_bwd_group_kernel<4, 1>), dim3((unsigned)g[c].start[g[c].n]), dim3(LNB_THREADS),
+                         (size_t)LNB_WAVES * 256 * sizeof(float), s, g[c]);
+    else
+      hipLaunchKernelGGL((ln_bwd_group_kernel<4, 2>), dim3((unsigned)g[c].start[g[c].n]), dim3(LNB_THREADS),
+                         (size_t)LNB_WAVES * 512 * sizeof(float), s, g[c]);
     rc = mesm_launch_status();
-    g.n = 0;
+    g[c].n = 0;
   };
-  int ngroupable = 0;
-  for (int i = 0; i < n; ++i) ngroupable += ln_group_class(list[i], true) ? 1 : 0;
+  int ngroupable[3] = {0, 0, 0};
+  for (int i = 0; i < n; ++i) ngroupable[ln_group_class(list[i], true)]++;
   for (int i = 0; i < n && rc == MESM_OK; ++i) {
     const MesmLnArgs& a = list[i];
     if (a.drop_p < 0.f || a.drop_p >= 1.f || a.drop2_p < 0.f || a.drop2_p >= 1.f) return MESM_EINVAL;
-    if (a.relu_in && !ln_group_class(a, true)) return MESM_EINVAL;  // the ReLU mask exists on the grouped kernel only
-    if ((ngroupable >= 2 || a.relu_in) && ln_group_class(a, true)) {
+    const int cls = ln_group_class(a, true);
+    if (a.relu_in && cls == 0) return MESM_EINVAL;  // the ReLU mask exists on the grouped kernels only
+    if (cls && (ngroupable[cls] >= 2 || a.relu_in)) {
       if (!a.dy || !a.x || !a.gamma || !a.mean || !a.rstd || !a.dgamma || !a.dbeta) return MESM_EINVAL;
       int64_t blocks = (a.rows + LNB_WAVES - 1) / LNB_WAVES;
       const int64_t cap = a.rows >= 4000 ? MESM_LNB_CAP : MESM_LNB_CAP / 2;
       if (blocks > cap) blocks = cap;
-      g.p[g.n] = ln_prob(a);
-      g.start[g.n + 1] = g.start[g.n] + (int)blocks;
-      if (++g.n == LN_GROUP_MAX) flush();
+      LnGroup& gg = g[cls - 1];
+      gg.p[gg.n] = ln_prob(a);
+      gg.start[gg.n + 1] = gg.start[gg.n] + (int)blocks;
+      if (++gg.n == LN_GROUP_MAX) flush(cls - 1);
     } else {
       rc = mesm_layernorm_bwd3(a.dy, a.x, a.gamma, a.mean, a.rstd, a.dx, a.dgamma, a.dbeta, a.rows, a.D, a.accumulate_dx,
                                a.drop_p, a.drop_seed, a.seed_offset, a.dx2, a.drop2_p, a.drop2_seed, a.dyb, a.addend,
                                stream);
     }
   }
-  if (rc == MESM_OK) flush();
+  for (int c = 0; c < 2 && rc == MESM_OK; ++c) flush(c);
   return rc;
 }

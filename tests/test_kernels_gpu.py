@@ -906,12 +906,17 @@ def test_gemm_row_split_keeps_the_dropout_mask_and_every_epilogue_term():
 def test_layernorm_group_matches_individual_launches():
     """mesm_layernorm_{fwd,bwd}_group: the LayerNorms of one launch phase (different row counts, fused dropout,
     second output, gradient joins, masked second gradient) in shared launches give bit for bit what the plain
-    launches give; a wide problem (D = 2818) in the same phase falls through to its own launch."""
+    launches give; a wide problem (D = 2818) in the same phase falls through to its own launch, the 512-wide ones
+    share a launch of their own class."""
     from mesm_amd import kernels as kn
     D = 256
     specs = [dict(rows=32), dict(rows=1024, add=True), dict(rows=4800, drop=(0.5, 11)), dict(rows=75, dyb=True, addend=True),
              dict(rows=2400, drop2=(0.1, 5)), dict(rows=7, add=True, dyb=True), dict(rows=300, D=2818),
-             dict(rows=33), dict(rows=640, addend=True, drop2=(0.1, 77)), dict(rows=1), dict(rows=129)]
+             dict(rows=33), dict(rows=640, addend=True, drop2=(0.1, 77)), dict(rows=1), dict(rows=129),
+             # the second class (256 < D <= 512: two chunks per lane) and parameter-gradient-only members
+             dict(rows=1024, D=512, drop=(0.5, 3), no_dx=True), dict(rows=32, D=512, no_dx=True), dict(rows=1, D=512),
+             dict(rows=1, D=512, drop=(0.1, 9)), dict(rows=77, D=384, add=True, dyb=True), dict(rows=50, no_dx=True),
+             dict(rows=3000, D=512, no_dx=True)]
     probs = []
     for i, sp in enumerate(specs):
         d = sp.get("D", D)
@@ -936,8 +941,8 @@ def test_layernorm_group_matches_individual_launches():
             for (sp, x, g, b, add, dy, dyb, addend), f in zip(probs, fw):
                 dg, db = torch.zeros_like(g), torch.zeros_like(b)
                 r = kn.layernorm_bwd(dy, x, g, f[1], f[2], dg, db, drop=sp.get("drop", (0.0, 0)), drop2=sp.get("drop2"),
-                                     dyb=dyb, addend=addend)
-                outs.append(list(f) + (list(r) if isinstance(r, tuple) else [r]) + [dg, db])
+                                     dyb=dyb, addend=addend, need_dx=not sp.get("no_dx"))
+                outs.append(list(f) + ([] if r is None else list(r) if isinstance(r, tuple) else [r]) + [dg, db])
         torch.cuda.synchronize()
         return outs
 
