@@ -751,6 +751,36 @@ int mesm_add_wrap(const float* a, const float* b, float* out, int64_t n, int64_t
 /* out[i] = srcs[0][i] + ... + srcs[k - 1][i], 1 <= k <= 8, n % 4 == 0, 16-byte aligned: the gradient of a tensor with
  * several consumers in one launch (mesm_amd.ops.fork) instead of the autograd engine's k - 1 pairwise adds. */
 int mesm_add_n(const float* const* srcs, int32_t k, float* out, int64_t n, void* stream);
+
+/*
+ * Assembly problems of one launch phase in ONE launch (mesm_glue_group): independent members -- none reads what another
+ * writes -- of the kinds below, with the argument meaning of the plain entry point of the same name.  op-specific
+ * fields: p = pointers in the order of that entry point's pointer arguments, n / i = its extents:
+ *   TOKEN_MIX_FWD   p: x, m1, tok1, m2, tok2, y          n[0] rows         i[0] D
+ *   TOKEN_MIX_BWD   p: dy, m1, m2, dx, dtok1, dtok2      n[0] rows         i[0] D
+ *   GATHER_ROWS_FWD p: x, idx, valid, y, rnorm           n[0] rows         i[0] D, i[1] normalize
+ *   GATHER_ROWS_BWD p: dy, y, rnorm, inv, valid, dx      n[0] source rows  i[0] D, i[1] normalize
+ *   UNSTACK_ROWS    p: d2, idx, dx                       n[0] R            i[0] N
+ *   STACK_ROWS      p: src, dst, idx (NULL: repeat)      n[0] row bytes    i[0] N      (one tensor of mesm_stack_rows)
+ *   ADD_TILE        p: a, b, out   out[k] = a[k % na] + b[k % nb]: n[0] = elements of out, n[1] = na, i[0..1] = nb as int64
+ */
+enum {
+  MESM_GLUE_TOKEN_MIX_FWD = 1,
+  MESM_GLUE_TOKEN_MIX_BWD = 2,
+  MESM_GLUE_GATHER_ROWS_FWD = 3,
+  MESM_GLUE_GATHER_ROWS_BWD = 4,
+  MESM_GLUE_UNSTACK_ROWS = 5,
+  MESM_GLUE_STACK_ROWS = 6,
+  MESM_GLUE_ADD_TILE = 7
+};
+typedef struct MesmGlueArgs {
+  int32_t op;
+  int32_t reserved0;
+  int32_t i[6];
+  int64_t n[2];
+  const void* p[8];
+} MesmGlueArgs;
+int mesm_glue_group(const MesmGlueArgs* list, int32_t n, void* stream);
 /* First node of a captured training step (no counterpart in the reference: its forward draws on the host and indexes
  * with host tensors, model.py:260, 361-384): copies slot (*pull_ctr % slots) of a ring of `slots` x slot_bytes in PINNED
  * HOST memory (device-readable) to dst, then *pull_ctr += 1 and, when given, *seed_ctr += 1 (the dropout seed offset of

@@ -77,6 +77,15 @@ class LnArgs(ctypes.Structure):
     ]
 
 
+class GlueArgs(ctypes.Structure):
+    _fields_ = [("op", ctypes.c_int32), ("reserved0", ctypes.c_int32), ("i", ctypes.c_int32 * 6), ("n", ctypes.c_int64 * 2),
+                ("p", c_ptr * 8)]
+
+
+GLUE_TOKEN_MIX_FWD, GLUE_TOKEN_MIX_BWD, GLUE_GATHER_ROWS_FWD, GLUE_GATHER_ROWS_BWD = 1, 2, 3, 4
+GLUE_UNSTACK_ROWS, GLUE_STACK_ROWS, GLUE_ADD_TILE = 5, 6, 7
+
+
 class CritFwdArgs(ctypes.Structure):
     _fields_ = [
         ("weights", c_ptr), ("lv", c_ptr), ("total", c_ptr), ("n_valid", c_ptr),
@@ -222,6 +231,7 @@ PROTOTYPES = {
     "mesm_ddp_last_error": (ctypes.c_char_p, []),
     "mesm_weighted_sum": (ctypes.c_int, [c_ptr, c_ptr, _i32, c_ptr, c_ptr]),
     "mesm_scale_vec": (ctypes.c_int, [c_ptr, c_ptr, _i32, c_ptr, c_ptr]),
+    "mesm_glue_group": (ctypes.c_int, [ctypes.POINTER(GlueArgs), _i32, c_ptr]),
     "mesm_criterion_fwd": (ctypes.c_int, [ctypes.POINTER(CritFwdArgs), c_ptr]),
     "mesm_criterion_bwd": (ctypes.c_int, [ctypes.POINTER(CritBwdArgs), c_ptr]),
 }

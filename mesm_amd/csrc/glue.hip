@@ -40,10 +40,10 @@ __global__ __launch_bounds__(256) void stack_rows_kernel(const StackArgs a) {
 
 // backward of one float tensor: dx[i, :] = d2[i, :] + sum over j with idx[j] == i of d2[N + j, :]
 // (idx == NULL: j == i).  Deterministic: every output row gathers its contributors (N <= a few hundred).
-__global__ __launch_bounds__(256) void unstack_rows_kernel(const float* __restrict__ d2, const int64_t* __restrict__ idx,
-                                                           float* __restrict__ dx, int N, int64_t R) {
-  const int i = blockIdx.x;
-  const int64_t c0 = ((int64_t)blockIdx.y * 256 + threadIdx.x) * 4;
+__device__ __forceinline__ void unstack_rows_body(const float* __restrict__ d2, const int64_t* __restrict__ idx,
+                                                  float* __restrict__ dx, int N, int64_t R, int bx, int by) {
+  const int i = bx;
+  const int64_t c0 = ((int64_t)by * 256 + threadIdx.x) * 4;
   if (c0 >= R) return;
   float4 acc = *reinterpret_cast<const float4*>(d2 + (int64_t)i * R + c0);
   if (idx == nullptr) {
@@ -57,6 +57,11 @@ __global__ __launch_bounds__(256) void unstack_rows_kernel(const float* __restri
       }
   }
   *reinterpret_cast<float4*>(dx + (int64_t)i * R + c0) = acc;
+}
+
+__global__ __launch_bounds__(256) void unstack_rows_kernel(const float* __restrict__ d2, const int64_t* __restrict__ idx,
+                                                           float* __restrict__ dx, int N, int64_t R) {
+  unstack_rows_body(d2, idx, dx, N, R, blockIdx.x, blockIdx.y);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -173,11 +178,11 @@ __global__ __launch_bounds__(256) void split_bwd_kernel(const float* __restrict_
 // mask is set, else 0; dtok1 += sum of dy over (m1 & ~m2) rows, dtok2 += sum over m2 rows (atomics, one
 // partial per workgroup of 32 rows).
 constexpr int TM_ROWS = 8;
-__global__ __launch_bounds__(256) void token_mix_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ m1,
-                                                            const float* __restrict__ tok1, const uint8_t* __restrict__ m2,
-                                                            const float* __restrict__ tok2, float* __restrict__ y,
-                                                            int64_t rows, int D) {
-  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+__device__ __forceinline__ void token_mix_fwd_body(const float* __restrict__ x, const uint8_t* __restrict__ m1,
+                                                   const float* __restrict__ tok1, const uint8_t* __restrict__ m2,
+                                                   const float* __restrict__ tok2, float* __restrict__ y,
+                                                   int64_t rows, int D, int bx) {
+  const int64_t r = (int64_t)bx * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
   const float* s = x + r * D;
   if (m2 && m2[r]) s = tok2;
@@ -186,11 +191,18 @@ __global__ __launch_bounds__(256) void token_mix_fwd_kernel(const float* __restr
     *reinterpret_cast<float4*>(y + r * D + c) = *reinterpret_cast<const float4*>(s + c);
 }
 
-__global__ __launch_bounds__(256) void token_mix_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ m1,
-                                                            const uint8_t* __restrict__ m2, float* __restrict__ dx,
-                                                            float* __restrict__ dtok1, float* __restrict__ dtok2,
+__global__ __launch_bounds__(256) void token_mix_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ m1,
+                                                            const float* __restrict__ tok1, const uint8_t* __restrict__ m2,
+                                                            const float* __restrict__ tok2, float* __restrict__ y,
                                                             int64_t rows, int D) {
-  const int64_t r0 = (int64_t)blockIdx.x * TM_ROWS;
+  token_mix_fwd_body(x, m1, tok1, m2, tok2, y, rows, D, blockIdx.x);
+}
+
+__device__ __forceinline__ void token_mix_bwd_body(const float* __restrict__ dy, const uint8_t* __restrict__ m1,
+                                                   const uint8_t* __restrict__ m2, float* __restrict__ dx,
+                                                   float* __restrict__ dtok1, float* __restrict__ dtok2,
+                                                   int64_t rows, int D, int bx) {
+  const int64_t r0 = (int64_t)bx * TM_ROWS;
   const int64_t r1 = (r0 + TM_ROWS) < rows ? (r0 + TM_ROWS) : rows;
   // the rows' mask bytes first, into LDS: read inside the loop they made every iteration wait for a global load
   __shared__ uint8_t mk1[TM_ROWS], mk2[TM_ROWS];
@@ -219,6 +231,13 @@ __global__ __launch_bounds__(256) void token_mix_bwd_kernel(const float* __restr
   }
 }
 
+__global__ __launch_bounds__(256) void token_mix_bwd_kernel(const float* __restrict__ dy, const uint8_t* __restrict__ m1,
+                                                            const uint8_t* __restrict__ m2, float* __restrict__ dx,
+                                                            float* __restrict__ dtok1, float* __restrict__ dtok2,
+                                                            int64_t rows, int D) {
+  token_mix_bwd_body(dy, m1, m2, dx, dtok1, dtok2, rows, D, blockIdx.x);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // gather_rows: y[j, :] = valid[j] ? x[idx[j], :] : 0 (valid == NULL: all), optionally L2-normalised with
 // F.normalize's eps (norm = 1: y / max(||y||, 1e-12), the reconstructed sentence token model.py:486).
@@ -227,11 +246,11 @@ __global__ __launch_bounds__(256) void token_mix_bwd_kernel(const float* __restr
 // host (inv[i] = j with idx[j] == i, or -1): dx[i, :] = inv[i] >= 0 ? dy-through-the-normalisation : 0, every
 // source row written exactly once -- no zero fill, no atomics.  (Rows gathered more than once are not
 // supported by this kernel; those sites keep index_add.)
-__global__ __launch_bounds__(256) void gather_rows_fwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx,
-                                                              const uint8_t* __restrict__ valid, float* __restrict__ y,
-                                                              float* __restrict__ rnorm, int64_t rows, int D, int norm) {
+__device__ __forceinline__ void gather_rows_fwd_body(const float* __restrict__ x, const int64_t* __restrict__ idx,
+                                                     const uint8_t* __restrict__ valid, float* __restrict__ y,
+                                                     float* __restrict__ rnorm, int64_t rows, int D, int norm, int bx) {
   const int lane = threadIdx.x & 63;
-  const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t j = (int64_t)bx * 4 + (threadIdx.x >> 6);
   if (j >= rows) return;
   const bool ok = valid == nullptr || valid[j] != 0;
   const float* s = x + idx[j] * D;
@@ -247,12 +266,18 @@ __global__ __launch_bounds__(256) void gather_rows_fwd_kernel(const float* __res
   for (int c = lane; c < D; c += 64) y[j * D + c] = ok ? s[c] * inv : 0.0f;
 }
 
-__global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                              const float* __restrict__ rnorm, const int64_t* __restrict__ inv,
-                                                              const uint8_t* __restrict__ valid, float* __restrict__ dx,
-                                                              int64_t src_rows, int D, int norm) {
+__global__ __launch_bounds__(256) void gather_rows_fwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx,
+                                                              const uint8_t* __restrict__ valid, float* __restrict__ y,
+                                                              float* __restrict__ rnorm, int64_t rows, int D, int norm) {
+  gather_rows_fwd_body(x, idx, valid, y, rnorm, rows, D, norm, blockIdx.x);
+}
+
+__device__ __forceinline__ void gather_rows_bwd_body(const float* __restrict__ dy, const float* __restrict__ y,
+                                                     const float* __restrict__ rnorm, const int64_t* __restrict__ inv,
+                                                     const uint8_t* __restrict__ valid, float* __restrict__ dx,
+                                                     int64_t src_rows, int D, int norm, int bx) {
   const int lane = threadIdx.x & 63;
-  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t i = (int64_t)bx * 4 + (threadIdx.x >> 6);
   if (i >= src_rows) return;
   const int64_t j = inv[i];
   const bool ok = j >= 0 && (valid == nullptr || valid[j] != 0);
@@ -271,6 +296,13 @@ __global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const float* __res
   dot = wave_sum(dot);
   if (n <= 1e-12f) dot = 0.0f;
   for (int c = lane; c < D; c += 64) dx[i * D + c] = (dy[j * D + c] - y[j * D + c] * dot) / n;
+}
+
+__global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                              const float* __restrict__ rnorm, const int64_t* __restrict__ inv,
+                                                              const uint8_t* __restrict__ valid, float* __restrict__ dx,
+                                                              int64_t src_rows, int D, int norm) {
+  gather_rows_bwd_body(dy, y, rnorm, inv, valid, dx, src_rows, D, norm, blockIdx.x);
 }
 
 // ---- backward of a Linear with at most 4 output features (the last layers of the box / class / anchor heads,
@@ -352,6 +384,83 @@ __global__ __launch_bounds__(256) void add_n_kernel(const AddNSrc s, int k, floa
         t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
       }
     reinterpret_cast<float4*>(out)[i] = t;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Grouped launch: up to GLUE_MAX INDEPENDENT assembly problems of one launch phase -- the stacked copies, token mixes and
+// clip gathers in front of the enhance stage (model.py:260-325) were six launches of ~5 us forward and as many backward
+// -- as workgroup ranges of ONE grid.  Every member is a 256-thread byte mover; a problem's workgroups see their index
+// inside the problem's own (gx, gy) grid.  The same device functions as the plain launches: identical results.
+constexpr int GLUE_MAX = 16;
+struct GlueGroup {
+  MesmGlueArgs p[GLUE_MAX];
+  int start[GLUE_MAX + 1];  // first workgroup of every problem
+  int gx[GLUE_MAX];         // the problem's grid is (gx, (start[k + 1] - start[k]) / gx)
+  int n;
+};
+
+__global__ __launch_bounds__(256) void glue_group_kernel(const GlueGroup g) {
+  const int bid = blockIdx.x;
+  int gi = 0;
+#pragma unroll
+  for (int k = 1; k < GLUE_MAX; ++k)
+    if (k < g.n && bid >= g.start[k]) gi = k;
+  // (read from the kernarg segment with a wave-uniform offset: indexing g.p[gi] would copy the array to scratch)
+  const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+  const int first = *reinterpret_cast<const int*>(ka + offsetof(GlueGroup, start) + (size_t)gi * sizeof(int));
+  const int gx = *reinterpret_cast<const int*>(ka + offsetof(GlueGroup, gx) + (size_t)gi * sizeof(int));
+  const MesmGlueArgs& a = *reinterpret_cast<const MesmGlueArgs*>(ka + offsetof(GlueGroup, p) + (size_t)gi * sizeof(MesmGlueArgs));
+  const int local = bid - first;
+  const int by = local / gx, bx = local - by * gx;
+  switch (a.op) {
+    case MESM_GLUE_TOKEN_MIX_FWD:
+      token_mix_fwd_body((const float*)a.p[0], (const uint8_t*)a.p[1], (const float*)a.p[2], (const uint8_t*)a.p[3],
+                         (const float*)a.p[4], (float*)a.p[5], a.n[0], a.i[0], bx);
+      break;
+    case MESM_GLUE_TOKEN_MIX_BWD:
+      token_mix_bwd_body((const float*)a.p[0], (const uint8_t*)a.p[1], (const uint8_t*)a.p[2], (float*)a.p[3], (float*)a.p[4],
+                         (float*)a.p[5], a.n[0], a.i[0], bx);
+      break;
+    case MESM_GLUE_GATHER_ROWS_FWD:
+      gather_rows_fwd_body((const float*)a.p[0], (const int64_t*)a.p[1], (const uint8_t*)a.p[2], (float*)a.p[3], (float*)a.p[4],
+                           a.n[0], a.i[0], a.i[1], bx);
+      break;
+    case MESM_GLUE_GATHER_ROWS_BWD:
+      gather_rows_bwd_body((const float*)a.p[0], (const float*)a.p[1], (const float*)a.p[2], (const int64_t*)a.p[3],
+                           (const uint8_t*)a.p[4], (float*)a.p[5], a.n[0], a.i[0], a.i[1], bx);
+      break;
+    case MESM_GLUE_UNSTACK_ROWS:
+      unstack_rows_body((const float*)a.p[0], (const int64_t*)a.p[1], (float*)a.p[2], a.i[0], a.n[0], bx, by);
+      break;
+    case MESM_GLUE_STACK_ROWS: {  // one tensor of a stack_rows call: dst (2N rows) = [src ; src[idx]] or [src ; src]
+      const int N = a.i[0], r = bx;
+      int sr = r < N ? r : r - N;
+      if (r >= N && a.p[2]) sr = (int)((const int64_t*)a.p[2])[r - N];
+      const int64_t rb = a.n[0];
+      const unsigned char* s = (const unsigned char*)a.p[0] + (int64_t)sr * rb;
+      unsigned char* d = (unsigned char*)a.p[1] + (int64_t)r * rb;
+      if ((rb & 15) == 0 && ((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0) {
+        const int64_t n16 = rb >> 4;
+        for (int64_t i = threadIdx.x; i < n16; i += 256) reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+      } else {
+        for (int64_t i = threadIdx.x; i < rb; i += 256) d[i] = s[i];
+      }
+      break;
+    }
+    case MESM_GLUE_ADD_TILE: {  // out[i] = a[i % na] + b[i % nb] (float4 units)
+      const float4* pa = (const float4*)a.p[0];
+      const float4* pb = (const float4*)a.p[1];
+      float4* po = (float4*)a.p[2];
+      const int64_t n4 = a.n[0], na4 = a.n[1], nb4 = ((const int64_t*)a.i)[0];
+      for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < n4; i += (int64_t)gx * 256) {
+        const float4 u = pa[i % na4], v = pb[i % nb4];
+        po[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+      }
+      break;
+    }
+    default:
+      break;
   }
 }
 
@@ -513,4 +622,76 @@ extern "C" int mesm_add_wrap(const float* a, const float* b, float* out, int64_t
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(add_wrap_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, b, out, n / 4, nb / 4);
   return mesm_launch_status();
+}
+
+extern "C" int mesm_glue_group(const MesmGlueArgs* list, int32_t n, void* stream) {
+  if (!list || n <= 0 || n > 64) return MESM_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  GlueGroup g;
+  g.n = 0;
+  g.start[0] = 0;
+  int rc = MESM_OK;
+  auto flush = [&]() {
+    if (g.n == 0) return;
+    hipLaunchKernelGGL(glue_group_kernel, dim3((unsigned)g.start[g.n]), dim3(256), 0, s, g);
+    rc = mesm_launch_status();
+    g.n = 0;
+  };
+  for (int k = 0; k < n && rc == MESM_OK; ++k) {
+    const MesmGlueArgs& a = list[k];
+    int64_t gx = 0, gy = 1;
+    const int D = a.i[0];
+    switch (a.op) {
+      case MESM_GLUE_TOKEN_MIX_FWD:  // p: x, m1, tok1, m2, tok2, y; n[0] rows; i[0] D
+        if (!a.p[0] || !a.p[1] || !a.p[2] || !a.p[5] || a.n[0] <= 0 || D <= 0 || (D & 3) || ((a.p[3] == nullptr) != (a.p[4] == nullptr)))
+          return MESM_EINVAL;
+        gx = (a.n[0] + 3) / 4;
+        break;
+      case MESM_GLUE_TOKEN_MIX_BWD:  // p: dy, m1, m2, dx, dtok1, dtok2
+        if (!a.p[0] || !a.p[1] || a.n[0] <= 0 || D <= 0) return MESM_EINVAL;
+        gx = (a.n[0] + TM_ROWS - 1) / TM_ROWS;
+        break;
+      case MESM_GLUE_GATHER_ROWS_FWD:  // p: x, idx, valid, y, rnorm; n[0] rows; i[0] D, i[1] normalize
+        if (!a.p[0] || !a.p[1] || !a.p[3] || a.n[0] <= 0 || D <= 0 || (a.i[1] && !a.p[4])) return MESM_EINVAL;
+        gx = (a.n[0] + 3) / 4;
+        break;
+      case MESM_GLUE_GATHER_ROWS_BWD:  // p: dy, y, rnorm, inv, valid, dx; n[0] source rows
+        if (!a.p[0] || !a.p[3] || !a.p[5] || a.n[0] <= 0 || D <= 0 || (a.i[1] && (!a.p[1] || !a.p[2]))) return MESM_EINVAL;
+        gx = (a.n[0] + 3) / 4;
+        break;
+      case MESM_GLUE_UNSTACK_ROWS:  // p: d2, idx, dx; i[0] N; n[0] R
+        if (!a.p[0] || !a.p[2] || a.i[0] <= 0 || a.n[0] <= 0 || (a.n[0] & 3)) return MESM_EINVAL;
+        if ((((uintptr_t)a.p[0]) | ((uintptr_t)a.p[2])) & 15) return MESM_EALIGN;
+        gx = a.i[0];
+        gy = (a.n[0] / 4 + 255) / 256;
+        break;
+      case MESM_GLUE_STACK_ROWS:  // p: src, dst, idx (NULL: repeat); i[0] N; n[0] row bytes
+        if (!a.p[0] || !a.p[1] || a.i[0] <= 0 || a.n[0] <= 0) return MESM_EINVAL;
+        gx = 2 * (int64_t)a.i[0];
+        break;
+      case MESM_GLUE_ADD_TILE: {  // p: a, b, out; n[0] elements of out, n[1] of a, (i[0], i[1]) = int64 elements of b
+        const int64_t nb = ((const int64_t*)a.i)[0];
+        if (!a.p[0] || !a.p[1] || !a.p[2] || a.n[0] <= 0 || a.n[1] <= 0 || nb <= 0 || ((a.n[0] | a.n[1] | nb) & 3)) return MESM_EINVAL;
+        if ((((uintptr_t)a.p[0]) | ((uintptr_t)a.p[1]) | ((uintptr_t)a.p[2])) & 15) return MESM_EALIGN;
+        gx = (a.n[0] / 4 + 255) / 256;
+        if (gx > 2048) gx = 2048;
+        break;
+      }
+      default:
+        return MESM_EINVAL;
+    }
+    if (gx <= 0 || gx * gy > (1 << 24)) return MESM_EINVAL;
+    MesmGlueArgs q = a;
+    if (a.op == MESM_GLUE_ADD_TILE) {  // (device form: float4 units)
+      q.n[0] = a.n[0] / 4;
+      q.n[1] = a.n[1] / 4;
+      ((int64_t*)q.i)[0] = ((const int64_t*)a.i)[0] / 4;
+    }
+    g.p[g.n] = q;
+    g.gx[g.n] = (int)gx;
+    g.start[g.n + 1] = g.start[g.n] + (int)(gx * gy);
+    if (++g.n == GLUE_MAX) flush();
+  }
+  if (rc == MESM_OK) flush();
+  return rc;
 }

@@ -201,7 +201,8 @@ class _Phase:
              ("ln_fwd", LnArgs, "mesm_layernorm_fwd_group", None),
              ("ln_bwd", LnArgs, "mesm_layernorm_bwd_group", None),
              ("attn_fwd", AttnArgs, "mesm_attn_fwd_group", "mesm_attn_fwd"),
-             ("attn_bwd", AttnArgs, "mesm_attn_bwd_group", "mesm_attn_bwd"))
+             ("attn_bwd", AttnArgs, "mesm_attn_bwd_group", "mesm_attn_bwd"),
+             ("glue", _lib.GlueArgs, "mesm_glue_group", None))
 
     def __init__(self):
         self.q = {k[0]: [] for k in self.KINDS}
@@ -959,6 +960,45 @@ def _u8(t):
     return t if t.dtype == torch.uint8 else t.view(torch.uint8)
 
 
+_glue_defer = 0
+
+
+class glue_deferred:
+    """Inside an open launch phase, the assembly kernels called in this block are QUEUED for the phase's one grouped
+    launch (mesm_glue_group) instead of running at once -- for callers whose assembly calls are independent of everything
+    else in the phase (ops.glue_block).  Without it an assembly kernel called inside a phase runs immediately, i.e. before
+    the phase's queued launches (what the transformer blocks rely on)."""
+
+    def __enter__(self):
+        global _glue_defer
+        _glue_defer += 1
+
+    def __exit__(self, *a):
+        global _glue_defer
+        _glue_defer -= 1
+        return False
+
+
+def glue_deferring():
+    return _phase is not None and _glue_defer > 0
+
+
+def _glue(op, p, n=(), i=(), keep=()):
+    """one assembly problem: queued in the open phase (glue_deferred) or launched on its own through the grouped entry"""
+    a = _lib.GlueArgs()
+    a.op = op
+    for k, t in enumerate(p):
+        a.p[k] = t.data_ptr() if torch.is_tensor(t) else t
+    for k, v in enumerate(n):
+        a.n[k] = int(v)
+    for k, v in enumerate(i):
+        a.i[k] = int(v)
+    if glue_deferring():
+        _phase.add("glue", a, tuple(keep))
+    else:
+        check(lib().mesm_glue_group(ctypes.byref(a), 1, stream_ptr()), "mesm_glue_group")
+
+
 def stack_rows(tensors, gather, idx):
     """[t ; t[idx]] (gather flag 1) or [t ; t] (0) along dim 0 for up to 8 tensors of N rows, one launch."""
     require_gpu(*tensors)
@@ -971,6 +1011,10 @@ def stack_rows(tensors, gather, idx):
     arr_b = (ctypes.c_int64 * n)(*rb)
     arr_g = (ctypes.c_int32 * n)(*[int(g) for g in gather])
     assert all(t.shape[0] == N for t in srcs) and (idx is None or (idx.dtype == torch.int64 and idx.numel() == N))
+    if glue_deferring():
+        for t, o, b, g in zip(srcs, outs, rb, gather):
+            _glue(_lib.GLUE_STACK_ROWS, (t, o, idx if g else None), n=(b,), i=(N,), keep=(t, o, idx))
+        return outs
     check(lib().mesm_stack_rows(arr_s, arr_d, arr_b, arr_g, n, ptr(idx), N, stream_ptr()), "mesm_stack_rows")
     return outs
 
@@ -980,6 +1024,9 @@ def unstack_rows(d2, idx, N):
     d2 = d2.contiguous()
     R = d2[0].numel()
     dx = torch.empty((N,) + tuple(d2.shape[1:]), device=d2.device, dtype=torch.float32)
+    if glue_deferring():
+        _glue(_lib.GLUE_UNSTACK_ROWS, (d2, idx, dx), n=(R,), i=(N,), keep=(d2, idx, dx))
+        return dx
     check(lib().mesm_unstack_rows(ptr(d2), ptr(idx), ptr(dx), N, R, stream_ptr()), "mesm_unstack_rows")
     return dx
 
@@ -1032,6 +1079,9 @@ def token_mix_fwd(x, m1, tok1, m2=None, tok2=None):
     D = x.shape[-1]
     assert x.is_contiguous() and m1.is_contiguous() and m1.numel() * D == x.numel()
     y = torch.empty_like(x)
+    if glue_deferring():
+        _glue(_lib.GLUE_TOKEN_MIX_FWD, (x, m1, tok1, m2, tok2, y), n=(m1.numel(),), i=(D,), keep=(x, m1, tok1, m2, tok2, y))
+        return y
     check(lib().mesm_token_mix_fwd(ptr(x), ptr(m1), ptr(tok1), ptr(m2), ptr(tok2), ptr(y), m1.numel(), D, stream_ptr()),
           "mesm_token_mix_fwd")
     return y
@@ -1039,6 +1089,9 @@ def token_mix_fwd(x, m1, tok1, m2=None, tok2=None):
 
 def token_mix_bwd(dy, m1, m2, dx, dtok1, dtok2):
     D = dy.shape[-1]
+    if glue_deferring():
+        _glue(_lib.GLUE_TOKEN_MIX_BWD, (dy, m1, m2, dx, dtok1, dtok2), n=(m1.numel(),), i=(D,), keep=(dy, m1, m2, dx, dtok1, dtok2))
+        return
     check(lib().mesm_token_mix_bwd(ptr(dy), ptr(m1), ptr(m2), ptr(dx), ptr(dtok1), ptr(dtok2), m1.numel(), D,
                                    stream_ptr()), "mesm_token_mix_bwd")
 
@@ -1050,6 +1103,10 @@ def gather_rows_fwd(x2d, idx, valid=None, normalize=False):
     D = x2d.shape[1]
     y = torch.empty(*idx.shape, D, device=x2d.device, dtype=torch.float32)
     rn = torch.empty(idx.numel(), device=x2d.device, dtype=torch.float32) if normalize else None
+    if glue_deferring():
+        _glue(_lib.GLUE_GATHER_ROWS_FWD, (x2d, idx, valid, y, rn), n=(idx.numel(),), i=(D, 1 if normalize else 0),
+              keep=(x2d, idx, valid, y, rn))
+        return y, rn
     check(lib().mesm_gather_rows_fwd(ptr(x2d), ptr(idx), ptr(valid), ptr(y), ptr(rn), idx.numel(), D,
                                      1 if normalize else 0, stream_ptr()), "mesm_gather_rows_fwd")
     return y, rn
@@ -1058,6 +1115,10 @@ def gather_rows_fwd(x2d, idx, valid=None, normalize=False):
 def gather_rows_bwd(dy, y, rnorm, inv, valid, src_rows, normalize):
     D = dy.shape[-1]
     dx = torch.empty(src_rows, D, device=dy.device, dtype=torch.float32)
+    if glue_deferring():
+        _glue(_lib.GLUE_GATHER_ROWS_BWD, (dy, y, rnorm, inv, valid, dx), n=(src_rows,), i=(D, 1 if normalize else 0),
+              keep=(dy, y, rnorm, inv, valid, dx))
+        return dx
     check(lib().mesm_gather_rows_bwd(ptr(dy), ptr(y), ptr(rnorm), ptr(inv), ptr(valid), ptr(dx), src_rows, D,
                                      1 if normalize else 0, stream_ptr()), "mesm_gather_rows_bwd")
     return dx
@@ -1078,6 +1139,18 @@ def add_n(ts):
     out = torch.empty_like(ts[0])
     arr = (ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts])
     check(lib().mesm_add_n(arr, len(ts), ptr(out), out.numel(), stream_ptr()), "mesm_add_n")
+    return out
+
+
+def add_tile(a, b, reps):
+    """[a + b] repeated `reps` times along dim 0 (a, b of one shape): the stacked passes' video + position sum formed
+    from the unstacked tensors (model.py:175-180, 281-286), one member of a grouped assembly launch."""
+    require_gpu(a, b)
+    assert a.is_contiguous() and b.is_contiguous() and a.shape == b.shape and a.dtype == torch.float32
+    out = torch.empty((reps * a.shape[0],) + tuple(a.shape[1:]), device=a.device, dtype=torch.float32)
+    nb = (ctypes.c_int64 * 1)(b.numel())
+    i2 = (ctypes.c_int32 * 2).from_buffer(nb)
+    _glue(_lib.GLUE_ADD_TILE, (a, b, out), n=(out.numel(), a.numel()), i=(i2[0], i2[1]), keep=(a, b, out))
     return out
 
 

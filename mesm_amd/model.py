@@ -439,9 +439,28 @@ class MESM(nn.Module):
             # one launch builds every stacked tensor of the stage: [x ; x] for the video side, [x ; x[neg_index]]
             # for the words (neg_words_feat = expanded_words_feat[neg_index][:, 1:] = projected words of the
             # negative query; the SS token is stripped again, model.py:264-266)
-            pv2, vpos2, vid_pad2, pw2, wpad2 = ops.stack_rows([pv, vpos, vid_pad, pw, words_pad], [0, 0, 0, 1, 1], ni)
-            # pv2 + position, formed without autograd: the consumer block folds its gradient into d pv2 (join_vid_p)
-            pvp2 = kn.add_wrap(pv2.detach(), vpos2)
+            # ... and the stage's other assembly steps -- the first query pv2 + position (formed without autograd: the
+            # consumer block folds its gradient into d pv2, join_vid_p), the SS-MESM query tokens, the MLM branch's
+            # token replacement and ground-truth clip gathers -- are independent of it and of each other: ONE autograd
+            # node whose kernels leave in one grouped assembly launch, forward and backward (ops.glue_block)
+            prep = [ops.stack_rows_call([pv, vpos, vid_pad, pw, words_pad], [0, 0, 0, 1, 1], ni),
+                    ops.add_tile_call(pv.detach(), vpos, 2)]
+            if self.rec_ss:
+                # the pair's own sentence slot is replaced by the learned token (model.py:493-501)
+                prep.append(ops.token_mix_call(bsent, plan.sent_loc, self.ss_reconstructor.masked_sent_token))
+            if mlm:
+                # FW-MESM masked-language-model branch (model.py:307-332): unknown words, then the drawn positions,
+                # become learned tokens (model.py:361-394); the ground-truth clips of every pair re-padded to Lc, and
+                # their position embeddings (model.py:312-325)
+                prep += [ops.token_mix_call(pw, kwargs["unknown_mask"], unk, plan.masked_words, msk),
+                         ops.gather_rows2_call(pv.reshape(N * Lv, d), plan.clip_src, plan.clip_inv, plan.clip_mask),
+                         ops.gather_rows2_call(vpos.reshape(N * Lv, d), plan.clip_src, plan.clip_inv, plan.clip_mask)]
+            prep = ops.par(prep)
+            (pv2, vpos2, vid_pad2, pw2, wpad2), pvp2 = prep[0], prep[1]
+            if self.rec_ss:
+                q_tok = prep[2]
+            if mlm:
+                w, cfeat, cpos = prep[-3:]
             stage, names = [], []
             tpos2 = None
             if self.rec_fw:
@@ -456,17 +475,9 @@ class MESM(nn.Module):
                                            join_vid_p=True))
                     names.append("E")
             if self.rec_ss:
-                # the pair's own sentence slot is replaced by the learned token (model.py:493-501)
-                q_tok = ops.token_mix(bsent, plan.sent_loc, self.ss_reconstructor.masked_sent_token)
                 stage.append(self.ss_reconstructor.recon_trans.steps(bvid, q_tok, None, None, bvid_pad, plan.sent_pad))
                 names.append("S")
             if mlm:
-                # FW-MESM masked-language-model branch (model.py:307-332): unknown words, then the drawn positions,
-                # become learned tokens (model.py:361-394): one launch
-                w = ops.token_mix(pw, kwargs["unknown_mask"], unk, plan.masked_words, msk)
-                # the ground-truth clips of every pair re-padded to Lc, and their position embeddings (model.py:312-325)
-                cfeat = ops.gather_rows2(pv.reshape(N * Lv, d), plan.clip_src, plan.clip_inv, plan.clip_mask)
-                cpos = kn.gather_rows_fwd(vpos.reshape(N * Lv, d), plan.clip_src, plan.clip_mask)[0]
                 m_chain = enc.steps(cfeat, w, cpos, tpos, plan.clip_pad, words_pad, is_mlm=True)  # pos_vid = txt_position
                 # beside the SS-MESM layers that outlast the enhance stack (3 rounds per layer)
                 lag = 3 * len(enc.t2v_encoder.layers) if ("E" in names and "S" in names) else 0

@@ -1454,7 +1454,8 @@ class TokenMixFn(Function):
                 bufs.append(g)
                 rets.append(g.view(tok.shape))
         kn.token_mix_bwd(dy, ctx.m1, ctx.m2, dx, bufs[0], bufs[1])
-        flush_ready()
+        if not kn.glue_deferring():  # (queued in a phase: ops._drive reports readiness once the phase is issued)
+            flush_ready()
         return dx, None, rets[0], None, rets[1]
 
 
@@ -1472,10 +1473,14 @@ class GatherRows2Fn(Function):
         y, rn = kn.gather_rows_fwd(x2d, idx, valid, normalize)
         ctx.save_for_backward(y if normalize else None, rn)
         ctx.idx_shape, ctx.inv, ctx.valid, ctx.rows, ctx.normalize = idx.shape, inv, valid, x2d.shape[0], normalize
+        if not ctx.needs_input_grad[0]:  # rows of a constant (position embeddings): consumers' gradients for them are dropped
+            ctx.mark_non_differentiable(y)
         return y
 
     @staticmethod
     def backward(ctx, dy):
+        if not ctx.needs_input_grad[0]:
+            return None, None, None, None, None
         y, rn = ctx.saved_tensors
         dx = kn.gather_rows_bwd(_c(dy), y, rn, ctx.inv, ctx.valid, ctx.rows, ctx.normalize)
         return dx, None, None, None, None
@@ -1485,6 +1490,65 @@ def gather_rows2(x2d, idx, inv, valid=None, normalize=False):
     if not (torch.is_grad_enabled() and x2d.requires_grad):
         return kn.gather_rows_fwd(_c(x2d), idx, valid, normalize)[0]
     return GatherRows2Fn.apply(x2d, idx, inv, valid, normalize)
+
+
+class AddTileFn(Function):
+    """[a + b] repeated `reps` times along dim 0, formed WITHOUT autograd (a constant for the engine: the consumer block
+    folds the gradient of its use into the gradient of the stacked a, mha's join_qp)."""
+
+    @staticmethod
+    def forward(ctx, a, b, reps):
+        out = kn.add_tile(_c(a), _c(b), reps)
+        ctx.mark_non_differentiable(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, None, None
+
+
+def glue_block(fn_cls, n_out, name):
+    """An assembly Function as a block for par() / lockstep: inside the node's launch phases its kernels are QUEUED
+    (kn.glue_deferred) and leave with the phase's one grouped assembly launch, forward and backward -- for assembly calls
+    that are independent of everything else in their round."""
+
+    class B:
+        N_OUT = n_out
+
+        @staticmethod
+        def fwd(ctx, *a):
+            with kn.glue_deferred():
+                return fn_cls.forward(ctx, *a)
+
+        @staticmethod
+        def bwd(ctx, *g):
+            with kn.glue_deferred():
+                return fn_cls.backward(ctx, *g)
+
+    B.__name__ = B.__qualname__ = name
+    return B
+
+
+StackRowsBlock = glue_block(StackRowsFn, lambda idx, gather, *xs: len(xs), "StackRowsBlock")
+TokenMixBlock = glue_block(TokenMixFn, 1, "TokenMixBlock")
+GatherRows2Block = glue_block(GatherRows2Fn, 1, "GatherRows2Block")
+AddTileBlock = glue_block(AddTileFn, 1, "AddTileBlock")
+
+
+def stack_rows_call(xs, gather, idx):
+    return Call(StackRowsBlock, (idx, tuple(gather)) + tuple(xs))
+
+
+def token_mix_call(x, m1, tok1, m2=None, tok2=None):
+    return Call(TokenMixBlock, (x, m1, tok1, m2, tok2))
+
+
+def gather_rows2_call(x2d, idx, inv, valid=None, normalize=False):
+    return Call(GatherRows2Block, (x2d, idx, inv, valid, normalize))
+
+
+def add_tile_call(a, b, reps):
+    return Call(AddTileBlock, (a, b, reps))
 
 
 # ----------------------------------------------------------------------------- decoder reference points

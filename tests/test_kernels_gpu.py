@@ -1121,3 +1121,57 @@ def test_fork_sums_the_consumers_gradients_like_autograd_does():
     assert rel_err(x.grad, x2.grad) < 1e-6
     y = gen((4, 8), 970).requires_grad_(True)
     assert all(t is y for t in ops.fork(y, 2))            # nothing to gain: no node
+
+
+def test_glue_group_matches_individual_launches():
+    """mesm_glue_group: the assembly problems of one launch phase (stacked copies, token mixes, gathers and their
+    backward forms, the tiled sum) as workgroup ranges of one grid give bit for bit what the plain launches give."""
+    from mesm_amd import kernels as kn
+    N, L, D = 6, 11, 64
+    g = torch.Generator().manual_seed(5)
+    x = gen((N, L, D), 1)
+    m1 = (torch.rand(N, L, generator=g) < 0.3).to(dev())
+    m2 = (torch.rand(N, L, generator=g) < 0.2).to(dev())
+    t1, t2 = gen((D,), 2), gen((D,), 3)
+    idx = torch.randperm(N * L, generator=g)[:40].to(dev())
+    valid = (torch.rand(40, generator=g) < 0.8).to(dev())
+    inv = torch.full((N * L,), -1, dtype=torch.int64)
+    inv[idx.cpu()] = torch.arange(40)
+    inv = inv.to(dev())
+    dy = gen((N, L, D), 4)
+    dg = gen((40, D), 5)
+    perm = torch.randperm(N, generator=g).to(dev())
+    pad = (torch.rand(N, L, generator=g) < 0.5).to(dev())
+    d2 = gen((2 * N, L, D), 6)
+    b = gen((N, L, D), 7)
+
+    def run(grouped):
+        import contextlib
+        with (kn.phase() if grouped else contextlib.nullcontext()), (kn.glue_deferred() if grouped else contextlib.nullcontext()):
+            outs = list(kn.stack_rows([x, pad, b], [1, 1, 0], perm))
+            outs.append(kn.token_mix_fwd(x, m1, t1, m2, t2))
+            outs.append(kn.token_mix_fwd(b, m1, t1))
+            y, rn = kn.gather_rows_fwd(x.view(-1, D), idx, valid, True)
+            outs += [y, rn]
+            outs.append(kn.gather_rows_fwd(b.view(-1, D), idx)[0])
+            dx, dt1, dt2 = torch.empty_like(dy), torch.zeros(D, device=dev()), torch.zeros(D, device=dev())
+            kn.token_mix_bwd(dy, m1, m2, dx, dt1, dt2)
+            outs += [dx, dt1, dt2]
+            outs.append(kn.unstack_rows(d2, perm, N))
+            outs.append(kn.unstack_rows(d2, None, N))
+            outs.append(kn.add_tile(x, b, 2))
+        # (second phase: the normalised gather's backward reads what the first phase wrote)
+        with (kn.phase() if grouped else contextlib.nullcontext()), (kn.glue_deferred() if grouped else contextlib.nullcontext()):
+            outs.append(kn.gather_rows_bwd(dg, y, rn, inv, valid, N * L, True))
+            outs.append(kn.gather_rows_bwd(dg, None, None, inv, None, N * L, False))
+        torch.cuda.synchronize()
+        return outs
+
+    ref, got = run(False), run(True)
+    assert len(ref) == len(got) == 16
+    for k, (a, c) in enumerate(zip(ref, got)):
+        if k in (9, 10):  # the token gradients: float atomics, the order of the adders is free
+            assert rel_err(c, a) < 1e-5, k
+        else:
+            assert torch.equal(a, c), k
+    assert torch.equal(got[13].view(2, N, L, D)[1], x + b)
