@@ -322,14 +322,16 @@ class DecoderLayer(nn.Module):
         so = self.self_attn.out_proj
         # (tgt_res: a second alias of tgt for the residual route, ops.fork: its gradient joins the others' in one launch)
         x = yield L(a, so.weight, so.bias, residual=tgt if tgt_res is None else tgt_res, out_drop=drop_state.next(self.p))
-        tgt = yield ops.layer_norm_call(x, self.norm1.weight, self.norm1.bias)
+        # (norm1's output feeds the cross-attention block and the residual of its output projection: two aliases, their
+        # gradients meet in the LayerNorm backward kernel)
+        tgt, tgt_r = yield ops.layer_norm_call(x, self.norm1.weight, self.norm1.bias, fork=True)
         wkv, bkv = pack("ca_kv")
         a = yield ops.dec_cross_attn_call(tgt, qs, qpp, memory, pos, mem_pad, self.ca_qcontent_proj.weight,
                                           self.ca_qcontent_proj.bias, wkv, bkv, self.ca_kpos_proj.weight,
                                           self.ca_kpos_proj.bias, is_first, h, drop=drop_state.next(self.p),
                                           mem_share=mem_share)
         co = self.cross_attn.out_proj
-        x = yield L(a, co.weight, co.bias, residual=tgt, out_drop=drop_state.next(self.p))
+        x = yield L(a, co.weight, co.bias, residual=tgt_r, out_drop=drop_state.next(self.p))
         tgt = yield ops.layer_norm_call(x, self.norm2.weight, self.norm2.bias)
         y = yield ops.ffn_call(tgt, tgt, self.linear1.weight, self.linear1.bias, self.activation.weight,
                                self.linear2.weight, self.linear2.bias, mid_drop=drop_state.next(self.p),

@@ -661,6 +661,42 @@ class LayerNormBlock:
         return (dx, None if dg else gg, None if db else gb, None, None, None, None)
 
 
+class LayerNormForkBlock:
+    """(y, y) = LayerNorm(x) for an output with TWO consumers (the decoder's norm1: the cross-attention block and the
+    residual of its output projection, transformer.py:754-793): the second output is an alias of the first, and the
+    backward kernel adds the two incoming gradients while it loads them (dyb) -- where the autograd engine would launch an
+    element-wise add in front of this block's backward."""
+    N_OUT = 2
+
+    @staticmethod
+    def fwd(ctx, x, gamma, beta, eps, sink):
+        ctx.set_materialize_grads(False)
+        x = _c(x)
+        y, mean, rstd = kn.layernorm_fwd(x, gamma, beta, eps, NO_DROP)
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.gamma, ctx.beta, ctx.sink = gamma, beta, sink
+        return y, y.view_as(y)
+
+    @staticmethod
+    def bwd(ctx, dy, dy2):
+        x, mean, rstd = ctx.saved_tensors
+        if dy is None:
+            dy, dy2 = dy2, None
+        gg, dg = grad_target(ctx.gamma)
+        gb, db = grad_target(ctx.beta)
+        need_dx = ctx.needs_input_grad[0]
+        sink = ctx.sink if need_dx else None
+        if dy2 is not None and not need_dx:  # (parameter gradients only: no kernel form with two gradients; tiny and rare)
+            dy, dy2 = dy + dy2, None
+        dx = kn.layernorm_bwd(_c(dy), x, ctx.gamma, mean, rstd, gg, gb, need_dx=need_dx,
+                              drop2=(sink.p, sink.seed) if sink is not None else None,
+                              dyb=_c(dy2) if dy2 is not None else None)
+        if sink is not None:
+            dx, sink.dz = dx
+            sink.src = dx
+        return (dx, None if dg else gg, None if db else gb, None, None)
+
+
 class LayerNormPosBlock:
     """(y, y + add) = LayerNorm(x): the second output is the `with_pos_embed` query of the attention block
     that consumes y (transformer.py:512, 577, 640), written by the same kernel; the backward adds the two
@@ -698,7 +734,15 @@ class LayerNormPosBlock:
         return (dx, None if dg else gg, None if db else gb, None, dy2 if ctx.needs_input_grad[4] else None, None)
 
 
-def layer_norm_call(x, gamma, beta, eps=1e-5, drop=NO_DROP, add=None):
+def layer_norm_call(x, gamma, beta, eps=1e-5, drop=NO_DROP, add=None, fork=False):
+    """fork: -> (y, alias of y) for an output with two consumers (their gradients meet inside the backward kernel)"""
+    if fork and torch.is_grad_enabled() and add is None and drop[0] == 0.0:
+        return Call(LayerNormForkBlock, (x, gamma, beta, eps, getattr(x, "_mesm_sink", None)))
+    if fork:
+        c = layer_norm_call(x, gamma, beta, eps, drop, add)
+        post = c.post
+        c.post = (lambda y: (lambda z: (z, z))(post(y) if post is not None else y))
+        return c
     if add is not None:
         assert drop[0] == 0.0
         return Call(LayerNormPosBlock, (x, gamma, beta, eps, add, getattr(x, "_mesm_sink", None)))
