@@ -565,7 +565,7 @@ __global__ __launch_bounds__(256 * SSM_G) void ss_mean_fwd_kernel(
 
 // Stage B, one workgroup per row n: sim[n,:] = cn[n] wn^T / tau (saved) and the row's loss term
 // (SupCon-style, +1e-6 inside the log); stage C sums the N row terms (deterministic).
-__global__ __launch_bounds__(256) void ss_loss_fwd_kernel(
+__global__ __launch_bounds__(1024) void ss_loss_fwd_kernel(
     const float* __restrict__ cn, const float* __restrict__ wn, const uint8_t* __restrict__ pos, int N,
     int D, float inv_tau, float* __restrict__ sim, float* __restrict__ rowloss, const int32_t* __restrict__ n_valid) {
   extern __shared__ float srow[];  // N
@@ -583,8 +583,9 @@ __global__ __launch_bounds__(256) void ss_loss_fwd_kernel(
 #pragma unroll
   for (int i = 0; i < 16; ++i) { const int c = lane + 64 * i; q[i] = c < D ? cn[(int64_t)n * D + c] : 0.0f; }
   // two columns per turn of a wave: both columns' loads are in flight before the first reduction starts
-  for (int k = wave; k < N; k += 8) {
-    const int k2 = k + 4 < N ? k + 4 : k;
+  const int nw = (int)(blockDim.x >> 6);  // (16 waves: one turn covers 32 columns)
+  for (int k = wave; k < N; k += 2 * nw) {
+    const int k2 = k + nw < N ? k + nw : k;
     float a = 0.0f, b = 0.0f;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(256) void ss_loss_fwd_kernel(
     b = wave_sum(b);
     if (lane == 0) {
       srow[k] = a * inv_tau; sim[(int64_t)n * ld + k] = a * inv_tau;
-      if (k + 4 < N) { srow[k2] = b * inv_tau; sim[(int64_t)n * ld + k2] = b * inv_tau; }
+      if (k + nw < N) { srow[k2] = b * inv_tau; sim[(int64_t)n * ld + k2] = b * inv_tau; }
     }
   }
   __syncthreads();
@@ -857,10 +858,10 @@ __device__ __forceinline__ void recfw_reduce_body(const float* __restrict__ row_
                                                   int Lw, float* __restrict__ out,
                                                   const int32_t* __restrict__ n_valid) {
   if (n_valid) N = *n_valid;
-  __shared__ float sh[3][4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float sh[3][16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (int)(blockDim.x >> 6);  // (16 waves: two pairs each at N = 32)
   float loss = 0.0f, ok = 0.0f, tot = 0.0f;
-  for (int n = wave; n < N; n += 4) {
+  for (int n = wave; n < N; n += nw) {
     float s = 0.0f, c = 0.0f, k = 0.0f;
     for (int w = lane; w < Lw; w += 64) {
       const float m = mask[(int64_t)n * Lw + w] ? 1.0f : 0.0f;
@@ -875,13 +876,13 @@ __device__ __forceinline__ void recfw_reduce_body(const float* __restrict__ row_
   __syncthreads();
   if (threadIdx.x == 0) {
     float a = 0, b = 0, c = 0;
-    for (int w = 0; w < 4; ++w) { a += sh[0][w]; b += sh[1][w]; c += sh[2][w]; }
+    for (int w = 0; w < nw; ++w) { a += sh[0][w]; b += sh[1][w]; c += sh[2][w]; }
     out[0] = a / (float)N;
     out[1] = b / c;
   }
 }
 
-__global__ __launch_bounds__(256) void recfw_reduce_kernel(const float* __restrict__ row_loss,
+__global__ __launch_bounds__(1024) void recfw_reduce_kernel(const float* __restrict__ row_loss,
                                                            const uint8_t* __restrict__ correct,
                                                            const uint8_t* __restrict__ mask, int N,
                                                            int Lw, float* __restrict__ out,
@@ -920,7 +921,7 @@ __global__ __launch_bounds__(1024) void crit_fwd_kernel(const MesmCritFwd a, con
   }
 }
 
-__global__ __launch_bounds__(256) void crit_tail_kernel(const MesmCritFwd a) {
+__global__ __launch_bounds__(1024) void crit_tail_kernel(const MesmCritFwd a) {
   if (a.fw_on) recfw_reduce_body(a.row_loss, a.correct, a.words_mask, a.N, a.fw_Lw, a.lv + a.fw_slot, a.n_valid);
   if (threadIdx.x < 64 && a.ss_on) {  // (ss_reduce_kernel)
     int N = a.N;
@@ -1178,7 +1179,7 @@ extern "C" int mesm_rec_ss_fwd_nv(const float* pv, const uint8_t* cmask, int32_t
                      D, cn, wn, stats);
   // stats (N, 4) has one spare use: the row losses are staged in column 0 of a second block
   float* rowloss = stats + (size_t)N * 4;
-  hipLaunchKernelGGL(ss_loss_fwd_kernel, dim3(N), dim3(256), (size_t)N * 4, s, cn, wn, pos, N, D,
+  hipLaunchKernelGGL(ss_loss_fwd_kernel, dim3(N), dim3(1024), (size_t)N * 4, s, cn, wn, pos, N, D,
                      1.0f / tau, sim, rowloss, n_valid);
   hipLaunchKernelGGL(ss_reduce_kernel, dim3(1), dim3(64), 0, s, rowloss, N, out, n_valid);
   return mesm_launch_status();
@@ -1265,9 +1266,9 @@ extern "C" int mesm_criterion_fwd(const MesmCritFwd* args, void* stream) {
       hipLaunchKernelGGL(crit_fwd_kernel<0>, dim3(r0.w), dim3(1024), lds, s, a, r0, P);
   }
   if (a.ss_on)
-    hipLaunchKernelGGL(ss_loss_fwd_kernel, dim3(a.N), dim3(256), (size_t)a.N * 4, s, a.cn, a.wn, a.ss_pos, a.N, a.ss_D,
+    hipLaunchKernelGGL(ss_loss_fwd_kernel, dim3(a.N), dim3(1024), (size_t)a.N * 4, s, a.cn, a.wn, a.ss_pos, a.N, a.ss_D,
                        1.0f / a.ss_tau, a.sim, a.stats + (size_t)a.N * 4, a.n_valid);
-  hipLaunchKernelGGL(crit_tail_kernel, dim3(1), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(crit_tail_kernel, dim3(1), dim3(1024), 0, s, a);
   return mesm_launch_status();
 }
 
@@ -1323,7 +1324,7 @@ extern "C" int mesm_criterion_bwd(const MesmCritBwd* args, void* stream) {
 extern "C" int mesm_rec_fw_reduce_nv(const float* row_loss, const uint8_t* correct, const uint8_t* mask,
                                      int32_t N, int32_t Lw, float* out2, const int32_t* n_valid, void* stream) {
   if (!row_loss || !correct || !mask || !out2 || N <= 0 || Lw <= 0) return MESM_EINVAL;
-  hipLaunchKernelGGL(recfw_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, row_loss, correct,
+  hipLaunchKernelGGL(recfw_reduce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, row_loss, correct,
                      mask, N, Lw, out2, n_valid);
   return mesm_launch_status();
 }

@@ -443,7 +443,12 @@ class MESM(nn.Module):
             # consumer block folds its gradient into d pv2, join_vid_p), the SS-MESM query tokens, the MLM branch's
             # token replacement and ground-truth clip gathers -- are independent of it and of each other: ONE autograd
             # node whose kernels leave in one grouped assembly launch, forward and backward (ops.glue_block)
-            prep = [ops.stack_rows_call([pv, vpos, vid_pad, pw, words_pad], [0, 0, 0, 1, 1], ni),
+            # (the projected video / words have three consumers each -- the stacked copy, the MLM branch, and the rec_ss
+            # loss resp. the expanded words: aliases whose gradients meet in one launch, ops.fork)
+            n_pv = 1 + (1 if mlm else 0) + (1 if self.rec_ss else 0)
+            pv_s, pv_g, pv_o = ops.fork(pv, 3) if n_pv == 3 else (pv, pv, pv)
+            pw_s, pw_t, pw_p = ops.fork(pw, 3) if n_pv == 3 else (pw, pw, pw)
+            prep = [ops.stack_rows_call([pv_s, vpos, vid_pad, pw_s, words_pad], [0, 0, 0, 1, 1], ni),
                     ops.add_tile_call(pv.detach(), vpos, 2)]
             if self.rec_ss:
                 # the pair's own sentence slot is replaced by the learned token (model.py:493-501)
@@ -452,8 +457,8 @@ class MESM(nn.Module):
                 # FW-MESM masked-language-model branch (model.py:307-332): unknown words, then the drawn positions,
                 # become learned tokens (model.py:361-394); the ground-truth clips of every pair re-padded to Lc, and
                 # their position embeddings (model.py:312-325)
-                prep += [ops.token_mix_call(pw, kwargs["unknown_mask"], unk, plan.masked_words, msk),
-                         ops.gather_rows2_call(pv.reshape(N * Lv, d), plan.clip_src, plan.clip_inv, plan.clip_mask),
+                prep += [ops.token_mix_call(pw_t, kwargs["unknown_mask"], unk, plan.masked_words, msk),
+                         ops.gather_rows2_call(pv_g.reshape(N * Lv, d), plan.clip_src, plan.clip_inv, plan.clip_mask),
                          ops.gather_rows2_call(vpos.reshape(N * Lv, d), plan.clip_src, plan.clip_inv, plan.clip_mask)]
             prep = ops.par(prep)
             (pv2, vpos2, vid_pad2, pw2, wpad2), pvp2 = prep[0], prep[1]
@@ -499,7 +504,7 @@ class MESM(nn.Module):
                 # the masked slot of every pair, L2-normalised (model.py:485-486): one kernel
                 recon = ops.gather_rows2(rec.reshape(-1, d), plan.recon_idx, plan.recon_inv, normalize=True)
                 # [recon ; words] and its padding mask (model.py:221-224), one launch
-                ewords, epad = ops.prepend(recon, pw, pad=words_pad, first_pad=False)
+                ewords, epad = ops.prepend(recon, pw_p, pad=words_pad, first_pad=False)
                 emask = plan.emask if getattr(plan, "emask", None) is not None else ~epad
             else:
                 ewords, emask = pw, words_mask
@@ -591,7 +596,7 @@ class MESM(nn.Module):
             out["recfw_words_logit"] = res2["H"]
             out["words_mask"] = words_mask
         if self.rec_ss:
-            out.update({"projed_video_feat": pv, "recon_feat": recon, "projed_recon_feat": projed_recon,
+            out.update({"projed_video_feat": pv_o, "recon_feat": recon, "projed_recon_feat": projed_recon,
                         "expanded_words_feat": ewords, "expanded_words_mask": emask,
                         "enhanced_video_feat": enhanced, "projed_words_feat": pw})
         return out
