@@ -781,6 +781,10 @@ typedef struct MesmGlueArgs {
   const void* p[8];
 } MesmGlueArgs;
 int mesm_glue_group(const MesmGlueArgs* list, int32_t n, void* stream);
+
+/* n <= 32 byte ranges (16-byte aligned, multiples of 16 bytes) set to zero in one launch: the zero-initialised scratch of a
+ * step (replaces one torch fill per step; no reference counterpart: the reference's tensors are fresh allocations). */
+int mesm_fill_ranges(void* const* ptrs, const int64_t* nbytes, int32_t n, void* stream);
 /* First node of a captured training step (no counterpart in the reference: its forward draws on the host and indexes
  * with host tensors, model.py:260, 361-384): copies slot (*pull_ctr % slots) of a ring of `slots` x slot_bytes in PINNED
  * HOST memory (device-readable) to dst, then *pull_ctr += 1 and, when given, *seed_ctr += 1 (the dropout seed offset of

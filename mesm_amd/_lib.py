@@ -231,6 +231,7 @@ PROTOTYPES = {
     "mesm_ddp_last_error": (ctypes.c_char_p, []),
     "mesm_weighted_sum": (ctypes.c_int, [c_ptr, c_ptr, _i32, c_ptr, c_ptr]),
     "mesm_scale_vec": (ctypes.c_int, [c_ptr, c_ptr, _i32, c_ptr, c_ptr]),
+    "mesm_fill_ranges": (ctypes.c_int, [c_ptr, c_ptr, _i32, c_ptr]),
     "mesm_glue_group": (ctypes.c_int, [ctypes.POINTER(GlueArgs), _i32, c_ptr]),
     "mesm_criterion_fwd": (ctypes.c_int, [ctypes.POINTER(CritFwdArgs), c_ptr]),
     "mesm_criterion_bwd": (ctypes.c_int, [ctypes.POINTER(CritBwdArgs), c_ptr]),

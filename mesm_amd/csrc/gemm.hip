@@ -1888,8 +1888,9 @@ int prepare(MesmGemmArgs& a, int& vec) {
     return MESM_EINVAL;
   if (a.split_k < 1) a.split_k = 1;
   if (a.split_k > 1) {
-    if (a.e_act != MESM_ACT_NONE || a.e_actgrad != MESM_ACT_NONE || a.e_drop_p > 0.f)
-      return MESM_EINVAL;
+    // (the epilogue dropout is linear in the partial sums: every k-slice applies the same mask, bias and residual join
+    // the first slice; activations are not)
+    if (a.e_act != MESM_ACT_NONE || a.e_actgrad != MESM_ACT_NONE) return MESM_EINVAL;
     a.accumulate = 2;
     int max_split = (a.K + BK_MAX - 1) / BK_MAX;
     if (a.split_k > max_split) a.split_k = max_split;

@@ -464,6 +464,24 @@ __global__ __launch_bounds__(256) void glue_group_kernel(const GlueGroup g) {
   }
 }
 
+// The zero-initialised scratch of a step in ONE launch: up to FILL_MAX byte ranges (16-byte units) cleared together -- the
+// pool of gradient tensors that kernels accumulate into, and the remainder ROWS of the 4800 / 4864-row GEMM outputs whose
+// last tiles are split along K and meet by atomic adds (kernels.ZeroPool).
+constexpr int FILL_MAX = 32;
+struct FillRanges {
+  uint4* p[FILL_MAX];
+  int64_t n16[FILL_MAX];
+};
+__global__ __launch_bounds__(256) void fill_ranges_kernel(const FillRanges r) {
+  uint4* d = r.p[0];
+  int64_t n = r.n16[0];
+#pragma unroll
+  for (int k = 1; k < FILL_MAX; ++k)
+    if ((int)blockIdx.y == k) { d = r.p[k]; n = r.n16[k]; }
+  const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = z;
+}
+
 // First node of a captured step: the step's host draws come from a ring of `slots` buffers in PINNED HOST memory
 // (read over the host link by this kernel: ~1 KB) instead of a host-to-device copy between two graph replays (a copy
 // on the stream between two graph launches cost ~50 us of idle queue per step, tools/host_cost.py), and the dropout
@@ -694,4 +712,21 @@ extern "C" int mesm_glue_group(const MesmGlueArgs* list, int32_t n, void* stream
   }
   if (rc == MESM_OK) flush();
   return rc;
+}
+
+extern "C" int mesm_fill_ranges(void* const* ptrs, const int64_t* nbytes, int32_t n, void* stream) {
+  if (!ptrs || !nbytes || n <= 0 || n > FILL_MAX) return MESM_EINVAL;
+  FillRanges r = {};
+  int64_t most = 0;
+  for (int k = 0; k < n; ++k) {
+    if (!ptrs[k] || nbytes[k] <= 0 || (nbytes[k] & 15)) return MESM_EINVAL;
+    if (((uintptr_t)ptrs[k]) & 15) return MESM_EALIGN;
+    r.p[k] = (uint4*)ptrs[k];
+    r.n16[k] = nbytes[k] >> 4;
+    if (r.n16[k] > most) most = r.n16[k];
+  }
+  int64_t gx = (most + 255) / 256;
+  if (gx > 512) gx = 512;
+  hipLaunchKernelGGL(fill_ranges_kernel, dim3((unsigned)gx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, r);
+  return mesm_launch_status();
 }

@@ -41,10 +41,20 @@ class ZeroPool:
     the gradient tensors that kernels accumulate into atomically (dq of an attention backward over several key tiles,
     token gradients, ...) used to be ~20 `torch.zeros` fill launches per step.  Sizes are learnt on the first step
     (served by plain torch.zeros, like anything that does not fit later); buffers that were ever handed out stay
-    referenced, so HIP graphs captured against them keep valid addresses when the pool grows."""
+    referenced, so HIP graphs captured against them keep valid addresses when the pool grows.
+    Round 5: a second buffer for tensors of which only the LAST ROWS start at zero (`tail_zeroed`: the GEMM outputs of
+    4800 / 4864 rows whose remainder tiles are split along K and meet by atomic adds, gemm()).  Which ranges those are is
+    learnt like the sizes -- a step's requests are the ranges the NEXT step's fill clears -- and the one fill launch of the
+    step (mesm_fill_ranges) clears the pool and those ranges together."""
 
     def __init__(self):
         self.buf, self.off, self.asked, self.retired = None, 0, 0, []
+        self.part, self.poff, self.pasked = None, 0, 0
+        self.cleared, self.wanted = set(), []  # (offset, length) float ranges of `part`: cleared by this step's fill / asked in it
+        self.active = False  # between begin() and the next forward without one (MESM._begin: no-grad forwards do not fill)
+
+    def idle(self):
+        self.active = False
 
     def begin(self, device):
         want = self.asked
@@ -53,8 +63,27 @@ class ZeroPool:
                 self.retired.append(self.buf)
             self.buf = torch.empty(want + want // 8, device=device, dtype=torch.float32)
         self.off = self.asked = 0
-        if self.buf is not None:
+        want = self.pasked
+        ranges = self.wanted
+        if want > 0 and (self.part is None or self.part.numel() < want or self.part.device != device):
+            if self.part is not None:
+                self.retired.append(self.part)
+            self.part = torch.empty(want + want // 8, device=device, dtype=torch.float32)
+        if self.part is None or self.part.device != device:
+            ranges = []
+        self.poff = self.pasked = 0
+        self.active = True
+        self.cleared, self.wanted = set(ranges), []
+        todo = [(self.buf, 0, self.buf.numel())] if self.buf is not None else []
+        todo += [(self.part, o, n) for o, n in ranges]
+        if len(todo) == 1 and self.buf is not None:
             self.buf.zero_()
+        elif todo:
+            for k in range(0, len(todo), 32):
+                chunk = todo[k:k + 32]
+                ptrs = (ctypes.c_void_p * len(chunk))(*[t.data_ptr() + 4 * o for t, o, _ in chunk])
+                nb = (ctypes.c_int64 * len(chunk))(*[4 * n for _, _, n in chunk])
+                check(lib().mesm_fill_ranges(ptrs, nb, len(chunk), stream_ptr()), "mesm_fill_ranges")
 
     def zeros(self, shape, device):
         n = 1
@@ -68,13 +97,49 @@ class ZeroPool:
             return v
         return torch.zeros(shape, device=device, dtype=torch.float32)
 
+    def tail_zeroed(self, shape, cut, device):
+        """fp32 (rows, cols) tensor whose rows [cut, rows) are zero when the step reaches it (the rows above: anything).
+        -> (tensor, True), or (None, False) when the pool cannot serve it in this step (first step of a shape, ...)."""
+        rows, cols = int(shape[0]), int(shape[1])
+        n = rows * cols
+        span = (n + 63) // 64 * 64
+        off = self.poff
+        rng = (off + cut * cols, (rows - cut) * cols)
+        self.pasked += span
+        self.poff += span
+        self.wanted.append(rng)
+        if (cut * cols) % 4 or ((rows - cut) * cols) % 4:
+            return None, False
+        if self.part is not None and self.part.device == device and off + span <= self.part.numel() and rng in self.cleared:
+            self.cleared.discard(rng)  # (handed out once per fill)
+            return self.part[off:off + n].view(rows, cols), True
+        return None, False
+
 
 zero_pool = ZeroPool()
+_tail_zero = {}  # data_ptr of a tensor from zero_pool.tail_zeroed -> (cut, rows): gemm() may split those rows along K
 
 
 def zeros(shape, device):
     """fp32 zeros that live until the next step begins (see ZeroPool)"""
     return zero_pool.zeros(tuple(shape), device)
+
+
+ROW_CUT = 4096  # rows of one full round of 64 x 64 tiles on 256 CUs at 256 columns (gemm(): _SPLIT_ROWS)
+
+
+def rows_out(like):
+    """Output tensor of a GEMM with like.shape: when it is one of the 4800 / 4864-row x 256-column products whose remainder
+    rows gemm() runs split along K, a tensor whose remainder rows start at zero (ZeroPool.tail_zeroed); else empty_like."""
+    cols = like.shape[-1]
+    rows = like.numel() // cols
+    if (_SPLIT_ROWS and _SPLIT_TAIL > 1 and cols == 256 and ROW_CUT < rows <= 5120 and like.dtype == torch.float32
+            and zero_pool.active):  # (the pool's fill runs at the start of a TRAINING step, MESM._begin)
+        t, ok = zero_pool.tail_zeroed((rows, cols), ROW_CUT, like.device)
+        if ok:
+            _tail_zero[t.data_ptr()] = (ROW_CUT, rows)
+            return t.view(like.shape)
+    return torch.empty_like(like)
 
 
 def _mat(t):
@@ -108,13 +173,18 @@ def gemm(A, B, C, *, trans_a=False, trans_b=False, A2=None, B2=None, bias=None, 
         # full.  Rows [0, 4096) = 256 tiles = exactly one round of the k-split 64 x 64 kernel; the remainder goes
         # to the 32 x 32 kernel (4800 x 256 x 1024: 37 us -> 30 us).  The epilogue-dropout mask index carries the
         # row offset, every other epilogue term is row-local.
-        cut = 4096
+        cut = ROW_CUT
         sl = lambda t_, a_, b_: None if t_ is None else t_[a_:b_]
+        # the remainder's 44 / 48 tiles alone are a second, mostly empty round: when its rows of C start at zero (rows_out)
+        # and the epilogue is linear, they are split along K as well -- 4 x as many workgroups, partial sums by atomic adds
+        # (bias / residual join the first slice, every slice applies the same dropout mask): 28.5 -> 21.8 us at 4800 rows
+        tail = (_tail_zero.get(C.data_ptr()) == (cut, C.shape[0]) and accumulate == 0 and e_act == ACT_NONE
+                and e_actgrad == ACT_NONE and pre_out is None and B2 is None and C.is_contiguous())
         for lo, hi in ((0, cut), (cut, C.shape[0])):
             gemm(A[lo:hi], B, C[lo:hi], trans_b=trans_b, B2=B2, bias=bias, residual=sl(residual, lo, hi),
                  aux=sl(aux, lo, hi), slope=slope, a_act=a_act, b_act=b_act, a_drop=a_drop, b_drop=b_drop,
                  e_act=e_act, e_actgrad=e_actgrad, e_drop=e_drop, out_scale=out_scale, accumulate=accumulate,
-                 pre_out=sl(pre_out, lo, hi), row0=lo if lo else -1)
+                 pre_out=sl(pre_out, lo, hi), row0=lo if lo else -1, split_k=_SPLIT_TAIL if (tail and lo) else 1)
         return C
     row0 = max(row0, 0)
     assert A.dtype == B.dtype == C.dtype == torch.float32
@@ -193,6 +263,7 @@ def gemm(A, B, C, *, trans_a=False, trans_b=False, A2=None, B2=None, bias=None, 
 
 
 _SPLIT_ROWS = os.environ.get("MESM_GEMM_SPLIT_ROWS", "1") == "1"
+_SPLIT_TAIL = int(os.environ.get("MESM_GEMM_SPLIT_TAIL", "4"))  # k-slices of the remainder rows (1: off)
 
 
 class _Phase:

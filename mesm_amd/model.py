@@ -199,6 +199,8 @@ class MESM(nn.Module):
         drop_state.begin(self.training, torch.initial_seed() + self._step)
         if torch.is_grad_enabled():
             kn.zero_pool.begin(device)  # ONE fill for every zero-initialised scratch tensor of the step
+        else:
+            kn.zero_pool.idle()
 
     def _proj(self, seq, x):
         for m in seq:

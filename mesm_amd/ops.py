@@ -579,7 +579,7 @@ class FFNBlock:
         kn.gemm(_2d(x), w1, _2d(h), trans_b=True, bias=b1, e_act=ACT_PRELU, slope=slope, e_drop=mid_drop,
                 pre_out=_2d(z))
         yield
-        y = torch.empty_like(x)
+        y = kn.rows_out(x)
         kn.gemm(_2d(h), w2, _2d(y), trans_b=True, bias=b2, e_drop=out_drop,
                 residual=_2d(_c(residual)) if residual is not None else None)
         ctx.save_for_backward(x, z, h)
@@ -610,7 +610,7 @@ class FFNBlock:
         fold_res = ctx.res_is_x and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
         _accum_dw(_2d(dz1), _2d(x), gw1, gb1)
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
+            dx = kn.rows_out(x)
             # residual input IS x: its gradient (dy) rides the epilogue of the dX GEMM
             kn.gemm(_2d(dz1), w1, _2d(dx), residual=dy2 if fold_res else None)
         return (dx, dy if ctx.has_res and ctx.needs_input_grad[1] and not fold_res else None,
@@ -777,7 +777,7 @@ class NormFFNBlock:
         kn.gemm(_2d(h), w1, _2d(a), trans_b=True, bias=b1, e_act=ACT_PRELU, slope=slope, e_drop=mid_drop,
                 pre_out=_2d(z))
         yield
-        y = torch.empty_like(x)
+        y = kn.rows_out(x)
         kn.gemm(_2d(a), w2, _2d(y), trans_b=True, bias=b2, e_drop=out_drop, residual=_2d(x))
         ctx.save_for_backward(x, mean, rstd, h, z, a)
         ctx.params = (gamma, beta, w1, b1, slope, w2, b2)
@@ -803,7 +803,7 @@ class NormFFNBlock:
         _accum_dw(dz2, _2d(a), gw2, gb2)
         kn.gemm(dz2, w2, _2d(dz1), e_drop=ctx.mid_drop, aux=_2d(z), e_actgrad=ACT_PRELU, slope=slope, dslope=gs)
         yield
-        dh = torch.empty_like(h)
+        dh = kn.rows_out(h)
         _accum_dw(_2d(dz1), _2d(h), gw1, gb1)
         kn.gemm(_2d(dz1), w1, _2d(dh))
         yield

@@ -412,7 +412,10 @@ def test_batches_prepared_by_loader_workers_replay_like_in_process_batches():
             assert gs is gsr, "prepared batch %d replayed another graph" % i
             assert abs(float(t) - tr) < 1e-6 * max(1.0, abs(tr)), (i, float(t), tr)
             rel = float((model.gradbuf().flat - gr).norm()) / max(float(gr.norm()), 1e-6)
-            assert rel < 1e-5, (i, rel)  # (split-K float atomics: the only run-to-run freedom)
+            # run-to-run freedom: the order of float atomic adds -- in the split-K weight gradients and, since round 5, in
+            # the K-split remainder rows of the 4800-row FFN products (activations differ in the last bit, which the layers
+            # behind them amplify to a few 1e-5 of the gradient norm; measured 2e-5)
+            assert rel < 1e-4, (i, rel)
         del loader
     assert cache.captures == caps0, "a prepared batch caused a capture"
     # a prepared batch of a bucket without a graph falls back to the in-process path through its raw batch

@@ -903,6 +903,46 @@ def test_gemm_row_split_keeps_the_dropout_mask_and_every_epilogue_term():
     assert float((outs[0] == res).float().mean()) > 0.05  # dropped elements (only the residual survives) exist
 
 
+@pytest.mark.parametrize("M,tb", [(4800, True), (4864, False)])
+def test_gemm_remainder_rows_split_along_k_onto_pool_zeroed_rows(M, tb):
+    """kn.rows_out hands out a C whose remainder rows [4096, M) the step's one fill launch has cleared (ZeroPool.tail_zeroed:
+    a step's requests are the ranges the next step's fill clears); gemm() then runs the remainder's tiles as four k-slices
+    that meet by atomic adds -- bias and residual on the first slice, the same dropout mask on every slice -- and the result
+    equals the unsplit launch; a first step (nothing cleared yet) and a no-grad call get plain tensors."""
+    from mesm_amd import kernels as kn
+    N, K = 256, 1024
+    A = gen((M, K), 1, 0.1)
+    W = gen((N, K), 2, 0.1) if tb else gen((K, N), 2, 0.1)
+    bias, res = gen((N,), 3), gen((M, N), 4)
+    like = torch.empty(M, N, device=dev())
+    pool, saved = kn.ZeroPool(), kn.zero_pool
+    kn.zero_pool = pool
+    try:
+        got = []
+        for step in range(3):
+            pool.begin(dev())
+            z = kn.zeros((300,), dev())  # (the pool's ordinary users share the fill launch)
+            C = kn.rows_out(like)
+            pooled = kn._tail_zero.get(C.data_ptr()) == (4096, M) and C.data_ptr() != like.data_ptr()
+            assert pooled == (step > 0), step
+            if pooled:
+                assert float(C[4096:].abs().max()) == 0.0 and float(z.abs().max()) == 0.0
+                assert kn.rows_out(like).data_ptr() != C.data_ptr()  # (not handed out twice)
+            C[:4096].fill_(7.0)  # (the rows above the cut may hold anything)
+            kn.gemm(A, W, C, trans_b=tb, bias=bias, residual=res, e_drop=(0.1, 321))
+            z += 1.0  # dirty the pool: the next step's fill has to clear it again
+            got.append(C.clone())
+        pool.idle()  # (a forward without a fill, MESM._begin under no_grad: plain tensors)
+        assert kn._tail_zero.get(kn.rows_out(like).data_ptr()) is None or not pool.cleared
+        ref = torch.empty(M, N, device=dev())
+        kn.gemm(A, W, ref, trans_b=tb, bias=bias, residual=res, e_drop=(0.1, 321))
+        for c in got:
+            assert rel_err(c, ref) < 1e-6
+        assert torch.equal(got[1][:4096], ref[:4096])  # (only the remainder's summation order is free)
+    finally:
+        kn.zero_pool = saved
+
+
 def test_layernorm_group_matches_individual_launches():
     """mesm_layernorm_{fwd,bwd}_group: the LayerNorms of one launch phase (different row counts, fused dropout,
     second output, gradient joins, masked second gradient) in shared launches give bit for bit what the plain

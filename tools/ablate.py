@@ -19,8 +19,8 @@ FAMILIES = {
            "mesm_layernorm_bwd3", "mesm_layernorm_fwd_group", "mesm_layernorm_bwd_group"],
     "glue": ["mesm_stack_rows", "mesm_unstack_rows", "mesm_prepend_fwd", "mesm_prepend_bwd", "mesm_split_token_fwd",
              "mesm_split_token_bwd", "mesm_token_mix_fwd", "mesm_token_mix_bwd", "mesm_gather_rows_fwd",
-             "mesm_gather_rows_bwd", "mesm_add_wrap"],
-    "loss": ["mesm_set_loss_fwd", "mesm_set_loss_fwd_layers", "mesm_set_loss_bwd", "mesm_rec_ss_fwd", "mesm_rec_ss_bwd", "mesm_rec_fw_reduce",
+             "mesm_gather_rows_bwd", "mesm_add_wrap", "mesm_glue_group", "mesm_add_n"],
+    "loss": ["mesm_criterion_fwd", "mesm_criterion_bwd", "mesm_set_loss_fwd", "mesm_set_loss_fwd_layers", "mesm_set_loss_bwd", "mesm_rec_ss_fwd", "mesm_rec_ss_bwd", "mesm_rec_fw_reduce",
              "mesm_rec_fw_rowgrad", "mesm_nll_smooth_fwd", "mesm_nll_smooth_bwd", "mesm_saliency_loss_fwd",
              "mesm_saliency_loss_bwd", "mesm_weighted_sum", "mesm_scale_vec", "mesm_rowdot_fwd", "mesm_rowdot_bwd"],
     "elt": ["mesm_dropout", "mesm_act_bias_bwd", "mesm_sine_pos_fwd", "mesm_query_sine_fwd", "mesm_query_sine_bwd",

@@ -3,7 +3,7 @@ separate runs: they do not fit one pass on gfx950).  Units and corrections per
 MI355X_MICROARCH.md "HBM": both counters are in KiB; on gfx950 FETCH_SIZE reports exactly half of
 the bytes of wide coalesced reads (128-B requests tallied at 64 B), so it is doubled; WRITE_SIZE is
 exact.  The number of training steps the profiled command executed is counted from the trace itself:
-saliency_fwd_kernel runs exactly once per step (eager warm-up, capture, replays and the PCIe-inclusive
+crit_tail_kernel (the criterion's finishing workgroup) runs exactly once per step (eager warm-up, capture, replays and the PCIe-inclusive
 leg of bench.py all included); the 4th argument is only the fallback when that kernel is absent.
 Usage: pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [steps] [bench.json] [tag]
 (bench.json of the same round: its roofline.launches_per_step is recorded so bench.py can tell a stale file)"""
@@ -23,7 +23,7 @@ def gemm_sum(path, counter):
         if "gemm_" in r["Kernel_Name"]:
             tot += float(r["Counter_Value"])
             n += 1
-        elif "saliency_fwd_kernel" in r["Kernel_Name"]:
+        elif "crit_tail_kernel" in r["Kernel_Name"]:
             steps += 1
     ALL[counter] = every
     return tot, n, steps
