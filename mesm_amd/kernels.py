@@ -52,9 +52,11 @@ class ZeroPool:
         self.part, self.poff, self.pasked = None, 0, 0
         self.cleared, self.wanted = set(), []  # (offset, length) float ranges of `part`: cleared by this step's fill / asked in it
         self.active = False  # between begin() and the next forward without one (MESM._begin: no-grad forwards do not fill)
+        self.handed = {}     # data_ptr -> (cut, rows) of the tail-zeroed tensors handed out in THIS step, until a GEMM takes them
 
     def idle(self):
         self.active = False
+        self.handed = {}
 
     def begin(self, device):
         want = self.asked
@@ -73,6 +75,7 @@ class ZeroPool:
             ranges = []
         self.poff = self.pasked = 0
         self.active = True
+        self.handed = {}
         self.cleared, self.wanted = set(ranges), []
         todo = [(self.buf, 0, self.buf.numel())] if self.buf is not None else []
         todo += [(self.part, o, n) for o, n in ranges]
@@ -117,7 +120,6 @@ class ZeroPool:
 
 
 zero_pool = ZeroPool()
-_tail_zero = {}  # data_ptr of a tensor from zero_pool.tail_zeroed -> (cut, rows): gemm() may split those rows along K
 
 
 def zeros(shape, device):
@@ -137,7 +139,7 @@ def rows_out(like):
             and zero_pool.active):  # (the pool's fill runs at the start of a TRAINING step, MESM._begin)
         t, ok = zero_pool.tail_zeroed((rows, cols), ROW_CUT, like.device)
         if ok:
-            _tail_zero[t.data_ptr()] = (ROW_CUT, rows)
+            zero_pool.handed[t.data_ptr()] = (ROW_CUT, rows)  # (gemm() takes it: valid for one product of this step)
             return t.view(like.shape)
     return torch.empty_like(like)
 
@@ -178,7 +180,7 @@ def gemm(A, B, C, *, trans_a=False, trans_b=False, A2=None, B2=None, bias=None, 
         # the remainder's 44 / 48 tiles alone are a second, mostly empty round: when its rows of C start at zero (rows_out)
         # and the epilogue is linear, they are split along K as well -- 4 x as many workgroups, partial sums by atomic adds
         # (bias / residual join the first slice, every slice applies the same dropout mask): 28.5 -> 21.8 us at 4800 rows
-        tail = (_tail_zero.get(C.data_ptr()) == (cut, C.shape[0]) and accumulate == 0 and e_act == ACT_NONE
+        tail = (zero_pool.handed.pop(C.data_ptr(), None) == (cut, C.shape[0]) and accumulate == 0 and e_act == ACT_NONE
                 and e_actgrad == ACT_NONE and pre_out is None and B2 is None and C.is_contiguous())
         for lo, hi in ((0, cut), (cut, C.shape[0])):
             gemm(A[lo:hi], B, C[lo:hi], trans_b=trans_b, B2=B2, bias=bias, residual=sl(residual, lo, hi),

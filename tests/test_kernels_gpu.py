@@ -923,17 +923,17 @@ def test_gemm_remainder_rows_split_along_k_onto_pool_zeroed_rows(M, tb):
             pool.begin(dev())
             z = kn.zeros((300,), dev())  # (the pool's ordinary users share the fill launch)
             C = kn.rows_out(like)
-            pooled = kn._tail_zero.get(C.data_ptr()) == (4096, M) and C.data_ptr() != like.data_ptr()
+            pooled = pool.handed.get(C.data_ptr()) == (4096, M)
             assert pooled == (step > 0), step
             if pooled:
                 assert float(C[4096:].abs().max()) == 0.0 and float(z.abs().max()) == 0.0
-                assert kn.rows_out(like).data_ptr() != C.data_ptr()  # (not handed out twice)
             C[:4096].fill_(7.0)  # (the rows above the cut may hold anything)
             kn.gemm(A, W, C, trans_b=tb, bias=bias, residual=res, e_drop=(0.1, 321))
             z += 1.0  # dirty the pool: the next step's fill has to clear it again
             got.append(C.clone())
+            assert not pool.handed  # (the product took its registration: valid for one GEMM)
         pool.idle()  # (a forward without a fill, MESM._begin under no_grad: plain tensors)
-        assert kn._tail_zero.get(kn.rows_out(like).data_ptr()) is None or not pool.cleared
+        assert kn.rows_out(like).data_ptr() not in pool.handed and not pool.handed
         ref = torch.empty(M, N, device=dev())
         kn.gemm(A, W, ref, trans_b=tb, bias=bias, residual=res, e_drop=(0.1, 321))
         for c in got:
