@@ -15,6 +15,7 @@
 #include <vector>
 
 #include <cstddef>
+#include <algorithm>
 #include "gemm_ws.hpp"
 
 
@@ -2067,6 +2068,20 @@ extern "C" int mesm_gemm_group(const MesmGemmArgs* args, int32_t n, void* stream
     list[i] = args[i];
     const int rc = prepare(list[i], vecs[i]);
     if (rc != MESM_OK) return rc;
+  }
+  // longest tiles first: the members of a call are independent, a workgroup's time is its slice of the reduce range, and
+  // the hardware hands out workgroups in index order -- a long-K member (a split-K weight gradient: 19 stages per wave)
+  // behind short ones (dX at K = 256: 1-2 stages) would start its tiles last and end the launch alone
+  static const bool lpt = [] { const char* e = getenv("MESM_GEMM_LPT"); return !e || atoi(e) != 0; }();
+  if (lpt && n > 1) {
+    int order[64];
+    for (int i = 0; i < n; ++i) order[i] = i;
+    auto depth = [&](int i) { return (list[i].K + list[i].split_k - 1) / list[i].split_k; };
+    std::stable_sort(order, order + n, [&](int a, int b) { return depth(a) > depth(b); });
+    MesmGemmArgs l2[64];
+    int v2[64];
+    for (int i = 0; i < n; ++i) { l2[i] = list[order[i]]; v2[i] = vecs[order[i]]; }
+    for (int i = 0; i < n; ++i) { list[i] = l2[i]; vecs[i] = v2[i]; }
   }
   if (g_tape.recording) {
     TapeEntry e;
