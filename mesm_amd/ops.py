@@ -8,6 +8,8 @@ model's flat gradient buffer (gradbuf.py); autograd only routes activation gradi
 All activations are batch-first (N, L, d) contiguous fp32; the reference's (L, N, d)
 layout (transformer.py:93-96) is never materialised.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -50,6 +52,12 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+# reduce indices per workgroup a small weight gradient aims at (0: the standalone rule only) and the workgroups it may become:
+# same-device step times 3.748 (off) / 3.70 (512) / 3.684 (600) / 3.73 (800) ms; 512 workgroups 3.72 (profiles/r5d/dw_split_ab.txt)
+_DW_WGS = int(os.environ.get("MESM_DW_WGS", "256"))
+_DW_DEPTH = int(os.environ.get("MESM_DW_DEPTH", "600"))
+
+
 def _dw_split(n_out, k_in, rows):
     """Split-k factor of a weight-gradient GEMM (n_out x k_in output, `rows` reduce indices): aim at one
     workgroup per CU (256) of the tile the dispatcher will pick -- 32 x 32 for small outputs, 64 x 64
@@ -63,6 +71,12 @@ def _dw_split(n_out, k_in, rows):
         s = 256 // t64
     else:
         s = 4 if t64 < 256 else 2  # 256 x 2818 x 2400: 49 us at 4 (52 at 1); 5003 x 256 x 1024: 37 us at 2 (43 at 1 or 4)
+    if _DW_DEPTH > 0 and t64 <= 128:
+        # inside the step a weight gradient never runs alone: it shares its launch with the dX product of the same block,
+        # whose tiles are 256 deep.  At split 4 a 256 x 256 gradient over 4800 rows is 64 workgroups of 1200 reduce indices
+        # -- they end the launch alone, 15 us after the 300 dX tiles beside them.  Slices about as deep as the neighbours'
+        # (and still at most one workgroup per CU for this member) end together with them.
+        s = max(s, min(rows // _DW_DEPTH, _DW_WGS // t64))
     return max(1, min(s, rows // 64, 32))
 
 
