@@ -100,6 +100,11 @@ class ZeroPool:
             return v
         return torch.zeros(shape, device=device, dtype=torch.float32)
 
+    def serves(self, n, device):
+        """would zeros() of n elements come out of the pool (no fill launch of its own)?"""
+        span = (n + 63) // 64 * 64
+        return self.buf is not None and self.buf.device == device and self.off + span <= self.buf.numel()
+
     def tail_zeroed(self, shape, cut, device):
         """fp32 (rows, cols) tensor whose rows [cut, rows) are zero when the step reaches it (the rows above: anything).
         -> (tensor, True), or (None, False) when the pool cannot serve it in this step (first step of a shape, ...)."""
@@ -130,11 +135,38 @@ def zeros(shape, device):
 ROW_CUT = 4096  # rows of one full round of 64 x 64 tiles on 256 CUs at 256 columns (gemm(): _SPLIT_ROWS)
 
 
-def rows_out(like):
+_DEEP_K = int(os.environ.get("MESM_GEMM_DEEP_K", "768"))        # products this deep with few tiles are split along K (0: off)
+_DEEP_DEPTH = int(os.environ.get("MESM_GEMM_DEEP_DEPTH", "256"))  # reduce indices per workgroup they aim at
+
+
+def deep_out(shape, K, device):
+    """Output tensor (fp32) of a product with K reduce indices and a LINEAR epilogue.  Few tiles x a deep reduce range --
+    320 x 256 x 1024 in the decoder's FFN, 1024 x 256 x 5003 behind the vocabulary head -- is a handful of workgroups that walk
+    16-80 stages each while the chip idles, and inside a grouped launch they are what the launch waits for.  Such an output
+    comes from the step's zero pool (cleared by the one fill launch) and gemm() splits the product along K, partial sums by
+    atomic adds; anything else gets a plain uninitialised tensor."""
+    shape = tuple(int(d_) for d_ in shape)
+    cols = shape[-1]
+    rows = 1
+    for d_ in shape[:-1]:
+        rows *= d_
+    t64 = ((rows + 63) // 64) * ((cols + 63) // 64)
+    if (zero_pool.active and _DEEP_K > 0 and K >= _DEEP_K and t64 <= 128 and min(K // _DEEP_DEPTH, 256 // t64) >= 2
+            and zero_pool.serves(rows * cols, device)):
+        t = zero_pool.zeros(shape, device)
+        zero_pool.handed[t.data_ptr()] = (0, rows)  # (gemm() takes it: every row starts at zero)
+        return t
+    return torch.empty(shape, device=device, dtype=torch.float32)
+
+
+def rows_out(like, K=0):
     """Output tensor of a GEMM with like.shape: when it is one of the 4800 / 4864-row x 256-column products whose remainder
-    rows gemm() runs split along K, a tensor whose remainder rows start at zero (ZeroPool.tail_zeroed); else empty_like."""
+    rows gemm() runs split along K, a tensor whose remainder rows start at zero (ZeroPool.tail_zeroed); a small output of a
+    deep product (K given): deep_out; else empty_like."""
     cols = like.shape[-1]
     rows = like.numel() // cols
+    if K and rows <= ROW_CUT:
+        return deep_out(like.shape, K, like.device)
     if (_SPLIT_ROWS and _SPLIT_TAIL > 1 and cols == 256 and ROW_CUT < rows <= 5120 and like.dtype == torch.float32
             and zero_pool.active):  # (the pool's fill runs at the start of a TRAINING step, MESM._begin)
         t, ok = zero_pool.tail_zeroed((rows, cols), ROW_CUT, like.device)
@@ -189,6 +221,14 @@ def gemm(A, B, C, *, trans_a=False, trans_b=False, A2=None, B2=None, bias=None, 
                  pre_out=sl(pre_out, lo, hi), row0=lo if lo else -1, split_k=_SPLIT_TAIL if (tail and lo) else 1)
         return C
     row0 = max(row0, 0)
+    if zero_pool.handed and zero_pool.handed.get(C.data_ptr()) == (0, C.shape[0]):
+        # an output from deep_out(): every row starts at zero -- few tiles, a deep reduce range, a linear epilogue: split along K
+        zero_pool.handed.pop(C.data_ptr())
+        Kd = A.shape[0] if trans_a else A.shape[1]
+        t64 = ((C.shape[0] + 63) // 64) * ((C.shape[1] + 63) // 64)
+        if (split_k == 1 and accumulate == 0 and e_act == ACT_NONE and e_actgrad == ACT_NONE and pre_out is None
+                and C.is_contiguous()):
+            split_k = max(1, min(Kd // _DEEP_DEPTH, 256 // t64, 16))
     assert A.dtype == B.dtype == C.dtype == torch.float32
     assert A.dim() == 2 and B.dim() == 2 and C.dim() == 2
     assert A.stride(1) == 1 and B.stride(1) == 1 and C.stride(1) == 1

@@ -484,7 +484,8 @@ class LinearBlock:
         x2c = _c(x2) if x2 is not None else None
         K = x.shape[-1]
         N = wv.shape[0]
-        y = torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=torch.float32)
+        y = (torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=torch.float32) if relu
+             else kn.deep_out(x.shape[:-1] + (N,), K, x.device))
         res2 = _2d(_c(residual)) if residual is not None else None
         kn.gemm(_2d(x), wv, _2d(y), trans_b=True, A2=_2d(x2c) if x2c is not None else None,
                 bias=bv, e_act=ACT_RELU if relu else ACT_NONE, a_drop=in_drop, e_drop=out_drop,
@@ -529,8 +530,8 @@ class LinearBlock:
         _accum_dw(dz, _2d(x), _rows(gw, rows), _rows(gb, rows) if gb is not None else None,
                   x2=_2d(x2) if x2 is not None else None, b_drop=ctx.in_drop)
         if need_dx:
-            dx = torch.empty_like(x)
             ir = ctx.in_relu if (x2 is None and ctx.in_drop[0] == 0.0) else None
+            dx = torch.empty_like(x) if ir is not None else kn.deep_out(x.shape, dz.shape[1], x.device)
             if ir is not None:  # x = relu(z) of the previous Linear: write d z (see ReluSink)
                 kn.gemm(dz, _rows(w, rows), _2d(dx), aux=_2d(x), e_actgrad=ACT_RELU)
                 ir.t = dx
@@ -593,7 +594,7 @@ class FFNBlock:
         kn.gemm(_2d(x), w1, _2d(h), trans_b=True, bias=b1, e_act=ACT_PRELU, slope=slope, e_drop=mid_drop,
                 pre_out=_2d(z))
         yield
-        y = kn.rows_out(x)
+        y = kn.rows_out(x, K=F_)
         kn.gemm(_2d(h), w2, _2d(y), trans_b=True, bias=b2, e_drop=out_drop,
                 residual=_2d(_c(residual)) if residual is not None else None)
         ctx.save_for_backward(x, z, h)
@@ -624,7 +625,7 @@ class FFNBlock:
         fold_res = ctx.res_is_x and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
         _accum_dw(_2d(dz1), _2d(x), gw1, gb1)
         if ctx.needs_input_grad[0]:
-            dx = kn.rows_out(x)
+            dx = kn.rows_out(x, K=z.shape[-1])
             # residual input IS x: its gradient (dy) rides the epilogue of the dX GEMM
             kn.gemm(_2d(dz1), w1, _2d(dx), residual=dy2 if fold_res else None)
         return (dx, dy if ctx.has_res and ctx.needs_input_grad[1] and not fold_res else None,
@@ -791,7 +792,7 @@ class NormFFNBlock:
         kn.gemm(_2d(h), w1, _2d(a), trans_b=True, bias=b1, e_act=ACT_PRELU, slope=slope, e_drop=mid_drop,
                 pre_out=_2d(z))
         yield
-        y = kn.rows_out(x)
+        y = kn.rows_out(x, K=F_)
         kn.gemm(_2d(a), w2, _2d(y), trans_b=True, bias=b2, e_drop=out_drop, residual=_2d(x))
         ctx.save_for_backward(x, mean, rstd, h, z, a)
         ctx.params = (gamma, beta, w1, b1, slope, w2, b2)
@@ -817,7 +818,7 @@ class NormFFNBlock:
         _accum_dw(dz2, _2d(a), gw2, gb2)
         kn.gemm(dz2, w2, _2d(dz1), e_drop=ctx.mid_drop, aux=_2d(z), e_actgrad=ACT_PRELU, slope=slope, dslope=gs)
         yield
-        dh = kn.rows_out(h)
+        dh = kn.rows_out(h, K=z.shape[-1])
         _accum_dw(_2d(dz1), _2d(h), gw1, gb1)
         kn.gemm(_2d(dz1), w1, _2d(dh))
         yield
