@@ -1890,8 +1890,9 @@ int prepare(MesmGemmArgs& a, int& vec) {
   if (a.split_k < 1) a.split_k = 1;
   if (a.split_k > 1) {
     // (the epilogue dropout is linear in the partial sums: every k-slice applies the same mask, bias and residual join
-    // the first slice; activations are not)
-    if (a.e_act != MESM_ACT_NONE || a.e_actgrad != MESM_ACT_NONE) return MESM_EINVAL;
+    // the first slice; so is the ReLU gradient -- a 0 / 1 factor per element read from aux; activations and the PReLU
+    // gradient with its slope reduction are not taken)
+    if (a.e_act != MESM_ACT_NONE || (a.e_actgrad != MESM_ACT_NONE && a.e_actgrad != MESM_ACT_RELU)) return MESM_EINVAL;
     a.accumulate = 2;
     int max_split = (a.K + BK_MAX - 1) / BK_MAX;
     if (a.split_k > max_split) a.split_k = max_split;

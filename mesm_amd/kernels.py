@@ -101,9 +101,13 @@ class ZeroPool:
         return torch.zeros(shape, device=device, dtype=torch.float32)
 
     def serves(self, n, device):
-        """would zeros() of n elements come out of the pool (no fill launch of its own)?"""
+        """would zeros() of n elements come out of the pool (no fill launch of its own)?  If not, the request is still
+        counted, so that the next step's pool has room for it."""
         span = (n + 63) // 64 * 64
-        return self.buf is not None and self.buf.device == device and self.off + span <= self.buf.numel()
+        ok = self.buf is not None and self.buf.device == device and self.off + span <= self.buf.numel()
+        if not ok:
+            self.asked += span
+        return ok
 
     def tail_zeroed(self, shape, cut, device):
         """fp32 (rows, cols) tensor whose rows [cut, rows) are zero when the step reaches it (the rows above: anything).
@@ -226,7 +230,7 @@ def gemm(A, B, C, *, trans_a=False, trans_b=False, A2=None, B2=None, bias=None, 
         zero_pool.handed.pop(C.data_ptr())
         Kd = A.shape[0] if trans_a else A.shape[1]
         t64 = ((C.shape[0] + 63) // 64) * ((C.shape[1] + 63) // 64)
-        if (split_k == 1 and accumulate == 0 and e_act == ACT_NONE and e_actgrad == ACT_NONE and pre_out is None
+        if (split_k == 1 and accumulate == 0 and e_act == ACT_NONE and e_actgrad in (ACT_NONE, ACT_RELU) and pre_out is None
                 and C.is_contiguous()):
             split_k = max(1, min(Kd // _DEEP_DEPTH, 256 // t64, 16))
     assert A.dtype == B.dtype == C.dtype == torch.float32

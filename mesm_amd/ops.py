@@ -531,7 +531,7 @@ class LinearBlock:
                   x2=_2d(x2) if x2 is not None else None, b_drop=ctx.in_drop)
         if need_dx:
             ir = ctx.in_relu if (x2 is None and ctx.in_drop[0] == 0.0) else None
-            dx = torch.empty_like(x) if ir is not None else kn.deep_out(x.shape, dz.shape[1], x.device)
+            dx = kn.deep_out(x.shape, dz.shape[1], x.device)  # (the ReLU mask of the ir route is linear in the k-slices too)
             if ir is not None:  # x = relu(z) of the previous Linear: write d z (see ReluSink)
                 kn.gemm(dz, _rows(w, rows), _2d(dx), aux=_2d(x), e_actgrad=ACT_RELU)
                 ir.t = dx

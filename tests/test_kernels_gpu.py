@@ -1215,3 +1215,28 @@ def test_glue_group_matches_individual_launches():
         else:
             assert torch.equal(a, c), k
     assert torch.equal(got[13].view(2, N, L, D)[1], x + b)
+
+
+@pytest.mark.parametrize("M,N,K,tb", [(320, 256, 1024, False), (1024, 256, 5003, True), (64, 256, 1030, False)])
+def test_split_k_takes_the_linear_epilogues(M, N, K, tb):
+    """Split-K (partial sums by atomic adds onto a zeroed C) with every epilogue term that is linear in the partial sums:
+    bias and residual (first slice), dropout (the same mask on every slice), the ReLU gradient (a 0 / 1 factor from aux) --
+    what kernels.deep_out relies on; the result equals the unsplit launch.  A nonlinear epilogue is refused."""
+    from mesm_amd import kernels as kn
+    from mesm_amd._lib import ACT_RELU, ACT_PRELU, MesmError
+    A = gen((M, K), 1, 0.1)
+    W = gen((N, K), 2, 0.1) if tb else gen((K, N), 2, 0.1)
+    bias, res, aux = gen((N,), 3), gen((M, N), 4), gen((M, N), 5)
+    for kw in (dict(bias=bias, residual=res, e_drop=(0.2, 77)), dict(aux=aux, e_actgrad=ACT_RELU),
+               dict(aux=aux, e_actgrad=ACT_RELU, e_drop=(0.5, 3), residual=res)):
+        ref = torch.empty(M, N, device=dev())
+        kn.gemm(A, W, ref, trans_b=tb, **kw)
+        for sk in (2, 4):
+            C = torch.zeros(M, N, device=dev())
+            kn.gemm(A, W, C, trans_b=tb, split_k=sk, **kw)
+            assert rel_err(C, ref) < 3e-6, (sorted(kw), sk)  # (another summation order over up to 5003 terms)
+    with pytest.raises(MesmError):
+        kn.gemm(A, W, torch.zeros(M, N, device=dev()), trans_b=tb, split_k=2, e_act=ACT_RELU)
+    with pytest.raises(MesmError):
+        kn.gemm(A, W, torch.zeros(M, N, device=dev()), trans_b=tb, split_k=2, aux=aux, e_actgrad=ACT_PRELU,
+                slope=torch.full((1,), 0.25, device=dev()))
