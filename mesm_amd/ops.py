@@ -54,6 +54,7 @@ def _c(t):
 
 # reduce indices per workgroup a small weight gradient aims at (0: the standalone rule only) and the workgroups it may become:
 # same-device step times 3.748 (off) / 3.70 (512) / 3.684 (600) / 3.73 (800) ms; 512 workgroups 3.72 (profiles/r5d/dw_split_ab.txt)
+_DW_SMALL = int(os.environ.get("MESM_DW_SMALL", "2"))  # cap of the split for gradients over fewer than 512 rows (0: none; same-device 3.638 -> 3.624 ms)
 _DW_WGS = int(os.environ.get("MESM_DW_WGS", "256"))
 _DW_DEPTH = int(os.environ.get("MESM_DW_DEPTH", "600"))
 
@@ -77,6 +78,8 @@ def _dw_split(n_out, k_in, rows):
         # -- they end the launch alone, 15 us after the 300 dX tiles beside them.  Slices about as deep as the neighbours'
         # (and still at most one workgroup per CU for this member) end together with them.
         s = max(s, min(rows // _DW_DEPTH, _DW_WGS // t64))
+    if _DW_SMALL > 0 and rows < 512:
+        s = min(s, _DW_SMALL)
     return max(1, min(s, rows // 64, 32))
 
 
