@@ -19,8 +19,27 @@ __global__ __launch_bounds__(256) void sine_pos_kernel(const uint8_t* __restrict
     __syncthreads();
     m = ms;
   }
-  // inclusive prefix count of valid clips (exact in fp32, like cumsum(dtype=float32))
-  if (threadIdx.x <= SP_ROWS) {
+  // inclusive prefix count of valid clips (exact in fp32, like cumsum(dtype=float32)): 64 positions per ballot of wave 0
+  // (a thread per prefix walking the mask bytes was a 75-deep chain in front of everything else)
+  __shared__ unsigned long long bal[16];
+  if (L <= 1024) {
+    if (threadIdx.x < 64)
+      for (int c0 = 0; c0 < L; c0 += 64) {
+        const int t = c0 + (int)threadIdx.x;
+        const unsigned long long bits = __ballot(t < L && m[t] != 0);
+        if (threadIdx.x == 0) bal[c0 >> 6] = bits;
+      }
+    __syncthreads();
+    if (threadIdx.x <= SP_ROWS) {
+      int upto = threadIdx.x == SP_ROWS ? L - 1 : l0 + (int)threadIdx.x;
+      upto = upto < L ? upto : L - 1;
+      int c = 0;
+      for (int q = 0; q < (upto >> 6); ++q) c += __popcll(bal[q]);
+      const int r = upto & 63;
+      c += __popcll(bal[upto >> 6] & (r == 63 ? ~0ull : ((1ull << (r + 1)) - 1ull)));
+      xs[threadIdx.x] = (float)c;
+    }
+  } else if (threadIdx.x <= SP_ROWS) {
     const int upto = threadIdx.x == SP_ROWS ? L - 1 : l0 + threadIdx.x;
     int c = 0;
     for (int t = 0; t <= upto && t < L; ++t) c += m[t] != 0;

@@ -75,12 +75,14 @@ __global__ __launch_bounds__(256) void prepend_fwd_kernel(const float* __restric
                                                           float* __restrict__ po, float* __restrict__ xp,
                                                           uint8_t* __restrict__ pado, int L, int D, int tok_per_row,
                                                           int first_pad) {
-  const int b = blockIdx.x, l = blockIdx.y;  // l in [0, L]
+  // (a wave per row, four rows per workgroup: one 64-thread workgroup per row was 4,928 workgroups for 5 MB)
+  const int b = blockIdx.x, l = blockIdx.y * 4 + (threadIdx.x >> 6);  // l in [0, L]
+  if (l > L) return;
   const int64_t orow = ((int64_t)b * (L + 1) + l) * D;
   const float* xs = l == 0 ? tok + (tok_per_row ? (int64_t)b * D : 0) : x + ((int64_t)b * L + l - 1) * D;
   const float* ps = nullptr;
   if (po || xp) ps = l == 0 ? ptok : pos + ((int64_t)b * L + l - 1) * D;
-  for (int c = threadIdx.x * 4; c < D; c += (int)blockDim.x * 4) {
+  for (int c = (threadIdx.x & 63) * 4; c < D; c += 256) {
     const float4 v = *reinterpret_cast<const float4*>(xs + c);
     *reinterpret_cast<float4*>(xo + orow + c) = v;
     if (ps) {
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256) void prepend_fwd_kernel(const float* __restric
       if (xp) *reinterpret_cast<float4*>(xp + orow + c) = make_float4(v.x + q.x, v.y + q.y, v.z + q.z, v.w + q.w);
     }
   }
-  if (pado && threadIdx.x == 0) pado[(int64_t)b * (L + 1) + l] = l == 0 ? (uint8_t)first_pad : pad[(int64_t)b * L + l - 1];
+  if (pado && (threadIdx.x & 63) == 0) pado[(int64_t)b * (L + 1) + l] = l == 0 ? (uint8_t)first_pad : pad[(int64_t)b * L + l - 1];
 }
 
 // backward: g = dxo (+ dxp) [+ dpo for the position outputs]
@@ -100,9 +102,33 @@ __global__ __launch_bounds__(256) void prepend_bwd_kernel(const float* __restric
                                                           const float* __restrict__ dpo, float* __restrict__ dx,
                                                           float* __restrict__ dtok, float* __restrict__ dptok, int L, int D,
                                                           int tok_per_row) {
-  const int b = blockIdx.x, l = blockIdx.y;
+  const int b = blockIdx.x, l = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (l > L) return;
+  if (l == 0 && !tok_per_row) {
+    // the shared token's gradient: ONE wave (b = 0) sums the token rows of every batch row and adds once per column -- an
+    // atomic per batch row was 64-way contention on 512 addresses, 8 of the launch's 11 us
+    if (b != 0) return;
+    const int B = (int)gridDim.x;
+    for (int c = (threadIdx.x & 63) * 4; c < D; c += 256) {
+      float4 g = make_float4(0.f, 0.f, 0.f, 0.f), gp = g;
+#pragma unroll 4
+      for (int bb = 0; bb < B; ++bb) {
+        const int64_t o = (int64_t)bb * (L + 1) * D + c;
+        if (dxo) { const float4 u = *reinterpret_cast<const float4*>(dxo + o); g.x += u.x; g.y += u.y; g.z += u.z; g.w += u.w; }
+        if (dxp) {
+          const float4 u = *reinterpret_cast<const float4*>(dxp + o);
+          g.x += u.x; g.y += u.y; g.z += u.z; g.w += u.w;
+          gp.x += u.x; gp.y += u.y; gp.z += u.z; gp.w += u.w;
+        }
+        if (dptok && dpo) { const float4 u = *reinterpret_cast<const float4*>(dpo + o); gp.x += u.x; gp.y += u.y; gp.z += u.z; gp.w += u.w; }
+      }
+      if (dtok) { atomicAdd(dtok + c, g.x); atomicAdd(dtok + c + 1, g.y); atomicAdd(dtok + c + 2, g.z); atomicAdd(dtok + c + 3, g.w); }
+      if (dptok) { atomicAdd(dptok + c, gp.x); atomicAdd(dptok + c + 1, gp.y); atomicAdd(dptok + c + 2, gp.z); atomicAdd(dptok + c + 3, gp.w); }
+    }
+    return;
+  }
   const int64_t orow = ((int64_t)b * (L + 1) + l) * D;
-  for (int c = threadIdx.x * 4; c < D; c += (int)blockDim.x * 4) {
+  for (int c = (threadIdx.x & 63) * 4; c < D; c += 256) {
     float4 g = make_float4(0.f, 0.f, 0.f, 0.f), gp = g;
     if (dxo) g = *reinterpret_cast<const float4*>(dxo + orow + c);
     if (dxp) {
@@ -137,9 +163,10 @@ __global__ __launch_bounds__(256) void prepend_bwd_kernel(const float* __restric
 __global__ __launch_bounds__(256) void split_fwd_kernel(const float* __restrict__ mem, float* __restrict__ g,
                                                         float* __restrict__ loc, float* __restrict__ dec, int L, int D,
                                                         int Bd) {
-  const int b = blockIdx.x, l = blockIdx.y;
+  const int b = blockIdx.x, l = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (l > L) return;
   const float* s = mem + ((int64_t)b * (L + 1) + l) * D;
-  for (int c = threadIdx.x * 4; c < D; c += (int)blockDim.x * 4) {
+  for (int c = (threadIdx.x & 63) * 4; c < D; c += 256) {
     const float4 v = *reinterpret_cast<const float4*>(s + c);
     if (l == 0) {
       *reinterpret_cast<float4*>(g + (int64_t)b * D + c) = v;
@@ -153,9 +180,10 @@ __global__ __launch_bounds__(256) void split_fwd_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void split_bwd_kernel(const float* __restrict__ dg, const float* __restrict__ dloc,
                                                         const float* __restrict__ ddec, float* __restrict__ dmem, int L,
                                                         int D, int Bd) {
-  const int b = blockIdx.x, l = blockIdx.y;
+  const int b = blockIdx.x, l = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (l > L) return;
   float* d = dmem + ((int64_t)b * (L + 1) + l) * D;
-  for (int c = threadIdx.x * 4; c < D; c += (int)blockDim.x * 4) {
+  for (int c = (threadIdx.x & 63) * 4; c < D; c += 256) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (l == 0) {
       if (dg) v = *reinterpret_cast<const float4*>(dg + (int64_t)b * D + c);
@@ -545,7 +573,7 @@ extern "C" int mesm_prepend_fwd(const float* tok, const float* x, const float* p
   if (!tok || !x || !xo || B <= 0 || L <= 0 || D <= 0 || (D & 3)) return MESM_EINVAL;
   if ((po || xp) && (!ptok || !pos)) return MESM_EINVAL;
   if (pado && !pad) return MESM_EINVAL;
-  hipLaunchKernelGGL(prepend_fwd_kernel, dim3(B, L + 1), dim3(64), 0, (hipStream_t)stream, tok, x, ptok, pos, pad, xo,
+  hipLaunchKernelGGL(prepend_fwd_kernel, dim3(B, (L + 4) / 4), dim3(256), 0, (hipStream_t)stream, tok, x, ptok, pos, pad, xo,
                      po, xp, pado, L, D, tok_per_row, first_pad);
   return mesm_launch_status();
 }
@@ -553,7 +581,7 @@ extern "C" int mesm_prepend_fwd(const float* tok, const float* x, const float* p
 extern "C" int mesm_prepend_bwd(const float* dxo, const float* dxp, const float* dpo, float* dx, float* dtok,
                                 float* dptok, int32_t B, int32_t L, int32_t D, int32_t tok_per_row, void* stream) {
   if ((!dxo && !dxp) || B <= 0 || L <= 0 || D <= 0 || (D & 3)) return MESM_EINVAL;
-  hipLaunchKernelGGL(prepend_bwd_kernel, dim3(B, L + 1), dim3(64), 0, (hipStream_t)stream, dxo, dxp, dpo, dx, dtok,
+  hipLaunchKernelGGL(prepend_bwd_kernel, dim3(B, (L + 4) / 4), dim3(256), 0, (hipStream_t)stream, dxo, dxp, dpo, dx, dtok,
                      dptok, L, D, tok_per_row);
   return mesm_launch_status();
 }
@@ -561,14 +589,14 @@ extern "C" int mesm_prepend_bwd(const float* dxo, const float* dxp, const float*
 extern "C" int mesm_split_token_fwd(const float* mem, float* g, float* loc, float* dec, int32_t B, int32_t L, int32_t D,
                                     int32_t Bd, void* stream) {
   if (!mem || !g || !loc || B <= 0 || L <= 0 || D <= 0 || (D & 3) || Bd < 0 || Bd > B) return MESM_EINVAL;
-  hipLaunchKernelGGL(split_fwd_kernel, dim3(B, L + 1), dim3(64), 0, (hipStream_t)stream, mem, g, loc, dec, L, D, Bd);
+  hipLaunchKernelGGL(split_fwd_kernel, dim3(B, (L + 4) / 4), dim3(256), 0, (hipStream_t)stream, mem, g, loc, dec, L, D, Bd);
   return mesm_launch_status();
 }
 
 extern "C" int mesm_split_token_bwd(const float* dg, const float* dloc, const float* ddec, float* dmem, int32_t B,
                                     int32_t L, int32_t D, int32_t Bd, void* stream) {
   if (!dmem || B <= 0 || L <= 0 || D <= 0 || (D & 3) || Bd < 0 || Bd > B) return MESM_EINVAL;
-  hipLaunchKernelGGL(split_bwd_kernel, dim3(B, L + 1), dim3(64), 0, (hipStream_t)stream, dg, dloc, ddec, dmem, L, D, Bd);
+  hipLaunchKernelGGL(split_bwd_kernel, dim3(B, (L + 4) / 4), dim3(256), 0, (hipStream_t)stream, dg, dloc, ddec, dmem, L, D, Bd);
   return mesm_launch_status();
 }
 

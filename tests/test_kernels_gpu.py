@@ -1240,3 +1240,38 @@ def test_split_k_takes_the_linear_epilogues(M, N, K, tb):
     with pytest.raises(MesmError):
         kn.gemm(A, W, torch.zeros(M, N, device=dev()), trans_b=tb, split_k=2, aux=aux, e_actgrad=ACT_PRELU,
                 slope=torch.full((1,), 0.25, device=dev()))
+
+
+@pytest.mark.parametrize("B,L,D", [(64, 75, 256), (5, 3, 64), (2, 9, 132)])
+def test_prepend_and_split_token_kernels(B, L, D):
+    """mesm_prepend_* / mesm_split_token_* (a wave per row, four rows per workgroup; the shared token's gradient summed over
+    the batch by one wave) against their torch statements: values bit-exact (copies and one add), gradients too where
+    nothing is summed, the shared token's batch sums within rounding."""
+    from mesm_amd import kernels as kn
+    tok, ptok = gen((D,), 1), gen((D,), 2)
+    x, pos = gen((B, L, D), 3), gen((B, L, D), 4)
+    pad = (torch.rand(B, L, generator=torch.Generator().manual_seed(5)) < 0.3).to(dev())
+    xo, po, xp, pado = kn.prepend_fwd(tok, x, ptok, pos, pad, True)
+    assert torch.equal(xo, torch.cat([tok.expand(B, 1, D), x], 1)) and torch.equal(po, torch.cat([ptok.expand(B, 1, D), pos], 1))
+    assert torch.equal(xp, xo + po) and torch.equal(pado, torch.cat([torch.ones(B, 1, dtype=pad.dtype, device=dev()), pad], 1))
+    rows = gen((B, D), 6)  # a token per batch row
+    xo2 = kn.prepend_fwd(rows, x, pad=pad, first_pad=False)[0]
+    assert torch.equal(xo2, torch.cat([rows[:, None], x], 1))
+    dxo, dxp, dpo = gen((B, L + 1, D), 7), gen((B, L + 1, D), 8), gen((B, L + 1, D), 9)
+    dx, dtok, dptok = torch.empty(B, L, D, device=dev()), torch.zeros(D, device=dev()), torch.zeros(D, device=dev())
+    kn.prepend_bwd(dxo, dxp, dpo, dx, dtok, dptok, B, L, D, False)
+    assert torch.equal(dx, (dxo + dxp)[:, 1:])
+    assert rel_err(dtok, (dxo + dxp)[:, 0].double().sum(0).float()) < 1e-6
+    assert rel_err(dptok, (dxp + dpo)[:, 0].double().sum(0).float()) < 1e-6
+    dx2, drows = torch.empty(B, L, D, device=dev()), torch.empty(B, D, device=dev())
+    kn.prepend_bwd(dxo, None, None, dx2, drows, None, B, L, D, True)
+    assert torch.equal(dx2, dxo[:, 1:]) and torch.equal(drows, dxo[:, 0])
+    mem = gen((B, L + 1, D), 10)
+    Bd = B // 2
+    g, loc, dec = kn.split_token_fwd(mem, Bd)
+    assert torch.equal(g, mem[:, 0]) and torch.equal(loc, mem[:, 1:]) and (Bd == 0 or torch.equal(dec, mem[:Bd, 1:]))
+    dg, dloc, ddec = gen((B, D), 11), gen((B, L, D), 12), gen((Bd, L, D), 13)
+    dmem = kn.split_token_bwd(dg, dloc, ddec, B, L, D, Bd, dev())
+    want = torch.cat([dg[:, None], dloc], 1)
+    want[:Bd, 1:] += ddec
+    assert torch.equal(dmem, want)
