@@ -427,5 +427,5 @@ extern "C" int mesm_act_dropout(const float* x, float* y, int64_t n, int32_t act
   return mesm_launch_status();
 }
 
-extern "C" int mesm_abi_version(void) { return 8; }  // 8: mesm_ref_init_*; 7: mesm_skinny_linear_bwd; 6: MesmAttnArgs.mask_mod, MesmLnArgs + group entries, *_nv, mesm_ddp_*, match_q = -1
+extern "C" int mesm_abi_version(void) { return 9; }  // 9: mesm_criterion_fwd / _bwd, mesm_glue_group, mesm_fill_ranges, mesm_add_n, split-K with dropout / ReLU-gradient epilogues (plane GEMM entries removed); 8: mesm_ref_init_*; 7: mesm_skinny_linear_bwd; 6: MesmAttnArgs.mask_mod, MesmLnArgs + group entries, *_nv, mesm_ddp_*, match_q = -1
 extern "C" const char* mesm_arch(void) { return "gfx950"; }
