@@ -105,14 +105,17 @@ __global__ __launch_bounds__(256) void prepend_bwd_kernel(const float* __restric
   const int b = blockIdx.x, l = blockIdx.y * 4 + (threadIdx.x >> 6);
   if (l > L) return;
   if (l == 0 && !tok_per_row) {
-    // the shared token's gradient: ONE wave (b = 0) sums the token rows of every batch row and adds once per column -- an
-    // atomic per batch row was 64-way contention on 512 addresses, 8 of the launch's 11 us
-    if (b != 0) return;
+    // the shared token's gradient: the wave of every 8th batch row sums the token rows of its 8 batch rows (loads in flight
+    // together) and adds once per column -- an atomic per batch row was 64-way contention on 512 addresses, 8 of the
+    // launch's 11 us; ONE wave walking all 64 rows was a 64-deep chain of loads, 50 us
+    if (b & 7) return;
     const int B = (int)gridDim.x;
     for (int c = (threadIdx.x & 63) * 4; c < D; c += 256) {
       float4 g = make_float4(0.f, 0.f, 0.f, 0.f), gp = g;
-#pragma unroll 4
-      for (int bb = 0; bb < B; ++bb) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int bb = b + u;
+        if (bb >= B) break;
         const int64_t o = (int64_t)bb * (L + 1) * D + c;
         if (dxo) { const float4 u = *reinterpret_cast<const float4*>(dxo + o); g.x += u.x; g.y += u.y; g.z += u.z; g.w += u.w; }
         if (dxp) {
