@@ -763,6 +763,7 @@ int mesm_add_n(const float* const* srcs, int32_t k, float* out, int64_t n, void*
  *   UNSTACK_ROWS    p: d2, idx, dx                       n[0] R            i[0] N
  *   STACK_ROWS      p: src, dst, idx (NULL: repeat)      n[0] row bytes    i[0] N      (one tensor of mesm_stack_rows)
  *   ADD_TILE        p: a, b, out   out[k] = a[k % na] + b[k % nb]: n[0] = elements of out, n[1] = na, i[0..1] = nb as int64
+ *   GATHER_ADD      p: a, b, idx, valid, y       y[j] = valid[j] ? a[idx[j]] + b[idx[j]] : 0: n[0] rows, i[0] D
  */
 enum {
   MESM_GLUE_TOKEN_MIX_FWD = 1,
@@ -771,7 +772,8 @@ enum {
   MESM_GLUE_GATHER_ROWS_BWD = 4,
   MESM_GLUE_UNSTACK_ROWS = 5,
   MESM_GLUE_STACK_ROWS = 6,
-  MESM_GLUE_ADD_TILE = 7
+  MESM_GLUE_ADD_TILE = 7,
+  MESM_GLUE_GATHER_ADD = 8
 };
 typedef struct MesmGlueArgs {
   int32_t op;

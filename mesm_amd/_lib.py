@@ -83,7 +83,7 @@ class GlueArgs(ctypes.Structure):
 
 
 GLUE_TOKEN_MIX_FWD, GLUE_TOKEN_MIX_BWD, GLUE_GATHER_ROWS_FWD, GLUE_GATHER_ROWS_BWD = 1, 2, 3, 4
-GLUE_UNSTACK_ROWS, GLUE_STACK_ROWS, GLUE_ADD_TILE = 5, 6, 7
+GLUE_UNSTACK_ROWS, GLUE_STACK_ROWS, GLUE_ADD_TILE, GLUE_GATHER_ADD = 5, 6, 7, 8
 
 
 class CritFwdArgs(ctypes.Structure):

@@ -490,6 +490,21 @@ __global__ __launch_bounds__(256) void glue_group_kernel(const GlueGroup g) {
       }
       break;
     }
+    case MESM_GLUE_GATHER_ADD: {  // y[j] = valid[j] ? a[idx[j]] + b[idx[j]] : 0 (a wave per row)
+      const float* pa = (const float*)a.p[0];
+      const float* pb = (const float*)a.p[1];
+      const int64_t* idx = (const int64_t*)a.p[2];
+      const uint8_t* valid = (const uint8_t*)a.p[3];
+      float* y = (float*)a.p[4];
+      const int D = a.i[0];
+      const int64_t j = (int64_t)bx * 4 + (threadIdx.x >> 6);
+      if (j < a.n[0]) {
+        const bool ok = valid == nullptr || valid[j] != 0;
+        const int64_t r = idx[j];
+        for (int c = threadIdx.x & 63; c < D; c += 64) y[j * D + c] = ok ? pa[r * D + c] + pb[r * D + c] : 0.0f;
+      }
+      break;
+    }
     default:
       break;
   }
@@ -726,6 +741,10 @@ extern "C" int mesm_glue_group(const MesmGlueArgs* list, int32_t n, void* stream
         if (gx > 2048) gx = 2048;
         break;
       }
+      case MESM_GLUE_GATHER_ADD:  // p: a, b, idx, valid, y; n[0] rows; i[0] D
+        if (!a.p[0] || !a.p[1] || !a.p[2] || !a.p[4] || a.n[0] <= 0 || D <= 0) return MESM_EINVAL;
+        gx = (a.n[0] + 3) / 4;
+        break;
       default:
         return MESM_EINVAL;
     }

@@ -1271,6 +1271,18 @@ def add_tile(a, b, reps):
     return out
 
 
+def gather_add(a2d, b2d, idx, valid=None):
+    """y[j] = valid[j] ? a2d[idx[j]] + b2d[idx[j]] : 0 -> (*idx.shape, D): gathered features + their gathered position
+    embeddings in one pass (the key-side query of the MLM branch, model.py:312-325 + transformer.py:512)"""
+    require_gpu(a2d, b2d, idx)
+    assert a2d.dim() == 2 and a2d.shape == b2d.shape and a2d.is_contiguous() and b2d.is_contiguous()
+    assert idx.dtype == torch.int64 and idx.is_contiguous()
+    D = a2d.shape[1]
+    y = torch.empty(*idx.shape, D, device=a2d.device, dtype=torch.float32)
+    _glue(_lib.GLUE_GATHER_ADD, (a2d, b2d, idx, valid, y), n=(idx.numel(),), i=(D,), keep=(a2d, b2d, idx, valid, y))
+    return y
+
+
 def add_wrap(a, b):
     """a + b with b repeated along dim 0 (a.numel() a multiple of b.numel())."""
     require_gpu(a, b)

@@ -158,8 +158,10 @@ class T2VLayer(nn.Module):
         self.p = dropout
 
     def steps(self, txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm=False, group=0, vid_p=None,
-              out_pos=None, kv_share=None, join_qp=False):
+              out_pos=None, kv_share=None, join_qp=False, txt_p=None):
         """The layer as a chain of three block calls (ops.lockstep).
+        txt_p: txt + pos_txt formed without autograd (ops.gather_add): the key projection reads it as a plain operand,
+        its gradient joins d txt inside the block (like join_qp on the query side) and d txt can be shared across layers.
         join_qp: vid_p was formed without autograd (vid + a constant): its gradient joins d vid inside the block.
         kv_share: ops.GradShare of the stack's layers for d txt (no key position term).
         vid_p: vid + pos_vid when the producer of vid has already written it (None: formed here).
@@ -167,10 +169,11 @@ class T2VLayer(nn.Module):
         sa = self.self_attn
         if vid_p is None and pos_vid is not None:
             vid_p = vid + pos_vid
-        x = yield ops.mha_call(vid, vid_p, txt, pos_txt, vid, sa.in_proj_weight, sa.in_proj_bias,
+        keyless = pos_txt is None or txt_p is not None  # (no position term left on the key side of the backward)
+        x = yield ops.mha_call(vid, vid_p, txt, pos_txt if txt_p is None else None, vid, sa.in_proj_weight, sa.in_proj_bias,
                                sa.out_proj.weight, sa.out_proj.bias, self.nhead, kpad=txt_pad, qpad=vid_pad,
                                attn_drop=drop_state.next(self.p), out_drop=drop_state.next(self.p), group=group,
-                               kv_share=kv_share if pos_txt is None else None, join_qp=join_qp)
+                               kv_share=kv_share if keyless else None, join_qp=join_qp, xkp=txt_p)
         alt = self.two_mlp and is_mlm
         n1, n2 = (self.norm1_1, self.norm2_1) if alt else (self.norm1, self.norm2)
         l1, l2 = (self.linear1_1, self.linear2_1) if alt else (self.linear1, self.linear2)
@@ -195,14 +198,15 @@ class T2VStack(nn.Module):
         self.layers = _clones(layer, n)
 
     def steps(self, txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm=False, group=0, vid_p=None,
-              out_pos=None, join_vid_p=False):
+              out_pos=None, join_vid_p=False, txt_p=None):
         n = len(self.layers)
         # every layer reads the same txt: their d txt shares are summed by the dX GEMMs' epilogues, not by autograd
-        share = ops.GradShare(n) if (n > 1 and pos_txt is None and torch.is_grad_enabled() and txt.requires_grad) else None
+        share = ops.GradShare(n) if (n > 1 and (pos_txt is None or txt_p is not None) and torch.is_grad_enabled()
+                                     and txt.requires_grad) else None
         for i, l in enumerate(self.layers):
             op = out_pos if i == n - 1 else pos_vid
             res = yield from l.steps(txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm, group, vid_p=vid_p,
-                                     out_pos=op, kv_share=share, join_qp=join_vid_p and i == 0)
+                                     out_pos=op, kv_share=share, join_qp=join_vid_p and i == 0, txt_p=txt_p)
             vid, vid_p = res if op is not None else (res, None)
         return (vid, vid_p) if out_pos is not None else vid
 
@@ -233,9 +237,9 @@ class T2VEncoder(nn.Module):
                                 out_pos=out_pos)
 
     def steps(self, txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm=False, group=0, vid_p=None, out_pos=None,
-              join_vid_p=False):
+              join_vid_p=False, txt_p=None):
         return self.t2v_encoder.steps(txt, vid, pos_txt, pos_vid, txt_pad, vid_pad, is_mlm, group, vid_p=vid_p,
-                                      out_pos=out_pos, join_vid_p=join_vid_p)
+                                      out_pos=out_pos, join_vid_p=join_vid_p, txt_p=txt_p)
 
 
 class EncoderLayer(nn.Module):

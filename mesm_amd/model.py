@@ -461,13 +461,16 @@ class MESM(nn.Module):
                 # their position embeddings (model.py:312-325)
                 prep += [ops.token_mix_call(pw_t, kwargs["unknown_mask"], unk, plan.masked_words, msk),
                          ops.gather_rows2_call(pv_g.reshape(N * Lv, d), plan.clip_src, plan.clip_inv, plan.clip_mask),
-                         ops.gather_rows2_call(vpos.reshape(N * Lv, d), plan.clip_src, plan.clip_inv, plan.clip_mask)]
+                         ops.gather_rows2_call(vpos.reshape(N * Lv, d), plan.clip_src, plan.clip_inv, plan.clip_mask),
+                         # clips + their positions in one pass: the key-side input of the MLM blocks (a plain operand)
+                         ops.gather_add_call(pv.detach().reshape(N * Lv, d), vpos.reshape(N * Lv, d), plan.clip_src,
+                                             plan.clip_mask)]
             prep = ops.par(prep)
             (pv2, vpos2, vid_pad2, pw2, wpad2), pvp2 = prep[0], prep[1]
             if self.rec_ss:
                 q_tok = prep[2]
             if mlm:
-                w, cfeat, cpos = prep[-3:]
+                w, cfeat, cpos, cfeat_p = prep[-4:]
             stage, names = [], []
             tpos2 = None
             if self.rec_fw:
@@ -485,7 +488,7 @@ class MESM(nn.Module):
                 stage.append(self.ss_reconstructor.recon_trans.steps(bvid, q_tok, None, None, bvid_pad, plan.sent_pad))
                 names.append("S")
             if mlm:
-                m_chain = enc.steps(cfeat, w, cpos, tpos, plan.clip_pad, words_pad, is_mlm=True)  # pos_vid = txt_position
+                m_chain = enc.steps(cfeat, w, cpos, tpos, plan.clip_pad, words_pad, is_mlm=True, txt_p=cfeat_p)  # pos_vid = txt_position
                 # beside the SS-MESM layers that outlast the enhance stack (3 rounds per layer)
                 lag = 3 * len(enc.t2v_encoder.layers) if ("E" in names and "S" in names) else 0
                 stage.append(ops.delayed(m_chain, lag))

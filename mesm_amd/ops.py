@@ -1078,7 +1078,10 @@ class MHABlock:
 
     @staticmethod
     def fwd(ctx, xq, xqp, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad, qpad, attn_drop,
-            out_drop, self_attn, group=0, sink=None, kv_share=None, join_qp=False):
+            out_drop, self_attn, group=0, sink=None, kv_share=None, join_qp=False, xkp=None):
+        # xkp: xk + its position embedding formed WITHOUT autograd (ops.gather_add): the key projection reads it as a plain
+        # operand (a second-operand product runs outside the grouped launch) and its gradient belongs to xk -- the key side's
+        # backward is then the position-free one: one dX product, shared across the layers of a stack
         ctx.set_materialize_grads(False)
         ctx.sink = sink
         ctx.kv_share = kv_share
@@ -1106,11 +1109,17 @@ class MHABlock:
             q = torch.empty(N, Lq, d, device=dev, dtype=torch.float32)
             kn.gemm(_2d(xqp), w_in[:d], _2d(q), trans_b=True, bias=b_in[:d])
             xk = _c(xk)
-            pk = _c(pk) if pk is not None else None
+            if xkp is not None:
+                pk = _c(xkp)  # (saved in pk's slot; ctx.has_xkp tells the backward which it is)
+            else:
+                pk = _c(pk) if pk is not None else None
             Lk = xk.shape[1]
             kv = torch.empty(N, Lk, 2 * d, device=dev, dtype=torch.float32)
             kv2 = _2d(kv)
-            if pk is None:
+            if xkp is not None:
+                kn.gemm(_2d(pk), w_in[d:2 * d], kv2[:, :d], trans_b=True, bias=b_in[d:2 * d])
+                kn.gemm(_2d(xk), w_in[2 * d:], kv2[:, d:], trans_b=True, bias=b_in[2 * d:])
+            elif pk is None:
                 kn.gemm(_2d(xk), w_in[d:], kv2, trans_b=True, bias=b_in[d:])
             else:
                 kn.gemm(_2d(xk), w_in[d:2 * d], kv2[:, :d], trans_b=True, A2=_2d(pk), bias=b_in[d:2 * d])
@@ -1123,6 +1132,7 @@ class MHABlock:
         kn.gemm(_2d(o), w_out, _2d(out), trans_b=True, bias=b_out, e_drop=out_drop,
                 residual=_2d(_c(residual)) if residual is not None else None)
         ctx.save_for_backward(xq, xqp if has_p else None, xk, pk, q, k, v, o, lse)
+        ctx.has_xkp = xkp is not None and not self_attn
         ctx.params = (w_in, b_in, w_out, b_out)
         ctx.res_is_xq = residual is not None and residual.data_ptr() == xq.data_ptr() and residual.shape == xq.shape
         ctx.cfg = (H, kpad, qpad, attn_drop, out_drop, self_attn, residual is not None, group, has_p)
@@ -1131,6 +1141,9 @@ class MHABlock:
     @staticmethod
     def bwd(ctx, dy):
         xq, xqp, xk, pk, q, k, v, o, lse = ctx.saved_tensors
+        xkp = None
+        if ctx.has_xkp:
+            xkp, pk = pk, None
         w_in, b_in, w_out, b_out = ctx.params
         H, kpad, qpad, attn_drop, out_drop, self_attn, has_res, group, has_p = ctx.cfg
         if xqp is None:
@@ -1187,7 +1200,10 @@ class MHABlock:
             g2 = _2d(dkv)
             # dWq, dWkv, dX(query side), dX(key side): all independent
             _accum_dw(_2d(dq), _2d(xqp), gwi[:d], gbi[:d])
-            if pk is None:
+            if xkp is not None:
+                _accum_dw(g2[:, :d], _2d(xkp), gwi[d:2 * d], gbi[d:2 * d])
+                _accum_dw(g2[:, d:], _2d(xk), gwi[2 * d:], gbi[2 * d:])
+            elif pk is None:
                 _accum_dw(g2, _2d(xk), gwi[d:], gbi[d:])
             else:
                 _accum_dw(g2[:, :d], _2d(xk), gwi[d:2 * d], gbi[d:2 * d], x2=_2d(pk))
@@ -1227,14 +1243,14 @@ class MHABlock:
                     kn.gemm(g2[:, d:], w_in[2 * d:], _2d(dxk), residual=_2d(dk_in))
         return (dxq, dxqp, dxk, dpk, dy if has_res and ctx.needs_input_grad[4] and not fold else None,
                 None if d_wi else gwi, None if d_bi else gbi, None if d_wo else gwo,
-                None if d_bo else gbo, None, None, None, None, None, None, None, None, None, None)
+                None if d_bo else gbo, None, None, None, None, None, None, None, None, None, None, None)
 
 
 def mha_call(xq, xqp, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad=None, qpad=None,
-             attn_drop=NO_DROP, out_drop=NO_DROP, self_attn=False, group=0, kv_share=None, join_qp=False):
+             attn_drop=NO_DROP, out_drop=NO_DROP, self_attn=False, group=0, kv_share=None, join_qp=False, xkp=None):
     sink = _sink_for(out_drop)
     return Call(MHABlock, (xq, xqp, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad, qpad, attn_drop,
-                           out_drop, self_attn, group, sink, kv_share, join_qp), lambda y: _tag(y, sink))
+                           out_drop, self_attn, group, sink, kv_share, join_qp, xkp), lambda y: _tag(y, sink))
 
 
 def mha(xq, xqp, xk, pk, residual, w_in, b_in, w_out, b_out, H, kpad=None, qpad=None,
@@ -1569,6 +1585,21 @@ class AddTileFn(Function):
         return None, None, None
 
 
+class GatherAddFn(Function):
+    """a2d[idx] + b2d[idx] (rows masked by valid), formed WITHOUT autograd: the key-side input of an attention block whose
+    gradient the block folds into the gradient of its plain key input (MHABlock xkp)."""
+
+    @staticmethod
+    def forward(ctx, a2d, b2d, idx, valid):
+        y = kn.gather_add(_c(a2d), _c(b2d), idx, valid)
+        ctx.mark_non_differentiable(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return None, None, None, None
+
+
 def glue_block(fn_cls, n_out, name):
     """An assembly Function as a block for par() / lockstep: inside the node's launch phases its kernels are QUEUED
     (kn.glue_deferred) and leave with the phase's one grouped assembly launch, forward and backward -- for assembly calls
@@ -1595,6 +1626,7 @@ StackRowsBlock = glue_block(StackRowsFn, lambda idx, gather, *xs: len(xs), "Stac
 TokenMixBlock = glue_block(TokenMixFn, 1, "TokenMixBlock")
 GatherRows2Block = glue_block(GatherRows2Fn, 1, "GatherRows2Block")
 AddTileBlock = glue_block(AddTileFn, 1, "AddTileBlock")
+GatherAddBlock = glue_block(GatherAddFn, 1, "GatherAddBlock")
 
 
 def stack_rows_call(xs, gather, idx):
@@ -1611,6 +1643,10 @@ def gather_rows2_call(x2d, idx, inv, valid=None, normalize=False):
 
 def add_tile_call(a, b, reps):
     return Call(AddTileBlock, (a, b, reps))
+
+
+def gather_add_call(a2d, b2d, idx, valid=None):
+    return Call(GatherAddBlock, (a2d, b2d, idx, valid))
 
 
 # ----------------------------------------------------------------------------- decoder reference points
