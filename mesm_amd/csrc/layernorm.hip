@@ -67,17 +67,28 @@ __device__ __forceinline__ void st_vec(float* __restrict__ p, const float* s) {
 // run at about half rate here: 2400 x 2818 20.8 -> 29.7 us); the first and the last chunk of a row are partial and go
 // element by element.  The 2-wide / 1-wide paths this replaces ran 36 / 72 narrow accesses per lane and row:
 // 8192 x 4098 (TACoS) 192 us = 1.4 TB/s against 69 us at 4096 columns.
+// A TWIN output (tw.y != NULL): the same input normalised once, written twice under two dropout masks -- the reference
+// projects the raw video features twice (model.py:166, 201: the main path and the SS-MESM copy of the batch), each through
+// its own Dropout; when the copy IS the batch the two LayerNorms read the same 27 MB.
+struct LnTwin {
+  float* y;
+  float* mean;
+  float* rstd;
+  LnDrop dr;
+};
+
 template <int VEC, int NCH, bool TAIL = false>
 __device__ __forceinline__ void ln_fwd_body(
     const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ y, float* __restrict__ mean,
     float* __restrict__ rstd, int64_t rows, int D, float eps, LnDrop dr,
-    const float* __restrict__ add, float* __restrict__ y2, int bid, int nblk) {
+    const float* __restrict__ add, float* __restrict__ y2, int bid, int nblk, const LnTwin tw = LnTwin{}) {
   const int lane = threadIdx.x & 63;
   const int64_t wave_global = (int64_t)bid * LN_WAVES + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)nblk * LN_WAVES;
   const float invD = 1.0f / (float)D;
   const uint32_t dseed = dr.seed + (dr.seed_offset ? *dr.seed_offset : 0u);
+  const uint32_t dseed_b = tw.dr.seed + (tw.dr.seed_offset ? *tw.dr.seed_offset : 0u);
   for (int64_t row = wave_global; row < rows; row += nwaves) {
     const float* xr = x + row * D;
     const int sh = TAIL ? (int)((row * D) & 3) : 0;  // chunk c of lane l starts at column (c * 64 + l) * VEC - sh
@@ -121,6 +132,11 @@ __device__ __forceinline__ void ln_fwd_body(
         for (int e = 0; e < VEC; ++e) {
           if (col + e >= 0 && col + e < D) {
             float o = (v[c][e] - mu) * rs * gamma[col + e] + beta[col + e];
+            if (tw.y) {
+              float ob = o;
+              if (tw.dr.thresh) ob = mesm_dropout_apply(ob, (uint32_t)(row * D + col + e), dseed_b, tw.dr.thresh, tw.dr.inv_keep);
+              tw.y[row * D + col + e] = ob;
+            }
             if (dr.thresh) o = mesm_dropout_apply(o, (uint32_t)(row * D + col + e), dseed, dr.thresh, dr.inv_keep);
             yr[col + e] = o;
             if (y2) y2[row * D + col + e] = o + add[row * D + col + e];
@@ -139,10 +155,19 @@ __device__ __forceinline__ void ln_fwd_body(
           ld_vec<VEC>(beta + col, b);
         }
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          o[e] = (v[c][e] - mu) * rs * g[e] + b[e];
-          if (dr.thresh) o[e] = mesm_dropout_apply(o[e], (uint32_t)(row * D + col + e), dseed, dr.thresh, dr.inv_keep);
+        for (int e = 0; e < VEC; ++e) o[e] = (v[c][e] - mu) * rs * g[e] + b[e];
+        if (tw.y) {
+          float ob[VEC];
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            ob[e] = o[e];
+            if (tw.dr.thresh) ob[e] = mesm_dropout_apply(ob[e], (uint32_t)(row * D + col + e), dseed_b, tw.dr.thresh, tw.dr.inv_keep);
+          }
+          st_vec<VEC>(tw.y + row * D + col, ob);
         }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if (dr.thresh) o[e] = mesm_dropout_apply(o[e], (uint32_t)(row * D + col + e), dseed, dr.thresh, dr.inv_keep);
         st_vec<VEC>(yr + col, o);
         if (y2) {  // y + add: the `with_pos_embed` query of the attention block that consumes y
           float a[VEC];
@@ -156,6 +181,7 @@ __device__ __forceinline__ void ln_fwd_body(
     if (lane == 0) {
       mean[row] = mu;
       rstd[row] = rs;
+      if (tw.y) { tw.mean[row] = mu; tw.rstd[row] = rs; }
     }
   }
 }
@@ -209,6 +235,13 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(
     float* __restrict__ rstd, int64_t rows, int D, float eps, LnDrop dr,
     const float* __restrict__ add, float* __restrict__ y2) {
   ln_fwd_body<VEC, NCH, TAIL>(x, gamma, beta, y, mean, rstd, rows, D, eps, dr, add, y2, blockIdx.x, gridDim.x);
+}
+
+template <int NCH>
+__global__ __launch_bounds__(LN_THREADS) void ln_fwd_twin_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
+    float* __restrict__ mean, float* __restrict__ rstd, int64_t rows, int D, float eps, LnDrop dr, const LnTwin tw) {
+  ln_fwd_body<4, NCH, true>(x, gamma, beta, y, mean, rstd, rows, D, eps, dr, nullptr, nullptr, blockIdx.x, gridDim.x, tw);
 }
 
 // up to LN_GROUP_MAX independent LayerNorms (same VEC / NCH class) in ONE launch
@@ -380,25 +413,29 @@ __global__ __launch_bounds__(LNB_THREADS) void ln_bwd_group_kernel(const LnGroup
 // 2818-d video features): a column-parallel reduction.  A workgroup owns 64 columns x one row chunk; its 4 waves
 // take every 4th row of the chunk, 4 rows in flight each (the row loop is a chain of dependent global loads
 // otherwise), meet in LDS, and wave 0 issues the one atomic per column and workgroup.
+// dy_b / dr_b (optional): the gradient of a TWIN output (LnTwin: the same x normalised once, two dropout masks) -- x is read
+// once for both.
 __global__ __launch_bounds__(256) void ln_bwd_params_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean,
     const float* __restrict__ rstd, float* __restrict__ dgamma, float* __restrict__ dbeta, int64_t rows,
-    int D, int rows_per_block, LnDrop dr) {
+    int D, int rows_per_block, LnDrop dr, const float* __restrict__ dy_b, LnDrop dr_b) {
   __shared__ float red[2][3][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + lane;
   const bool live = col < D;
   const int c = live ? col : D - 1;
   const uint32_t dseed = dr.seed + (dr.seed_offset ? *dr.seed_offset : 0u);
+  const uint32_t dseed_b = dr_b.seed + (dr_b.seed_offset ? *dr_b.seed_offset : 0u);
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
   float dg = 0.0f, db = 0.0f;
   for (int64_t r = r0 + w; r < r1; r += 16) {
-    float d[4], xv[4], mu[4], rs[4];
+    float d[4], d2[4], xv[4], mu[4], rs[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int64_t rr = r + 4 * u < r1 ? r + 4 * u : r1 - 1;
       d[u] = dy[rr * D + c];
+      d2[u] = dy_b ? dy_b[rr * D + c] : 0.0f;
       xv[u] = x[rr * D + c];
       mu[u] = mean[rr];
       rs[u] = rstd[rr];
@@ -409,6 +446,11 @@ __global__ __launch_bounds__(256) void ln_bwd_params_kernel(
       if (rr < r1) {
         float dv = d[u];
         if (dr.thresh) dv = mesm_dropout_apply(dv, (uint32_t)(rr * D + c), dseed, dr.thresh, dr.inv_keep);
+        if (dy_b) {
+          float dvb = d2[u];
+          if (dr_b.thresh) dvb = mesm_dropout_apply(dvb, (uint32_t)(rr * D + c), dseed_b, dr_b.thresh, dr_b.inv_keep);
+          dv += dvb;
+        }
         dg += dv * (xv[u] - mu[u]) * rs[u];
         db += dv;
       }
@@ -549,7 +591,7 @@ extern "C" int mesm_layernorm_bwd3(const float* dy, const float* x, const float*
     const int rpb = (int)((rows + rb - 1) / rb);
     rb = (int)((rows + rpb - 1) / rpb);
     hipLaunchKernelGGL(ln_bwd_params_kernel, dim3(cb, rb), dim3(256), 0, s, dy, x, mean, rstd, dgamma,
-                       dbeta, rows, D, rpb, dr);
+                       dbeta, rows, D, rpb, dr, (const float*)nullptr, LnDrop{});
     return mesm_launch_status();
   }
   int vec = pick_vec(D, x, dy, dx, gamma);
@@ -599,6 +641,51 @@ int ln_group_class(const MesmLnArgs& a, bool bwd) {
   return a.D <= 256 ? 1 : 2;
 }
 
+// twins: two LayerNorm problems of one phase over the SAME x / gamma / beta with different dropout masks (the raw video
+// features projected for the main path and for the SS-MESM copy of the batch when the copy is the batch itself)
+bool ln_fwd_twins(const MesmLnArgs& a, const MesmLnArgs& b) {
+  return a.x == b.x && a.gamma == b.gamma && a.beta == b.beta && a.rows == b.rows && a.D == b.D && a.eps == b.eps && !a.add &&
+         !b.add && !a.y2 && !b.y2 && a.y != b.y && a.D % 4 == 2 && a.D >= 1024 && a.D + 3 <= 17 * 256 &&
+         pick_vec(4, a.x, a.y, a.gamma, a.beta) == 4 && pick_vec(4, b.y, nullptr, nullptr, nullptr) == 4;
+}
+
+int ln_fwd_twin_launch(const MesmLnArgs& a, const MesmLnArgs& b, hipStream_t s) {
+  const LnDrop dr = make_drop(a.drop_p, a.drop_seed, a.seed_offset);
+  LnTwin tw;
+  tw.y = b.y; tw.mean = b.mean; tw.rstd = b.rstd;
+  tw.dr = make_drop(b.drop_p, b.drop_seed, b.seed_offset);
+  int64_t blocks = (a.rows + LN_WAVES - 1) / LN_WAVES;
+  if (blocks > 4096) blocks = 4096;
+  const int need = (a.D + 3 + 255) / 256;
+  if (need <= 8)
+    hipLaunchKernelGGL(ln_fwd_twin_kernel<8>, dim3((unsigned)blocks), dim3(LN_THREADS), 0, s, a.x, a.gamma, a.beta, a.y, a.mean,
+                       a.rstd, a.rows, a.D, a.eps, dr, tw);
+  else if (need <= 12)
+    hipLaunchKernelGGL(ln_fwd_twin_kernel<12>, dim3((unsigned)blocks), dim3(LN_THREADS), 0, s, a.x, a.gamma, a.beta, a.y,
+                       a.mean, a.rstd, a.rows, a.D, a.eps, dr, tw);
+  else
+    hipLaunchKernelGGL(ln_fwd_twin_kernel<17>, dim3((unsigned)blocks), dim3(LN_THREADS), 0, s, a.x, a.gamma, a.beta, a.y,
+                       a.mean, a.rstd, a.rows, a.D, a.eps, dr, tw);
+  return mesm_launch_status();
+}
+
+bool ln_bwd_param_twins(const MesmLnArgs& a, const MesmLnArgs& b) {
+  return !a.dx && !b.dx && a.x == b.x && a.dgamma == b.dgamma && a.dbeta == b.dbeta && a.rows == b.rows && a.D == b.D &&
+         a.dy != b.dy && !a.dyb && !b.dyb && !a.addend && !b.addend && !a.dx2 && !b.dx2 && a.D > 512;
+}
+
+int ln_bwd_param_twin_launch(const MesmLnArgs& a, const MesmLnArgs& b, hipStream_t s) {
+  const int cb = (a.D + 63) / 64;
+  int rb = (int)((1024 + cb - 1) / cb);  // (as mesm_layernorm_bwd3: about 1024 workgroups, of 32 rows or more)
+  if ((int64_t)rb * 32 > a.rows) rb = (int)((a.rows + 31) / 32);
+  const int rpb = (int)((a.rows + rb - 1) / rb);
+  rb = (int)((a.rows + rpb - 1) / rpb);
+  hipLaunchKernelGGL(ln_bwd_params_kernel, dim3(cb, rb), dim3(256), 0, s, a.dy, a.x, a.mean, a.rstd, a.dgamma, a.dbeta, a.rows,
+                     a.D, rpb, make_drop(a.drop_p, a.drop_seed, a.seed_offset), b.dy,
+                     make_drop(b.drop_p, b.drop_seed, b.seed_offset));
+  return mesm_launch_status();
+}
+
 LnProb ln_prob(const MesmLnArgs& a) {
   LnProb q;
   q.x = a.x; q.gamma = a.gamma; q.beta = a.beta; q.y = a.y; q.mean = a.mean; q.rstd = a.rstd;
@@ -632,10 +719,23 @@ extern "C" int mesm_layernorm_fwd_group(const MesmLnArgs* list, int32_t n, void*
   };
   int ngroupable[3] = {0, 0, 0};
   for (int i = 0; i < n; ++i) ngroupable[ln_group_class(list[i], false)]++;
+  bool done[64] = {};
   for (int i = 0; i < n && rc == MESM_OK; ++i) {
+    if (done[i]) continue;
     const MesmLnArgs& a = list[i];
     if ((a.add == nullptr) != (a.y2 == nullptr) || a.drop_p < 0.f || a.drop_p >= 1.f) return MESM_EINVAL;
     const int cls = ln_group_class(a, false);
+    if (cls == 0 && a.x && a.gamma && a.beta && a.y && a.mean && a.rstd) {
+      int j = i + 1;
+      while (j < n && !(ln_group_class(list[j], false) == 0 && list[j].y && list[j].mean && list[j].rstd &&
+                        list[j].drop_p >= 0.f && list[j].drop_p < 1.f && ln_fwd_twins(a, list[j])))
+        ++j;
+      if (j < n) {
+        done[j] = true;
+        rc = ln_fwd_twin_launch(a, list[j], s);
+        continue;
+      }
+    }
     if (cls && ngroupable[cls] >= 2) {
       if (!a.x || !a.gamma || !a.beta || !a.y || !a.mean || !a.rstd) return MESM_EINVAL;
       int64_t blocks = (a.rows + LN_WAVES - 1) / LN_WAVES;
@@ -673,10 +773,23 @@ extern "C" int mesm_layernorm_bwd_group(const MesmLnArgs* list, int32_t n, void*
   };
   int ngroupable[3] = {0, 0, 0};
   for (int i = 0; i < n; ++i) ngroupable[ln_group_class(list[i], true)]++;
+  bool done[64] = {};
   for (int i = 0; i < n && rc == MESM_OK; ++i) {
+    if (done[i]) continue;
     const MesmLnArgs& a = list[i];
     if (a.drop_p < 0.f || a.drop_p >= 1.f || a.drop2_p < 0.f || a.drop2_p >= 1.f) return MESM_EINVAL;
     const int cls = ln_group_class(a, true);
+    if (cls == 0 && !a.dx && a.dy && a.x && a.mean && a.rstd && a.dgamma && a.dbeta && !a.accumulate_dx) {
+      int j = i + 1;
+      while (j < n && !(ln_group_class(list[j], true) == 0 && list[j].dy && list[j].drop_p >= 0.f && list[j].drop_p < 1.f &&
+                        !list[j].accumulate_dx && ln_bwd_param_twins(a, list[j])))
+        ++j;
+      if (j < n) {
+        done[j] = true;
+        rc = ln_bwd_param_twin_launch(a, list[j], s);
+        continue;
+      }
+    }
     if (a.relu_in && cls == 0) return MESM_EINVAL;  // the ReLU mask exists on the grouped kernels only
     if (cls && (ngroupable[cls] >= 2 || a.relu_in)) {
       if (!a.dy || !a.x || !a.gamma || !a.mean || !a.rstd || !a.dgamma || !a.dbeta) return MESM_EINVAL;

@@ -458,8 +458,9 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dgamma, dbeta, dx=None, accumulate_d
     dy2 = dy.reshape(-1, D)
     assert x2.is_contiguous() and dy2.is_contiguous()
     assert not relu_in or (need_dx and D <= 512)
-    if _phase is not None and not need_dx and D <= 512 and x2.shape[0] <= 2048 and drop2 is None and dyb is None and addend is None:
-        # parameter gradients of a small problem (the 512-d word / sentence inputs): rides in the phase's grouped launch
+    if _phase is not None and not need_dx and drop2 is None and dyb is None and addend is None:
+        # parameter gradients only: a small problem (the 512-d word / sentence inputs) rides in the phase's grouped launch,
+        # two wide ones over the same x (the raw video features' twin LayerNorms) share one pass over x
         a = LnArgs()
         a.dy, a.x, a.gamma, a.mean, a.rstd = dy2.data_ptr(), x2.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr()
         a.dgamma, a.dbeta = dgamma.data_ptr(), dbeta.data_ptr()

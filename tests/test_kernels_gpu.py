@@ -956,12 +956,18 @@ def test_layernorm_group_matches_individual_launches():
              # the second class (256 < D <= 512: two chunks per lane) and parameter-gradient-only members
              dict(rows=1024, D=512, drop=(0.5, 3), no_dx=True), dict(rows=32, D=512, no_dx=True), dict(rows=1, D=512),
              dict(rows=1, D=512, drop=(0.1, 9)), dict(rows=77, D=384, add=True, dyb=True), dict(rows=50, no_dx=True),
-             dict(rows=3000, D=512, no_dx=True)]
+             dict(rows=3000, D=512, no_dx=True),
+             # twins: the same wide x normalised once under two dropout masks (forward) / one pass over x for both parameter
+             # gradients (backward)
+             dict(rows=300, D=2818, drop=(0.5, 21), no_dx=True, twin_of=6), dict(rows=2400, D=2818, drop=(0.5, 5), no_dx=True),
+             dict(rows=2400, D=2818, drop=(0.5, 6), no_dx=True, twin_of=19)]
     probs = []
     for i, sp in enumerate(specs):
         d = sp.get("D", D)
         x = gen((sp["rows"], d), 100 + i)
         g, b = gen((d,), 200 + i) + 1.0, gen((d,), 300 + i)
+        if "twin_of" in sp:  # (same input and parameters as that problem: what the grouped entry points look for)
+            x, g, b = probs[sp["twin_of"]][1], probs[sp["twin_of"]][2], probs[sp["twin_of"]][3]
         add = gen((sp["rows"], d), 400 + i) if sp.get("add") else None
         dy = gen((sp["rows"], d), 500 + i)
         dyb = gen((sp["rows"], d), 600 + i) if sp.get("dyb") else None
@@ -977,9 +983,13 @@ def test_layernorm_group_matches_individual_launches():
             for sp, x, g, b, add, dy, dyb, addend in probs:
                 fw.append(kn.layernorm_fwd(x, g, b, 1e-5, sp.get("drop", (0.0, 0)), add=add))
         ctx = kn.phase() if grouped else contextlib.nullcontext()
+        shared = {}
         with ctx:
-            for (sp, x, g, b, add, dy, dyb, addend), f in zip(probs, fw):
+            for i, ((sp, x, g, b, add, dy, dyb, addend), f) in enumerate(zip(probs, fw)):
                 dg, db = torch.zeros_like(g), torch.zeros_like(b)
+                if "twin_of" in sp and sp.get("no_dx") and probs[sp["twin_of"]][0].get("no_dx"):
+                    dg, db = shared[sp["twin_of"]]  # (one parameter: both gradients accumulate into the same views)
+                shared[i] = (dg, db)
                 r = kn.layernorm_bwd(dy, x, g, f[1], f[2], dg, db, drop=sp.get("drop", (0.0, 0)), drop2=sp.get("drop2"),
                                      dyb=dyb, addend=addend, need_dx=not sp.get("no_dx"))
                 outs.append(list(f) + ([] if r is None else list(r) if isinstance(r, tuple) else [r]) + [dg, db])
