@@ -143,7 +143,13 @@ _DEEP_K = int(os.environ.get("MESM_GEMM_DEEP_K", "768"))        # products this 
 _DEEP_DEPTH = int(os.environ.get("MESM_GEMM_DEEP_DEPTH", "256"))  # reduce indices per workgroup they aim at
 
 
-def deep_out(shape, K, device):
+# forward products onto pool-zeroed outputs by atomic adds make the ACTIVATIONS differ in the last bit from run to run; a
+# ReLU / PReLU kink or a dropped / kept boundary that flips on such a bit moves the step's gradient by a few 1e-5 of its norm
+# (tools/probe/run_to_run.py).  0: only backward products are split that way (gradients then differ at the 1e-7 level).
+_FWD_ATOMICS = os.environ.get("MESM_GEMM_FWD_ATOMICS", "1") == "1"
+
+
+def deep_out(shape, K, device, fwd=False):
     """Output tensor (fp32) of a product with K reduce indices and a LINEAR epilogue.  Few tiles x a deep reduce range --
     320 x 256 x 1024 in the decoder's FFN, 1024 x 256 x 5003 behind the vocabulary head -- is a handful of workgroups that walk
     16-80 stages each while the chip idles, and inside a grouped launch they are what the launch waits for.  Such an output
@@ -155,22 +161,24 @@ def deep_out(shape, K, device):
     for d_ in shape[:-1]:
         rows *= d_
     t64 = ((rows + 63) // 64) * ((cols + 63) // 64)
-    if (zero_pool.active and _DEEP_K > 0 and K >= _DEEP_K and t64 <= 128 and min(K // _DEEP_DEPTH, 256 // t64) >= 2
-            and zero_pool.serves(rows * cols, device)):
+    if (zero_pool.active and _DEEP_K > 0 and (_FWD_ATOMICS or not fwd) and K >= _DEEP_K and t64 <= 128
+            and min(K // _DEEP_DEPTH, 256 // t64) >= 2 and zero_pool.serves(rows * cols, device)):
         t = zero_pool.zeros(shape, device)
         zero_pool.handed[t.data_ptr()] = (0, rows)  # (gemm() takes it: every row starts at zero)
         return t
     return torch.empty(shape, device=device, dtype=torch.float32)
 
 
-def rows_out(like, K=0):
+def rows_out(like, K=0, fwd=False):
     """Output tensor of a GEMM with like.shape: when it is one of the 4800 / 4864-row x 256-column products whose remainder
     rows gemm() runs split along K, a tensor whose remainder rows start at zero (ZeroPool.tail_zeroed); a small output of a
     deep product (K given): deep_out; else empty_like."""
     cols = like.shape[-1]
     rows = like.numel() // cols
+    if fwd and not _FWD_ATOMICS:
+        return torch.empty_like(like)
     if K and rows <= ROW_CUT:
-        return deep_out(like.shape, K, like.device)
+        return deep_out(like.shape, K, like.device, fwd)
     if (_SPLIT_ROWS and _SPLIT_TAIL > 1 and cols == 256 and ROW_CUT < rows <= 5120 and like.dtype == torch.float32
             and zero_pool.active):  # (the pool's fill runs at the start of a TRAINING step, MESM._begin)
         t, ok = zero_pool.tail_zeroed((rows, cols), ROW_CUT, like.device)

@@ -488,7 +488,7 @@ class LinearBlock:
         K = x.shape[-1]
         N = wv.shape[0]
         y = (torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=torch.float32) if relu
-             else kn.deep_out(x.shape[:-1] + (N,), K, x.device))
+             else kn.deep_out(x.shape[:-1] + (N,), K, x.device, fwd=True))
         res2 = _2d(_c(residual)) if residual is not None else None
         kn.gemm(_2d(x), wv, _2d(y), trans_b=True, A2=_2d(x2c) if x2c is not None else None,
                 bias=bv, e_act=ACT_RELU if relu else ACT_NONE, a_drop=in_drop, e_drop=out_drop,
@@ -597,7 +597,7 @@ class FFNBlock:
         kn.gemm(_2d(x), w1, _2d(h), trans_b=True, bias=b1, e_act=ACT_PRELU, slope=slope, e_drop=mid_drop,
                 pre_out=_2d(z))
         yield
-        y = kn.rows_out(x, K=F_)
+        y = kn.rows_out(x, K=F_, fwd=True)
         kn.gemm(_2d(h), w2, _2d(y), trans_b=True, bias=b2, e_drop=out_drop,
                 residual=_2d(_c(residual)) if residual is not None else None)
         ctx.save_for_backward(x, z, h)
@@ -795,7 +795,7 @@ class NormFFNBlock:
         kn.gemm(_2d(h), w1, _2d(a), trans_b=True, bias=b1, e_act=ACT_PRELU, slope=slope, e_drop=mid_drop,
                 pre_out=_2d(z))
         yield
-        y = kn.rows_out(x, K=F_)
+        y = kn.rows_out(x, K=F_, fwd=True)
         kn.gemm(_2d(a), w2, _2d(y), trans_b=True, bias=b2, e_drop=out_drop, residual=_2d(x))
         ctx.save_for_backward(x, mean, rstd, h, z, a)
         ctx.params = (gamma, beta, w1, b1, slope, w2, b2)

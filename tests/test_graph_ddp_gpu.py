@@ -77,7 +77,10 @@ def test_load_batch_replays_a_different_batch(workload, ragged2):
                            neg_index=g.plan.neg_index, masked_words=g.plan.masked_words, device=dev())
     total_e, flat_e = _eager(model, crit, b2, args.dataset_name, plan)
     assert abs(total_e - total_g) < 1e-5 * max(1.0, abs(total_e)), (total_e, total_g)
-    assert float((flat_e - flat_g).norm()) / max(float(flat_e.norm()), 1e-6) < 1e-4
+    # (run-to-run spread of one step: float atomic adds -- since round 5 also in forward products split along K, whose
+    # last-bit activation differences now and then flip a ReLU / PReLU kink: 3e-5 to 1.2e-4 of the gradient norm measured,
+    # tools/probe/run_to_run.py; with MESM_GEMM_FWD_ATOMICS=0 it is 1e-7)
+    assert float((flat_e - flat_g).norm()) / max(float(flat_e.norm()), 1e-6) < 1e-3
     # and it differs from the first batch's step (the stale-plan defect would reproduce batch 1's targets)
     g.load_batch(synthetic.workload_batch(workload, seed=1, ragged=ragged2))
     total_1 = float(g.run(redraw=False))
@@ -265,7 +268,7 @@ def test_allreduce_captured_inside_the_step_graph(mode):
     assert res["launch_log_tail"] == [5, 4, 3, 2, 1, 0], res
     # the second graph's warm-up ran without collectives: only its capture recorded the six buckets
     assert res["second_graph_launches"] == 6, res
-    assert res["loss_err"] < 1e-5 and res["grad_err"] < 1e-4, res
+    assert res["loss_err"] < 1e-5 and res["grad_err"] < 1e-3, res  # (run-to-run spread: see test_graph_replay... above)
 
 
 @pytest.mark.parametrize("mode", ["own-overlapped", "own-inline"])
@@ -287,7 +290,7 @@ def test_own_communicator_allreduce_captured_inside_the_step_graph(mode):
         res = json.loads(lines[-1][7:])
         assert res["launch_log_tail"] == [5, 4, 3, 2, 1, 0], res
         assert res["second_graph_launches"] == 6, res
-        assert res["loss_err"] < 1e-5 and res["grad_err"] < 1e-4, res
+        assert res["loss_err"] < 1e-5 and res["grad_err"] < 1e-3, res  # (run-to-run spread: see test_graph_replay... above)
 
 
 @pytest.mark.parametrize("workload", ["C3b", "C2"])
@@ -414,8 +417,8 @@ def test_batches_prepared_by_loader_workers_replay_like_in_process_batches():
             rel = float((model.gradbuf().flat - gr).norm()) / max(float(gr.norm()), 1e-6)
             # run-to-run freedom: the order of float atomic adds -- in the split-K weight gradients and, since round 5, in
             # the K-split remainder rows of the 4800-row FFN products (activations differ in the last bit, which the layers
-            # behind them amplify to a few 1e-5 of the gradient norm; measured 2e-5)
-            assert rel < 1e-4, (i, rel)
+            # behind them amplify -- a ReLU / PReLU kink flips now and then -- to 3e-5 ... 1.2e-4 of the gradient norm)
+            assert rel < 1e-3, (i, rel)
         del loader
     assert cache.captures == caps0, "a prepared batch caused a capture"
     # a prepared batch of a bucket without a graph falls back to the in-process path through its raw batch
