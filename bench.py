@@ -19,17 +19,23 @@ Prints ONE JSON line on rank 0 (contract in the task statement) including
   roofline     — SURVEY 8d's step-level figures: `step_hbm_frac` = algorithmic bytes of the step
                  (0.272 GB + N_pairs x 109.0 MB) / t_step / 8 TB/s and `step_mfma_frac` = N_pairs x 6.22
                  GFLOP / t_step / 157.3 TF; and, as achieved / peak / frac, the dominant kernel family
-                 (mesm_gemm_f32: f32 GEMMs whose large products run as six bf16 MFMA products over exactly split
-                 operands, f32 accumulate -- MESM_GEMM_BF16X=0 for f32 MFMA throughout): algorithmic FLOPs per launch / mean launch
+                 (mesm_gemm_f32: f32 GEMMs whose large products run as three fp16 MFMA products over operands split
+                 into two fp16 terms under a wave-owned power-of-two scale, f32 accumulate -- MESM_GEMM_BF16X=6 for
+                 round 4's six bf16 products, 0 for f32 MFMA throughout): algorithmic FLOPs per launch / mean launch
                  duration, HIP events on the launch stream around back-to-back replays of the GEMM
                  launches of one captured step, right after the timed region; `traffic` = HBM bytes per
                  launch from the rocprofv3 PMC passes committed under profiles/ (null when that profile
                  was taken with another launch count, i.e. is stale); `families` = in-situ ms per kernel
                  family (GEMM / attention / LayerNorm / losses / element-wise / assembly) by ablation;
                  `attention_hbm_frac` / `layernorm_hbm_frac` = SURVEY 8d's byte split / family ms / 8 TB/s;
-                 `exact_f32` / `exact_f32_ms` = the same step with every product on the f32 MFMA instruction;
-                 `experimental` = the two-term split (MESM_GEMM_BF16X=3), never the headline;
-  config       — besides the workload: `ddp`, and (not part of the metric) the eager step, the optimizer tail, the
+                 `exact_f32` / `exact_f32_ms` / `bf16x6` = the same step with every product on the f32 MFMA instruction /
+                 in round 4's six-product bf16 split (child processes of this run);
+                 `deterministic_ms_per_step` / `run_to_run_grad_spread` = the step with MESM_GEMM_FWD_ATOMICS=0 (bit-
+                 reproducible loss) and the gradient spread between two replays of one batch in either setting;
+  config       — besides the workload: `ddp`, and (not part of the metric) the eager step, `unchanged_caller_ms_per_step`
+                 (the reference's loop body train.py:64-72 verbatim -- model(**batch), criterion(...), zero_grad, backward,
+                 torch's clip_grad_norm_ and AdamW.step -- on graph replays behind that call sequence, mesm_amd/autograph.py),
+                 `other_workloads_not_in_metric` (C2 / C3b / C5 step times with their roofline fractions), the optimizer tail, the
                  PCIe-inclusive rate, and `loader_like_epoch_not_in_metric`: a stream of loader-shaped batches
                  from host memory through StepCache (pair axis padded, real count on the device);
   cpu_baseline — the CPU oracle (a port of the reference step, oracle/mesm_oracle.py) timed on
@@ -60,7 +66,7 @@ def gemm_mode():
 
 def dtype_name():
     return {6: "f32 (3-term split-bf16 products, f32 accumulate)", 0: "f32",
-            3: "f32 (EXPERIMENTAL 2-term split-bf16 products: 16-bit mantissa)"}[gemm_mode()]
+            2: "f32 (2-term split-fp16 products under a wave-owned power-of-two scale, 3 MFMA products, f32 accumulate)"}[gemm_mode()]
 
 
 def draws_mode():
@@ -297,6 +303,7 @@ def main():
     model = build_model(args)
     crit = build_criterion(args)
     model.train()
+    model.autograph(False)  # this script drives its graphs itself; `unchanged_caller` below switches it on for its loop
     from mesm_amd.graphed import GraphedStep
 
     if world > 1:
@@ -596,6 +603,61 @@ def main():
             eager_ms = (time.perf_counter() - t1) / 5 * 1e3
         torch.cuda.current_stream().wait_stream(side)
 
+    # The reference's loop body, train.py:64-72, VERBATIM on the caller's stream with torch's own optimizer and clipping:
+    # the first visit of the shape runs eager, the second captures, from the third on every call is a graph replay
+    # (mesm_amd/autograph.py).  lr = 0 so that the later sections of this script see unchanged weights (the kernels of
+    # AdamW.step run all the same).  The batch is device-resident like after prepare_batch_input.
+    unchanged = None
+    if extras and not opt.eager and world == 1:
+        try:
+            from torch import nn
+            model.autograph(True)
+            ref_opt = torch.optim.AdamW(model.parameters(), lr=0.0, weight_decay=1e-4)
+
+            def loop_body():
+                outputs = model(**batch, dataset_name=args.dataset_name, is_training=True)
+                loss_dict, loss = crit(outputs, batch, is_training=True)
+                ref_opt.zero_grad()
+                loss.backward()
+                nn.utils.clip_grad_norm_(model.parameters(), 0.1)
+                ref_opt.step()
+                return outputs, loss
+            for _ in range(4):
+                outputs, loss = loop_body()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(opt.steps):
+                loop_body()
+            torch.cuda.synchronize()
+            uc = (time.perf_counter() - t1) / opt.steps * 1e3
+            t1 = time.perf_counter()
+            for _ in range(opt.steps):
+                _, loss = loop_body()
+                float(loss)  # train.py:75: the reference's logging reads the loss every step
+            torch.cuda.synchronize()
+            uc_sync = (time.perf_counter() - t1) / opt.steps * 1e3
+            t1 = time.perf_counter()
+            for _ in range(opt.steps):
+                outputs = model(**batch, dataset_name=args.dataset_name, is_training=True)
+                loss_dict, loss = crit(outputs, batch, is_training=True)
+                ref_opt.zero_grad()
+                loss.backward()
+            torch.cuda.synchronize()
+            uc_fb = (time.perf_counter() - t1) / opt.steps * 1e3
+            a = model._auto
+            unchanged = {"ms_per_step": uc, "ms_per_step_with_the_loops_float_of_the_loss": uc_sync,
+                         "fwd_criterion_zero_grad_backward_only_ms": uc_fb,
+                         "pairs_per_s": n_pairs / (uc * 1e-3), "replayed": outputs._auto_step is not None,
+                         "eager_visits": a.eager, "captures": a.captures, "replays": a.replays,
+                         "sequence": "train.py:64-72: model(**batch) / criterion(outputs, batch) / optimizer.zero_grad() / "
+                                     "loss.backward() / nn.utils.clip_grad_norm_ / torch.optim.AdamW.step (lr = 0)"}
+            log("unchanged caller: %.3f ms/step (%.3f with float(loss), %.3f without clip + step)" % (uc, uc_sync, uc_fb))
+        except Exception as e:
+            unchanged = {"error": "%s: %s" % (type(e).__name__, e)}
+        finally:
+            model.autograph(False)
+            model.zero_grad(set_to_none=True)
+
     roofline = {"bound": "mfma", "achieved": None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": None,
                 "traffic": None}
     # SURVEY 8d step-level definition (per rank: every rank runs the same per-GPU workload)
@@ -632,7 +694,10 @@ def main():
                 roofline["step_traffic"] = tj["step_hbm_bytes_all_kernels"]
                 roofline["step_traffic_source"] = "profiles/gemm_traffic.json (%s), FETCH_SIZE x 2 + WRITE_SIZE over every kernel" % tj.get("profile", "?")
             roofline.update({
-                "kernel": "mesm_gemm_f32 family (gemm_wstage64_group / gemm_wstage64: v_mfma_f32_32x32x16_bf16 x 6 over "
+                "kernel": "mesm_gemm_f32 family (gemm_wstage64_group / gemm_wstage64: v_mfma_f32_32x32x16_f16 x 3 over "
+                          "operands split into two fp16 terms; gemm_wstage / gemm_lds64 / gemm_frag: v_mfma_f32_32x32x2_f32)"
+                          if gemm_mode() == 2 else
+                          "mesm_gemm_f32 family (gemm_wstage64_group / gemm_wstage64: v_mfma_f32_32x32x16_bf16 x 6 over "
                           "split operands; gemm_wstage / gemm_lds64 / gemm_frag: v_mfma_f32_32x32x2_f32)"
                           if gemm_mode() == 6 else
                           "mesm_gemm_f32 family (gemm_wstage / gemm_lds64 / gemm_frag / gemm_f32 kernels, v_mfma_f32_32x32x2_f32)",
@@ -786,45 +851,90 @@ def main():
         roofline["attention_hbm_frac"] = _hbm_frac(0.45e9, families.get("attention_ms"))
         roofline["layernorm_hbm_frac"] = _hbm_frac(0.65e9, families.get("layernorm_ms"))
 
-    # The same step in the other GEMM arithmetics, each in a child process (the switch is read once at load):
-    # `exact_f32` = every product on v_mfma_f32_32x32x2_f32 (MESM_GEMM_BF16X=0; `exact_f32_ms` beside the headline so a
-    # reader sees both); `experimental.bf16x3` = the two-term split (16-bit mantissa: narrower than the reference, fails
-    # parity tests, never the headline).  `parity` = the GPU parity suite under that mode at unchanged tolerances
-    # (tools/experimental_parity.py, committed under profiles/)
+    # The same step in the other GEMM arithmetics and with the forward's atomically summed products off, each in a child
+    # process (the switches are read once at load): `exact_f32` = every product on v_mfma_f32_32x32x2_f32
+    # (MESM_GEMM_BF16X=0; `exact_f32_ms` beside the headline so a reader sees both); `bf16x6` = round 4's split;
+    # `deterministic_ms_per_step` = MESM_GEMM_FWD_ATOMICS=0 (K-split forward products off: bit-reproducible loss).
     if extras and not opt.eager and world == 1 and opt.workload == "C3a" and "MESM_GEMM_BF16X" not in os.environ:
-        ppath = os.path.join(ROOT, "profiles", "experimental_parity.json")
-        parity = json.load(open(ppath)) if os.path.exists(ppath) else {}
-
-        def other_mode(mode):
+        def child(**env):
             try:
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", str(opt.steps), "--warmup",
                                     str(opt.warmup), "--cpu-steps", "0", "--no-extras"],
-                                   env=dict(os.environ, MESM_GEMM_BF16X=mode), capture_output=True, text=True, timeout=300)
+                                   env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
                 lj = json.loads(r.stdout.strip().splitlines()[-1])
                 return {"ms_per_step": lj["ms_per_step"], "gemm_tflops": lj["roofline"]["achieved"],
-                        "gemm_ms_per_step": lj["roofline"].get("gemm_ms_per_step"),
-                        "parity": parity.get({"0": "exact_f32", "3": "bf16x3"}[mode], "not recorded")}
+                        "gemm_ms_per_step": lj["roofline"].get("gemm_ms_per_step"), "dtype": lj["dtype"]}
             except Exception as e:
                 return {"error": "%s: %s" % (type(e).__name__, e)}
-        ex = other_mode("0")
+        ex = child(MESM_GEMM_BF16X="0")
         roofline["exact_f32"] = ex
         roofline["exact_f32_ms"] = ex.get("ms_per_step")
-        roofline["experimental"] = {"bf16x3": other_mode("3"),
-                                    "note": "two-term split (hi*hi + hi*mid + mid*hi): 16-bit mantissa, NOT the headline"}
-    if roofline.get("achieved") and gemm_mode() == 6:
-        # what the matrix pipes see: six bf16 products per algorithmic f32 product on the launches that take the split
-        # path (an upper bound: it prices EVERY GEMM flop of the step at six products, the small 32 x 32-tile launches
-        # still run v_mfma_f32_32x32x2_f32)
-        roofline["bf16_mfma_issue"] = {"achieved_upper": 6.0 * roofline["achieved"], "peak": PEAK_BF16_MFMA_TFLOPS,
-                                       "unit": "TFLOP/s", "frac_upper": 6.0 * roofline["achieved"] / PEAK_BF16_MFMA_TFLOPS}
-        # the two honest ceilings side by side: `frac` = algorithmic f32 flops / the f32 matrix peak (what an
-        # exact-f32 kernel could reach: continuity with earlier rounds); `frac_issue` = the same flops / the ceiling of a
-        # kernel that issues six bf16 products per f32 flop, 2.5 PF / 6
-        roofline["issue_peak"] = PEAK_BF16_MFMA_TFLOPS / 6.0
-        roofline["frac_issue"] = roofline["achieved"] / (PEAK_BF16_MFMA_TFLOPS / 6.0)
-        roofline["arithmetic"] = ("operands split exactly into hi + mid + lo bf16 (x = hi + mid + lo), products lo*hi, hi*lo, "
-                                  "mid*mid, mid*hi, hi*mid, hi*hi on v_mfma_f32_32x32x16_bf16, f32 accumulate; `achieved` / "
-                                  "`frac` stay ALGORITHMIC f32 flops against the f32 MFMA peak (157.3 TF)")
+        roofline["bf16x6"] = child(MESM_GEMM_BF16X="6")
+        if "MESM_GEMM_FWD_ATOMICS" not in os.environ:
+            roofline["deterministic_ms_per_step"] = child(MESM_GEMM_FWD_ATOMICS="0").get("ms_per_step")
+    mode = gemm_mode()
+    if roofline.get("achieved") and mode in (2, 6):
+        # what the matrix pipes see: `per` half-precision products per algorithmic f32 product on the launches that take
+        # the split path (an upper bound: it prices EVERY GEMM flop of the step that way, the small 32 x 32-tile launches
+        # still run v_mfma_f32_32x32x2_f32).  The two honest ceilings side by side: `frac` = algorithmic f32
+        # flops / the f32 matrix peak (what an exact-f32 kernel could reach: continuity with earlier rounds); `frac_issue` =
+        # the same flops / the ceiling of a kernel that issues `per` 16-bit products per f32 flop, 2.5 PF / per
+        per = 3.0 if mode == 2 else 6.0
+        roofline["half_mfma_issue"] = {"products_per_flop": per, "achieved_upper": per * roofline["achieved"],
+                                       "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                       "frac_upper": per * roofline["achieved"] / PEAK_BF16_MFMA_TFLOPS}
+        roofline["issue_peak"] = PEAK_BF16_MFMA_TFLOPS / per
+        roofline["frac_issue"] = roofline["achieved"] / (PEAK_BF16_MFMA_TFLOPS / per)
+        roofline["arithmetic"] = (
+            "operands scaled by a wave-owned power of two and split into hi = f16_rne(x), lo = f16_rne(x - hi) (22-24 "
+            "significand bits), products lo*hi, hi*lo, hi*hi on v_mfma_f32_32x32x16_f16, f32 accumulate, accumulators rescaled "
+            "when a stage leaves the scale's band" if mode == 2 else
+            "operands split exactly into hi + mid + lo bf16 (x = hi + mid + lo), products lo*hi, hi*lo, mid*mid, mid*hi, "
+            "hi*mid, hi*hi on v_mfma_f32_32x32x16_bf16, f32 accumulate") + (
+            "; `achieved` / `frac` stay ALGORITHMIC f32 flops against the f32 MFMA peak (157.3 TF)")
+
+    # run-to-run spread of the replayed step: two replays of one batch with the same draws and dropout masks off (the
+    # float atomics of split-K products order by arrival); gradient difference / gradient norm, loss difference
+    spread = None
+    if extras and not opt.eager and world == 1 and opt.workload == "C3a":
+        try:
+            saved_p = {}
+            for m_ in model.modules():
+                if hasattr(m_, "p") and isinstance(getattr(m_, "p"), float):
+                    saved_p[m_] = m_.p
+                    m_.p = 0.0
+            rstep = GraphedStep(model, crit, batch, args.dataset_name, warmup=1)
+            rstep.run(redraw=False); torch.cuda.synchronize()
+            g1, l1 = model.gradbuf().flat.clone(), float(rstep.total)
+            worst, lworst = 0.0, 0.0
+            for _ in range(4):
+                rstep.run(redraw=False); torch.cuda.synchronize()
+                worst = max(worst, float((model.gradbuf().flat - g1).norm() / g1.norm()))
+                lworst = max(lworst, abs(float(rstep.total) - l1))
+            spread = {"grad_rel_l2_max_of_4_replays": worst, "loss_abs_max": lworst,
+                      "fwd_atomics": os.environ.get("MESM_GEMM_FWD_ATOMICS", "1")}
+            del rstep
+        except Exception as e:
+            spread = {"error": "%s: %s" % (type(e).__name__, e)}
+        finally:
+            for m_, p_ in saved_p.items():
+                m_.p = p_
+        roofline["run_to_run_grad_spread"] = spread
+
+    # the other BASELINE.json configs that fit one GPU, one graph each, 10 steps (child processes; not the metric)
+    others = None
+    if extras and not opt.eager and world == 1 and opt.workload == "C3a" and not opt.no_roofline:
+        others = {}
+        for w in ("C2", "C3b", "C5"):
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", w, "--steps", "10", "--warmup", "3",
+                                    "--cpu-steps", "0", "--no-extras", "--no-roofline"], capture_output=True, text=True, timeout=300)
+                lj = json.loads(r.stdout.strip().splitlines()[-1])
+                others[w] = {"ms_per_step": lj["ms_per_step"], "pairs_per_s": lj["value"],
+                             "step_hbm_frac": lj["roofline"]["step_hbm_frac"], "step_mfma_frac": lj["roofline"]["step_mfma_frac"],
+                             "workload": lj["config"]["workload"]}
+            except Exception as e:
+                others[w] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     cpu_baseline = None
     if rank == 0 and world == 1 and opt.cpu_steps > 0:
@@ -870,6 +980,9 @@ def main():
                        "host_draws": draws_mode(),
                        "settled_not_in_metric": settled,
                        "eager_ms_per_step_not_in_metric": eager_ms,
+                       "unchanged_caller_ms_per_step": unchanged.get("ms_per_step") if unchanged else None,
+                       "unchanged_caller_not_in_metric": unchanged,
+                       "other_workloads_not_in_metric": others,
                        "optimizer_tail_ms_not_in_metric": opt_tail_ms,
                        "pcie_inclusive_not_in_metric": pcie,
                        "loader_like_epoch_not_in_metric": loader},

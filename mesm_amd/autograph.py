@@ -1,0 +1,281 @@
+"""Graph replay behind the UNCHANGED caller (reference train.py:64-72):
+
+    outputs = model(**batch, dataset_name=..., is_training=True)
+    loss_dict, loss = criterion(outputs, batch, is_training=True)
+    optimizer.zero_grad()
+    loss.backward()
+    clip_grad_norm_(model.parameters(), ...); optimizer.step()
+
+The eager path issues ~260 launches from Python and is host-bound (17 ms per step where the device needs 3.5).  An
+`AutoGraph` hangs off every `MESM` and turns that same call sequence into three HIP-graph replays
+(graphed.SplitGraphedStep: forward | criterion | backward over one memory pool) once a batch shape has been seen:
+
+  * first visit of a shape bucket: eager, exactly as before (it is also the step the criterion introduces itself in:
+    `Criterion.forward` finds the model on the outputs it is handed);
+  * second visit: the bucket is captured (warm-up step + three captures; the caller's gradients are put back as they
+    were) and replayed; from then on `model(...)` = host plans + one arena upload + forward replay,
+    `criterion(...)` = criterion replay, `loss.backward()` = ONE autograd node whose backward replays the third graph
+    and leaves `param.grad` aliasing the flat gradient buffer like the eager backward does.  `optimizer.zero_grad()`
+    in between, `clip_grad_norm_`, any `torch.optim` optimizer: unchanged.  Gradients ACCUMULATE when `param.grad` is
+    not None at backward time (the caller skipped zero_grad), like autograd's.
+
+What a replayed step cannot do, and says so instead of computing something else: the activations the backward reads are
+static memory that the next forward overwrites, so ONE forward may be in flight -- a backward (or criterion call) that
+belongs to an older forward raises; the outputs carry no autograd history of their own (they are consumed by this
+build's criterion; anything else that wants gradients through them needs the eager path).  `MESM_AUTOGRAPH=0`, or
+`model.autograph(False)`, keeps every step eager.
+
+Buckets: key = (dataset, train/eval mode, pairs, clip / word extents, feature dims, group-size bucket, batch keys).
+The reference's loaders emit another (pairs, Lv, Lw) almost every batch; `model.autograph(pad=(max_v_l, max_words_l),
+pairs=8)` pads every batch like graphed.StepCache does (clips / words to fixed extents, the pair axis to a multiple of
+`pairs` with the real count as a device scalar), so that an epoch replays from a handful of graphs.
+"""
+import os
+import warnings
+import weakref
+from collections import OrderedDict
+
+import torch
+
+from . import kernels as kn
+
+
+class AutoOutputs(dict):
+    """the dict MESM.forward returns, remembering which forward made it (a plain dict to every reader)"""
+    _mesm_model = None   # weakref to the model (eager and replayed outputs)
+    _auto_step = None    # the SplitGraphedStep whose forward graph wrote these tensors (replayed outputs only)
+    _auto_gen = -1
+    _auto_batch = None
+    _mesm_side = None    # the stream an eager forward ran on when that was not the caller's (eager outputs only)
+
+
+class _Backward(torch.autograd.Function):
+    """loss = f(token): the ONE node of a replayed step; its backward replays the third graph"""
+
+    @staticmethod
+    def forward(ctx, token, total, auto, step, gen):
+        ctx.auto, ctx.step, ctx.gen = auto, step, gen
+        return total.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.auto.backward(ctx.step, ctx.gen, g)
+        return None, None, None, None, None
+
+
+def _enabled_default():
+    return os.environ.get("MESM_AUTOGRAPH", "1") != "0"
+
+
+GROUP_CAPS = (1, 2, 3, 5, 9, 16, 32, 64)  # largest-video-group buckets (9 = the QVHighlights maximum, base.py:116-162)
+
+
+class AutoGraph:
+    def __init__(self, model):
+        self.model = weakref.ref(model)
+        self.enabled = _enabled_default()
+        self.crit = None
+        self.steps = OrderedDict()  # key -> [SplitGraphedStep]
+        self.seen = {}
+        self.bad = set()
+        self.max_graphs = int(os.environ.get("MESM_AUTOGRAPH_MAX", "16"))
+        self.pad = None
+        self.pairs = None
+        self.gen = 0          # forwards of this model (eager ones included): one may be in flight
+        self.busy = False     # inside a capture: the model's forward is being called by the step itself
+        self.token = None
+        self.captures = self.replays = self.eager = 0
+
+    # ------------------------------------------------------------------ configuration
+    def configure(self, enabled=None, pad=None, pairs=None, max_graphs=None):
+        if enabled is not None:
+            self.enabled = bool(enabled)
+        if pad is not None:
+            self.pad = tuple(pad)
+        if pairs is not None:
+            self.pairs = int(pairs)
+        if max_graphs is not None:
+            self.max_graphs = int(max_graphs)
+        return self
+
+    def note_criterion(self, crit):
+        if self.crit is None or self.crit() is not crit:
+            self.crit = weakref.ref(crit)
+            if self.steps:  # graphs captured with another criterion object: its weights / losses are baked in
+                self.steps.clear()
+                self.seen.clear()
+
+    # ------------------------------------------------------------------ forward
+    def _shaped(self, batch):
+        """the batch padded like StepCache pads it (device tensors stay on the device)"""
+        if self.pad is not None:
+            from .graphed import StepCache
+            Lv, Lw = self.pad
+            if batch["video_feat"].shape[1] > Lv or batch["words_id"].shape[1] > Lw:
+                return None
+            b = dict(batch)
+            for k in StepCache.CLIP_KEYS:
+                if k in b:
+                    b[k] = StepCache._pad_dim1(b[k], Lv)
+            for k in StepCache.WORD_KEYS:
+                if k in b:
+                    b[k] = StepCache._pad_dim1(b[k], Lw)
+            batch = b
+        if self.pairs:
+            from .batching import pad_pairs
+            n = batch["video_feat"].shape[0]
+            batch = pad_pairs(batch, (n + self.pairs - 1) // self.pairs * self.pairs)
+        return batch
+
+    @staticmethod
+    def _key(model, batch, dataset_name):
+        n = batch["video_mask"].shape[0]
+        gmax = int(batch["num_clips"].max())
+        gcap = next((c for c in GROUP_CAPS if c >= gmax), gmax)
+        sig = tuple(sorted(k for k, v in batch.items() if not k.startswith("_")))
+        return (dataset_name, bool(model.training), n, tuple(batch["video_feat"].shape[1:]),
+                tuple(batch["words_id"].shape[1:]), gcap, "_n_real" in batch, sig), gcap
+
+    def eligible(self, model, batch, kwargs):
+        return (self.enabled and not self.busy and kwargs.get("is_training") is True and kwargs.get("plan") is None
+                and torch.is_grad_enabled() and batch["video_feat"].is_cuda
+                and kwargs.get("neg_index") is None and kwargs.get("masked_words") is None
+                and not torch.cuda.is_current_stream_capturing())
+
+    def eager_stream(self, dev):
+        """the stream an EAGER grad-enabled forward of a caller on the default stream runs on (None: where the caller is)"""
+        if not self.enabled or self.busy or not torch.is_grad_enabled() or torch.cuda.is_current_stream_capturing():
+            return None
+        if torch.cuda.current_stream(dev) != torch.cuda.default_stream(dev):
+            return None
+        from .graphed import capture_stream
+        return capture_stream(dev)
+
+    def forward(self, batch, dataset_name):
+        """-> AutoOutputs of a replayed forward, or None: run this forward eagerly"""
+        model = self.model()
+        self.gen += 1
+        crit = self.crit() if self.crit is not None else None
+        try:
+            shaped = self._shaped(batch)
+            if shaped is None:
+                return None
+            key, gcap = self._key(model, shaped, dataset_name)
+        except Exception:
+            return None
+        if key in self.bad:
+            return None
+        if crit is None or (key not in self.steps and self.seen.get(key, 0) < 1):
+            self.seen[key] = self.seen.get(key, 0) + 1
+            self.eager += 1
+            return None
+        step = None
+        for s in self.steps.get(key, []):
+            try:
+                s.load_batch(shaped, redraw=True)
+            except ValueError:
+                continue
+            step = s
+            break
+        if step is None:
+            step = self._capture(key, gcap, shaped, dataset_name, crit)
+            if step is None:
+                return None
+        else:
+            self.steps.move_to_end(key)
+        out = step.forward_replay()
+        self.replays += 1
+        n = batch["video_feat"].shape[0]
+        res = AutoOutputs(out if shaped["video_mask"].shape[0] == n else self._real_rows(out, n))
+        res._mesm_model = self.model
+        res._auto_step, res._auto_gen, res._auto_batch = step, self.gen, batch
+        return res
+
+    @staticmethod
+    def _real_rows(out, n):
+        """outputs of a pair-padded replay, cut back to the caller's pairs (views; every entry leads with the pair axis)"""
+        cut = lambda t: t[:n] if torch.is_tensor(t) and t.dim() >= 1 else t
+        return {k: ([{kk: cut(vv) for kk, vv in d.items()} for d in v] if isinstance(v, list) else cut(v))
+                for k, v in out.items()}
+
+    def _capture(self, key, gcap, batch, dataset_name, crit):
+        from .graphed import SplitGraphedStep
+        model = self.model()
+        gb = model.gradbuf()
+        while sum(len(v) for v in self.steps.values()) >= self.max_graphs and self.steps:
+            self.steps.popitem(last=False)
+        dev = batch["video_feat"].device
+        clone = lambda v: v.clone() if torch.is_tensor(v) else v
+        static = {}
+        for k, v in batch.items():
+            if k == "_n_real":
+                continue
+            if isinstance(v, list) and v and isinstance(v[0], dict):
+                static[k] = [{kk: clone(vv) for kk, vv in d.items()} for d in v]
+            else:
+                static[k] = clone(v)
+        if "_n_real" in batch:
+            static["_n_real"] = batch["_n_real"]
+            P = static["video_mask"].shape[0]
+            for kk in ("video_feat", "words_id"):
+                t = static[kk]
+                if t.shape[0] < P:
+                    static[kk] = torch.cat([t, t[:1].expand((P - t.shape[0],) + tuple(t.shape[1:]))]).contiguous()
+        # the warm-up and capture steps run real backward passes: the caller's gradients are put back afterwards
+        had = [p.grad is not None for p in gb.params]
+        saved = gb.flat.clone() if (gb.flat is not None and any(had)) else None
+        self.busy = True
+        try:
+            step = SplitGraphedStep(model, crit, static, dataset_name, warmup=1, caps="auto", group_cap=gcap if gcap > 1 else None)
+        except Exception as e:  # a shape this build cannot capture: stay eager for it, say so once
+            self.bad.add(key)
+            warnings.warn("mesm_amd.autograph: capture failed for %r (%s: %s); this shape stays eager" % (key, type(e).__name__, e))
+            step = None
+        finally:
+            self.busy = False
+            if saved is not None:
+                gb.flat.copy_(saved)
+            for p, h in zip(gb.params, had):
+                p.grad = p._mesm_gview if h else None
+        if step is None:
+            return None
+        self.steps.setdefault(key, []).append(step)
+        self.captures += 1
+        return step
+
+    # ------------------------------------------------------------------ criterion / backward
+    def _check(self, step, gen, what):
+        if gen != self.gen:
+            raise RuntimeError(
+                "mesm_amd.autograph: %s of a forward that is no longer the latest one of this model -- a replayed step keeps "
+                "its activations in static graph memory, so only ONE forward may be in flight (forward -> criterion -> "
+                "backward).  Set MESM_AUTOGRAPH=0 (or model.autograph(False)) for patterns that interleave forwards." % what)
+
+    def criterion(self, crit, outputs, targets, is_training):
+        step = outputs._auto_step
+        self._check(step, outputs._auto_gen, "criterion call on the outputs")
+        if self.crit is None or self.crit() is not crit:
+            raise RuntimeError("mesm_amd.autograph: these outputs belong to a step captured with another criterion object; "
+                               "call model.autograph(False) to mix criteria")
+        if not is_training:
+            raise RuntimeError("mesm_amd.autograph: criterion(..., is_training=False) on the outputs of a training forward")
+        b = outputs._auto_batch
+        if targets is not b and any(targets.get(k) is not b.get(k) for k in ("video_mask", "saliency_label", "norm_span", "words_label")):
+            raise RuntimeError("mesm_amd.autograph: the criterion's targets are not the batch the forward was called with "
+                               "(a replayed step reads its targets when the forward starts)")
+        losses, total = step.criterion_replay()
+        if self.token is None or self.token.device != total.device:
+            self.token = torch.zeros((), device=total.device, requires_grad=True)
+        return losses, _Backward.apply(self.token, total, self, step, outputs._auto_gen)
+
+    def backward(self, step, gen, g):
+        self._check(step, gen, "backward")
+        model = self.model()
+        gb = model.gradbuf()
+        prev = gb.flat.clone() if any(p.grad is not None for p in gb.params) else None
+        step.backward_replay(g)
+        if prev is not None:
+            gb.flat.add_(prev)  # the captured backward starts from a cleared buffer: accumulate like autograd does
+        for p in step.grad_params:
+            if p.grad is None:
+                p.grad = p._mesm_gview

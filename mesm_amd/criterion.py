@@ -8,6 +8,7 @@ from torch import nn
 from torch.autograd import Function
 
 from . import kernels as kn
+from .autograph import AutoOutputs
 
 
 def span_cxw_to_xx(s):
@@ -307,6 +308,24 @@ class Criterion(nn.Module):
         return wv
 
     def forward(self, outputs, targets, is_training=True):
+        if isinstance(outputs, AutoOutputs) and outputs._mesm_model is not None:
+            m = outputs._mesm_model()
+            auto = getattr(m, "_auto", None)
+            if auto is not None and outputs._auto_step is not None:
+                return auto.criterion(self, outputs, targets, is_training)  # replayed forward: replay the criterion graph
+            if auto is not None and not auto.busy:
+                auto.note_criterion(self)  # eager step: the model learns which criterion its steps are captured with
+            side = outputs._mesm_side
+            if side is not None and torch.cuda.current_stream(side.device) != side:
+                cur = torch.cuda.current_stream(side.device)  # stay on the stream the eager forward ran on (model.py)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    res = self._forward(outputs, targets, is_training)
+                cur.wait_stream(side)
+                return res
+        return self._forward(outputs, targets, is_training)
+
+    def _forward(self, outputs, targets, is_training=True):
         device = outputs["pred_spans"].device
         plan = targets.get("_target_plan")
         if plan is None:

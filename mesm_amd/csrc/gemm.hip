@@ -1117,6 +1117,8 @@ __device__ __forceinline__ void wstage64_body(const MesmGemmArgs& p, const Blk b
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   float csum[2] = {0.0f, 0.0f};
   const bool do_colsum = (p.colsum != nullptr) && (blk.y == 0);
+  HalfScales hs;  // BF == 2: this wave's operand scales (gemm_ws.hpp)
+  hs.init();
 
   L64_STAMP(1);
   if (nst > 0) issue(0);
@@ -1167,7 +1169,31 @@ __device__ __forceinline__ void wstage64_body(const MesmGemmArgs& p, const Blk b
             b[t][s_][j] = y;
           }
     }
-    if (BF > 0) {
+    if (BF == 2) {
+      const float ma = frag_amax(a[0], a[1]), mb = frag_amax(b[0], b[1]);
+      if (hs.a.leaves(ma) || hs.b.leaves(mb)) {  // wave-uniform; homogeneous operands: taken at the wave's first stage only
+        const int delta = hs.repick(frag_amax_finite(a[0], a[1]), frag_amax_finite(b[0], b[1]), st == 0);
+        if (delta != 0) {
+#pragma unroll
+          for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) acc[ti][tj][r] = __builtin_ldexpf(acc[ti][tj][r], delta);
+        }
+      }
+      HalfFrag fa[2], fb[2];
+      const float sca = hs.a.scale(), scb = hs.b.scale();
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        fa[t].make(a[t], sca);
+        fb[t].make(b[t], scb);
+      }
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = half_mma(fa[ti], fb[tj], acc[ti][tj]);
+    } else if (BF > 0) {
       SplitFrag<BF> sa[2], sb[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -1201,6 +1227,15 @@ __device__ __forceinline__ void wstage64_body(const MesmGemmArgs& p, const Blk b
   }
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
   L64_STAMP(28);
+  if (BF == 2 && hs.a.e + hs.b.e != 0) {  // back to unit scale before the waves' partial tiles meet
+    const int back = -(hs.a.e + hs.b.e);
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ti][tj][r] = __builtin_ldexpf(acc[ti][tj][r], back);
+  }
 
   if (do_colsum) {
 #pragma unroll
@@ -1287,7 +1322,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_wstage64_group_kernel(const 
 }
 
 
-// MESM_GEMM_BF16X: unset / 6 = split-bf16 products, three exact terms (see SplitFrag); 3 = experimental two-term form;
+// MESM_GEMM_BF16X: 6 = split-bf16 products, three exact terms (see SplitFrag); 2 = two fp16 terms, three products (HalfFrag);
 // anything else = exact f32
 inline int bf16x_mode() { return mesm_gemm_bf16x(); }
 int mesm_gemm_group64();
@@ -1300,7 +1335,7 @@ int launch_wstage64_l(const MesmGemmArgs& a, hipStream_t s) {
   const int bf = xf ? 0 : bf16x_mode();  // (operand transforms + split: 260-288 VGPRs, one workgroup per CU or spills)
   const SideRed sr = take_side(s);
   if (bf == 6) hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, false, 6>), grid, dim3(NTHREADS), 0, s, a, sr);
-  else if (bf == 3) hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, false, 3>), grid, dim3(NTHREADS), 0, s, a, sr);
+  else if (bf == 2) hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, false, 2>), grid, dim3(NTHREADS), 0, s, a, sr);
   else if (xf) hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, true>), grid, dim3(NTHREADS), 0, s, a, sr);
   else hipLaunchKernelGGL((gemm_wstage64_kernel<LA, LB, false>), grid, dim3(NTHREADS), 0, s, a, sr);
   const int rc = mesm_launch_status();
@@ -1818,10 +1853,12 @@ Tape g_tape;
 
 // tuning switches, read ONCE when the library is loaded (they used to be getenv calls per dispatch)
 int g_force_tile = []() { const char* e = getenv("MESM_GEMM_TILE"); return e ? atoi(e) : 0; }();
-// MESM_GEMM_BF16X: 6 (default) = the large products on v_mfma_f32_32x32x16_bf16 over operands split exactly into three
-// bf16 terms, six cross products, f32 accumulate (error at or below the f32 MFMA kernels' own, tools/bf16x_check.py);
-// 0 = every product on v_mfma_f32_32x32x2_f32; 3 = EXPERIMENTAL two-term split (16-bit mantissa: fails parity tests)
-int g_bf16x = []() { const char* e = getenv("MESM_GEMM_BF16X"); const int m = e ? atoi(e) : 6; return (m == 3 || m == 6) ? m : 0; }();
+// MESM_GEMM_BF16X: 2 (default since round 6) = the large products on v_mfma_f32_32x32x16_f16 over operands split into two
+// fp16 terms under a wave-owned power-of-two scale, THREE cross products, f32 accumulate (gemm_ws.hpp; error at or below the
+// f32 MFMA kernels' own, tools/bf16x_check.py, tests/test_gemm_f16x3_gpu.py); 6 = three bf16 terms by truncation, six
+// products on v_mfma_f32_32x32x16_bf16 (round 4's default);
+// 0 = every product on v_mfma_f32_32x32x2_f32.  (The two-term bf16 form, 16 significand bits, failed 13 parity tests: deleted.)
+int g_bf16x = []() { const char* e = getenv("MESM_GEMM_BF16X"); const int m = e ? atoi(e) : 2; return (m == 2 || m == 6) ? m : 0; }();
 
 int mesm_gemm_force_tile() { return g_force_tile; }
 int mesm_gemm_bf16x() { return g_bf16x; }
@@ -1830,7 +1867,7 @@ int mesm_gemm_bf16x() { return g_bf16x; }
 // ms/step; in exact-f32 mode it loses, 4.609 -> 4.642, and stays off; off in the experimental two-term mode as well, whose
 // grouped kernel is not instantiated: every product of that mode then runs the two-term split); 0 = launched one by one
 int g_group64 = []() { const char* e = getenv("MESM_GEMM_GROUP64"); return e ? atoi(e) : -1; }();
-int mesm_gemm_group64() { return g_group64 >= 0 ? g_group64 : (g_bf16x == 6 ? 1 : 0); }
+int mesm_gemm_group64() { return g_group64 >= 0 ? g_group64 : (g_bf16x != 0 ? 1 : 0); }
 
 int dispatch(const MesmGemmArgs& a, int vec, hipStream_t s) {
   {
@@ -1994,6 +2031,7 @@ int launch_group(const MesmGemmArgs* list, const int* vecs, int n, hipStream_t s
       const SideRed sr = take_side(s);
       const int bf = bf16x_mode();
       if (bf == 6) hipLaunchKernelGGL(gemm_wstage64_group_kernel<6>, dim3(g64.start[g64.n]), dim3(NTHREADS), 0, s, g64, sr);
+      else if (bf == 2) hipLaunchKernelGGL(gemm_wstage64_group_kernel<2>, dim3(g64.start[g64.n]), dim3(NTHREADS), 0, s, g64, sr);
       else hipLaunchKernelGGL(gemm_wstage64_group_kernel<0>, dim3(g64.start[g64.n]), dim3(NTHREADS), 0, s, g64, sr);
       rc = mesm_launch_status();
       for (int k = 0; k < g64.n && rc == MESM_OK; ++k) {
@@ -2102,7 +2140,7 @@ extern "C" int mesm_gemm_get_bf16x(void) { return g_bf16x; }
 
 extern "C" int mesm_gemm_set_switches(int32_t force_tile, int32_t bf16x) {
   if (force_tile >= 0) g_force_tile = force_tile;
-  if (bf16x >= 0) g_bf16x = (bf16x == 3 || bf16x == 6) ? bf16x : 0;
+  if (bf16x >= 0) g_bf16x = (bf16x == 2 || bf16x == 6) ? bf16x : 0;
   return MESM_OK;
 }
 

@@ -90,15 +90,22 @@ struct GroupArgs {
 };
 
 
-// Split-precision products (BF = 6: the default for the large products since round 4; BF = 3 experimental): a stage
-// on v_mfma_f32_32x32x16_bf16 (16x the f32 MFMA rate) with every f32 operand value split exactly into bf16 terms
-// x = hi + mid + lo (8 mantissa bits each; hi and mid by truncation, so x - hi and x - hi - mid are exact f32
-// subtractions) and the significant cross products accumulated in f32:
-//   BF = 6: hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi   (error ~2^-24 of |a||b|, the f32 product's own)
-//   BF = 3: hi*hi + hi*mid + mid*hi                              (error ~2^-16)
-// Selected at run time by MESM_GEMM_BF16X=6|3 (bench.py reports both under roofline.experimental with the parity
-// suite's verdict at unchanged tolerances); the split is done on the fragment registers (~6 VALU per value).
+// Split-precision products: a stage on the 16-deep half-precision matrix instructions (16x the f32 MFMA rate) with every
+// f32 operand value split in the wave's fragment registers and the significant cross products accumulated in f32.
+//   BF = 6 (round 4): x = hi + mid + lo, three bf16 terms by truncation (both residual subtractions exact), six products
+//           hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (error ~2^-24 of |a||b|);
+//           ~5.5 VALU per value.
+//   BF = 2 (round 6): x' = 2^e x, hi = f16_rne(x'), lo = f16_rne(x' - hi) (22-24 significand bits), THREE products
+//           lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_f16; 2 VALU per value (v_fma_mix{lo,hi}_f16 scales, subtracts,
+//           rounds and packs in one instruction) + 0.5 for the range watch.  fp16 has 5 exponent bits, so the power-of-two
+//           scale 2^e is DYNAMIC and owned by the wave: it keeps each operand's fragment maximum inside [2^3, 2^15) (target
+//           [2^10, 2^11): every value down to 2^-12 of the fragment maximum keeps its full 22 bits, smaller ones an absolute
+//           error of 2^-35 of it); when a stage leaves the band the wave picks a new exponent and rescales its accumulators
+//           (v_ldexp_f32, wave-uniform branch: never taken on homogeneous data after the first stage).  The accumulators
+//           are brought back to unit scale before the cross-wave reduction.  No scale crosses a kernel boundary.
+// Selected at run time by MESM_GEMM_BF16X = 6 | 2 (0 = exact f32 MFMA); bench.py names the arithmetic in `dtype`.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 template <int BF>
@@ -116,10 +123,8 @@ struct SplitFrag {
         const float r0 = x0 - __uint_as_float(u0 & 0xFFFF0000u), r1 = x1 - __uint_as_float(u1 & 0xFFFF0000u);
         const unsigned m0 = __float_as_uint(r0), m1 = __float_as_uint(r1);
         mid[t][i] = __builtin_amdgcn_perm(m1, m0, 0x07060302u);
-        if (BF == 6) {
-          const float q0 = r0 - __uint_as_float(m0 & 0xFFFF0000u), q1 = r1 - __uint_as_float(m1 & 0xFFFF0000u);
-          lo[t][i] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
-        }
+        const float q0 = r0 - __uint_as_float(m0 & 0xFFFF0000u), q1 = r1 - __uint_as_float(m1 & 0xFFFF0000u);
+        lo[t][i] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302u);
       }
   }
 };
@@ -128,12 +133,10 @@ template <int BF>
 __device__ __forceinline__ f32x16 split_mma(const SplitFrag<BF>& a, const SplitFrag<BF>& b, f32x16 acc) {
 #define MESM_BF(x) __builtin_bit_cast(bf16x8, x)
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    if (BF == 6) {  // smallest terms first
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MESM_BF(a.lo[t]), MESM_BF(b.hi[t]), acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MESM_BF(a.hi[t]), MESM_BF(b.lo[t]), acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MESM_BF(a.mid[t]), MESM_BF(b.mid[t]), acc, 0, 0, 0);
-    }
+  for (int t = 0; t < 2; ++t) {  // smallest terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MESM_BF(a.lo[t]), MESM_BF(b.hi[t]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MESM_BF(a.hi[t]), MESM_BF(b.lo[t]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MESM_BF(a.mid[t]), MESM_BF(b.mid[t]), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MESM_BF(a.mid[t]), MESM_BF(b.hi[t]), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MESM_BF(a.hi[t]), MESM_BF(b.mid[t]), acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(MESM_BF(a.hi[t]), MESM_BF(b.hi[t]), acc, 0, 0, 0);
@@ -141,6 +144,134 @@ __device__ __forceinline__ f32x16 split_mma(const SplitFrag<BF>& a, const SplitF
 #undef MESM_BF
   return acc;
 }
+
+// ---- BF = 2: two fp16 terms -----------------------------------------------------------------------------------------
+struct HalfFrag {
+  u32x4 hi[2], lo[2];  // [f16 k-step of 16][4 dwords = 8 f16], the slot map of SplitFrag
+  // s = 2^e (wave-uniform).  x * s and x * s - hi are exact in f32 (a power-of-two product; a residual of <= 13 bits), so
+  // each v_fma_mix rounds ONCE, to fp16, to nearest even.
+  __device__ __forceinline__ void make(const float (&v)[4][4], float s) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float x0 = v[2 * t + (i >> 1)][2 * (i & 1)], x1 = v[2 * t + (i >> 1)][2 * (i & 1) + 1];
+        unsigned h, l;
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "v"(s));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "v"(s));
+        asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(s), "v"(h));
+        asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "v"(s), "v"(h));
+        hi[t][i] = h;
+        lo[t][i] = l;
+      }
+  }
+};
+
+__device__ __forceinline__ f32x16 half_mma(const HalfFrag& a, const HalfFrag& b, f32x16 acc) {
+#define MESM_HF(x) __builtin_bit_cast(f16x8, x)
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(MESM_HF(a.lo[t]), MESM_HF(b.hi[t]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(MESM_HF(a.hi[t]), MESM_HF(b.lo[t]), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(MESM_HF(a.hi[t]), MESM_HF(b.hi[t]), acc, 0, 0, 0);
+  }
+#undef MESM_HF
+  return acc;
+}
+
+// |x| maximum of a lane's 32 fragment values (NaNs drop out of v_max; an infinity stays).  v_max3_f32 with |.| source
+// modifiers: one instruction per two values (the compiler's fmaxf canonicalises every operand first: 7 per four).
+__device__ __forceinline__ float frag_amax(const float (&u)[4][4], const float (&w)[4][4]) {
+  float m0 = 0.0f, m1 = 0.0f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int j = 0; j < 4; j += 2) {
+      asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m0) : "v"(u[s][j]), "v"(u[s][j + 1]));
+      asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(m1) : "v"(w[s][j]), "v"(w[s][j + 1]));
+    }
+  asm("v_max_f32 %0, %0, %1" : "+v"(m0) : "v"(m1));
+  return m0;
+}
+__device__ __forceinline__ float frag_amax_finite(const float (&u)[4][4], const float (&w)[4][4]) {
+  float m = 0.0f;
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = __builtin_fabsf(u[s][j]), b = __builtin_fabsf(w[s][j]);
+      m = __builtin_fmaxf(m, a <= 3.4028234e38f ? a : 0.0f);
+      m = __builtin_fmaxf(m, b <= 3.4028234e38f ? b : 0.0f);
+    }
+  return m;
+}
+
+// The wave's scale exponent of one operand and the band its fragment maxima must stay in (bit patterns of |x|).
+struct HalfScale {
+  int e;                 // values are multiplied by 2^e
+  unsigned over, under;  // |x| bits >= over: 2^e |x| >= 2^15 (fp16 would overflow); no lane >= under: fragment maximum < 2^3
+  __device__ __forceinline__ void set(int e_) {
+    e = e_;
+    over = (unsigned)(127 + 15 - e_) << 23;
+    under = (unsigned)(127 + 3 - e_) << 23;
+  }
+  __device__ __forceinline__ float scale() const { return __uint_as_float((unsigned)(127 + e) << 23); }
+  // wave-uniform: does this stage's fragment leave the band?  (an all-zero fragment does not)
+  __device__ __forceinline__ bool leaves(float lane_amax) const {
+    const unsigned u = __float_as_uint(lane_amax);
+    const bool up = __builtin_amdgcn_ballot_w64(u >= over) != 0;
+    const bool in = __builtin_amdgcn_ballot_w64(u >= under) != 0;
+    const bool any = __builtin_amdgcn_ballot_w64(u != 0u) != 0;
+    return up || (!in && any);
+  }
+  // new exponent from the wave's largest FINITE |x|: 2^e |x|max in [2^10, 2^11)
+  __device__ __forceinline__ int pick(float lane_amax_finite) const {
+    const float wm = wave_max(lane_amax_finite);
+    if (wm == 0.0f) return e;
+    int eb = (int)((__float_as_uint(wm) >> 23) & 0xFFu);
+    eb = eb < 1 ? 1 : eb;
+    int ne = 137 - eb;
+    ne = ne > 110 ? 110 : (ne < -110 ? -110 : ne);
+    return ne;
+  }
+};
+
+// Both operands' scales of a wave and a bound on what its accumulators hold (in units of 2^-(ea + eb)): a stage adds at
+// most 32 x 2^15 x 2^15 = 2^35 per element, so <= 2^43 between two re-picks of a <= 256-stage range.  Scaling DOWN (a stage
+// with larger values arrived) is always safe; scaling UP (smaller values: keeps THEIR significand bits) is capped so that
+// the accumulators stay below 2^100.  `repick` returns the exponent the accumulators have to be shifted by.
+struct HalfScales {
+  HalfScale a, b;
+  int bexp;
+  __device__ __forceinline__ void init() {
+    a.set(0);
+    b.set(0);
+    bexp = -1000;
+  }
+  __device__ __forceinline__ int repick(float fa, float fb, bool empty) {
+    int ea = a.pick(fa), eb = b.pick(fb);
+    int delta = 0;
+    if (!empty) {
+      bexp = (bexp > 43 ? bexp : 43) + 1;
+      const int room = 100 - bexp;
+      int excess = (ea - a.e) + (eb - b.e) - room;
+      if (excess > 0) {
+        int ua = ea - a.e;
+        ua = ua > 0 ? (ua < excess ? ua : excess) : 0;
+        ea -= ua;
+        excess -= ua;
+        int ub = eb - b.e;
+        ub = ub > 0 ? (ub < excess ? ub : excess) : 0;
+        eb -= ub;
+      }
+      delta = (ea - a.e) + (eb - b.e);
+      bexp += delta;
+    }
+    a.set(ea);
+    b.set(eb);
+    return delta;
+  }
+};
 
 
 }  // namespace

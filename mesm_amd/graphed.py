@@ -202,12 +202,7 @@ class GraphedStep:
             # alive by gradbuf's hooks) to the stream of its first use, and a capture on another stream records the
             # hand-over to that stream as a side branch of the graph -- a second hardware queue at replay, which
             # costs every kernel boundary of the main chain (5.2 -> 5.5 ms per step)
-            with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
-                if self._pull is not None:
-                    self._pull.capture_node(self.counter)  # draws from the pinned ring + seed offset += 1: one node
-                else:
-                    self.counter.add_(1)
-                self.total, self.losses = self._step_body()
+            self._capture(side)
             if dot:
                 self.graph.debug_dump(dot)
             if self._pull is not None:
@@ -217,6 +212,15 @@ class GraphedStep:
             if instrument:
                 kn.gemm_tape(False)
         self._ptrs = self._param_ptrs()
+
+    def _capture(self, side):
+        """the whole step -- forward, criterion, backward -- as ONE graph (SplitGraphedStep: three)"""
+        with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
+            if self._pull is not None:
+                self._pull.capture_node(self.counter)  # draws from the pinned ring + seed offset += 1: one node
+            else:
+                self.counter.add_(1)
+            self.total, self.losses = self._step_body()
 
     # ------------------------------------------------------------------ host half (shared with the loader workers)
     def _resolve_caps(self, caps, batch, group_cap=None):
@@ -437,6 +441,74 @@ class GraphedStep:
             self.redraw()
         self.graph.replay()
         return self.total
+
+
+class SplitGraphedStep(GraphedStep):
+    """The same captured step cut where the reference's loop holds the reins (train.py:64-72): THREE graphs over one
+    memory pool -- `model(**batch)` | `criterion(outputs, batch)` | `loss.backward()` -- so that the unchanged caller's
+    `optimizer.zero_grad()` between the second and the third lands where it always did (mesm_amd/autograph.py replays
+    them from inside MESM.forward, Criterion.forward and ONE autograd node's backward: the structure of
+    torch.cuda.make_graphed_callables, with this build's arena / draw / capacity machinery).  The activations the
+    backward graph reads live in the pool until the next forward replay overwrites them: one forward in flight."""
+
+    def __init__(self, *a, **kw):
+        if kw.get("reducer") is not None:
+            raise ValueError("SplitGraphedStep: gradient collectives ride in the one-graph step (GraphedStep)")
+        super().__init__(*a, **kw)
+
+    def _capture(self, side):
+        if self._pull is not None:
+            raise RuntimeError("SplitGraphedStep: MESM_STEP_PULL is a one-graph option")
+        pool = torch.cuda.graph_pool_handle()
+        self.g_fwd, self.g_crit, self.g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        b = self.batch
+        kw = dict(stream=side, pool=pool, capture_error_mode="thread_local")
+        with torch.cuda.graph(self.g_fwd, **kw):
+            self.counter.add_(1)
+            out = self.model(**b, dataset_name=self.dataset_name, is_training=True, plan=self.plan)
+        with torch.cuda.graph(self.g_crit, **kw):
+            losses, total = self.crit(out, b, True)
+        self.model.zero_grad(set_to_none=True)
+        with torch.cuda.stream(side):
+            self.seed = torch.ones_like(total)
+        with torch.cuda.graph(self.g_bwd, **kw):
+            total.backward(self.seed)
+        gb = self.model.gradbuf()
+        self.grad_params = [p for p in gb.params if p.grad is not None]
+        det = lambda t: t.detach() if torch.is_tensor(t) else t
+        self.out = {k: ([{kk: det(vv) for kk, vv in d.items()} for d in v] if isinstance(v, list) else det(v))
+                    for k, v in out.items()}
+        self.total = total.detach()
+        vals = list(losses.values())
+        base = vals[0]._base if vals and vals[0]._base is not None else None
+        # the loss entries are elements of ONE vector (CriterionFn): a replay hands out a copy of it, one launch
+        self.loss_vec = base.detach() if base is not None and all(v._base is base for v in vals) else None
+        self.loss_index = ({k: int(v.storage_offset() - base.storage_offset()) for k, v in losses.items()}
+                           if self.loss_vec is not None else None)
+        self.losses = {k: v.detach() for k, v in losses.items()}
+
+    def run(self, redraw=True):
+        raise RuntimeError("SplitGraphedStep is replayed in three parts (forward_replay / criterion_replay / backward_replay)")
+
+    def forward_replay(self):
+        if self._param_ptrs() != self._ptrs:
+            raise RuntimeError("SplitGraphedStep: a parameter or the gradient buffer moved after capture")
+        self.g_fwd.replay()
+        return self.out
+
+    def criterion_replay(self):
+        self.g_crit.replay()
+        if self.loss_vec is not None:
+            lv = self.loss_vec.clone()
+            losses = {k: lv[i] for k, i in self.loss_index.items()}
+        else:
+            losses = {k: v.clone() for k, v in self.losses.items()}
+        return losses, self.total
+
+    def backward_replay(self, grad=None):
+        if grad is not None:
+            self.seed.copy_(grad)
+        self.g_bwd.replay()
 
 
 class StepCache:

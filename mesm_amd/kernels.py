@@ -202,6 +202,11 @@ def gemm_switches(tile=None, bf16x=None):
           "mesm_gemm_set_switches")
 
 
+def gemm_mode():
+    """the GEMM arithmetic in force: 6 = three-term bf16 split, 2 = two-term fp16 split, 0 = exact f32 MFMA"""
+    return int(lib().mesm_gemm_get_bf16x())
+
+
 def gemm(A, B, C, *, trans_a=False, trans_b=False, A2=None, B2=None, bias=None, residual=None,
          aux=None, slope=None, dslope=None, colsum=None, a_act=ACT_NONE, b_act=ACT_NONE,
          a_drop=(0.0, 0), b_drop=(0.0, 0), e_act=ACT_NONE, e_actgrad=ACT_NONE,

@@ -12,6 +12,7 @@ reference module, so `runner.build_model` / train.py / eval.py can use it unchan
 """
 import contextlib
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -21,6 +22,7 @@ from torch import nn
 from . import draws
 from . import kernels as kn
 from . import ops
+from .autograph import AutoGraph, AutoOutputs
 from .gradbuf import GradBuffer
 from .layers import (LinearLayer, MLPHead, ParamLayerNorm, ParamLinear, T2VLayer, T2VStack,
                      inverse_sigmoid)
@@ -133,6 +135,7 @@ class MESM(nn.Module):
         self._flat_params = None
         self._step = 0
         self._flat_checked = -1
+        self._auto = None
 
     # ------------------------------------------------------------------ infrastructure
     def gradbuf(self):
@@ -360,9 +363,45 @@ class MESM(nn.Module):
         return pl
 
     # ------------------------------------------------------------------ forward
+    def autograph(self, enabled=None, pad=None, pairs=None, max_graphs=None):
+        """Graph replay behind the unchanged `model(...) / criterion(...) / loss.backward()` sequence (autograph.py):
+        on by default (MESM_AUTOGRAPH=0 turns it off); `pad=(max_v_l, max_words_l), pairs=8` pads batches like
+        graphed.StepCache so that a loader's ever-changing shapes replay from a handful of graphs."""
+        if self._auto is None:
+            self._auto = AutoGraph(self)
+        return self._auto.configure(enabled, pad, pairs, max_graphs)
+
     def forward(self, video_feat, video_mask, words_id, words_mask, words_weight, num_clips, **kwargs):
         dev = video_feat.device
         is_training = kwargs["is_training"]
+        auto = self._auto if self._auto is not None else self.autograph()
+        if auto.eligible(self, {"video_feat": video_feat}, kwargs):
+            batch = dict(video_feat=video_feat, video_mask=video_mask, words_id=words_id, words_mask=words_mask,
+                         words_weight=words_weight, num_clips=num_clips)
+            batch.update({k: v for k, v in kwargs.items() if k not in ("dataset_name", "is_training", "plan")})
+            res = auto.forward(batch, kwargs["dataset_name"])
+            if res is not None:
+                return res
+        elif torch.is_grad_enabled() and not auto.busy:
+            auto.gen += 1
+        side = auto.eager_stream(dev)
+        if side is not None:
+            # an eager visit of a shape that may be captured later runs on THE capture stream of the process: autograd pins
+            # every AccumulateGrad node to the stream of its first use, and a capture on another stream would record the
+            # hand-over as a second hardware queue (graphed.capture_stream)
+            cur = torch.cuda.current_stream(dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                out = self._forward(video_feat, video_mask, words_id, words_mask, words_weight, num_clips, **kwargs)
+            cur.wait_stream(side)
+            out._mesm_side = side
+            return out
+        return self._forward(video_feat, video_mask, words_id, words_mask, words_weight, num_clips, **kwargs)
+
+    def _forward(self, video_feat, video_mask, words_id, words_mask, words_weight, num_clips, **kwargs):
+        dev = video_feat.device
+        is_training = kwargs["is_training"]
+        auto = self._auto
         self._begin(dev, is_training)
         d, h = self.hidden_dim, self.transformer.nhead
         N, Lv = video_mask.shape
@@ -604,4 +643,7 @@ class MESM(nn.Module):
             out.update({"projed_video_feat": pv_o, "recon_feat": recon, "projed_recon_feat": projed_recon,
                         "expanded_words_feat": ewords, "expanded_words_mask": emask,
                         "enhanced_video_feat": enhanced, "projed_words_feat": pw})
+        if not auto.busy:  # (the criterion finds the model on its outputs: autograph.py)
+            out = AutoOutputs(out)
+            out._mesm_model = weakref.ref(self)
         return out

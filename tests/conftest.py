@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# the suite's eager-path tests call model / criterion / backward repeatedly on one shape and mean EAGER steps; graph replay
+# behind that call sequence (mesm_amd/autograph.py, on by default for users) has its own file, tests/test_autograph_gpu.py,
+# which switches it on per model
+os.environ.setdefault("MESM_AUTOGRAPH", "0")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
