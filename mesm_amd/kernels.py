@@ -53,12 +53,41 @@ class ZeroPool:
         self.cleared, self.wanted = set(), []  # (offset, length) float ranges of `part`: cleared by this step's fill / asked in it
         self.active = False  # between begin() and the next forward without one (MESM._begin: no-grad forwards do not fill)
         self.handed = {}     # data_ptr -> (cut, rows) of the tail-zeroed tensors handed out in THIS step, until a GEMM takes them
+        # FORWARD activations live in the pool too (deep_out / rows_out with fwd=True: outputs that later blocks save for
+        # their backward).  `fwd_live`: such tensors were handed out and no backward has reached the model's input side
+        # since (MESM._forward hooks its first projection's gradient).  A begin() in that state -- a second grad-enabled
+        # forward before the first one's backward: deferred backward, two models in one process -- must not clear or
+        # re-issue those buffers: it lets go of them (the saved tensors keep their storage alive) and the step is served by
+        # plain allocations; the next step gets fresh buffers.  Buffers a HIP graph was captured against are never freed.
+        self.fwd_live = False
+        self.in_graphs = False
+        self.let_go = 0
 
     def idle(self):
         self.active = False
         self.handed = {}
 
+    def backward_reached_inputs(self):
+        self.fwd_live = False
+
+    def _release(self):
+        """drop this step's buffers without touching their contents (see fwd_live)"""
+        for name in ("buf", "part"):
+            b = getattr(self, name)
+            if b is not None and self.in_graphs:
+                self.retired.append(b)
+            setattr(self, name, None)
+        self.in_graphs = False
+        self.cleared, self.wanted = set(), []
+        self.let_go += 1
+
     def begin(self, device):
+        capturing = torch.cuda.is_current_stream_capturing() if device.type == "cuda" else False
+        if self.fwd_live and not capturing:
+            self._release()
+        self.fwd_live = False
+        if capturing:
+            self.in_graphs = True
         want = self.asked
         if want > 0 and (self.buf is None or self.buf.numel() < want or self.buf.device != device):
             if self.buf is not None:
@@ -165,6 +194,7 @@ def deep_out(shape, K, device, fwd=False):
             and min(K // _DEEP_DEPTH, 256 // t64) >= 2 and zero_pool.serves(rows * cols, device)):
         t = zero_pool.zeros(shape, device)
         zero_pool.handed[t.data_ptr()] = (0, rows)  # (gemm() takes it: every row starts at zero)
+        zero_pool.fwd_live = zero_pool.fwd_live or fwd
         return t
     return torch.empty(shape, device=device, dtype=torch.float32)
 
@@ -184,6 +214,7 @@ def rows_out(like, K=0, fwd=False):
         t, ok = zero_pool.tail_zeroed((rows, cols), ROW_CUT, like.device)
         if ok:
             zero_pool.handed[t.data_ptr()] = (ROW_CUT, rows)  # (gemm() takes it: valid for one product of this step)
+            zero_pool.fwd_live = zero_pool.fwd_live or fwd
             return t.view(like.shape)
     return torch.empty_like(like)
 

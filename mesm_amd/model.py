@@ -38,6 +38,10 @@ def _scope(name):
     return torch.profiler.record_function("R:" + name) if _SCOPES else contextlib.nullcontext()
 
 
+def _pool_spent(_g):
+    kn.zero_pool.backward_reached_inputs()
+
+
 class TrainablePositionalEncoding(nn.Module):
     """position_encoding.py:10-32: dropout(LayerNorm(x + E[0:L])).  Bypassed while use_txt_pos=False
     (model.py:169-172, every shipped config), like in the reference."""
@@ -462,6 +466,10 @@ class MESM(nn.Module):
                            proj_chain(self.input_txt_proj, self.masked_token.view(1, 1, -1))]
             res = ops.lockstep(chains)
             pv, pw = res[0], res[1]
+            if pv.requires_grad and not torch.cuda.is_current_stream_capturing():
+                # the backward has reached the input side: the pool-backed activations of this forward are spent
+                # (kernels.ZeroPool.fwd_live; under capture the step is one forward + one backward by construction)
+                pv.register_hook(_pool_spent)
             if self.rec_ss:
                 bvid, bsent = res[2], res[3]
             if mlm:

@@ -32,3 +32,18 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture
+def deterministic_forward():
+    """Eager-vs-replay and replay-vs-replay comparisons run with the forward's atomically summed K-split products off
+    (MESM_GEMM_FWD_ATOMICS=0): activations are then bit-reproducible, gradients agree to rounding, and the comparison keeps
+    its TIGHT bound (1e-4) -- the run-to-run freedom of the default setting is measured by the one test that is parametrized
+    on it (test_model_gpu.py::test_run_to_run_spread_of_a_replayed_step), not absorbed by every other threshold."""
+    from mesm_amd import kernels as kn
+    saved = kn._FWD_ATOMICS
+    kn._FWD_ATOMICS = False
+    try:
+        yield
+    finally:
+        kn._FWD_ATOMICS = saved

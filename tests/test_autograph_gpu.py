@@ -8,8 +8,8 @@
     optimizer.step()
 
 run literally, with torch's own AdamW and clip_grad_norm_: first visit of a shape eager, every later one three graph
-replays; loss and gradients of a replayed step equal the eager step on the same batch and draws (the bound of the
-one-graph replay test, test_graph_ddp_gpu.py), parameters really update, gradients accumulate when zero_grad is skipped,
+replays; loss and gradients of a replayed step equal the eager step on the same batch and draws (1e-4 of the gradient norm with the
+forward deterministic, the bound of the one-graph replay test), parameters really update, gradients accumulate when zero_grad is skipped,
 a second forward in flight is refused, other shapes get their own graphs, padded buckets serve changing pair counts."""
 import os
 
@@ -72,7 +72,7 @@ def _eager_on(model, crit, batch, name, neg, mw):
 
 
 @pytest.mark.parametrize("workload", ["C3a", "C2"])
-def test_reference_loop_body_runs_on_graph_replays_and_equals_eager(workload):
+def test_reference_loop_body_runs_on_graph_replays_and_equals_eager(workload, deterministic_forward):
     from mesm_amd import synthetic
     from mesm_amd.autograph import AutoOutputs
     args, model, crit = _build(workload)
@@ -104,7 +104,7 @@ def test_reference_loop_body_runs_on_graph_replays_and_equals_eager(workload):
             for k, v in out_g.items():
                 d = (out_e[k].double() - v.double()).abs().max().item() if v.dtype.is_floating_point else float((out_e[k] != v).sum())
                 assert d <= 1e-4 * max(1.0, float(out_e[k].double().abs().max()) if v.dtype.is_floating_point else 1.0), (k, d)
-            assert float((flat_e - flat_g).norm()) / max(float(flat_e.norm()), 1e-6) < 1e-3
+            assert float((flat_e - flat_g).norm()) / max(float(flat_e.norm()), 1e-6) < 1e-4
             assert had == [p.grad is not None for p in model.gradbuf().params]
             model.gradbuf().flat.copy_(flat_g)  # the step goes on with the replayed gradients
         return hook
@@ -128,7 +128,7 @@ def argparse_like(args, **kw):
     return argparse.Namespace(**d)
 
 
-def test_gradients_accumulate_when_zero_grad_is_skipped_and_stale_steps_are_refused():
+def test_gradients_accumulate_when_zero_grad_is_skipped_and_stale_steps_are_refused(deterministic_forward):
     from mesm_amd import synthetic
     args, model, crit = _build("C3a")
     name = args.dataset_name
@@ -153,7 +153,7 @@ def test_gradients_accumulate_when_zero_grad_is_skipped_and_stale_steps_are_refu
     model.zero_grad(set_to_none=True)
     neg, mw = out2._auto_step._draws
     _, _, _, g2 = _eager_on(model, crit, b[2], name, neg, mw)
-    assert float((g12 - g1 - g2).norm()) / float(g2.norm()) < 1e-3
+    assert float((g12 - g1 - g2).norm()) / float(g2.norm()) < 2e-4
     # two forwards, then the first one's criterion / backward: refused, not silently wrong
     o_a = model(**b[1], dataset_name=name, is_training=True)
     _, loss_a = crit(o_a, b[1], is_training=True)
@@ -210,7 +210,7 @@ def test_other_shapes_get_their_own_graphs_and_dropout_draws_fresh_masks():
     assert losses[4][1] != losses[5][1]  # same batch, new dropout masks and draws per replay
 
 
-def test_padded_buckets_serve_changing_pair_counts():
+def test_padded_buckets_serve_changing_pair_counts(deterministic_forward):
     """model.autograph(pad=..., pairs=8): batches of 41 / 43 / 46 pairs replay the 48-pair graph; outputs come back with
     the caller's pair count and the step equals the eager step on the unpadded batch"""
     from mesm_amd import synthetic
@@ -242,5 +242,5 @@ def test_padded_buckets_serve_changing_pair_counts():
         n = sum(groups)
         _, _, total_e, flat_e = _eager_on(model, crit, batch, name, neg[:n], None if mw is None else mw[:n])
         assert abs(total_e - float(loss)) < 1e-5 * max(1.0, abs(total_e))
-        assert float((flat_e - flat_g).norm()) / max(float(flat_e.norm()), 1e-6) < 1e-3
+        assert float((flat_e - flat_g).norm()) / max(float(flat_e.norm()), 1e-6) < 1e-4
     assert auto.captures == 1 and auto.replays == 2

@@ -2,7 +2,9 @@
 dataset, group sizes, sequence lengths, padding, widths / heads (incl. head dim 32: matrix-core attention), layer
 counts, projection depth and the ablation switches are drawn per case; outputs, losses, matcher indices and
 gradients are compared.  A seeded 20-case slice runs in the GPU suite (tests/test_fuzz_gpu.py imports fuzz_case);
-the long sweeps are a bug hunt.  usage: fuzz_parity.py [n_cases] [seed]"""
+the long sweeps are a bug hunt.  Referees for a gradient outside the bound: the fp64 oracle; the fp64 oracle on the device's
+PReLU branch; the fp64 oracle on the other ReLU branch of an input projection (each only within 1e-5 of the kink).
+usage: fuzz_parity.py [n_cases] [seed]"""
 import os, random, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -167,6 +169,61 @@ def device_kink_referee(model, crit, spec, args, batch, neg, masked, sd, grads, 
     return w[0] < bound, "device-side PReLU kink at %d element(s), max |z64| %.2e; against the fp64 oracle on the device's branch: %.2e (%s)" % (nflip, zmax, w[0], w[1])
 
 
+def relu_kink_referee(spec, args, batch, neg, masked, sd, grads, bound=5e-3, zeps=1e-5, max_near=8, max_flips=4):
+    """Fourth referee (round 6, sweep 6006 case 282): the ReLUs of the input projections (LinearLayer, model.py:412-434; two
+    of them with n_input_proj = 3) have the same kink as the FFNs' PReLU and the PReLU referee above does not see them.
+    Host-only: every ReLU pre-activation of the fp64 oracle within zeps of zero is a candidate; the fp64 oracle is re-run
+    with the OTHER branch taken at every subset of up to max_flips candidates (gradient mask flipped, the value is ~0
+    either way) and the device gradients have to meet `bound` against one of those runs.  -> (ok, note)."""
+    import itertools
+    calls, ro = [], O._relu
+
+    def rec(x):
+        calls.append(x.detach().clone())
+        return ro(x)
+    O._relu = rec
+    try:
+        O.train_step64(sd, dict(vars(args)), batch, neg, masked)
+    finally:
+        O._relu = ro
+    near = [(i, tuple(ix.tolist()), float(z[tuple(ix.tolist())])) for i, z in enumerate(calls)
+            for ix in (z.abs() <= zeps).nonzero()]
+    if not near:
+        return False, "no ReLU pre-activation of the fp64 oracle within %.0e of zero" % zeps
+    if len(near) > max_near:
+        return False, "%d ReLU pre-activations within %.0e of zero: too many branch combinations to referee" % (len(near), zeps)
+    best = None
+    for r in range(1, min(len(near), max_flips) + 1):
+        for sub in itertools.combinations(near, r):
+            cnt = [0]
+
+            def forced(x):
+                i = cnt[0]
+                cnt[0] += 1
+                y = torch.relu(x)
+                for ci, ix, zv in sub:
+                    if ci == i:
+                        m = torch.zeros_like(x, dtype=torch.bool)
+                        m[ix] = True
+                        y = torch.where(m, x if zv <= 0 else 0 * x, y)
+                return y
+            O._relu = forced
+            try:
+                g = O.train_step64(sd, dict(vars(args)), batch, neg, masked)[3]
+            finally:
+                O._relu = ro
+            w = max((l2(grads[k], v.float()), k) for k, v in g.items())
+            if best is None or w[0] < best[0]:
+                best = (w[0], w[1], sub)
+            if w[0] < bound:
+                break
+        if best[0] < bound:
+            break
+    return best[0] < bound, ("ReLU kink of an input projection: %d pre-activation(s) within %.0e of zero in fp64 (max |z64| %.2e); "
+                             "against the fp64 oracle on the other branch at %d of them: %.2e (%s)"
+                             % (len(near), zeps, max(abs(z) for _, _, z in near), len(best[2]), best[0], best[1]))
+
+
 def fuzz_case(rng, case):
     """one random configuration -> (description, 'ok' | 'MISMATCH ...' | 'ERROR ...')"""
     tag, spec = draw(rng, case)
@@ -234,6 +291,12 @@ def fuzz_case(rng, case):
                     print("   (case %d: device off by %.2e on %s against both oracles; %s)" % (case, w64[0], w64[1], note))
                     if ok_k:
                         w = (0.0, w64[1])
+                    else:
+                        ok_r, note = relu_kink_referee(spec, args, batch, neg, masked, sd,
+                                                       {k: v.detach().cpu() for k, v in grads.items()})
+                        print("   (case %d: %s)" % (case, note))
+                        if ok_r:
+                            w = (0.0, w64[1])
             if not w[0] < 5e-3:
                 errs.append("grad L2 %s %.2e (norms %.3e vs %.3e)" % (w[1], w[0], float(grads[w[1]].norm()), float(o_grads[w[1]].norm())))
         status = "ok" if not errs else "MISMATCH " + "; ".join(errs[:6])
