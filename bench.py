@@ -212,7 +212,7 @@ def ddp_diagnostics(opt, world, rank, dev, model, crit, batch, args, g_after, r_
     diag["probe_ms"] = {"after": timed(after_step)}
     got = reduced(after_step)
     same, spread = ranks_agree(got)
-    diag["grad_checksum_spread_over_ranks"] = {"after": spread}
+    diag["grad_checksum_spread_by_form"] = {"after": spread}  # (`grad_checksum_spread_over_ranks`: the headline form's)
     diag["after_ranks_agree"] = bool(same)
     diag["_after_objs"] = (g_after, r_after, True)
     best, own = None, None
@@ -261,7 +261,7 @@ def ddp_diagnostics(opt, world, rank, dev, model, crit, batch, args, g_after, r_
             same, spread = ranks_agree(got)
             fin = bool(torch.isfinite(got).all())
             diag["own_forms_ranks_agree"][c] = {"ranks_agree": bool(same), "checksum_spread": spread, "finite": fin}
-            diag["grad_checksum_spread_over_ranks"][c] = spread
+            diag["grad_checksum_spread_by_form"][c] = spread
             verified = diag["own_comm_selftest_exact"] and same and fin
             if not verified:
                 diag.setdefault("refused_forms", []).append(c)
@@ -654,14 +654,37 @@ def main():
                 loss.backward()
             torch.cuda.synchronize()
             uc_fb = (time.perf_counter() - t1) / opt.steps * 1e3
+            # the same loop with ONE more changed line: `optimizer = mesm_amd.build_optimizer(opt, model)` (FlatAdamW: global-
+            # norm clip + AdamW over the flat buffers, two launches) whose step(grad_clip=...) replaces lines 70-72
+            from mesm_amd.optim import FlatAdamW
+            flat_opt = FlatAdamW(model, lr=0.0, weight_decay=1e-4)
+            for _ in range(2):
+                outputs = model(**batch, dataset_name=args.dataset_name, is_training=True)
+                loss_dict, loss = crit(outputs, batch, is_training=True)
+                flat_opt.zero_grad()
+                loss.backward()
+                flat_opt.step(grad_clip=0.1)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(opt.steps):
+                outputs = model(**batch, dataset_name=args.dataset_name, is_training=True)
+                loss_dict, loss = crit(outputs, batch, is_training=True)
+                flat_opt.zero_grad()
+                loss.backward()
+                flat_opt.step(grad_clip=0.1)
+            torch.cuda.synchronize()
+            uc_flat = (time.perf_counter() - t1) / opt.steps * 1e3
+            del flat_opt
             a = model._auto
             unchanged = {"ms_per_step": uc, "ms_per_step_with_the_loops_float_of_the_loss": uc_sync,
+                         "with_this_builds_optimizer_step_instead_of_clip_and_torch_adamw_ms": uc_flat,
                          "fwd_criterion_zero_grad_backward_only_ms": uc_fb,
                          "pairs_per_s": n_pairs / (uc * 1e-3), "replayed": outputs._auto_step is not None,
                          "eager_visits": a.eager, "captures": a.captures, "replays": a.replays,
                          "sequence": "train.py:64-72: model(**batch) / criterion(outputs, batch) / optimizer.zero_grad() / "
                                      "loss.backward() / nn.utils.clip_grad_norm_ / torch.optim.AdamW.step (lr = 0)"}
-            log("unchanged caller: %.3f ms/step (%.3f with float(loss), %.3f without clip + step)" % (uc, uc_sync, uc_fb))
+            log("unchanged caller: %.3f ms/step (%.3f with float(loss), %.3f without clip + step, %.3f with FlatAdamW.step)"
+                % (uc, uc_sync, uc_fb, uc_flat))
         except Exception as e:
             unchanged = {"error": "%s: %s" % (type(e).__name__, e)}
         finally:

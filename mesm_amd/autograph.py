@@ -63,6 +63,66 @@ class _Backward(torch.autograd.Function):
         return None, None, None, None, None
 
 
+_NP = {torch.float32: "float32", torch.float64: "float64", torch.int64: "int64", torch.int32: "int32",
+       torch.bool: "bool", torch.uint8: "uint8", torch.int16: "int16", torch.float16: "float16", torch.int8: "int8"}
+
+
+class _Fetch:
+    """Everything small of a DEVICE batch (prepare_batch_input has moved it there, dataset/base.py:358-384) back on the host
+    in ONE transfer: the index plans and the flattened targets are host arithmetic on masks, labels and target windows (a few
+    KB), and one `.cpu()` per tensor is one stream synchronisation each -- 77 per C3a batch, 1.2 ms.  The tensors are packed
+    by one concatenation kernel (largest element size first, so every piece stays aligned), copied into a pinned buffer and
+    cut into numpy views.  The per-pair target lists travel as one tensor per entry; the word-validity mask of pre-extracted
+    word features (2 MB of features otherwise) is formed on the device with hostplan.HostSpec.words_mask's arithmetic."""
+
+    def __init__(self):
+        self.pinned = None
+
+    def __call__(self, batch, spec, big):
+        import numpy as np
+        items, lists = [], {}
+        for k, v in batch.items():
+            if torch.is_tensor(v):
+                if v.is_cuda and v.dtype in _NP and v.numel() * v.element_size() <= big:
+                    items.append((k, v))
+            elif isinstance(v, list) and v and isinstance(v[0], dict):
+                for kk in v[0]:
+                    ts = [d[kk] for d in v]
+                    if all(torch.is_tensor(t) and t.is_cuda for t in ts):
+                        lists[(k, kk)] = [int(t.shape[0]) for t in ts]
+                        items.append(((k, kk), torch.cat(ts)))
+        w = batch["words_id"]
+        if w.dim() == 3 and w.is_cuda:
+            a = w
+            if spec.normalize_txt:
+                a = a / a.pow(2).sum(-1, keepdim=True).sqrt().clamp_min(1e-5)
+            items.append(("_words_mask", a.sum(-1) != 0))
+        items.sort(key=lambda kv: -kv[1].element_size())
+        flat = torch.cat([t.contiguous().view(-1).view(torch.uint8) for _, t in items])
+        n = flat.numel()
+        if self.pinned is None or self.pinned.numel() < n:
+            self.pinned = torch.empty(max(2 * n, 1 << 16), dtype=torch.uint8, pin_memory=True)
+        self.pinned[:n].copy_(flat, non_blocking=True)
+        torch.cuda.current_stream(flat.device).synchronize()
+        raw = self.pinned.numpy()[:n].copy()  # (the pinned buffer is reused by the next batch)
+        host, off = {}, 0
+        for key, t in items:
+            nb = t.numel() * t.element_size()
+            arr = raw[off:off + nb].view(_NP[t.dtype]).reshape(tuple(t.shape))
+            off += nb
+            host[key] = torch.from_numpy(arr)
+        out = {}
+        for k, v in batch.items():
+            if torch.is_tensor(v):
+                out[k] = host.get(k, v)
+            elif isinstance(v, list) and v and isinstance(v[0], dict) and all((k, kk) in lists for kk in v[0]):
+                parts = {kk: host[(k, kk)].split(lists[(k, kk)]) for kk in v[0]}
+                out[k] = [{kk: parts[kk][i] for kk in v[0]} for i in range(len(v))]
+        if "_words_mask" in host:
+            out["_words_mask"] = host["_words_mask"]
+        return out
+
+
 def _enabled_default():
     return os.environ.get("MESM_AUTOGRAPH", "1") != "0"
 
@@ -85,6 +145,8 @@ class AutoGraph:
         self.busy = False     # inside a capture: the model's forward is being called by the step itself
         self.token = None
         self.captures = self.replays = self.eager = 0
+        self.fetch = _Fetch()
+        self.spec = None
 
     # ------------------------------------------------------------------ configuration
     def configure(self, enabled=None, pad=None, pairs=None, max_graphs=None):
@@ -128,9 +190,9 @@ class AutoGraph:
         return batch
 
     @staticmethod
-    def _key(model, batch, dataset_name):
+    def _key(model, batch, dataset_name, num_clips=None):
         n = batch["video_mask"].shape[0]
-        gmax = int(batch["num_clips"].max())
+        gmax = int((batch["num_clips"] if num_clips is None else num_clips).max())
         gcap = next((c for c in GROUP_CAPS if c >= gmax), gmax)
         sig = tuple(sorted(k for k, v in batch.items() if not k.startswith("_")))
         return (dataset_name, bool(model.training), n, tuple(batch["video_feat"].shape[1:]),
@@ -160,7 +222,14 @@ class AutoGraph:
             shaped = self._shaped(batch)
             if shaped is None:
                 return None
-            key, gcap = self._key(model, shaped, dataset_name)
+            host = None
+            if crit is not None:
+                if self.spec is None or self.spec.dataset_name != dataset_name:
+                    from .hostplan import HostSpec
+                    self.spec = HostSpec.from_model(model, crit, dataset_name)
+                from .graphed import GraphedStep
+                host = self.fetch(shaped, self.spec, GraphedStep.BIG)
+            key, gcap = self._key(model, shaped, dataset_name, None if host is None else host["num_clips"])
         except Exception:
             return None
         if key in self.bad:
@@ -172,7 +241,7 @@ class AutoGraph:
         step = None
         for s in self.steps.get(key, []):
             try:
-                s.load_batch(shaped, redraw=True)
+                s.load_batch(shaped, redraw=True, host=host, defer_targets=True)
             except ValueError:
                 continue
             step = s
@@ -184,6 +253,11 @@ class AutoGraph:
         else:
             self.steps.move_to_end(key)
         out = step.forward_replay()
+        if step._pending_targets is not None:
+            try:
+                step.finish_targets()  # (the criterion's arrays, while the forward graph runs)
+            except ValueError:
+                return None  # targets beyond the captured capacities: this step runs eagerly
         self.replays += 1
         n = batch["video_feat"].shape[0]
         res = AutoOutputs(out if shaped["video_mask"].shape[0] == n else self._real_rows(out, n))

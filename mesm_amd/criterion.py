@@ -43,14 +43,20 @@ class TargetPlan:
         read the true counts from tgt_off, so padding changes no result."""
         import numpy as np
         if multi_clip:
-            sizes = [len(t["spans"]) for t in targets["norm_span"]]
-            cxw = torch.cat([t["spans"] for t in targets["norm_span"]]).float().cpu()
-            xx = torch.cat([t["moments"] for t in targets["norm_moment"]]).float().cpu()
-            mom = torch.stack([torch.stack([t["moments"].min(), t["moments"].max()])
-                               for t in targets["norm_moment"]]).float().cpu()
+            spans, moms = [t["spans"] for t in targets["norm_span"]], [t["moments"] for t in targets["norm_moment"]]
+            sizes = [int(t.shape[0]) for t in spans]
+            cxw = torch.cat(spans).float().cpu().numpy()
+            xx = torch.cat(moms).float().cpu().numpy()
+            if min(sizes) > 0 and [int(t.shape[0]) for t in moms] == sizes:
+                # the merged moment of every pair, [min, max] over its windows (criterion.py:226-229): segment reductions
+                # (32 pairs x 3 small tensor ops cost 0.4 ms on the host path of every replayed step)
+                first = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+                mom = np.stack([np.minimum.reduceat(xx.min(1), first), np.maximum.reduceat(xx.max(1), first)], axis=1)
+            else:
+                mom = torch.stack([torch.stack([t.min(), t.max()]) for t in moms]).float().cpu().numpy()
         else:
-            cxw = targets["norm_span"].float().cpu()
-            xx = targets["norm_moment"].float().cpu()
+            cxw = targets["norm_span"].float().cpu().numpy()
+            xx = targets["norm_moment"].float().cpu().numpy()
             sizes = [1] * cxw.shape[0]
             mom = xx
         N, Tmax, sumT = len(sizes), max(sizes), cxw.shape[0]
@@ -58,7 +64,6 @@ class TargetPlan:
             if Tmax > Tmax_cap:
                 raise ValueError("TargetPlan: a pair has %d target windows > Tmax_cap %d" % (Tmax, Tmax_cap))
             Tmax = Tmax_cap
-        cxw, xx = cxw.numpy(), xx.numpy()
         if T_cap is not None:
             if sumT > T_cap:
                 raise ValueError("TargetPlan: %d target windows > T_cap %d" % (sumT, T_cap))
@@ -68,7 +73,15 @@ class TargetPlan:
         groups = [int(g) for g in targets["num_clips"].tolist()]
         gid = np.repeat(np.arange(len(groups)), groups)
         gmask = gid[:, None] == gid[None, :]
-        ss_pos = ((generalized_temporal_iou(mom, mom) >= gamma).numpy() & gmask).astype(np.uint8)
+        # generalized_temporal_iou(mom, mom) >= gamma in fp32, the arithmetic of utils/span_utils.py:92-121 operation for
+        # operation (numpy float32 = torch float32 element-wise)
+        a = np.ascontiguousarray(mom, dtype=np.float32)
+        inter = np.maximum(np.minimum(a[:, None, 1], a[None, :, 1]) - np.maximum(a[:, None, 0], a[None, :, 0]), np.float32(0))
+        union = (a[:, 1] - a[:, 0])[:, None] + (a[:, 1] - a[:, 0])[None, :] - inter
+        enc = np.maximum(np.maximum(a[:, None, 1], a[None, :, 1]) - np.minimum(a[:, None, 0], a[None, :, 0]), np.float32(0))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            giou = inter / union - (enc - union) / enc
+        ss_pos = ((giou >= np.float32(gamma)) & gmask).astype(np.uint8)
         arr = {"tgt_cxw": np.ascontiguousarray(cxw, dtype=np.float32), "tgt_xx": np.ascontiguousarray(xx, dtype=np.float32),
                "tgt_off": np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32), "group_mask": gmask, "ss_pos": ss_pos}
         return arr, {"sizes": sizes, "N": N, "Tmax": Tmax, "sumT": sumT}

@@ -226,10 +226,11 @@ class GraphedStep:
     def _resolve_caps(self, caps, batch, group_cap=None):
         return self.spec.resolve_caps(caps, batch, self._groups, group_cap)
 
-    def _host_arrays(self, host, neg_index, masked_words):
+    def _host_arrays(self, host, neg_index, masked_words, targets=True):
         """hostplan.HostSpec.host_arrays with this step's groups / capacities: {name: numpy array} of everything small
         the captured step reads, the two metas and the word mask"""
-        return self.spec.host_arrays(host, self._groups, self.caps, self._n_real, neg_index, masked_words, self.BIG)
+        return self.spec.host_arrays(host, self._groups, self.caps, self._n_real, neg_index, masked_words, self.BIG,
+                                     targets=targets)
 
     def _param_ptrs(self):
         gb = self.model.gradbuf()
@@ -251,14 +252,14 @@ class GraphedStep:
         return total.detach(), {k: v.detach() for k, v in losses.items()}
 
     # ------------------------------------------------------------------ new batch, same graph
-    def load_batch(self, batch, redraw=False):
+    def load_batch(self, batch, redraw=False, host=None, defer_targets=False):
         """Make the captured step run on `batch` (host tensors; device tensors are brought to the host first,
         the plans are host work): same (N, Lv, Lw, Dv, Dt) and the same group sizes; GT-clip counts, group video
         lengths and target windows may differ within the capture-time capacities.  Everything small -- index
         plans, targets, masks, labels -- goes up in ONE pinned transfer (arena.Arena), the feature tensors in one
         copy each.  redraw: also draw new negatives / MLM words here (then call run(redraw=False): one upload per
         step instead of two).  Raises ValueError (nothing is modified) when it does not fit."""
-        groups = [int(g) for g in batch["num_clips"].tolist()]
+        groups = [int(g) for g in (batch if host is None else host)["num_clips"].tolist()]
         if groups != self._groups and (self.caps.get("M") is None or sum(groups) != sum(self._groups)):
             # exact-extent graphs (caps=None) are tied to their grouping; with capacities any grouping of the
             # same number of pairs fits as long as its largest group does (checked by the plan below)
@@ -270,12 +271,12 @@ class GraphedStep:
         old_groups, self._groups = self._groups, groups
         old_real, self._n_real = self._n_real, n_real
         try:
-            self._load_batch(batch, redraw)
+            self._load_batch(batch, redraw, host, defer_targets)
         except ValueError:
             self._groups, self._n_real = old_groups, old_real
             raise
 
-    def _load_batch(self, batch, redraw):
+    def _load_batch(self, batch, redraw, host_given=None, defer_targets=False):
         for k, cur in self.batch.items():
             v = batch.get(k)
             if k == "num_clips" or k.startswith("_"):
@@ -286,19 +287,28 @@ class GraphedStep:
                     continue  # the real rows only: the rest of the static input keeps (finite) older rows
                 raise ValueError("GraphedStep.load_batch: %s changed shape %s -> %s"
                                  % (k, tuple(cur.shape), tuple(v.shape)))
-        host = {k: (v.detach().cpu() if v.is_cuda and v.numel() * v.element_size() <= self.BIG else v)
-                for k, v in batch.items() if torch.is_tensor(v)}
-        for k in ("video_mask", "clip_mask"):
-            if k in host and host[k].is_cuda:
-                host[k] = host[k].cpu()
-        if host["words_id"].is_cuda:
-            host["words_id"] = host["words_id"].cpu()
-        for k in ("norm_span", "norm_moment"):
-            if isinstance(batch.get(k), list):
-                host[k] = [{kk: vv.detach().cpu() for kk, vv in d.items()} for d in batch[k]]
+        if host_given is not None:
+            # (autograph._Fetch: every small tensor of a device batch in ONE transfer, the word mask formed on the device)
+            host = {k: v for k, v in host_given.items() if torch.is_tensor(v) or isinstance(v, list)}
+        else:
+            host = {k: (v.detach().cpu() if v.is_cuda and v.numel() * v.element_size() <= self.BIG else v)
+                    for k, v in batch.items() if torch.is_tensor(v)}
+            for k in ("video_mask", "clip_mask"):
+                if k in host and host[k].is_cuda:
+                    host[k] = host[k].cpu()
+            if host["words_id"].is_cuda:
+                host["words_id"] = host["words_id"].cpu()
+            for k in ("norm_span", "norm_moment"):
+                if isinstance(batch.get(k), list):
+                    host[k] = [{kk: vv.detach().cpu() for kk, vv in d.items()} for d in batch[k]]
         # keep the current host draws unless asked to redraw (plan_arrays draws when given None)
         arr, pmeta, tmeta, wm = self._host_arrays(host, None if redraw else self._draws[0],
-                                                  None if redraw else self._draws[1])
+                                                  None if redraw else self._draws[1], targets=not defer_targets)
+        if defer_targets:
+            # the criterion's arrays are built and uploaded by finish_targets(), after the forward graph has been launched;
+            # until then the arena image keeps the previous batch's (they are not part of this upload)
+            arr.update({k: v for k, v in self._arr.items() if k.startswith("t.")})
+            self._pending_targets = host
         for k in ("vid_identity", "has_vid_src"):
             if pmeta.get(k) != self._pmeta.get(k):
                 raise ValueError("GraphedStep.load_batch: plan.%s changed (%r -> %r): needs its own graph"
@@ -307,8 +317,11 @@ class GraphedStep:
         # nothing above modified anything; from here on only copies
         self._arr = arr
         self._draws = (arr["p.neg_index"], arr.get("p.masked_words"))
-        self.arena.upload(arr)
-        self.tplan.sizes, self.tplan.sumT = tmeta["sizes"], tmeta["sumT"]
+        if defer_targets:
+            self.arena.upload(arr, only=[k for k in arr if not k.startswith("t.")])
+        else:
+            self.arena.upload(arr)
+            self.tplan.sizes, self.tplan.sumT = tmeta["sizes"], tmeta["sumT"]
         for k, cur in self.batch.items():
             v = batch.get(k)
             if k.startswith("_"):
@@ -325,6 +338,21 @@ class GraphedStep:
                     self._stage_big(k, cur, v)
         self._turn ^= 1
         self._wm_cpu = wm
+
+    _pending_targets = None
+
+    def finish_targets(self):
+        """second half of load_batch(defer_targets=True): the criterion's flattened targets, built and uploaded while the
+        forward graph runs.  Raises ValueError when they do not fit the captured capacities (the caller then runs the step
+        eagerly: nothing but static graph memory has been touched)."""
+        host, self._pending_targets = self._pending_targets, None
+        tarr, tmeta = self.spec.target_arrays(host, self.caps)
+        arr = dict(self._arr)
+        arr.update(tarr)
+        self.arena.check(arr)
+        self._arr = arr
+        self.arena.upload(arr, only=list(tarr))
+        self.tplan.sizes, self.tplan.sumT = tmeta["sizes"], tmeta["sumT"]
 
     def load_prepared(self, prep):
         """load_batch for a batch whose host half was done elsewhere (loader.HostPipeline.prepare in a worker process):
@@ -491,8 +519,17 @@ class SplitGraphedStep(GraphedStep):
         raise RuntimeError("SplitGraphedStep is replayed in three parts (forward_replay / criterion_replay / backward_replay)")
 
     def forward_replay(self):
-        if self._param_ptrs() != self._ptrs:
-            raise RuntimeError("SplitGraphedStep: a parameter or the gradient buffer moved after capture")
+        # the 273-address comparison of GraphedStep.run costs 0.1 ms of the caller's critical path: here it runs when the
+        # model says tensors may have moved (MESM._apply / a re-flattening bump _addr_gen), and the two flat buffers'
+        # addresses are compared every time
+        m = self.model
+        gen = m.__dict__.get("_addr_gen", 0)
+        fp = m._flat_params
+        quick = (fp.data_ptr() if fp is not None else 0, m.gradbuf().flat.data_ptr())
+        if gen != getattr(self, "_addr_gen", None) or quick != getattr(self, "_quick_ptrs", None):
+            if self._param_ptrs() != self._ptrs:
+                raise RuntimeError("SplitGraphedStep: a parameter or the gradient buffer moved after capture")
+            self._addr_gen, self._quick_ptrs = gen, quick
         self.g_fwd.replay()
         return self.out
 

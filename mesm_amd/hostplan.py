@@ -50,6 +50,8 @@ class HostSpec:
     def words_mask(self, host):
         """the collate mask for token ids (cut like model.py:114-116), the non-zero rows of pre-extracted features
         (post_process_text, model.py:145-152)"""
+        if host.get("_words_mask") is not None:  # formed on the device with the arithmetic below (autograph._Fetch)
+            return host["_words_mask"]
         w = host["words_id"]
         if w.dim() != 3:
             return host["words_mask"][:, :self.max_words_l]
@@ -91,11 +93,16 @@ class HostSpec:
         return dict(caps)
 
     # ---- everything small the captured step reads
-    def host_arrays(self, host, groups, caps, n_real, neg_index, masked_words, big):
+    def target_arrays(self, host, caps):
+        """the criterion's half: {"t." + name: array}, meta (TargetPlan.arrays)"""
+        from .criterion import TargetPlan
+        tarr, tmeta = TargetPlan.arrays(host, self.multi_clip, self.gamma, T_cap=caps.get("T"), Tmax_cap=caps.get("Tmax"))
+        return {"t." + k: v for k, v in tarr.items()}, tmeta
+
+    def host_arrays(self, host, groups, caps, n_real, neg_index, masked_words, big, targets=True):
         """{name: numpy array}: "p." the forward's plan, "t." the criterion's target plan, "b." batch tensors of at
         most `big` bytes; plus the two metas and the word mask.  neg_index / masked_words None: drawn here (the caller
         is the training process); workers pass placeholders and the training process draws (GraphedStep.redraw)."""
-        from .criterion import TargetPlan
         wm = self.words_mask(host)
         P = host["video_mask"].shape[0]
         if wm.shape[0] < P:  # a big feature tensor that arrived with its real rows only (batching.pad_pairs)
@@ -105,11 +112,17 @@ class HostSpec:
                                        neg_index=neg_index, masked_words=masked_words,
                                        words_weight=host.get("words_weight"), Lc_cap=caps.get("Lc"),
                                        Lss_cap=caps.get("Lss"), M_cap=caps.get("M"), n_valid=n_real)
-        tarr, tmeta = TargetPlan.arrays(host, self.multi_clip, self.gamma, T_cap=caps.get("T"), Tmax_cap=caps.get("Tmax"))
         arr = {"p." + k: v for k, v in parr.items()}
-        arr.update({"t." + k: v for k, v in tarr.items()})
         for k, v in host.items():
             # (num_clips has one entry per GROUP and is only read on the host: the step reads the plans)
-            if torch.is_tensor(v) and k not in ("words_weight", "num_clips") and v.numel() * v.element_size() <= big:
+            if torch.is_tensor(v) and k not in ("words_weight", "num_clips") and not k.startswith("_") and not v.is_cuda \
+                    and v.numel() * v.element_size() <= big:
                 arr["b." + k] = v.numpy()
+        # the criterion's arrays LAST: they sit together at the end of the arena, so a caller that replays the forward
+        # before the criterion (autograph.py) can build and upload them while the forward graph already runs
+        # (targets=False: the caller does that itself, target_arrays)
+        tmeta = None
+        if targets:
+            tarr, tmeta = self.target_arrays(host, caps)
+            arr.update(tarr)
         return arr, pmeta, tmeta, wm
