@@ -263,19 +263,20 @@ def check(rc, what):
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
-_dev_index = None
+_get_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
 def set_device_index(idx):
-    """the device the step runs on (MESM._begin): lets stream_ptr() skip torch.cuda.current_stream()'s device lookup and
-    Stream object (1.9 ms per eager step over its ~1,900 launches)"""
-    global _dev_index
-    _dev_index = None if idx is None else int(idx)
+    """(kept for callers of round 5: the device is no longer remembered -- ADVICE r5: a sticky index sent the launches of a
+    second model on another device, or of direct kernel calls after a forward, to the wrong device's stream)"""
 
 
 def stream_ptr():
-    if _raw_stream is not None and _dev_index is not None:
-        return ctypes.c_void_p(_raw_stream(_dev_index))
+    """the raw HIP stream torch would launch on right now: the CURRENT device's current stream, through the two C entry
+    points (torch.cuda.current_stream() builds a Stream object and looks the device up in Python: 1.9 ms per eager step
+    over its ~1,900 launches; these two calls cost a third of a microsecond)"""
+    if _raw_stream is not None and _get_device is not None:
+        return ctypes.c_void_p(_raw_stream(_get_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

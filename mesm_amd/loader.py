@@ -135,6 +135,21 @@ class PinnedRing:
                 self.pinned = int(rc) == 0
             except Exception:  # a runtime without host registration: the ring still works, copies are synchronous
                 self.pinned = False
+        if self.pinned:
+            # the registration ends before the shared buffer is freed, in the process that made it
+            import os
+            import weakref
+            weakref.finalize(self, PinnedRing._unregister, self.buf.data_ptr(), os.getpid())
+
+    @staticmethod
+    def _unregister(addr, pid):
+        import os
+        if os.getpid() != pid:  # forked workers inherit the object, not the registration
+            return
+        try:
+            torch.cuda.cudart().cudaHostUnregister(addr)
+        except Exception:
+            pass
 
     def put(self, slot, tensors):
         off, desc = 0, {}
@@ -190,7 +205,13 @@ H2D_EVENTS = collections.deque(maxlen=16)
 
 
 class PreparedLoader:
-    """iterable over prepared batches; with a ring, `big` comes back as views of the ring's slots"""
+    """iterable over prepared batches; with a ring, `big` comes back as views of the ring's slots.
+
+    CONTRACT of the ring path: the `big` views of a prepared batch are valid UNTIL THE NEXT BATCH IS FETCHED
+    from this iterator -- the fetch hands the slot's index on to a worker once the device copies that read it have
+    finished (the events GraphedStep._stage_big records, at most `keep` per batch: video_feat and words_id).  Consume a
+    batch (StepCache.run_prepared) before fetching the next one; `list(loader)` or a look-ahead queue of prepared batches
+    would hold views of slots that workers overwrite.  Without a ring (ring=False) batches own their memory."""
 
     def __init__(self, loader, ring, keep=2):
         self.loader, self.ring, self.keep = loader, ring, keep
