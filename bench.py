@@ -654,6 +654,23 @@ def main():
                 loss.backward()
             torch.cuda.synchronize()
             uc_fb = (time.perf_counter() - t1) / opt.steps * 1e3
+            # the same loop on a batch whose collate kept the host copies of its small tensors (batching.attach_host_side: one
+            # line in the DataLoader's collate_fn): the forward needs no transfer back and no synchronisation
+            from mesm_amd import batching as _bt
+            hbatch = synthetic.to_device(_bt.attach_host_side(dict(batch_cpu)), dev)
+            keep = batch
+            try:
+                batch = hbatch
+                for _ in range(3):
+                    loop_body()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(opt.steps):
+                    loop_body()
+                torch.cuda.synchronize()
+                uc_host = (time.perf_counter() - t1) / opt.steps * 1e3
+            finally:
+                batch = keep
             # the same loop with ONE more changed line: `optimizer = mesm_amd.build_optimizer(opt, model)` (FlatAdamW: global-
             # norm clip + AdamW over the flat buffers, two launches) whose step(grad_clip=...) replaces lines 70-72
             from mesm_amd.optim import FlatAdamW
@@ -678,6 +695,7 @@ def main():
             a = model._auto
             unchanged = {"ms_per_step": uc, "ms_per_step_with_the_loops_float_of_the_loss": uc_sync,
                          "with_this_builds_optimizer_step_instead_of_clip_and_torch_adamw_ms": uc_flat,
+                         "with_host_side_kept_by_the_collate_ms": uc_host,
                          "fwd_criterion_zero_grad_backward_only_ms": uc_fb,
                          "pairs_per_s": n_pairs / (uc * 1e-3), "replayed": outputs._auto_step is not None,
                          "eager_visits": a.eager, "captures": a.captures, "replays": a.replays,

@@ -147,6 +147,7 @@ class AutoGraph:
         self.captures = self.replays = self.eager = 0
         self.fetch = _Fetch()
         self.spec = None
+        self.host_side = 0    # forwards served from the collate's host copies (batch["_host"]) instead of a fetch
 
     # ------------------------------------------------------------------ configuration
     def configure(self, enabled=None, pad=None, pairs=None, max_graphs=None):
@@ -168,8 +169,45 @@ class AutoGraph:
                 self.seen.clear()
 
     # ------------------------------------------------------------------ forward
+    @staticmethod
+    def _with_host_side(batch, spec):
+        """the batch with its small tensors replaced by the host copies the collate kept (batching.attach_host_side) -> a dict
+        that serves both as the shaped batch (big device tensors) and as the host half (everything else), or None when
+        `_host` is absent / does not mirror the batch"""
+        hs = batch.get("_host")
+        if not isinstance(hs, dict):
+            return None
+        work = {}
+        for k, v in batch.items():
+            if k == "_host":
+                continue
+            if torch.is_tensor(v) and v.is_cuda and k in hs:
+                h = hs[k]
+                if not torch.is_tensor(h) or h.is_cuda or tuple(h.shape) != tuple(v.shape) or h.dtype != v.dtype:
+                    return None
+                work[k] = h
+            elif isinstance(v, list) and v and isinstance(v[0], dict) and k in hs:
+                if len(hs[k]) != len(v):
+                    return None
+                work[k] = hs[k]
+            elif torch.is_tensor(v) and v.is_cuda and v.numel() * v.element_size() <= (1 << 20):
+                return None  # a small device tensor the collate did not keep: fetch instead
+            else:
+                work[k] = v
+        w = batch["words_id"]
+        if w.dim() == 3:
+            m = hs.get("_words_mask_norm" if spec.normalize_txt else "_words_mask_raw")
+            if m is None or tuple(m.shape) != tuple(w.shape[:2]):
+                return None
+            work["_words_mask"] = m
+        return work
+
     def _shaped(self, batch):
         """the batch padded like StepCache pads it (device tensors stay on the device)"""
+        if self.pad is not None and "_words_mask" in batch:
+            from .graphed import StepCache
+            batch = dict(batch)
+            batch["_words_mask"] = StepCache._pad_dim1(batch["_words_mask"], self.pad[1])
         if self.pad is not None:
             from .graphed import StepCache
             Lv, Lw = self.pad
@@ -219,14 +257,20 @@ class AutoGraph:
         self.gen += 1
         crit = self.crit() if self.crit is not None else None
         try:
-            shaped = self._shaped(batch)
+            host = None
+            if crit is not None and (self.spec is None or self.spec.dataset_name != dataset_name):
+                from .hostplan import HostSpec
+                self.spec = HostSpec.from_model(model, crit, dataset_name)
+            work = self._with_host_side(batch, self.spec) if crit is not None else None
+            if work is not None:
+                # the collate kept the host copies: no transfer back, no synchronisation in front of the forward launch
+                shaped = host = self._shaped(work)
+                self.host_side += 1
+            else:
+                shaped = self._shaped({k: v for k, v in batch.items() if k != "_host"})
             if shaped is None:
                 return None
-            host = None
-            if crit is not None:
-                if self.spec is None or self.spec.dataset_name != dataset_name:
-                    from .hostplan import HostSpec
-                    self.spec = HostSpec.from_model(model, crit, dataset_name)
+            if crit is not None and host is None:
                 from .graphed import GraphedStep
                 host = self.fetch(shaped, self.spec, GraphedStep.BIG)
             key, gcap = self._key(model, shaped, dataset_name, None if host is None else host["num_clips"])

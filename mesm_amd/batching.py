@@ -127,6 +127,39 @@ def collate_qvh(batch):
     return out
 
 
+HOST_SIDE_BIG = 1 << 20  # (= graphed.GraphedStep.BIG: tensors above 1 MiB are features, not plan inputs)
+
+
+def attach_host_side(batch):
+    """Keep the HOST copies of everything small in a collated batch under `batch["_host"]` (call it at the end of the collate, in
+    the loader worker: `collate_fn=lambda items: attach_host_side(collate_qvh(items))`).  `prepare_batch_input` -- the reference's
+    (dataset/base.py:358-384) or this module's -- moves the batch's tensors to the device and drops the host tensors; the step's
+    index plans, flattened targets and host-RNG draws are host arithmetic on the masks, labels and target windows, so a model
+    driven through the unchanged `model(**batch)` call (mesm_amd/autograph.py) otherwise has to fetch them back with a device
+    synchronisation in front of every forward.  `_host` is a plain dict: prepare_batch_input leaves it alone and
+    `model(**batch)` hands it through; with it the forward launch needs no synchronisation and the host runs ahead of the device.
+    Contents: every tensor of at most 1 MiB, the per-pair target lists, and -- for pre-extracted word features -- the two forms of
+    the word-validity mask (hostplan.HostSpec.words_mask with and without the text normalisation)."""
+    import numpy as np
+    host = {}
+    for k, v in batch.items():
+        if torch.is_tensor(v) and v.numel() * v.element_size() <= HOST_SIDE_BIG:
+            host[k] = v
+        elif isinstance(v, list) and v and isinstance(v[0], dict):
+            host[k] = [dict(d) for d in v]
+    w = batch.get("words_id")
+    if torch.is_tensor(w) and w.dim() == 3:
+        a = w.numpy()
+        n = np.maximum(np.sqrt((a * a).sum(-1, keepdims=True)), 1e-5)
+        host["_words_mask_norm"] = torch.from_numpy((a / n).sum(-1) != 0)
+        host["_words_mask_raw"] = torch.from_numpy(a.sum(-1) != 0)
+    if "moment" in batch and "norm_span" not in batch:  # what prepare_batch_input derives on the device (base.py:380-384)
+        host["norm_moment"] = batch["moment"] / batch["duration"].unsqueeze(1)
+        host["norm_span"] = span_xx_to_cxw(host["norm_moment"])
+    batch["_host"] = host
+    return batch
+
+
 def span_xx_to_cxw(xx):
     return torch.stack([xx.sum(-1) * 0.5, xx[..., 1] - xx[..., 0]], dim=-1)
 

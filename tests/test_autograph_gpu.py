@@ -244,3 +244,44 @@ def test_padded_buckets_serve_changing_pair_counts(deterministic_forward):
         assert abs(total_e - float(loss)) < 1e-5 * max(1.0, abs(total_e))
         assert float((flat_e - flat_g).norm()) / max(float(flat_e.norm()), 1e-6) < 1e-4
     assert auto.captures == 1 and auto.replays == 2
+
+
+@pytest.mark.parametrize("workload", ["C3a", "C2"])
+def test_host_side_kept_by_the_collate_serves_the_plans_without_a_fetch(workload, deterministic_forward):
+    """batching.attach_host_side at the end of the collate: `batch["_host"]` survives prepare_batch_input and the **batch call,
+    the replayed forward builds its plans from it (no transfer back, no synchronisation) and equals the eager step"""
+    from mesm_amd import batching, synthetic
+    args, model, crit = _build(workload)
+    name = args.dataset_name
+    auto = model._auto
+    for i in range(3):
+        cpu = batching.attach_host_side(synthetic.workload_batch(workload, seed=70 + i, ragged=True))
+        batch = synthetic.to_device(cpu, dev())
+        assert isinstance(batch["_host"], dict) and not batch["_host"]["video_mask"].is_cuda
+        if "norm_span" not in batch:  # prepare_batch_input's derived targets (dataset/base.py:380-384)
+            batch["norm_moment"] = batch["moment"] / batch["duration"].unsqueeze(1)
+            batch["norm_span"] = batching.span_xx_to_cxw(batch["norm_moment"])
+        out = model(**batch, dataset_name=name, is_training=True)
+        _, loss = crit(out, batch, is_training=True)
+        model.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.cuda.synchronize()
+        if i == 0:
+            continue
+        assert out._auto_step is not None
+        flat_g = model.gradbuf().flat.clone()
+        neg, mw = out._auto_step._draws
+        plain = {k: v for k, v in batch.items() if k != "_host"}
+        _, _, total_e, flat_e = _eager_on(model, crit, plain, name, neg, mw)
+        assert abs(total_e - float(loss)) < 1e-5 * max(1.0, abs(total_e))
+        assert float((flat_e - flat_g).norm()) / max(float(flat_e.norm()), 1e-6) < 1e-4
+    assert auto.replays == 2 and auto.host_side == 2
+    # a `_host` that does not mirror the batch is not trusted: the fetch path serves the step
+    cpu = batching.attach_host_side(synthetic.workload_batch(workload, seed=80, ragged=True))
+    batch = synthetic.to_device(cpu, dev())
+    del batch["_host"]["video_mask"]
+    if "norm_span" not in batch:
+        batch["norm_moment"] = batch["moment"] / batch["duration"].unsqueeze(1)
+        batch["norm_span"] = batching.span_xx_to_cxw(batch["norm_moment"])
+    out = model(**batch, dataset_name=name, is_training=True)
+    assert out._auto_step is not None and auto.host_side == 2
