@@ -153,8 +153,9 @@ int mesm_gemm_flush_side(void* stream);
 /* Tuning tools only: the dispatch switches MESM_GEMM_TILE / MESM_GEMM_BF16X are read from the environment ONCE, when the
  * library is loaded; this entry changes them between calls of one process (a negative value keeps the current one). */
 int mesm_gemm_set_switches(int32_t force_tile, int32_t bf16x);
-/* The GEMM arithmetic in force: 6 = f32 products as six bf16 matrix products over exactly split operands (the default),
- * 3 = experimental two-term split, 0 = every product on the f32 matrix instruction (what bench.py reports as `dtype`). */
+/* The GEMM arithmetic in force: 2 = f32 products as THREE fp16 matrix products over operands split into two fp16 terms under a
+ * wave-owned power-of-two scale (the default since round 6, csrc/gemm_ws.hpp), 6 = six bf16 matrix products over operands split
+ * exactly into three bf16 terms (round 4), 0 = every product on the f32 matrix instruction (what bench.py reports as `dtype`). */
 int mesm_gemm_get_bf16x(void);
 /* Forget the pending reductions without running them (error paths: their workspaces may already be released). */
 int mesm_gemm_drop_side(void);
