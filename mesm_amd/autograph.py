@@ -255,6 +255,10 @@ class AutoGraph:
         """-> AutoOutputs of a replayed forward, or None: run this forward eagerly"""
         model = self.model()
         self.gen += 1
+        if model.gradbuf().on_ready is not None:
+            # a ddp.GradReducer is hooked into the gradient buffer: its collectives belong in the one-graph step that was
+            # built WITH the reducer (GraphedStep / StepCache(reducer=...)), not in a capture made behind its back
+            return None
         crit = self.crit() if self.crit is not None else None
         try:
             host = None

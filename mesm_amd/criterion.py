@@ -28,6 +28,53 @@ def generalized_temporal_iou(a, b):
     return inter / union - (enc - union) / enc
 
 
+class _LossPack:
+    """host copy of a step's loss vector, fetched ONCE: the reference's loop reads every entry of the loss dict with float()
+    (train.py:75-77: 14 device synchronisations per step); the entries handed out below share this pack, so the first
+    float() / .item() costs one transfer + one event wait and the others are host reads"""
+    __slots__ = ("vec", "vals")
+
+    def __init__(self, vec):
+        self.vec, self.vals = vec, None
+
+    def host(self):
+        if self.vals is None:
+            v = self.vec
+            if v.is_cuda:
+                buf = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
+                buf.copy_(v, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(v.device))
+                ev.synchronize()
+                v = buf
+            self.vals = v.tolist()
+        return self.vals
+
+
+class LossEntry(torch.Tensor):
+    """one element of the loss vector: a tensor like any other (every torch operation returns a plain tensor), whose float() /
+    .item() read the shared host copy"""
+    __torch_function__ = torch._C._disabled_torch_function_impl
+
+    @staticmethod
+    def __new__(cls, t, pack, i):
+        r = torch.Tensor._make_subclass(cls, t, False)
+        r._pack, r._i = pack, i
+        return r
+
+    def item(self):
+        return self._pack.host()[self._i]
+
+    def __float__(self):
+        return float(self._pack.host()[self._i])
+
+
+def loss_entries(lv, index):
+    """{name: LossEntry} over the 1-D, gradient-free loss vector `lv`; index = {name: position}"""
+    pack = _LossPack(lv)
+    return {n: LossEntry(lv[i], pack, i) for n, i in index.items()}
+
+
 class TargetPlan:
     """Flattened targets + host-built index tensors (built once per batch, reused for the aux
     decoder layers): tgt_cxw / tgt_xx (sumT, 2), tgt_off (N+1) int32, Tmax, group_mask (N, N) bool (True where two
@@ -432,5 +479,5 @@ class Criterion(nn.Module):
         spec.wv = self._weights(wnames, device)
         total, lv = CriterionFn.apply(spec, *tensors)
         self.last_match = spec.matches
-        losses = {n: lv[i] for i, n in enumerate(names) if n not in hidden}
+        losses = loss_entries(lv, {n: i for i, n in enumerate(names) if n not in hidden})
         return losses, total

@@ -508,11 +508,11 @@ class SplitGraphedStep(GraphedStep):
                     for k, v in out.items()}
         self.total = total.detach()
         vals = list(losses.values())
-        base = vals[0]._base if vals and vals[0]._base is not None else None
-        # the loss entries are elements of ONE vector (CriterionFn): a replay hands out a copy of it, one launch
-        self.loss_vec = base.detach() if base is not None and all(v._base is base for v in vals) else None
-        self.loss_index = ({k: int(v.storage_offset() - base.storage_offset()) for k, v in losses.items()}
-                           if self.loss_vec is not None else None)
+        # the loss entries are elements of ONE vector (criterion.loss_entries): a replay hands out a copy of it, one launch
+        pack = getattr(vals[0], "_pack", None) if vals else None
+        same = pack is not None and all(getattr(v, "_pack", None) is pack for v in vals)
+        self.loss_vec = pack.vec.detach() if same else None
+        self.loss_index = {k: int(v._i) for k, v in losses.items()} if same else None
         self.losses = {k: v.detach() for k, v in losses.items()}
 
     def run(self, redraw=True):
@@ -536,8 +536,8 @@ class SplitGraphedStep(GraphedStep):
     def criterion_replay(self):
         self.g_crit.replay()
         if self.loss_vec is not None:
-            lv = self.loss_vec.clone()
-            losses = {k: lv[i] for k, i in self.loss_index.items()}
+            from .criterion import loss_entries
+            losses = loss_entries(self.loss_vec.clone(), self.loss_index)  # (float() of all entries = one transfer)
         else:
             losses = {k: v.clone() for k, v in self.losses.items()}
         return losses, self.total

@@ -117,6 +117,10 @@ def test_reference_loop_body_runs_on_graph_replays_and_equals_eager(workload, de
         assert seen["replayed"] == (i >= 1), i
         float(loss)  # train.py:75
         assert all(torch.isfinite(v).all() for v in loss_dict.values())
+        # train.py:76-77 reads every entry with float(): they share ONE host fetch (criterion.LossEntry) and equal the device values
+        for k, v in loss_dict.items():
+            assert float(v) == v.item() == float(v.clone()), k
+            assert type(v * 2.0) is torch.Tensor
     assert (auto.eager, auto.captures, auto.replays) == (1, 1, 3)
     assert float((model.flat_params() - p0).abs().max()) > 0  # the optimizer's updates went through the views
 
