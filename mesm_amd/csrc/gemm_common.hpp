@@ -171,6 +171,26 @@ __device__ __forceinline__ float staged_epilogue(const MesmGemmArgs& p, float (&
   const float bias_v = (p.bias != nullptr && first_split) ? p.bias[colc] : 0.0f;
 #endif
   const float sc = p.out_scale;
+#ifdef MESM_LN_PROBE
+  // Probe build (tools/probe/ln_stats.py): LayerNorm WITHOUT a launch of its own, the decomposition of the
+  // round-5 review -- the producing GEMM's epilogue accumulates the row statistics of its output (reserved0 == 1, below the
+  // residual add), the CONSUMING GEMM runs on the raw tensor with weights pre-scaled by gamma and normalises in its epilogue:
+  //   LN(x) W^T + b = rstd_r (x W'^T - mu_r c) + d,   W' = W diag(gamma), c = W gamma, d = W beta + b     (reserved0 == 2)
+  // stats = dslope_ws: (sum, sum of squares) per row of a D = ldaux wide tensor; c = aux (a vector here); d = bias.
+  if (p.reserved0 == 2) {
+    const float invD = 1.0f / (float)p.ldaux;
+    const float cn = p.aux[colc];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int row = rbase + RO(i);
+      row = row < p.M ? row : p.M - 1;
+      const float2 st = reinterpret_cast<const float2*>(p.dslope_ws)[row];
+      const float mu = st.x * invD;
+      const float rs = rsqrtf(fmaxf(st.y * invD - mu * mu, 0.0f) + 1e-5f);
+      t[i] = rs * (t[i] - mu * cn) + bias_v;
+    }
+  } else
+#endif
 #pragma unroll
   for (int i = 0; i < NV; ++i) t[i] = t[i] * sc + bias_v;
   if (p.pre_out != nullptr) {  // second output: the pre-activation (what the backward's e_actgrad reads as aux)
@@ -233,6 +253,22 @@ __device__ __forceinline__ float staged_epilogue(const MesmGemmArgs& p, float (&
 #pragma unroll
     for (int i = 0; i < NV; ++i) t[i] += add[i];
   }
+#ifdef MESM_LN_PROBE
+  if (p.reserved0 == 1) {  // row statistics of the finished output: 32 columns of a row sit in the 32 lanes of a half wave
+    const int lane_ = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const float v = ok[i] ? t[i] : 0.0f;
+      float s1 = add_xor16(sum_within<16>(v));
+      float s2 = add_xor16(sum_within<16>(v * v));
+      const int row = rbase + RO(i);
+      if ((lane_ & 31) == 0 && row < p.M) {
+        atomicAdd(p.dslope_ws + 2 * (int64_t)row, s1);
+        atomicAdd(p.dslope_ws + 2 * (int64_t)row + 1, s2);
+      }
+    }
+  }
+#endif
   float* cp = p.C + ((int64_t)rbase * p.ldc + col);
   if (p.accumulate == 2) {
 #pragma unroll
