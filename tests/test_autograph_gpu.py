@@ -71,13 +71,16 @@ def _eager_on(model, crit, batch, name, neg, mw):
     return out, losses, float(total.detach()), model.gradbuf().flat.clone()
 
 
-@pytest.mark.parametrize("workload", ["C3a", "C2"])
-def test_reference_loop_body_runs_on_graph_replays_and_equals_eager(workload, deterministic_forward):
-    from mesm_amd import synthetic
+@pytest.mark.parametrize("workload,factory", [("C3a", "torch"), ("C2", "torch"), ("C3a", "this build")])
+def test_reference_loop_body_runs_on_graph_replays_and_equals_eager(workload, factory, deterministic_forward):
+    from mesm_amd import build_optimizer, synthetic
     from mesm_amd.autograph import AutoOutputs
     args, model, crit = _build(workload)
-    opt = argparse_like(args, grad_clip=0.1)
-    optimizer = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-4)  # the reference's class (runner.py:348-352)
+    opt = argparse_like(args, grad_clip=0.1, lr=1e-4, weight_decay=1e-4, lr_drop=400, gamma=0.1)
+    if factory == "torch":   # the reference's own class (runner.py:348-352)
+        optimizer = torch.optim.AdamW(model.parameters(), lr=1e-4, weight_decay=1e-4)
+    else:                    # what train.py:115 gets when all three factories of its lines 17-18 come from this build
+        optimizer, _ = build_optimizer(opt, model)
     auto = model._auto
     name = args.dataset_name
     seen = {}
