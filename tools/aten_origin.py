@@ -1,6 +1,7 @@
 """Which Python lines launch the ATen (non-library) kernels of one eager training step: torch profiler
 with stacks, grouped by op and innermost mesm_amd frame.  usage: aten_origin.py [workload]"""
 import collections, os, sys
+os.environ.setdefault("MESM_AUTOGRAPH", "0")  # this tool looks at the EAGER step (autograph.py would replay graphs behind these calls)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch

@@ -2,6 +2,7 @@
 forward kernels grouped by model region (record_function scopes set by MESM_SCOPES=1), backward
 kernels grouped by autograd node.  Usage: python tools/count_kernels.py [workload]"""
 import collections, os, sys
+os.environ.setdefault("MESM_AUTOGRAPH", "0")  # this tool looks at the EAGER step (autograph.py would replay graphs behind these calls)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["MESM_SCOPES"] = "1"
 import torch

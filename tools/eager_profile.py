@@ -2,6 +2,7 @@
 pays): cProfile over 10 steps of C3a, top functions by own time and by cumulative time.
 usage: python tools/eager_profile.py [workload] [n]"""
 import cProfile, os, pstats, sys, time
+os.environ.setdefault("MESM_AUTOGRAPH", "0")  # this tool looks at the EAGER step (autograph.py would replay graphs behind these calls)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch

@@ -1,6 +1,7 @@
 """Census of the GEMM launches of one training step (shape, layouts, fusions), each config timed
 alone in a captured graph chain (8 rotating operand sets), and the projected total."""
 import collections, os, sys, time
+os.environ.setdefault("MESM_AUTOGRAPH", "0")  # this tool looks at the EAGER step (autograph.py would replay graphs behind these calls)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch

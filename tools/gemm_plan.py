@@ -2,6 +2,7 @@
 32 x 32 one, which are launched alone), and every single-problem call: python tools/gemm_plan.py [workload] 2> plan.txt
 (the library prints one `[gemm plan]` line per mesm_gemm_group call when MESM_GEMM_PLAN_LOG is set)"""
 import os, sys
+os.environ.setdefault("MESM_AUTOGRAPH", "0")  # this tool looks at the EAGER step (autograph.py would replay graphs behind these calls)
 os.environ.setdefault("MESM_GEMM_PLAN_LOG", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
