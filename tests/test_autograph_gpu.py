@@ -292,3 +292,26 @@ def test_host_side_kept_by_the_collate_serves_the_plans_without_a_fetch(workload
         batch["norm_span"] = batching.span_xx_to_cxw(batch["norm_moment"])
     out = model(**batch, dataset_name=name, is_training=True)
     assert out._auto_step is not None and auto.host_side == 2
+
+
+def test_prepare_batch_input_copies_page_locked_batches_directly_and_equals_the_packed_path():
+    """batching.prepare_batch_input: a DataLoader(pin_memory=True) batch goes to the device by asynchronous per-tensor copies (the
+    reference's own way, dataset/base.py:358-384), a pageable one through one packed transfer: same tensors either way, words_weight
+    stays on the host, `_host` untouched"""
+    from mesm_amd import batching, synthetic
+    cpu = batching.attach_host_side(synthetic.workload_batch("C3b", seed=5, ragged=True))
+    pin = lambda v: v.pin_memory() if torch.is_tensor(v) else ([{kk: vv.pin_memory() for kk, vv in d.items()} for d in v]
+                                                               if isinstance(v, list) and v and isinstance(v[0], dict) else v)
+    pinned = {k: (pin(v) if k != "_host" else v) for k, v in cpu.items()}
+    a = batching.prepare_batch_input(dict(cpu), dev())
+    b = batching.prepare_batch_input(dict(pinned), dev(), non_blocking=True)
+    torch.cuda.synchronize()
+    assert set(a) == set(b)
+    for k in a:
+        if k == "_host":
+            assert a[k] is cpu["_host"] and b[k] is cpu["_host"]
+        elif torch.is_tensor(a[k]):
+            assert a[k].device == b[k].device and torch.equal(a[k], b[k]), k
+            assert a[k].is_cuda == (k != "words_weight"), k
+        elif isinstance(a[k], list) and a[k] and isinstance(a[k][0], dict):
+            assert all(torch.equal(x[kk], y[kk]) and x[kk].is_cuda for x, y in zip(a[k], b[k]) for kk in x), k

@@ -115,3 +115,29 @@ def test_loader_workers_hand_feature_tensors_over_through_the_shared_ring():
             assert prep["key"] == ref["key"] and prep["groups"] == ref["groups"]
             got += 1
         assert got == len(batches)
+
+
+@pytest.mark.parametrize("kind", ["base", "qvh"])
+def test_host_side_kept_by_the_collate_survives_prepare_batch_input(kind):
+    """batching.attach_host_side: the host copies of everything small ride under batch["_host"], a plain dict that
+    prepare_batch_input (dataset/base.py:358-384 semantics: tensors and the two target lists move, everything else stays) leaves
+    alone; its entries are the batch's own values, and for tensor-target datasets the derived norm_moment / norm_span are there too."""
+    from mesm_amd import batching as B
+    fn = B.collate if kind == "base" else B.collate_qvh
+    out = B.attach_host_side(fn(group_samples(kind, META[kind + ".seed"])))
+    host = out["_host"]
+    assert isinstance(host, dict) and "video_mask" in host and "num_clips" in host
+    for k, v in host.items():
+        if torch.is_tensor(v) and k in out and torch.is_tensor(out[k]):
+            assert v.numel() * v.element_size() <= B.HOST_SIDE_BIG and torch.equal(v, out[k]), k
+    assert "video_feat" not in host or out["video_feat"].numel() * out["video_feat"].element_size() <= B.HOST_SIDE_BIG
+    prep = B.prepare_batch_input(dict(out), torch.device("cpu"))
+    assert prep["_host"] is host
+    check(kind + ".prep.", {k: v for k, v in prep.items() if k != "_host"})
+    if kind == "base":
+        assert torch.equal(host["norm_moment"], prep["norm_moment"]) and torch.equal(host["norm_span"], prep["norm_span"])
+    else:
+        assert [torch.equal(a["spans"], b["spans"]) for a, b in zip(host["norm_span"], prep["norm_span"])]
+    w = out["words_id"]
+    if w.dim() == 3:
+        assert host["_words_mask_raw"].shape == w.shape[:2] and host["_words_mask_norm"].dtype == torch.bool
