@@ -412,6 +412,30 @@ int mesm_ref_update_bwd(const float* out, const float* ref, const float* dout, f
  * backward dp[j] += out[0, j] (1 - out[0, j]) sum_n dout[n, j] into the parameter's gradient view (one workgroup). */
 int mesm_ref_init_fwd(const float* p, float* out, int32_t N, int32_t QC, void* stream);
 int mesm_ref_init_bwd(const float* out, const float* dout, float* dp, int32_t N, int32_t QC, void* stream);
+/*
+ * The reference points at a decoder layer boundary as ONE launch (transformer.py:343-397; round 6): the refined point,
+ * its sine embedding (the next layer's ref_point_head input) and that embedding modulated by query_scale / ref_anchor_head
+ * (the next layer's ca_qpos_sine_proj input) were ref_update | query_sine | qsine_scale, in front of layer 0
+ * ref_init | query_sine.  R = pairs * queries rows, one wave per row, results bit-identical to the separate kernels.
+ *   fwd   p != NULL (INIT): ref_out[r, c] = sigmoid(p[(2 r + c) mod QC]); else (NEXT): sigmoid(delta + inverse_sigmoid(prev)).
+ *         qsine (R, D) = gen_sineembed_for_position(ref_out); anchor != NULL: qscaled (R, D) = qsine * scale *
+ *         sigmoid(anchor[r]) / ref_out[r, 1] (scale may be NULL = 1).
+ *   bwd   (NEXT; the reference detaches the refined point before embedding it, transformer.py:397) ddelta / dprev from
+ *         dref_out (NULL = zero; dprev may be NULL), dscale / danchor from dqscaled (NULL = zero; dscale may be NULL);
+ *         ddelta == NULL or danchor == NULL skips that half.
+ *   init_sine_bwd   dp[j] += ref[j] (1 - ref[j]) sum_n (da + db + dc + query_sine_bwd(dqsine + dqsine2))[n, j]: the
+ *         gradients of the initial points' consumers (stacked output, width modulation, first refinement) and of the
+ *         embedding's (ref_point_head, modulation) are summed in the kernel; any may be NULL.
+ *         One workgroup, deterministic; N * QC / 2 <= 4096 rows.
+ */
+int mesm_ref_step_fwd(const float* p, int32_t QC, const float* delta, const float* prev, float eps,
+                      const float* scale, const float* anchor, float* ref_out, float* qsine, float* qscaled,
+                      int64_t R, int32_t D, void* stream);
+int mesm_ref_step_bwd(const float* ref, const float* prev, const float* dref_out, float eps, const float* qsine,
+                      const float* scale, const float* anchor, const float* dqscaled, float* ddelta, float* dprev,
+                      float* dscale, float* danchor, int64_t R, int32_t D, void* stream);
+int mesm_ref_init_sine_bwd(const float* ref, const float* da, const float* db, const float* dc, const float* dqsine,
+                           const float* dqsine2, float* dp, int32_t N, int32_t QC, int32_t D, void* stream);
 int mesm_qsine_scale_fwd(const float* qsine, const float* scale, const float* anchor,
                          const float* ref, float* out, int64_t R, int32_t D, void* stream);
 int mesm_qsine_scale_bwd(const float* qsine, const float* scale, const float* anchor,

@@ -170,6 +170,9 @@ PROTOTYPES = {
     "mesm_ref_update_bwd": (ctypes.c_int, [c_ptr] * 5 + [_i64, _f32, c_ptr]),
     "mesm_ref_init_fwd": (ctypes.c_int, [c_ptr, c_ptr, _i32, _i32, c_ptr]),
     "mesm_ref_init_bwd": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, _i32, _i32, c_ptr]),
+    "mesm_ref_step_fwd": (ctypes.c_int, [c_ptr, _i32, c_ptr, c_ptr, _f32] + [c_ptr] * 5 + [_i64, _i32, c_ptr]),
+    "mesm_ref_step_bwd": (ctypes.c_int, [c_ptr] * 3 + [_f32] + [c_ptr] * 8 + [_i64, _i32, c_ptr]),
+    "mesm_ref_init_sine_bwd": (ctypes.c_int, [c_ptr] * 7 + [_i32, _i32, _i32, c_ptr]),
     "mesm_qsine_scale_fwd": (ctypes.c_int, [c_ptr] * 5 + [_i64, _i32, c_ptr]),
     "mesm_qsine_scale_bwd": (ctypes.c_int, [c_ptr] * 9 + [_i64, _i32, c_ptr]),
     "mesm_act_dropout": (ctypes.c_int, [c_ptr, c_ptr, _i64, _i32, c_ptr, _f32, _u32, c_ptr, c_ptr]),

@@ -248,6 +248,143 @@ __global__ __launch_bounds__(256) void qsine_scale_bwd_kernel(
   }
 }
 
+// ---- the decoder's reference points at a layer boundary, ONE launch (transformer.py:343-397) ----
+// What the loop does between two decoder layers is a chain of tiny dependent tensors -- the refined reference point
+// (n, nq, 2), its sine embedding (the next layer's ref_point_head input) and that embedding modulated by the
+// query_scale / ref_anchor_head outputs (the next layer's ca_qpos_sine_proj input) -- which as kernels of their own
+// (ref_update | query_sine | qsine_scale; in front of layer 0: ref_init | query_sine) cost a ~4.7 us launch each.
+//   INIT (p):     ref[r, c] = sigmoid(p[(r % Q) * 2 + c])                                    r = pair * Q + query
+//   NEXT (delta): ref[r, c] = sigmoid(delta[r, c] + inverse_sigmoid(prev[r, c]))
+//   qsine[r, :]   = gen_sineembed_for_position(ref[r, :])                       (transformer.py:43-59)
+//   qscaled[r, :] = qsine[r, :] * scale[r, :] * sigmoid(anchor[r]) / ref[r, 1]  (transformer.py:366-376; when anchor)
+// Same expressions as the separate kernels above (bit-identical results).  One wave per row.
+__global__ __launch_bounds__(256) void ref_step_fwd_kernel(const float* __restrict__ p, int QC,
+                                                          const float* __restrict__ delta,
+                                                          const float* __restrict__ prev, float eps,
+                                                          const float* __restrict__ scale,
+                                                          const float* __restrict__ anchor, float* __restrict__ ref_out,
+                                                          float* __restrict__ qsine, float* __restrict__ qscaled,
+                                                          int64_t R, int D) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  float rc[2];
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    if (p) {
+      rc[c] = 1.0f / (1.0f + expf(-p[(r * 2 + c) % QC]));
+    } else {
+      float d;
+      const float t = delta[r * 2 + c] + inv_sigmoid(prev[r * 2 + c], eps, d);
+      rc[c] = 1.0f / (1.0f + expf(-t));
+    }
+  }
+  if (lane < 2) ref_out[r * 2 + lane] = lane ? rc[1] : rc[0];
+  const float f = anchor ? (1.0f / (1.0f + expf(-anchor[r]))) / rc[1] : 0.0f;
+  const int half = D / 2;
+  for (int i = lane; i < D; i += 64) {
+    const int which = i >= half;
+    const int ii = which ? i - half : i;
+    const float e = (float)(2 * (ii / 2)) / (float)half;
+    const float dim_t = powf(10000.0f, e);
+    const float v = (which ? rc[1] : rc[0]) * TWO_PI_F / dim_t;
+    const float q = (ii & 1) ? cosf(v) : sinf(v);
+    qsine[r * D + i] = q;
+    if (anchor) qscaled[r * D + i] = q * (scale ? scale[r * D + i] : 1.0f) * f;
+  }
+}
+
+// NEXT backward: d delta / d prev from d ref (the refined point is detached before the sine embedding is taken:
+// nothing reaches it through qsine / qscaled), d scale / d anchor from d qscaled.  Either gradient may be absent.
+__global__ __launch_bounds__(256) void ref_step_bwd_kernel(
+    const float* __restrict__ ref, const float* __restrict__ prev, const float* __restrict__ dref_out, float eps,
+    const float* __restrict__ qsine, const float* __restrict__ scale, const float* __restrict__ anchor,
+    const float* __restrict__ dqscaled, float* __restrict__ ddelta, float* __restrict__ dprev,
+    float* __restrict__ dscale, float* __restrict__ danchor, int64_t R, int D) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  if (ddelta && lane < 2) {
+    const int64_t i = r * 2 + lane;
+    const float s = ref[i];
+    const float dpre = dref_out ? dref_out[i] * s * (1.0f - s) : 0.0f;
+    float d;
+    inv_sigmoid(prev[i], eps, d);
+    ddelta[i] = dpre;
+    if (dprev) dprev[i] = dpre * d;
+  }
+  if (danchor) {
+    const float sg = 1.0f / (1.0f + expf(-anchor[r]));
+    const float w = ref[r * 2 + 1];
+    const float f = sg / w;
+    float df = 0.0f;
+    if (dqscaled) {
+      for (int c = lane; c < D; c += 64) {
+        const float q = qsine[r * D + c], g = dqscaled[r * D + c];
+        const float sc = scale ? scale[r * D + c] : 1.0f;
+        if (dscale) dscale[r * D + c] = g * q * f;
+        df += g * q * sc;
+      }
+      df = wave_sum(df);
+    } else if (dscale) {
+      for (int c = lane; c < D; c += 64) dscale[r * D + c] = 0.0f;
+    }
+    if (lane == 0) danchor[r] = df * sg * (1.0f - sg) / w;
+  }
+}
+
+// INIT backward: dp[j] += s (1 - s) sum_n (d ref_a + d ref_b + d ref_c + query_sine_bwd(d qsine + d qsine2))[n, j] -- the
+// initial reference points have three consumers besides their sine embedding (the stacked output, the layer-0 width
+// modulation, the first refinement) and the embedding has two (ref_point_head, the modulation); their gradients are
+// summed HERE instead of by element-wise launches of the autograd engine.
+// One workgroup of 16 waves: per-row terms into LDS, then every (query, coordinate) sums its pairs in order
+// (deterministic, like ref_init_bwd).  R * 2 floats of LDS.
+constexpr int RIS_MAX_ROWS = 4096;
+__global__ __launch_bounds__(1024) void ref_init_sine_bwd_kernel(
+    const float* __restrict__ ref, const float* __restrict__ da, const float* __restrict__ db,
+    const float* __restrict__ dc, const float* __restrict__ dqsine, const float* __restrict__ dqsine2,
+    float* __restrict__ dp, int N, int QC, int D) {
+  __shared__ float part[RIS_MAX_ROWS * 2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int R = N * (QC / 2);
+  const int half = D / 2;
+  for (int r = wave; r < R; r += 16) {
+    float g0 = 0.0f, g1 = 0.0f;
+    if (dqsine || dqsine2) {
+      for (int i = lane; i < D; i += 64) {
+        const int which = i >= half;
+        const int ii = which ? i - half : i;
+        const float e = (float)(2 * (ii / 2)) / (float)half;
+        const float dim_t = powf(10000.0f, e);
+        const float x = ref[r * 2 + which] * TWO_PI_F;
+        const float v = x / dim_t;
+        const float dvdr = TWO_PI_F / dim_t;
+        const float d = (ii & 1) ? -sinf(v) : cosf(v);
+        const float go = (dqsine ? dqsine[(int64_t)r * D + i] : 0.0f) + (dqsine2 ? dqsine2[(int64_t)r * D + i] : 0.0f);
+        const float g = go * d * dvdr;
+        if (which) g1 += g; else g0 += g;
+      }
+      g0 = wave_sum(g0);
+      g1 = wave_sum(g1);
+    }
+    if (lane < 2) {
+      float g = lane ? g1 : g0;
+      const int i = r * 2 + lane;
+      if (da) g += da[i];
+      if (db) g += db[i];
+      if (dc) g += dc[i];
+      part[i] = g;
+    }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < QC; j += 1024) {
+    float acc = 0.0f;
+    for (int n = 0; n < N; ++n) acc += part[n * QC + j];
+    const float sg = ref[j];
+    dp[j] += acc * sg * (1.0f - sg);
+  }
+}
+
 constexpr int AB_ROWS = 32;  // rows per workgroup when column sums are accumulated (few atomics);
                              // 4 when there is nothing to reduce (row chains are dependent loads)
 
@@ -396,6 +533,40 @@ extern "C" int mesm_ref_init_bwd(const float* out, const float* dout, float* dp,
   return mesm_launch_status();
 }
 
+extern "C" int mesm_ref_step_fwd(const float* p, int32_t QC, const float* delta, const float* prev, float eps,
+                                 const float* scale, const float* anchor, float* ref_out, float* qsine, float* qscaled,
+                                 int64_t R, int32_t D, void* stream) {
+  if (!ref_out || !qsine || R <= 0 || D <= 0 || (D & 1)) return MESM_EINVAL;
+  if (p ? (QC <= 0 || (QC & 1) || delta || prev) : (!delta || !prev)) return MESM_EINVAL;
+  if (anchor ? !qscaled : (scale != nullptr)) return MESM_EINVAL;
+  hipLaunchKernelGGL(ref_step_fwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, QC, delta,
+                     prev, eps, scale, anchor, ref_out, qsine, qscaled, R, D);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_ref_step_bwd(const float* ref, const float* prev, const float* dref_out, float eps,
+                                 const float* qsine, const float* scale, const float* anchor, const float* dqscaled,
+                                 float* ddelta, float* dprev, float* dscale, float* danchor, int64_t R, int32_t D,
+                                 void* stream) {
+  if (!ref || R <= 0 || D <= 0 || (D & 1)) return MESM_EINVAL;
+  if (ddelta ? !prev : (dprev != nullptr)) return MESM_EINVAL;
+  if (danchor ? (!anchor || !qsine) : (dscale != nullptr)) return MESM_EINVAL;
+  if (!ddelta && !danchor) return MESM_OK;
+  hipLaunchKernelGGL(ref_step_bwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ref, prev,
+                     dref_out, eps, qsine, scale, anchor, dqscaled, ddelta, dprev, dscale, danchor, R, D);
+  return mesm_launch_status();
+}
+
+extern "C" int mesm_ref_init_sine_bwd(const float* ref, const float* da, const float* db, const float* dc,
+                                      const float* dqsine, const float* dqsine2, float* dp, int32_t N, int32_t QC,
+                                      int32_t D, void* stream) {
+  if (!ref || !dp || N <= 0 || QC <= 0 || (QC & 1) || D <= 0 || (D & 1)) return MESM_EINVAL;
+  if ((int64_t)N * (QC / 2) > RIS_MAX_ROWS) return MESM_EINVAL;
+  hipLaunchKernelGGL(ref_init_sine_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ref, da, db, dc, dqsine,
+                     dqsine2, dp, N, QC, D);
+  return mesm_launch_status();
+}
+
 extern "C" int mesm_qsine_scale_fwd(const float* qsine, const float* scale, const float* anchor,
                                     const float* ref, float* out, int64_t R, int32_t D, void* stream) {
   if (!qsine || !anchor || !ref || !out || R <= 0 || D <= 0) return MESM_EINVAL;
@@ -427,5 +598,5 @@ extern "C" int mesm_act_dropout(const float* x, float* y, int64_t n, int32_t act
   return mesm_launch_status();
 }
 
-extern "C" int mesm_abi_version(void) { return 9; }  // 9: mesm_criterion_fwd / _bwd, mesm_glue_group, mesm_fill_ranges, mesm_add_n, split-K with dropout / ReLU-gradient epilogues (plane GEMM entries removed); 8: mesm_ref_init_*; 7: mesm_skinny_linear_bwd; 6: MesmAttnArgs.mask_mod, MesmLnArgs + group entries, *_nv, mesm_ddp_*, match_q = -1
+extern "C" int mesm_abi_version(void) { return 10; }  // 10: mesm_ref_step_fwd / _bwd, mesm_ref_init_sine_bwd; 9: mesm_criterion_fwd / _bwd, mesm_glue_group, mesm_fill_ranges, mesm_add_n, split-K with dropout / ReLU-gradient epilogues (plane GEMM entries removed); 8: mesm_ref_init_*; 7: mesm_skinny_linear_bwd; 6: MesmAttnArgs.mask_mod, MesmLnArgs + group entries, *_nv, mesm_ddp_*, match_q = -1
 extern "C" const char* mesm_arch(void) { return "gfx950"; }

@@ -452,15 +452,20 @@ class phase:
 gemm_group = phase  # the older name: a phase that only holds GEMMs
 
 
-def layernorm_fwd(x, gamma, beta, eps=1e-5, drop=(0.0, 0), add=None):
+def layernorm_fwd(x, gamma, beta, eps=1e-5, drop=(0.0, 0), add=None, out=None):
     """y = dropout(LN(x)) (drop = (p, seed); p = 0: plain LayerNorm), mean, rstd.
-    add (same shape as x): also return y + add as a fourth value (one extra store stream)."""
+    add (same shape as x): also return y + add as a fourth value (one extra store stream).
+    out: where y is written (a contiguous tensor of x's size, e.g. a slot of a stacked output)."""
     require_gpu(x, gamma, beta)
     D = x.shape[-1]
     x2 = x.reshape(-1, D)
     assert x2.is_contiguous()
     rows = x2.shape[0]
-    y = torch.empty_like(x2)
+    if out is not None:
+        assert out.is_contiguous() and out.numel() == x2.numel() and out.dtype == x2.dtype and out.device == x2.device
+        y = out.view(rows, D)
+    else:
+        y = torch.empty_like(x2)
     mean = torch.empty(rows, device=x.device, dtype=torch.float32)
     rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
     _check_drop_index(x2.numel(), float(drop[0]))

@@ -375,44 +375,51 @@ class Decoder(nn.Module):
         n = memory.shape[0]
         nq = refpoints_unsigmoid.shape[0]
         d = self.d_model
-        # sigmoid(refpoints)[None].expand(n, nq, 2), materialised by one kernel (backward: one more)
-        ref = ops.ref_init(refpoints_unsigmoid, n)
-        refs = [ref]
-        out = kn.zeros((n, nq, d), memory.device) if torch.is_grad_enabled() else torch.zeros(n, nq, d, device=memory.device)
-        inter = []
         nl = len(self.layers)
+        dev = memory.device
+        # the two stacked outputs (transformer.py:411-415) are written in place by the kernels that produce their slices
+        hs_buf = torch.empty((nl, n, nq, d), device=dev, dtype=torch.float32)
+        refs_buf = torch.empty((nl, n, nq, 2), device=dev, dtype=torch.float32)
+        # sigmoid(refpoints)[None].expand(n, nq, 2) into slot 0 and its sine embedding: one kernel (backward: one more,
+        # which also sums the gradients of ref's three consumers)
+        ref_s, ref_w, ref_u, qsine, qsine_m = ops.ref_init_sine(refpoints_unsigmoid, n, d, ops.Slot(refs_buf, 0))
+        refs = [ref_s]
+        out = kn.zeros((n, nq, d), dev) if torch.is_grad_enabled() else torch.zeros(n, nq, d, device=dev)
+        inter = []
         # layer 0: anchor head beside the reference-point head (query_scale is 1 on layer 0, transformer.py:366-369)
-        qsine = ops.query_sine(ref, d)
         (query_pos, anchor), _ = yield from mlp_heads_steps([(self.ref_point_head, qsine), (self.ref_anchor_head, out)])
-        scale = None
+        # qsine * (sigmoid(ref_anchor_head(out)) / ref_width): one kernel
+        qsine = ops.qsine_scale(qsine_m, None, anchor, ref_w)
         # every layer reads the same memory: their d memory shares are summed by the dX GEMMs' epilogues
         mem_share = ops.GradShare(nl) if (nl > 1 and torch.is_grad_enabled() and memory.requires_grad) else None
         out_res = None
+        ref = ref_u
         for li, layer in enumerate(self.layers):
-            # qsine * query_scale(out) * (sigmoid(ref_anchor_head(out)) / ref_width): one kernel
-            qsine = ops.qsine_scale(qsine, scale, anchor, ref)
             out = yield from layer.steps(out, memory, mem_pad, pos, query_pos, qsine, li == 0,
                                          lambda key, li=li: pack("dec%d.%s" % (li, key)), mem_share=mem_share,
                                          tgt_res=out_res)
-            # a layer's output has up to six consumers (box head, final norm, the next layer's anchor / scale heads, the
+            norm = ops.layer_norm_call
+            if li + 1 == nl:
+                # the last layer's box refinement is DEAD in the reference: new_reference_points is neither appended
+                # (transformer.py:395-396) nor read again, so bbox_embed(output) of that layer reaches no output and no
+                # loss -- three GEMM launches and a ref_update that this build used to run (round 6)
+                inter.append((yield norm(out, self.norm.weight, self.norm.bias, slot=ops.Slot(hs_buf, li))))
+                break
+            # a layer's output has six consumers (box head, final norm, the next layer's anchor / scale heads, the
             # next layer's self-attention and its residual): their gradients meet in one launch (ops.fork)
-            o_box, o_norm, o_anchor, o_scale, o_next, out_res = ops.fork(out, 6) if li + 1 < nl else (out,) * 6
-            heads = [(self.bbox_embed, o_box)]
-            if li + 1 < nl:
-                heads += [(self.ref_anchor_head, o_anchor), (self.query_scale, o_scale)]
-            res, ex = yield from mlp_heads_steps(heads, extra=[ops.layer_norm_call(o_norm, self.norm.weight, self.norm.bias)])
+            o_box, o_norm, o_anchor, o_scale, o_next, out_res = ops.fork(out, 6)
+            heads = [(self.bbox_embed, o_box), (self.ref_anchor_head, o_anchor), (self.query_scale, o_scale)]
+            res, ex = yield from mlp_heads_steps(
+                heads, extra=[norm(o_norm, self.norm.weight, self.norm.bias, slot=ops.Slot(hs_buf, li))])
             out = o_next
             inter.append(ex[0])
-            # sigmoid(bbox_embed(out) + inverse_sigmoid(ref)): one kernel
-            new_ref = ops.ref_update(res[0], ref)
-            if li != self.num_layers - 1:
-                refs.append(new_ref)
+            # ONE kernel: new_ref = sigmoid(bbox_embed(out) + inverse_sigmoid(ref)) into its slot, and from its detached
+            # value the next layer's sine embedding and qsine * query_scale(out) * (sigmoid(ref_anchor_head(out)) / width)
+            new_ref, qsine_raw, qsine = ops.ref_step(res[0], ref, res[2], res[1], d, ops.Slot(refs_buf, li + 1))
+            refs.append(new_ref)
             ref = new_ref.detach()
-            if li + 1 < nl:
-                anchor, scale = res[1], res[2]
-                qsine = ops.query_sine(ref, d)
-                (query_pos,), _ = yield from mlp_heads_steps([(self.ref_point_head, qsine)])
-        return torch.stack(inter), torch.stack(refs)
+            (query_pos,), _ = yield from mlp_heads_steps([(self.ref_point_head, qsine_raw)])
+        return ops.stacked(hs_buf, inter), ops.stacked(refs_buf, refs)
 
     def forward(self, *a, **kw):
         return ops.seq(self.steps(*a, **kw))

@@ -469,6 +469,41 @@ def fork(x, n):
     return ForkFn.apply(x, n)
 
 
+# ----------------------------------------------------------------------------- stacked outputs written in place
+class Slot:
+    """One slot buf[k] of a stacked output (`torch.stack` without the copy): the kernel that produces the k-th tensor
+    writes it there (layer_norm_call(slot=), ref_init / ref_step), and `stacked` hands the buffer out as the stack.  A plain
+    object, not a tensor, so that an autograd node does not see the buffer as one of its inputs."""
+    __slots__ = ("buf", "k", "t")
+
+    def __init__(self, buf, k):
+        self.buf, self.k, self.t = buf, k, buf[k]
+
+
+class StackedFn(Function):
+    """torch.stack(xs) of tensors that already live in the slots of `holder[0]`, in order: no copy forward (the decoder's
+    per-layer outputs and reference points, transformer.py:411-415, were two concatenation launches per step); backward
+    hands every producer its slice of the gradient, like torch.stack's own."""
+
+    @staticmethod
+    def forward(ctx, holder, *xs):
+        buf = holder[0]
+        assert buf.shape[0] == len(xs)
+        for k, x in enumerate(xs):
+            assert x.data_ptr() == buf[k].data_ptr() and x.shape == buf.shape[1:] and x.is_contiguous(), \
+                "stacked: tensor %d does not live in its slot" % k
+        ctx.n = len(xs)
+        return buf.view_as(buf)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None,) + tuple(g[k] for k in range(ctx.n))
+
+
+def stacked(buf, xs):
+    return StackedFn.apply([buf], *xs)
+
+
 # ----------------------------------------------------------------------------- Linear
 class LinearBlock:
     """y = dropout_out( relu?( dropout_in(x [+ x2]) @ W[rows]^T + b[rows] ) ) [+ residual].
@@ -652,9 +687,9 @@ class LayerNormBlock:
     N_OUT = 1
 
     @staticmethod
-    def fwd(ctx, x, gamma, beta, eps, drop=NO_DROP, sink=None, in_relu=None):
+    def fwd(ctx, x, gamma, beta, eps, drop=NO_DROP, sink=None, in_relu=None, slot=None):
         x = _c(x)
-        y, mean, rstd = kn.layernorm_fwd(x, gamma, beta, eps, drop)
+        y, mean, rstd = kn.layernorm_fwd(x, gamma, beta, eps, drop, out=slot.t if slot is not None else None)
         ctx.save_for_backward(x, mean, rstd)
         ctx.gamma, ctx.beta, ctx.drop = gamma, beta, drop
         ctx.sink = sink  # DropSink of the block that produced x (post-norm pattern), or None
@@ -676,7 +711,7 @@ class LayerNormBlock:
             sink.src = dx
         if ir is not None:
             ir.t = dx
-        return (dx, None if dg else gg, None if db else gb, None, None, None, None)
+        return (dx, None if dg else gg, None if db else gb, None, None, None, None, None)
 
 
 class LayerNormForkBlock:
@@ -752,8 +787,11 @@ class LayerNormPosBlock:
         return (dx, None if dg else gg, None if db else gb, None, dy2 if ctx.needs_input_grad[4] else None, None)
 
 
-def layer_norm_call(x, gamma, beta, eps=1e-5, drop=NO_DROP, add=None, fork=False):
-    """fork: -> (y, alias of y) for an output with two consumers (their gradients meet inside the backward kernel)"""
+def layer_norm_call(x, gamma, beta, eps=1e-5, drop=NO_DROP, add=None, fork=False, slot=None):
+    """fork: -> (y, alias of y) for an output with two consumers (their gradients meet inside the backward kernel).
+    slot (ops.Slot): y is written into that slot of a stacked output (ops.stacked) instead of a tensor of its own."""
+    if slot is not None:
+        assert not fork and add is None
     if fork and torch.is_grad_enabled() and add is None and drop[0] == 0.0:
         return Call(LayerNormForkBlock, (x, gamma, beta, eps, getattr(x, "_mesm_sink", None)))
     if fork:
@@ -765,7 +803,7 @@ def layer_norm_call(x, gamma, beta, eps=1e-5, drop=NO_DROP, add=None, fork=False
         assert drop[0] == 0.0
         return Call(LayerNormPosBlock, (x, gamma, beta, eps, add, getattr(x, "_mesm_sink", None)))
     return Call(LayerNormBlock, (x, gamma, beta, eps, drop, getattr(x, "_mesm_sink", None),
-                                 getattr(x, "_mesm_relu", None)))
+                                 getattr(x, "_mesm_relu", None), slot))
 
 
 def layer_norm(x, gamma, beta, eps=1e-5, drop=NO_DROP, add=None):
@@ -1703,6 +1741,114 @@ class RefUpdateFn(Function):
 
 def ref_update(delta, ref, eps=1e-3):
     return RefUpdateFn.apply(delta, ref, eps)
+
+
+RIS_MAX_ROWS = 4096  # mesm_ref_init_sine_bwd: rows of per-pair terms its one workgroup keeps in LDS
+
+
+class RefInitSineFn(Function):
+    """(ref, ref, ref, qsine, qsine): ref (n, nq, 2) = sigmoid(refpoints_unsigmoid) for every pair, written into its slot of
+    the stacked reference points, and its sine embedding (transformer.py:343-351), ONE launch (were ref_init | query_sine).
+    The three aliases of ref are for its three consumers -- the stacked output, the layer-0 width modulation and the first
+    refinement --, the two of qsine for ref_point_head and the modulation: the backward kernel sums their gradients itself
+    (were two launches and four element-wise adds of the autograd engine) into the parameter's gradient view."""
+
+    @staticmethod
+    def forward(ctx, p, n, D, slot):
+        ctx.set_materialize_grads(False)
+        pc = _c(p)
+        ref = slot.t if slot is not None else torch.empty((n,) + tuple(p.shape), device=p.device, dtype=torch.float32)
+        assert ref.shape == (n,) + tuple(p.shape) and p.shape[-1] == 2
+        qs = torch.empty(tuple(ref.shape[:-1]) + (D,), device=p.device, dtype=torch.float32)
+        kn.check(kn.lib().mesm_ref_step_fwd(kn.ptr(pc), pc.numel(), None, None, 0.0, None, None, kn.ptr(ref), kn.ptr(qs),
+                                            None, ref.numel() // 2, D, kn.stream_ptr()), "mesm_ref_step_fwd")
+        ctx.save_for_backward(ref)
+        ctx.p, ctx.D = p, D
+        return ref, ref.view_as(ref), ref.view_as(ref), qs, qs.view_as(qs)
+
+    @staticmethod
+    def backward(ctx, da, db, dc, dqs, dqs2):
+        (ref,) = ctx.saved_tensors
+        g, direct = grad_target(ctx.p)
+        ds = [_c(t) if t is not None else None for t in (da, db, dc, dqs, dqs2)]
+        kn.check(kn.lib().mesm_ref_init_sine_bwd(kn.ptr(ref), kn.ptr(ds[0]), kn.ptr(ds[1]), kn.ptr(ds[2]), kn.ptr(ds[3]),
+                                                 kn.ptr(ds[4]), kn.ptr(g), ref.shape[0], ctx.p.numel(), ctx.D,
+                                                 kn.stream_ptr()), "mesm_ref_init_sine_bwd")
+        flush_ready()
+        return (None if direct else g), None, None, None
+
+
+def ref_init_sine(p, n, D, slot=None):
+    """-> (ref for the stack, ref for qsine_scale, ref for the first refinement, qsine for ref_point_head, qsine for
+    qsine_scale)"""
+    if n * p.shape[0] > RIS_MAX_ROWS:  # (beyond the fused backward's LDS: the separate kernels)
+        ref = ref_init(p, n)
+        if slot is not None:
+            slot.t.copy_(ref.detach())
+            ref = RebaseFn.apply(ref, slot)
+        qs = query_sine(ref, D)
+        return ref, ref, ref, qs, qs
+    return RefInitSineFn.apply(p, n, D, slot)
+
+
+class RebaseFn(Function):
+    """x, living in `slot` from now on (the copy is the caller's): identity for autograd"""
+
+    @staticmethod
+    def forward(ctx, x, slot):
+        return slot.t.view_as(slot.t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class RefStepFn(Function):
+    """(new_ref, qsine, qscaled) at the boundary between two decoder layers (transformer.py:389-397 of layer l, :349-376 of
+    layer l + 1), ONE launch each way (were ref_update | query_sine | qsine_scale and ref_update_bwd | qsine_scale_bwd):
+    new_ref = sigmoid(delta + inverse_sigmoid(prev)) into its slot of the stacked reference points; from its DETACHED
+    value (transformer.py:397) qsine = gen_sineembed_for_position(new_ref) -- no gradient -- and
+    qscaled = qsine * scale * sigmoid(anchor) / new_ref[..., 1] -- gradients to scale and anchor only."""
+
+    @staticmethod
+    def forward(ctx, delta, prev, scale, anchor, D, slot, eps):
+        ctx.set_materialize_grads(False)
+        delta, prev, scale, anchor = _c(delta), _c(prev), _c(scale), _c(anchor)
+        ref = slot.t if slot is not None else torch.empty_like(delta)
+        assert ref.shape == delta.shape == prev.shape and delta.shape[-1] == 2
+        R = delta.numel() // 2
+        assert scale.numel() == R * D and anchor.numel() == R
+        qs = torch.empty(tuple(delta.shape[:-1]) + (D,), device=delta.device, dtype=torch.float32)
+        qsc = torch.empty_like(qs)
+        kn.check(kn.lib().mesm_ref_step_fwd(None, 0, kn.ptr(delta), kn.ptr(prev), float(eps), kn.ptr(scale), kn.ptr(anchor),
+                                            kn.ptr(ref), kn.ptr(qs), kn.ptr(qsc), R, D, kn.stream_ptr()),
+                 "mesm_ref_step_fwd")
+        ctx.save_for_backward(ref, prev, qs, scale, anchor)
+        ctx.eps, ctx.D = eps, D
+        ctx.mark_non_differentiable(qs)
+        return ref, qs, qsc
+
+    @staticmethod
+    def backward(ctx, dref, _dqs, dqsc):
+        ref, prev, qs, scale, anchor = ctx.saved_tensors
+        nd, npv, nsc, nan = ctx.needs_input_grad[:4]
+        R = ref.numel() // 2
+        want_ref = (nd or npv) and dref is not None
+        want_q = (nsc or nan) and dqsc is not None
+        dd = torch.empty_like(ref) if want_ref else None
+        dp = torch.empty_like(ref) if (want_ref and npv) else None
+        dsc = torch.empty_like(scale) if (want_q and nsc) else None
+        dan = torch.empty_like(anchor) if want_q else None
+        if want_ref or want_q:
+            kn.check(kn.lib().mesm_ref_step_bwd(kn.ptr(ref), kn.ptr(prev), kn.ptr(_c(dref)) if want_ref else None,
+                                                float(ctx.eps), kn.ptr(qs), kn.ptr(scale), kn.ptr(anchor),
+                                                kn.ptr(_c(dqsc)) if want_q else None, kn.ptr(dd), kn.ptr(dp), kn.ptr(dsc),
+                                                kn.ptr(dan), R, ctx.D, kn.stream_ptr()), "mesm_ref_step_bwd")
+        return (dd if nd else None, dp, dsc, dan if nan else None, None, None, None)
+
+
+def ref_step(delta, prev, scale, anchor, D, slot=None, eps=1e-3):
+    return RefStepFn.apply(delta, prev, scale, anchor, D, slot, eps)
 
 
 class QSineScaleFn(Function):

@@ -272,6 +272,94 @@ def test_reference_point_init_matches_sigmoid_expand_and_its_autograd():
     assert rel_err(p.grad, pd.grad) < 1e-5
 
 
+@pytest.mark.parametrize("n,nq,D", [(32, 10, 256), (3, 7, 32), (512, 10, 64)])
+def test_fused_reference_point_init_equals_ref_init_then_query_sine(n, nq, D):
+    """ops.ref_init_sine (one launch each way, three aliases of ref) against ref_init | query_sine and the autograd
+    engine's fan-in adds: bit-identical forward, parameter gradient to rounding; (512, 10): beyond the fused backward's
+    LDS rows, the separate kernels behind the same call."""
+    from mesm_amd import ops
+    p = gen((nq, 2), 80).requires_grad_(True)
+    buf = torch.empty((2, n, nq, 2), device=dev())
+    ra, rb, rc, qs, qsb = ops.ref_init_sine(p, n, D, ops.Slot(buf, 0))
+    p2 = p.detach().clone().requires_grad_(True)
+    ref = ops.ref_init(p2, n)
+    qs2 = ops.query_sine(ref, D)
+    assert torch.equal(ra, ref) and torch.equal(qs, qs2)
+    assert ra.data_ptr() == buf[0].data_ptr() and torch.equal(buf[0], ref)
+    ga, gb, gc, gq = gen((n, nq, 2), 81), gen((n, nq, 2), 82), gen((n, nq, 2), 83), gen((n, nq, D), 84)
+    gq2 = gen((n, nq, D), 85)
+    torch.autograd.backward([ra, rb, rc, qs, qsb], [ga, gb, gc, gq, gq2])
+    torch.autograd.backward([ref, qs2], [ga + gb + gc, gq + gq2])
+    assert rel_err(p.grad, p2.grad) < 1e-5
+    # only some consumers deliver a gradient
+    p3 = p.detach().clone().requires_grad_(True)
+    ra, rb, rc, qs, qsb = ops.ref_init_sine(p3, n, D)
+    torch.autograd.backward([rb], [gb])
+    p4 = p.detach().clone().requires_grad_(True)
+    ops.ref_init(p4, n).backward(gb)
+    assert rel_err(p3.grad, p4.grad) < 1e-5
+
+
+@pytest.mark.parametrize("n,nq,D,prev_grad", [(32, 10, 256, True), (32, 10, 256, False), (5, 3, 32, True)])
+def test_fused_reference_point_step_equals_ref_update_query_sine_qsine_scale(n, nq, D, prev_grad):
+    """ops.ref_step (the layer boundary of the decoder as one launch each way) against ref_update | query_sine(detached) |
+    qsine_scale(detached): bit-identical forward and gradients."""
+    from mesm_amd import ops
+    ins = [gen((n, nq, 2), 90, 0.5), torch.sigmoid(gen((n, nq, 2), 91)), gen((n, nq, D), 92), gen((n, nq, 1), 93)]
+    outs = []
+    for fused in (True, False):
+        delta, prev, scale, anchor = [t.clone().requires_grad_(i != 1 or prev_grad) for i, t in enumerate(ins)]
+        if fused:
+            buf = torch.empty((3, n, nq, 2), device=dev())
+            new_ref, qs, qsc = ops.ref_step(delta, prev, scale, anchor, D, ops.Slot(buf, 2))
+            assert new_ref.data_ptr() == buf[2].data_ptr() and not qs.requires_grad
+        else:
+            new_ref = ops.ref_update(delta, prev)
+            qs = ops.query_sine(new_ref.detach(), D)
+            qsc = ops.qsine_scale(qs, scale, anchor, new_ref.detach())
+        torch.autograd.backward([new_ref, qsc], [gen((n, nq, 2), 94), gen((n, nq, D), 95)])
+        outs.append([new_ref, qs, qsc, delta.grad, prev.grad, scale.grad, anchor.grad])
+    for a, b in zip(*outs):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a, b)
+    # one of the two output gradients absent
+    delta, prev, scale, anchor = [t.clone().requires_grad_(True) for t in ins]
+    new_ref, qs, qsc = ops.ref_step(delta, prev, scale, anchor, D)
+    new_ref.backward(gen((n, nq, 2), 94))
+    assert torch.equal(delta.grad, outs[1][3]) and scale.grad is None and anchor.grad is None
+    delta, prev, scale, anchor = [t.clone().requires_grad_(True) for t in ins]
+    new_ref, qs, qsc = ops.ref_step(delta, prev, scale, anchor, D)
+    qsc.backward(gen((n, nq, D), 95))
+    assert torch.equal(scale.grad, outs[1][5]) and torch.equal(anchor.grad, outs[1][6]) and delta.grad is None
+
+
+def test_stacked_outputs_written_in_place_equal_torch_stack():
+    """ops.stacked over slots that LayerNorm kernels wrote (the decoder's per-layer outputs): the values and gradients of
+    torch.stack without its copy."""
+    from mesm_amd import ops
+    xs = [gen((32, 10, 256), 100 + i) for i in range(2)]
+    gamma, beta = gen((256,), 110).requires_grad_(True), gen((256,), 111).requires_grad_(True)
+    g = gen((2, 32, 10, 256), 112)
+    res = []
+    for in_place in (True, False):
+        xi = [x.clone().requires_grad_(True) for x in xs]
+        gm, bt = gamma.detach().clone().requires_grad_(True), beta.detach().clone().requires_grad_(True)
+        if in_place:
+            buf = torch.empty((2, 32, 10, 256), device=dev())
+            ys = [ops.run(ops.layer_norm_call(x, gm, bt, slot=ops.Slot(buf, k))) for k, x in enumerate(xi)]
+            st = ops.stacked(buf, ys)
+            assert st.data_ptr() == buf.data_ptr()
+        else:
+            st = torch.stack([ops.layer_norm(x, gm, bt) for x in xi])
+        st.backward(g)
+        res.append([st.detach()] + [x.grad for x in xi] + [gm.grad, bt.grad])
+    for a, b in zip(*res):
+        assert rel_err(a, b) < 1e-6
+    with pytest.raises(AssertionError):
+        ops.stacked(torch.empty((2, 32, 10, 256), device=dev()), [x for x in xs])
+
+
 # --------------------------------------------------------------------------- attention
 def attn_reference(q, k, v, H, kpad, qpad, scale, quirk_B=None):
     """fp64 restatement of nn.MultiheadAttention's core incl. the reference's
