@@ -425,8 +425,8 @@ int mesm_ref_init_bwd(const float* out, const float* dout, float* dp, int32_t N,
  *         ddelta == NULL or danchor == NULL skips that half.
  *   init_sine_bwd   dp[j] += ref[j] (1 - ref[j]) sum_n (da + db + dc + query_sine_bwd(dqsine + dqsine2))[n, j]: the
  *         gradients of the initial points' consumers (stacked output, width modulation, first refinement) and of the
- *         embedding's (ref_point_head, modulation) are summed in the kernel; any may be NULL.
- *         One workgroup, deterministic; N * QC / 2 <= 4096 rows.
+ *         embedding's (ref_point_head, modulation) are summed in the kernel; any may be NULL.  One wave per row; the
+ *         pairs' terms meet by float atomics in dp.
  */
 int mesm_ref_step_fwd(const float* p, int32_t QC, const float* delta, const float* prev, float eps,
                       const float* scale, const float* anchor, float* ref_out, float* qsine, float* qscaled,

@@ -333,55 +333,46 @@ __global__ __launch_bounds__(256) void ref_step_bwd_kernel(
   }
 }
 
-// INIT backward: dp[j] += s (1 - s) sum_n (d ref_a + d ref_b + d ref_c + query_sine_bwd(d qsine + d qsine2))[n, j] -- the
+// INIT backward: dp[j] += sum_n s (1 - s) (d ref_a + d ref_b + d ref_c + query_sine_bwd(d qsine + d qsine2))[n, j] -- the
 // initial reference points have three consumers besides their sine embedding (the stacked output, the layer-0 width
 // modulation, the first refinement) and the embedding has two (ref_point_head, the modulation); their gradients are
-// summed HERE instead of by element-wise launches of the autograd engine.
-// One workgroup of 16 waves: per-row terms into LDS, then every (query, coordinate) sums its pairs in order
-// (deterministic, like ref_init_bwd).  R * 2 floats of LDS.
-constexpr int RIS_MAX_ROWS = 4096;
-__global__ __launch_bounds__(1024) void ref_init_sine_bwd_kernel(
+// summed HERE instead of by element-wise launches of the autograd engine.  One wave per row (the embedding's
+// transcendental functions are the cost: a single workgroup looping over the rows took 142 us), the pairs' terms of a
+// (query, coordinate) meet by float atomics in the parameter's gradient view, like every weight gradient of the step.
+__global__ __launch_bounds__(256) void ref_init_sine_bwd_kernel(
     const float* __restrict__ ref, const float* __restrict__ da, const float* __restrict__ db,
     const float* __restrict__ dc, const float* __restrict__ dqsine, const float* __restrict__ dqsine2,
-    float* __restrict__ dp, int N, int QC, int D) {
-  __shared__ float part[RIS_MAX_ROWS * 2];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int R = N * (QC / 2);
+    float* __restrict__ dp, int64_t R, int QC, int D) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
   const int half = D / 2;
-  for (int r = wave; r < R; r += 16) {
-    float g0 = 0.0f, g1 = 0.0f;
-    if (dqsine || dqsine2) {
-      for (int i = lane; i < D; i += 64) {
-        const int which = i >= half;
-        const int ii = which ? i - half : i;
-        const float e = (float)(2 * (ii / 2)) / (float)half;
-        const float dim_t = powf(10000.0f, e);
-        const float x = ref[r * 2 + which] * TWO_PI_F;
-        const float v = x / dim_t;
-        const float dvdr = TWO_PI_F / dim_t;
-        const float d = (ii & 1) ? -sinf(v) : cosf(v);
-        const float go = (dqsine ? dqsine[(int64_t)r * D + i] : 0.0f) + (dqsine2 ? dqsine2[(int64_t)r * D + i] : 0.0f);
-        const float g = go * d * dvdr;
-        if (which) g1 += g; else g0 += g;
-      }
-      g0 = wave_sum(g0);
-      g1 = wave_sum(g1);
+  float g0 = 0.0f, g1 = 0.0f;
+  if (dqsine || dqsine2) {
+    for (int i = lane; i < D; i += 64) {
+      const int which = i >= half;
+      const int ii = which ? i - half : i;
+      const float e = (float)(2 * (ii / 2)) / (float)half;
+      const float dim_t = powf(10000.0f, e);
+      const float x = ref[r * 2 + which] * TWO_PI_F;
+      const float v = x / dim_t;
+      const float dvdr = TWO_PI_F / dim_t;
+      const float d = (ii & 1) ? -sinf(v) : cosf(v);
+      const float go = (dqsine ? dqsine[r * D + i] : 0.0f) + (dqsine2 ? dqsine2[r * D + i] : 0.0f);
+      const float g = go * d * dvdr;
+      if (which) g1 += g; else g0 += g;
     }
-    if (lane < 2) {
-      float g = lane ? g1 : g0;
-      const int i = r * 2 + lane;
-      if (da) g += da[i];
-      if (db) g += db[i];
-      if (dc) g += dc[i];
-      part[i] = g;
-    }
+    g0 = wave_sum(g0);
+    g1 = wave_sum(g1);
   }
-  __syncthreads();
-  for (int j = threadIdx.x; j < QC; j += 1024) {
-    float acc = 0.0f;
-    for (int n = 0; n < N; ++n) acc += part[n * QC + j];
-    const float sg = ref[j];
-    dp[j] += acc * sg * (1.0f - sg);
+  if (lane < 2) {
+    float g = lane ? g1 : g0;
+    const int64_t i = r * 2 + lane;
+    if (da) g += da[i];
+    if (db) g += db[i];
+    if (dc) g += dc[i];
+    const float sg = ref[i];
+    atomicAdd(dp + (int)(i % QC), g * sg * (1.0f - sg));
   }
 }
 
@@ -561,9 +552,9 @@ extern "C" int mesm_ref_init_sine_bwd(const float* ref, const float* da, const f
                                       const float* dqsine, const float* dqsine2, float* dp, int32_t N, int32_t QC,
                                       int32_t D, void* stream) {
   if (!ref || !dp || N <= 0 || QC <= 0 || (QC & 1) || D <= 0 || (D & 1)) return MESM_EINVAL;
-  if ((int64_t)N * (QC / 2) > RIS_MAX_ROWS) return MESM_EINVAL;
-  hipLaunchKernelGGL(ref_init_sine_bwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, ref, da, db, dc, dqsine,
-                     dqsine2, dp, N, QC, D);
+  const int64_t R = (int64_t)N * (QC / 2);
+  hipLaunchKernelGGL(ref_init_sine_bwd_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, ref, da, db,
+                     dc, dqsine, dqsine2, dp, R, QC, D);
   return mesm_launch_status();
 }
 

@@ -1743,9 +1743,6 @@ def ref_update(delta, ref, eps=1e-3):
     return RefUpdateFn.apply(delta, ref, eps)
 
 
-RIS_MAX_ROWS = 4096  # mesm_ref_init_sine_bwd: rows of per-pair terms its one workgroup keeps in LDS
-
-
 class RefInitSineFn(Function):
     """(ref, ref, ref, qsine, qsine): ref (n, nq, 2) = sigmoid(refpoints_unsigmoid) for every pair, written into its slot of
     the stacked reference points, and its sine embedding (transformer.py:343-351), ONE launch (were ref_init | query_sine).
@@ -1781,26 +1778,7 @@ class RefInitSineFn(Function):
 def ref_init_sine(p, n, D, slot=None):
     """-> (ref for the stack, ref for qsine_scale, ref for the first refinement, qsine for ref_point_head, qsine for
     qsine_scale)"""
-    if n * p.shape[0] > RIS_MAX_ROWS:  # (beyond the fused backward's LDS: the separate kernels)
-        ref = ref_init(p, n)
-        if slot is not None:
-            slot.t.copy_(ref.detach())
-            ref = RebaseFn.apply(ref, slot)
-        qs = query_sine(ref, D)
-        return ref, ref, ref, qs, qs
     return RefInitSineFn.apply(p, n, D, slot)
-
-
-class RebaseFn(Function):
-    """x, living in `slot` from now on (the copy is the caller's): identity for autograd"""
-
-    @staticmethod
-    def forward(ctx, x, slot):
-        return slot.t.view_as(slot.t)
-
-    @staticmethod
-    def backward(ctx, g):
-        return g, None
 
 
 class RefStepFn(Function):

@@ -275,8 +275,7 @@ def test_reference_point_init_matches_sigmoid_expand_and_its_autograd():
 @pytest.mark.parametrize("n,nq,D", [(32, 10, 256), (3, 7, 32), (512, 10, 64)])
 def test_fused_reference_point_init_equals_ref_init_then_query_sine(n, nq, D):
     """ops.ref_init_sine (one launch each way, three aliases of ref) against ref_init | query_sine and the autograd
-    engine's fan-in adds: bit-identical forward, parameter gradient to rounding; (512, 10): beyond the fused backward's
-    LDS rows, the separate kernels behind the same call."""
+    engine's fan-in adds: bit-identical forward, parameter gradient to rounding."""
     from mesm_amd import ops
     p = gen((nq, 2), 80).requires_grad_(True)
     buf = torch.empty((2, n, nq, 2), device=dev())
