@@ -22,6 +22,16 @@
 #include "attention_blk.hpp"
 #include "common.hpp"
 
+// Output stores: write-through (common.hpp mesm_store_wt) unless built with -DMESM_ATTN_WT=0
+#ifndef MESM_ATTN_WT
+#define MESM_ATTN_WT 1
+#endif
+#if MESM_ATTN_WT
+#define ATTN_ST(ptr, val) mesm_store_wt((ptr), (val))
+#else
+#define ATTN_ST(ptr, val) (*(ptr) = (val))
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -227,9 +237,9 @@ __device__ __forceinline__ void attn_blk_bwd_body(const MesmAttnArgs& p, const i
         const int jj = j0 + 4 * kq + r;
         if (jj < Lk) {
 #pragma unroll
-          for (int c = 0; c < ND; ++c) (16 * c >= DKH ? dkb2 : dkb)[(int64_t)jj * p.k_ls + 16 * c + jl] = dKa[c][r];
+          for (int c = 0; c < ND; ++c) ATTN_ST((16 * c >= DKH ? dkb2 : dkb) + ((int64_t)jj * p.k_ls + 16 * c + jl), dKa[c][r]);
 #pragma unroll
-          for (int c = 0; c < 2; ++c) dvb[(int64_t)jj * p.v_ls + 16 * c + jl] = dVa[c][r];
+          for (int c = 0; c < 2; ++c) ATTN_ST(dvb + ((int64_t)jj * p.v_ls + 16 * c + jl), dVa[c][r]);
         }
       }
     } else {
@@ -289,7 +299,7 @@ __device__ __forceinline__ void attn_blk_bwd_body(const MesmAttnArgs& p, const i
         const int ii = i0 + 4 * kq + r;
         if (ii < Lq) {
 #pragma unroll
-          for (int c = 0; c < ND; ++c) (16 * c >= DKH ? dqb2 : dqb)[(int64_t)ii * p.q_ls + 16 * c + jl] = dQa[c][r];
+          for (int c = 0; c < ND; ++c) ATTN_ST((16 * c >= DKH ? dqb2 : dqb) + ((int64_t)ii * p.q_ls + 16 * c + jl), dQa[c][r]);
         }
       }
     }
@@ -434,10 +444,10 @@ __global__ __launch_bounds__(BT) void attn_blk_bwd_long_kernel(const MesmAttnArg
       for (int r = 0; r < 4; ++r) {
         const int jj = j0 + 4 * kq + r;
         if (jj < Lk) {
-          dkb[(int64_t)jj * p.k_ls + jl] = dKa[0][r];
-          dkb[(int64_t)jj * p.k_ls + 16 + jl] = dKa[1][r];
-          dvb[(int64_t)jj * p.v_ls + jl] = dVa[0][r];
-          dvb[(int64_t)jj * p.v_ls + 16 + jl] = dVa[1][r];
+          ATTN_ST(dkb + ((int64_t)jj * p.k_ls + jl), dKa[0][r]);
+          ATTN_ST(dkb + ((int64_t)jj * p.k_ls + 16 + jl), dKa[1][r]);
+          ATTN_ST(dvb + ((int64_t)jj * p.v_ls + jl), dVa[0][r]);
+          ATTN_ST(dvb + ((int64_t)jj * p.v_ls + 16 + jl), dVa[1][r]);
         }
       }
     }
@@ -522,8 +532,8 @@ __global__ __launch_bounds__(BT) void attn_blk_bwd_long_kernel(const MesmAttnArg
       for (int r = 0; r < 4; ++r) {
         const int ii = i0 + 4 * kq + r;
         if (ii < Lq) {
-          dqb[(int64_t)ii * p.q_ls + jl] = dQa[0][r];
-          dqb[(int64_t)ii * p.q_ls + 16 + jl] = dQa[1][r];
+          ATTN_ST(dqb + ((int64_t)ii * p.q_ls + jl), dQa[0][r]);
+          ATTN_ST(dqb + ((int64_t)ii * p.q_ls + 16 + jl), dQa[1][r]);
         }
       }
     }
@@ -717,8 +727,8 @@ __device__ __forceinline__ void attn_blk_fwd_body(const MesmAttnArgs& p, const i
     for (int r = 0; r < 4; ++r) {
       const int ii = i0 + 4 * kq + r;
       if (ii < Lq) {
-        ob[(int64_t)ii * p.o_ls + jl] = oa[0][r];
-        ob[(int64_t)ii * p.o_ls + 16 + jl] = oa[1][r];
+        ATTN_ST(ob + ((int64_t)ii * p.o_ls + jl), oa[0][r]);
+        ATTN_ST(ob + ((int64_t)ii * p.o_ls + 16 + jl), oa[1][r]);
       }
     }
     if (kq == 0 && i < Lq && p.lse) p.lse[(int64_t)bh * Lq + i] = m + __logf(l);
@@ -857,8 +867,8 @@ __global__ __launch_bounds__(BT) void attn_blk_fwd_long_kernel(const MesmAttnArg
     for (int r = 0; r < 4; ++r) {
       const int ii = i0 + 4 * kq + r;
       if (ii < Lq) {
-        ob[(int64_t)ii * p.o_ls + jl] = oa[0][r];
-        ob[(int64_t)ii * p.o_ls + 16 + jl] = oa[1][r];
+        ATTN_ST(ob + ((int64_t)ii * p.o_ls + jl), oa[0][r]);
+        ATTN_ST(ob + ((int64_t)ii * p.o_ls + 16 + jl), oa[1][r]);
       }
     }
     if (kq == 0 && i < Lq && p.lse) p.lse[(int64_t)bh * Lq + i] = m_run + __logf(l_run);

@@ -41,6 +41,45 @@ __device__ __forceinline__ float mesm_act(float x, int act, float slope) {
   return x;
 }
 
+// WRITE-THROUGH output stores (round 6).  A plain store leaves its line dirty in the XCD's L2 until the kernel boundary's
+// release writes every dirty line back -- time at the END of the launch, behind the last tile, that nothing overlaps; a
+// store with sc1 leaves L2 when it is issued, while other workgroups still compute (tools/probe/store_tail.hip: a chain of
+// launches that each write 5 / 20 / 39 MB: 3.82 / 6.48 / 9.11 -> 3.47 / 5.35 / 7.98 us per launch; 4-byte sc1 stores of a
+// half wave's 128 contiguous bytes cost what 16-byte ones do).  The price: the line is dropped from that L2, so a consumer
+// workgroup that lands on the SAME XCD reads it from the Infinity Cache like the other seven XCDs' do (+0.2-0.9 us in the
+// probe's reader pass below 20 MB).  In the step the GEMM epilogues alone: 3.370 -> 3.332 ms, with every size of output
+// (thresholds at 1 M / 4 M elements gave less / nothing: profiles/r6q/ab_sc1.txt).  -DMESM_WT_STORES=0: plain stores.
+#ifndef MESM_WT_STORES
+#define MESM_WT_STORES 1
+#endif
+typedef float mesm_f32x4 __attribute__((ext_vector_type(4)));
+typedef float mesm_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void mesm_store_wt(float* p, float v) {
+#if MESM_WT_STORES
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // global_store_dword ... sc1
+#else
+  *p = v;
+#endif
+}
+__device__ __forceinline__ void mesm_store_wt2(float* p, float a, float b) {
+#if MESM_WT_STORES
+  const mesm_f32x2 v = {a, b};
+  asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+#else
+  *reinterpret_cast<float2*>(p) = make_float2(a, b);
+#endif
+}
+__device__ __forceinline__ void mesm_store_wt4(float* p, float a, float b, float c, float d) {
+#if MESM_WT_STORES
+  const mesm_f32x4 v = {a, b, c, d};
+  // (s_nop: a vector-memory store of more than 64 bits reads its data registers late; a VALU write to them within the next
+  // wait states corrupts the store -- the compiler pads its own stores, not inline assembly: LayerNorm twin outputs differed)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+#else
+  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+#endif
+}
+
 // Wave-wide reductions on the DPP path (gfx9 row operations): four in-row butterfly steps
 // (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), two row broadcasts (row_bcast:15 into rows
 // 1 and 3, row_bcast:31 into rows 2 and 3) and one v_readlane of lane 63 -- 7 VALU-rate instructions.

@@ -197,7 +197,7 @@ __device__ __forceinline__ float staged_epilogue(const MesmGemmArgs& p, float (&
     float* pp = p.pre_out + ((int64_t)rbase * p.ldpre + col);
 #pragma unroll
     for (int i = 0; i < NV; ++i)
-      if (ok[i]) pp[(int64_t)RO(i) * p.ldpre] = t[i];
+      if (ok[i]) mesm_store_wt(pp + (int64_t)RO(i) * p.ldpre, t[i]);
   }
   if (p.e_act != MESM_ACT_NONE) {
 #pragma unroll
@@ -277,7 +277,7 @@ __device__ __forceinline__ float staged_epilogue(const MesmGemmArgs& p, float (&
   } else {
 #pragma unroll
     for (int i = 0; i < NV; ++i)
-      if (ok[i]) cp[(int64_t)RO(i) * p.ldc] = t[i];
+      if (ok[i]) mesm_store_wt(cp + (int64_t)RO(i) * p.ldc, t[i]);  // (write-through: common.hpp)
   }
   return dslope_part;
 }

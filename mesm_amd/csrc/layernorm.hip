@@ -56,10 +56,27 @@ __device__ __forceinline__ void ld_vec(const float* __restrict__ p, float* d) {
 }
 
 template <int VEC>
-__device__ __forceinline__ void st_vec(float* __restrict__ p, const float* s) {
+__device__ __forceinline__ void st_lds(float* __restrict__ p, const float* s) {  // (LDS scratch: plain stores)
   if (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(s[0], s[1], s[2], s[3]);
   else if (VEC == 2) *reinterpret_cast<float2*>(p) = make_float2(s[0], s[1]);
   else *p = s[0];
+}
+
+// (output stores: write-through, common.hpp, unless built with -DMESM_LN_WT=0)
+#ifndef MESM_LN_WT
+#define MESM_LN_WT 1
+#endif
+template <int VEC>
+__device__ __forceinline__ void st_vec(float* __restrict__ p, const float* s) {
+#if MESM_LN_WT
+  if (VEC == 4) mesm_store_wt4(p, s[0], s[1], s[2], s[3]);
+  else if (VEC == 2) mesm_store_wt2(p, s[0], s[1]);
+  else mesm_store_wt(p, s[0]);
+#else
+  if (VEC == 4) *reinterpret_cast<float4*>(p) = make_float4(s[0], s[1], s[2], s[3]);
+  else if (VEC == 2) *reinterpret_cast<float2*>(p) = make_float2(s[0], s[1]);
+  else *p = s[0];
+#endif
 }
 
 // TAIL (VEC = 4 only): D is not a multiple of 4, so rows start 8- or 4-byte aligned.  The lane chunks are SHIFTED per
@@ -363,7 +380,7 @@ __device__ __forceinline__ void ln_bwd_body(
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         int col = (c * 64 + lane) * VEC;
-        if (col < D) st_vec<VEC>(red + wave * D + col, round == 0 ? dg[c] : db[c]);
+        if (col < D) st_lds<VEC>(red + wave * D + col, round == 0 ? dg[c] : db[c]);
       }
       __syncthreads();
       float* dst = round == 0 ? dgamma : dbeta;
