@@ -196,7 +196,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd_kernel(const MesmAttnArgs
   for (int r = wave; r < nq; r += AT_WAVES) {
     const int i = q0 + r;
     const float l = Ls[r];
-    if (lane < DV) ob[(int64_t)i * p.o_ls + lane] = Os[r * DV + lane] / l;
+    if (lane < DV) mesm_store_wt(ob + ((int64_t)i * p.o_ls + lane), Os[r * DV + lane] / l);  // (write-through: common.hpp)
     if (lane == 0 && p.lse) p.lse[(int64_t)bh * p.Lq + i] = Ms[r] + __logf(l);
   }
 }
@@ -402,7 +402,7 @@ __device__ __forceinline__ void attn_bwd_body(const MesmAttnArgs& p, const int b
   __syncthreads();
   for (int idx = tid; idx < KT * DK; idx += BW_THREADS) {
     int r = idx / DK, c = idx % DK;
-    if (k0 + r < p.Lk) (c >= DKH ? dkb2 : dkb)[(int64_t)(k0 + r) * p.k_ls + c] = Red[r * DR + c];
+    if (k0 + r < p.Lk) mesm_store_wt((c >= DKH ? dkb2 : dkb) + ((int64_t)(k0 + r) * p.k_ls + c), Red[r * DR + c]);
   }
   for (int w = 0; w < BW_WAVES; ++w) {
     __syncthreads();
@@ -418,7 +418,7 @@ __device__ __forceinline__ void attn_bwd_body(const MesmAttnArgs& p, const int b
   __syncthreads();
   for (int idx = tid; idx < KT * DV; idx += BW_THREADS) {
     int r = idx / DV, c = idx % DV;
-    if (k0 + r < p.Lk) dvb[(int64_t)(k0 + r) * p.v_ls + c] = Red[r * DR + c];
+    if (k0 + r < p.Lk) mesm_store_wt(dvb + ((int64_t)(k0 + r) * p.v_ls + c), Red[r * DR + c]);
   }
 }
 

@@ -80,6 +80,12 @@ __device__ __forceinline__ void mesm_store_wt4(float* p, float a, float b, float
 #endif
 }
 
+__device__ __forceinline__ void mesm_store_wt4(float* p, const float4& v) { mesm_store_wt4(p, v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void mesm_store_wt16(void* p, const uint4& v) {  // 16 bytes of any type
+  mesm_store_wt4(reinterpret_cast<float*>(p), __uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z),
+                 __uint_as_float(v.w));
+}
+
 // Wave-wide reductions on the DPP path (gfx9 row operations): four in-row butterfly steps
 // (quad_perm xor 1, xor 2, row_half_mirror, row_mirror), two row broadcasts (row_bcast:15 into rows
 // 1 and 3, row_bcast:31 into rows 2 and 3) and one v_readlane of lane 63 -- 7 VALU-rate instructions.

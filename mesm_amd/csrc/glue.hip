@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void stack_rows_kernel(const StackArgs a) {
   unsigned char* d = a.dst[t] + (int64_t)r * rb;
   if ((rb & 15) == 0 && ((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0) {
     const int64_t n16 = rb >> 4;
-    for (int64_t i = threadIdx.x; i < n16; i += 256) reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+    for (int64_t i = threadIdx.x; i < n16; i += 256) mesm_store_wt16(reinterpret_cast<uint4*>(d) + i, reinterpret_cast<const uint4*>(s)[i]);
   } else {
     for (int64_t i = threadIdx.x; i < rb; i += 256) d[i] = s[i];
   }
@@ -56,7 +56,7 @@ __device__ __forceinline__ void unstack_rows_body(const float* __restrict__ d2, 
         acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
       }
   }
-  *reinterpret_cast<float4*>(dx + (int64_t)i * R + c0) = acc;
+  mesm_store_wt4(dx + (int64_t)i * R + c0, acc);
 }
 
 __global__ __launch_bounds__(256) void unstack_rows_kernel(const float* __restrict__ d2, const int64_t* __restrict__ idx,
@@ -84,11 +84,11 @@ __global__ __launch_bounds__(256) void prepend_fwd_kernel(const float* __restric
   if (po || xp) ps = l == 0 ? ptok : pos + ((int64_t)b * L + l - 1) * D;
   for (int c = (threadIdx.x & 63) * 4; c < D; c += 256) {
     const float4 v = *reinterpret_cast<const float4*>(xs + c);
-    *reinterpret_cast<float4*>(xo + orow + c) = v;
+    mesm_store_wt4(xo + orow + c, v);
     if (ps) {
       const float4 q = *reinterpret_cast<const float4*>(ps + c);
-      if (po) *reinterpret_cast<float4*>(po + orow + c) = q;
-      if (xp) *reinterpret_cast<float4*>(xp + orow + c) = make_float4(v.x + q.x, v.y + q.y, v.z + q.z, v.w + q.w);
+      if (po) mesm_store_wt4(po + orow + c, q);
+      if (xp) mesm_store_wt4(xp + orow + c, make_float4(v.x + q.x, v.y + q.y, v.z + q.z, v.w + q.w));
     }
   }
   if (pado && (threadIdx.x & 63) == 0) pado[(int64_t)b * (L + 1) + l] = l == 0 ? (uint8_t)first_pad : pad[(int64_t)b * L + l - 1];
@@ -139,11 +139,11 @@ __global__ __launch_bounds__(256) void prepend_bwd_kernel(const float* __restric
       g.x += gp.x; g.y += gp.y; g.z += gp.z; g.w += gp.w;
     }
     if (l > 0) {
-      if (dx) *reinterpret_cast<float4*>(dx + ((int64_t)b * L + l - 1) * D + c) = g;
+      if (dx) mesm_store_wt4(dx + ((int64_t)b * L + l - 1) * D + c, g);
     } else {
       if (dtok) {
         if (tok_per_row) {
-          *reinterpret_cast<float4*>(dtok + (int64_t)b * D + c) = g;
+          mesm_store_wt4(dtok + (int64_t)b * D + c, g);
         } else {
           atomicAdd(dtok + c, g.x); atomicAdd(dtok + c + 1, g.y); atomicAdd(dtok + c + 2, g.z); atomicAdd(dtok + c + 3, g.w);
         }
@@ -172,10 +172,10 @@ __global__ __launch_bounds__(256) void split_fwd_kernel(const float* __restrict_
   for (int c = (threadIdx.x & 63) * 4; c < D; c += 256) {
     const float4 v = *reinterpret_cast<const float4*>(s + c);
     if (l == 0) {
-      *reinterpret_cast<float4*>(g + (int64_t)b * D + c) = v;
+      mesm_store_wt4(g + (int64_t)b * D + c, v);
     } else {
-      *reinterpret_cast<float4*>(loc + ((int64_t)b * L + l - 1) * D + c) = v;
-      if (dec && b < Bd) *reinterpret_cast<float4*>(dec + ((int64_t)b * L + l - 1) * D + c) = v;
+      mesm_store_wt4(loc + ((int64_t)b * L + l - 1) * D + c, v);
+      if (dec && b < Bd) mesm_store_wt4(dec + ((int64_t)b * L + l - 1) * D + c, v);
     }
   }
 }
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void split_bwd_kernel(const float* __restrict_
         v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
       }
     }
-    *reinterpret_cast<float4*>(d + c) = v;
+    mesm_store_wt4(d + c, v);
   }
 }
 
@@ -219,7 +219,7 @@ __device__ __forceinline__ void token_mix_fwd_body(const float* __restrict__ x, 
   if (m2 && m2[r]) s = tok2;
   else if (m1[r]) s = tok1;
   for (int c = (threadIdx.x & 63) * 4; c < D; c += 256)
-    *reinterpret_cast<float4*>(y + r * D + c) = *reinterpret_cast<const float4*>(s + c);
+    mesm_store_wt4(y + r * D + c, *reinterpret_cast<const float4*>(s + c));
 }
 
 __global__ __launch_bounds__(256) void token_mix_fwd_kernel(const float* __restrict__ x, const uint8_t* __restrict__ m1,
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256) void glue_group_kernel(const GlueGroup g) {
       unsigned char* d = (unsigned char*)a.p[1] + (int64_t)r * rb;
       if ((rb & 15) == 0 && ((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0) {
         const int64_t n16 = rb >> 4;
-        for (int64_t i = threadIdx.x; i < n16; i += 256) reinterpret_cast<uint4*>(d)[i] = reinterpret_cast<const uint4*>(s)[i];
+        for (int64_t i = threadIdx.x; i < n16; i += 256) mesm_store_wt16(reinterpret_cast<uint4*>(d) + i, reinterpret_cast<const uint4*>(s)[i]);
       } else {
         for (int64_t i = threadIdx.x; i < rb; i += 256) d[i] = s[i];
       }
@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void glue_group_kernel(const GlueGroup g) {
       const int64_t n4 = a.n[0], na4 = a.n[1], nb4 = ((const int64_t*)a.i)[0];
       for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < n4; i += (int64_t)gx * 256) {
         const float4 u = pa[i % na4], v = pb[i % nb4];
-        po[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+        mesm_store_wt4(reinterpret_cast<float*>(po + i), u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
       }
       break;
     }
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256) void fill_ranges_kernel(const FillRanges r) {
   for (int k = 1; k < FILL_MAX; ++k)
     if ((int)blockIdx.y == k) { d = r.p[k]; n = r.n16[k]; }
   const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) d[i] = z;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) mesm_store_wt16(d + i, z);
 }
 
 // First node of a captured step: the step's host draws come from a ring of `slots` buffers in PINNED HOST memory
@@ -776,7 +776,7 @@ extern "C" int mesm_fill_ranges(void* const* ptrs, const int64_t* nbytes, int32_
     if (r.n16[k] > most) most = r.n16[k];
   }
   int64_t gx = (most + 255) / 256;
-  if (gx > 512) gx = 512;
+  if (gx > 1024) gx = 1024;
   hipLaunchKernelGGL(fill_ranges_kernel, dim3((unsigned)gx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, r);
   return mesm_launch_status();
 }

@@ -109,7 +109,7 @@ __device__ __forceinline__ void nll_bwd_body(const float* __restrict__ logit, co
       float p = __expf(x[c] - lse);
       v = g * (p - (c == lab ? (1.0f - eps) : 0.0f) - u);
     }
-    d[c] = v;
+    mesm_store_wt(d + c, v);  // (20 MB at C = 5003: write-through, common.hpp)
   }
 }
 

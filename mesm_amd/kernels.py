@@ -160,6 +160,13 @@ class ZeroPool:
 zero_pool = ZeroPool()
 
 
+def fill_zero(t):
+    """t (contiguous, 16-byte aligned, a multiple of 16 bytes) <- 0 in one launch of the library's own fill"""
+    ptrs = (ctypes.c_void_p * 1)(t.data_ptr())
+    nb = (ctypes.c_int64 * 1)(t.numel() * t.element_size())
+    check(lib().mesm_fill_ranges(ptrs, nb, 1, stream_ptr()), "mesm_fill_ranges")
+
+
 def zeros(shape, device):
     """fp32 zeros that live until the next step begins (see ZeroPool)"""
     return zero_pool.zeros(tuple(shape), device)
