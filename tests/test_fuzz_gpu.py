@@ -1,4 +1,4 @@
-"""A seeded slice of tools/fuzz_parity.py in the GPU suite: 20 random configurations (dataset, group sizes, lengths,
+"""A seeded slice of tools/fuzz_parity.py in the GPU suite: 48 random configurations (dataset, group sizes, lengths,
 padding, widths / heads, layer counts, projection depth, every ablation switch) of the HIP path against the CPU oracle
 -- outputs, losses, matcher indices, the set of parameters with a gradient and the gradients."""
 import os
@@ -15,7 +15,7 @@ def test_seeded_fuzz_slice_against_the_oracle():
     from fuzz_parity import fuzz_case
     rng = random.Random(20261003)
     bad = []
-    for case in range(20):
+    for case in range(48):  # (the first 20 are the slice of rounds 3-6: same seed, same stream)
         tag, status = fuzz_case(rng, case)
         if status != "ok":
             bad.append(tag + " -> " + status)
@@ -48,3 +48,23 @@ def test_case_with_a_device_side_activation_kink_is_refereed():
         draw(rng, case)
     tag, status = fuzz_case(rng, 227)
     assert status == "ok", tag + " -> " + status
+
+
+def test_seeded_slice_of_the_unchanged_caller_sweep():
+    """A seeded slice of tools/fuzz_autograph.py: 12 random configurations through the reference's loop body (train.py:64-72, torch's
+    AdamW) on three batches each -- first visit eager, then capture and replays -- every replayed step against the eager step
+    on the same batch and draws (losses 1e-5, gradient buffer 1e-4 relative L2, the set of parameters with a gradient)."""
+    from mesm_amd import kernels as kn
+    saved = kn._FWD_ATOMICS
+    try:
+        import fuzz_autograph  # (switches the forward's K-split products off: a deterministic forward for the comparison)
+        kn._FWD_ATOMICS = False
+        rng = random.Random(20261004)
+        bad = []
+        for case in range(12):
+            tag, status = fuzz_autograph.case(rng, case)
+            if status != "ok":
+                bad.append(tag + " -> " + status)
+        assert not bad, "\n".join(bad)
+    finally:
+        kn._FWD_ATOMICS = saved
