@@ -914,10 +914,12 @@ def main():
                              for k, v in hb.items()} for _, hb in stream_b]
 
                 def epoch(keep_host):
+                    # keep_host False: dataset/base.py:358-384's semantics exactly (what an unchanged train.py gets from the
+                    # reference's own `dataset` package); True: this build's prepare_batch_input, which keeps the host copies
+                    # of the small tensors it has in hand (batching.attach_host_side)
+                    _bt._KEEP_HOST_SIDE = bool(keep_host)
                     for hb in pinned_b:
                         b_ = dict(hb)
-                        if keep_host:
-                            _bt.attach_host_side(b_)
                         b_ = _bt.prepare_batch_input(b_, dev, non_blocking=True)
                         out_ = model(**b_, dataset_name=args.dataset_name, is_training=True)
                         _, loss_ = crit(out_, b_, is_training=True)
@@ -936,13 +938,15 @@ def main():
                 loader["unchanged_caller"] = {
                     "ms_per_step": t_plain / nb * 1e3, "pairs_per_s": npairs / t_plain, "graphs_captured": cap,
                     "timed_pass_replayed_fraction": rep_frac,
-                    "ms_per_step_with_host_side_kept_by_the_collate": t_host / nb * 1e3,
+                    "ms_per_step_with_this_builds_prepare_batch_input": t_host / nb * 1e3,
                     "note": "the same 36 host batches, page-locked like a DataLoader(pin_memory=True) delivers them, through "
                             "prepare_batch_input (asynchronous copies) and the reference's loop "
                             "body with torch's clip_grad_norm_ + AdamW (lr = 0); model.autograph(pad=(Lv, Lw), pairs=16)"}
             except Exception as e:
                 log("unchanged-caller loader section skipped: %s: %s" % (type(e).__name__, e))
             finally:
+                import mesm_amd.batching as _bt2
+                _bt2._KEEP_HOST_SIDE = True
                 model.autograph(False)
                 model._auto.pad = model._auto.pairs = None
                 model.zero_grad(set_to_none=True)

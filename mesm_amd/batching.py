@@ -14,6 +14,8 @@ host staging buffer (16-byte aligned segments), copied once, and the batch tenso
 buffer.  Results are identical to the reference's (tests/test_batching_cpu.py compares with fixtures
 produced by the real functions).
 """
+import os
+
 import torch
 
 
@@ -186,9 +188,19 @@ class _Packer:
         return [dev[off:off + nbytes].view(t.dtype).view(t.shape) for t, off, nbytes in self.items]
 
 
+# prepare_batch_input keeps the host side of a host batch it sends to a GPU (attach_host_side) unless MESM_KEEP_HOST_SIDE=0
+_KEEP_HOST_SIDE = os.environ.get("MESM_KEEP_HOST_SIDE", "1") != "0"
+
+
 def prepare_batch_input(batched_data, device, non_blocking=False):
-    """dataset/base.py:358-384 (mutates and returns `batched_data`)."""
+    """dataset/base.py:358-384 (mutates and returns `batched_data`).  One addition: a HOST batch on its way to a GPU keeps the
+    host copies of its small tensors under `batched_data["_host"]` (attach_host_side: they are in hand here, and the step's
+    host arithmetic needs them -- without them the unchanged `model(**batch)` call has to fetch them back behind a device
+    synchronisation, ~0.5 ms per step); a batch whose collate attached them already is left alone."""
     device = torch.device(device)
+    if (_KEEP_HOST_SIDE and device.type == "cuda" and "_host" not in batched_data
+            and all(not v.is_cuda for v in batched_data.values() if isinstance(v, torch.Tensor))):
+        attach_host_side(batched_data)
     big = [v for k, v in batched_data.items() if isinstance(v, torch.Tensor) and k != "words_weight" and v.numel() * v.element_size() > (1 << 20)]
     if device.type == "cpu":
         moved = {k: v for k, v in batched_data.items()}

@@ -141,3 +141,27 @@ def test_host_side_kept_by_the_collate_survives_prepare_batch_input(kind):
     w = out["words_id"]
     if w.dim() == 3:
         assert host["_words_mask_raw"].shape == w.shape[:2] and host["_words_mask_norm"].dtype == torch.bool
+
+
+@pytest.mark.gpu
+def test_prepare_batch_input_keeps_the_host_side_of_a_host_batch_bound_for_the_gpu():
+    """batching.prepare_batch_input: a host batch on its way to a GPU keeps the host copies of its small tensors under `_host`
+    (what the collate-side attach_host_side leaves there), a batch that carries them already is left alone, a CPU target and
+    MESM_KEEP_HOST_SIDE=0 give the reference's key set."""
+    from mesm_amd import batching as B
+    out = B.collate_qvh(group_samples("qvh", META["qvh.seed"]))
+    want = B.attach_host_side({k: v for k, v in out.items()})["_host"]
+    prep = B.prepare_batch_input(dict(out), torch.device("cuda:0"))
+    assert set(prep["_host"]) == set(want)
+    for k, v in want.items():
+        if torch.is_tensor(v):
+            assert not prep["_host"][k].is_cuda and torch.equal(prep["_host"][k], v), k
+    mine = B.attach_host_side(dict(out))
+    token = mine["_host"]
+    assert B.prepare_batch_input(mine, torch.device("cuda:0"))["_host"] is token
+    assert "_host" not in B.prepare_batch_input(dict(out), torch.device("cpu"))
+    B._KEEP_HOST_SIDE = False
+    try:
+        assert "_host" not in B.prepare_batch_input(dict(out), torch.device("cuda:0"))
+    finally:
+        B._KEEP_HOST_SIDE = True
