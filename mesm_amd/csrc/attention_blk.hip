@@ -351,9 +351,18 @@ __global__ __launch_bounds__(BT) void attn_blk_bwd_long_kernel(const MesmAttnArg
     f[4] = c.x; f[5] = c.y; f[6] = c.z; f[7] = c.w;
   };
 
+  // TAIL workgroups (round 6).  TACoS' encoder runs 513 = 4 x 128 + 1 rows a side: the fifth workgroup of a side owned ONE
+  // block of 16 rows -- one busy wave walking all 33 blocks of the other side while seven waves only helped to stage, for as
+  // long as a full workgroup takes (2 of 10 workgroups per head in the backward).  A workgroup whose share is a single block
+  // now SPREADS that block over its eight waves by (chunk, block) unit -- unit u goes to wave u % 8 -- and adds the waves'
+  // partial gradients up through LDS at the end: it is done in about a third of the time.  (Nine-wave workgroups of 144 rows
+  // were 45 % slower: 3 + 2 + 2 + 2 waves on the four SIMDs.  Handing the block to the side's last FULL workgroup, every wave
+  // taking its turns at it, kept a second set of fragments and accumulators alive: 89 -> 156 registers, one workgroup per CU,
+  // 393 -> 473 us.)
   if (part < nJc) {
     // ---------------------------------------------------------------- J workgroup: keys [part * 128, + 128)
-    const int j0 = part * LW + 16 * wave;
+    const bool spread = Lk - part * LW <= 16;  // this workgroup's share is one block: every wave works on it
+    const int j0 = part * LW + (spread ? 0 : 16 * wave);
     const bool active = j0 < Lk;
     float kf[8], vf[8];
     load8g(kb, p.k_ls, j0 + jl, active ? Lk : 0, kf);
@@ -366,6 +375,7 @@ __global__ __launch_bounds__(BT) void attn_blk_bwd_long_kernel(const MesmAttnArg
     }
     f32x4 dVa[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     f32x4 dKa[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    int unit = 0;
     for (int ic = 0; ic < Lq; ic += LC) {
       __syncthreads();  // the previous chunk has been consumed
       for (int idx = tid; idx < LC * 8; idx += BT) {
@@ -390,7 +400,8 @@ __global__ __launch_bounds__(BT) void attn_blk_bwd_long_kernel(const MesmAttnArg
       __syncthreads();
       if (!active) continue;
       const int nb = (min(LC, Lq - ic) + 15) >> 4;
-      for (int ib = 0; ib < nb; ++ib) {
+      for (int ib = 0; ib < nb; ++ib, ++unit) {
+        if (spread && (unit & 7) != wave) continue;
         const int i0 = ib << 4;  // inside the chunk
         float qf[8], gf[8];
         loadN<8>(Xs + (i0 + jl) * BS + 8 * kq, qf);
@@ -437,7 +448,25 @@ __global__ __launch_bounds__(BT) void attn_blk_bwd_long_kernel(const MesmAttnArg
         }
       }
     }
-    if (active) {
+    if (spread) {
+      // the waves' shares of the block's gradients meet in LDS (the chunk buffers are free), wave after wave; wave 0 stores
+      for (int w = 0; w < BT / 64; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            f32x4& v = a == 0 ? dVa[0] : (a == 1 ? dVa[1] : (a == 2 ? dKa[0] : dKa[1]));
+            float4* slot = reinterpret_cast<float4*>(Xs) + a * 64 + lane;  // 4 x 64 x 4 = 1024 of Xs' 2304 floats
+            if (w > 0) {
+              const float4 t = *slot;
+              v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+            }
+            if (w + 1 < BT / 64) *slot = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+      }
+    }
+    if (active && (!spread || wave == BT / 64 - 1)) {
       float* dkb = p.dk_ + (int64_t)b * p.k_bs + h * 32;
       float* dvb = p.dv_ + (int64_t)b * p.v_bs + h * 32;
 #pragma unroll
@@ -453,7 +482,8 @@ __global__ __launch_bounds__(BT) void attn_blk_bwd_long_kernel(const MesmAttnArg
     }
   } else {
     // ---------------------------------------------------------------- I workgroup: queries [ic0, ic0 + 128)
-    const int i0 = (part - nJc) * LW + 16 * wave;
+    const bool spread = Lq - (part - nJc) * LW <= 16;  // (see the J side)
+    const int i0 = (part - nJc) * LW + (spread ? 0 : 16 * wave);
     const bool active = i0 < Lq;
     const int i = i0 + jl;
     float qf[8], gf[8], of[8];
@@ -468,6 +498,7 @@ __global__ __launch_bounds__(BT) void attn_blk_bwd_long_kernel(const MesmAttnArg
     const float qp_i = (quirk && active && i < Lq && p.qpad[(int64_t)b2 * Lq + i] != 0) ? 1.0f : 0.0f;
     const uint32_t rowi = (row0 + (uint32_t)i) * (uint32_t)Lk;
     f32x4 dQa[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    int unit = 0;
     for (int jc = 0; jc < Lk; jc += LC) {
       __syncthreads();
       for (int idx = tid; idx < LC * 8; idx += BT) {
@@ -490,7 +521,8 @@ __global__ __launch_bounds__(BT) void attn_blk_bwd_long_kernel(const MesmAttnArg
       __syncthreads();
       if (!active) continue;
       const int nb = (min(LC, Lk - jc) + 15) >> 4;
-      for (int jb = 0; jb < nb; ++jb) {
+      for (int jb = 0; jb < nb; ++jb, ++unit) {
+        if (spread && (unit & 7) != wave) continue;
         const int j0 = jb << 4;
         float kf[8], vf[8];
         loadN<8>(Xs + (j0 + jl) * BS + 8 * kq, kf);
@@ -526,7 +558,23 @@ __global__ __launch_bounds__(BT) void attn_blk_bwd_long_kernel(const MesmAttnArg
         }
       }
     }
-    if (active) {
+    if (spread) {
+      for (int w = 0; w < BT / 64; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            float4* slot = reinterpret_cast<float4*>(Xs) + a * 64 + lane;
+            if (w > 0) {
+              const float4 t = *slot;
+              dQa[a][0] += t.x; dQa[a][1] += t.y; dQa[a][2] += t.z; dQa[a][3] += t.w;
+            }
+            if (w + 1 < BT / 64) *slot = make_float4(dQa[a][0], dQa[a][1], dQa[a][2], dQa[a][3]);
+          }
+        }
+      }
+    }
+    if (active && (!spread || wave == BT / 64 - 1)) {
       float* dqb = p.dq + (int64_t)b * p.q_bs + h * 32;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {

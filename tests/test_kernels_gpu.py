@@ -418,7 +418,11 @@ ATTN_CASES = [
     (2, 4, 96, 112, 32, 32, True, True),
     (2, 4, 112, 112, 32, 32, True, False),
     (2, 4, 140, 200, 32, 32, True, True),
-    (2, 8, 513, 513, 32, 32, True, True),   # TACoS encoder: J / I workgroups streaming the other side
+    (2, 8, 513, 513, 32, 32, True, True),   # TACoS encoder: J / I workgroups streaming the other side; the 1-row tail block of
+                                            # each side rides with the side's last full workgroup
+    (1, 4, 512, 512, 32, 32, True, True),   # ... no tail
+    (2, 4, 272, 397, 32, 32, True, True),   # ... a full 16-row tail block (272 = 2 x 128 + 16) beside a side without one
+    (1, 2, 140, 258, 32, 32, False, False),  # ... tails of 12 and 2 rows, no masks
     (1, 2, 300, 130, 32, 32, False, False),
 ]
 
