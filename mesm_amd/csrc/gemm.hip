@@ -1289,7 +1289,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_wstage64_kernel(const MesmGe
 // Grouped launch of 64 x 64 k-split tiles (same GroupArgs as the 32 x 32 one): the problems of one call that are large
 // enough for this tile share ONE launch whatever their shapes, layouts and fusions -- a kernel costs ~9 us of ramp
 // whatever it computes, and in split-bf16 mode a 64 x 64-per-wave tile is the only one that amortises the split.
-template <int BF>
+// MASK: the operand-layout pairs the launch's members use (bit = 2 * (A outer-contiguous) + (B outer-contiguous)); only
+// those bodies are in the kernel.  With all four side by side the kernel is ~200 KB of code of which a workgroup runs one
+// variant; the forward's calls (one layout pair) and the backward's (dW + dX: two) get kernels a quarter / half that size:
+// 3.295 -> 3.277 ms per step (round 6; MASK = 15 stays for BF = 0 / 6 and anything else).
+template <int BF, int MASK = 15>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_wstage64_group_kernel(const GroupArgs g, const SideRed sr) {
   side_reduce(sr);
   __shared__ __attribute__((aligned(16))) float L[4 * 4 * WS_SLAB];
@@ -1309,10 +1313,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_wstage64_group_kernel(const 
   const bool xf = p.a_act != MESM_ACT_NONE || p.b_act != MESM_ACT_NONE || p.a_drop_p > 0.f || p.b_drop_p > 0.f;
   const int sel = (p.a_layout == O ? 2 : 0) + (p.b_layout == O ? 1 : 0);
   if (!xf) {
-    if (sel == 0) wstage64_body<R, R, false, BF>(p, blk, L);
-    else if (sel == 1) wstage64_body<R, O, false, BF>(p, blk, L);
-    else if (sel == 2) wstage64_body<O, R, false, BF>(p, blk, L);
-    else wstage64_body<O, O, false, BF>(p, blk, L);
+    if ((MASK & 1) && sel == 0) wstage64_body<R, R, false, BF>(p, blk, L);
+    else if ((MASK & 2) && sel == 1) wstage64_body<R, O, false, BF>(p, blk, L);
+    else if ((MASK & 4) && sel == 2) wstage64_body<O, R, false, BF>(p, blk, L);
+    else if ((MASK & 8) && sel == 3) wstage64_body<O, O, false, BF>(p, blk, L);
   } else if (BF == 0) {  // (operand transforms in split mode stay out of the group: register budget)
     if (sel == 0) wstage64_body<R, R, true, 0>(p, blk, L);
     else if (sel == 1) wstage64_body<R, O, true, 0>(p, blk, L);
@@ -1324,6 +1328,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_wstage64_group_kernel(const 
 
 // MESM_GEMM_BF16X: 6 = split-bf16 products, three exact terms (see SplitFrag); 2 = two fp16 terms, three products (HalfFrag);
 // anything else = exact f32
+inline bool layout_masks() {  // MESM_G64_LAYOUT_MASKS=0: the four-variant kernel for every grouped 64 x 64 launch (A/B)
+  static const bool v = []() { const char* e = getenv("MESM_G64_LAYOUT_MASKS"); return !(e && atoi(e) == 0); }();
+  return v;
+}
 inline int bf16x_mode() { return mesm_gemm_bf16x(); }
 int mesm_gemm_group64();
 
@@ -2030,7 +2038,16 @@ int launch_group(const MesmGemmArgs* list, const int* vecs, int n, hipStream_t s
     } else {
       const SideRed sr = take_side(s);
       const int bf = bf16x_mode();
-      if (bf == 6) hipLaunchKernelGGL(gemm_wstage64_group_kernel<6>, dim3(g64.start[g64.n]), dim3(NTHREADS), 0, s, g64, sr);
+      constexpr int O_ = MESM_LAYOUT_OUTER_CONTIG;
+      int mask = 0;  // the operand-layout pairs of this launch's members (see the kernel)
+      for (int k = 0; k < g64.n; ++k) mask |= 1 << ((g64.p[k].a_layout == O_ ? 2 : 0) + (g64.p[k].b_layout == O_ ? 1 : 0));
+      if (!layout_masks()) mask = 15;
+      const dim3 gr(g64.start[g64.n]);
+      if (bf == 6) hipLaunchKernelGGL(gemm_wstage64_group_kernel<6>, gr, dim3(NTHREADS), 0, s, g64, sr);
+      else if (bf == 2 && mask == 1) hipLaunchKernelGGL((gemm_wstage64_group_kernel<2, 1>), gr, dim3(NTHREADS), 0, s, g64, sr);
+      else if (bf == 2 && mask == 2) hipLaunchKernelGGL((gemm_wstage64_group_kernel<2, 2>), gr, dim3(NTHREADS), 0, s, g64, sr);
+      else if (bf == 2 && mask == 8) hipLaunchKernelGGL((gemm_wstage64_group_kernel<2, 8>), gr, dim3(NTHREADS), 0, s, g64, sr);
+      else if (bf == 2 && mask == 10) hipLaunchKernelGGL((gemm_wstage64_group_kernel<2, 10>), gr, dim3(NTHREADS), 0, s, g64, sr);
       else if (bf == 2) hipLaunchKernelGGL(gemm_wstage64_group_kernel<2>, dim3(g64.start[g64.n]), dim3(NTHREADS), 0, s, g64, sr);
       else hipLaunchKernelGGL(gemm_wstage64_group_kernel<0>, dim3(g64.start[g64.n]), dim3(NTHREADS), 0, s, g64, sr);
       rc = mesm_launch_status();
