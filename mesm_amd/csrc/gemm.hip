@@ -983,7 +983,10 @@ __global__ WS_BOUNDS void gemm_wstage_kernel(const MesmGemmArgs p, const SideRed
 // dispatch + ~3 us of exposed latency chain whatever its size, and the backward of every block as well
 // as the decoder are made of independent 5 us GEMMs).  The workgroups of all problems are laid out
 // back to back on blockIdx.x; layouts / transforms are selected per problem at run time (wave-uniform).
-template <int STAGES>
+// MASK / XFM: the operand-layout pairs (bit = 2 * (A outer-contiguous) + (B outer-contiguous)) and whether operand transforms
+// occur among the launch's members; only those bodies are in the kernel (the kernel with all eight is 109 KB of code: see
+// gemm_wstage64_group_kernel).
+template <int STAGES, int MASK = 15, bool XFM = true>
 __global__ WS_BOUNDS void gemm_wstage_group_kernel(const GroupArgs g, const SideRed sr) {
   side_reduce(sr);
   __shared__ __attribute__((aligned(16))) float L[ws_lds_floats(STAGES)];
@@ -1007,15 +1010,15 @@ __global__ WS_BOUNDS void gemm_wstage_group_kernel(const GroupArgs g, const Side
   const bool xf = p.a_act != MESM_ACT_NONE || p.b_act != MESM_ACT_NONE || p.a_drop_p > 0.f || p.b_drop_p > 0.f;
   const int sel = (p.a_layout == O ? 2 : 0) + (p.b_layout == O ? 1 : 0);
   if (!xf) {
-    if (sel == 0) wstage_body<R, R, false, STAGES>(p, blk, L);
-    else if (sel == 1) wstage_body<R, O, false, STAGES>(p, blk, L);
-    else if (sel == 2) wstage_body<O, R, false, STAGES>(p, blk, L);
-    else wstage_body<O, O, false, STAGES>(p, blk, L);
-  } else {
-    if (sel == 0) wstage_body<R, R, true, STAGES>(p, blk, L);
-    else if (sel == 1) wstage_body<R, O, true, STAGES>(p, blk, L);
-    else if (sel == 2) wstage_body<O, R, true, STAGES>(p, blk, L);
-    else wstage_body<O, O, true, STAGES>(p, blk, L);
+    if ((MASK & 1) && sel == 0) wstage_body<R, R, false, STAGES>(p, blk, L);
+    else if ((MASK & 2) && sel == 1) wstage_body<R, O, false, STAGES>(p, blk, L);
+    else if ((MASK & 4) && sel == 2) wstage_body<O, R, false, STAGES>(p, blk, L);
+    else if ((MASK & 8) && sel == 3) wstage_body<O, O, false, STAGES>(p, blk, L);
+  } else if (XFM) {
+    if ((MASK & 1) && sel == 0) wstage_body<R, R, true, STAGES>(p, blk, L);
+    else if ((MASK & 2) && sel == 1) wstage_body<R, O, true, STAGES>(p, blk, L);
+    else if ((MASK & 4) && sel == 2) wstage_body<O, R, true, STAGES>(p, blk, L);
+    else if ((MASK & 8) && sel == 3) wstage_body<O, O, true, STAGES>(p, blk, L);
   }
 }
 
@@ -2002,8 +2005,22 @@ int launch_group(const MesmGemmArgs* list, const int* vecs, int n, hipStream_t s
       bool one = true;  // single-stage staging only if every problem of the group wants it
       for (int k = 0; k < g.n; ++k) one = one && ws_stages_for(g.p[k]) == 1;
       const SideRed sr = take_side(s);
-      if (one) hipLaunchKernelGGL(gemm_wstage_group_kernel<1>, dim3(g.start[g.n]), dim3(WS_THREADS), 0, s, g, sr);
-      else hipLaunchKernelGGL(gemm_wstage_group_kernel<2>, dim3(g.start[g.n]), dim3(WS_THREADS), 0, s, g, sr);
+      constexpr int O_ = MESM_LAYOUT_OUTER_CONTIG;
+      int mask = 0;
+      bool any_xf = false;
+      for (int k = 0; k < g.n; ++k) {
+        const MesmGemmArgs& a = g.p[k];
+        mask |= 1 << ((a.a_layout == O_ ? 2 : 0) + (a.b_layout == O_ ? 1 : 0));
+        any_xf = any_xf || a.a_act != MESM_ACT_NONE || a.b_act != MESM_ACT_NONE || a.a_drop_p > 0.f || a.b_drop_p > 0.f;
+      }
+      if (!layout_masks() || any_xf || !one) mask = 15;
+      const dim3 gr(g.start[g.n]), bl(WS_THREADS);
+      if (one && mask == 1) hipLaunchKernelGGL((gemm_wstage_group_kernel<1, 1, false>), gr, bl, 0, s, g, sr);
+      else if (one && mask == 2) hipLaunchKernelGGL((gemm_wstage_group_kernel<1, 2, false>), gr, bl, 0, s, g, sr);
+      else if (one && mask == 8) hipLaunchKernelGGL((gemm_wstage_group_kernel<1, 8, false>), gr, bl, 0, s, g, sr);
+      else if (one && mask == 10) hipLaunchKernelGGL((gemm_wstage_group_kernel<1, 10, false>), gr, bl, 0, s, g, sr);
+      else if (one) hipLaunchKernelGGL(gemm_wstage_group_kernel<1>, gr, bl, 0, s, g, sr);
+      else hipLaunchKernelGGL(gemm_wstage_group_kernel<2>, gr, bl, 0, s, g, sr);
       rc = mesm_launch_status();
       for (int k = 0; k < g.n && rc == MESM_OK; ++k) {
         const MesmGemmArgs& a = g.p[k];
