@@ -59,3 +59,33 @@ def test_linear_defaults_outside_the_stacks():
         assert float(mod.bias.abs().max()) <= bound * (1 + 1e-6), name
     ln = m.input_vid_proj[0].LayerNorm
     assert float((ln.weight - 1).abs().max()) == 0.0 and float(ln.bias.abs().max()) == 0.0
+
+
+def test_stacked_outputs_in_place_host_logic():
+    """ops.Slot / ops.stacked (the decoder's stacked outputs written in place): plain torch on the host -- the buffer comes back as the
+    stack, the gradient reaches every producer as its slice, a tensor that does not live in its slot is refused."""
+    import pytest
+    import torch
+    from mesm_amd import ops
+    buf = torch.zeros(3, 4, 5)
+    xs = [torch.randn(4, 5, requires_grad=True) for _ in range(3)]
+
+    class Into(torch.autograd.Function):  # a producer that writes its result into a slot (what the kernels do)
+        @staticmethod
+        def forward(ctx, x, slot):
+            slot.t.data.copy_(2.0 * x)  # (like a kernel: through the storage, not through torch's in-place machinery)
+            return slot.t.view_as(slot.t)
+
+        @staticmethod
+        def backward(ctx, g):
+            return 2.0 * g, None
+
+    ys = [Into.apply(x, ops.Slot(buf, k)) for k, x in enumerate(xs)]
+    st = ops.stacked(buf, ys)
+    assert st.data_ptr() == buf.data_ptr() and torch.equal(st, torch.stack([2.0 * x.detach() for x in xs]))
+    g = torch.randn(3, 4, 5)
+    st.backward(g)
+    for k, x in enumerate(xs):
+        assert torch.equal(x.grad, 2.0 * g[k])
+    with pytest.raises(AssertionError):
+        ops.stacked(torch.zeros(3, 4, 5), [x.detach() for x in xs])
